@@ -1,0 +1,86 @@
+"""ctypes binding of libhalo2_mi355x.so (include/halo2_mi355x.h).  No torch types cross the ABI."""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libhalo2_mi355x.so")
+HOSTCHECK_PATH = os.path.join(CSRC, "libhm_hostcheck.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "halo2_mi355x.h")
+
+_u64p = ctypes.POINTER(ctypes.c_uint64)
+_vp = ctypes.c_void_p
+
+
+class Halo2Mi355xError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"libhalo2_mi355x error {code}: {message}")
+        self.code = code
+
+
+class MsmStats(ctypes.Structure):
+    _fields_ = [("digits_ms", ctypes.c_double), ("sort_ms", ctypes.c_double), ("accumulate_ms", ctypes.c_double),
+                ("reduce_ms", ctypes.c_double), ("total_ms", ctypes.c_double), ("pairs", ctypes.c_uint64),
+                ("tasks", ctypes.c_uint64), ("window_bits", ctypes.c_uint32), ("windows", ctypes.c_uint32)]
+
+
+def build(force: bool = False) -> str:
+    """Compile every HIP source for gfx950 into csrc/libhalo2_mi355x.so (in-tree) with hipcc."""
+    args = ["make", "-C", CSRC, "-j4"]
+    if force:
+        subprocess.run(["make", "-C", CSRC, "clean"], check=True)
+    subprocess.run(args, check=True)
+    return LIB_PATH
+
+
+_SIGNATURES = {
+    "hm_device_count": (ctypes.c_int, []),
+    "hm_set_device": (ctypes.c_int, [ctypes.c_int]),
+    "hm_shutdown": (ctypes.c_int, []),
+    "hm_last_error": (ctypes.c_char_p, []),
+    "hm_version": (ctypes.c_char_p, []),
+    "hm_msm_bn256_g1": (ctypes.c_int, [_u64p, _u64p, ctypes.c_size_t, _u64p, ctypes.POINTER(ctypes.c_int)]),
+    "hm_msm_bn256_g1_jacobian": (ctypes.c_int, [_u64p, _u64p, ctypes.c_size_t, _u64p]),
+    "hm_register_bases": (ctypes.c_int, [_u64p, ctypes.c_size_t, _u64p]),
+    "hm_release_bases": (ctypes.c_int, [ctypes.c_uint64]),
+    "hm_msm_bn256_g1_h": (ctypes.c_int, [ctypes.c_uint64, ctypes.c_size_t, _u64p, ctypes.c_size_t, _u64p,
+                                          ctypes.POINTER(ctypes.c_int)]),
+    "hm_register_bases_dev": (ctypes.c_int, [_vp, ctypes.c_size_t, _vp, _u64p]),
+    "hm_msm_bn256_g1_dev": (ctypes.c_int, [ctypes.c_uint64, ctypes.c_size_t, _vp, ctypes.c_size_t, _vp, _u64p]),
+    "hm_msm_set_window": (ctypes.c_int, [ctypes.c_int]),
+    "hm_ntt_bn256_fr": (ctypes.c_int, [_u64p, _u64p, ctypes.c_uint32]),
+    "hm_ntt_bn256_fr_dev": (ctypes.c_int, [_vp, _u64p, ctypes.c_uint32, _vp]),
+    "hm_ifft_bn256_fr_dev": (ctypes.c_int, [_vp, _u64p, ctypes.c_uint32, _u64p, _vp]),
+    "hm_coset_ntt_bn256_fr_dev": (ctypes.c_int, [_vp, _u64p, ctypes.c_uint32, _u64p, _vp]),
+    "hm_fr_scale_dev": (ctypes.c_int, [_vp, ctypes.c_size_t, _u64p, _vp]),
+    "hm_fr_distribute_powers_dev": (ctypes.c_int, [_vp, ctypes.c_size_t, _u64p, _vp]),
+    "hm_g1_fixed_base_mul_dev": (ctypes.c_int, [_vp, ctypes.c_size_t, _u64p, _vp, _vp]),
+    "hm_get_msm_stats": (ctypes.c_int, [ctypes.POINTER(MsmStats)]),
+}
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    """Load the HIP library; raises (never falls back) when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise FileNotFoundError(
+                f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(there is no CPU fallback for the MSM/NTT path)")
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        raise Halo2Mi355xError(rc, load().hm_last_error().decode())

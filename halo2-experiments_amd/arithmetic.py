@@ -1,0 +1,168 @@
+"""Host-side mirror of ``halo2_proofs::arithmetic`` for BN256 (same names, argument meaning and
+error behaviour as the reference's crate, /root/reference/Cargo.toml:10, tag v2023_02_02):
+
+    best_multiexp(coeffs: &[Fr], bases: &[G1Affine]) -> G1      (assert_eq!(coeffs.len(), bases.len()))
+    best_fft(a: &mut [Fr], omega: Fr, log_n: u32)               (assert_eq!(a.len(), 1 << log_n))
+
+Arrays are ``numpy.uint64`` in the reference's memory layout (little-endian
+Montgomery limbs; Fr = 4, G1Affine = 8, G1 = 12 words) or CUDA/HIP ``torch`` tensors of dtype
+int64/uint64 with the same shape, in which case the data never leaves HBM.  Everything goes
+through the C ABI of libhalo2_mi355x.so; if that library is missing these functions raise.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional, Union
+
+import numpy as np
+
+from . import _lib
+
+_u64p = ctypes.POINTER(ctypes.c_uint64)
+
+
+def _is_tensor(x) -> bool:
+    return hasattr(x, "data_ptr") and hasattr(x, "is_cuda")
+
+
+def _np(a, cols: int, name: str, writable: bool = False) -> np.ndarray:
+    arr = np.asarray(a)
+    if arr.dtype != np.uint64:
+        raise TypeError(f"{name} must be uint64 limbs, got {arr.dtype}")
+    arr = arr.reshape(-1, cols)
+    if not arr.flags["C_CONTIGUOUS"]:
+        if writable:
+            raise ValueError(f"{name} must be C-contiguous to be transformed in place")
+        arr = np.ascontiguousarray(arr)
+    return arr
+
+
+def _ptr(arr: np.ndarray):
+    return arr.ctypes.data_as(_u64p)
+
+
+def _stream_ptr(t) -> int:
+    import torch
+
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _tensor_rows(t, cols: int, name: str) -> int:
+    if not t.is_cuda:
+        raise ValueError(f"{name}: torch tensors must live on the GPU (pass numpy arrays for host data)")
+    if t.element_size() != 8 or not t.is_contiguous():
+        raise ValueError(f"{name}: need a contiguous 64-bit integer tensor")
+    if t.numel() % cols:
+        raise ValueError(f"{name}: size is not a multiple of {cols} words")
+    return t.numel() // cols
+
+
+class BasesHandle:
+    """A device-resident, pre-converted base set (``ParamsKZG::g`` / ``g_lagrange``)."""
+
+    def __init__(self, handle: int, n: int):
+        self.handle, self.n = handle, n
+
+    def __len__(self) -> int:
+        return self.n
+
+
+def register_bases(bases) -> BasesHandle:
+    lib = _lib.load()
+    h = ctypes.c_uint64(0)
+    if _is_tensor(bases):
+        n = _tensor_rows(bases, 8, "bases")
+        _lib.check(lib.hm_register_bases_dev(ctypes.c_void_p(bases.data_ptr()), n, ctypes.c_void_p(_stream_ptr(bases)),
+                                             ctypes.byref(h)))
+    else:
+        b = _np(bases, 8, "bases")
+        n = b.shape[0]
+        _lib.check(lib.hm_register_bases(_ptr(b), n, ctypes.byref(h)))
+    return BasesHandle(h.value, n)
+
+
+def release_bases(handle: BasesHandle) -> None:
+    _lib.check(_lib.load().hm_release_bases(ctypes.c_uint64(handle.handle)))
+
+
+def best_multiexp(coeffs, bases: Union[np.ndarray, BasesHandle, "object"], offset: int = 0) -> np.ndarray:
+    """sum_i coeffs[i] * bases[i] -> G1 as 12 words (x, y, 1) Montgomery, or all-zero for the identity.
+
+    ``bases`` may be an array/tensor (converted and cached per call, as the drop-in does) or a
+    ``BasesHandle`` (then ``coeffs`` pairs with ``bases[offset : offset + len(coeffs)]``)."""
+    lib = _lib.load()
+    out = np.zeros(12, dtype=np.uint64)
+    if isinstance(bases, BasesHandle):
+        if _is_tensor(coeffs):
+            n = _tensor_rows(coeffs, 4, "coeffs")
+            _lib.check(lib.hm_msm_bn256_g1_dev(ctypes.c_uint64(bases.handle), offset, ctypes.c_void_p(coeffs.data_ptr()), n,
+                                               ctypes.c_void_p(_stream_ptr(coeffs)), _ptr(out)))
+            return out
+        c = _np(coeffs, 4, "coeffs")
+        xy = np.zeros(8, dtype=np.uint64)
+        is_id = ctypes.c_int(0)
+        _lib.check(lib.hm_msm_bn256_g1_h(ctypes.c_uint64(bases.handle), offset, _ptr(c), c.shape[0], _ptr(xy),
+                                         ctypes.byref(is_id)))
+        if not is_id.value:
+            out[:8] = xy
+            out[8:] = FQ_ONE_MONT
+        return out
+    if _is_tensor(coeffs) or _is_tensor(bases):
+        if not (_is_tensor(coeffs) and _is_tensor(bases)):
+            raise TypeError("coeffs and bases must both be host arrays or both be GPU tensors")
+        n = _tensor_rows(coeffs, 4, "coeffs")
+        if n != _tensor_rows(bases, 8, "bases"):
+            raise ValueError("best_multiexp: coeffs.len() != bases.len()")
+        h = register_bases(bases)
+        try:
+            return best_multiexp(coeffs, h)
+        finally:
+            release_bases(h)
+    c, b = _np(coeffs, 4, "coeffs"), _np(bases, 8, "bases")
+    if c.shape[0] != b.shape[0]:
+        raise ValueError("best_multiexp: coeffs.len() != bases.len()")  # upstream: assert_eq! panic
+    _lib.check(lib.hm_msm_bn256_g1_jacobian(_ptr(c), _ptr(b), c.shape[0], _ptr(out)))
+    return out
+
+
+def best_fft(a, omega, log_n: int) -> None:
+    """In place: a[j] <- sum_i a[i] omega^(ij); natural order, unscaled."""
+    lib = _lib.load()
+    w = _np(omega, 4, "omega")
+    if w.shape[0] != 1:
+        raise ValueError("omega must be one field element")
+    if _is_tensor(a):
+        n = _tensor_rows(a, 4, "a")
+        if n != 1 << log_n:
+            raise ValueError("best_fft: a.len() != 1 << log_n")
+        _lib.check(lib.hm_ntt_bn256_fr_dev(ctypes.c_void_p(a.data_ptr()), _ptr(w), log_n, ctypes.c_void_p(_stream_ptr(a))))
+        return
+    if not isinstance(a, np.ndarray):
+        raise TypeError("best_fft transforms in place: pass a numpy array or a GPU tensor")
+    arr = _np(a, 4, "a", writable=True)
+    if arr.shape[0] != 1 << log_n:
+        raise ValueError("best_fft: a.len() != 1 << log_n")  # upstream: assert_eq! panic
+    _lib.check(lib.hm_ntt_bn256_fr(_ptr(arr), _ptr(w), log_n))
+
+
+def g1_fixed_base_mul(scalars, base_xy: np.ndarray):
+    """out[i] = [scalars[i]] * base, affine (ParamsKZG::setup's per-row G1 work).  GPU tensors only."""
+    import torch
+
+    lib = _lib.load()
+    n = _tensor_rows(scalars, 4, "scalars")
+    out = torch.empty((n, 8), dtype=torch.int64, device=scalars.device)
+    b = _np(base_xy, 8, "base")
+    _lib.check(lib.hm_g1_fixed_base_mul_dev(ctypes.c_void_p(scalars.data_ptr()), n, _ptr(b), ctypes.c_void_p(out.data_ptr()),
+                                            ctypes.c_void_p(_stream_ptr(scalars))))
+    return out
+
+
+def msm_stats() -> dict:
+    st = _lib.MsmStats()
+    _lib.check(_lib.load().hm_get_msm_stats(ctypes.byref(st)))
+    return {k: getattr(st, k) for k, _ in st._fields_}
+
+
+# Montgomery one of Fq (2^256 mod p): the z coordinate of a normalised G1
+FQ_ONE_MONT = np.array([0xD35D438DC58F0D9D, 0x0A78EB28F5C70B3D, 0x666EA36F7879462C, 0x0E0A77C19A07DF2F], dtype=np.uint64)

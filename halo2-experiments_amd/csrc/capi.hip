@@ -1,0 +1,366 @@
+// capi.hip -- the extern "C" boundary declared in include/halo2_mi355x.h.
+// Host pointers in, host results out; device staging, base-set caching and locking live here.
+#include <hip/hip_runtime.h>
+
+#include <map>
+
+#include "hm_internal.h"
+
+namespace hm {
+
+static thread_local std::string g_last_error;
+static std::mutex g_ctx_mu;
+static std::map<int, std::unique_ptr<DeviceCtx>> g_ctx;
+
+int hm_fail(int code, const std::string& what) {
+  g_last_error = what;
+  return code;
+}
+
+void msm_set_window_override(int c);  // msm.hip
+
+DeviceCtx* ctx_for_current_device() {
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+    hm_fail(HM_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU fallback)");
+    return nullptr;
+  }
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) {
+    hm_fail(HM_ERR_NO_DEVICE, "hipGetDevice failed");
+    return nullptr;
+  }
+  std::lock_guard<std::mutex> lk(g_ctx_mu);
+  auto it = g_ctx.find(dev);
+  if (it == g_ctx.end()) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+      hm_fail(HM_ERR_NO_DEVICE, "hipGetDeviceProperties failed");
+      return nullptr;
+    }
+    if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0) {
+      hm_fail(HM_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
+      return nullptr;
+    }
+    auto c = std::make_unique<DeviceCtx>();
+    c->device = dev;
+    it = g_ctx.emplace(dev, std::move(c)).first;
+  }
+  return it->second.get();
+}
+
+static BasesEntry* find_bases(DeviceCtx& ctx, uint64_t handle) {
+  for (auto& b : ctx.bases)
+    if (b.handle == handle) return &b;
+  return nullptr;
+}
+
+static int register_from_device(DeviceCtx& ctx, const uint32_t* d_ext, size_t n, hipStream_t stream, uint64_t* out_handle) {
+  BasesEntry e;
+  e.n = n;
+  HM_HIP_CHECK(hipMalloc((void**)&e.d_xy, n ? n * 64 : 64));
+  HM_HIP_CHECK(hipMalloc((void**)&e.d_inf, n ? n : 1));
+  int rc = msm_convert_bases(d_ext, e.d_xy, e.d_inf, n, stream);
+  if (rc != HM_OK) return rc;
+  e.handle = ctx.next_handle++;
+  ctx.bases.push_back(e);
+  *out_handle = e.handle;
+  return HM_OK;
+}
+
+static int jac_to_affine_out(const uint64_t jac[12], int is_id, uint64_t out_xy[8], int* out_is_identity) {
+  if (is_id) {
+    std::memset(out_xy, 0, 64);
+  } else {
+    std::memcpy(out_xy, jac, 64);  // msm_run returns (x, y, 1): already affine
+  }
+  if (out_is_identity) *out_is_identity = is_id;
+  return HM_OK;
+}
+
+}  // namespace hm
+
+using namespace hm;
+
+extern "C" {
+
+int hm_device_count(void) {
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess) return 0;
+  return count;
+}
+
+int hm_set_device(int device) {
+  int count = hm_device_count();
+  if (count <= 0) return hm_fail(HM_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU fallback)");
+  if (device < 0 || device >= count) return hm_fail(HM_ERR_BAD_ARG, "hm_set_device: device index out of range");
+  HM_HIP_CHECK(hipSetDevice(device));
+  return HM_OK;
+}
+
+const char* hm_last_error(void) { return g_last_error.c_str(); }
+const char* hm_version(void) { return "halo2_mi355x 0.1 (gfx950; ff29 field layer)"; }
+
+int hm_shutdown(void) {
+  int dev = 0;
+  if (hm_device_count() <= 0 || hipGetDevice(&dev) != hipSuccess) return HM_OK;
+  std::lock_guard<std::mutex> lk(g_ctx_mu);
+  auto it = g_ctx.find(dev);
+  if (it == g_ctx.end()) return HM_OK;
+  DeviceCtx& c = *it->second;
+  std::lock_guard<std::mutex> lk2(c.mu);
+  (void)hipDeviceSynchronize();
+  for (auto& t : c.ntt_tables) {
+    if (t->d_omega) (void)hipFree(t->d_omega);
+    if (t->d_lo) (void)hipFree(t->d_lo);
+    if (t->d_hi) (void)hipFree(t->d_hi);
+    for (auto& s : t->d_stage)
+      if (s) (void)hipFree(s);
+  }
+  c.ntt_tables.clear();
+  for (auto& b : c.bases) {
+    if (b.d_xy) (void)hipFree(b.d_xy);
+    if (b.d_inf) (void)hipFree(b.d_inf);
+  }
+  c.bases.clear();
+  c.scratch.release(); c.io.release(); c.io_bases.release(); c.conv_bases.release(); c.conv_inf.release();
+  c.msm_ws.release(); c.small.release();
+  c.cached_host_bases = nullptr;
+  c.cached_host_n = 0;
+  return HM_OK;
+}
+
+int hm_msm_set_window(int c) {
+  if (c != 0 && (c < 2 || c > 16)) return hm_fail(HM_ERR_BAD_ARG, "hm_msm_set_window: c must be 0 or in [2, 16]");
+  msm_set_window_override(c);
+  return HM_OK;
+}
+
+// ---- MSM -------------------------------------------------------------------------------------
+
+int hm_register_bases(const uint64_t* bases, size_t n, uint64_t* out_handle) {
+  if (!out_handle || (n && !bases)) return hm_fail(HM_ERR_BAD_ARG, "hm_register_bases: null argument");
+  DeviceCtx* ctx = ctx_for_current_device();
+  if (!ctx) return HM_ERR_NO_DEVICE;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  void* stage = ctx->io_bases.ensure(n ? n * 64 : 64);
+  if (!stage) return hm_fail(HM_ERR_HIP, "hm_register_bases: staging allocation failed");
+  HM_HIP_CHECK(hipMemcpy(stage, bases, n * 64, hipMemcpyHostToDevice));
+  int rc = register_from_device(*ctx, (const uint32_t*)stage, n, nullptr, out_handle);
+  if (rc != HM_OK) return rc;
+  HM_HIP_CHECK(hipStreamSynchronize(nullptr));
+  return HM_OK;
+}
+
+int hm_register_bases_dev(const void* d_bases, size_t n, void* stream, uint64_t* out_handle) {
+  if (!out_handle || (n && !d_bases)) return hm_fail(HM_ERR_BAD_ARG, "hm_register_bases_dev: null argument");
+  DeviceCtx* ctx = ctx_for_current_device();
+  if (!ctx) return HM_ERR_NO_DEVICE;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  int rc = register_from_device(*ctx, (const uint32_t*)d_bases, n, (hipStream_t)stream, out_handle);
+  if (rc != HM_OK) return rc;
+  HM_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+  return HM_OK;
+}
+
+int hm_release_bases(uint64_t handle) {
+  DeviceCtx* ctx = ctx_for_current_device();
+  if (!ctx) return HM_ERR_NO_DEVICE;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  for (size_t i = 0; i < ctx->bases.size(); ++i) {
+    if (ctx->bases[i].handle == handle) {
+      (void)hipDeviceSynchronize();
+      if (ctx->bases[i].d_xy) (void)hipFree(ctx->bases[i].d_xy);
+      if (ctx->bases[i].d_inf) (void)hipFree(ctx->bases[i].d_inf);
+      ctx->bases.erase(ctx->bases.begin() + i);
+      return HM_OK;
+    }
+  }
+  return hm_fail(HM_ERR_NOT_FOUND, "hm_release_bases: unknown handle");
+}
+
+int hm_msm_bn256_g1_dev(uint64_t handle, size_t offset, const void* d_scalars, size_t n, void* stream, uint64_t out_xyz[12]) {
+  if (!out_xyz || (n && !d_scalars)) return hm_fail(HM_ERR_BAD_ARG, "hm_msm_bn256_g1_dev: null argument");
+  DeviceCtx* ctx = ctx_for_current_device();
+  if (!ctx) return HM_ERR_NO_DEVICE;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  BasesEntry* b = find_bases(*ctx, handle);
+  if (!b) return hm_fail(HM_ERR_NOT_FOUND, "hm_msm_bn256_g1_dev: unknown base handle");
+  if (offset > b->n || n > b->n - offset) return hm_fail(HM_ERR_BAD_ARG, "hm_msm_bn256_g1_dev: offset + n exceeds the base set");
+  int is_id = 0;
+  return msm_run(*ctx, (const uint32_t*)d_scalars, b->d_xy + offset * 16, b->d_inf + offset, n, 0, out_xyz, &is_id,
+                 (hipStream_t)stream);
+}
+
+int hm_msm_bn256_g1_h(uint64_t handle, size_t offset, const uint64_t* scalars, size_t n, uint64_t out_xy[8],
+                      int* out_is_identity) {
+  if (!out_xy || (n && !scalars)) return hm_fail(HM_ERR_BAD_ARG, "hm_msm_bn256_g1_h: null argument");
+  DeviceCtx* ctx = ctx_for_current_device();
+  if (!ctx) return HM_ERR_NO_DEVICE;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  BasesEntry* b = find_bases(*ctx, handle);
+  if (!b) return hm_fail(HM_ERR_NOT_FOUND, "hm_msm_bn256_g1_h: unknown base handle");
+  if (offset > b->n || n > b->n - offset) return hm_fail(HM_ERR_BAD_ARG, "hm_msm_bn256_g1_h: offset + n exceeds the base set");
+  void* d_s = ctx->io.ensure(n ? n * 32 : 32);
+  if (!d_s) return hm_fail(HM_ERR_HIP, "hm_msm_bn256_g1_h: staging allocation failed");
+  HM_HIP_CHECK(hipMemcpy(d_s, scalars, n * 32, hipMemcpyHostToDevice));
+  uint64_t jac[12];
+  int is_id = 0;
+  int rc = msm_run(*ctx, (const uint32_t*)d_s, b->d_xy + offset * 16, b->d_inf + offset, n, 0, jac, &is_id, nullptr);
+  if (rc != HM_OK) return rc;
+  return jac_to_affine_out(jac, is_id, out_xy, out_is_identity);
+}
+
+static int msm_host(const uint64_t* scalars, const uint64_t* bases, size_t n, uint64_t jac[12], int* is_id) {
+  if (n && (!scalars || !bases)) return hm_fail(HM_ERR_BAD_ARG, "hm_msm_bn256_g1: null argument");
+  DeviceCtx* ctx = ctx_for_current_device();
+  if (!ctx) return HM_ERR_NO_DEVICE;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (n == 0) return msm_run(*ctx, nullptr, nullptr, nullptr, 0, 0, jac, is_id, nullptr);
+  // base cache: same pointer, same length, same first/last words => reuse the converted copy
+  uint64_t probe[4] = {bases[0], bases[4], bases[(n - 1) * 8 + 3], bases[(n - 1) * 8 + 7]};
+  const bool hit = ctx->cached_host_bases == (const void*)bases && ctx->cached_host_n == n &&
+                   std::memcmp(probe, ctx->cached_probe, sizeof probe) == 0;
+  uint32_t* d_xy = (uint32_t*)ctx->conv_bases.ensure(n * 64);
+  uint8_t* d_inf = (uint8_t*)ctx->conv_inf.ensure(n);
+  if (!d_xy || !d_inf) return hm_fail(HM_ERR_HIP, "hm_msm_bn256_g1: base buffer allocation failed");
+  if (!hit) {
+    ctx->cached_host_bases = nullptr;
+    void* stage = ctx->io_bases.ensure(n * 64);
+    if (!stage) return hm_fail(HM_ERR_HIP, "hm_msm_bn256_g1: staging allocation failed");
+    HM_HIP_CHECK(hipMemcpy(stage, bases, n * 64, hipMemcpyHostToDevice));
+    int rc = msm_convert_bases((const uint32_t*)stage, d_xy, d_inf, n, nullptr);
+    if (rc != HM_OK) return rc;
+    ctx->cached_host_bases = bases;
+    ctx->cached_host_n = n;
+    std::memcpy(ctx->cached_probe, probe, sizeof probe);
+  }
+  void* d_s = ctx->io.ensure(n * 32);
+  if (!d_s) return hm_fail(HM_ERR_HIP, "hm_msm_bn256_g1: staging allocation failed");
+  HM_HIP_CHECK(hipMemcpy(d_s, scalars, n * 32, hipMemcpyHostToDevice));
+  return msm_run(*ctx, (const uint32_t*)d_s, d_xy, d_inf, n, 0, jac, is_id, nullptr);
+}
+
+int hm_msm_bn256_g1(const uint64_t* scalars, const uint64_t* bases, size_t n, uint64_t out_xy[8], int* out_is_identity) {
+  if (!out_xy) return hm_fail(HM_ERR_BAD_ARG, "hm_msm_bn256_g1: null output");
+  uint64_t jac[12];
+  int is_id = 0;
+  int rc = msm_host(scalars, bases, n, jac, &is_id);
+  if (rc != HM_OK) return rc;
+  return jac_to_affine_out(jac, is_id, out_xy, out_is_identity);
+}
+
+int hm_msm_bn256_g1_jacobian(const uint64_t* scalars, const uint64_t* bases, size_t n, uint64_t out_xyz[12]) {
+  if (!out_xyz) return hm_fail(HM_ERR_BAD_ARG, "hm_msm_bn256_g1_jacobian: null output");
+  int is_id = 0;
+  return msm_host(scalars, bases, n, out_xyz, &is_id);
+}
+
+int hm_get_msm_stats(hm_msm_stats* out) {
+  if (!out) return hm_fail(HM_ERR_BAD_ARG, "hm_get_msm_stats: null output");
+  DeviceCtx* ctx = ctx_for_current_device();
+  if (!ctx) return HM_ERR_NO_DEVICE;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  const MsmStats& s = ctx->last_msm;
+  out->digits_ms = s.t_digits_ms; out->sort_ms = s.t_sort_ms; out->accumulate_ms = s.t_accum_ms;
+  out->reduce_ms = s.t_reduce_ms; out->total_ms = s.t_total_ms;
+  out->pairs = s.pairs; out->tasks = s.tasks; out->window_bits = s.c; out->windows = s.windows;
+  return HM_OK;
+}
+
+// ---- NTT -------------------------------------------------------------------------------------
+
+int hm_ntt_bn256_fr_dev(void* d_a, const uint64_t omega[4], uint32_t log_n, void* stream) {
+  if (!d_a || !omega) return hm_fail(HM_ERR_BAD_ARG, "hm_ntt_bn256_fr_dev: null argument");
+  DeviceCtx* ctx = ctx_for_current_device();
+  if (!ctx) return HM_ERR_NO_DEVICE;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  return ntt_run(*ctx, (uint32_t*)d_a, omega, log_n, nullptr, nullptr, (hipStream_t)stream);
+}
+
+int hm_ntt_bn256_fr(uint64_t* a, const uint64_t omega[4], uint32_t log_n) {
+  if (!a || !omega) return hm_fail(HM_ERR_BAD_ARG, "hm_ntt_bn256_fr: null argument");
+  if (log_n > 28) return hm_fail(HM_ERR_BAD_ARG, "hm_ntt_bn256_fr: log_n > 28");
+  DeviceCtx* ctx = ctx_for_current_device();
+  if (!ctx) return HM_ERR_NO_DEVICE;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  const size_t bytes = ((size_t)32) << log_n;
+  void* d_a = ctx->io.ensure(bytes);
+  if (!d_a) return hm_fail(HM_ERR_HIP, "hm_ntt_bn256_fr: staging allocation failed");
+  HM_HIP_CHECK(hipMemcpy(d_a, a, bytes, hipMemcpyHostToDevice));
+  int rc = ntt_run(*ctx, (uint32_t*)d_a, omega, log_n, nullptr, nullptr, nullptr);
+  if (rc != HM_OK) return rc;
+  HM_HIP_CHECK(hipMemcpy(a, d_a, bytes, hipMemcpyDeviceToHost));
+  return HM_OK;
+}
+
+static int small_consts(DeviceCtx& ctx, const uint64_t* ext, uint32_t count, hipStream_t stream, uint32_t** d_int) {
+  // small buffer layout: [0, 4096) reserved for the fixed-base table header; constants live after it
+  uint8_t* sm = (uint8_t*)ctx.small.ensure(64 + (size_t)64 * 15 * 28 * 4 + 4096);
+  if (!sm) return hm_fail(HM_ERR_HIP, "constant buffer allocation failed");
+  uint8_t* area = sm + 64 + (size_t)64 * 15 * 28 * 4;
+  uint32_t* d_ext = (uint32_t*)area;
+  *d_int = (uint32_t*)(area + 1024);
+  HM_HIP_CHECK(hipMemcpyAsync(d_ext, ext, (size_t)count * 32, hipMemcpyHostToDevice, stream));
+  return fr_ext_to_int_run(d_ext, *d_int, count, stream);
+}
+
+int hm_ifft_bn256_fr_dev(void* d_a, const uint64_t omega_inv[4], uint32_t log_n, const uint64_t divisor[4], void* stream) {
+  if (!d_a || !omega_inv || !divisor) return hm_fail(HM_ERR_BAD_ARG, "hm_ifft_bn256_fr_dev: null argument");
+  DeviceCtx* ctx = ctx_for_current_device();
+  if (!ctx) return HM_ERR_NO_DEVICE;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  uint32_t* d_int = nullptr;
+  int rc = small_consts(*ctx, divisor, 1, (hipStream_t)stream, &d_int);
+  if (rc != HM_OK) return rc;
+  return ntt_run(*ctx, (uint32_t*)d_a, omega_inv, log_n, d_int, nullptr, (hipStream_t)stream);
+}
+
+int hm_coset_ntt_bn256_fr_dev(void* d_a, const uint64_t omega[4], uint32_t log_n, const uint64_t coset[12], void* stream) {
+  if (!d_a || !omega || !coset) return hm_fail(HM_ERR_BAD_ARG, "hm_coset_ntt_bn256_fr_dev: null argument");
+  DeviceCtx* ctx = ctx_for_current_device();
+  if (!ctx) return HM_ERR_NO_DEVICE;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  uint32_t* d_int = nullptr;
+  int rc = small_consts(*ctx, coset, 3, (hipStream_t)stream, &d_int);
+  if (rc != HM_OK) return rc;
+  return ntt_run(*ctx, (uint32_t*)d_a, omega, log_n, nullptr, d_int, (hipStream_t)stream);
+}
+
+int hm_fr_scale_dev(void* d_a, size_t n, const uint64_t c[4], void* stream) {
+  if ((n && !d_a) || !c) return hm_fail(HM_ERR_BAD_ARG, "hm_fr_scale_dev: null argument");
+  DeviceCtx* ctx = ctx_for_current_device();
+  if (!ctx) return HM_ERR_NO_DEVICE;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (n == 0) return HM_OK;
+  uint8_t* sm = (uint8_t*)ctx->small.ensure(64 + (size_t)64 * 15 * 28 * 4 + 4096);
+  if (!sm) return hm_fail(HM_ERR_HIP, "hm_fr_scale_dev: constant buffer allocation failed");
+  uint32_t* d_c = (uint32_t*)(sm + 64 + (size_t)64 * 15 * 28 * 4 + 2048);
+  HM_HIP_CHECK(hipMemcpyAsync(d_c, c, 32, hipMemcpyHostToDevice, (hipStream_t)stream));
+  return fr_scale_run((uint32_t*)d_a, d_c, n, (hipStream_t)stream);
+}
+
+int hm_fr_distribute_powers_dev(void* d_a, size_t n, const uint64_t c3[12], void* stream) {
+  if ((n && !d_a) || !c3) return hm_fail(HM_ERR_BAD_ARG, "hm_fr_distribute_powers_dev: null argument");
+  DeviceCtx* ctx = ctx_for_current_device();
+  if (!ctx) return HM_ERR_NO_DEVICE;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (n == 0) return HM_OK;
+  uint8_t* sm = (uint8_t*)ctx->small.ensure(64 + (size_t)64 * 15 * 28 * 4 + 4096);
+  if (!sm) return hm_fail(HM_ERR_HIP, "hm_fr_distribute_powers_dev: constant buffer allocation failed");
+  uint32_t* d_c = (uint32_t*)(sm + 64 + (size_t)64 * 15 * 28 * 4 + 3072);
+  HM_HIP_CHECK(hipMemcpyAsync(d_c, c3, 96, hipMemcpyHostToDevice, (hipStream_t)stream));
+  return fr_mul_pattern3_run((uint32_t*)d_a, d_c, n, (hipStream_t)stream);
+}
+
+int hm_g1_fixed_base_mul_dev(const void* d_scalars, size_t n, const uint64_t base_xy[8], void* d_out_xy, void* stream) {
+  if ((n && (!d_scalars || !d_out_xy)) || !base_xy) return hm_fail(HM_ERR_BAD_ARG, "hm_g1_fixed_base_mul_dev: null argument");
+  DeviceCtx* ctx = ctx_for_current_device();
+  if (!ctx) return HM_ERR_NO_DEVICE;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  // make sure the shared small buffer has its full size before the table is carved from it
+  if (!ctx->small.ensure(64 + (size_t)64 * 15 * 28 * 4 + 4096)) return hm_fail(HM_ERR_HIP, "small buffer allocation failed");
+  return g1_fixed_base_mul_run(*ctx, (const uint32_t*)d_scalars, n, base_xy, (uint32_t*)d_out_xy, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,191 @@
+// g1.h -- BN256 G1 (y^2 = x^3 + 3 over Fq) in Jacobian coordinates on the ff29 field layer.
+//
+// Coordinates are kept in the internal Montgomery form of ff29.h.  "Class" bounds (checked for
+// every formula by the HM_BOUNDS host build, see tests/test_ff29_host.py):
+//     Jacobian point:  X, Y normalised limbs, value < G1_XYB * p;  Z a product output (< 2p)
+//     affine operand:  x, y product outputs (< 2p)
+// Identity is carried as an explicit flag (never encoded in Z) so the hot loop has no compare
+// against zero; the exceptional cases of the addition law (P = Q, P = -Q) are detected from
+// products the formula computes anyway.
+//
+// Formulas: madd-2007-bl / add-2007-bl / dbl-2009-l from the Explicit-Formulas Database, the
+// textbook laws for a = 0 short-Weierstrass curves, re-associated so that no stored coordinate
+// needs a modular reduction (only carry normalisation).
+#pragma once
+#include "ff29.h"
+
+namespace hm {
+
+using Fq = Fe<FqParams>;
+using Fr = Fe<FrParams>;
+
+struct G1Aff {
+  Fq x, y;
+};
+struct G1Jac {
+  Fq x, y, z;
+  bool inf;
+};
+
+// class bound on stored X, Y (multiples of p); the subtraction constants below are chosen against it
+#define HM_G1_XYB 12.0
+#define HM_G1_ZB 2.0
+
+#ifdef HM_BOUNDS
+inline void g1_check_class(const G1Jac& p, const char* what) {
+  HM_CHECK(p.x.lb <= MASK29 && p.y.lb <= MASK29 && p.z.lb <= MASK29, what);
+  HM_CHECK(p.x.vb <= HM_G1_XYB && p.y.vb <= HM_G1_XYB && p.z.vb <= HM_G1_ZB, what);
+}
+#define HM_G1_CHECK(p, what) g1_check_class(p, what)
+#else
+#define HM_G1_CHECK(p, what) ((void)0)
+#endif
+
+HM_HD G1Jac g1_identity() {
+  G1Jac r;
+  r.x = fe_zero<FqParams>();
+  r.y = fe_zero<FqParams>();
+  r.z = fe_zero<FqParams>();
+  r.inf = true;
+  return r;
+}
+
+HM_HD G1Jac g1_from_affine(const G1Aff& p) {
+  G1Jac r;
+  r.x = p.x;
+  r.y = p.y;
+  r.z = fe_one<FqParams>();
+  r.inf = false;
+  return r;
+}
+
+// y -> -y for an affine operand (value < 2p): 3p - y, renormalised
+HM_HD G1Aff g1_neg_affine(const G1Aff& p) {
+  G1Aff r;
+  r.x = p.x;
+  r.y = fe_norm(fe_sub<3, 29>(fe_zero<FqParams>(), p.y));
+  return r;
+}
+HM_HD G1Aff g1_cneg_affine(const G1Aff& p, bool neg) {
+  G1Aff n = g1_neg_affine(p);
+  G1Aff r;
+  r.x = p.x;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) r.y.l[i] = neg ? n.y.l[i] : p.y.l[i];
+#ifdef HM_BOUNDS
+  r.y.vb = n.y.vb > p.y.vb ? n.y.vb : p.y.vb;
+  r.y.lb = MASK29;
+  r.y.tb = n.y.tb > p.y.tb ? n.y.tb : p.y.tb;
+#endif
+  return r;
+}
+
+// Doubling for a = 0 (dbl-2009-l with D = 4*X*Y^2 taken as a product so that no stored
+// coordinate inherits a large subtraction constant): 3M + 4S.  p must not be the identity.
+HM_HD G1Jac g1_double_nz(const G1Jac& p) {
+  HM_G1_CHECK(p, "g1_double_nz input outside class");
+  const Fq A = fe_sqr(p.x);                                  // X^2
+  const Fq B = fe_sqr(p.y);                                  // Y^2
+  const Fq C = fe_sqr(B);                                    // Y^4
+  const Fq S = fe_mul(p.x, B);                               // X*Y^2
+  const Fq D = fe_norm(fe_mul4(S));                          // D = 4*X*Y^2
+  const Fq E = fe_norm(fe_add(fe_dbl(A), A));                // E = 3*X^2
+  const Fq Fv = fe_sqr(E);
+  const Fq twoD = fe_dbl(D);                                 // 2D (limbs < 2^30)
+  G1Jac r;
+  r.x = fe_norm(fe_sub<10, 30>(Fv, twoD));                   // X3 = E^2 - 2D
+  const Fq dx = fe_norm(fe_sub<12, 29>(D, r.x));             // D - X3
+  const Fq ed = fe_mul(E, dx);
+  const Fq c8 = fe_dbl(fe_norm(fe_mul4(C)));                 // 8*Y^4 (limbs < 2^30)
+  r.y = fe_norm(fe_sub<9, 30>(ed, c8));                      // Y3 = E(D - X3) - 8C
+  r.z = fe_mul(fe_dbl(p.y), p.z);                            // Z3 = 2*Y*Z
+  r.inf = false;
+  return r;
+}
+
+HM_HD G1Jac g1_double(const G1Jac& p) {
+  if (p.inf) return p;
+  return g1_double_nz(p);
+}
+
+// madd-2007-bl re-associated (8M + 3S): acc (Jacobian, class bounds) + q (affine, product outputs).
+// Neither operand may be the identity; the result may be.
+HM_HD G1Jac g1_madd_nz(const G1Jac& p, const G1Aff& q) {
+  HM_G1_CHECK(p, "g1_madd_nz input outside class");
+  const Fq z1z1 = fe_sqr(p.z);
+  const Fq u2 = fe_mul(q.x, z1z1);
+  const Fq s2 = fe_mul(q.y, fe_mul(p.z, z1z1));
+  const Fq h = fe_norm(fe_sub<13, 29>(u2, p.x));             // U2 - X1
+  const Fq hh = fe_sqr(h);
+  if (fe_is_zero_mod(hh)) {                                  // X1 = U2: doubling or inverse
+    const Fq r0 = fe_norm(fe_sub<13, 29>(s2, p.y));
+    const Fq rr0 = fe_sqr(r0);
+    if (fe_is_zero_mod(rr0)) return g1_double_nz(p);
+    return g1_identity();
+  }
+  const Fq i4 = fe_mul4(hh);                                 // I = 4*HH   (limbs < 2^31)
+  const Fq j = fe_mul(h, i4);
+  const Fq r0 = fe_norm(fe_sub<13, 29>(s2, p.y));            // (S2 - Y1)
+  const Fq r = fe_dbl(r0);                                   // r = 2(S2 - Y1)  (limbs < 2^30)
+  const Fq v = fe_mul(p.x, i4);
+  const Fq rr = fe_sqr(r);
+  const Fq t2 = fe_add(j, fe_dbl(v));                        // J + 2V  (limbs < 3*2^29)
+  G1Jac o;
+  o.x = fe_norm(fe_sub<6, 31>(rr, t2));                      // r^2 - J - 2V
+  const Fq vx = fe_norm(fe_sub<13, 29>(v, o.x));             // V - X3
+  const Fq m1 = fe_mul(r0, vx);
+  const Fq m2 = fe_mul(p.y, j);
+  o.y = fe_norm(fe_dbl(fe_sub<3, 29>(m1, m2)));              // 2(r0 (V - X3) - Y1 J)
+  o.z = fe_mul(p.z, fe_dbl(h));                              // 2 Z1 H
+  o.inf = false;
+  return o;
+}
+
+HM_HD G1Jac g1_madd(const G1Jac& p, const G1Aff& q) {
+  if (p.inf) return g1_from_affine(q);
+  return g1_madd_nz(p, q);
+}
+
+// add-2007-bl re-associated (12M + 4S): both Jacobian, neither the identity.
+HM_HD G1Jac g1_add_nz(const G1Jac& p, const G1Jac& q) {
+  HM_G1_CHECK(p, "g1_add_nz input p outside class");
+  HM_G1_CHECK(q, "g1_add_nz input q outside class");
+  const Fq z1z1 = fe_sqr(p.z);
+  const Fq z2z2 = fe_sqr(q.z);
+  const Fq u1 = fe_mul(p.x, z2z2);
+  const Fq u2 = fe_mul(q.x, z1z1);
+  const Fq s1 = fe_mul(p.y, fe_mul(q.z, z2z2));
+  const Fq s2 = fe_mul(q.y, fe_mul(p.z, z1z1));
+  const Fq h = fe_norm(fe_sub<3, 29>(u2, u1));
+  const Fq hh = fe_sqr(h);
+  if (fe_is_zero_mod(hh)) {
+    const Fq r0 = fe_norm(fe_sub<3, 29>(s2, s1));
+    const Fq rr0 = fe_sqr(r0);
+    if (fe_is_zero_mod(rr0)) return g1_double_nz(p);
+    return g1_identity();
+  }
+  const Fq i4 = fe_mul4(hh);
+  const Fq j = fe_mul(h, i4);
+  const Fq r0 = fe_norm(fe_sub<3, 29>(s2, s1));
+  const Fq r = fe_dbl(r0);
+  const Fq v = fe_mul(u1, i4);
+  const Fq rr = fe_sqr(r);
+  const Fq t2 = fe_add(j, fe_dbl(v));
+  G1Jac o;
+  o.x = fe_norm(fe_sub<4, 31>(rr, t2));
+  const Fq vx = fe_norm(fe_sub<7, 29>(v, o.x));
+  const Fq m1 = fe_mul(r0, vx);
+  const Fq m2 = fe_mul(s1, j);
+  o.y = fe_norm(fe_dbl(fe_sub<3, 29>(m1, m2)));
+  o.z = fe_mul(fe_mul(p.z, q.z), fe_dbl(h));                 // 2 Z1 Z2 H
+  o.inf = false;
+  return o;
+}
+
+HM_HD G1Jac g1_add(const G1Jac& p, const G1Jac& q) {
+  if (p.inf) return q;
+  if (q.inf) return p;
+  return g1_add_nz(p, q);
+}
+
+}  // namespace hm

@@ -1,0 +1,115 @@
+// hm_internal.h -- private declarations shared by the translation units of libhalo2_mi355x.so
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/halo2_mi355x.h"
+
+namespace hm {
+
+int hm_fail(int code, const std::string& what);  // records the message for hm_last_error(), returns code
+
+#define HM_HIP_CHECK(expr)                                                                          \
+  do {                                                                                              \
+    hipError_t _e = (expr);                                                                         \
+    if (_e != hipSuccess)                                                                           \
+      return ::hm::hm_fail(HM_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));          \
+  } while (0)
+#define HM_HIP_CHECK_PTR(expr)                                                                      \
+  do {                                                                                              \
+    hipError_t _e = (expr);                                                                         \
+    if (_e != hipSuccess) {                                                                         \
+      ::hm::hm_fail(HM_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));                 \
+      return nullptr;                                                                               \
+    }                                                                                               \
+  } while (0)
+
+struct NttTables {
+  uint32_t log_n = 0;
+  uint64_t omega[4] = {0, 0, 0, 0};
+  uint32_t log_lb = 0;
+  void* d_omega = nullptr;
+  uint32_t* d_lo = nullptr;
+  uint32_t* d_hi = nullptr;
+  uint32_t* d_stage[16] = {};
+};
+
+// grow-only device buffer
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  void* ensure(size_t bytes) {
+    if (bytes <= cap) return p;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+    cap = bytes;
+    return p;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+
+struct BasesEntry {          // device-resident, converted base set (hm_register_bases)
+  uint64_t handle = 0;
+  size_t n = 0;
+  uint32_t* d_xy = nullptr;  // n x 16 u32: x, y packed internal form
+  uint8_t* d_inf = nullptr;  // n flags: base is the identity
+  bool owned = true;
+};
+
+struct MsmStats {
+  double t_digits_ms = 0, t_sort_ms = 0, t_accum_ms = 0, t_reduce_ms = 0, t_total_ms = 0;
+  uint64_t pairs = 0, tasks = 0;
+  uint32_t c = 0, windows = 0;
+};
+
+struct DeviceCtx {
+  int device = 0;
+  std::mutex mu;
+  std::vector<std::unique_ptr<NttTables>> ntt_tables;
+  DevBuf scratch;         // NTT ping-pong buffer
+  DevBuf io;              // staging for host-pointer calls (scalars / NTT array)
+  DevBuf io_bases;        // staging for raw external bases of host-pointer MSM calls
+  DevBuf conv_bases;      // converted bases of un-registered calls
+  DevBuf conv_inf;
+  DevBuf msm_ws;          // MSM workspace (digits, histograms, sorted indices, bucket sums ...)
+  DevBuf small;           // small constants
+  std::vector<BasesEntry> bases;
+  uint64_t next_handle = 1;
+  // host-pointer MSM: cache of the last converted un-registered base array (keyed by ptr,len,probe)
+  const void* cached_host_bases = nullptr;
+  size_t cached_host_n = 0;
+  uint64_t cached_probe[4] = {0, 0, 0, 0};
+  MsmStats last_msm;
+  void* ensure_scratch(size_t bytes) { return scratch.ensure(bytes); }
+};
+
+DeviceCtx* ctx_for_current_device();
+
+// ntt.hip
+int ntt_run(DeviceCtx& ctx, uint32_t* d_a, const uint64_t omega_ext[4], uint32_t log_n, const uint32_t* d_scale_int,
+            const uint32_t* d_coset_int, hipStream_t stream);
+int fr_scale_run(uint32_t* d_a, const uint32_t* d_c_ext, uint64_t n, hipStream_t stream);
+int fr_mul_pattern3_run(uint32_t* d_a, const uint32_t* d_c3_ext, uint64_t n, hipStream_t stream);
+int fr_ext_to_int_run(const uint32_t* d_c_ext, uint32_t* d_out, uint32_t count, hipStream_t stream);
+
+// msm.hip
+int msm_convert_bases(const uint32_t* d_bases_ext, uint32_t* d_xy, uint8_t* d_inf, size_t n, hipStream_t stream);
+// out_windows: host buffer of W x 12 u64 external Jacobian + flags
+int msm_run(DeviceCtx& ctx, const uint32_t* d_scalars_ext, const uint32_t* d_xy, const uint8_t* d_inf, size_t n,
+            int c_override, uint64_t out_jac_ext[12], int* out_is_identity, hipStream_t stream);
+int g1_fixed_base_mul_run(DeviceCtx& ctx, const uint32_t* d_scalars_ext, size_t n, const uint64_t base_affine_ext[8],
+                          uint32_t* d_out_affine_ext, hipStream_t stream);
+
+}  // namespace hm

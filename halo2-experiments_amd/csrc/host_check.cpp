@@ -1,0 +1,153 @@
+// host_check.cpp -- CPU build of the device arithmetic headers (ff29.h, g1.h) with worst-case
+// bound tracking (-DHM_BOUNDS).  Not part of the product path: it exists so that the `-m "not gpu"`
+// tests can (a) compare the exact code the kernels run with the oracle and (b) prove, by running
+// every formula once with its inputs declared at the class bounds, that no 64-bit column sum,
+// limb or lazy value can overflow for ANY input (the tracked bounds are data-independent).
+//
+// Build: g++ -O2 -std=c++17 -DHM_BOUNDS -shared -fPIC -o libhm_hostcheck.so host_check.cpp
+#include <cstring>
+
+#include "g1.h"
+
+using namespace hm;
+
+namespace {
+
+template <class F>
+Fe<F> load_ext(const uint64_t* p) {
+  uint32_t w[8];
+  std::memcpy(w, p, 32);
+  return fe_from_ext<F>(w);
+}
+template <class F>
+void store_ext(uint64_t* p, const Fe<F>& a) {
+  uint32_t w[8];
+  fe_to_ext(w, a);
+  std::memcpy(p, w, 32);
+}
+
+template <class F>
+void force_bounds(Fe<F>& a, double vb) {  // declare the class maximum regardless of the actual value
+  a.vb = vb;
+  a.lb = MASK29;
+  a.tb = top_bound_from_value<F>(vb);
+}
+
+G1Jac load_jac(const uint64_t* p, int inf) {
+  G1Jac r;
+  r.x = load_ext<FqParams>(p);
+  r.y = load_ext<FqParams>(p + 4);
+  r.z = load_ext<FqParams>(p + 8);
+  r.inf = inf != 0;
+  return r;
+}
+void store_jac(uint64_t* p, int* inf, const G1Jac& r) {
+  if (r.inf) {
+    std::memset(p, 0, 96);
+    *inf = 1;
+    return;
+  }
+  store_ext(p, r.x);
+  store_ext(p + 4, r.y);
+  store_ext(p + 8, r.z);
+  *inf = 0;
+}
+void at_class_max(G1Jac& p) {
+  force_bounds(p.x, HM_G1_XYB);
+  force_bounds(p.y, HM_G1_XYB);
+  force_bounds(p.z, HM_G1_ZB);
+}
+
+template <class F>
+void field_op(int op, const uint64_t* a, const uint64_t* b, uint64_t* o, size_t n) {
+  for (size_t i = 0; i < n; ++i) {
+    Fe<F> x = load_ext<F>(a + 4 * i), y = load_ext<F>(b + 4 * i), r;
+    switch (op) {
+      case 0: r = fe_mul(x, y); break;
+      case 1: r = fe_sqr(x); break;
+      case 2: r = fe_norm(fe_add(x, y)); break;
+      case 3: r = fe_norm(fe_sub<3, 29>(x, y)); break;
+      case 4: {  // lazy chain: ((x + y) * (x - y + 3p)) + x*x, exercises unnormalised operands
+        Fe<F> s = fe_add(x, y), d = fe_sub<3, 29>(x, y);
+        r = fe_norm(fe_add(fe_mul(s, fe_norm(d)), fe_sqr(x)));
+        break;
+      }
+      default: r = x;
+    }
+    store_ext(o + 4 * i, r);
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+// field: 0 = Fq, 1 = Fr.  op: 0 mul, 1 sqr, 2 add, 3 sub, 4 lazy chain.  external Montgomery in/out
+void hc_field_op(int field, int op, const uint64_t* a, const uint64_t* b, uint64_t* o, size_t n) {
+  if (field == 0) field_op<FqParams>(op, a, b, o, n);
+  else field_op<FrParams>(op, a, b, o, n);
+}
+
+// unpack/pack round trip and canonicalisation of raw (possibly non-canonical) 256-bit words
+void hc_fr_reduce_raw(const uint64_t* a, uint64_t* o, size_t n) {
+  for (size_t i = 0; i < n; ++i) {
+    uint32_t w[8];
+    std::memcpy(w, a + 4 * i, 32);
+    Fe<FrParams> x = fe_unpack<FrParams>(w);
+    // x * 2^261 * 2^-261 = x mod r, canonical
+    Fe<FrParams> y = fe_canonical(fe_mul(x, fe_const<FrParams>(FrParams::ONE)));
+    fe_pack(w, y);
+    std::memcpy(o + 4 * i, w, 32);
+  }
+}
+
+void hc_g1_madd(const uint64_t* pj, int pinf, const uint64_t* q_aff, int neg, uint64_t* out, int* out_inf) {
+  G1Jac p = load_jac(pj, pinf);
+  G1Aff q;
+  q.x = load_ext<FqParams>(q_aff);
+  q.y = load_ext<FqParams>(q_aff + 4);
+  q = g1_cneg_affine(q, neg != 0);
+  store_jac(out, out_inf, g1_madd(p, q));
+}
+void hc_g1_add(const uint64_t* pj, int pinf, const uint64_t* qj, int qinf, uint64_t* out, int* out_inf) {
+  store_jac(out, out_inf, g1_add(load_jac(pj, pinf), load_jac(qj, qinf)));
+}
+void hc_g1_double(const uint64_t* pj, int pinf, uint64_t* out, int* out_inf) {
+  store_jac(out, out_inf, g1_double(load_jac(pj, pinf)));
+}
+// k chained madds of the same affine point followed by doublings: stresses class closure on data
+void hc_g1_chain(const uint64_t* q_aff, int k, int dbl, uint64_t* out, int* out_inf) {
+  G1Aff q;
+  q.x = load_ext<FqParams>(q_aff);
+  q.y = load_ext<FqParams>(q_aff + 4);
+  G1Jac acc = g1_identity();
+  for (int i = 0; i < k; ++i) acc = g1_madd(acc, q);
+  for (int i = 0; i < dbl; ++i) acc = g1_double(acc);
+  store_jac(out, out_inf, acc);
+}
+
+// Run every curve formula with inputs DECLARED at the class maxima; any precondition violation
+// aborts.  Writes the resulting output bounds (x.vb, y.vb, z.vb per formula) for the report.
+int hc_bounds_closure(const uint64_t* pj, const uint64_t* qj, const uint64_t* q_aff, double* report) {
+  G1Jac p = load_jac(pj, 0), q2 = load_jac(qj, 0);
+  at_class_max(p);
+  at_class_max(q2);
+  G1Aff q;
+  q.x = load_ext<FqParams>(q_aff);
+  q.y = load_ext<FqParams>(q_aff + 4);
+  force_bounds(q.x, 2.0);
+  force_bounds(q.y, 2.0);
+  q = g1_cneg_affine(q, true);
+  G1Jac r[3] = {g1_madd_nz(p, q), g1_add_nz(p, q2), g1_double_nz(p)};
+  int ok = 1;
+  for (int i = 0; i < 3; ++i) {
+    report[3 * i + 0] = r[i].x.vb;
+    report[3 * i + 1] = r[i].y.vb;
+    report[3 * i + 2] = r[i].z.vb;
+    if (r[i].x.vb > HM_G1_XYB || r[i].y.vb > HM_G1_XYB || r[i].z.vb > HM_G1_ZB) ok = 0;
+    if (r[i].x.lb > MASK29 || r[i].y.lb > MASK29 || r[i].z.lb > MASK29) ok = 0;
+  }
+  return ok;
+}
+
+}  // extern "C"

@@ -1,0 +1,670 @@
+// msm.hip -- Pippenger bucket MSM over BN256 G1 for gfx950 (replaces
+// halo2_proofs::arithmetic::best_multiexp, SURVEY.md §3.3: sum_i coeffs[i] * bases[i]).
+//
+// Pipeline (all device-resident; one mid-pipeline 8-byte readback to size the task grid):
+//   K0  digits      scalar (radix-2^256 Montgomery) -> canonical -> W signed c-bit digits
+//   K2a hist        per-(chunk, window) bucket histogram in LDS (2^(c-1)+1 counters <= 128 KiB)
+//   K2b scan        per-bucket prefix over chunks, then bucket offsets + accumulation-task offsets
+//   K2c scatter     counting-sort scatter through LDS cursors -> point indices grouped by bucket
+//   K3  accumulate  one lane per task (a bucket, or a <= L-long slice of a long bucket): a serial
+//                   chain of mixed additions, the accumulator living in registers
+//   K3b finalize    per bucket: sum of its task partials
+//   K4a/K4b reduce  per window sum_b b*B_b by segmented running sums, then a tree in LDS
+//   host            Horner over the W window sums (c doublings each) and affine normalisation
+// Differences from the reference's CPU algorithm that do not change the (canonical) result:
+// signed digits (half the buckets), a window size chosen for the whole array instead of per
+// thread chunk, buckets summed in sorted order.  Long buckets (constant columns, tiny scalars) are
+// split into tasks so that one hot bucket cannot serialise the launch.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+
+#include "g1.h"
+#include "hm_internal.h"
+
+namespace hm {
+
+constexpr int PT_WORDS = 28;  // device Jacobian record: 27 limbs + identity flag
+
+__device__ __forceinline__ G1Jac load_jac(const uint32_t* p) {
+  const uint4* q = reinterpret_cast<const uint4*>(p);
+  uint32_t w[PT_WORDS];
+#pragma unroll
+  for (int i = 0; i < 7; ++i) {
+    const uint4 v = q[i];
+    w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
+  }
+  G1Jac r;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    r.x.l[i] = w[i];
+    r.y.l[i] = w[9 + i];
+    r.z.l[i] = w[18 + i];
+  }
+  r.inf = w[27] != 0;
+  return r;
+}
+__device__ __forceinline__ void store_jac(uint32_t* p, const G1Jac& a) {
+  uint32_t w[PT_WORDS];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    w[i] = a.x.l[i];
+    w[9 + i] = a.y.l[i];
+    w[18 + i] = a.z.l[i];
+  }
+  w[27] = a.inf ? 1u : 0u;
+  uint4* q = reinterpret_cast<uint4*>(p);
+#pragma unroll
+  for (int i = 0; i < 7; ++i) q[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
+}
+
+__device__ __forceinline__ G1Aff load_base(const uint32_t* xy, uint32_t idx) {
+  const uint4* q = reinterpret_cast<const uint4*>(xy + (size_t)idx * 16);
+  const uint4 a = q[0], b = q[1], c = q[2], d = q[3];
+  const uint32_t wx[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+  const uint32_t wy[8] = {c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w};
+  G1Aff r;
+  r.x = fe_unpack<FqParams>(wx);
+  r.y = fe_unpack<FqParams>(wy);
+  return r;
+}
+
+// ---------------------------------------------------------------------------------------------
+// bases: external affine -> internal packed (x, y) + identity flags
+// ---------------------------------------------------------------------------------------------
+__global__ void msm_convert_bases_kernel(const uint32_t* __restrict__ ext, uint32_t* __restrict__ xy,
+                                         uint8_t* __restrict__ inf, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint4* q = reinterpret_cast<const uint4*>(ext + i * 16);
+  const uint4 a = q[0], b = q[1], c = q[2], d = q[3];
+  const uint32_t wx[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+  const uint32_t wy[8] = {c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w};
+  uint32_t any = 0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) any |= wx[k] | wy[k];
+  uint32_t ox[8], oy[8];
+  fe_pack(ox, fe_from_ext<FqParams>(wx));
+  fe_pack(oy, fe_from_ext<FqParams>(wy));
+  uint4* o = reinterpret_cast<uint4*>(xy + i * 16);
+  o[0] = make_uint4(ox[0], ox[1], ox[2], ox[3]);
+  o[1] = make_uint4(ox[4], ox[5], ox[6], ox[7]);
+  o[2] = make_uint4(oy[0], oy[1], oy[2], oy[3]);
+  o[3] = make_uint4(oy[4], oy[5], oy[6], oy[7]);
+  inf[i] = any == 0 ? 1 : 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K0: signed window digits.  digits[w*n + i] in [-2^(c-1)+1, 2^(c-1)], 0 = skip.
+// ---------------------------------------------------------------------------------------------
+__global__ void msm_digits_kernel(const uint32_t* __restrict__ scalars, const uint8_t* __restrict__ inf,
+                                  int32_t* __restrict__ digits, size_t n, uint32_t c, uint32_t W) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint4* q = reinterpret_cast<const uint4*>(scalars + i * 8);
+  const uint4 lo = q[0], hi = q[1];
+  const uint32_t w_in[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+  // s_mont * 32 * 2^-261 = s_mont * 2^-256 = the canonical scalar (Fr::to_repr)
+  Fr k32 = fe_zero<FrParams>();
+  k32.l[0] = 32;
+  const Fr s = fe_canonical(fe_mul(fe_unpack<FrParams>(w_in), k32));
+  uint32_t v[9];
+  {
+    uint32_t t[8];
+    fe_pack(t, s);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = t[k];
+    v[8] = 0;
+  }
+  const bool skip = inf[i] != 0;
+  const uint32_t mask = (1u << c) - 1u, half = 1u << (c - 1);
+  uint32_t carry = 0;
+  for (uint32_t w = 0; w < W; ++w) {
+    uint32_t d = (v[0] & mask) + carry;
+    int32_t sd;
+    if (d > half) {
+      sd = (int32_t)d - (int32_t)(1u << c);
+      carry = 1;
+    } else {
+      sd = (int32_t)d;
+      carry = 0;
+    }
+    digits[(size_t)w * n + i] = skip ? 0 : sd;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = __funnelshift_r(v[k], v[k + 1], c);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K2: counting sort of (bucket, point index) per window through LDS
+// ---------------------------------------------------------------------------------------------
+constexpr int SORT_THREADS = 1024;
+
+__global__ __launch_bounds__(SORT_THREADS) void msm_hist_kernel(const int32_t* __restrict__ digits,
+                                                                uint32_t* __restrict__ blockhist, size_t n,
+                                                                size_t chunk, uint32_t NBP) {
+  extern __shared__ uint32_t hist[];
+  const uint32_t g = blockIdx.x, w = blockIdx.y, G = gridDim.x;
+  for (uint32_t b = threadIdx.x; b < NBP; b += SORT_THREADS) hist[b] = 0;
+  __syncthreads();
+  const size_t lo = (size_t)g * chunk, hi = lo + chunk < n ? lo + chunk : n;
+  const int32_t* dw = digits + (size_t)w * n;
+  for (size_t i = lo + threadIdx.x; i < hi; i += SORT_THREADS) {
+    const int32_t d = dw[i];
+    if (d != 0) atomicAdd(&hist[d < 0 ? -d : d], 1u);
+  }
+  __syncthreads();
+  uint32_t* out = blockhist + ((size_t)w * G + g) * NBP;
+  for (uint32_t b = threadIdx.x; b < NBP; b += SORT_THREADS) out[b] = hist[b];
+}
+
+// per (window, bucket): exclusive prefix over chunks in place, total into bcnt
+__global__ void msm_scan_blocks_kernel(uint32_t* __restrict__ blockhist, uint32_t* __restrict__ bcnt, uint32_t G,
+                                       uint32_t NBP, uint32_t W) {
+  const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= W * NBP) return;
+  const uint32_t w = idx / NBP, b = idx - w * NBP;
+  uint32_t run = 0;
+  for (uint32_t g = 0; g < G; ++g) {
+    uint32_t* p = blockhist + ((size_t)w * G + g) * NBP + b;
+    const uint32_t t = *p;
+    *p = run;
+    run += t;
+  }
+  bcnt[idx] = run;
+}
+
+// single block: bucket offsets (exclusive scan of counts) and task offsets (ceil(count / L))
+__global__ __launch_bounds__(1024) void msm_scan_buckets_kernel(const uint32_t* __restrict__ bcnt,
+                                                                uint32_t* __restrict__ boff,
+                                                                uint32_t* __restrict__ toff,
+                                                                uint32_t* __restrict__ totals, uint32_t NBT, uint32_t L) {
+  __shared__ uint32_t s_pairs[1024], s_tasks[1024];
+  const uint32_t t = threadIdx.x;
+  const uint32_t per = (NBT + 1023) / 1024;
+  const uint32_t lo = t * per, hi = lo + per < NBT ? lo + per : NBT;
+  uint32_t sp = 0, st = 0;
+  for (uint32_t i = lo; i < hi; ++i) {
+    const uint32_t c = bcnt[i];
+    sp += c;
+    st += (c + L - 1) / L;
+  }
+  s_pairs[t] = sp;
+  s_tasks[t] = st;
+  __syncthreads();
+  for (uint32_t off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan
+    uint32_t a = 0, b = 0;
+    if (t >= off) { a = s_pairs[t - off]; b = s_tasks[t - off]; }
+    __syncthreads();
+    s_pairs[t] += a;
+    s_tasks[t] += b;
+    __syncthreads();
+  }
+  uint32_t rp = s_pairs[t] - sp, rt = s_tasks[t] - st;  // exclusive
+  for (uint32_t i = lo; i < hi; ++i) {
+    const uint32_t c = bcnt[i];
+    boff[i] = rp;
+    toff[i] = rt;
+    rp += c;
+    rt += (c + L - 1) / L;
+  }
+  if (t == 1023) {
+    totals[0] = s_pairs[1023];
+    totals[1] = s_tasks[1023];
+  }
+  if (t == 0) toff[NBT] = s_tasks[1023];
+}
+
+__global__ __launch_bounds__(SORT_THREADS) void msm_scatter_kernel(const int32_t* __restrict__ digits,
+                                                                   const uint32_t* __restrict__ blockhist,
+                                                                   const uint32_t* __restrict__ boff,
+                                                                   uint32_t* __restrict__ sorted, size_t n, size_t chunk,
+                                                                   uint32_t NBP) {
+  extern __shared__ uint32_t cursor[];
+  const uint32_t g = blockIdx.x, w = blockIdx.y, G = gridDim.x;
+  const uint32_t* pre = blockhist + ((size_t)w * G + g) * NBP;
+  const uint32_t* bo = boff + (size_t)w * NBP;
+  for (uint32_t b = threadIdx.x; b < NBP; b += SORT_THREADS) cursor[b] = bo[b] + pre[b];
+  __syncthreads();
+  const size_t lo = (size_t)g * chunk, hi = lo + chunk < n ? lo + chunk : n;
+  const int32_t* dw = digits + (size_t)w * n;
+  for (size_t i = lo + threadIdx.x; i < hi; i += SORT_THREADS) {
+    const int32_t d = dw[i];
+    if (d != 0) {
+      const uint32_t pos = atomicAdd(&cursor[d < 0 ? -d : d], 1u);
+      sorted[pos] = (uint32_t)i | (d < 0 ? 0x80000000u : 0u);
+    }
+  }
+}
+
+__global__ void msm_task_fill_kernel(const uint32_t* __restrict__ toff, uint32_t* __restrict__ task_bucket, uint32_t NBT) {
+  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= NBT) return;
+  const uint32_t lo = toff[b], hi = toff[b + 1];
+  for (uint32_t t = lo; t < hi; ++t) task_bucket[t] = b;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K3: bucket accumulation -- one lane per task, serial chain of mixed additions
+// ---------------------------------------------------------------------------------------------
+constexpr int ACC_THREADS = 64;
+
+__global__ __launch_bounds__(ACC_THREADS) void msm_accumulate_kernel(const uint32_t* __restrict__ sorted,
+                                                                     const uint32_t* __restrict__ task_bucket,
+                                                                     const uint32_t* __restrict__ boff,
+                                                                     const uint32_t* __restrict__ bcnt,
+                                                                     const uint32_t* __restrict__ toff,
+                                                                     const uint32_t* __restrict__ xy,
+                                                                     uint32_t* __restrict__ partial, uint32_t T, uint32_t L) {
+  const uint32_t t = blockIdx.x * ACC_THREADS + threadIdx.x;
+  if (t >= T) return;
+  const uint32_t b = task_bucket[t];
+  const uint32_t k = t - toff[b];
+  const uint32_t start = boff[b] + k * L;
+  const uint32_t bucket_end = boff[b] + bcnt[b];
+  const uint32_t end = start + L < bucket_end ? start + L : bucket_end;
+  G1Jac acc = g1_identity();
+  for (uint32_t p = start; p < end; ++p) {
+    const uint32_t v = sorted[p];
+    G1Aff q = load_base(xy, v & 0x7fffffffu);
+    q = g1_cneg_affine(q, (v >> 31) != 0);
+    if (acc.inf) {
+      acc = g1_from_affine(q);
+    } else {
+      acc = g1_madd_nz(acc, q);
+    }
+  }
+  store_jac(partial + (size_t)t * PT_WORDS, acc);
+}
+
+// K3b: bucket = sum of its task partials
+__global__ __launch_bounds__(ACC_THREADS) void msm_bucket_finalize_kernel(const uint32_t* __restrict__ partial,
+                                                                          const uint32_t* __restrict__ toff,
+                                                                          uint32_t* __restrict__ bucket, uint32_t NBT) {
+  const uint32_t b = blockIdx.x * ACC_THREADS + threadIdx.x;
+  if (b >= NBT) return;
+  const uint32_t lo = toff[b], hi = toff[b + 1];
+  G1Jac acc = g1_identity();
+  for (uint32_t t = lo; t < hi; ++t) acc = g1_add(acc, load_jac(partial + (size_t)t * PT_WORDS));
+  store_jac(bucket + (size_t)b * PT_WORDS, acc);
+}
+
+// ---------------------------------------------------------------------------------------------
+// K4: per-window sum_b b * B_b
+// ---------------------------------------------------------------------------------------------
+// K4a: one lane per segment of SEG consecutive buckets [lo, lo+SEG): running sums give
+// sum (b - lo + 1) B_b; the remaining (lo - 1) * (sum B_b) is a short double-and-add.
+__global__ __launch_bounds__(ACC_THREADS) void msm_reduce_segments_kernel(const uint32_t* __restrict__ bucket,
+                                                                          uint32_t* __restrict__ segres, uint32_t W,
+                                                                          uint32_t NB, uint32_t NBP, uint32_t SEG,
+                                                                          uint32_t nseg) {
+  const uint32_t idx = blockIdx.x * ACC_THREADS + threadIdx.x;
+  if (idx >= W * nseg) return;
+  const uint32_t w = idx / nseg, sgi = idx - w * nseg;
+  const uint32_t lo = sgi * SEG + 1;
+  const uint32_t hi = lo + SEG - 1 < NB ? lo + SEG - 1 : NB;
+  const uint32_t* bw = bucket + (size_t)w * NBP * PT_WORDS;
+  G1Jac run = g1_identity(), acc = g1_identity();
+  for (uint32_t b = hi; b >= lo; --b) {
+    run = g1_add(run, load_jac(bw + (size_t)b * PT_WORDS));
+    acc = g1_add(acc, run);
+  }
+  uint32_t m = lo - 1;  // < 2^15
+  if (m != 0 && !run.inf) {
+    G1Jac r = g1_identity();
+    for (int bit = 15; bit >= 0; --bit) {
+      r = g1_double(r);
+      if ((m >> bit) & 1) r = g1_add(r, run);
+    }
+    acc = g1_add(acc, r);
+  }
+  store_jac(segres + (size_t)idx * PT_WORDS, acc);
+}
+
+// K4b: one workgroup per window: strided serial sum then an LDS tree; lane 0 converts to the
+// external Jacobian format (12 x u64 + flag word).
+constexpr int WIN_THREADS = 256;
+__global__ __launch_bounds__(WIN_THREADS) void msm_reduce_windows_kernel(const uint32_t* __restrict__ segres,
+                                                                         uint32_t nseg, uint32_t* __restrict__ winres) {
+  __shared__ uint32_t tree[WIN_THREADS * PT_WORDS];
+  const uint32_t w = blockIdx.x, t = threadIdx.x;
+  const uint32_t* sw = segres + (size_t)w * nseg * PT_WORDS;
+  G1Jac acc = g1_identity();
+  for (uint32_t s = t; s < nseg; s += WIN_THREADS) acc = g1_add(acc, load_jac(sw + (size_t)s * PT_WORDS));
+  store_jac(tree + t * PT_WORDS, acc);
+  __syncthreads();
+  for (uint32_t off = WIN_THREADS / 2; off > 0; off >>= 1) {
+    if (t < off) {
+      const G1Jac a = load_jac(tree + t * PT_WORDS), b = load_jac(tree + (t + off) * PT_WORDS);
+      store_jac(tree + t * PT_WORDS, g1_add(a, b));
+    }
+    __syncthreads();
+  }
+  if (t == 0) {
+    const G1Jac r = load_jac(tree);
+    uint32_t* o = winres + (size_t)w * 32;
+    uint32_t wx[8], wy[8], wz[8];
+    if (r.inf) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) wx[k] = wy[k] = wz[k] = 0;
+    } else {
+      fe_to_ext(wx, r.x);
+      fe_to_ext(wy, r.y);
+      fe_to_ext(wz, r.z);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      o[k] = wx[k];
+      o[8 + k] = wy[k];
+      o[16 + k] = wz[k];
+    }
+    o[24] = r.inf ? 1u : 0u;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// fixed-base scalar multiplication (ParamsKZG::setup's G1 work; also builds the bench SRS)
+// out[i] = [k_i] B, affine external.  One lane per scalar: 4-bit fixed windows over a 64 x 15
+// table of multiples of B built by the first kernel; final inversion by Fermat per lane.
+// ---------------------------------------------------------------------------------------------
+__global__ void g1_fixed_table_kernel(const uint32_t* __restrict__ base_ext, uint32_t* __restrict__ table) {
+  // table[w][d-1] = [d * 16^w] B as Jacobian records, w < 64, d in 1..15.  One lane per window.
+  const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= 64) return;
+  uint32_t wx[8], wy[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { wx[k] = base_ext[k]; wy[k] = base_ext[8 + k]; }
+  G1Aff b;
+  b.x = fe_from_ext<FqParams>(wx);
+  b.y = fe_from_ext<FqParams>(wy);
+  G1Jac p = g1_from_affine(b);
+  for (uint32_t k = 0; k < 4 * w; ++k) p = g1_double(p);
+  G1Jac acc = p;
+  for (uint32_t d = 1; d <= 15; ++d) {
+    store_jac(table + ((size_t)w * 15 + (d - 1)) * PT_WORDS, acc);
+    acc = g1_add(acc, p);
+  }
+}
+
+__device__ __forceinline__ Fq fq_inverse(const Fq& a) {  // a^(p-2), a a product output
+  // exponent p - 2 in 29-bit limbs
+  uint32_t e[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) e[i] = FqParams::MOD[i];
+  e[0] -= 2;  // MOD[0] is odd and > 2: no borrow
+  Fq acc = fe_one<FqParams>();
+  for (int i = 8; i >= 0; --i) {
+    const int top = i == 8 ? 24 : 28;
+    for (int bit = top; bit >= 0; --bit) {
+      acc = fe_sqr(acc);
+      if ((e[i] >> bit) & 1) acc = fe_mul(acc, a);
+    }
+  }
+  return acc;
+}
+
+__global__ __launch_bounds__(ACC_THREADS) void g1_fixed_base_mul_kernel(const uint32_t* __restrict__ scalars,
+                                                                        const uint32_t* __restrict__ table,
+                                                                        uint32_t* __restrict__ out, size_t n) {
+  const size_t i = (size_t)blockIdx.x * ACC_THREADS + threadIdx.x;
+  if (i >= n) return;
+  const uint4* q = reinterpret_cast<const uint4*>(scalars + i * 8);
+  const uint4 lo = q[0], hi = q[1];
+  const uint32_t w_in[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+  Fr k32 = fe_zero<FrParams>();
+  k32.l[0] = 32;
+  uint32_t v[8];
+  fe_pack(v, fe_canonical(fe_mul(fe_unpack<FrParams>(w_in), k32)));
+  G1Jac acc = g1_identity();
+  for (uint32_t w = 0; w < 64; ++w) {
+    const uint32_t d = (v[w >> 3] >> ((w & 7) * 4)) & 15u;
+    if (d != 0) acc = g1_add(acc, load_jac(table + ((size_t)w * 15 + (d - 1)) * PT_WORDS));
+  }
+  uint32_t ox[8], oy[8];
+  if (acc.inf) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) ox[k] = oy[k] = 0;
+  } else {
+    const Fq zi = fq_inverse(acc.z);
+    const Fq zi2 = fe_sqr(zi);
+    const Fq zi3 = fe_mul(zi2, zi);
+    fe_to_ext(ox, fe_mul(acc.x, zi2));
+    fe_to_ext(oy, fe_mul(acc.y, zi3));
+  }
+  uint4* o = reinterpret_cast<uint4*>(out + i * 16);
+  o[0] = make_uint4(ox[0], ox[1], ox[2], ox[3]);
+  o[1] = make_uint4(ox[4], ox[5], ox[6], ox[7]);
+  o[2] = make_uint4(oy[0], oy[1], oy[2], oy[3]);
+  o[3] = make_uint4(oy[4], oy[5], oy[6], oy[7]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+int msm_convert_bases(const uint32_t* d_bases_ext, uint32_t* d_xy, uint8_t* d_inf, size_t n, hipStream_t stream) {
+  if (n == 0) return HM_OK;
+  hipLaunchKernelGGL(msm_convert_bases_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, stream, d_bases_ext, d_xy,
+                     d_inf, n);
+  HM_HIP_CHECK(hipGetLastError());
+  return HM_OK;
+}
+
+static uint32_t ilog2(size_t n) {
+  uint32_t l = 0;
+  while ((n >> (l + 1)) != 0) ++l;
+  return l;
+}
+
+// host-side Horner over the window sums and affine normalisation, on the same field code
+static void host_fold(const uint32_t* winres, uint32_t W, uint32_t c, uint64_t out_jac_ext[12], int* out_is_identity) {
+  G1Jac acc = g1_identity();
+  for (int w = (int)W - 1; w >= 0; --w) {
+    for (uint32_t k = 0; k < c; ++k) acc = g1_double(acc);
+    const uint32_t* o = winres + (size_t)w * 32;
+    if (o[24] == 0) {
+      uint32_t wx[8], wy[8], wz[8];
+      for (int k = 0; k < 8; ++k) { wx[k] = o[k]; wy[k] = o[8 + k]; wz[k] = o[16 + k]; }
+      G1Jac p;
+      p.x = fe_from_ext<FqParams>(wx);
+      p.y = fe_from_ext<FqParams>(wy);
+      p.z = fe_from_ext<FqParams>(wz);
+      p.inf = false;
+      acc = g1_add(acc, p);
+    }
+  }
+  if (acc.inf) {
+    std::memset(out_jac_ext, 0, 96);
+    *out_is_identity = 1;
+    return;
+  }
+  // z^-1 by Fermat on the host
+  uint32_t e[9];
+  for (int i = 0; i < 9; ++i) e[i] = FqParams::MOD[i];
+  e[0] -= 2;
+  Fq zi = fe_one<FqParams>();
+  for (int i = 8; i >= 0; --i) {
+    const int top = i == 8 ? 24 : 28;
+    for (int bit = top; bit >= 0; --bit) {
+      zi = fe_sqr(zi);
+      if ((e[i] >> bit) & 1) zi = fe_mul(zi, acc.z);
+    }
+  }
+  const Fq zi2 = fe_sqr(zi), zi3 = fe_mul(zi2, zi);
+  uint32_t ox[8], oy[8], oz[8];
+  fe_to_ext(ox, fe_mul(acc.x, zi2));
+  fe_to_ext(oy, fe_mul(acc.y, zi3));
+  fe_to_ext(oz, fe_one<FqParams>());
+  std::memcpy(out_jac_ext, ox, 32);
+  std::memcpy(out_jac_ext + 4, oy, 32);
+  std::memcpy(out_jac_ext + 8, oz, 32);
+  *out_is_identity = 0;
+}
+
+static int g_window_override = 0;
+void msm_set_window_override(int c) { g_window_override = c; }
+
+int msm_run(DeviceCtx& ctx, const uint32_t* d_scalars_ext, const uint32_t* d_xy, const uint8_t* d_inf, size_t n,
+            int c_override, uint64_t out_jac_ext[12], int* out_is_identity, hipStream_t stream) {
+  if (n == 0) {
+    std::memset(out_jac_ext, 0, 96);
+    *out_is_identity = 1;
+    return HM_OK;
+  }
+  if (n >= (1ull << 31)) return hm_fail(HM_ERR_BAD_ARG, "msm: n must be < 2^31");
+  // ---- plan ---------------------------------------------------------------------------------
+  int ci = c_override > 0 ? c_override : (g_window_override > 0 ? g_window_override : 0);
+  if (ci == 0) {
+    const int l2 = (int)ilog2(n);
+    ci = l2 - 6;
+    if (ci < 4) ci = 4;
+    if (ci > 16) ci = 16;
+  }
+  if (ci < 2 || ci > 16) return hm_fail(HM_ERR_BAD_ARG, "msm: window size must be in [2, 16]");
+  const uint32_t c = (uint32_t)ci;
+  const uint32_t W = (255 + c - 1) / c;
+  const uint32_t NB = 1u << (c - 1), NBP = NB + 1, NBT = W * NBP;
+  if ((uint64_t)n * W >= (1ull << 32)) return hm_fail(HM_ERR_BAD_ARG, "msm: n * windows must be < 2^32");
+  const double mean = (double)n / (double)NB;
+  uint32_t L = (uint32_t)(mean + 4.0 * std::sqrt(mean) + 8.0);
+  if (L < 16) L = 16;
+  uint32_t G = (uint32_t)((n + 16383) / 16384);
+  if (G < 1) G = 1;
+  if (G > 256) G = 256;
+  const size_t chunk = (n + G - 1) / G;
+  const uint64_t pairs_max = (uint64_t)n * W;
+  const uint64_t T_max = pairs_max / L + NBT + 1;
+  uint32_t SEG = 32;
+  if (SEG > NB) SEG = NB;
+  const uint32_t nseg = (NB + SEG - 1) / SEG;
+
+  // ---- workspace ----------------------------------------------------------------------------
+  auto align = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  size_t off = 0;
+  auto carve = [&](size_t bytes) { size_t o = off; off += align(bytes); return o; };
+  const size_t o_digits = carve((size_t)W * n * 4);
+  const size_t o_bh = carve((size_t)W * G * NBP * 4);
+  const size_t o_bcnt = carve((size_t)NBT * 4);
+  const size_t o_boff = carve((size_t)NBT * 4);
+  const size_t o_toff = carve(((size_t)NBT + 1) * 4);
+  const size_t o_tot = carve(16);
+  const size_t o_sorted = carve(pairs_max * 4);
+  const size_t o_tb = carve(T_max * 4);
+  const size_t o_partial = carve(T_max * PT_WORDS * 4);
+  const size_t o_bucket = carve((size_t)NBT * PT_WORDS * 4);
+  const size_t o_seg = carve((size_t)W * nseg * PT_WORDS * 4);
+  const size_t o_win = carve((size_t)W * 32 * 4);
+  uint8_t* ws = (uint8_t*)ctx.msm_ws.ensure(off);
+  if (!ws) return hm_fail(HM_ERR_HIP, "msm: workspace allocation failed");
+  int32_t* d_digits = (int32_t*)(ws + o_digits);
+  uint32_t* d_bh = (uint32_t*)(ws + o_bh);
+  uint32_t* d_bcnt = (uint32_t*)(ws + o_bcnt);
+  uint32_t* d_boff = (uint32_t*)(ws + o_boff);
+  uint32_t* d_toff = (uint32_t*)(ws + o_toff);
+  uint32_t* d_tot = (uint32_t*)(ws + o_tot);
+  uint32_t* d_sorted = (uint32_t*)(ws + o_sorted);
+  uint32_t* d_tb = (uint32_t*)(ws + o_tb);
+  uint32_t* d_partial = (uint32_t*)(ws + o_partial);
+  uint32_t* d_bucket = (uint32_t*)(ws + o_bucket);
+  uint32_t* d_seg = (uint32_t*)(ws + o_seg);
+  uint32_t* d_win = (uint32_t*)(ws + o_win);
+
+  static bool attr_set = false;
+  if (!attr_set) {
+    HM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(msm_hist_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 32769 * 4));
+    HM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(msm_scatter_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 32769 * 4));
+    attr_set = true;
+  }
+  hipEvent_t ev[5];
+  for (auto& e : ev) HM_HIP_CHECK(hipEventCreate(&e));
+  HM_HIP_CHECK(hipEventRecord(ev[0], stream));
+
+  // ---- K0 ------------------------------------------------------------------------------------
+  hipLaunchKernelGGL(msm_digits_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, stream, d_scalars_ext, d_inf,
+                     d_digits, n, c, W);
+  HM_HIP_CHECK(hipGetLastError());
+  HM_HIP_CHECK(hipEventRecord(ev[1], stream));
+
+  // ---- K2 ------------------------------------------------------------------------------------
+  const size_t lds_hist = (size_t)NBP * 4;
+  hipLaunchKernelGGL(msm_hist_kernel, dim3(G, W), dim3(SORT_THREADS), lds_hist, stream, (const int32_t*)d_digits, d_bh, n,
+                     chunk, NBP);
+  HM_HIP_CHECK(hipGetLastError());
+  hipLaunchKernelGGL(msm_scan_blocks_kernel, dim3((NBT + 255) / 256), dim3(256), 0, stream, d_bh, d_bcnt, G, NBP, W);
+  HM_HIP_CHECK(hipGetLastError());
+  hipLaunchKernelGGL(msm_scan_buckets_kernel, dim3(1), dim3(1024), 0, stream, (const uint32_t*)d_bcnt, d_boff, d_toff,
+                     d_tot, NBT, L);
+  HM_HIP_CHECK(hipGetLastError());
+  hipLaunchKernelGGL(msm_scatter_kernel, dim3(G, W), dim3(SORT_THREADS), lds_hist, stream, (const int32_t*)d_digits,
+                     (const uint32_t*)d_bh, (const uint32_t*)d_boff, d_sorted, n, chunk, NBP);
+  HM_HIP_CHECK(hipGetLastError());
+  hipLaunchKernelGGL(msm_task_fill_kernel, dim3((NBT + 255) / 256), dim3(256), 0, stream, (const uint32_t*)d_toff, d_tb,
+                     NBT);
+  HM_HIP_CHECK(hipGetLastError());
+  uint32_t totals[4] = {0, 0, 0, 0};
+  HM_HIP_CHECK(hipMemcpyAsync(totals, d_tot, 8, hipMemcpyDeviceToHost, stream));
+  HM_HIP_CHECK(hipEventRecord(ev[2], stream));
+  HM_HIP_CHECK(hipStreamSynchronize(stream));
+  const uint32_t T = totals[1];
+  if ((uint64_t)T > T_max) return hm_fail(HM_ERR_INTERNAL, "msm: task count exceeds its bound");
+
+  // ---- K3 ------------------------------------------------------------------------------------
+  if (T > 0) {
+    hipLaunchKernelGGL(msm_accumulate_kernel, dim3((T + ACC_THREADS - 1) / ACC_THREADS), dim3(ACC_THREADS), 0, stream,
+                       (const uint32_t*)d_sorted, (const uint32_t*)d_tb, (const uint32_t*)d_boff, (const uint32_t*)d_bcnt,
+                       (const uint32_t*)d_toff, d_xy, d_partial, T, L);
+    HM_HIP_CHECK(hipGetLastError());
+  }
+  hipLaunchKernelGGL(msm_bucket_finalize_kernel, dim3((NBT + ACC_THREADS - 1) / ACC_THREADS), dim3(ACC_THREADS), 0, stream,
+                     (const uint32_t*)d_partial, (const uint32_t*)d_toff, d_bucket, NBT);
+  HM_HIP_CHECK(hipGetLastError());
+  HM_HIP_CHECK(hipEventRecord(ev[3], stream));
+
+  // ---- K4 ------------------------------------------------------------------------------------
+  hipLaunchKernelGGL(msm_reduce_segments_kernel, dim3((W * nseg + ACC_THREADS - 1) / ACC_THREADS), dim3(ACC_THREADS), 0,
+                     stream, (const uint32_t*)d_bucket, d_seg, W, NB, NBP, SEG, nseg);
+  HM_HIP_CHECK(hipGetLastError());
+  hipLaunchKernelGGL(msm_reduce_windows_kernel, dim3(W), dim3(WIN_THREADS), 0, stream, (const uint32_t*)d_seg, nseg, d_win);
+  HM_HIP_CHECK(hipGetLastError());
+  std::vector<uint32_t> win((size_t)W * 32);
+  HM_HIP_CHECK(hipMemcpyAsync(win.data(), d_win, win.size() * 4, hipMemcpyDeviceToHost, stream));
+  HM_HIP_CHECK(hipEventRecord(ev[4], stream));
+  HM_HIP_CHECK(hipStreamSynchronize(stream));
+
+  host_fold(win.data(), W, c, out_jac_ext, out_is_identity);
+
+  float ms[4] = {0, 0, 0, 0}, total = 0;
+  for (int i = 0; i < 4; ++i) (void)hipEventElapsedTime(&ms[i], ev[i], ev[i + 1]);
+  (void)hipEventElapsedTime(&total, ev[0], ev[4]);
+  for (auto& e : ev) (void)hipEventDestroy(e);
+  ctx.last_msm.t_digits_ms = ms[0];
+  ctx.last_msm.t_sort_ms = ms[1];
+  ctx.last_msm.t_accum_ms = ms[2];
+  ctx.last_msm.t_reduce_ms = ms[3];
+  ctx.last_msm.t_total_ms = total;
+  ctx.last_msm.pairs = totals[0];
+  ctx.last_msm.tasks = T;
+  ctx.last_msm.c = c;
+  ctx.last_msm.windows = W;
+  return HM_OK;
+}
+
+int g1_fixed_base_mul_run(DeviceCtx& ctx, const uint32_t* d_scalars_ext, size_t n, const uint64_t base_affine_ext[8],
+                          uint32_t* d_out_affine_ext, hipStream_t stream) {
+  if (n == 0) return HM_OK;
+  uint8_t* sm = (uint8_t*)ctx.small.ensure(64 + (size_t)64 * 15 * PT_WORDS * 4);
+  if (!sm) return hm_fail(HM_ERR_HIP, "fixed-base: table allocation failed");
+  uint32_t* d_base = (uint32_t*)sm;
+  uint32_t* d_table = (uint32_t*)(sm + 64);
+  HM_HIP_CHECK(hipMemcpyAsync(d_base, base_affine_ext, 64, hipMemcpyHostToDevice, stream));
+  hipLaunchKernelGGL(g1_fixed_table_kernel, dim3(1), dim3(64), 0, stream, (const uint32_t*)d_base, d_table);
+  HM_HIP_CHECK(hipGetLastError());
+  hipLaunchKernelGGL(g1_fixed_base_mul_kernel, dim3((uint32_t)((n + ACC_THREADS - 1) / ACC_THREADS)), dim3(ACC_THREADS), 0,
+                     stream, d_scalars_ext, (const uint32_t*)d_table, d_out_affine_ext, n);
+  HM_HIP_CHECK(hipGetLastError());
+  return HM_OK;
+}
+
+}  // namespace hm

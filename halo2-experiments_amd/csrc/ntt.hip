@@ -1,0 +1,391 @@
+// ntt.hip -- radix-2 NTT over BN256 Fr for gfx950 (replaces halo2_proofs::arithmetic::best_fft,
+// natural order in, natural order out, unscaled, a'[j] = sum_i a[i] omega^(ij)).
+//
+// Structure (MI355X-first, not the reference's recursion): the 2^log_n transform is factored
+// into <= 3 digit passes  n = R0*R1*R2  (Cooley-Tukey "four-step" applied twice).  One workgroup
+// owns a tile of 2^LOG_TILE elements = R (the pass's digit, a full R-point sub-transform done
+// entirely in LDS with radix-2 DIT stages) x C adjacent columns (so every HBM access is a
+// C*32-byte contiguous segment).  The first pass reads `a` and writes the scratch buffer, the
+// middle pass works in place in scratch, the last pass reads scratch rows and writes `a` in
+// natural order (the digit reversal is folded into its store), canonicalising on the way out.
+// HBM traffic = passes * 64 B/element; there is no separate bit-reversal pass and no n/2-entry
+// twiddle table (the reference's is 256 MiB at 2^24): inter-pass twiddles come from two
+// sqrt(n)-sized tables (one extra product), stage twiddles from a <= 512-entry table.
+//
+// Field layer: ff29.h.  The NTT is linear in the data, so the reference's radix-2^256
+// Montgomery words are simply reinterpreted as internal-form values (of x/32) -- no conversion
+// on the way in or out; only omega and the twiddles are converted (once per (omega, log_n)).
+#include <hip/hip_runtime.h>
+
+#include "g1.h"
+#include "hm_internal.h"
+
+namespace hm {
+
+constexpr int NTT_THREADS = 256;
+
+// ---------------------------------------------------------------------------------------------
+// twiddle tables
+// ---------------------------------------------------------------------------------------------
+// out[j] = base^(j << shift), internal form, normalised, value < 2r.   9 x u32 per entry.
+__global__ void ntt_pow_table_kernel(const uint32_t* __restrict__ omega_ext, uint32_t* __restrict__ out,
+                                     uint32_t count, uint32_t shift) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= count) return;
+  uint32_t w[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) w[i] = omega_ext[i];
+  const Fr base = fe_from_ext<FrParams>(w);
+  const uint64_t e = (uint64_t)j << shift;
+  Fr acc = fe_one<FrParams>();
+  for (int bit = 40; bit >= 0; --bit) {
+    acc = fe_sqr(acc);
+    if ((e >> bit) & 1) acc = fe_mul(acc, base);
+  }
+#pragma unroll
+  for (int i = 0; i < 9; ++i) out[(size_t)j * 9 + i] = acc.l[i];
+}
+
+__device__ __forceinline__ Fr load_tw(const uint32_t* __restrict__ tab, uint32_t idx) {
+  Fr r;
+  const uint32_t* p = tab + (size_t)idx * 9;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) r.l[i] = p[i];
+  HM_DECLARE(r, 2.0);
+  return r;
+}
+
+// ---------------------------------------------------------------------------------------------
+// LDS tile helpers: structure-of-arrays, plane l holds limb l of every element of the tile
+// ---------------------------------------------------------------------------------------------
+template <int LOG_TILE>
+__device__ __forceinline__ Fr lds_load(const uint32_t* lds, uint32_t e) {
+  Fr r;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) r.l[i] = lds[(i << LOG_TILE) + e];
+  return r;
+}
+template <int LOG_TILE>
+__device__ __forceinline__ void lds_store(uint32_t* lds, uint32_t e, const Fr& a) {
+#pragma unroll
+  for (int i = 0; i < 9; ++i) lds[(i << LOG_TILE) + e] = a.l[i];
+}
+
+__device__ __forceinline__ uint32_t bitrev(uint32_t v, uint32_t bits) {
+  return bits == 0 ? 0u : (__brev(v) >> (32 - bits));
+}
+
+struct NttPassParams {
+  uint32_t log_n;        // transform size
+  uint32_t s;            // log2 of this pass's digit R
+  uint32_t log_stride;   // log2 of the element stride between consecutive digit values (non-last passes)
+  uint32_t log_c;        // log2 of the columns (non-last) / rows (last) per tile
+  uint32_t last;         // 1: stride-1 pass with the digit-reversing, canonicalising store
+  uint32_t log_r0;       // last pass of a 3-pass plan: log2 R0 (else 0)
+  uint32_t log_rows;     // last pass: log2 of the number of rows = log_n - s
+  uint32_t log_lb;       // split point of the two-level inter-pass twiddle table
+  uint32_t has_scale;    // last pass: multiply by `scale` (internal-form constant) instead of ONE
+  uint32_t has_coset;    // first pass: multiply a[i] by coset[i % 3] on load
+};
+
+// One digit pass.  in/out: n x 8 u32 (external words).  stage_tw: omega_R^j, j < R/2.
+// tw_lo/tw_hi: omega_n^j (j < 2^log_lb) and omega_n^(j << log_lb).
+template <int LOG_TILE>
+__global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(const uint32_t* in, uint32_t* out,
+                                                               NttPassParams pp, const uint32_t* __restrict__ stage_tw,
+                                                               const uint32_t* __restrict__ tw_lo,
+                                                               const uint32_t* __restrict__ tw_hi,
+                                                               const uint32_t* __restrict__ scale_int,
+                                                               const uint32_t* __restrict__ coset_int) {
+  extern __shared__ uint32_t lds[];
+  const uint32_t tid = threadIdx.x;
+  const uint32_t s = pp.s, log_c = pp.log_c;
+  const uint32_t tile_elems = 1u << (s + log_c);  // <= 2^LOG_TILE
+  const uint32_t cmask = (1u << log_c) - 1u;
+  const uint64_t tile = blockIdx.x;
+
+  // ---- tile -> global index mapping ---------------------------------------------------------
+  // non-last: element (d, c) lives at  o*m + d*stride + i0 + c        (m = R*stride)
+  // last    : element (d, c) lives at  row(c)*R + d, row(c) = digit-reversed (dest_lo0 + c)
+  uint64_t base = 0;      // non-last: o*m + i0
+  uint32_t i0 = 0;        // non-last: first column (for the twiddle exponent)
+  uint64_t dest_lo0 = 0;  // last: first destination low index
+  if (!pp.last) {
+    const uint32_t log_tiles_per_block = pp.log_stride - log_c;
+    const uint64_t o = tile >> log_tiles_per_block;
+    i0 = (uint32_t)(tile & ((1ull << log_tiles_per_block) - 1ull)) << log_c;
+    base = (o << (s + pp.log_stride)) + i0;
+  } else {
+    dest_lo0 = tile << log_c;
+  }
+  auto row_of = [&](uint32_t c) -> uint64_t {  // last pass only
+    const uint64_t dl = dest_lo0 + c;
+    if (pp.log_r0 == 0) return dl;                       // 1- or 2-pass plan: row = k0 = dest_lo
+    const uint64_t k0 = dl & ((1ull << pp.log_r0) - 1ull);  // dest_lo = k0 + R0*k1
+    const uint64_t k1 = dl >> pp.log_r0;
+    return (k0 << (pp.log_rows - pp.log_r0)) + k1;       // row = k0*R1 + k1
+  };
+
+  // ---- load: unpack to 29-bit limbs, scatter to the bit-reversed digit position -------------
+  for (uint32_t e = tid; e < tile_elems; e += NTT_THREADS) {
+    uint32_t d, c;
+    uint64_t g;
+    if (!pp.last) {
+      c = e & cmask;
+      d = e >> log_c;
+      g = base + ((uint64_t)d << pp.log_stride) + c;
+    } else {
+      d = e & ((1u << s) - 1u);
+      c = e >> s;
+      g = (row_of(c) << s) + d;
+    }
+    const uint4* src = reinterpret_cast<const uint4*>(in + g * 8);
+    const uint4 lo = src[0], hi = src[1];
+    const uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    Fr x = fe_unpack<FrParams>(w);
+    if (pp.has_coset) {
+      Fr cz;
+      const uint32_t* cp = coset_int + (uint32_t)(g % 3) * 9;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) cz.l[i] = cp[i];
+      HM_DECLARE(cz, 2.0);
+      x = fe_mul(x, cz);
+    }
+    lds_store<LOG_TILE>(lds, (bitrev(d, s) << log_c) + c, x);
+  }
+  __syncthreads();
+
+  // ---- R-point DIT over the digit, all columns of the tile at once ---------------------------
+  // stage q pairs positions (p, p + 2^q); twiddle omega_R^((p mod 2^q) << (s-1-q))
+  const uint32_t nbf = tile_elems >> 1;
+  for (uint32_t q = 0; q < s; ++q) {
+    const uint32_t log_h = q + log_c;  // butterfly distance in tile elements = 2^q * C
+    const uint32_t hmask = (1u << log_h) - 1u;
+    for (uint32_t b = tid; b < nbf; b += NTT_THREADS) {
+      const uint32_t lo = b & hmask;
+      const uint32_t e0 = ((b >> log_h) << (log_h + 1)) + lo;
+      const uint32_t e1 = e0 + (1u << log_h);
+      const Fr a = lds_load<LOG_TILE>(lds, e0);
+      Fr t = lds_load<LOG_TILE>(lds, e1);
+      if (q != 0) {
+        const uint32_t j = (lo >> log_c) << (s - 1 - q);
+        t = fe_mul(t, load_tw(stage_tw, j));
+      }
+      lds_store<LOG_TILE>(lds, e0, fe_norm(fe_add(a, t)));
+      // t is a product output (< 2r) except in stage 0, where it is a raw input (< 2^256 < 6r)
+      lds_store<LOG_TILE>(lds, e1, fe_norm(fe_sub<6, 29>(a, t)));
+    }
+    __syncthreads();
+  }
+
+  // ---- store ---------------------------------------------------------------------------------
+  if (!pp.last) {
+    const uint32_t shift_m = pp.log_n - (s + pp.log_stride);  // omega_m = omega_n^(2^shift_m)
+    const uint32_t lbmask = (1u << pp.log_lb) - 1u;
+    for (uint32_t e = tid; e < tile_elems; e += NTT_THREADS) {
+      const uint32_t c = e & cmask, k = e >> log_c;
+      Fr y = lds_load<LOG_TILE>(lds, e);
+      const uint64_t ex = ((uint64_t)(i0 + c) * k) << shift_m;  // < n
+      const uint32_t elo = (uint32_t)ex & lbmask, ehi = (uint32_t)(ex >> pp.log_lb);
+      Fr tw = load_tw(tw_hi, ehi);
+      if (elo != 0) tw = fe_mul(tw, load_tw(tw_lo, elo));
+      y = fe_mul(y, tw);  // product output: normalised, < 2r < 2^256
+      uint32_t w[8];
+      fe_pack(w, y);
+      uint4* dst = reinterpret_cast<uint4*>(out + (base + ((uint64_t)k << pp.log_stride) + c) * 8);
+      dst[0] = make_uint4(w[0], w[1], w[2], w[3]);
+      dst[1] = make_uint4(w[4], w[5], w[6], w[7]);
+    }
+  } else {
+    Fr fin;
+    if (pp.has_scale) {
+#pragma unroll
+      for (int i = 0; i < 9; ++i) fin.l[i] = scale_int[i];
+      HM_DECLARE(fin, 2.0);
+    } else {
+      fin = fe_one<FrParams>();
+    }
+    for (uint32_t e = tid; e < tile_elems; e += NTT_THREADS) {
+      const uint32_t c = e & cmask, k = e >> log_c;
+      Fr y = lds_load<LOG_TILE>(lds, (k << log_c) + c);  // position (digit k, row c) -- same index e
+      y = fe_canonical(fe_mul(y, fin));
+      uint32_t w[8];
+      fe_pack(w, y);
+      const uint64_t g = (dest_lo0 + c) + ((uint64_t)k << pp.log_rows);
+      uint4* dst = reinterpret_cast<uint4*>(out + g * 8);
+      dst[0] = make_uint4(w[0], w[1], w[2], w[3]);
+      dst[1] = make_uint4(w[4], w[5], w[6], w[7]);
+    }
+  }
+}
+
+// element-wise a[i] *= c (external canonical in/out); used by the domain helpers
+__global__ void fr_scale_kernel(uint32_t* __restrict__ a, const uint32_t* __restrict__ c_ext, uint64_t n) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t cw[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) cw[k] = c_ext[k];
+  // c_int = c * 2^261; a_ext * c_int * 2^-261 = (a*c) in external form
+  const Fr c_int = fe_from_ext<FrParams>(cw);
+  uint4* p = reinterpret_cast<uint4*>(a + i * 8);
+  const uint4 lo = p[0], hi = p[1];
+  const uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+  Fr y = fe_canonical(fe_mul(fe_unpack<FrParams>(w), c_int));
+  uint32_t o[8];
+  fe_pack(o, y);
+  p[0] = make_uint4(o[0], o[1], o[2], o[3]);
+  p[1] = make_uint4(o[4], o[5], o[6], o[7]);
+}
+
+// a[i] *= c3[i % 3] (EvaluationDomain::distribute_powers_zeta); c3: 3 external constants
+__global__ void fr_mul_pattern3_kernel(uint32_t* a, const uint32_t* __restrict__ c3_ext, uint64_t n) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t cw[8];
+  const uint32_t* cp = c3_ext + (uint32_t)(i % 3) * 8;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) cw[k] = cp[k];
+  const Fr c_int = fe_from_ext<FrParams>(cw);
+  uint4* p = reinterpret_cast<uint4*>(a + i * 8);
+  const uint4 lo = p[0], hi = p[1];
+  const uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+  Fr y = fe_canonical(fe_mul(fe_unpack<FrParams>(w), c_int));
+  uint32_t o[8];
+  fe_pack(o, y);
+  p[0] = make_uint4(o[0], o[1], o[2], o[3]);
+  p[1] = make_uint4(o[4], o[5], o[6], o[7]);
+}
+
+// c_ext (external canonical) -> 9-limb internal form, for scale / coset constants
+__global__ void fr_ext_to_int_kernel(const uint32_t* __restrict__ c_ext, uint32_t* __restrict__ out, uint32_t count) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= count) return;
+  uint32_t w[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) w[i] = c_ext[j * 8 + i];
+  const Fr x = fe_from_ext<FrParams>(w);
+#pragma unroll
+  for (int i = 0; i < 9; ++i) out[j * 9 + i] = x.l[i];
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side: plan + launch
+// ---------------------------------------------------------------------------------------------
+constexpr int LOG_TILE = 11;
+
+static int plan_digits(uint32_t log_n, uint32_t digits[3]) {
+  if (log_n <= (uint32_t)LOG_TILE) {
+    digits[0] = log_n;
+    return 1;
+  }
+  const int passes = log_n <= 16 ? 2 : 3;
+  uint32_t rem = log_n;
+  for (int p = 0; p < passes; ++p) {
+    digits[p] = (rem + (passes - p) - 1) / (passes - p);
+    rem -= digits[p];
+  }
+  return passes;
+}
+
+NttTables* ntt_get_tables(DeviceCtx& ctx, const uint64_t omega_ext[4], uint32_t log_n, hipStream_t stream) {
+  for (auto& t : ctx.ntt_tables)
+    if (t->log_n == log_n && std::memcmp(t->omega, omega_ext, 32) == 0) return t.get();
+  auto t = std::make_unique<NttTables>();
+  t->log_n = log_n;
+  std::memcpy(t->omega, omega_ext, 32);
+  uint32_t digits[3] = {0, 0, 0};
+  const int passes = plan_digits(log_n, digits);
+  t->log_lb = (log_n + 1) / 2;
+  HM_HIP_CHECK_PTR(hipMalloc(&t->d_omega, 32));
+  HM_HIP_CHECK_PTR(hipMemcpyAsync(t->d_omega, omega_ext, 32, hipMemcpyHostToDevice, stream));
+  auto make = [&](uint32_t count, uint32_t shift, uint32_t** dst) -> bool {
+    if (hipMalloc(dst, (size_t)count * 36) != hipSuccess) return false;
+    hipLaunchKernelGGL(ntt_pow_table_kernel, dim3((count + 127) / 128), dim3(128), 0, stream,
+                       (const uint32_t*)t->d_omega, *dst, count, shift);
+    return hipGetLastError() == hipSuccess;
+  };
+  if (passes > 1) {
+    if (!make(1u << t->log_lb, 0, &t->d_lo)) return nullptr;
+    if (!make(1u << (log_n - t->log_lb), t->log_lb, &t->d_hi)) return nullptr;
+  }
+  for (int p = 0; p < passes; ++p) {
+    const uint32_t s = digits[p];
+    if (t->d_stage[s] == nullptr) {
+      const uint32_t count = s == 0 ? 1 : (1u << (s - 1));
+      if (!make(count == 0 ? 1 : count, log_n - s, &t->d_stage[s])) return nullptr;
+    }
+  }
+  ctx.ntt_tables.push_back(std::move(t));
+  return ctx.ntt_tables.back().get();
+}
+
+// d_a: n x 32 B device buffer, transformed in place.  d_scale_int / d_coset_int: optional 9-limb
+// internal-form constants already on the device.
+int ntt_run(DeviceCtx& ctx, uint32_t* d_a, const uint64_t omega_ext[4], uint32_t log_n, const uint32_t* d_scale_int,
+            const uint32_t* d_coset_int, hipStream_t stream) {
+  if (log_n > 28) return hm_fail(HM_ERR_BAD_ARG, "ntt: log_n > 28 (Fr has 2-adicity 28)");
+  NttTables* tab = ntt_get_tables(ctx, omega_ext, log_n, stream);
+  if (!tab) return hm_fail(HM_ERR_HIP, "ntt: twiddle table allocation failed");
+  uint32_t digits[3] = {0, 0, 0};
+  const int passes = plan_digits(log_n, digits);
+  const uint64_t n = 1ull << log_n;
+  uint32_t* scratch = nullptr;
+  if (passes > 1) {
+    scratch = (uint32_t*)ctx.ensure_scratch(n * 32);
+    if (!scratch) return hm_fail(HM_ERR_HIP, "ntt: scratch allocation failed");
+  }
+  const size_t lds_bytes = (size_t)9 * sizeof(uint32_t) << LOG_TILE;
+  static bool attr_set = false;
+  if (!attr_set) {
+    HM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ntt_pass_kernel<LOG_TILE>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    attr_set = true;
+  }
+  uint32_t log_stride = log_n;
+  for (int p = 0; p < passes; ++p) {
+    NttPassParams pp{};
+    pp.log_n = log_n;
+    pp.s = digits[p];
+    log_stride -= digits[p];
+    pp.log_stride = log_stride;
+    pp.last = (p == passes - 1) ? 1u : 0u;
+    pp.log_lb = tab->log_lb;
+    pp.log_rows = log_n - pp.s;
+    pp.log_r0 = (pp.last && passes == 3) ? digits[0] : 0u;
+    pp.has_scale = (pp.last && d_scale_int) ? 1u : 0u;
+    pp.has_coset = (p == 0 && d_coset_int) ? 1u : 0u;
+    uint32_t log_c = (uint32_t)LOG_TILE > pp.s ? (uint32_t)LOG_TILE - pp.s : 0u;
+    const uint32_t avail = pp.last ? pp.log_rows : pp.log_stride;  // columns / rows that exist
+    if (log_c > avail) log_c = avail;
+    pp.log_c = log_c;
+    const uint64_t tiles = n >> (pp.s + log_c);
+    const uint32_t* src = (p == 0) ? d_a : scratch;
+    uint32_t* dst = (p == passes - 1) ? d_a : scratch;
+    hipLaunchKernelGGL(ntt_pass_kernel<LOG_TILE>, dim3((uint32_t)tiles), dim3(NTT_THREADS), lds_bytes, stream, src, dst, pp,
+                       (const uint32_t*)tab->d_stage[pp.s], (const uint32_t*)tab->d_lo, (const uint32_t*)tab->d_hi,
+                       d_scale_int, d_coset_int);
+    HM_HIP_CHECK(hipGetLastError());
+  }
+  return HM_OK;
+}
+
+int fr_scale_run(uint32_t* d_a, const uint32_t* d_c_ext, uint64_t n, hipStream_t stream) {
+  hipLaunchKernelGGL(fr_scale_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, stream, d_a, d_c_ext, n);
+  HM_HIP_CHECK(hipGetLastError());
+  return HM_OK;
+}
+
+int fr_mul_pattern3_run(uint32_t* d_a, const uint32_t* d_c3_ext, uint64_t n, hipStream_t stream) {
+  hipLaunchKernelGGL(fr_mul_pattern3_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, stream, d_a, d_c3_ext, n);
+  HM_HIP_CHECK(hipGetLastError());
+  return HM_OK;
+}
+
+int fr_ext_to_int_run(const uint32_t* d_c_ext, uint32_t* d_out, uint32_t count, hipStream_t stream) {
+  hipLaunchKernelGGL(fr_ext_to_int_kernel, dim3((count + 63) / 64), dim3(64), 0, stream, d_c_ext, d_out, count);
+  HM_HIP_CHECK(hipGetLastError());
+  return HM_OK;
+}
+
+}  // namespace hm

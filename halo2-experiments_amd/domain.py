@@ -1,0 +1,103 @@
+"""Host-side mirror of ``halo2_proofs::poly::EvaluationDomain`` for BN256 Fr -- the steps either
+side of every ``best_fft`` call in ``create_proof`` (upstream
+``halo2_proofs/src/poly/domain.rs`` at the tag pinned by /root/reference/Cargo.toml:10):
+
+    new(j, k)             extended_k = smallest e with 2^e >= 2^k * (j - 1); omega, extended_omega,
+                          g_coset = ZETA, ifft divisors
+    lagrange_to_coeff(a)  ifft(a, omega_inv, k, 1/n)
+    coeff_to_extended(a)  zero-pad to 2^extended_k, a[i] *= {1, zeta, zeta^2}[i % 3], best_fft(extended_omega)
+    extended_to_coeff(a)  ifft(extended), a[i] *= {1, zeta^-1, zeta^-2}[i % 3], truncate to n*(j-1)
+
+The scale-by-divisor and the coset shift are fused into the last / first NTT pass on the GPU.
+Arrays are GPU tensors (int64 views of 4-limb Montgomery words); constants are derived here with
+Python integers from the field's definition.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from .arithmetic import _ptr, _stream_ptr, _tensor_rows
+
+FR_MODULUS = 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001
+FR_S = 28
+FR_GENERATOR = 7
+FR_ROOT_OF_UNITY = pow(FR_GENERATOR, (FR_MODULUS - 1) >> FR_S, FR_MODULUS)
+FR_ZETA = 0x30644E72E131A029048B6E193FD84104CC37A73FEC2BC5E9B8CA0B2D36636F23
+_MONT = 1 << 256
+
+
+def fr_words(v: int) -> np.ndarray:
+    """Canonical integer -> 4 Montgomery limbs (the bytes Rust's ``Fr`` holds)."""
+    m = (v % FR_MODULUS) * _MONT % FR_MODULUS
+    return np.array([(m >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)], dtype=np.uint64)
+
+
+class EvaluationDomain:
+    def __init__(self, j: int, k: int):
+        if j < 2:
+            raise ValueError("EvaluationDomain: j (max degree) must be >= 2")
+        self.k = k
+        self.n = 1 << k
+        self.quotient_poly_degree = j - 1
+        extended_k = k
+        while (1 << extended_k) < self.n * self.quotient_poly_degree:
+            extended_k += 1
+        if extended_k > FR_S:
+            raise ValueError("EvaluationDomain: extended_k exceeds the field's two-adicity")
+        self.extended_k = extended_k
+        r = FR_MODULUS
+        self.extended_omega = pow(FR_ROOT_OF_UNITY, 1 << (FR_S - extended_k), r)
+        self.extended_omega_inv = pow(self.extended_omega, -1, r)
+        self.omega = pow(self.extended_omega, 1 << (extended_k - k), r)
+        self.omega_inv = pow(self.omega, -1, r)
+        self.g_coset = FR_ZETA
+        self.g_coset_inv = FR_ZETA * FR_ZETA % r
+        self.ifft_divisor = pow(self.n, -1, r)
+        self.extended_ifft_divisor = pow(1 << extended_k, -1, r)
+
+    # -- helpers ------------------------------------------------------------------------------
+    def extended_len(self) -> int:
+        return 1 << self.extended_k
+
+    def _ifft(self, a, omega_inv: int, log_n: int, divisor: int) -> None:
+        n = _tensor_rows(a, 4, "a")
+        if n != 1 << log_n:
+            raise ValueError("ifft: a.len() != 1 << log_n")
+        _lib.check(_lib.load().hm_ifft_bn256_fr_dev(ctypes.c_void_p(a.data_ptr()), _ptr(fr_words(omega_inv)), log_n,
+                                                     _ptr(fr_words(divisor)), ctypes.c_void_p(_stream_ptr(a))))
+
+    # -- the reference's methods --------------------------------------------------------------
+    def lagrange_to_coeff(self, a):
+        """In place on a (n, 4) GPU tensor; returns it."""
+        self._ifft(a, self.omega_inv, self.k, self.ifft_divisor)
+        return a
+
+    def coeff_to_extended(self, a):
+        """(n, 4) coefficient tensor -> new (2^extended_k, 4) tensor of evaluations on the zeta-coset."""
+        import torch
+
+        n = _tensor_rows(a, 4, "a")
+        if n != self.n:
+            raise ValueError("coeff_to_extended: a.len() != n")
+        ext = torch.zeros((self.extended_len(), 4), dtype=a.dtype, device=a.device)
+        ext[:n] = a.reshape(n, 4)
+        r = FR_MODULUS
+        coset = np.concatenate([fr_words(1), fr_words(self.g_coset), fr_words(self.g_coset * self.g_coset % r)])
+        _lib.check(_lib.load().hm_coset_ntt_bn256_fr_dev(ctypes.c_void_p(ext.data_ptr()), _ptr(fr_words(self.extended_omega)),
+                                                          self.extended_k, _ptr(coset), ctypes.c_void_p(_stream_ptr(ext))))
+        return ext
+
+    def extended_to_coeff(self, a):
+        """In place on a (2^extended_k, 4) tensor; returns the first n*(j-1) rows (a view)."""
+        n = _tensor_rows(a, 4, "a")
+        if n != self.extended_len():
+            raise ValueError("extended_to_coeff: a.len() != extended_len()")
+        self._ifft(a, self.extended_omega_inv, self.extended_k, self.extended_ifft_divisor)
+        r = FR_MODULUS
+        c3 = np.concatenate([fr_words(1), fr_words(self.g_coset_inv), fr_words(self.g_coset_inv * self.g_coset_inv % r)])
+        _lib.check(_lib.load().hm_fr_distribute_powers_dev(ctypes.c_void_p(a.data_ptr()), n, _ptr(c3),
+                                                            ctypes.c_void_p(_stream_ptr(a))))
+        return a.reshape(n, 4)[: self.n * self.quotient_poly_degree]

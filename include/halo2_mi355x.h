@@ -1,0 +1,126 @@
+/*
+ * halo2_mi355x.h -- C ABI of libhalo2_mi355x.so: the MI355X (gfx950) backend for the two
+ * arithmetic kernels that dominate halo2_proofs::plonk::create_proof under KZG on BN256.
+ *
+ * What it replaces.  The reference (summa-dev/halo2-experiments) reaches this path only through
+ * full_prover (/root/reference/src/circuits/utils.rs:22-70: ParamsKZG::setup :28, keygen_vk :31,
+ * keygen_pk :35, create_proof :40-48), which runs the free functions of the halo2_proofs crate
+ * pinned at /root/reference/Cargo.toml:10 (git tag v2023_02_02; source not vendored):
+ *
+ *     pub fn best_multiexp<C: CurveAffine>(coeffs: &[C::Scalar], bases: &[C]) -> C::Curve
+ *     pub fn best_fft<G: Group>(a: &mut [G], omega: G::Scalar, log_n: u32)
+ *
+ * instantiated with C = bn256::G1Affine and G = bn256::Fr.  Those crates have no FFI; the
+ * boundary below is what a `[patch]`-ed halo2_proofs::arithmetic would bind (INTEGRATION.md
+ * shows the Rust side).  Each entry point names the upstream function it stands in for.
+ *
+ * Memory formats (halo2curves bn256) -- exactly the bytes Rust holds:
+ *   Fr / Fq   4 x u64 little-endian limbs, Montgomery form (v * 2^256 mod m), fully reduced
+ *   G1Affine  { x: Fq, y: Fq } = 8 x u64; the identity is (0, 0)
+ *   G1        Jacobian { x, y, z: Fq } = 12 x u64; the identity has z = 0
+ *
+ * Conventions: every function returns HM_OK (0) or a negative HM_ERR_* code and never aborts or
+ * throws across the boundary; hm_last_error() returns the message of the calling thread's last
+ * failure.  Pointers are borrowed for the duration of the call only.  Calls are thread-safe (one
+ * lock per device).  There is no CPU fallback inside this library: without a usable gfx950
+ * device every compute entry point fails with HM_ERR_NO_DEVICE.
+ */
+#ifndef HALO2_MI355X_H
+#define HALO2_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HM_OK 0
+#define HM_ERR_BAD_ARG (-1)
+#define HM_ERR_NO_DEVICE (-2)
+#define HM_ERR_HIP (-3)
+#define HM_ERR_NOT_FOUND (-4)
+#define HM_ERR_INTERNAL (-5)
+
+/* ---- lifecycle ---------------------------------------------------------------------------- */
+
+/* Select the HIP device this thread's subsequent calls use (default: the current HIP device).
+ * One process per GPU is the intended deployment; a single process may also drive several. */
+int hm_set_device(int device);
+/* Number of visible HIP devices (0 when there is none); never fails. */
+int hm_device_count(void);
+/* Free every device buffer, twiddle table and registered base set of the current device. */
+int hm_shutdown(void);
+/* Message of the last failure on the calling thread ("" if none). */
+const char* hm_last_error(void);
+/* Library version string. */
+const char* hm_version(void);
+
+/* ---- MSM: stands in for halo2_proofs::arithmetic::best_multiexp::<bn256::G1Affine> --------- */
+
+/* sum_i scalars[i] * bases[i].  scalars: n x 4 u64 (Fr), bases: n x 8 u64 (G1Affine), both host
+ * memory.  Result as an affine point (out_xy, Montgomery) plus an identity flag, which is the
+ * canonical form of the G1 value best_multiexp returns; n == 0 yields the identity.
+ * The converted base array is cached on the device keyed by (pointer, n, content probe), because
+ * create_proof passes the same params.g / params.g_lagrange slices to every commitment. */
+int hm_msm_bn256_g1(const uint64_t* scalars, const uint64_t* bases, size_t n, uint64_t out_xy[8], int* out_is_identity);
+
+/* Same, Jacobian output (x, y, 1) / (0, 0, 0): the `C::Curve` value itself. */
+int hm_msm_bn256_g1_jacobian(const uint64_t* scalars, const uint64_t* bases, size_t n, uint64_t out_xyz[12]);
+
+/* Device-resident base sets (ParamsKZG::g / g_lagrange live for the whole proof):
+ * upload + convert once, then run MSMs against bases[offset .. offset + n). */
+int hm_register_bases(const uint64_t* bases, size_t n, uint64_t* out_handle);
+int hm_release_bases(uint64_t handle);
+int hm_msm_bn256_g1_h(uint64_t handle, size_t offset, const uint64_t* scalars, size_t n, uint64_t out_xy[8],
+                      int* out_is_identity);
+
+/* Device-pointer forms (inputs already in HBM; `stream` is a hipStream_t or NULL).  The result is
+ * written to host memory, so the call synchronises `stream` before returning. */
+int hm_register_bases_dev(const void* d_bases, size_t n, void* stream, uint64_t* out_handle);
+int hm_msm_bn256_g1_dev(uint64_t handle, size_t offset, const void* d_scalars, size_t n, void* stream,
+                        uint64_t out_xyz[12]);
+
+/* Window-size override for experiments (0 = automatic). */
+int hm_msm_set_window(int c);
+
+/* ---- NTT: stands in for halo2_proofs::arithmetic::best_fft::<bn256::Fr> --------------------- */
+
+/* In place on host memory: a[j] <- sum_i a[i] * omega^(i*j), natural order in and out, unscaled.
+ * a: 2^log_n x 4 u64 (Fr); omega: 4 u64 (Fr), a 2^log_n-th root of unity; log_n <= 28. */
+int hm_ntt_bn256_fr(uint64_t* a, const uint64_t omega[4], uint32_t log_n);
+
+/* Device-pointer form, in place, asynchronous on `stream`. */
+int hm_ntt_bn256_fr_dev(void* d_a, const uint64_t omega[4], uint32_t log_n, void* stream);
+
+/* ---- next rows: the EvaluationDomain steps either side of best_fft ----------- */
+
+/* EvaluationDomain::ifft: best_fft(a, omega_inv, log_n) then a[i] *= divisor, with the scaling
+ * fused into the last NTT pass.  Device pointers, in place. */
+int hm_ifft_bn256_fr_dev(void* d_a, const uint64_t omega_inv[4], uint32_t log_n, const uint64_t divisor[4], void* stream);
+/* EvaluationDomain::coeff_to_extended's arithmetic: a[i] *= coset[i % 3] (distribute_powers_zeta
+ * with coset = {1, g, g^2}) fused into the first pass of best_fft(a, omega_ext, log_n).
+ * The caller has already zero-padded a to 2^log_n. */
+int hm_coset_ntt_bn256_fr_dev(void* d_a, const uint64_t omega[4], uint32_t log_n, const uint64_t coset[12], void* stream);
+/* a[i] *= c element-wise (device pointer, in place). */
+int hm_fr_scale_dev(void* d_a, size_t n, const uint64_t c[4], void* stream);
+/* EvaluationDomain::distribute_powers_zeta on its own: a[i] *= c3[i % 3] (device pointer, in place). */
+int hm_fr_distribute_powers_dev(void* d_a, size_t n, const uint64_t c3[12], void* stream);
+
+/* ParamsKZG::setup's G1 work: out[i] = [scalars[i]] * base (fixed-base), affine output.
+ * scalars: n x 4 u64 device; out: n x 8 u64 device. */
+int hm_g1_fixed_base_mul_dev(const void* d_scalars, size_t n, const uint64_t base_xy[8], void* d_out_xy, void* stream);
+
+/* ---- introspection --------------------------------------------------------------------------- */
+
+typedef struct hm_msm_stats {
+  double digits_ms, sort_ms, accumulate_ms, reduce_ms, total_ms; /* hipEvent times of the last MSM */
+  uint64_t pairs, tasks;                                         /* non-zero digits, accumulation tasks */
+  uint32_t window_bits, windows;
+} hm_msm_stats;
+int hm_get_msm_stats(hm_msm_stats* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HALO2_MI355X_H */
