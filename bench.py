@@ -1,0 +1,213 @@
+#!/usr/bin/env python3
+"""bench.py -- BN256 G1 MSM throughput on MI355X (BASELINE.json metric), one process per GPU.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one best_multiexp over the global array: every rank runs the MSM of its index-range
+shard (2^24 points per GPU, inputs resident in HBM before the timed region), the 96-byte partial
+results are all-gathered over RCCL and folded on every rank.  Weak scaling: N=1 is the north
+star's 2^24 headline, N=4 is BASELINE config 5's 2^26.  Rank 0 prints ONE JSON line.
+
+Extra objects on that line:
+  roofline      dominant kernel = msm_accumulate_kernel; achieved = 96 B/point (SURVEY.md §8d:
+                32 B scalar + 64 B affine base, each read once) x points per launch / the
+                launch's duration from HIP events on its own stream (hm_get_msm_stats).
+  ntt           2^24 Fr NTT on one GPU (64 B/element algorithmic), same treatment.
+  cpu_baseline  oracle/cpu_ref.c (C restatement of halo2_proofs v2023_02_02's best_multiexp) timed
+                on this box's host cores on a bounded sample of the same workload (rank 0, N=1).
+The oracle is used for nothing else here.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+MSM_BYTES_PER_POINT = 96
+NTT_BYTES_PER_ELEM = 64
+
+
+def rand_fr(n, seed, device):
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    x = torch.randint(-(2 ** 63), 2 ** 63 - 1, (n, 4), dtype=torch.int64, device=device, generator=g)
+    x[:, 3] &= 0x0FFFFFFFFFFFFFFF      # < 2^252 < r: uniform fully-reduced Montgomery words
+    return x
+
+
+def fq_mont_words(v):
+    p = 0x30644E72E131A029B85045B68181585D97816A916871CA8D3C208C16D87CFD47
+    m = v * (1 << 256) % p
+    return [(m >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)]
+
+
+def cpu_baseline(log_sample, device):
+    """Time the oracle's best_multiexp on a bounded sample (the only use of oracle/ in this file)."""
+    import halo2_experiments_amd as h
+    from oracle import cpu_ref
+    cpu_ref.build()
+    n = 1 << log_sample
+    gen = np.array(fq_mont_words(1) + fq_mont_words(2), dtype=np.uint64)
+    bases = h.g1_fixed_base_mul(rand_fr(n, 4242, device), gen).cpu().numpy().view(np.uint64)
+    scalars = rand_fr(n, 4243, device).cpu().numpy().view(np.uint64)
+    threads = min(cpu_ref.default_threads(), 64)
+    t0 = time.perf_counter()
+    ref = cpu_ref.best_multiexp(scalars, bases, threads)
+    dt = time.perf_counter() - t0
+    got = h.best_multiexp(scalars, bases)
+    ok = bool(np.array_equal(cpu_ref.g1_to_affine(ref)[0], got[:8]))
+    return {"value": n / dt, "unit": "points/s", "cores": threads, "kind": "port",
+            "sample": f"one 2^{log_sample}-point MSM, same distributions, {dt:.2f} s wall; "
+                      "C restatement of halo2_proofs v2023_02_02 best_multiexp (not the Rust binary)",
+            "agrees_with_gpu": ok}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--log-points", type=int, default=24, help="log2 of the points per GPU")
+    ap.add_argument("--log-ntt", type=int, default=24)
+    ap.add_argument("--cpu-log-sample", type=int, default=21)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-ntt", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N>1")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback exists for this path)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    import halo2_experiments_amd as h
+    from halo2_experiments_amd import _lib
+    from halo2_experiments_amd.sharding import shard_range, sharded_multiexp
+
+    n_local = 1 << args.log_points
+    n_global = n_local * world
+    lo, hi = shard_range(n_global, rank, world)
+    assert hi - lo == n_local
+
+    # ---- synthetic inputs, resident in HBM before the timed region -----------------------------
+    gen = np.array(fq_mont_words(1) + fq_mont_words(2), dtype=np.uint64)        # G = (1, 2)
+    ks = rand_fr(n_local, 0x48324D49 + rank, device)                            # bases P_i = [k_i] G
+    bases = h.g1_fixed_base_mul(ks, gen)
+    handle = h.register_bases(bases)                                            # device-resident SRS slice
+    del ks, bases
+    scalars = rand_fr(n_local, 0x33353558 + rank, device)                       # uniform in [0, r)
+    torch.cuda.synchronize()
+
+    def step():
+        return sharded_multiexp(scalars, handle)
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    acc_ms, sort_ms, tot_ms = [], [], []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        result = step()
+        st = h.msm_stats()
+        acc_ms.append(st["accumulate_kernel_ms"])
+        sort_ms.append(st["sort_ms"])
+        tot_ms.append(st["total_ms"])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    st = h.msm_stats()
+
+    # ---- NTT (single GPU by design: "replicas only") -------------------------------------------
+    ntt = None
+    if not args.no_ntt and rank == 0:
+        from halo2_experiments_amd.domain import FR_MODULUS, FR_ROOT_OF_UNITY, fr_words
+        k = args.log_ntt
+        omega = fr_words(pow(FR_ROOT_OF_UNITY, 1 << (28 - k), FR_MODULUS))
+        a = rand_fr(1 << k, 99, device)
+        for _ in range(2):
+            h.best_fft(a, omega, k)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = max(3, args.steps)
+        e0.record()                      # the NTT launches on torch's current stream (passed through the ABI)
+        for _ in range(reps):
+            h.best_fft(a, omega, k)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        gbs = (NTT_BYTES_PER_ELEM << k) / (ms * 1e-3) / 1e9
+        ntt = {"log_n": k, "ms": ms, "elements_per_s": (1 << k) / (ms * 1e-3),
+               "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                            "traffic": None, "note": "3 digit passes: actual HBM traffic is 3x the algorithmic 64 B/element"}}
+        del a
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args.cpu_log_sample, device)
+
+    if rank == 0:
+        acc = float(np.mean(acc_ms))
+        achieved = MSM_BYTES_PER_POINT * n_local / (acc * 1e-3) / 1e9
+        line = {
+            "metric": "BN256 G1 MSM throughput",
+            "value": n_global * args.steps / elapsed,
+            "unit": "points/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32 (254-bit modular integers as 9x29-bit limbs, v_mad_u64_u32 accumulation)",
+            "data": "synthetic",
+            "config": {"workload": f"standalone BN256 G1 MSM, 2^{args.log_points} points per GPU "
+                                   f"(global 2^{args.log_points} x {world}; BASELINE configs[4] microbench, north-star headline size)",
+                       "points_per_gpu": n_local, "global_points": n_global,
+                       "scalars": "uniform in [0, r), torch Philox per rank", "bases": "[k_i]G, k_i uniform, device-resident",
+                       "window_bits": st["window_bits"], "windows": st["windows"], "parallelism": f"index-range shards x{world}, "
+                       "all-gather of 96 B partials (RCCL) + host fold"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "msm_accumulate_kernel", "kernel_ms": acc,
+                         "note": "integer-VALU bound (SURVEY.md §8d): ~2.7e8 mixed additions x ~2.9e3 32-bit ops per launch"},
+            "msm_phase_ms": {"sort": float(np.mean(sort_ms)), "accumulate_kernel": acc, "device_total": float(np.mean(tot_ms))},
+            "result_is_identity": bool(not result[8:].any()),
+        }
+        if ntt is not None:
+            line["ntt"] = ntt
+        if cpu is not None:
+            line["cpu_baseline"] = cpu
+        print(json.dumps(line))
+        sys.stdout.flush()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

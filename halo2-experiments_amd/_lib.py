@@ -23,7 +23,8 @@ class Halo2Mi355xError(RuntimeError):
 
 class MsmStats(ctypes.Structure):
     _fields_ = [("digits_ms", ctypes.c_double), ("sort_ms", ctypes.c_double), ("accumulate_ms", ctypes.c_double),
-                ("reduce_ms", ctypes.c_double), ("total_ms", ctypes.c_double), ("pairs", ctypes.c_uint64),
+                ("reduce_ms", ctypes.c_double), ("total_ms", ctypes.c_double), ("accumulate_kernel_ms", ctypes.c_double),
+                ("pairs", ctypes.c_uint64),
                 ("tasks", ctypes.c_uint64), ("window_bits", ctypes.c_uint32), ("windows", ctypes.c_uint32)]
 
 
@@ -50,6 +51,7 @@ _SIGNATURES = {
                                           ctypes.POINTER(ctypes.c_int)]),
     "hm_register_bases_dev": (ctypes.c_int, [_vp, ctypes.c_size_t, _vp, _u64p]),
     "hm_msm_bn256_g1_dev": (ctypes.c_int, [ctypes.c_uint64, ctypes.c_size_t, _vp, ctypes.c_size_t, _vp, _u64p]),
+    "hm_g1_sum": (ctypes.c_int, [_u64p, ctypes.c_size_t, _u64p]),
     "hm_msm_set_window": (ctypes.c_int, [ctypes.c_int]),
     "hm_ntt_bn256_fr": (ctypes.c_int, [_u64p, _u64p, ctypes.c_uint32]),
     "hm_ntt_bn256_fr_dev": (ctypes.c_int, [_vp, _u64p, ctypes.c_uint32, _vp]),

@@ -256,6 +256,14 @@ int hm_msm_bn256_g1_jacobian(const uint64_t* scalars, const uint64_t* bases, siz
   return msm_host(scalars, bases, n, out_xyz, &is_id);
 }
 
+int hm_g1_sum(const uint64_t* points_xyz, size_t count, uint64_t out_xyz[12]) {
+  if (!out_xyz || (count && !points_xyz)) return hm_fail(HM_ERR_BAD_ARG, "hm_g1_sum: null argument");
+  if (count > (1u << 20)) return hm_fail(HM_ERR_BAD_ARG, "hm_g1_sum: meant for a handful of partial results");
+  int is_id = 0;
+  host_sum_points(points_xyz, count, out_xyz, &is_id);
+  return HM_OK;
+}
+
 int hm_get_msm_stats(hm_msm_stats* out) {
   if (!out) return hm_fail(HM_ERR_BAD_ARG, "hm_get_msm_stats: null output");
   DeviceCtx* ctx = ctx_for_current_device();
@@ -263,7 +271,7 @@ int hm_get_msm_stats(hm_msm_stats* out) {
   std::lock_guard<std::mutex> lk(ctx->mu);
   const MsmStats& s = ctx->last_msm;
   out->digits_ms = s.t_digits_ms; out->sort_ms = s.t_sort_ms; out->accumulate_ms = s.t_accum_ms;
-  out->reduce_ms = s.t_reduce_ms; out->total_ms = s.t_total_ms;
+  out->reduce_ms = s.t_reduce_ms; out->total_ms = s.t_total_ms; out->accumulate_kernel_ms = s.t_accum_kernel_ms;
   out->pairs = s.pairs; out->tasks = s.tasks; out->window_bits = s.c; out->windows = s.windows;
   return HM_OK;
 }

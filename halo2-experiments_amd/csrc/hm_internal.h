@@ -69,7 +69,7 @@ struct BasesEntry {          // device-resident, converted base set (hm_register
 };
 
 struct MsmStats {
-  double t_digits_ms = 0, t_sort_ms = 0, t_accum_ms = 0, t_reduce_ms = 0, t_total_ms = 0;
+  double t_digits_ms = 0, t_sort_ms = 0, t_accum_ms = 0, t_reduce_ms = 0, t_total_ms = 0, t_accum_kernel_ms = 0;
   uint64_t pairs = 0, tasks = 0;
   uint32_t c = 0, windows = 0;
 };
@@ -109,6 +109,7 @@ int msm_convert_bases(const uint32_t* d_bases_ext, uint32_t* d_xy, uint8_t* d_in
 // out_windows: host buffer of W x 12 u64 external Jacobian + flags
 int msm_run(DeviceCtx& ctx, const uint32_t* d_scalars_ext, const uint32_t* d_xy, const uint8_t* d_inf, size_t n,
             int c_override, uint64_t out_jac_ext[12], int* out_is_identity, hipStream_t stream);
+void host_sum_points(const uint64_t* pts, size_t count, uint64_t out_jac_ext[12], int* out_is_identity);
 int g1_fixed_base_mul_run(DeviceCtx& ctx, const uint32_t* d_scalars_ext, size_t n, const uint64_t base_affine_ext[8],
                           uint32_t* d_out_affine_ext, hipStream_t stream);
 

@@ -278,16 +278,59 @@ __global__ __launch_bounds__(ACC_THREADS) void msm_accumulate_kernel(const uint3
   store_jac(partial + (size_t)t * PT_WORDS, acc);
 }
 
-// K3b: bucket = sum of its task partials
+// Workgroup-wide sum of one point per lane through an LDS tree; the result is valid in lane 0.
+constexpr int WIN_THREADS = 256;
+__device__ __forceinline__ G1Jac block_sum_points(uint32_t* tree, G1Jac acc) {
+  const uint32_t t = threadIdx.x;
+  store_jac(tree + t * PT_WORDS, acc);
+  __syncthreads();
+  for (uint32_t off = WIN_THREADS / 2; off > 0; off >>= 1) {
+    if (t < off) {
+      const G1Jac a = load_jac(tree + t * PT_WORDS), b = load_jac(tree + (t + off) * PT_WORDS);
+      store_jac(tree + t * PT_WORDS, g1_add(a, b));
+    }
+    __syncthreads();
+  }
+  return load_jac(tree);
+}
+
+// K3b: bucket = sum of its task partials.  Buckets with at most FINALIZE_SERIAL partials are
+// summed by one lane; longer ones (hot buckets that K3 split into many tasks) are queued for
+// the workgroup-per-bucket kernel below so that no single lane walks a long chain.
+constexpr uint32_t FINALIZE_SERIAL = 8;
 __global__ __launch_bounds__(ACC_THREADS) void msm_bucket_finalize_kernel(const uint32_t* __restrict__ partial,
                                                                           const uint32_t* __restrict__ toff,
-                                                                          uint32_t* __restrict__ bucket, uint32_t NBT) {
+                                                                          uint32_t* __restrict__ bucket, uint32_t NBT,
+                                                                          uint32_t* __restrict__ big_count,
+                                                                          uint32_t* __restrict__ big_list) {
   const uint32_t b = blockIdx.x * ACC_THREADS + threadIdx.x;
   if (b >= NBT) return;
   const uint32_t lo = toff[b], hi = toff[b + 1];
+  if (hi - lo > FINALIZE_SERIAL) {
+    big_list[atomicAdd(big_count, 1u)] = b;
+    return;
+  }
   G1Jac acc = g1_identity();
   for (uint32_t t = lo; t < hi; ++t) acc = g1_add(acc, load_jac(partial + (size_t)t * PT_WORDS));
   store_jac(bucket + (size_t)b * PT_WORDS, acc);
+}
+
+__global__ __launch_bounds__(WIN_THREADS) void msm_bucket_finalize_big_kernel(const uint32_t* __restrict__ partial,
+                                                                              const uint32_t* __restrict__ toff,
+                                                                              uint32_t* __restrict__ bucket,
+                                                                              const uint32_t* __restrict__ big_count,
+                                                                              const uint32_t* __restrict__ big_list) {
+  __shared__ uint32_t tree[WIN_THREADS * PT_WORDS];
+  const uint32_t count = *big_count;
+  for (uint32_t item = blockIdx.x; item < count; item += gridDim.x) {
+    const uint32_t b = big_list[item];
+    const uint32_t lo = toff[b], hi = toff[b + 1];
+    G1Jac acc = g1_identity();
+    for (uint32_t t = lo + threadIdx.x; t < hi; t += WIN_THREADS) acc = g1_add(acc, load_jac(partial + (size_t)t * PT_WORDS));
+    const G1Jac r = block_sum_points(tree, acc);
+    if (threadIdx.x == 0) store_jac(bucket + (size_t)b * PT_WORDS, r);
+    __syncthreads();
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -324,7 +367,6 @@ __global__ __launch_bounds__(ACC_THREADS) void msm_reduce_segments_kernel(const 
 
 // K4b: one workgroup per window: strided serial sum then an LDS tree; lane 0 converts to the
 // external Jacobian format (12 x u64 + flag word).
-constexpr int WIN_THREADS = 256;
 __global__ __launch_bounds__(WIN_THREADS) void msm_reduce_windows_kernel(const uint32_t* __restrict__ segres,
                                                                          uint32_t nseg, uint32_t* __restrict__ winres) {
   __shared__ uint32_t tree[WIN_THREADS * PT_WORDS];
@@ -332,17 +374,8 @@ __global__ __launch_bounds__(WIN_THREADS) void msm_reduce_windows_kernel(const u
   const uint32_t* sw = segres + (size_t)w * nseg * PT_WORDS;
   G1Jac acc = g1_identity();
   for (uint32_t s = t; s < nseg; s += WIN_THREADS) acc = g1_add(acc, load_jac(sw + (size_t)s * PT_WORDS));
-  store_jac(tree + t * PT_WORDS, acc);
-  __syncthreads();
-  for (uint32_t off = WIN_THREADS / 2; off > 0; off >>= 1) {
-    if (t < off) {
-      const G1Jac a = load_jac(tree + t * PT_WORDS), b = load_jac(tree + (t + off) * PT_WORDS);
-      store_jac(tree + t * PT_WORDS, g1_add(a, b));
-    }
-    __syncthreads();
-  }
+  const G1Jac r = block_sum_points(tree, acc);
   if (t == 0) {
-    const G1Jac r = load_jac(tree);
     uint32_t* o = winres + (size_t)w * 32;
     uint32_t wx[8], wy[8], wz[8];
     if (r.inf) {
@@ -501,6 +534,18 @@ static void host_fold(const uint32_t* winres, uint32_t W, uint32_t c, uint64_t o
   *out_is_identity = 0;
 }
 
+// sum of `count` external Jacobian points (12 u64 each, z = 0 for the identity) on the host:
+// the fold of per-GPU partial MSM results after the RCCL all-gather (a few points, latency only)
+void host_sum_points(const uint64_t* pts, size_t count, uint64_t out_jac_ext[12], int* out_is_identity) {
+  std::vector<uint32_t> win(count * 32, 0);
+  for (size_t i = 0; i < count; ++i) {
+    const uint64_t* p = pts + i * 12;
+    std::memcpy(&win[i * 32], p, 96);
+    win[i * 32 + 24] = (p[8] | p[9] | p[10] | p[11]) == 0 ? 1u : 0u;
+  }
+  host_fold(win.data(), (uint32_t)count, 0, out_jac_ext, out_is_identity);
+}
+
 static int g_window_override = 0;
 void msm_set_window_override(int c) { g_window_override = c; }
 
@@ -527,6 +572,11 @@ int msm_run(DeviceCtx& ctx, const uint32_t* d_scalars_ext, const uint32_t* d_xy,
   if ((uint64_t)n * W >= (1ull << 32)) return hm_fail(HM_ERR_BAD_ARG, "msm: n * windows must be < 2^32");
   const double mean = (double)n / (double)NB;
   uint32_t L = (uint32_t)(mean + 4.0 * std::sqrt(mean) + 8.0);
+  {
+    // small inputs: shorter tasks so that the launch still fills 256 CUs x 4 SIMDs x ~5 waves
+    const double fill = (double)n * W / 655360.0;
+    if ((double)L > fill) L = (uint32_t)fill;
+  }
   if (L < 16) L = 16;
   uint32_t G = (uint32_t)((n + 16383) / 16384);
   if (G < 1) G = 1;
@@ -554,6 +604,7 @@ int msm_run(DeviceCtx& ctx, const uint32_t* d_scalars_ext, const uint32_t* d_xy,
   const size_t o_bucket = carve((size_t)NBT * PT_WORDS * 4);
   const size_t o_seg = carve((size_t)W * nseg * PT_WORDS * 4);
   const size_t o_win = carve((size_t)W * 32 * 4);
+  const size_t o_big = carve(((size_t)NBT + 4) * 4);
   uint8_t* ws = (uint8_t*)ctx.msm_ws.ensure(off);
   if (!ws) return hm_fail(HM_ERR_HIP, "msm: workspace allocation failed");
   int32_t* d_digits = (int32_t*)(ws + o_digits);
@@ -568,6 +619,8 @@ int msm_run(DeviceCtx& ctx, const uint32_t* d_scalars_ext, const uint32_t* d_xy,
   uint32_t* d_bucket = (uint32_t*)(ws + o_bucket);
   uint32_t* d_seg = (uint32_t*)(ws + o_seg);
   uint32_t* d_win = (uint32_t*)(ws + o_win);
+  uint32_t* d_big_count = (uint32_t*)(ws + o_big);
+  uint32_t* d_big_list = d_big_count + 4;
 
   static bool attr_set = false;
   if (!attr_set) {
@@ -577,7 +630,7 @@ int msm_run(DeviceCtx& ctx, const uint32_t* d_scalars_ext, const uint32_t* d_xy,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 32769 * 4));
     attr_set = true;
   }
-  hipEvent_t ev[5];
+  hipEvent_t ev[7];
   for (auto& e : ev) HM_HIP_CHECK(hipEventCreate(&e));
   HM_HIP_CHECK(hipEventRecord(ev[0], stream));
 
@@ -611,15 +664,26 @@ int msm_run(DeviceCtx& ctx, const uint32_t* d_scalars_ext, const uint32_t* d_xy,
   if ((uint64_t)T > T_max) return hm_fail(HM_ERR_INTERNAL, "msm: task count exceeds its bound");
 
   // ---- K3 ------------------------------------------------------------------------------------
+  HM_HIP_CHECK(hipEventRecord(ev[5], stream));
   if (T > 0) {
     hipLaunchKernelGGL(msm_accumulate_kernel, dim3((T + ACC_THREADS - 1) / ACC_THREADS), dim3(ACC_THREADS), 0, stream,
                        (const uint32_t*)d_sorted, (const uint32_t*)d_tb, (const uint32_t*)d_boff, (const uint32_t*)d_bcnt,
                        (const uint32_t*)d_toff, d_xy, d_partial, T, L);
     HM_HIP_CHECK(hipGetLastError());
   }
+  HM_HIP_CHECK(hipEventRecord(ev[6], stream));
+  HM_HIP_CHECK(hipMemsetAsync(d_big_count, 0, 16, stream));
   hipLaunchKernelGGL(msm_bucket_finalize_kernel, dim3((NBT + ACC_THREADS - 1) / ACC_THREADS), dim3(ACC_THREADS), 0, stream,
-                     (const uint32_t*)d_partial, (const uint32_t*)d_toff, d_bucket, NBT);
+                     (const uint32_t*)d_partial, (const uint32_t*)d_toff, d_bucket, NBT, d_big_count, d_big_list);
   HM_HIP_CHECK(hipGetLastError());
+  {
+    uint32_t big_grid = T / (FINALIZE_SERIAL + 1) + 1;  // upper bound on the number of queued buckets
+    if (big_grid > 2048) big_grid = 2048;              // the kernel strides over the queue
+    hipLaunchKernelGGL(msm_bucket_finalize_big_kernel, dim3(big_grid), dim3(WIN_THREADS), 0, stream,
+                       (const uint32_t*)d_partial, (const uint32_t*)d_toff, d_bucket, (const uint32_t*)d_big_count,
+                       (const uint32_t*)d_big_list);
+    HM_HIP_CHECK(hipGetLastError());
+  }
   HM_HIP_CHECK(hipEventRecord(ev[3], stream));
 
   // ---- K4 ------------------------------------------------------------------------------------
@@ -638,6 +702,9 @@ int msm_run(DeviceCtx& ctx, const uint32_t* d_scalars_ext, const uint32_t* d_xy,
   float ms[4] = {0, 0, 0, 0}, total = 0;
   for (int i = 0; i < 4; ++i) (void)hipEventElapsedTime(&ms[i], ev[i], ev[i + 1]);
   (void)hipEventElapsedTime(&total, ev[0], ev[4]);
+  float acc_kernel = 0;
+  (void)hipEventElapsedTime(&acc_kernel, ev[5], ev[6]);
+  ctx.last_msm.t_accum_kernel_ms = acc_kernel;
   for (auto& e : ev) (void)hipEventDestroy(e);
   ctx.last_msm.t_digits_ms = ms[0];
   ctx.last_msm.t_sort_ms = ms[1];

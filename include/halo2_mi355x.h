@@ -81,6 +81,11 @@ int hm_register_bases_dev(const void* d_bases, size_t n, void* stream, uint64_t*
 int hm_msm_bn256_g1_dev(uint64_t handle, size_t offset, const void* d_scalars, size_t n, void* stream,
                         uint64_t out_xyz[12]);
 
+/* Sum of `count` G1 values (12 x u64 each, z = 0 for the identity), normalised to (x, y, 1): the
+ * fold of per-GPU partial results of a sharded best_multiexp after the RCCL all-gather.  Pure host
+ * arithmetic on a handful of points (the exchange is ~96 B per rank); needs no device. */
+int hm_g1_sum(const uint64_t* points_xyz, size_t count, uint64_t out_xyz[12]);
+
 /* Window-size override for experiments (0 = automatic). */
 int hm_msm_set_window(int c);
 
@@ -115,6 +120,7 @@ int hm_g1_fixed_base_mul_dev(const void* d_scalars, size_t n, const uint64_t bas
 
 typedef struct hm_msm_stats {
   double digits_ms, sort_ms, accumulate_ms, reduce_ms, total_ms; /* hipEvent times of the last MSM */
+  double accumulate_kernel_ms;                                   /* the bucket-accumulation launch alone */
   uint64_t pairs, tasks;                                         /* non-zero digits, accumulation tasks */
   uint32_t window_bits, windows;
 } hm_msm_stats;

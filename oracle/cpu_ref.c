@@ -100,33 +100,29 @@ static inline void fe_neg(const field *F, fe *o, const fe *a) {
 }
 static inline void fe_dbl(const field *F, fe *o, const fe *a) { fe_add(F, o, a, a); }
 
-/* CIOS Montgomery multiplication, 4 x 64-bit limbs */
-static inline void fe_mul(const field *F, fe *o, const fe *a, const fe *b) {
-    uint64_t t[6] = {0, 0, 0, 0, 0, 0};
+/* CIOS Montgomery multiplication, 4 x 64-bit limbs (scalar temporaries so they stay in registers) */
+static inline __attribute__((always_inline)) void fe_mul(const field *F, fe *o, const fe *a, const fe *b) {
+    const uint64_t m0 = F->mod.l[0], m1 = F->mod.l[1], m2 = F->mod.l[2], m3 = F->mod.l[3], inv = F->inv;
+    const uint64_t a0 = a->l[0], a1 = a->l[1], a2 = a->l[2], a3 = a->l[3];
+    uint64_t t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
+#pragma GCC unroll 4
     for (int i = 0; i < 4; ++i) {
-        u128 c = 0;
-        for (int j = 0; j < 4; ++j) {
-            c += (u128)t[j] + (u128)a->l[j] * b->l[i];
-            t[j] = (uint64_t)c;
-            c >>= 64;
-        }
-        c += t[4];
-        t[4] = (uint64_t)c;
-        t[5] = (uint64_t)(c >> 64);
-        uint64_t m = t[0] * F->inv;
-        c = (u128)t[0] + (u128)m * F->mod.l[0];
-        c >>= 64;
-        for (int j = 1; j < 4; ++j) {
-            c += (u128)t[j] + (u128)m * F->mod.l[j];
-            t[j - 1] = (uint64_t)c;
-            c >>= 64;
-        }
-        c += t[4];
-        t[3] = (uint64_t)c;
-        t[4] = t[5] + (uint64_t)(c >> 64);
+        const uint64_t bi = b->l[i];
+        u128 c = (u128)a0 * bi + t0; t0 = (uint64_t)c; c >>= 64;
+        c += (u128)a1 * bi + t1; t1 = (uint64_t)c; c >>= 64;
+        c += (u128)a2 * bi + t2; t2 = (uint64_t)c; c >>= 64;
+        c += (u128)a3 * bi + t3; t3 = (uint64_t)c; c >>= 64;
+        c += t4; t4 = (uint64_t)c;
+        const uint64_t t5 = (uint64_t)(c >> 64);
+        const uint64_t m = t0 * inv;
+        c = (u128)m * m0 + t0; c >>= 64;
+        c += (u128)m * m1 + t1; t0 = (uint64_t)c; c >>= 64;
+        c += (u128)m * m2 + t2; t1 = (uint64_t)c; c >>= 64;
+        c += (u128)m * m3 + t3; t2 = (uint64_t)c; c >>= 64;
+        c += t4; t3 = (uint64_t)c; t4 = t5 + (uint64_t)(c >> 64);
     }
-    fe r = {{t[0], t[1], t[2], t[3]}};
-    if (t[4] || fe_geq(&r, &F->mod)) fe_sub_raw(&r, &r, &F->mod);
+    fe r = {{t0, t1, t2, t3}};
+    if (t4 || fe_geq(&r, &F->mod)) fe_sub_raw(&r, &r, &F->mod);
     *o = r;
 }
 static inline void fe_sqr(const field *F, fe *o, const fe *a) { fe_mul(F, o, a, a); }

@@ -1,0 +1,95 @@
+"""CPU suite: the C-ABI shared library loads, exports every symbol include/halo2_mi355x.h declares,
+and fails loudly (never falls back) when no gfx950 device is present."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from halo2_experiments_amd import _lib
+import halo2_experiments_amd as h
+
+
+def declared_symbols():
+    text = open(_lib.HEADER_PATH).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(hm_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_is_in_tree_and_loads():
+    assert os.path.dirname(_lib.LIB_PATH).endswith(os.path.join("halo2-experiments_amd", "csrc"))
+    lib = _lib.load()
+    assert b"gfx950" in lib.hm_version()
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    names = declared_symbols()
+    assert len(names) >= 20
+    for name in names:
+        assert hasattr(lib, name), f"{name} declared in the header but not exported"
+        assert name in _lib._SIGNATURES, f"{name} has no ctypes signature"
+    assert set(_lib._SIGNATURES) == set(names)
+
+
+def test_argument_errors_are_reported_not_thrown():
+    lib = _lib.load()
+    assert lib.hm_msm_bn256_g1(None, None, 0, None, None) == -1          # HM_ERR_BAD_ARG: null output
+    assert b"null" in lib.hm_last_error()
+    assert lib.hm_ntt_bn256_fr(None, None, 3) == -1
+    assert lib.hm_msm_set_window(99) == -1
+    assert lib.hm_msm_set_window(0) == 0
+    assert lib.hm_g1_sum(None, 0, None) == -1
+
+
+def test_no_device_means_error_not_fallback():
+    lib = _lib.load()
+    if lib.hm_device_count() > 0:
+        pytest.skip("a GPU is present")
+    s, b = np.zeros((4, 4), dtype=np.uint64), np.zeros((4, 8), dtype=np.uint64)
+    with pytest.raises(_lib.Halo2Mi355xError) as e:
+        h.best_multiexp(s, b)
+    assert e.value.code == -2 and "no CPU fallback" in str(e.value)
+    a = np.zeros((8, 4), dtype=np.uint64)
+    with pytest.raises(_lib.Halo2Mi355xError):
+        h.best_fft(a, np.zeros(4, dtype=np.uint64), 3)
+    assert lib.hm_set_device(0) == -2
+
+
+def test_host_mirror_argument_checks():
+    s, b = np.zeros((4, 4), dtype=np.uint64), np.zeros((5, 8), dtype=np.uint64)
+    with pytest.raises(ValueError, match="coeffs.len"):          # upstream: assert_eq!(coeffs.len(), bases.len())
+        h.best_multiexp(s, b)
+    with pytest.raises(ValueError, match="1 << log_n"):          # upstream: assert_eq!(a.len(), 1 << log_n)
+        h.best_fft(np.zeros((6, 4), dtype=np.uint64), np.zeros(4, dtype=np.uint64), 3)
+    with pytest.raises(TypeError):
+        h.best_fft([[0, 0, 0, 0]], np.zeros(4, dtype=np.uint64), 0)
+    with pytest.raises(TypeError):
+        h.best_multiexp(np.zeros((4, 4), dtype=np.int32), b)
+
+
+def test_g1_sum_host_fold(cref, golden):
+    """hm_g1_sum (the multi-GPU fold) is pure host code: check it against the oracle here."""
+    from halo2_experiments_amd.sharding import g1_sum
+    g = golden["msm"]
+    s, b = g["n255_uniform_s"], g["n255_uniform_b"]
+    parts = np.stack([cref.best_multiexp(s[lo:hi], b[lo:hi], 2) for lo, hi in [(0, 100), (100, 100), (100, 255)]])
+    tot = g1_sum(parts)
+    assert np.array_equal(tot[:8], g["n255_uniform_r"]) and tot[8:].any()
+    pm = np.stack([cref.best_multiexp(g["pmone_s"][:32], g["pmone_b"][:32], 1), cref.best_multiexp(g["pmone_s"][32:], g["pmone_b"][32:], 1)])
+    assert not g1_sum(pm).any()                                     # identity
+    assert not g1_sum(np.zeros((0, 12), dtype=np.uint64)).any()
+
+
+def test_evaluation_domain_constants(pyref):
+    o = pyref
+    from halo2_experiments_amd.domain import EvaluationDomain, FR_MODULUS, FR_ROOT_OF_UNITY, fr_words
+    assert FR_MODULUS == o.R and FR_ROOT_OF_UNITY == o.FR_ROOT_OF_UNITY
+    d = EvaluationDomain(j=7, k=9)             # MerkleSumTree-like: max degree 7 -> extended_k = k + 3
+    assert d.extended_k == 12 and d.quotient_poly_degree == 6
+    assert d.omega == o.fr_omega(9) and d.extended_omega == o.fr_omega(12)
+    assert d.omega * d.omega_inv % o.R == 1 and d.ifft_divisor * 512 % o.R == 1
+    assert d.g_coset == o.FR_ZETA and d.g_coset * d.g_coset_inv % o.R == 1
+    assert EvaluationDomain(j=3, k=4).extended_k == 5 and EvaluationDomain(j=2, k=4).extended_k == 4
+    assert fr_words(5).tolist() == o.fr_array([5])[0].tolist()

@@ -1,0 +1,100 @@
+"""CPU suite: the device field/curve headers (csrc/ff29.h, csrc/g1.h) compiled for the host with
+worst-case bound tracking (-DHM_BOUNDS): bit-exactness against the golden vectors, and the proof
+that no column sum / limb / lazy value can overflow (any violated precondition aborts the process)."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from halo2_experiments_amd import _lib
+
+P64 = ctypes.POINTER(ctypes.c_uint64)
+
+
+def p(a):
+    return a.ctypes.data_as(P64)
+
+
+@pytest.fixture(scope="module")
+def hc():
+    subprocess.run(["make", "-C", _lib.CSRC, "libhm_hostcheck.so"], check=True, capture_output=True)
+    return ctypes.CDLL(_lib.HOSTCHECK_PATH)
+
+
+def field_op(hc, field, op, a, b):
+    a, b = np.ascontiguousarray(a), np.ascontiguousarray(b)
+    out = np.zeros_like(a)
+    hc.hc_field_op(field, op, p(a), p(b), p(out), ctypes.c_size_t(a.shape[0]))
+    return out
+
+
+@pytest.mark.parametrize("name,field", [("fq", 0), ("fr", 1)])
+def test_field_ops_bit_exact(hc, golden, name, field):
+    g = golden["field"]
+    a, b = g[f"{name}_a"], g[f"{name}_b"]
+    assert np.array_equal(field_op(hc, field, 0, a, b), g[f"{name}_mul"])
+    assert np.array_equal(field_op(hc, field, 1, a, a), field_op(hc, field, 0, a, a))     # sqr == mul(a, a)
+    assert np.array_equal(field_op(hc, field, 2, a, b), g[f"{name}_add"])
+    assert np.array_equal(field_op(hc, field, 3, a, b), g[f"{name}_sub"])
+
+
+def test_lazy_chain_matches_oracle(hc, cref, golden):
+    g = golden["field"]
+    a, b = g["fr_a"], g["fr_b"]
+    exp = cref.fr_add(cref.fr_mul(cref.fr_add(a, b), cref.fr_sub(a, b)), cref.fr_mul(a, a))
+    assert np.array_equal(field_op(hc, 1, 4, a, b), exp)
+
+
+def test_raw_256bit_words_reduce(hc, pyref):
+    o = pyref
+    raw = np.array([[2**64 - 1] * 4, [0, 0, 0, 2**63], o.to_limbs(o.R), o.to_limbs(o.R - 1), o.to_limbs(2 * o.R + 5)], dtype=np.uint64)
+    out = np.zeros_like(raw)
+    hc.hc_fr_reduce_raw(p(raw), p(out), ctypes.c_size_t(raw.shape[0]))
+    for r_in, r_out in zip(raw, out):
+        assert o.from_limbs(r_out) == o.from_limbs(r_in) % o.R
+
+
+def jac_words(o, pt, z):
+    if pt is None:
+        return np.zeros(12, dtype=np.uint64)
+    x, y = pt
+    X, Y = x * z * z % o.P, y * z * z * z % o.P
+    return np.array(o.to_limbs(X * o.MONT % o.P) + o.to_limbs(Y * o.MONT % o.P) + o.to_limbs(z * o.MONT % o.P), dtype=np.uint64)
+
+
+def test_curve_ops_and_exceptional_cases(hc, pyref, golden):
+    o = pyref
+    g = golden["curve"]
+    out = np.zeros(12, dtype=np.uint64)
+    oi = ctypes.c_int(0)
+
+    def dec():
+        return None if oi.value else o.g1_jacobian_from_array(out)[0]
+
+    pa, pb, ps = o.g1_affine_from_array(g["add_a"]), o.g1_affine_from_array(g["add_b"]), o.g1_affine_from_array(g["add_sum"])
+    for i, (a, b, s) in enumerate(zip(pa, pb, ps)):
+        z1, z2 = 3 + 2 * i, 1000003 + i
+        if b is not None:
+            for neg in (0, 1):
+                hc.hc_g1_madd(p(jac_words(o, a, z1)), 0, p(o.g1_affine_array([b])[0]), neg, p(out), ctypes.byref(oi))
+                assert dec() == o.g1_add(a, o.g1_neg(b) if neg else b), (i, neg)
+        hc.hc_g1_add(p(jac_words(o, a, z1)), 0, p(jac_words(o, b, z2)), int(b is None), p(out), ctypes.byref(oi))
+        assert dec() == s, i
+        hc.hc_g1_double(p(jac_words(o, a, z1)), 0, p(out), ctypes.byref(oi))
+        assert dec() == o.g1_add(a, a)
+    for k, d in [(1, 0), (2, 0), (3, 5), (17, 3), (100, 20)]:
+        hc.hc_g1_chain(p(o.g1_affine_array([pa[0]])[0]), k, d, p(out), ctypes.byref(oi))
+        assert dec() == o.g1_mul(k << d, pa[0])
+
+
+def test_bound_closure_proof(hc, pyref):
+    """Every curve formula, run with its inputs declared at the class maxima, must (a) violate no
+    precondition (the library aborts otherwise) and (b) return coordinates inside the class."""
+    o = pyref
+    pts = [o.g1_mul(k, o.G1_GEN) for k in (11, 22, 33)]
+    rep = (ctypes.c_double * 9)()
+    ok = hc.hc_bounds_closure(p(jac_words(o, pts[0], 5)), p(jac_words(o, pts[1], 7)), p(o.g1_affine_array([pts[2]])[0]), rep)
+    assert ok == 1, list(rep)
+    assert max(rep[0], rep[1], rep[3], rep[4], rep[6], rep[7]) <= 12.0 and max(rep[2], rep[5], rep[8]) <= 2.0

@@ -1,0 +1,180 @@
+"""GPU suite: best_multiexp on the MI355X through the C ABI vs the oracle (bit-exact after affine
+normalisation), the committed golden vectors, the edge cases of the domain, and known-answer /
+additivity properties at the benchmark's full size."""
+import ctypes
+
+import numpy as np
+import pytest
+
+import halo2_experiments_amd as h
+from halo2_experiments_amd import _lib
+from conftest import g1_equal
+
+pytestmark = pytest.mark.gpu
+
+
+def rand_fr_gpu(n, seed):
+    import torch
+    g = torch.Generator(device="cuda")
+    g.manual_seed(seed)
+    x = torch.randint(-(2 ** 63), 2 ** 63 - 1, (n, 4), dtype=torch.int64, device="cuda", generator=g)
+    x[:, 3] &= 0x0FFFFFFFFFFFFFFF
+    return x
+
+
+def test_golden_vectors(golden):
+    g = golden["msm"]
+    for name in g["names"]:
+        got = h.best_multiexp(g[f"{name}_s"], g[f"{name}_b"])
+        assert g1_equal(got, g[f"{name}_r"]), name
+
+
+def test_empty_and_identity_results(golden):
+    g = golden["msm"]
+    out = h.best_multiexp(np.zeros((0, 4), dtype=np.uint64), np.zeros((0, 8), dtype=np.uint64))
+    assert not out.any()
+    assert not h.best_multiexp(g["n33_zero_s"], g["n33_zero_b"]).any()
+    xy = np.ones(8, dtype=np.uint64)
+    is_id = ctypes.c_int(0)
+    P64 = ctypes.POINTER(ctypes.c_uint64)
+    s, b = np.ascontiguousarray(g["pmone_s"]), np.ascontiguousarray(g["pmone_b"])
+    _lib.check(_lib.load().hm_msm_bn256_g1(s.ctypes.data_as(P64), b.ctypes.data_as(P64), s.shape[0], xy.ctypes.data_as(P64),
+                                           ctypes.byref(is_id)))
+    assert is_id.value == 1 and not xy.any()
+
+
+@pytest.mark.parametrize("window", [0, 4, 7, 11, 13, 16])
+def test_every_window_size(golden, window):
+    g = golden["msm"]
+    lib = _lib.load()
+    _lib.check(lib.hm_msm_set_window(window))
+    try:
+        for name in ("n255_uniform", "n1024_prover", "n33_edge", "same", "pm", "ident", "n1024_rminus1"):
+            assert g1_equal(h.best_multiexp(g[f"{name}_s"], g[f"{name}_b"]), g[f"{name}_r"]), (window, name)
+    finally:
+        lib.hm_msm_set_window(0)
+
+
+@pytest.mark.parametrize("log_n,kind", [(12, "uniform"), (14, "prover"), (16, "uniform"), (16, "small"), (17, "one")])
+def test_matches_oracle_mid_sizes(cref, pyref, log_n, kind):
+    """Random bases [k_i]G from the fixed-base kernel; scalars of several distributions, with an
+    identity base and duplicate points planted; oracle = the C restatement (8 threads)."""
+    o = pyref
+    n = 1 << log_n
+    gen = cref.g1_generator()
+    bases = h.g1_fixed_base_mul(rand_fr_gpu(n, 3 * log_n), gen).cpu().numpy().view(np.uint64).copy()
+    bases[2] = 0
+    bases[5] = bases[6]
+    if kind == "uniform":
+        s = rand_fr_gpu(n, log_n).cpu().numpy().view(np.uint64)
+    else:
+        base = o.fr_array(o.rand_scalars(4096, log_n, kind))
+        s = np.tile(base, (n // 4096, 1))
+    exp = cref.g1_to_affine(cref.best_multiexp(s, bases, 8))[0]
+    assert g1_equal(h.best_multiexp(s, bases), exp)
+
+
+def test_fixed_base_kernel_matches_oracle(cref):
+    gen = cref.g1_generator()
+    ks = rand_fr_gpu(16, 5)
+    ks[3] = 0
+    pts = h.g1_fixed_base_mul(ks, gen).cpu().numpy().view(np.uint64)
+    kh = ks.cpu().numpy().view(np.uint64)
+    for i in range(16):
+        assert np.array_equal(pts[i], cref.g1_mul(kh[i], gen)), i
+    assert not pts[3].any()
+
+
+def test_registered_bases_offsets_and_device_scalars(cref, golden):
+    import torch
+    g = golden["msm"]
+    s, b, = g["n1024_uniform_s"], g["n1024_uniform_b"]
+    hd = h.register_bases(b)
+    try:
+        assert g1_equal(h.best_multiexp(s, hd), g["n1024_uniform_r"])
+        lo, cnt = 100, 500
+        exp = cref.g1_to_affine(cref.best_multiexp(s[lo:lo + cnt], b[lo:lo + cnt], 4))[0]
+        assert g1_equal(h.best_multiexp(s[lo:lo + cnt], hd, offset=lo), exp)
+        sd = torch.from_numpy(s[lo:lo + cnt].view(np.int64).copy()).cuda()
+        assert g1_equal(h.best_multiexp(sd, hd, offset=lo), exp)
+        with pytest.raises(_lib.Halo2Mi355xError):
+            h.best_multiexp(s, hd, offset=1)            # offset + n exceeds the set
+    finally:
+        h.release_bases(hd)
+    with pytest.raises(_lib.Halo2Mi355xError):
+        h.best_multiexp(s, hd)                          # released handle
+
+
+def test_hot_bucket_columns_are_split(cref):
+    """Constant columns (every scalar equal) put all points in one bucket per window: must stay
+    correct and must not serialise (the tasks statistic shows the split)."""
+    n = 1 << 16
+    gen = cref.g1_generator()
+    bases = h.g1_fixed_base_mul(rand_fr_gpu(n, 9), gen)
+    hd = h.register_bases(bases)
+    try:
+        one = rand_fr_gpu(1, 10).repeat(n, 1).contiguous()
+        got = h.best_multiexp(one, hd)
+        st = h.msm_stats()
+        assert st["tasks"] > 1000
+        bh = bases.cpu().numpy().view(np.uint64)
+        # sum of all bases times the scalar, via the oracle
+        ones = np.tile(cref.fr_to_mont(np.array([[1, 0, 0, 0]], dtype=np.uint64)), (n, 1))
+        tot = cref.best_multiexp(ones, bh, 8)
+        exp = cref.g1_mul(one[0].cpu().numpy().view(np.uint64), cref.g1_to_affine(tot)[0])
+        assert g1_equal(got, exp)
+    finally:
+        h.release_bases(hd)
+
+
+@pytest.mark.parametrize("log_n", [20, 24])
+def test_full_size_kzg_known_answer_and_additivity(cref, pyref, log_n):
+    """The KZG consistency check of SURVEY.md §8c at the benchmark's size: with the SRS g_i = [x^i]G,
+    MSM(coeffs(f), g) == [f(x)]G; plus MSM(whole) == MSM(first half) + MSM(second half)."""
+    import torch
+    from halo2_experiments_amd.sharding import g1_sum
+    o = pyref
+    n = 1 << log_n
+    x = o.fr_array([0x48324D4933353558])[0]
+    powers = torch.from_numpy(cref.fr_powers(x, n).view(np.int64)).cuda()       # x^i, oracle-side Fr work
+    srs = h.g1_fixed_base_mul(powers, cref.g1_generator())                     # ParamsKZG::setup's g
+    hd = h.register_bases(srs)
+    try:
+        f = rand_fr_gpu(n, 2024)
+        got = h.best_multiexp(f, hd)
+        fx = cref.fr_horner(f.cpu().numpy().view(np.uint64), x)
+        assert g1_equal(got, cref.g1_mul(fx, cref.g1_generator()))
+        half = n // 2
+        lo = h.best_multiexp(f[:half].contiguous(), hd)
+        hi = h.best_multiexp(f[half:].contiguous(), hd, offset=half)
+        assert np.array_equal(g1_sum(np.stack([lo, hi])), got)
+    finally:
+        h.release_bases(hd)
+
+
+def test_commit_lagrange_equals_commit(cref, pyref):
+    """MSM and NTT together, as ParamsKZG::commit / commit_lagrange use them: committing to the
+    evaluations with g_lagrange equals committing to the coefficients with g, where
+    g_lagrange = n^-1 * NTT_{omega^-1}-transform of g in the exponent -- here checked through
+    scalars: MSM(evals, [L_i(x)]G) == MSM(coeffs, [x^i]G)."""
+    import torch
+    o = pyref
+    k, n = 10, 1 << 10
+    xv = 987654321
+    w = o.fr_omega(k)
+    f = o.rand_scalars(n, 31337)
+    evals = o.ntt_fast(f, w)                                                  # f(omega^j)
+    # Lagrange basis at x: L_j(x) = (x^n - 1) / n * omega^j / (x - omega^j)
+    xn1 = (pow(xv, n, o.R) - 1) * pow(n, -1, o.R) % o.R
+    lag = [xn1 * pow(w, j, o.R) % o.R * pow((xv - pow(w, j, o.R)) % o.R, -1, o.R) % o.R for j in range(n)]
+    gen = cref.g1_generator()
+    g = h.g1_fixed_base_mul(torch.from_numpy(o.fr_array([pow(xv, i, o.R) for i in range(n)]).view(np.int64)).cuda(), gen)
+    gl = h.g1_fixed_base_mul(torch.from_numpy(o.fr_array(lag).view(np.int64)).cuda(), gen)
+    a = torch.from_numpy(o.fr_array(f).view(np.int64)).cuda()
+    c1 = h.best_multiexp(a, h.register_bases(g))
+    ev = a.clone()
+    h.best_fft(ev, o.fr_array([w])[0], k)
+    assert np.array_equal(ev.cpu().numpy().view(np.uint64), o.fr_array(evals))
+    c2 = h.best_multiexp(ev, h.register_bases(gl))
+    assert np.array_equal(c1, c2) and c1[8:].any()
+    assert g1_equal(c1, cref.g1_mul(o.fr_array([o.poly_eval(f, xv)])[0], gen))

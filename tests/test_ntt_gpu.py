@@ -1,0 +1,133 @@
+"""GPU suite: best_fft on the MI355X through the C ABI vs the oracle (bit-exact), the committed
+golden vectors, and size-independent properties at the benchmark's full size."""
+import numpy as np
+import pytest
+
+import halo2_experiments_amd as h
+from halo2_experiments_amd.domain import EvaluationDomain, fr_words
+
+pytestmark = pytest.mark.gpu
+
+
+def rand_fr_gpu(n, seed):
+    import torch
+    g = torch.Generator(device="cuda")
+    g.manual_seed(seed)
+    x = torch.randint(-(2 ** 63), 2 ** 63 - 1, (n, 4), dtype=torch.int64, device="cuda", generator=g)
+    x[:, 3] &= 0x0FFFFFFFFFFFFFFF  # < 2^252 < r: a fully reduced Montgomery word
+    return x
+
+
+def test_golden_vectors(golden):
+    g = golden["ntt"]
+    for k in range(0, 11):
+        a = g[f"k{k}_in"].copy()
+        h.best_fft(a, g[f"k{k}_omega"], k)
+        assert np.array_equal(a, g[f"k{k}_out"]), k
+    for name in ("delta", "ones"):
+        a = g[f"{name}_in"].copy()
+        h.best_fft(a, g["k5_omega"], 5)
+        assert np.array_equal(a, g[f"{name}_out"])
+    a = g["w3_in"].copy()
+    h.best_fft(a, g["w3_omega"], 5)          # omega is an argument, not assumed to be ROOT^(2^(28-k))
+    assert np.array_equal(a, g["w3_out"])
+
+
+@pytest.mark.parametrize("k", list(range(0, 20)))
+def test_host_api_matches_oracle_every_log_n(cref, pyref, k):
+    """Covers the 1-pass (<= 2^11), 2-pass (<= 2^16) and 3-pass plans and every digit split."""
+    a = rand_fr_gpu(1 << k, 1000 + k).cpu().numpy().view(np.uint64)
+    w = pyref.fr_array([pyref.fr_omega(k)])[0]
+    exp = cref.best_fft(a, w, k, 8)
+    got = a.copy()
+    h.best_fft(got, w, k)
+    assert np.array_equal(got, exp)
+
+
+@pytest.mark.parametrize("k", [12, 17, 21])
+def test_device_api_matches_host_api(pyref, k):
+    import torch
+    x = rand_fr_gpu(1 << k, 77 + k)
+    w = pyref.fr_array([pyref.fr_omega(k)])[0]
+    host = x.cpu().numpy().view(np.uint64).copy()
+    h.best_fft(host, w, k)
+    h.best_fft(x, w, k)
+    torch.cuda.synchronize()
+    assert np.array_equal(x.cpu().numpy().view(np.uint64), host)
+
+
+def test_edge_values(cref, pyref):
+    o = pyref
+    k = 6
+    vals = [0, 1, o.R - 1, o.R - 2, 2, (1 << 253) % o.R] * 11
+    a = o.fr_array(vals[:64])
+    w = o.fr_array([o.fr_omega(k)])[0]
+    exp = cref.best_fft(a, w, k, 1)
+    h.best_fft(a, w, k)
+    assert np.array_equal(a, exp)
+    z = np.zeros((1 << 13, 4), dtype=np.uint64)
+    h.best_fft(z, o.fr_array([o.fr_omega(13)])[0], 13)
+    assert not z.any()
+
+
+@pytest.mark.parametrize("k", [20, 24])
+def test_full_size_properties(cref, pyref, k):
+    """At sizes no oracle brute-forces: inverse(forward(x)) * n^-1 == x bit-exactly, linearity, and
+    spot checks of single outputs by Horner evaluation X_j = f(omega^j)."""
+    import torch
+    o = pyref
+    n = 1 << k
+    w, winv = o.fr_omega(k), pow(o.fr_omega(k), -1, o.R)
+    x = rand_fr_gpu(n, 5)
+    y = x.clone()
+    h.best_fft(y, o.fr_array([w])[0], k)
+    # spot checks against the oracle's Horner evaluation (bounded: 2 points)
+    xh = x.cpu().numpy().view(np.uint64)
+    yh = y.cpu().numpy().view(np.uint64)
+    if k <= 20:
+        for j in (1, n - 3):
+            pt = o.fr_array([pow(w, j, o.R)])[0]
+            assert np.array_equal(cref.fr_horner(xh, pt), yh[j]), j
+    # linearity: NTT(x + x') == NTT(x) + NTT(x')  (checked on a slice with the oracle's field add)
+    x2 = rand_fr_gpu(n, 6)
+    y2 = x2.clone()
+    h.best_fft(y2, o.fr_array([w])[0], k)
+    sl = slice(12345, 12345 + 4096)
+    xs = torch.from_numpy(cref.fr_add(xh, x2.cpu().numpy().view(np.uint64)).view(np.int64)).cuda()
+    h.best_fft(xs, o.fr_array([w])[0], k)
+    assert np.array_equal(xs.cpu().numpy().view(np.uint64)[sl], cref.fr_add(yh[sl], y2.cpu().numpy().view(np.uint64)[sl]))
+    # round trip through the fused inverse (EvaluationDomain::ifft)
+    from halo2_experiments_amd import _lib
+    import ctypes
+    from halo2_experiments_amd.arithmetic import _ptr, _stream_ptr
+    _lib.check(_lib.load().hm_ifft_bn256_fr_dev(ctypes.c_void_p(y.data_ptr()), _ptr(fr_words(winv)), k,
+                                                 _ptr(fr_words(pow(n, -1, o.R))), ctypes.c_void_p(_stream_ptr(y))))
+    torch.cuda.synchronize()
+    assert torch.equal(y, x)
+
+
+def test_evaluation_domain_steps(cref, pyref):
+    """lagrange_to_coeff / coeff_to_extended / extended_to_coeff against the oracle's compositions."""
+    import torch
+    o = pyref
+    d = EvaluationDomain(j=7, k=10)
+    n, en = d.n, d.extended_len()
+    a = rand_fr_gpu(n, 42)
+    ah = a.cpu().numpy().view(np.uint64)
+    # lagrange_to_coeff = best_fft(omega_inv) then * n^-1
+    exp = cref.fr_mul(cref.best_fft(ah, fr_words(d.omega_inv), d.k, 4), np.tile(fr_words(d.ifft_divisor), (n, 1)))
+    coeff = d.lagrange_to_coeff(a.clone())
+    assert np.array_equal(coeff.cpu().numpy().view(np.uint64), exp)
+    # coeff_to_extended = zero-pad, a[i] *= zeta^(i%3), best_fft(extended_omega)
+    pad = np.zeros((en, 4), dtype=np.uint64)
+    pad[:n] = exp
+    zpow = [1, d.g_coset, d.g_coset * d.g_coset % o.R]
+    pat = np.stack([fr_words(zpow[i % 3]) for i in range(en)])
+    exp_ext = cref.best_fft(cref.fr_mul(pad, pat), fr_words(d.extended_omega), d.extended_k, 4)
+    ext = d.coeff_to_extended(coeff)
+    assert np.array_equal(ext.cpu().numpy().view(np.uint64), exp_ext)
+    # extended_to_coeff inverts it (and truncates to n * (j - 1) rows)
+    back = d.extended_to_coeff(ext.clone())
+    bh = back.cpu().numpy().view(np.uint64)
+    assert bh.shape[0] == n * 6
+    assert np.array_equal(bh[:n], exp) and not bh[n:].any()
