@@ -175,45 +175,101 @@ __global__ void msm_scan_blocks_kernel(uint32_t* __restrict__ blockhist, uint32_
   bcnt[idx] = run;
 }
 
-// single block: bucket offsets (exclusive scan of counts) and task offsets (ceil(count / L))
-__global__ __launch_bounds__(1024) void msm_scan_buckets_kernel(const uint32_t* __restrict__ bcnt,
-                                                                uint32_t* __restrict__ boff,
-                                                                uint32_t* __restrict__ toff,
-                                                                uint32_t* __restrict__ totals, uint32_t NBT, uint32_t L) {
-  __shared__ uint32_t s_pairs[1024], s_tasks[1024];
-  const uint32_t t = threadIdx.x;
-  const uint32_t per = (NBT + 1023) / 1024;
-  const uint32_t lo = t * per, hi = lo + per < NBT ? lo + per : NBT;
+// bucket offsets (exclusive scan of counts) and task offsets (exclusive scan of ceil(count / L)):
+// three small launches -- per-block sums, a one-block scan of those, per-block rescan + offset.
+constexpr int SCAN_THREADS = 256;
+constexpr int SCAN_ITEMS = 8;                       // items per lane; a block covers 2048 buckets
+constexpr int SCAN_BLOCK = SCAN_THREADS * SCAN_ITEMS;
+
+__device__ __forceinline__ void block_scan_pair(uint32_t& p, uint32_t& t, uint32_t* s_p, uint32_t* s_t) {
+  // inclusive scan over the block of (p, t); returns inclusive values in p, t
+  const uint32_t tid = threadIdx.x;
+  s_p[tid] = p;
+  s_t[tid] = t;
+  __syncthreads();
+  for (uint32_t off = 1; off < SCAN_THREADS; off <<= 1) {
+    uint32_t a = 0, b = 0;
+    if (tid >= off) { a = s_p[tid - off]; b = s_t[tid - off]; }
+    __syncthreads();
+    s_p[tid] += a;
+    s_t[tid] += b;
+    __syncthreads();
+  }
+  p = s_p[tid];
+  t = s_t[tid];
+}
+
+__global__ __launch_bounds__(SCAN_THREADS) void msm_scan_partial_kernel(const uint32_t* __restrict__ bcnt,
+                                                                        uint32_t* __restrict__ blocksums, uint32_t NBT,
+                                                                        uint32_t L) {
+  __shared__ uint32_t s_p[SCAN_THREADS], s_t[SCAN_THREADS];
+  const uint32_t base = blockIdx.x * SCAN_BLOCK + threadIdx.x * SCAN_ITEMS;
   uint32_t sp = 0, st = 0;
-  for (uint32_t i = lo; i < hi; ++i) {
-    const uint32_t c = bcnt[i];
+#pragma unroll
+  for (int k = 0; k < SCAN_ITEMS; ++k) {
+    const uint32_t c = base + k < NBT ? bcnt[base + k] : 0u;
     sp += c;
     st += (c + L - 1) / L;
   }
-  s_pairs[t] = sp;
-  s_tasks[t] = st;
-  __syncthreads();
-  for (uint32_t off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan
-    uint32_t a = 0, b = 0;
-    if (t >= off) { a = s_pairs[t - off]; b = s_tasks[t - off]; }
+  block_scan_pair(sp, st, s_p, s_t);
+  if (threadIdx.x == SCAN_THREADS - 1) {
+    blocksums[2 * blockIdx.x] = sp;
+    blocksums[2 * blockIdx.x + 1] = st;
+  }
+}
+
+// one block: exclusive scan of the per-block sums in place; totals[0] = pairs, totals[1] = tasks
+__global__ __launch_bounds__(SCAN_THREADS) void msm_scan_blocksums_kernel(uint32_t* __restrict__ blocksums, uint32_t nblocks,
+                                                                          uint32_t* __restrict__ totals) {
+  __shared__ uint32_t s_p[SCAN_THREADS], s_t[SCAN_THREADS];
+  uint32_t carry_p = 0, carry_t = 0;
+  for (uint32_t start = 0; start < nblocks; start += SCAN_THREADS) {
+    const uint32_t i = start + threadIdx.x;
+    uint32_t p = i < nblocks ? blocksums[2 * i] : 0u, t = i < nblocks ? blocksums[2 * i + 1] : 0u;
+    const uint32_t p0 = p, t0 = t;
+    block_scan_pair(p, t, s_p, s_t);
+    if (i < nblocks) {
+      blocksums[2 * i] = carry_p + p - p0;
+      blocksums[2 * i + 1] = carry_t + t - t0;
+    }
+    carry_p += s_p[SCAN_THREADS - 1];
+    carry_t += s_t[SCAN_THREADS - 1];
     __syncthreads();
-    s_pairs[t] += a;
-    s_tasks[t] += b;
-    __syncthreads();
   }
-  uint32_t rp = s_pairs[t] - sp, rt = s_tasks[t] - st;  // exclusive
-  for (uint32_t i = lo; i < hi; ++i) {
-    const uint32_t c = bcnt[i];
-    boff[i] = rp;
-    toff[i] = rt;
-    rp += c;
-    rt += (c + L - 1) / L;
+  if (threadIdx.x == 0) {
+    totals[0] = carry_p;
+    totals[1] = carry_t;
   }
-  if (t == 1023) {
-    totals[0] = s_pairs[1023];
-    totals[1] = s_tasks[1023];
+}
+
+__global__ __launch_bounds__(SCAN_THREADS) void msm_scan_final_kernel(const uint32_t* __restrict__ bcnt,
+                                                                      const uint32_t* __restrict__ blocksums,
+                                                                      uint32_t* __restrict__ boff, uint32_t* __restrict__ toff,
+                                                                      const uint32_t* __restrict__ totals, uint32_t NBT,
+                                                                      uint32_t L) {
+  __shared__ uint32_t s_p[SCAN_THREADS], s_t[SCAN_THREADS];
+  const uint32_t base = blockIdx.x * SCAN_BLOCK + threadIdx.x * SCAN_ITEMS;
+  uint32_t c[SCAN_ITEMS];
+  uint32_t sp = 0, st = 0;
+#pragma unroll
+  for (int k = 0; k < SCAN_ITEMS; ++k) {
+    c[k] = base + k < NBT ? bcnt[base + k] : 0u;
+    sp += c[k];
+    st += (c[k] + L - 1) / L;
   }
-  if (t == 0) toff[NBT] = s_tasks[1023];
+  const uint32_t sp0 = sp, st0 = st;
+  block_scan_pair(sp, st, s_p, s_t);
+  uint32_t rp = blocksums[2 * blockIdx.x] + sp - sp0, rt = blocksums[2 * blockIdx.x + 1] + st - st0;
+#pragma unroll
+  for (int k = 0; k < SCAN_ITEMS; ++k) {
+    if (base + k < NBT) {
+      boff[base + k] = rp;
+      toff[base + k] = rt;
+    }
+    rp += c[k];
+    rt += (c[k] + L - 1) / L;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) toff[NBT] = totals[1];
 }
 
 __global__ __launch_bounds__(SORT_THREADS) void msm_scatter_kernel(const int32_t* __restrict__ digits,
@@ -573,9 +629,11 @@ int msm_run(DeviceCtx& ctx, const uint32_t* d_scalars_ext, const uint32_t* d_xy,
   const double mean = (double)n / (double)NB;
   uint32_t L = (uint32_t)(mean + 4.0 * std::sqrt(mean) + 8.0);
   {
-    // small inputs: shorter tasks so that the launch still fills 256 CUs x 4 SIMDs x ~5 waves
-    const double fill = (double)n * W / 655360.0;
-    if ((double)L > fill) L = (uint32_t)fill;
+    // small inputs: if one task per bucket would leave the chip (256 CUs x 4 SIMDs x ~5 waves x 64
+    // lanes) mostly idle, cut the tasks shorter so that the launch still fills it
+    const double target_tasks = 327680.0;
+    const double pairs = (double)n * W;
+    if (pairs / (double)L < target_tasks) L = (uint32_t)(pairs / target_tasks);
   }
   if (L < 16) L = 16;
   uint32_t G = (uint32_t)((n + 16383) / 16384);
@@ -598,6 +656,7 @@ int msm_run(DeviceCtx& ctx, const uint32_t* d_scalars_ext, const uint32_t* d_xy,
   const size_t o_boff = carve((size_t)NBT * 4);
   const size_t o_toff = carve(((size_t)NBT + 1) * 4);
   const size_t o_tot = carve(16);
+  const size_t o_bsum = carve(((size_t)NBT / SCAN_BLOCK + 2) * 8);
   const size_t o_sorted = carve(pairs_max * 4);
   const size_t o_tb = carve(T_max * 4);
   const size_t o_partial = carve(T_max * PT_WORDS * 4);
@@ -613,6 +672,7 @@ int msm_run(DeviceCtx& ctx, const uint32_t* d_scalars_ext, const uint32_t* d_xy,
   uint32_t* d_boff = (uint32_t*)(ws + o_boff);
   uint32_t* d_toff = (uint32_t*)(ws + o_toff);
   uint32_t* d_tot = (uint32_t*)(ws + o_tot);
+  uint32_t* d_bsum = (uint32_t*)(ws + o_bsum);
   uint32_t* d_sorted = (uint32_t*)(ws + o_sorted);
   uint32_t* d_tb = (uint32_t*)(ws + o_tb);
   uint32_t* d_partial = (uint32_t*)(ws + o_partial);
@@ -647,9 +707,15 @@ int msm_run(DeviceCtx& ctx, const uint32_t* d_scalars_ext, const uint32_t* d_xy,
   HM_HIP_CHECK(hipGetLastError());
   hipLaunchKernelGGL(msm_scan_blocks_kernel, dim3((NBT + 255) / 256), dim3(256), 0, stream, d_bh, d_bcnt, G, NBP, W);
   HM_HIP_CHECK(hipGetLastError());
-  hipLaunchKernelGGL(msm_scan_buckets_kernel, dim3(1), dim3(1024), 0, stream, (const uint32_t*)d_bcnt, d_boff, d_toff,
-                     d_tot, NBT, L);
-  HM_HIP_CHECK(hipGetLastError());
+  {
+    const uint32_t nblocks = (NBT + SCAN_BLOCK - 1) / SCAN_BLOCK;
+    hipLaunchKernelGGL(msm_scan_partial_kernel, dim3(nblocks), dim3(SCAN_THREADS), 0, stream, (const uint32_t*)d_bcnt,
+                       d_bsum, NBT, L);
+    hipLaunchKernelGGL(msm_scan_blocksums_kernel, dim3(1), dim3(SCAN_THREADS), 0, stream, d_bsum, nblocks, d_tot);
+    hipLaunchKernelGGL(msm_scan_final_kernel, dim3(nblocks), dim3(SCAN_THREADS), 0, stream, (const uint32_t*)d_bcnt,
+                       (const uint32_t*)d_bsum, d_boff, d_toff, (const uint32_t*)d_tot, NBT, L);
+    HM_HIP_CHECK(hipGetLastError());
+  }
   hipLaunchKernelGGL(msm_scatter_kernel, dim3(G, W), dim3(SORT_THREADS), lds_hist, stream, (const int32_t*)d_digits,
                      (const uint32_t*)d_bh, (const uint32_t*)d_boff, d_sorted, n, chunk, NBP);
   HM_HIP_CHECK(hipGetLastError());
