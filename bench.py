@@ -73,6 +73,23 @@ def cpu_baseline(log_sample, device):
             "agrees_with_gpu": ok}
 
 
+def pmc_traffic(kernel, corrected):
+    """HBM bytes per launch from the committed rocprofv3 --pmc summary (tools/pmc_traffic.sh, separate
+    FETCH_SIZE / WRITE_SIZE passes of this same command).  `corrected` applies the gfx950 x2 on
+    FETCH_SIZE, which MI355X_MICROARCH.md calibrates for wide coalesced streams only (true for the NTT
+    passes, checked: 2 x 258 MiB + 512 MiB = one read + one write of the array); the MSM accumulation
+    kernel reads by 64-byte gathers, an uncalibrated shape, so its raw counter sum is reported."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    try:
+        with open(path) as f:
+            d = json.load(f)[kernel]
+        if corrected:
+            return d["hbm_bytes_per_launch_corrected"]
+        return (d["FETCH_SIZE_KiB_per_launch"] + d["WRITE_SIZE_KiB_per_launch"]) * 1024.0
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -83,6 +100,8 @@ def main():
     ap.add_argument("--cpu-log-sample", type=int, default=21)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ntt", action="store_true")
+    ap.add_argument("--replay", default="merkle_sum_tree_k18",
+                    help="create_proof MSM/NTT trace to replay after the timed MSM steps ('none' to skip)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -163,8 +182,18 @@ def main():
         gbs = (NTT_BYTES_PER_ELEM << k) / (ms * 1e-3) / 1e9
         ntt = {"log_n": k, "ms": ms, "elements_per_s": (1 << k) / (ms * 1e-3),
                "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                            "traffic": None, "note": "3 digit passes: actual HBM traffic is 3x the algorithmic 64 B/element"}}
+                            "traffic": (pmc_traffic("hm::ntt_pass_kernel<11>", True) if k == 24 else None),
+                            "note": "traffic is per pass launch; 3 digit passes => 3x the algorithmic 64 B/element per transform; "
+                                    "VALU-issue bound (~4.9e3 32-bit ops per element)"}}
         del a
+
+    replay = None
+    if args.replay != "none":
+        from halo2_experiments_amd.replay import run_replay
+        h.release_bases(handle)
+        del scalars
+        torch.cuda.empty_cache()
+        replay = run_replay(args.replay, device=device)       # every rank takes part (MSMs are sharded)
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -193,7 +222,10 @@ def main():
                        "window_bits": st["window_bits"], "windows": st["windows"], "parallelism": f"index-range shards x{world}, "
                        "all-gather of 96 B partials (RCCL) + host fold"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": (pmc_traffic("hm::msm_accumulate_kernel", False) if args.log_points == 24 else None),
+                         "traffic_note": "raw FETCH_SIZE+WRITE_SIZE (64-byte gathers: gfx950 x2 read correction not calibrated for this "
+                                         "shape); every base is gathered once per window (W = 16), inherent to bucketed Pippenger",
                          "kernel": "msm_accumulate_kernel", "kernel_ms": acc,
                          "note": "integer-VALU bound (SURVEY.md §8d): ~2.7e8 mixed additions x ~2.9e3 32-bit ops per launch"},
             "msm_phase_ms": {"sort": float(np.mean(sort_ms)), "accumulate_kernel": acc, "device_total": float(np.mean(tot_ms))},
@@ -201,6 +233,8 @@ def main():
         }
         if ntt is not None:
             line["ntt"] = ntt
+        if replay is not None:
+            line["create_proof_replay"] = replay
         if cpu is not None:
             line["cpu_baseline"] = cpu
         print(json.dumps(line))

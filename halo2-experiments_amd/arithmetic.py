@@ -164,5 +164,16 @@ def msm_stats() -> dict:
     return {k: getattr(st, k) for k, _ in st._fields_}
 
 
+FQ_MODULUS = 0x30644E72E131A029B85045B68181585D97816A916871CA8D3C208C16D87CFD47
+
+
+def fq_words(v: int) -> np.ndarray:
+    """Canonical integer -> 4 Montgomery limbs of Fq (the bytes Rust's ``Fq`` holds)."""
+    m = (v % FQ_MODULUS) * (1 << 256) % FQ_MODULUS
+    return np.array([(m >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)], dtype=np.uint64)
+
+
 # Montgomery one of Fq (2^256 mod p): the z coordinate of a normalised G1
-FQ_ONE_MONT = np.array([0xD35D438DC58F0D9D, 0x0A78EB28F5C70B3D, 0x666EA36F7879462C, 0x0E0A77C19A07DF2F], dtype=np.uint64)
+FQ_ONE_MONT = fq_words(1)
+# bn256::G1Affine::generator() = (1, 2)
+G1_GENERATOR = np.concatenate([fq_words(1), fq_words(2)])

@@ -1,0 +1,180 @@
+"""Replay of ``create_proof``'s MSM / NTT call trace (BASELINE.json configs 2-4).
+
+The Rust prover cannot be built in this image, so end-to-end numbers come from replaying the
+sequence of ``best_multiexp`` / ``EvaluationDomain`` calls that ``create_proof`` issues for a
+circuit of a given shape (upstream ``halo2_proofs/src/plonk/prover.rs`` at the tag
+pinned by /root/reference/Cargo.toml:10), on synthetic polynomials: dense columns uniform in
+[0, r); sparse columns zero except ``used_rows`` small values and the last 6 (blinding) rows.
+The column counts are the estimates of SURVEY.md §3.2 -- labelled as such in the output; a Rust
+build of the shim would replace them with counted calls.
+
+What is replayed per proof (A advice, L lookups, P equality columns, max degree d, n = 2^k,
+extended domain 2^ek with ek = k + ceil(log2(d-1))):
+    commit_lagrange (MSM n)   A advice (sparse) + 2L permuted (sparse) + Zp + L grand products + 1 random
+    commit          (MSM n)   (d-1) quotient pieces + 2 SHPLONK polynomials
+    lagrange_to_coeff (iNTT n, scale fused)          A + 1 instance + 3L + Zp
+    coeff_to_extended (coset NTT 2^ek, shift fused)  A + 1 + 3L + Zp
+    extended_to_coeff (iNTT 2^ek)                    1
+Everything else in ``create_proof`` (witness synthesis, ``evaluate_h``'s gate arithmetic, Horner
+evaluations, the transcript) stays on the CPU in the reference and is NOT part of this number.
+"""
+from __future__ import annotations
+
+import math
+import time
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+
+from .arithmetic import G1_GENERATOR, best_multiexp, g1_fixed_base_mul, register_bases, release_bases
+from .domain import EvaluationDomain, FR_MODULUS, fr_words
+from .sharding import shard_range, sharded_multiexp
+
+
+@dataclass(frozen=True)
+class CircuitShape:
+    name: str
+    k: int
+    advice: int
+    lookups: int
+    equality_columns: int
+    max_degree: int
+    used_rows: int
+    source: str
+
+
+# SURVEY.md §3.2 / §8d estimates (reference files named there)
+SHAPES = {
+    "poseidon_k11": CircuitShape("Poseidon (config 2)", 11, 6, 0, 5, 7, 40,
+                                 "chips/poseidon/hash.rs:50-57; estimate"),
+    "merkle_v3_k17": CircuitShape("MerkleTreeV3 depth 20 (config 3)", 17, 8, 0, 6, 7, 840,
+                                  "chips/merkle_v3.rs:5-7,70-73; estimate"),
+    "merkle_sum_tree_k18": CircuitShape("MerkleSumTree depth 20 (config 4)", 18, 20, 8, 12, 7, 1100,
+                                        "chips/merkle_sum_tree.rs:32-138; estimate"),
+}
+
+
+def _rand_fr(n, seed, device):
+    import torch
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    x = torch.randint(-(2 ** 63), 2 ** 63 - 1, (n, 4), dtype=torch.int64, device=device, generator=g)
+    x[:, 3] &= 0x0FFFFFFFFFFFFFFF
+    return x
+
+
+def _sparse_column(n, used_rows, seed, device):
+    """Zero except `used_rows` leading small values (half of them the constant 1 -- the hot-bucket
+    worst case of selector / flag columns -- half random 16-bit integers) and 6 random blinding
+    rows, in Montgomery form like every ``Fr`` the prover holds."""
+    import ctypes
+
+    import torch
+
+    from . import _lib
+    from .arithmetic import _ptr, _stream_ptr
+    col = torch.zeros((n, 4), dtype=torch.int64, device=device)
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    col[:used_rows, 0] = torch.randint(1, 1 << 16, (used_rows,), dtype=torch.int64, device=device, generator=g)
+    col[: used_rows // 2, 0] = 1
+    # raw word v read as a Montgomery word is the field element v / R; times R gives v, stored as v*R
+    _lib.check(_lib.load().hm_fr_scale_dev(ctypes.c_void_p(col.data_ptr()), n, _ptr(fr_words((1 << 256) % FR_MODULUS)),
+                                           ctypes.c_void_p(_stream_ptr(col))))
+    col[n - 6:] = _rand_fr(6, seed + 1, device)
+    return col
+
+
+def run_replay(shape_name: str, device=None, group=None, include_host_pointer_estimate: bool = True) -> dict:
+    import torch
+    import torch.distributed as dist
+
+    shape = SHAPES[shape_name]
+    device = device or torch.device("cuda", torch.cuda.current_device())
+    world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+    rank = dist.get_rank(group) if world > 1 else 0
+    k, n = shape.k, 1 << shape.k
+    dom = EvaluationDomain(shape.max_degree, k)
+    d = shape.max_degree
+    zp = math.ceil(shape.equality_columns / (d - 2))
+    A, L = shape.advice, shape.lookups
+    counts = {
+        "msm_sparse": A + 2 * L, "msm_dense": zp + L + 1 + (d - 1) + 2,
+        "intt_n": A + 1 + 3 * L + zp, "coset_ntt_ext": A + 1 + 3 * L + zp, "intt_ext": 1,
+    }
+
+    # resident SRS slices for this rank: g and g_lagrange (random points: timing does not depend on them)
+    lo, hi = shard_range(n, rank, world)
+    gen = G1_GENERATOR
+    g_h = register_bases(g1_fixed_base_mul(_rand_fr(hi - lo, 17 + rank, device), gen))
+    gl_h = register_bases(g1_fixed_base_mul(_rand_fr(hi - lo, 1717 + rank, device), gen))
+    dense = [_rand_fr(n, 100 + i, device) for i in range(2)]
+    sparse = [_sparse_column(n, shape.used_rows, 200 + i, device) for i in range(2)]
+
+    def msm(col, handle):
+        return sharded_multiexp(col[lo:hi].contiguous() if world > 1 else col, handle, group=group)
+
+    def proof_once():
+        t = {"msm": 0.0, "ntt": 0.0}
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(counts["msm_sparse"]):
+            msm(sparse[i & 1], gl_h)
+        for i in range(counts["msm_dense"]):
+            msm(dense[i & 1], g_h if i >= counts["msm_dense"] - (d - 1) - 2 else gl_h)
+        torch.cuda.synchronize()
+        t["msm"] = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        if rank == 0:                                   # NTT stays single-GPU (north star)
+            for i in range(counts["intt_n"]):
+                dom.lagrange_to_coeff(dense[i & 1])
+            ext = None
+            for i in range(counts["coset_ntt_ext"]):
+                ext = dom.coeff_to_extended(dense[i & 1])
+            for _ in range(counts["intt_ext"]):
+                dom.extended_to_coeff(ext)
+        torch.cuda.synchronize()
+        t["ntt"] = time.perf_counter() - t0
+        return t
+
+    proof_once()                                        # warm-up: tables, workspaces
+    if world > 1:
+        dist.barrier(group)
+    t0 = time.perf_counter()
+    phases = proof_once()
+    if world > 1:
+        dist.barrier(group)
+    wall = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([wall], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX, group=group)
+        wall = float(tt.item())
+
+    out = {
+        "circuit": shape.name, "k": k, "extended_k": dom.extended_k, "n_gpus": world,
+        "shape": {"advice": A, "lookups": L, "equality_columns": shape.equality_columns, "max_degree": d,
+                  "source": shape.source},
+        "calls": counts,
+        "device_resident_s": {"msm": phases["msm"], "ntt": phases["ntt"], "total": wall},
+        "note": "MSM/NTT trace replay on synthetic polynomials (no Rust toolchain here); CPU-side parts of create_proof excluded",
+    }
+    if include_host_pointer_estimate and world == 1:
+        # the drop-in (host-pointer) cost of the same trace: one representative call of each kind
+        import ctypes
+        h_s = dense[0].cpu().numpy().view(np.uint64)
+        t0 = time.perf_counter(); best_multiexp(h_s, gl_h); t_msm = time.perf_counter() - t0
+        from .arithmetic import best_fft
+        a_n = h_s.copy()
+        t0 = time.perf_counter(); best_fft(a_n, fr_words(dom.omega), k); t_ntt_n = time.perf_counter() - t0
+        a_e = np.zeros((dom.extended_len(), 4), dtype=np.uint64); a_e[:n] = h_s
+        best_fft(a_e, fr_words(dom.extended_omega), dom.extended_k)
+        t0 = time.perf_counter(); best_fft(a_e, fr_words(dom.extended_omega), dom.extended_k); t_ntt_e = time.perf_counter() - t0
+        out["host_pointer_estimate_s"] = {
+            "msm_each": t_msm, "ntt_n_each": t_ntt_n, "ntt_ext_each": t_ntt_e,
+            "total": t_msm * (counts["msm_sparse"] + counts["msm_dense"]) + t_ntt_n * counts["intt_n"]
+                     + t_ntt_e * (counts["coset_ntt_ext"] + counts["intt_ext"]),
+            "note": "PCIe-inclusive: every call uploads its scalars / moves its array both ways"}
+    release_bases(g_h)
+    release_bases(gl_h)
+    return out
