@@ -147,7 +147,8 @@ def run_replay(shape_name: str, device=None, group=None, include_host_pointer_es
         dist.barrier(group)
     wall = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([wall], dtype=torch.float64, device=device)
+        comm_dev = device if dist.get_backend(group) == "nccl" else torch.device("cpu")
+        tt = torch.tensor([wall], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX, group=group)
         wall = float(tt.item())
 
