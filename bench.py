@@ -100,8 +100,9 @@ def main():
     ap.add_argument("--cpu-log-sample", type=int, default=21)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ntt", action="store_true")
-    ap.add_argument("--replay", default="merkle_sum_tree_k18",
-                    help="create_proof MSM/NTT trace to replay after the timed MSM steps ('none' to skip)")
+    ap.add_argument("--replay", default="poseidon_k11,merkle_v3_k17,merkle_sum_tree_k18",
+                    help="comma-separated create_proof MSM/NTT traces to replay after the timed MSM steps ('none' to skip)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the prover-like and host-pointer MSM side measurements")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -196,13 +197,45 @@ def main():
                                     "VALU-issue bound (~4.9e3 32-bit ops per element)"}}
         del a
 
+    # ---- side measurements: prover-like scalars; the PCIe-inclusive drop-in call ----
+    extras = None
+    if not args.no_extras and world == 1:
+        extras = {}
+        u = torch.rand(n_local, device=device, generator=torch.Generator(device=device).manual_seed(7))
+        pl = scalars.clone()
+        pl[u < 0.95, 1:] = 0                                   # 5 % stay uniform
+        pl[u < 0.95, 0] &= 0xFFFF                              # 5 % below 2^16 ...
+        pl[u < 0.90] = 0                                       # ... 90 % zero
+        # raw small words are not Montgomery form: scale by R so the canonical values are the small ones
+        from halo2_experiments_amd.domain import FR_MODULUS, fr_words
+        from halo2_experiments_amd.arithmetic import _ptr, _stream_ptr
+        _lib.check(_lib.load().hm_fr_scale_dev(ctypes.c_void_p(pl.data_ptr()), n_local, _ptr(fr_words((1 << 256) % FR_MODULUS)),
+                                               ctypes.c_void_p(_stream_ptr(pl))))
+        uni = u >= 0.95
+        pl[uni] = scalars[uni]
+        h.best_multiexp(pl, handle)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(3):
+            h.best_multiexp(pl, handle)
+        dt = (time.perf_counter() - t1) / 3
+        extras["msm_prover_like"] = {"points_per_s": n_local / dt, "ms": dt * 1e3, "pairs": h.msm_stats()["pairs"],
+                                     "scalars": "90 % zero, 5 % < 2^16, 5 % uniform"}
+        del pl, u, uni
+        hs = scalars.cpu().numpy().view(np.uint64)
+        t1 = time.perf_counter()
+        h.best_multiexp(hs, handle)
+        extras["msm_host_pointer"] = {"ms": (time.perf_counter() - t1) * 1e3,
+                                      "note": "hm_msm_bn256_g1_h: scalars cross PCIe in the call (pageable host memory); never `value`"}
+        del hs
+
     replay = None
     if args.replay != "none":
         from halo2_experiments_amd.replay import run_replay
         h.release_bases(handle)
         del scalars
         torch.cuda.empty_cache()
-        replay = run_replay(args.replay, device=device)       # every rank takes part (MSMs are sharded)
+        replay = [run_replay(name, device=device) for name in args.replay.split(",")]   # every rank takes part
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -242,6 +275,8 @@ def main():
         }
         if ntt is not None:
             line["ntt"] = ntt
+        if extras is not None:
+            line.update(extras)
         if replay is not None:
             line["create_proof_replay"] = replay
         if cpu is not None:

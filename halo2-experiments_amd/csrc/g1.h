@@ -2,7 +2,7 @@
 //
 // Coordinates are kept in the internal Montgomery form of ff29.h.  "Class" bounds (checked for
 // every formula by the HM_BOUNDS host build, see tests/test_ff29_host.py):
-//     Jacobian point:  X, Y normalised limbs, value < G1_XYB * p;  Z a product output (< 2p)
+//     Jacobian point:  X, Y normalised limbs, X < HM_G1_XB * p, Y < HM_G1_YB * p;  Z a product output (< 2p)
 //     affine operand:  x, y product outputs (< 2p)
 // Identity is carried as an explicit flag (never encoded in Z) so the hot loop has no compare
 // against zero; the exceptional cases of the addition law (P = Q, P = -Q) are detected from
@@ -27,14 +27,15 @@ struct G1Jac {
   bool inf;
 };
 
-// class bound on stored X, Y (multiples of p); the subtraction constants below are chosen against it
-#define HM_G1_XYB 12.0
+// class bounds on stored X and Y (multiples of p); the subtraction constants below are chosen against them
+#define HM_G1_XB 12.0
+#define HM_G1_YB 5.0
 #define HM_G1_ZB 2.0
 
 #ifdef HM_BOUNDS
 inline void g1_check_class(const G1Jac& p, const char* what) {
   HM_CHECK(p.x.lb <= MASK29 && p.y.lb <= MASK29 && p.z.lb <= MASK29, what);
-  HM_CHECK(p.x.vb <= HM_G1_XYB && p.y.vb <= HM_G1_XYB && p.z.vb <= HM_G1_ZB, what);
+  HM_CHECK(p.x.vb <= HM_G1_XB && p.y.vb <= HM_G1_YB && p.z.vb <= HM_G1_ZB, what);
 }
 #define HM_G1_CHECK(p, what) g1_check_class(p, what)
 #else
@@ -80,24 +81,24 @@ HM_HD G1Aff g1_cneg_affine(const G1Aff& p, bool neg) {
   return r;
 }
 
-// Doubling for a = 0 (dbl-2009-l with D = 4*X*Y^2 taken as a product so that no stored
-// coordinate inherits a large subtraction constant): 3M + 4S.  p must not be the identity.
+// Doubling for a = 0 (dbl-2009-l; D = 4*X*Y^2 taken as a product, and X3, Y3 produced by fused
+// products so that they are reduction outputs): p must not be the identity.
 HM_HD G1Jac g1_double_nz(const G1Jac& p) {
   HM_G1_CHECK(p, "g1_double_nz input outside class");
+  const Fq one = fe_one<FqParams>();
   const Fq A = fe_sqr(p.x);                                  // X^2
   const Fq B = fe_sqr(p.y);                                  // Y^2
   const Fq C = fe_sqr(B);                                    // Y^4
   const Fq S = fe_mul(p.x, B);                               // X*Y^2
   const Fq D = fe_norm(fe_mul4(S));                          // D = 4*X*Y^2
   const Fq E = fe_norm(fe_add(fe_dbl(A), A));                // E = 3*X^2
-  const Fq Fv = fe_sqr(E);
-  const Fq twoD = fe_dbl(D);                                 // 2D (limbs < 2^30)
+  const Fq n2d = fe_sub<10, 30>(fe_zero<FqParams>(), fe_dbl(D));   // -2D  (limbs < 2^31)
   G1Jac r;
-  r.x = fe_norm(fe_sub<10, 30>(Fv, twoD));                   // X3 = E^2 - 2D
-  const Fq dx = fe_norm(fe_sub<12, 29>(D, r.x));             // D - X3
-  const Fq ed = fe_mul(E, dx);
+  r.x = fe_mul2(E, E, n2d, one);                             // X3 = E^2 - 2D
+  const Fq dx = fe_norm(fe_sub<3, 29>(D, r.x));              // D - X3
   const Fq c8 = fe_dbl(fe_norm(fe_mul4(C)));                 // 8*Y^4 (limbs < 2^30)
-  r.y = fe_norm(fe_sub<9, 30>(ed, c8));                      // Y3 = E(D - X3) - 8C
+  const Fq n8c = fe_sub<9, 30>(fe_zero<FqParams>(), c8);     // -8C
+  r.y = fe_mul2(E, dx, n8c, one);                            // Y3 = E(D - X3) - 8C
   r.z = fe_mul(fe_dbl(p.y), p.z);                            // Z3 = 2*Y*Z
   r.inf = false;
   return r;
@@ -108,24 +109,35 @@ HM_HD G1Jac g1_double(const G1Jac& p) {
   return g1_double_nz(p);
 }
 
-// madd-2007-bl re-associated (8M + 3S): acc (Jacobian, class bounds) + q (affine, product outputs).
-// Neither operand may be the identity; the result may be.
-HM_HD G1Jac g1_madd_nz(const G1Jac& p, const G1Aff& q) {
+// madd-2007-bl re-associated: acc (Jacobian, class bounds) + (neg ? -q : q), q affine with product-
+// output coordinates.  7M + 3S + one fused double product; the sign is applied to S2 = y2*Z1^3
+// (the only place y2 enters), so negating the operand costs 18 instructions instead of a
+// subtraction and a renormalisation.  Neither operand may be the identity; the result may be.
+HM_HD G1Jac g1_madd_nz(const G1Jac& p, const G1Aff& q, bool neg = false) {
   HM_G1_CHECK(p, "g1_madd_nz input outside class");
   const Fq z1z1 = fe_sqr(p.z);
   const Fq u2 = fe_mul(q.x, z1z1);
-  const Fq s2 = fe_mul(q.y, fe_mul(p.z, z1z1));
+  const Fq s2p = fe_mul(q.y, fe_mul(p.z, z1z1));
+  Fq s2;                                                      // +-S2, limbs <= 2^30
+  {
+    const Fq s2n = fe_sub<3, 29>(fe_zero<FqParams>(), s2p);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) s2.l[i] = neg ? s2n.l[i] : s2p.l[i];
+#ifdef HM_BOUNDS
+    s2.vb = s2n.vb; s2.lb = s2n.lb; s2.tb = s2n.tb;
+#endif
+  }
   const Fq h = fe_norm(fe_sub<13, 29>(u2, p.x));             // U2 - X1
   const Fq hh = fe_sqr(h);
   if (fe_is_zero_mod(hh)) {                                  // X1 = U2: doubling or inverse
-    const Fq r0 = fe_norm(fe_sub<13, 29>(s2, p.y));
+    const Fq r0 = fe_norm(fe_sub<6, 29>(s2, p.y));
     const Fq rr0 = fe_sqr(r0);
     if (fe_is_zero_mod(rr0)) return g1_double_nz(p);
     return g1_identity();
   }
   const Fq i4 = fe_mul4(hh);                                 // I = 4*HH   (limbs < 2^31)
   const Fq j = fe_mul(h, i4);
-  const Fq r0 = fe_norm(fe_sub<13, 29>(s2, p.y));            // (S2 - Y1)
+  const Fq r0 = fe_norm(fe_sub<6, 29>(s2, p.y));             // +-S2 - Y1
   const Fq r = fe_dbl(r0);                                   // r = 2(S2 - Y1)  (limbs < 2^30)
   const Fq v = fe_mul(p.x, i4);
   const Fq rr = fe_sqr(r);
@@ -133,20 +145,19 @@ HM_HD G1Jac g1_madd_nz(const G1Jac& p, const G1Aff& q) {
   G1Jac o;
   o.x = fe_norm(fe_sub<6, 31>(rr, t2));                      // r^2 - J - 2V
   const Fq vx = fe_norm(fe_sub<13, 29>(v, o.x));             // V - X3
-  const Fq m1 = fe_mul(r0, vx);
-  const Fq m2 = fe_mul(p.y, j);
-  o.y = fe_norm(fe_dbl(fe_sub<3, 29>(m1, m2)));              // 2(r0 (V - X3) - Y1 J)
+  const Fq ny2 = fe_dbl(fe_sub<6, 29>(fe_zero<FqParams>(), p.y));   // -2*Y1 (limbs < 2^31)
+  o.y = fe_mul2(r, vx, ny2, j);                              // r (V - X3) - 2 Y1 J
   o.z = fe_mul(p.z, fe_dbl(h));                              // 2 Z1 H
   o.inf = false;
   return o;
 }
 
-HM_HD G1Jac g1_madd(const G1Jac& p, const G1Aff& q) {
-  if (p.inf) return g1_from_affine(q);
-  return g1_madd_nz(p, q);
+HM_HD G1Jac g1_madd(const G1Jac& p, const G1Aff& q, bool neg = false) {
+  if (p.inf) return g1_from_affine(neg ? g1_neg_affine(q) : q);
+  return g1_madd_nz(p, q, neg);
 }
 
-// add-2007-bl re-associated (12M + 4S): both Jacobian, neither the identity.
+// add-2007-bl re-associated (11M + 4S + one fused double product): both Jacobian, neither the identity.
 HM_HD G1Jac g1_add_nz(const G1Jac& p, const G1Jac& q) {
   HM_G1_CHECK(p, "g1_add_nz input p outside class");
   HM_G1_CHECK(q, "g1_add_nz input q outside class");
@@ -174,9 +185,8 @@ HM_HD G1Jac g1_add_nz(const G1Jac& p, const G1Jac& q) {
   G1Jac o;
   o.x = fe_norm(fe_sub<4, 31>(rr, t2));
   const Fq vx = fe_norm(fe_sub<7, 29>(v, o.x));
-  const Fq m1 = fe_mul(r0, vx);
-  const Fq m2 = fe_mul(s1, j);
-  o.y = fe_norm(fe_dbl(fe_sub<3, 29>(m1, m2)));
+  const Fq ns1 = fe_dbl(fe_sub<3, 29>(fe_zero<FqParams>(), s1));   // -2*S1 (limbs < 2^31)
+  o.y = fe_mul2(r, vx, ns1, j);                              // r (V - X3) - 2 S1 J
   o.z = fe_mul(fe_mul(p.z, q.z), fe_dbl(h));                 // 2 Z1 Z2 H
   o.inf = false;
   return o;

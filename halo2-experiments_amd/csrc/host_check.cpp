@@ -53,8 +53,8 @@ void store_jac(uint64_t* p, int* inf, const G1Jac& r) {
   *inf = 0;
 }
 void at_class_max(G1Jac& p) {
-  force_bounds(p.x, HM_G1_XYB);
-  force_bounds(p.y, HM_G1_XYB);
+  force_bounds(p.x, HM_G1_XB);
+  force_bounds(p.y, HM_G1_YB);
   force_bounds(p.z, HM_G1_ZB);
 }
 
@@ -106,8 +106,7 @@ void hc_g1_madd(const uint64_t* pj, int pinf, const uint64_t* q_aff, int neg, ui
   G1Aff q;
   q.x = load_ext<FqParams>(q_aff);
   q.y = load_ext<FqParams>(q_aff + 4);
-  q = g1_cneg_affine(q, neg != 0);
-  store_jac(out, out_inf, g1_madd(p, q));
+  store_jac(out, out_inf, g1_madd(p, q, neg != 0));
 }
 void hc_g1_add(const uint64_t* pj, int pinf, const uint64_t* qj, int qinf, uint64_t* out, int* out_inf) {
   store_jac(out, out_inf, g1_add(load_jac(pj, pinf), load_jac(qj, qinf)));
@@ -137,14 +136,13 @@ int hc_bounds_closure(const uint64_t* pj, const uint64_t* qj, const uint64_t* q_
   q.y = load_ext<FqParams>(q_aff + 4);
   force_bounds(q.x, 2.0);
   force_bounds(q.y, 2.0);
-  q = g1_cneg_affine(q, true);
-  G1Jac r[3] = {g1_madd_nz(p, q), g1_add_nz(p, q2), g1_double_nz(p)};
+  G1Jac r[3] = {g1_madd_nz(p, q, true), g1_add_nz(p, q2), g1_double_nz(p)};
   int ok = 1;
   for (int i = 0; i < 3; ++i) {
     report[3 * i + 0] = r[i].x.vb;
     report[3 * i + 1] = r[i].y.vb;
     report[3 * i + 2] = r[i].z.vb;
-    if (r[i].x.vb > HM_G1_XYB || r[i].y.vb > HM_G1_XYB || r[i].z.vb > HM_G1_ZB) ok = 0;
+    if (r[i].x.vb > HM_G1_XB || r[i].y.vb > HM_G1_YB || r[i].z.vb > HM_G1_ZB) ok = 0;
     if (r[i].x.lb > MASK29 || r[i].y.lb > MASK29 || r[i].z.lb > MASK29) ok = 0;
   }
   return ok;

@@ -306,6 +306,20 @@ __global__ void msm_task_fill_kernel(const uint32_t* __restrict__ toff, uint32_t
 // ---------------------------------------------------------------------------------------------
 constexpr int ACC_THREADS = 64;
 
+typedef __attribute__((address_space(3))) void hm_lds_void;
+typedef __attribute__((address_space(1))) const void hm_gbl_void;
+
+// Start the gather of base `idx` into this lane's staging slots: four 16-byte LDS-DMA pieces
+// (global_load_lds_dwordx4: per-lane source address, destination = M0 base + 16 * lane), so the
+// 64-byte point of the NEXT iteration is in flight while the current mixed addition runs and costs
+// no VGPRs.
+__device__ __forceinline__ void stage_base_async(const uint32_t* xy, uint32_t idx, uint4 (*stage)[ACC_THREADS]) {
+  const uint4* src = reinterpret_cast<const uint4*>(xy + (size_t)idx * 16);
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    __builtin_amdgcn_global_load_lds((hm_gbl_void*)(src + k), (hm_lds_void*)&stage[k][0], 16, 0, 0);
+}
+
 __global__ __launch_bounds__(ACC_THREADS) void msm_accumulate_kernel(const uint32_t* __restrict__ sorted,
                                                                      const uint32_t* __restrict__ task_bucket,
                                                                      const uint32_t* __restrict__ boff,
@@ -313,25 +327,46 @@ __global__ __launch_bounds__(ACC_THREADS) void msm_accumulate_kernel(const uint3
                                                                      const uint32_t* __restrict__ toff,
                                                                      const uint32_t* __restrict__ xy,
                                                                      uint32_t* __restrict__ partial, uint32_t T, uint32_t L) {
-  const uint32_t t = blockIdx.x * ACC_THREADS + threadIdx.x;
-  if (t >= T) return;
-  const uint32_t b = task_bucket[t];
-  const uint32_t k = t - toff[b];
-  const uint32_t start = boff[b] + k * L;
-  const uint32_t bucket_end = boff[b] + bcnt[b];
-  const uint32_t end = start + L < bucket_end ? start + L : bucket_end;
+  __shared__ uint4 stage[4][ACC_THREADS];
+  const uint32_t lane = threadIdx.x;
+  const uint32_t t = blockIdx.x * ACC_THREADS + lane;
+  uint32_t start = 0, end = 0;
+  if (t < T) {
+    const uint32_t b = task_bucket[t];
+    const uint32_t k = t - toff[b];
+    start = boff[b] + k * L;
+    const uint32_t bucket_end = boff[b] + bcnt[b];
+    end = start + L < bucket_end ? start + L : bucket_end;
+  }
   G1Jac acc = g1_identity();
+  uint32_t v_cur = 0, v_next = 0;
+  if (start < end) {
+    v_cur = sorted[start];
+    stage_base_async(xy, v_cur & 0x7fffffffu, stage);
+    if (start + 1 < end) v_next = sorted[start + 1];
+  }
   for (uint32_t p = start; p < end; ++p) {
-    const uint32_t v = sorted[p];
-    G1Aff q = load_base(xy, v & 0x7fffffffu);
-    q = g1_cneg_affine(q, (v >> 31) != 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the staged point (and v_next) have landed
+    const uint4 a = stage[0][lane], b4 = stage[1][lane], c4 = stage[2][lane], d4 = stage[3][lane];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // ... and are in registers before the slots are reused
+    const bool neg = (v_cur >> 31) != 0;
+    if (p + 1 < end) {
+      v_cur = v_next;
+      stage_base_async(xy, v_cur & 0x7fffffffu, stage);       // next point: in flight during this addition
+      if (p + 2 < end) v_next = sorted[p + 2];
+    }
+    const uint32_t wx[8] = {a.x, a.y, a.z, a.w, b4.x, b4.y, b4.z, b4.w};
+    const uint32_t wy[8] = {c4.x, c4.y, c4.z, c4.w, d4.x, d4.y, d4.z, d4.w};
+    G1Aff q;
+    q.x = fe_unpack<FqParams>(wx);
+    q.y = fe_unpack<FqParams>(wy);
     if (acc.inf) {
-      acc = g1_from_affine(q);
+      acc = g1_from_affine(neg ? g1_neg_affine(q) : q);
     } else {
-      acc = g1_madd_nz(acc, q);
+      acc = g1_madd_nz(acc, q, neg);
     }
   }
-  store_jac(partial + (size_t)t * PT_WORDS, acc);
+  if (t < T) store_jac(partial + (size_t)t * PT_WORDS, acc);
 }
 
 // Workgroup-wide sum of one point per lane through an LDS tree; the result is valid in lane 0.

@@ -35,6 +35,20 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(skip)
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _init_torch_gpu_first():
+    """On a GPU box initialise torch's HIP context before the library makes its first HIP call."""
+    try:
+        if _device_count() > 0:
+            import torch
+            if torch.cuda.is_available():
+                torch.cuda.init()
+                torch.zeros(1, device="cuda")
+    except Exception:
+        pass
+    yield
+
+
 @pytest.fixture(scope="session")
 def cref():
     """The C restatement oracle (built on first use)."""
