@@ -74,6 +74,12 @@ def load() -> ctypes.CDLL:
             raise FileNotFoundError(
                 f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(there is no CPU fallback for the MSM/NTT path)")
+        try:
+            # torch bundles its own libamdhip64; if ours pulled /opt/rocm's copy in first, torch would
+            # later load a second HIP runtime and see no device.  Load torch's first when it exists.
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         lib = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(lib, name)

@@ -92,6 +92,8 @@ struct DeviceCtx {
   size_t cached_host_n = 0;
   uint64_t cached_probe[4] = {0, 0, 0, 0};
   MsmStats last_msm;
+  hipEvent_t msm_events[7] = {};
+  bool msm_events_ready = false;
   void* ensure_scratch(size_t bytes) { return scratch.ensure(bytes); }
 };
 

@@ -3,9 +3,9 @@
 //
 // Pipeline (all device-resident; one mid-pipeline 8-byte readback to size the task grid):
 //   K0  digits      scalar (radix-2^256 Montgomery) -> canonical -> W signed c-bit digits
-//   K2a hist        per-(chunk, window) bucket histogram in LDS (2^(c-1)+1 counters <= 128 KiB)
-//   K2b scan        per-bucket prefix over chunks, then bucket offsets + accumulation-task offsets
-//   K2c scatter     counting-sort scatter through LDS cursors -> point indices grouped by bucket
+//   K2  sort        two-level counting sort through LDS (coarse partition, then one workgroup per
+//                   region: fine histogram -> bucket counts; global scan -> bucket + task offsets;
+//                   in-region scatter) -> point indices grouped by bucket
 //   K3  accumulate  one lane per task (a bucket, or a <= L-long slice of a long bucket): a serial
 //                   chain of mixed additions, the accumulator living in registers
 //   K3b finalize    per bucket: sum of its task partials
@@ -22,6 +22,7 @@
 
 #include "g1.h"
 #include "hm_internal.h"
+#include "host_fq.h"
 
 namespace hm {
 
@@ -137,42 +138,185 @@ __global__ void msm_digits_kernel(const uint32_t* __restrict__ scalars, const ui
 }
 
 // ---------------------------------------------------------------------------------------------
-// K2: counting sort of (bucket, point index) per window through LDS
+// K2: grouping (bucket, point index) pairs by bucket -- a two-level counting sort through LDS.
+//
+// A one-level sort (every chunk scattering straight into 2^(c-1) bucket runs) writes each 32-byte
+// HBM sector from ~8 different workgroups at different times: 8x write amplification, measured
+// (profiles/r01_pmc_traffic.json: 8.2 GiB written for a 1 GiB index array).  Instead:
+//   part 1  partition by the HIGH `cb` bits of the bucket: each (chunk, window) workgroup appends
+//           its items to 2^cb coarse bins in ~1 KiB runs; an item is ONE 32-bit word
+//           [fine bucket bits | sign | point index].
+//   part 2  one workgroup per (coarse bin, window) owns a contiguous region of the final array:
+//           fine histogram in LDS -> bucket counts; after the global scan it scatters the items of
+//           its own region, so every sector is completed by one workgroup while still in L2.
+// When fine bits + sign + index bits fit 32 bits with cb = 0 (n <= 2^19) part 1 disappears and
+// part 2 reads the digits directly.
 // ---------------------------------------------------------------------------------------------
 constexpr int SORT_THREADS = 1024;
 
-__global__ __launch_bounds__(SORT_THREADS) void msm_hist_kernel(const int32_t* __restrict__ digits,
-                                                                uint32_t* __restrict__ blockhist, size_t n,
-                                                                size_t chunk, uint32_t NBP) {
+// Apply f(index, word) to base[lo .. hi) with the whole workgroup, 16 bytes per lane per load:
+// one 4-byte load in flight per lane keeps only ~1 MB outstanding chip-wide (latency-bound at
+// ~0.5 TB/s); four words per load quadruple the bytes in flight.
+template <class T, class F>
+__device__ __forceinline__ void block_for_each_word(const T* __restrict__ base, size_t lo, size_t hi, F f) {
+  size_t a = lo;
+  while (a < hi && (reinterpret_cast<uintptr_t>(base + a) & 15u)) ++a;      // aligned start
+  const size_t nvec = (hi - a) / 4;
+  if (threadIdx.x < a - lo) f(lo + threadIdx.x, base[lo + threadIdx.x]);     // <= 3 head words
+  const size_t tail = a + nvec * 4;
+  if (threadIdx.x < hi - tail) f(tail + threadIdx.x, base[tail + threadIdx.x]);   // <= 3 tail words
+  typedef T vec4 __attribute__((ext_vector_type(4)));
+  const vec4* vb = reinterpret_cast<const vec4*>(base + a);
+  for (size_t v = threadIdx.x; v < nvec; v += SORT_THREADS) {
+    const vec4 q = vb[v];
+    const size_t i = a + v * 4;
+    f(i, q.x);
+    f(i + 1, q.y);
+    f(i + 2, q.z);
+    f(i + 3, q.w);
+  }
+}
+
+__global__ __launch_bounds__(SORT_THREADS) void msm_part1_hist_kernel(const int32_t* __restrict__ digits,
+                                                                      uint32_t* __restrict__ chist, size_t n, size_t chunk,
+                                                                      uint32_t fb, uint32_t NC) {
   extern __shared__ uint32_t hist[];
   const uint32_t g = blockIdx.x, w = blockIdx.y, G = gridDim.x;
-  for (uint32_t b = threadIdx.x; b < NBP; b += SORT_THREADS) hist[b] = 0;
+  for (uint32_t b = threadIdx.x; b < NC; b += SORT_THREADS) hist[b] = 0;
   __syncthreads();
   const size_t lo = (size_t)g * chunk, hi = lo + chunk < n ? lo + chunk : n;
   const int32_t* dw = digits + (size_t)w * n;
-  for (size_t i = lo + threadIdx.x; i < hi; i += SORT_THREADS) {
-    const int32_t d = dw[i];
-    if (d != 0) atomicAdd(&hist[d < 0 ? -d : d], 1u);
-  }
+  block_for_each_word(dw, lo, hi, [&](size_t, int32_t d) {
+    if (d != 0) atomicAdd(&hist[((uint32_t)(d < 0 ? -d : d) - 1u) >> fb], 1u);
+  });
   __syncthreads();
-  uint32_t* out = blockhist + ((size_t)w * G + g) * NBP;
-  for (uint32_t b = threadIdx.x; b < NBP; b += SORT_THREADS) out[b] = hist[b];
+  uint32_t* out = chist + ((size_t)w * G + g) * NC;
+  for (uint32_t b = threadIdx.x; b < NC; b += SORT_THREADS) out[b] = hist[b];
 }
 
-// per (window, bucket): exclusive prefix over chunks in place, total into bcnt
-__global__ void msm_scan_blocks_kernel(uint32_t* __restrict__ blockhist, uint32_t* __restrict__ bcnt, uint32_t G,
-                                       uint32_t NBP, uint32_t W) {
+// per (window, coarse bin): exclusive prefix over chunks in place, total into ctot
+__global__ void msm_part1_scan_kernel(uint32_t* __restrict__ chist, uint32_t* __restrict__ ctot, uint32_t G, uint32_t NC,
+                                      uint32_t W) {
   const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= W * NBP) return;
-  const uint32_t w = idx / NBP, b = idx - w * NBP;
+  if (idx >= W * NC) return;
+  const uint32_t w = idx / NC, b = idx - w * NC;
   uint32_t run = 0;
   for (uint32_t g = 0; g < G; ++g) {
-    uint32_t* p = blockhist + ((size_t)w * G + g) * NBP + b;
+    uint32_t* p = chist + ((size_t)w * G + g) * NC + b;
     const uint32_t t = *p;
     *p = run;
     run += t;
   }
-  bcnt[idx] = run;
+  ctot[idx] = run;
+}
+
+// one block: cstart = exclusive scan of ctot (count <= 16 * 1024 + 1 entries; cstart[count] = total)
+__global__ __launch_bounds__(1024) void msm_part1_starts_kernel(const uint32_t* __restrict__ ctot,
+                                                                uint32_t* __restrict__ cstart, uint32_t count) {
+  __shared__ uint32_t s[1024];
+  const uint32_t t = threadIdx.x;
+  const uint32_t per = (count + 1023) / 1024;
+  const uint32_t lo = t * per, hi = lo + per < count ? lo + per : count;
+  uint32_t sum = 0;
+  for (uint32_t i = lo; i < hi; ++i) sum += ctot[i];
+  s[t] = sum;
+  __syncthreads();
+  for (uint32_t off = 1; off < 1024; off <<= 1) {
+    uint32_t a = 0;
+    if (t >= off) a = s[t - off];
+    __syncthreads();
+    s[t] += a;
+    __syncthreads();
+  }
+  uint32_t run = s[t] - sum;
+  for (uint32_t i = lo; i < hi; ++i) {
+    cstart[i] = run;
+    run += ctot[i];
+  }
+  if (t == 1023) cstart[count] = s[1023];
+}
+
+__global__ __launch_bounds__(SORT_THREADS) void msm_part1_scatter_kernel(const int32_t* __restrict__ digits,
+                                                                         const uint32_t* __restrict__ chist,
+                                                                         const uint32_t* __restrict__ cstart,
+                                                                         uint32_t* __restrict__ tmp, size_t n, size_t chunk,
+                                                                         uint32_t fb, uint32_t ib, uint32_t NC) {
+  extern __shared__ uint32_t cursor[];
+  const uint32_t g = blockIdx.x, w = blockIdx.y, G = gridDim.x;
+  const uint32_t* pre = chist + ((size_t)w * G + g) * NC;
+  const uint32_t* cs = cstart + (size_t)w * NC;
+  for (uint32_t b = threadIdx.x; b < NC; b += SORT_THREADS) cursor[b] = cs[b] + pre[b];
+  __syncthreads();
+  const size_t lo = (size_t)g * chunk, hi = lo + chunk < n ? lo + chunk : n;
+  const int32_t* dw = digits + (size_t)w * n;
+  const uint32_t fmask = (1u << fb) - 1u;
+  block_for_each_word(dw, lo, hi, [&](size_t i, int32_t d) {
+    if (d != 0) {
+      const uint32_t b1 = (uint32_t)(d < 0 ? -d : d) - 1u;
+      const uint32_t pos = atomicAdd(&cursor[b1 >> fb], 1u);
+      tmp[pos] = ((b1 & fmask) << (ib + 1)) | ((d < 0 ? 1u : 0u) << ib) | (uint32_t)i;
+    }
+  });
+}
+
+// part 2, first half: fine histogram of one (coarse bin, window) region -> bucket counts.
+// FROM_DIGITS (cb = 0): the "region" is the whole window and items are read from the digit array.
+template <bool FROM_DIGITS>
+__global__ __launch_bounds__(SORT_THREADS) void msm_part2_hist_kernel(const uint32_t* __restrict__ tmp,
+                                                                      const int32_t* __restrict__ digits,
+                                                                      const uint32_t* __restrict__ cstart,
+                                                                      uint32_t* __restrict__ bcnt, size_t n, uint32_t fb,
+                                                                      uint32_t ib, uint32_t NC, uint32_t NBP) {
+  extern __shared__ uint32_t fine[];
+  const uint32_t hb = blockIdx.x, w = blockIdx.y;
+  const uint32_t NF = 1u << fb;
+  for (uint32_t b = threadIdx.x; b < NF; b += SORT_THREADS) fine[b] = 0;
+  __syncthreads();
+  if (FROM_DIGITS) {
+    const int32_t* dw = digits + (size_t)w * n;
+    block_for_each_word(dw, 0, n, [&](size_t, int32_t d) {
+      if (d != 0) atomicAdd(&fine[(uint32_t)(d < 0 ? -d : d) - 1u], 1u);
+    });
+  } else {
+    const uint32_t lo = cstart[w * NC + hb], hi = cstart[w * NC + hb + 1];
+    block_for_each_word(tmp, lo, hi, [&](size_t, uint32_t item) { atomicAdd(&fine[item >> (ib + 1)], 1u); });
+  }
+  __syncthreads();
+  uint32_t* out = bcnt + (size_t)w * NBP + 1 + ((size_t)hb << fb);
+  for (uint32_t b = threadIdx.x; b < NF; b += SORT_THREADS) out[b] = fine[b];
+  if (hb == 0 && threadIdx.x == 0) bcnt[(size_t)w * NBP] = 0;   // bucket 0 (digit 0) is never used
+}
+
+// part 2, second half: scatter the region's items to their final places (boff = global bucket offsets)
+template <bool FROM_DIGITS>
+__global__ __launch_bounds__(SORT_THREADS) void msm_part2_scatter_kernel(const uint32_t* __restrict__ tmp,
+                                                                         const int32_t* __restrict__ digits,
+                                                                         const uint32_t* __restrict__ cstart,
+                                                                         const uint32_t* __restrict__ boff,
+                                                                         uint32_t* __restrict__ sorted, size_t n, uint32_t fb,
+                                                                         uint32_t ib, uint32_t NC, uint32_t NBP) {
+  extern __shared__ uint32_t cursor[];
+  const uint32_t hb = blockIdx.x, w = blockIdx.y;
+  const uint32_t NF = 1u << fb;
+  const uint32_t* bo = boff + (size_t)w * NBP + 1 + ((size_t)hb << fb);
+  for (uint32_t b = threadIdx.x; b < NF; b += SORT_THREADS) cursor[b] = bo[b];
+  __syncthreads();
+  if (FROM_DIGITS) {
+    const int32_t* dw = digits + (size_t)w * n;
+    block_for_each_word(dw, 0, n, [&](size_t i, int32_t d) {
+      if (d != 0) {
+        const uint32_t pos = atomicAdd(&cursor[(uint32_t)(d < 0 ? -d : d) - 1u], 1u);
+        sorted[pos] = (uint32_t)i | (d < 0 ? 0x80000000u : 0u);
+      }
+    });
+  } else {
+    const uint32_t lo = cstart[w * NC + hb], hi = cstart[w * NC + hb + 1];
+    const uint32_t imask = (1u << ib) - 1u;
+    block_for_each_word(tmp, lo, hi, [&](size_t, uint32_t item) {
+      const uint32_t pos = atomicAdd(&cursor[item >> (ib + 1)], 1u);
+      sorted[pos] = (item & imask) | (((item >> ib) & 1u) << 31);
+    });
+  }
 }
 
 // bucket offsets (exclusive scan of counts) and task offsets (exclusive scan of ceil(count / L)):
@@ -270,28 +414,6 @@ __global__ __launch_bounds__(SCAN_THREADS) void msm_scan_final_kernel(const uint
     rt += (c[k] + L - 1) / L;
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) toff[NBT] = totals[1];
-}
-
-__global__ __launch_bounds__(SORT_THREADS) void msm_scatter_kernel(const int32_t* __restrict__ digits,
-                                                                   const uint32_t* __restrict__ blockhist,
-                                                                   const uint32_t* __restrict__ boff,
-                                                                   uint32_t* __restrict__ sorted, size_t n, size_t chunk,
-                                                                   uint32_t NBP) {
-  extern __shared__ uint32_t cursor[];
-  const uint32_t g = blockIdx.x, w = blockIdx.y, G = gridDim.x;
-  const uint32_t* pre = blockhist + ((size_t)w * G + g) * NBP;
-  const uint32_t* bo = boff + (size_t)w * NBP;
-  for (uint32_t b = threadIdx.x; b < NBP; b += SORT_THREADS) cursor[b] = bo[b] + pre[b];
-  __syncthreads();
-  const size_t lo = (size_t)g * chunk, hi = lo + chunk < n ? lo + chunk : n;
-  const int32_t* dw = digits + (size_t)w * n;
-  for (size_t i = lo + threadIdx.x; i < hi; i += SORT_THREADS) {
-    const int32_t d = dw[i];
-    if (d != 0) {
-      const uint32_t pos = atomicAdd(&cursor[d < 0 ? -d : d], 1u);
-      sorted[pos] = (uint32_t)i | (d < 0 ? 0x80000000u : 0u);
-    }
-  }
 }
 
 __global__ void msm_task_fill_kernel(const uint32_t* __restrict__ toff, uint32_t* __restrict__ task_bucket, uint32_t NBT) {
@@ -580,49 +702,22 @@ static uint32_t ilog2(size_t n) {
   return l;
 }
 
-// host-side Horner over the window sums and affine normalisation, on the same field code
+// host-side Horner over the window sums and affine normalisation (host_fq.h: native 4 x u64
+// arithmetic on the external-format words the reduction kernel wrote)
 static void host_fold(const uint32_t* winres, uint32_t W, uint32_t c, uint64_t out_jac_ext[12], int* out_is_identity) {
-  G1Jac acc = g1_identity();
+  host::G1J acc = host::g1_identity();
   for (int w = (int)W - 1; w >= 0; --w) {
-    for (uint32_t k = 0; k < c; ++k) acc = g1_double(acc);
+    for (uint32_t k = 0; k < c; ++k) acc = host::g1_double(acc);
     const uint32_t* o = winres + (size_t)w * 32;
     if (o[24] == 0) {
-      uint32_t wx[8], wy[8], wz[8];
-      for (int k = 0; k < 8; ++k) { wx[k] = o[k]; wy[k] = o[8 + k]; wz[k] = o[16 + k]; }
-      G1Jac p;
-      p.x = fe_from_ext<FqParams>(wx);
-      p.y = fe_from_ext<FqParams>(wy);
-      p.z = fe_from_ext<FqParams>(wz);
-      p.inf = false;
-      acc = g1_add(acc, p);
+      host::G1J p;
+      std::memcpy(p.x.l, o, 32);
+      std::memcpy(p.y.l, o + 8, 32);
+      std::memcpy(p.z.l, o + 16, 32);
+      acc = host::g1_add(acc, p);
     }
   }
-  if (acc.inf) {
-    std::memset(out_jac_ext, 0, 96);
-    *out_is_identity = 1;
-    return;
-  }
-  // z^-1 by Fermat on the host
-  uint32_t e[9];
-  for (int i = 0; i < 9; ++i) e[i] = FqParams::MOD[i];
-  e[0] -= 2;
-  Fq zi = fe_one<FqParams>();
-  for (int i = 8; i >= 0; --i) {
-    const int top = i == 8 ? 24 : 28;
-    for (int bit = top; bit >= 0; --bit) {
-      zi = fe_sqr(zi);
-      if ((e[i] >> bit) & 1) zi = fe_mul(zi, acc.z);
-    }
-  }
-  const Fq zi2 = fe_sqr(zi), zi3 = fe_mul(zi2, zi);
-  uint32_t ox[8], oy[8], oz[8];
-  fe_to_ext(ox, fe_mul(acc.x, zi2));
-  fe_to_ext(oy, fe_mul(acc.y, zi3));
-  fe_to_ext(oz, fe_one<FqParams>());
-  std::memcpy(out_jac_ext, ox, 32);
-  std::memcpy(out_jac_ext + 4, oy, 32);
-  std::memcpy(out_jac_ext + 8, oz, 32);
-  *out_is_identity = 0;
+  host::g1_normalise(acc, out_jac_ext, out_is_identity);
 }
 
 // sum of `count` external Jacobian points (12 u64 each, z = 0 for the identity) on the host:
@@ -651,8 +746,10 @@ int msm_run(DeviceCtx& ctx, const uint32_t* d_scalars_ext, const uint32_t* d_xy,
   // ---- plan ---------------------------------------------------------------------------------
   int ci = c_override > 0 ? c_override : (g_window_override > 0 ? g_window_override : 0);
   if (ci == 0) {
+    // mean bucket load n / 2^(c-1) ~ 16: short accumulation chains, (almost) no bucket splitting,
+    // fewest (point, bucket) pairs; capped by the 2^15-counter LDS histogram of the sort
     const int l2 = (int)ilog2(n);
-    ci = l2 - 6;
+    ci = l2 - 3;
     if (ci < 4) ci = 4;
     if (ci > 16) ci = 16;
   }
@@ -677,7 +774,7 @@ int msm_run(DeviceCtx& ctx, const uint32_t* d_scalars_ext, const uint32_t* d_xy,
   const size_t chunk = (n + G - 1) / G;
   const uint64_t pairs_max = (uint64_t)n * W;
   const uint64_t T_max = pairs_max / L + NBT + 1;
-  uint32_t SEG = 32;
+  uint32_t SEG = 8;    // running-sum chain per lane in K4a: 2*SEG additions + a <= 15-bit scalar multiple
   if (SEG > NB) SEG = NB;
   const uint32_t nseg = (NB + SEG - 1) / SEG;
 
@@ -686,7 +783,16 @@ int msm_run(DeviceCtx& ctx, const uint32_t* d_scalars_ext, const uint32_t* d_xy,
   size_t off = 0;
   auto carve = [&](size_t bytes) { size_t o = off; off += align(bytes); return o; };
   const size_t o_digits = carve((size_t)W * n * 4);
-  const size_t o_bh = carve((size_t)W * G * NBP * 4);
+  // sort plan: item = [fine bucket bits | sign | point index] in 32 bits
+  uint32_t ib = ilog2(n) + ((n & (n - 1)) ? 1u : 0u);
+  if (ib == 0) ib = 1;
+  uint32_t fb = c - 1 < 31 - ib ? c - 1 : 31 - ib;
+  if (n >= (1u << 15) && (c - 1) - fb < 5) fb = c - 1 > 5 ? c - 1 - 5 : 0;   // >= 32 regions per window: enough workgroups
+  const uint32_t cb = (c - 1) - fb, NC = 1u << cb;
+  const size_t o_chist = carve((size_t)W * G * NC * 4);
+  const size_t o_ctot = carve((size_t)W * NC * 4);
+  const size_t o_cstart = carve(((size_t)W * NC + 1) * 4);
+  const size_t o_tmp = carve(cb ? pairs_max * 4 : 4);
   const size_t o_bcnt = carve((size_t)NBT * 4);
   const size_t o_boff = carve((size_t)NBT * 4);
   const size_t o_toff = carve(((size_t)NBT + 1) * 4);
@@ -702,7 +808,10 @@ int msm_run(DeviceCtx& ctx, const uint32_t* d_scalars_ext, const uint32_t* d_xy,
   uint8_t* ws = (uint8_t*)ctx.msm_ws.ensure(off);
   if (!ws) return hm_fail(HM_ERR_HIP, "msm: workspace allocation failed");
   int32_t* d_digits = (int32_t*)(ws + o_digits);
-  uint32_t* d_bh = (uint32_t*)(ws + o_bh);
+  uint32_t* d_chist = (uint32_t*)(ws + o_chist);
+  uint32_t* d_ctot = (uint32_t*)(ws + o_ctot);
+  uint32_t* d_cstart = (uint32_t*)(ws + o_cstart);
+  uint32_t* d_tmp = (uint32_t*)(ws + o_tmp);
   uint32_t* d_bcnt = (uint32_t*)(ws + o_bcnt);
   uint32_t* d_boff = (uint32_t*)(ws + o_boff);
   uint32_t* d_toff = (uint32_t*)(ws + o_toff);
@@ -719,14 +828,21 @@ int msm_run(DeviceCtx& ctx, const uint32_t* d_scalars_ext, const uint32_t* d_xy,
 
   static bool attr_set = false;
   if (!attr_set) {
-    HM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(msm_hist_kernel),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 32769 * 4));
-    HM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(msm_scatter_kernel),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 32769 * 4));
+    HM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(msm_part2_hist_kernel<true>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 32768 * 4));
+    HM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(msm_part2_hist_kernel<false>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 32768 * 4));
+    HM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(msm_part2_scatter_kernel<true>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 32768 * 4));
+    HM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(msm_part2_scatter_kernel<false>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 32768 * 4));
     attr_set = true;
   }
-  hipEvent_t ev[7];
-  for (auto& e : ev) HM_HIP_CHECK(hipEventCreate(&e));
+  hipEvent_t* ev = ctx.msm_events;
+  if (!ctx.msm_events_ready) {
+    for (int i = 0; i < 7; ++i) HM_HIP_CHECK(hipEventCreate(&ev[i]));
+    ctx.msm_events_ready = true;
+  }
   HM_HIP_CHECK(hipEventRecord(ev[0], stream));
 
   // ---- K0 ------------------------------------------------------------------------------------
@@ -736,11 +852,22 @@ int msm_run(DeviceCtx& ctx, const uint32_t* d_scalars_ext, const uint32_t* d_xy,
   HM_HIP_CHECK(hipEventRecord(ev[1], stream));
 
   // ---- K2 ------------------------------------------------------------------------------------
-  const size_t lds_hist = (size_t)NBP * 4;
-  hipLaunchKernelGGL(msm_hist_kernel, dim3(G, W), dim3(SORT_THREADS), lds_hist, stream, (const int32_t*)d_digits, d_bh, n,
-                     chunk, NBP);
-  HM_HIP_CHECK(hipGetLastError());
-  hipLaunchKernelGGL(msm_scan_blocks_kernel, dim3((NBT + 255) / 256), dim3(256), 0, stream, d_bh, d_bcnt, G, NBP, W);
+  const size_t lds_fine = (size_t)4 << fb;
+  if (cb) {
+    const size_t lds_coarse = (size_t)NC * 4;
+    hipLaunchKernelGGL(msm_part1_hist_kernel, dim3(G, W), dim3(SORT_THREADS), lds_coarse, stream, (const int32_t*)d_digits,
+                       d_chist, n, chunk, fb, NC);
+    hipLaunchKernelGGL(msm_part1_scan_kernel, dim3((W * NC + 255) / 256), dim3(256), 0, stream, d_chist, d_ctot, G, NC, W);
+    hipLaunchKernelGGL(msm_part1_starts_kernel, dim3(1), dim3(1024), 0, stream, (const uint32_t*)d_ctot, d_cstart, W * NC);
+    hipLaunchKernelGGL(msm_part1_scatter_kernel, dim3(G, W), dim3(SORT_THREADS), lds_coarse, stream,
+                       (const int32_t*)d_digits, (const uint32_t*)d_chist, (const uint32_t*)d_cstart, d_tmp, n, chunk, fb, ib,
+                       NC);
+    hipLaunchKernelGGL(msm_part2_hist_kernel<false>, dim3(NC, W), dim3(SORT_THREADS), lds_fine, stream,
+                       (const uint32_t*)d_tmp, (const int32_t*)d_digits, (const uint32_t*)d_cstart, d_bcnt, n, fb, ib, NC, NBP);
+  } else {
+    hipLaunchKernelGGL(msm_part2_hist_kernel<true>, dim3(1, W), dim3(SORT_THREADS), lds_fine, stream,
+                       (const uint32_t*)d_tmp, (const int32_t*)d_digits, (const uint32_t*)d_cstart, d_bcnt, n, fb, ib, NC, NBP);
+  }
   HM_HIP_CHECK(hipGetLastError());
   {
     const uint32_t nblocks = (NBT + SCAN_BLOCK - 1) / SCAN_BLOCK;
@@ -751,8 +878,15 @@ int msm_run(DeviceCtx& ctx, const uint32_t* d_scalars_ext, const uint32_t* d_xy,
                        (const uint32_t*)d_bsum, d_boff, d_toff, (const uint32_t*)d_tot, NBT, L);
     HM_HIP_CHECK(hipGetLastError());
   }
-  hipLaunchKernelGGL(msm_scatter_kernel, dim3(G, W), dim3(SORT_THREADS), lds_hist, stream, (const int32_t*)d_digits,
-                     (const uint32_t*)d_bh, (const uint32_t*)d_boff, d_sorted, n, chunk, NBP);
+  if (cb) {
+    hipLaunchKernelGGL(msm_part2_scatter_kernel<false>, dim3(NC, W), dim3(SORT_THREADS), lds_fine, stream,
+                       (const uint32_t*)d_tmp, (const int32_t*)d_digits, (const uint32_t*)d_cstart, (const uint32_t*)d_boff,
+                       d_sorted, n, fb, ib, NC, NBP);
+  } else {
+    hipLaunchKernelGGL(msm_part2_scatter_kernel<true>, dim3(1, W), dim3(SORT_THREADS), lds_fine, stream,
+                       (const uint32_t*)d_tmp, (const int32_t*)d_digits, (const uint32_t*)d_cstart, (const uint32_t*)d_boff,
+                       d_sorted, n, fb, ib, NC, NBP);
+  }
   HM_HIP_CHECK(hipGetLastError());
   hipLaunchKernelGGL(msm_task_fill_kernel, dim3((NBT + 255) / 256), dim3(256), 0, stream, (const uint32_t*)d_toff, d_tb,
                      NBT);
@@ -806,7 +940,6 @@ int msm_run(DeviceCtx& ctx, const uint32_t* d_scalars_ext, const uint32_t* d_xy,
   float acc_kernel = 0;
   (void)hipEventElapsedTime(&acc_kernel, ev[5], ev[6]);
   ctx.last_msm.t_accum_kernel_ms = acc_kernel;
-  for (auto& e : ev) (void)hipEventDestroy(e);
   ctx.last_msm.t_digits_ms = ms[0];
   ctx.last_msm.t_sort_ms = ms[1];
   ctx.last_msm.t_accum_ms = ms[2];
