@@ -114,6 +114,7 @@ int hm_shutdown(void) {
     if (t->d_omega) (void)hipFree(t->d_omega);
     if (t->d_lo) (void)hipFree(t->d_lo);
     if (t->d_hi) (void)hipFree(t->d_hi);
+    if (t->d_mid) (void)hipFree(t->d_mid);
     for (auto& s : t->d_stage)
       if (s) (void)hipFree(s);
   }

@@ -37,6 +37,7 @@ struct NttTables {
   void* d_omega = nullptr;
   uint32_t* d_lo = nullptr;
   uint32_t* d_hi = nullptr;
+  uint32_t* d_mid = nullptr;   // direct twiddles of the middle pass of a 3-pass plan
   uint32_t* d_stage[16] = {};
 };
 

@@ -22,7 +22,7 @@
 
 namespace hm {
 
-constexpr int NTT_THREADS = 256;
+constexpr int NTT_THREADS = 512;
 
 // ---------------------------------------------------------------------------------------------
 // twiddle tables
@@ -58,17 +58,24 @@ __device__ __forceinline__ Fr load_tw(const uint32_t* __restrict__ tab, uint32_t
 // ---------------------------------------------------------------------------------------------
 // LDS tile helpers: structure-of-arrays, plane l holds limb l of every element of the tile
 // ---------------------------------------------------------------------------------------------
+// element index -> word index inside a plane.  XOR-ing bits 3..4 with bits 6..7 keeps the first
+// register round (8 consecutive digit positions per lane, i.e. a 64-word lane stride) off the
+// same banks without growing the tile (a +8-per-64 pad would push two tiles past 160 KiB).
+__device__ __forceinline__ uint32_t lds_swz(uint32_t e) { return e ^ (((e >> 6) & 3u) << 3); }
+
 template <int LOG_TILE>
 __device__ __forceinline__ Fr lds_load(const uint32_t* lds, uint32_t e) {
   Fr r;
+  const uint32_t a = lds_swz(e);
 #pragma unroll
-  for (int i = 0; i < 9; ++i) r.l[i] = lds[(i << LOG_TILE) + e];
+  for (int i = 0; i < 9; ++i) r.l[i] = lds[(i << LOG_TILE) + a];
   return r;
 }
 template <int LOG_TILE>
 __device__ __forceinline__ void lds_store(uint32_t* lds, uint32_t e, const Fr& a) {
+  const uint32_t ad = lds_swz(e);
 #pragma unroll
-  for (int i = 0; i < 9; ++i) lds[(i << LOG_TILE) + e] = a.l[i];
+  for (int i = 0; i < 9; ++i) lds[(i << LOG_TILE) + ad] = a.l[i];
 }
 
 __device__ __forceinline__ uint32_t bitrev(uint32_t v, uint32_t bits) {
@@ -86,7 +93,63 @@ struct NttPassParams {
   uint32_t log_lb;       // split point of the two-level inter-pass twiddle table
   uint32_t has_scale;    // last pass: multiply by `scale` (internal-form constant) instead of ONE
   uint32_t has_coset;    // first pass: multiply a[i] by coset[i % 3] on load
+  uint32_t direct_tw;    // non-last pass: tw_lo holds omega_m^e for every e < m (no forming product)
 };
+
+// everything a register round needs
+struct NttTileCtx {
+  uint32_t tid, s, log_c, cmask, tile_elems, i0;
+  uint64_t base, dest_lo0;
+};
+
+// One register round of the R-point DIT: every lane takes groups of 2^RB positions
+// p = base + j * 2^q0 (same column), runs stages q0 .. q0+RB-1 on them in registers and writes them
+// back normalised: one LDS round trip per <= 3 stages instead of one per stage.  (The pass epilogue
+// stays a separate one-element-per-iteration loop: folding it into the last round multiplies the
+// number of inlined ~230-instruction products and pushes the kernel out of the instruction cache.)
+template <int LOG_TILE, int RB>
+__device__ __forceinline__ void ntt_round(uint32_t* lds, const NttTileCtx& cx, uint32_t q0,
+                                          const uint32_t* __restrict__ stage_tw) {
+  constexpr int GE = 1 << RB;
+  const uint32_t s = cx.s, log_c = cx.log_c;
+  const uint32_t ngroups = cx.tile_elems >> RB;
+  for (uint32_t gid = cx.tid; gid < ngroups; gid += NTT_THREADS) {
+    const uint32_t c = gid & cx.cmask, u = gid >> log_c;
+    const uint32_t base_lo = u & ((1u << q0) - 1u);
+    const uint32_t pbase = ((u >> q0) << (q0 + RB)) | base_lo;
+    Fr x[GE];
+#pragma unroll
+    for (int j = 0; j < GE; ++j) x[j] = lds_load<LOG_TILE>(lds, ((pbase + ((uint32_t)j << q0)) << log_c) + c);
+#pragma unroll
+    for (int t = 0; t < RB; ++t) {
+      const uint32_t q = q0 + t;
+#pragma unroll
+      for (int m = 0; m < (1 << t); ++m) {
+        if (q == 0) {   // stage 0: twiddle 1; b is a raw input (< 2^256) or a product
+#pragma unroll
+          for (int h = 0; h < (1 << (RB - t - 1)); ++h) {
+            const int j = m + (h << (t + 1));
+            const Fr a = x[j], b = x[j + (1 << t)];
+            x[j] = fe_add(a, b);
+            x[j + (1 << t)] = fe_sub<6, 29>(a, b);
+          }
+        } else {
+          const Fr w = load_tw(stage_tw, (base_lo + ((uint32_t)m << q0)) << (s - 1 - q));
+#pragma unroll
+          for (int h = 0; h < (1 << (RB - t - 1)); ++h) {
+            const int j = m + (h << (t + 1));
+            const Fr a = x[j];
+            const Fr tt = fe_mul(x[j + (1 << t)], w);
+            x[j] = fe_add(a, tt);
+            x[j + (1 << t)] = fe_sub<3, 29>(a, tt);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < GE; ++j) lds_store<LOG_TILE>(lds, ((pbase + ((uint32_t)j << q0)) << log_c) + c, fe_norm(x[j]));
+  }
+}
 
 // One digit pass.  in/out: n x 8 u32 (external words).  stage_tw: omega_R^j, j < R/2.
 // tw_lo/tw_hi: omega_n^j (j < 2^log_lb) and omega_n^(j << log_lb).
@@ -155,41 +218,38 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(const uint32_t* i
   }
   __syncthreads();
 
-  // ---- R-point DIT over the digit, all columns of the tile at once ---------------------------
-  // stage q pairs positions (p, p + 2^q); twiddle omega_R^((p mod 2^q) << (s-1-q))
-  const uint32_t nbf = tile_elems >> 1;
-  for (uint32_t q = 0; q < s; ++q) {
-    const uint32_t log_h = q + log_c;  // butterfly distance in tile elements = 2^q * C
-    const uint32_t hmask = (1u << log_h) - 1u;
-    for (uint32_t b = tid; b < nbf; b += NTT_THREADS) {
-      const uint32_t lo = b & hmask;
-      const uint32_t e0 = ((b >> log_h) << (log_h + 1)) + lo;
-      const uint32_t e1 = e0 + (1u << log_h);
-      const Fr a = lds_load<LOG_TILE>(lds, e0);
-      Fr t = lds_load<LOG_TILE>(lds, e1);
-      if (q != 0) {
-        const uint32_t j = (lo >> log_c) << (s - 1 - q);
-        t = fe_mul(t, load_tw(stage_tw, j));
-      }
-      lds_store<LOG_TILE>(lds, e0, fe_norm(fe_add(a, t)));
-      // t is a product output (< 2r) except in stage 0, where it is a raw input (< 2^256 < 6r)
-      lds_store<LOG_TILE>(lds, e1, fe_norm(fe_sub<6, 29>(a, t)));
-    }
+  // ---- R-point DIT over the digit in register rounds of <= 3 stages ---------------------------
+  NttTileCtx cx;
+  cx.tid = tid; cx.s = s; cx.log_c = log_c; cx.cmask = cmask; cx.tile_elems = tile_elems;
+  cx.i0 = i0; cx.base = base; cx.dest_lo0 = dest_lo0;
+  // split s into rounds of 3 stages, ending 3 / 2+2 / 3+2 so that no round is a single stage unless s == 1
+  uint32_t q0 = 0;
+  while (q0 < s) {
+    uint32_t r = s - q0;
+    if (r > 2) r = 2;
+    if (r == 2) ntt_round<LOG_TILE, 2>(lds, cx, q0, stage_tw);
+    else ntt_round<LOG_TILE, 1>(lds, cx, q0, stage_tw);
+    q0 += r;
     __syncthreads();
   }
 
-  // ---- store ---------------------------------------------------------------------------------
+  // ---- epilogue: inter-pass twiddle + packed store, or canonicalise (+ fused scale) on the last pass
   if (!pp.last) {
     const uint32_t shift_m = pp.log_n - (s + pp.log_stride);  // omega_m = omega_n^(2^shift_m)
     const uint32_t lbmask = (1u << pp.log_lb) - 1u;
     for (uint32_t e = tid; e < tile_elems; e += NTT_THREADS) {
       const uint32_t c = e & cmask, k = e >> log_c;
-      Fr y = lds_load<LOG_TILE>(lds, e);
-      const uint64_t ex = ((uint64_t)(i0 + c) * k) << shift_m;  // < n
-      const uint32_t elo = (uint32_t)ex & lbmask, ehi = (uint32_t)(ex >> pp.log_lb);
-      Fr tw = load_tw(tw_hi, ehi);
-      if (elo != 0) tw = fe_mul(tw, load_tw(tw_lo, elo));
-      y = fe_mul(y, tw);  // product output: normalised, < 2r < 2^256
+      const Fr y0 = lds_load<LOG_TILE>(lds, e);
+      Fr tw;
+      if (pp.direct_tw) {
+        tw = load_tw(tw_lo, (i0 + c) * k);                      // omega_m^(i*k), i*k < m <= 2^16
+      } else {
+        const uint64_t ex = ((uint64_t)(i0 + c) * k) << shift_m;  // < n
+        const uint32_t elo = (uint32_t)ex & lbmask, ehi = (uint32_t)(ex >> pp.log_lb);
+        tw = load_tw(tw_hi, ehi);
+        if (elo != 0) tw = fe_mul(tw, load_tw(tw_lo, elo));
+      }
+      const Fr y = fe_mul(y0, tw);  // product output: normalised, < 2r < 2^256
       uint32_t w[8];
       fe_pack(w, y);
       uint4* dst = reinterpret_cast<uint4*>(out + (base + ((uint64_t)k << pp.log_stride) + c) * 8);
@@ -197,18 +257,15 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(const uint32_t* i
       dst[1] = make_uint4(w[4], w[5], w[6], w[7]);
     }
   } else {
-    Fr fin;
+    Fr fin = fe_one<FrParams>();
     if (pp.has_scale) {
 #pragma unroll
       for (int i = 0; i < 9; ++i) fin.l[i] = scale_int[i];
       HM_DECLARE(fin, 2.0);
-    } else {
-      fin = fe_one<FrParams>();
     }
     for (uint32_t e = tid; e < tile_elems; e += NTT_THREADS) {
       const uint32_t c = e & cmask, k = e >> log_c;
-      Fr y = lds_load<LOG_TILE>(lds, (k << log_c) + c);  // position (digit k, row c) -- same index e
-      y = fe_canonical(fe_mul(y, fin));
+      const Fr y = fe_canonical(fe_mul(lds_load<LOG_TILE>(lds, e), fin));
       uint32_t w[8];
       fe_pack(w, y);
       const uint64_t g = (dest_lo0 + c) + ((uint64_t)k << pp.log_rows);
@@ -273,6 +330,7 @@ __global__ void fr_ext_to_int_kernel(const uint32_t* __restrict__ c_ext, uint32_
 // host side: plan + launch
 // ---------------------------------------------------------------------------------------------
 constexpr int LOG_TILE = 11;
+constexpr uint32_t NTT_DIRECT_LOG = 16;   // sub-problems up to 2^16 get a direct inter-pass twiddle table (2.4 MB)
 
 static int plan_digits(uint32_t log_n, uint32_t digits[3]) {
   if (log_n <= (uint32_t)LOG_TILE) {
@@ -306,8 +364,15 @@ NttTables* ntt_get_tables(DeviceCtx& ctx, const uint64_t omega_ext[4], uint32_t 
     return hipGetLastError() == hipSuccess;
   };
   if (passes > 1) {
-    if (!make(1u << t->log_lb, 0, &t->d_lo)) return nullptr;
-    if (!make(1u << (log_n - t->log_lb), t->log_lb, &t->d_hi)) return nullptr;
+    if (log_n <= NTT_DIRECT_LOG) {
+      if (!make(1u << log_n, 0, &t->d_lo)) return nullptr;                       // omega_n^e for every e < n
+    } else {
+      if (!make(1u << t->log_lb, 0, &t->d_lo)) return nullptr;
+      if (!make(1u << (log_n - t->log_lb), t->log_lb, &t->d_hi)) return nullptr;
+      const uint32_t log_m1 = log_n - digits[0];                                 // size of the middle pass's sub-problem
+      if (passes == 3 && log_m1 <= NTT_DIRECT_LOG)
+        if (!make(1u << log_m1, digits[0], &t->d_mid)) return nullptr;           // omega_m1^e = omega_n^(e << s0)
+    }
   }
   for (int p = 0; p < passes; ++p) {
     const uint32_t s = digits[p];
@@ -362,9 +427,19 @@ int ntt_run(DeviceCtx& ctx, uint32_t* d_a, const uint64_t omega_ext[4], uint32_t
     const uint64_t tiles = n >> (pp.s + log_c);
     const uint32_t* src = (p == 0) ? d_a : scratch;
     uint32_t* dst = (p == passes - 1) ? d_a : scratch;
+    const uint32_t* lo_tab = tab->d_lo;
+    if (!pp.last) {
+      const uint32_t log_m = pp.s + pp.log_stride;
+      if (log_n <= NTT_DIRECT_LOG) {
+        pp.direct_tw = 1;            // d_lo = omega_n^e; omega_m^e = omega_n^(e << (log_n - log_m)) only for p == 0 (m = n)
+      } else if (p == 1 && tab->d_mid) {
+        pp.direct_tw = 1;
+        lo_tab = tab->d_mid;
+      }
+      (void)log_m;
+    }
     hipLaunchKernelGGL(ntt_pass_kernel<LOG_TILE>, dim3((uint32_t)tiles), dim3(NTT_THREADS), lds_bytes, stream, src, dst, pp,
-                       (const uint32_t*)tab->d_stage[pp.s], (const uint32_t*)tab->d_lo, (const uint32_t*)tab->d_hi,
-                       d_scale_int, d_coset_int);
+                       (const uint32_t*)tab->d_stage[pp.s], lo_tab, (const uint32_t*)tab->d_hi, d_scale_int, d_coset_int);
     HM_HIP_CHECK(hipGetLastError());
   }
   return HM_OK;
