@@ -10,6 +10,6 @@ echo "== smoke" && timeout -k 10 300 python -c "import __graft_entry__ as g; g.s
 [ $rc -ne 0 ] && exit $rc
 echo "== bench" && timeout -k 10 600 python bench.py --steps 10 --warmup 2 > gpurun_out/bench.json 2> gpurun_out/bench.err; rc=$?; cat gpurun_out/bench.json; tail -3 gpurun_out/bench.err
 [ $rc -ne 0 ] && exit $rc
-echo "== rocprofv3 kernel trace" && (cd /tmp && timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/gpurun_out/prof" -- python3 "$OLDPWD/bench.py" --steps 5 --warmup 1 --no-cpu-baseline > "$OLDPWD/gpurun_out/rocprof_bench.json" 2> "$OLDPWD/gpurun_out/rocprof.err"); rc=$?
+echo "== rocprofv3 kernel trace" && (cd /tmp && timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/gpurun_out/prof" -- python3 "$OLDPWD/bench.py" --steps 5 --warmup 1 --no-cpu-baseline --replay none --no-extras > "$OLDPWD/gpurun_out/rocprof_bench.json" 2> "$OLDPWD/gpurun_out/rocprof.err"); rc=$?
 tail -2 gpurun_out/rocprof.err; find gpurun_out/prof -name "*stats*" | head
 exit $rc
