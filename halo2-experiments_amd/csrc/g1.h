@@ -67,20 +67,6 @@ HM_HD G1Aff g1_neg_affine(const G1Aff& p) {
   r.y = fe_norm(fe_sub<3, 29>(fe_zero<FqParams>(), p.y));
   return r;
 }
-HM_HD G1Aff g1_cneg_affine(const G1Aff& p, bool neg) {
-  G1Aff n = g1_neg_affine(p);
-  G1Aff r;
-  r.x = p.x;
-#pragma unroll
-  for (int i = 0; i < 9; ++i) r.y.l[i] = neg ? n.y.l[i] : p.y.l[i];
-#ifdef HM_BOUNDS
-  r.y.vb = n.y.vb > p.y.vb ? n.y.vb : p.y.vb;
-  r.y.lb = MASK29;
-  r.y.tb = n.y.tb > p.y.tb ? n.y.tb : p.y.tb;
-#endif
-  return r;
-}
-
 // Doubling for a = 0 (dbl-2009-l; D = 4*X*Y^2 taken as a product, and X3, Y3 produced by fused
 // products so that they are reduction outputs): p must not be the identity.
 HM_HD G1Jac g1_double_nz(const G1Jac& p) {

@@ -95,6 +95,7 @@ struct DeviceCtx {
   MsmStats last_msm;
   hipEvent_t msm_events[7] = {};
   bool msm_events_ready = false;
+  bool msm_attr_set = false, ntt_attr_set = false;
   void* ensure_scratch(size_t bytes) { return scratch.ensure(bytes); }
 };
 

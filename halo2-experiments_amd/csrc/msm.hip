@@ -826,8 +826,7 @@ int msm_run(DeviceCtx& ctx, const uint32_t* d_scalars_ext, const uint32_t* d_xy,
   uint32_t* d_big_count = (uint32_t*)(ws + o_big);
   uint32_t* d_big_list = d_big_count + 4;
 
-  static bool attr_set = false;
-  if (!attr_set) {
+  if (!ctx.msm_attr_set) {   // per device: a process may drive several GPUs
     HM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(msm_part2_hist_kernel<true>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 32768 * 4));
     HM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(msm_part2_hist_kernel<false>),
@@ -836,7 +835,7 @@ int msm_run(DeviceCtx& ctx, const uint32_t* d_scalars_ext, const uint32_t* d_xy,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 32768 * 4));
     HM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(msm_part2_scatter_kernel<false>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 32768 * 4));
-    attr_set = true;
+    ctx.msm_attr_set = true;
   }
   hipEvent_t* ev = ctx.msm_events;
   if (!ctx.msm_events_ready) {

@@ -401,11 +401,10 @@ int ntt_run(DeviceCtx& ctx, uint32_t* d_a, const uint64_t omega_ext[4], uint32_t
     if (!scratch) return hm_fail(HM_ERR_HIP, "ntt: scratch allocation failed");
   }
   const size_t lds_bytes = (size_t)9 * sizeof(uint32_t) << LOG_TILE;
-  static bool attr_set = false;
-  if (!attr_set) {
+  if (!ctx.ntt_attr_set) {   // per device: a process may drive several GPUs
     HM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ntt_pass_kernel<LOG_TILE>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    attr_set = true;
+    ctx.ntt_attr_set = true;
   }
   uint32_t log_stride = log_n;
   for (int p = 0; p < passes; ++p) {
