@@ -50,6 +50,8 @@ _SIGNATURES = {
     "hm_msm_bn256_g1_h": (ctypes.c_int, [ctypes.c_uint64, ctypes.c_size_t, _u64p, ctypes.c_size_t, _u64p,
                                           ctypes.POINTER(ctypes.c_int)]),
     "hm_register_bases_dev": (ctypes.c_int, [_vp, ctypes.c_size_t, _vp, _u64p]),
+    "hm_register_bases_precomp": (ctypes.c_int, [_u64p, ctypes.c_size_t, _u64p]),
+    "hm_register_bases_precomp_dev": (ctypes.c_int, [_vp, ctypes.c_size_t, _vp, _u64p]),
     "hm_msm_bn256_g1_dev": (ctypes.c_int, [ctypes.c_uint64, ctypes.c_size_t, _vp, ctypes.c_size_t, _vp, _u64p]),
     "hm_g1_sum": (ctypes.c_int, [_u64p, ctypes.c_size_t, _u64p]),
     "hm_msm_set_window": (ctypes.c_int, [ctypes.c_int]),

@@ -67,17 +67,21 @@ class BasesHandle:
         return self.n
 
 
-def register_bases(bases) -> BasesHandle:
+def register_bases(bases, precompute: bool = False) -> BasesHandle:
+    """Upload + convert a base set once.  ``precompute=True`` also stores 2^(c*j) * P_i for every
+    window (W x the memory) so that whole-set MSMs share one bucket set -- the mode for an SRS that
+    lives for the whole proving session."""
     lib = _lib.load()
     h = ctypes.c_uint64(0)
     if _is_tensor(bases):
         n = _tensor_rows(bases, 8, "bases")
-        _lib.check(lib.hm_register_bases_dev(ctypes.c_void_p(bases.data_ptr()), n, ctypes.c_void_p(_stream_ptr(bases)),
-                                             ctypes.byref(h)))
+        fn = lib.hm_register_bases_precomp_dev if precompute else lib.hm_register_bases_dev
+        _lib.check(fn(ctypes.c_void_p(bases.data_ptr()), n, ctypes.c_void_p(_stream_ptr(bases)), ctypes.byref(h)))
     else:
         b = _np(bases, 8, "bases")
         n = b.shape[0]
-        _lib.check(lib.hm_register_bases(_ptr(b), n, ctypes.byref(h)))
+        fn = lib.hm_register_bases_precomp if precompute else lib.hm_register_bases
+        _lib.check(fn(_ptr(b), n, ctypes.byref(h)))
     return BasesHandle(h.value, n)
 
 

@@ -55,13 +55,24 @@ static BasesEntry* find_bases(DeviceCtx& ctx, uint64_t handle) {
   return nullptr;
 }
 
-static int register_from_device(DeviceCtx& ctx, const uint32_t* d_ext, size_t n, hipStream_t stream, uint64_t* out_handle) {
+static int register_from_device(DeviceCtx& ctx, const uint32_t* d_ext, size_t n, hipStream_t stream, uint64_t* out_handle,
+                                bool precomp = false) {
   BasesEntry e;
   e.n = n;
-  HM_HIP_CHECK(hipMalloc((void**)&e.d_xy, n ? n * 64 : 64));
+  if (precomp && n >= 256) {   // tiny sets gain nothing from a shared bucket set
+    e.pc_c = msm_precomp_window(n);
+    e.pc_W = (255 + e.pc_c - 1) / e.pc_c;
+    if ((uint64_t)n * e.pc_W >= (1ull << 31)) { e.pc_c = 0; e.pc_W = 0; }
+  }
+  const size_t copies = e.pc_c ? e.pc_W : 1;
+  HM_HIP_CHECK(hipMalloc((void**)&e.d_xy, n ? n * 64 * copies : 64));
   HM_HIP_CHECK(hipMalloc((void**)&e.d_inf, n ? n : 1));
   int rc = msm_convert_bases(d_ext, e.d_xy, e.d_inf, n, stream);
   if (rc != HM_OK) return rc;
+  if (e.pc_c) {
+    rc = msm_precompute(e.d_xy, e.d_inf, n, e.pc_c, e.pc_W, stream);
+    if (rc != HM_OK) return rc;
+  }
   e.handle = ctx.next_handle++;
   ctx.bases.push_back(e);
   *out_handle = e.handle;
@@ -164,6 +175,31 @@ int hm_register_bases_dev(const void* d_bases, size_t n, void* stream, uint64_t*
   return HM_OK;
 }
 
+int hm_register_bases_precomp(const uint64_t* bases, size_t n, uint64_t* out_handle) {
+  if (!out_handle || (n && !bases)) return hm_fail(HM_ERR_BAD_ARG, "hm_register_bases_precomp: null argument");
+  DeviceCtx* ctx = ctx_for_current_device();
+  if (!ctx) return HM_ERR_NO_DEVICE;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  void* stage = ctx->io_bases.ensure(n ? n * 64 : 64);
+  if (!stage) return hm_fail(HM_ERR_HIP, "hm_register_bases_precomp: staging allocation failed");
+  HM_HIP_CHECK(hipMemcpy(stage, bases, n * 64, hipMemcpyHostToDevice));
+  int rc = register_from_device(*ctx, (const uint32_t*)stage, n, nullptr, out_handle, true);
+  if (rc != HM_OK) return rc;
+  HM_HIP_CHECK(hipStreamSynchronize(nullptr));
+  return HM_OK;
+}
+
+int hm_register_bases_precomp_dev(const void* d_bases, size_t n, void* stream, uint64_t* out_handle) {
+  if (!out_handle || (n && !d_bases)) return hm_fail(HM_ERR_BAD_ARG, "hm_register_bases_precomp_dev: null argument");
+  DeviceCtx* ctx = ctx_for_current_device();
+  if (!ctx) return HM_ERR_NO_DEVICE;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  int rc = register_from_device(*ctx, (const uint32_t*)d_bases, n, (hipStream_t)stream, out_handle, true);
+  if (rc != HM_OK) return rc;
+  HM_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+  return HM_OK;
+}
+
 int hm_release_bases(uint64_t handle) {
   DeviceCtx* ctx = ctx_for_current_device();
   if (!ctx) return HM_ERR_NO_DEVICE;
@@ -189,7 +225,8 @@ int hm_msm_bn256_g1_dev(uint64_t handle, size_t offset, const void* d_scalars, s
   if (!b) return hm_fail(HM_ERR_NOT_FOUND, "hm_msm_bn256_g1_dev: unknown base handle");
   if (offset > b->n || n > b->n - offset) return hm_fail(HM_ERR_BAD_ARG, "hm_msm_bn256_g1_dev: offset + n exceeds the base set");
   int is_id = 0;
-  return msm_run(*ctx, (const uint32_t*)d_scalars, b->d_xy + offset * 16, b->d_inf + offset, n, 0, out_xyz, &is_id,
+  const uint32_t pc = (offset == 0 && n == b->n) ? b->pc_c : 0u;   // the table only fits whole-set calls
+  return msm_run(*ctx, (const uint32_t*)d_scalars, b->d_xy + offset * 16, b->d_inf + offset, n, pc, out_xyz, &is_id,
                  (hipStream_t)stream);
 }
 
@@ -207,7 +244,8 @@ int hm_msm_bn256_g1_h(uint64_t handle, size_t offset, const uint64_t* scalars, s
   HM_HIP_CHECK(hipMemcpy(d_s, scalars, n * 32, hipMemcpyHostToDevice));
   uint64_t jac[12];
   int is_id = 0;
-  int rc = msm_run(*ctx, (const uint32_t*)d_s, b->d_xy + offset * 16, b->d_inf + offset, n, 0, jac, &is_id, nullptr);
+  const uint32_t pc = (offset == 0 && n == b->n) ? b->pc_c : 0u;
+  int rc = msm_run(*ctx, (const uint32_t*)d_s, b->d_xy + offset * 16, b->d_inf + offset, n, pc, jac, &is_id, nullptr);
   if (rc != HM_OK) return rc;
   return jac_to_affine_out(jac, is_id, out_xy, out_is_identity);
 }

@@ -66,7 +66,8 @@ struct BasesEntry {          // device-resident, converted base set (hm_register
   size_t n = 0;
   uint32_t* d_xy = nullptr;  // n x 16 u32: x, y packed internal form
   uint8_t* d_inf = nullptr;  // n flags: base is the identity
-  bool owned = true;
+  uint32_t pc_c = 0;         // != 0: d_xy holds pc_W * n points, entry j*n + i = 2^(pc_c * j) * P_i
+  uint32_t pc_W = 0;
 };
 
 struct MsmStats {
@@ -112,7 +113,9 @@ int fr_ext_to_int_run(const uint32_t* d_c_ext, uint32_t* d_out, uint32_t count, 
 int msm_convert_bases(const uint32_t* d_bases_ext, uint32_t* d_xy, uint8_t* d_inf, size_t n, hipStream_t stream);
 // out_windows: host buffer of W x 12 u64 external Jacobian + flags
 int msm_run(DeviceCtx& ctx, const uint32_t* d_scalars_ext, const uint32_t* d_xy, const uint8_t* d_inf, size_t n,
-            int c_override, uint64_t out_jac_ext[12], int* out_is_identity, hipStream_t stream);
+            uint32_t precomp_c, uint64_t out_jac_ext[12], int* out_is_identity, hipStream_t stream);
+uint32_t msm_precomp_window(size_t n);
+int msm_precompute(uint32_t* d_table, const uint8_t* d_inf, size_t n, uint32_t c, uint32_t W, hipStream_t stream);
 void host_sum_points(const uint64_t* pts, size_t count, uint64_t out_jac_ext[12], int* out_is_identity);
 int g1_fixed_base_mul_run(DeviceCtx& ctx, const uint32_t* d_scalars_ext, size_t n, const uint64_t base_affine_ext[8],
                           uint32_t* d_out_affine_ext, hipStream_t stream);

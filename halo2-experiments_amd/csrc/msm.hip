@@ -160,7 +160,7 @@ constexpr int SORT_THREADS = 1024;
 template <class T, class F>
 __device__ __forceinline__ void block_for_each_word(const T* __restrict__ base, size_t lo, size_t hi, F f) {
   size_t a = lo;
-  while (a < hi && (reinterpret_cast<uintptr_t>(base + a) & 15u)) ++a;      // aligned start
+  while (a < hi && (reinterpret_cast<uintptr_t>(base + a) & (4 * sizeof(T) - 1))) ++a;   // aligned start
   const size_t nvec = (hi - a) / 4;
   if (threadIdx.x < a - lo) f(lo + threadIdx.x, base[lo + threadIdx.x]);     // <= 3 head words
   const size_t tail = a + nvec * 4;
@@ -194,20 +194,32 @@ __global__ __launch_bounds__(SORT_THREADS) void msm_part1_hist_kernel(const int3
   for (uint32_t b = threadIdx.x; b < NC; b += SORT_THREADS) out[b] = hist[b];
 }
 
-// per (window, coarse bin): exclusive prefix over chunks in place, total into ctot
-__global__ void msm_part1_scan_kernel(uint32_t* __restrict__ chist, uint32_t* __restrict__ ctot, uint32_t G, uint32_t NC,
-                                      uint32_t W) {
-  const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+// per (window, coarse bin): exclusive prefix over chunks in place, total into ctot.
+// One 64-lane workgroup per (window, bin): lanes take contiguous runs of chunks, then a wave scan.
+__global__ __launch_bounds__(64) void msm_part1_scan_kernel(uint32_t* __restrict__ chist, uint32_t* __restrict__ ctot, uint32_t G,
+                                                            uint32_t NC, uint32_t W) {
+  const uint32_t idx = blockIdx.x;
   if (idx >= W * NC) return;
   const uint32_t w = idx / NC, b = idx - w * NC;
-  uint32_t run = 0;
-  for (uint32_t g = 0; g < G; ++g) {
+  const uint32_t lane = threadIdx.x;
+  const uint32_t per = (G + 63) / 64;
+  const uint32_t lo = lane * per, hi = lo + per < G ? lo + per : G;
+  uint32_t sum = 0;
+  for (uint32_t g = lo; g < hi; ++g) sum += chist[((size_t)w * G + g) * NC + b];
+  uint32_t incl = sum;                       // inclusive scan across the 64 lanes
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t v = __shfl_up(incl, off, 64);
+    if (lane >= (uint32_t)off) incl += v;
+  }
+  uint32_t run = incl - sum;
+  for (uint32_t g = lo; g < hi; ++g) {
     uint32_t* p = chist + ((size_t)w * G + g) * NC + b;
     const uint32_t t = *p;
     *p = run;
     run += t;
   }
-  ctot[idx] = run;
+  if (lane == 63) ctot[idx] = incl;
 }
 
 // one block: cstart = exclusive scan of ctot (count <= 16 * 1024 + 1 entries; cstart[count] = total)
@@ -236,10 +248,12 @@ __global__ __launch_bounds__(1024) void msm_part1_starts_kernel(const uint32_t* 
   if (t == 1023) cstart[count] = s[1023];
 }
 
+// ITEM = uint32_t when [fine bits | sign | index] fits 32 bits, else uint64_t
+template <class ITEM>
 __global__ __launch_bounds__(SORT_THREADS) void msm_part1_scatter_kernel(const int32_t* __restrict__ digits,
                                                                          const uint32_t* __restrict__ chist,
                                                                          const uint32_t* __restrict__ cstart,
-                                                                         uint32_t* __restrict__ tmp, size_t n, size_t chunk,
+                                                                         ITEM* __restrict__ tmp, size_t n, size_t chunk,
                                                                          uint32_t fb, uint32_t ib, uint32_t NC) {
   extern __shared__ uint32_t cursor[];
   const uint32_t g = blockIdx.x, w = blockIdx.y, G = gridDim.x;
@@ -254,15 +268,15 @@ __global__ __launch_bounds__(SORT_THREADS) void msm_part1_scatter_kernel(const i
     if (d != 0) {
       const uint32_t b1 = (uint32_t)(d < 0 ? -d : d) - 1u;
       const uint32_t pos = atomicAdd(&cursor[b1 >> fb], 1u);
-      tmp[pos] = ((b1 & fmask) << (ib + 1)) | ((d < 0 ? 1u : 0u) << ib) | (uint32_t)i;
+      tmp[pos] = ((ITEM)(b1 & fmask) << (ib + 1)) | ((ITEM)(d < 0 ? 1u : 0u) << ib) | (ITEM)i;
     }
   });
 }
 
 // part 2, first half: fine histogram of one (coarse bin, window) region -> bucket counts.
 // FROM_DIGITS (cb = 0): the "region" is the whole window and items are read from the digit array.
-template <bool FROM_DIGITS>
-__global__ __launch_bounds__(SORT_THREADS) void msm_part2_hist_kernel(const uint32_t* __restrict__ tmp,
+template <bool FROM_DIGITS, class ITEM>
+__global__ __launch_bounds__(SORT_THREADS) void msm_part2_hist_kernel(const ITEM* __restrict__ tmp,
                                                                       const int32_t* __restrict__ digits,
                                                                       const uint32_t* __restrict__ cstart,
                                                                       uint32_t* __restrict__ bcnt, size_t n, uint32_t fb,
@@ -279,7 +293,7 @@ __global__ __launch_bounds__(SORT_THREADS) void msm_part2_hist_kernel(const uint
     });
   } else {
     const uint32_t lo = cstart[w * NC + hb], hi = cstart[w * NC + hb + 1];
-    block_for_each_word(tmp, lo, hi, [&](size_t, uint32_t item) { atomicAdd(&fine[item >> (ib + 1)], 1u); });
+    block_for_each_word(tmp, lo, hi, [&](size_t, ITEM item) { atomicAdd(&fine[(uint32_t)(item >> (ib + 1))], 1u); });
   }
   __syncthreads();
   uint32_t* out = bcnt + (size_t)w * NBP + 1 + ((size_t)hb << fb);
@@ -288,8 +302,8 @@ __global__ __launch_bounds__(SORT_THREADS) void msm_part2_hist_kernel(const uint
 }
 
 // part 2, second half: scatter the region's items to their final places (boff = global bucket offsets)
-template <bool FROM_DIGITS>
-__global__ __launch_bounds__(SORT_THREADS) void msm_part2_scatter_kernel(const uint32_t* __restrict__ tmp,
+template <bool FROM_DIGITS, class ITEM>
+__global__ __launch_bounds__(SORT_THREADS) void msm_part2_scatter_kernel(const ITEM* __restrict__ tmp,
                                                                          const int32_t* __restrict__ digits,
                                                                          const uint32_t* __restrict__ cstart,
                                                                          const uint32_t* __restrict__ boff,
@@ -311,10 +325,10 @@ __global__ __launch_bounds__(SORT_THREADS) void msm_part2_scatter_kernel(const u
     });
   } else {
     const uint32_t lo = cstart[w * NC + hb], hi = cstart[w * NC + hb + 1];
-    const uint32_t imask = (1u << ib) - 1u;
-    block_for_each_word(tmp, lo, hi, [&](size_t, uint32_t item) {
-      const uint32_t pos = atomicAdd(&cursor[item >> (ib + 1)], 1u);
-      sorted[pos] = (item & imask) | (((item >> ib) & 1u) << 31);
+    const ITEM imask = ((ITEM)1 << ib) - 1;
+    block_for_each_word(tmp, lo, hi, [&](size_t, ITEM item) {
+      const uint32_t pos = atomicAdd(&cursor[(uint32_t)(item >> (ib + 1))], 1u);
+      sorted[pos] = (uint32_t)(item & imask) | ((uint32_t)((item >> ib) & 1) << 31);
     });
   }
 }
@@ -566,10 +580,10 @@ __global__ __launch_bounds__(ACC_THREADS) void msm_reduce_segments_kernel(const 
     run = g1_add(run, load_jac(bw + (size_t)b * PT_WORDS));
     acc = g1_add(acc, run);
   }
-  uint32_t m = lo - 1;  // < 2^15
+  uint32_t m = lo - 1;  // < NB
   if (m != 0 && !run.inf) {
     G1Jac r = g1_identity();
-    for (int bit = 15; bit >= 0; --bit) {
+    for (int bit = 31 - __clz(m); bit >= 0; --bit) {
       r = g1_double(r);
       if ((m >> bit) & 1) r = g1_add(r, run);
     }
@@ -578,35 +592,43 @@ __global__ __launch_bounds__(ACC_THREADS) void msm_reduce_segments_kernel(const 
   store_jac(segres + (size_t)idx * PT_WORDS, acc);
 }
 
-// K4b: one workgroup per window: strided serial sum then an LDS tree; lane 0 converts to the
-// external Jacobian format (12 x u64 + flag word).
-__global__ __launch_bounds__(WIN_THREADS) void msm_reduce_windows_kernel(const uint32_t* __restrict__ segres,
-                                                                         uint32_t nseg, uint32_t* __restrict__ winres) {
+// K4b: sum `count` points per window down to ceil(count / SUM_SPAN) (one workgroup per span: strided
+// serial sums then an LDS tree); applied until one point per window is left.
+constexpr uint32_t SUM_SPAN = WIN_THREADS * 16;
+__global__ __launch_bounds__(WIN_THREADS) void msm_sum_points_kernel(const uint32_t* __restrict__ in, uint32_t count,
+                                                                     uint32_t* __restrict__ out, uint32_t out_count) {
   __shared__ uint32_t tree[WIN_THREADS * PT_WORDS];
-  const uint32_t w = blockIdx.x, t = threadIdx.x;
-  const uint32_t* sw = segres + (size_t)w * nseg * PT_WORDS;
+  const uint32_t w = blockIdx.y, blk = blockIdx.x, t = threadIdx.x;
+  const uint32_t* sw = in + (size_t)w * count * PT_WORDS;
+  const uint32_t lo = blk * SUM_SPAN, hi = lo + SUM_SPAN < count ? lo + SUM_SPAN : count;
   G1Jac acc = g1_identity();
-  for (uint32_t s = t; s < nseg; s += WIN_THREADS) acc = g1_add(acc, load_jac(sw + (size_t)s * PT_WORDS));
+  for (uint32_t s = lo + t; s < hi; s += WIN_THREADS) acc = g1_add(acc, load_jac(sw + (size_t)s * PT_WORDS));
   const G1Jac r = block_sum_points(tree, acc);
-  if (t == 0) {
-    uint32_t* o = winres + (size_t)w * 32;
-    uint32_t wx[8], wy[8], wz[8];
-    if (r.inf) {
+  if (t == 0) store_jac(out + ((size_t)w * out_count + blk) * PT_WORDS, r);
+}
+
+// window sums -> the external Jacobian format (12 x u64 + flag word) the host fold reads
+__global__ void msm_windows_to_ext_kernel(const uint32_t* __restrict__ in, uint32_t W, uint32_t* __restrict__ winres) {
+  const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= W) return;
+  const G1Jac r = load_jac(in + (size_t)w * PT_WORDS);
+  uint32_t* o = winres + (size_t)w * 32;
+  uint32_t wx[8], wy[8], wz[8];
+  if (r.inf) {
 #pragma unroll
-      for (int k = 0; k < 8; ++k) wx[k] = wy[k] = wz[k] = 0;
-    } else {
-      fe_to_ext(wx, r.x);
-      fe_to_ext(wy, r.y);
-      fe_to_ext(wz, r.z);
-    }
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      o[k] = wx[k];
-      o[8 + k] = wy[k];
-      o[16 + k] = wz[k];
-    }
-    o[24] = r.inf ? 1u : 0u;
+    for (int k = 0; k < 8; ++k) wx[k] = wy[k] = wz[k] = 0;
+  } else {
+    fe_to_ext(wx, r.x);
+    fe_to_ext(wy, r.y);
+    fe_to_ext(wz, r.z);
   }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    o[k] = wx[k];
+    o[8 + k] = wy[k];
+    o[16 + k] = wz[k];
+  }
+  o[24] = r.inf ? 1u : 0u;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -648,6 +670,40 @@ __device__ __forceinline__ Fq fq_inverse(const Fq& a) {  // a^(p-2), a a product
     }
   }
   return acc;
+}
+
+// Precomputed multiples for a fixed base set: table[j*n + i] = 2^(c*j) * P_i (affine, internal
+// packed), j < W.  With them every window's digit indexes its own copy of the point and ALL windows
+// share one set of 2^(c-1) buckets, so the window size is no longer capped by W bucket sets (c = 22,
+// W = 12 at 2^24 instead of c = 16, W = 16: a quarter fewer mixed additions) and the final Horner
+// disappears.  One lane per point: c doublings, then a Fermat inversion per stored multiple.
+__global__ __launch_bounds__(ACC_THREADS) void msm_precompute_kernel(uint32_t* __restrict__ table,
+                                                                     const uint8_t* __restrict__ inf, size_t n, uint32_t c,
+                                                                     uint32_t W) {
+  const size_t i = (size_t)blockIdx.x * ACC_THREADS + threadIdx.x;
+  if (i >= n) return;
+  if (inf[i]) {
+    for (uint32_t j = 1; j < W; ++j) {
+      uint4* o = reinterpret_cast<uint4*>(table + ((size_t)j * n + i) * 16);
+      o[0] = o[1] = o[2] = o[3] = make_uint4(0, 0, 0, 0);
+    }
+    return;
+  }
+  G1Jac p = g1_from_affine(load_base(table, (uint32_t)i));
+  for (uint32_t j = 1; j < W; ++j) {
+    for (uint32_t k = 0; k < c; ++k) p = g1_double_nz(p);   // a point of odd prime order never doubles to the identity
+    const Fq zi = fq_inverse(p.z);
+    const Fq zi2 = fe_sqr(zi);
+    const Fq zi3 = fe_mul(zi2, zi);
+    uint32_t ox[8], oy[8];
+    fe_pack(ox, fe_mul(p.x, zi2));
+    fe_pack(oy, fe_mul(p.y, zi3));
+    uint4* o = reinterpret_cast<uint4*>(table + ((size_t)j * n + i) * 16);
+    o[0] = make_uint4(ox[0], ox[1], ox[2], ox[3]);
+    o[1] = make_uint4(ox[4], ox[5], ox[6], ox[7]);
+    o[2] = make_uint4(oy[0], oy[1], oy[2], oy[3]);
+    o[3] = make_uint4(oy[4], oy[5], oy[6], oy[7]);
+  }
 }
 
 __global__ __launch_bounds__(ACC_THREADS) void g1_fixed_base_mul_kernel(const uint32_t* __restrict__ scalars,
@@ -735,8 +791,69 @@ void host_sum_points(const uint64_t* pts, size_t count, uint64_t out_jac_ext[12]
 static int g_window_override = 0;
 void msm_set_window_override(int c) { g_window_override = c; }
 
+// Window size for a precomputed (single bucket set) base set of n points: minimise
+// n * W(c) mixed additions + ~3 * 2^(c-1) addition-equivalents of bucket reduction.
+uint32_t msm_precomp_window(size_t n) {
+  uint32_t best = 8;
+  double best_cost = 1e300;
+  for (uint32_t c = 8; c <= 24; ++c) {
+    const double W = (double)((255 + c - 1) / c);
+    const double cost = (double)n * W + 3.0 * (double)(1ull << (c - 1));
+    if (cost < best_cost) { best_cost = cost; best = c; }
+  }
+  return best;
+}
+
+int msm_precompute(uint32_t* d_table, const uint8_t* d_inf, size_t n, uint32_t c, uint32_t W, hipStream_t stream) {
+  if (n == 0 || W <= 1) return HM_OK;
+  hipLaunchKernelGGL(msm_precompute_kernel, dim3((uint32_t)((n + ACC_THREADS - 1) / ACC_THREADS)), dim3(ACC_THREADS), 0, stream,
+                     d_table, d_inf, n, c, W);
+  HM_HIP_CHECK(hipGetLastError());
+  return HM_OK;
+}
+
+template <class ITEM>
+static int launch_sort(const int32_t* d_digits, uint32_t* d_chist, uint32_t* d_ctot, uint32_t* d_cstart, void* d_tmp,
+                       uint32_t* d_bcnt, size_t sn, size_t chunk, uint32_t G, uint32_t SW, uint32_t fb, uint32_t ib, uint32_t cb,
+                       uint32_t NC, uint32_t NBP, hipStream_t stream) {
+  const size_t lds_fine = (size_t)4 << fb;
+  if (cb) {
+    const size_t lds_coarse = (size_t)NC * 4;
+    hipLaunchKernelGGL(msm_part1_hist_kernel, dim3(G, SW), dim3(SORT_THREADS), lds_coarse, stream, d_digits, d_chist, sn, chunk,
+                       fb, NC);
+    hipLaunchKernelGGL(msm_part1_scan_kernel, dim3(SW * NC), dim3(64), 0, stream, d_chist, d_ctot, G, NC, SW);
+    hipLaunchKernelGGL(msm_part1_starts_kernel, dim3(1), dim3(1024), 0, stream, (const uint32_t*)d_ctot, d_cstart, SW * NC);
+    hipLaunchKernelGGL(msm_part1_scatter_kernel<ITEM>, dim3(G, SW), dim3(SORT_THREADS), lds_coarse, stream, d_digits,
+                       (const uint32_t*)d_chist, (const uint32_t*)d_cstart, (ITEM*)d_tmp, sn, chunk, fb, ib, NC);
+    hipLaunchKernelGGL((msm_part2_hist_kernel<false, ITEM>), dim3(NC, SW), dim3(SORT_THREADS), lds_fine, stream,
+                       (const ITEM*)d_tmp, d_digits, (const uint32_t*)d_cstart, d_bcnt, sn, fb, ib, NC, NBP);
+  } else {
+    hipLaunchKernelGGL((msm_part2_hist_kernel<true, ITEM>), dim3(1, SW), dim3(SORT_THREADS), lds_fine, stream,
+                       (const ITEM*)d_tmp, d_digits, (const uint32_t*)d_cstart, d_bcnt, sn, fb, ib, NC, NBP);
+  }
+  HM_HIP_CHECK(hipGetLastError());
+  return HM_OK;
+}
+
+template <class ITEM>
+static int launch_sort_scatter(const int32_t* d_digits, const uint32_t* d_cstart, const void* d_tmp, const uint32_t* d_boff,
+                               uint32_t* d_sorted, size_t sn, uint32_t SW, uint32_t fb, uint32_t ib, uint32_t cb, uint32_t NC,
+                               uint32_t NBP, hipStream_t stream) {
+  const size_t lds_fine = (size_t)4 << fb;
+  if (cb) {
+    hipLaunchKernelGGL((msm_part2_scatter_kernel<false, ITEM>), dim3(NC, SW), dim3(SORT_THREADS), lds_fine, stream,
+                       (const ITEM*)d_tmp, d_digits, d_cstart, d_boff, d_sorted, sn, fb, ib, NC, NBP);
+  } else {
+    hipLaunchKernelGGL((msm_part2_scatter_kernel<true, ITEM>), dim3(1, SW), dim3(SORT_THREADS), lds_fine, stream,
+                       (const ITEM*)d_tmp, d_digits, d_cstart, d_boff, d_sorted, sn, fb, ib, NC, NBP);
+  }
+  HM_HIP_CHECK(hipGetLastError());
+  return HM_OK;
+}
+
+// d_xy: n points (plain) or the precomputed table of precomp_W * n points (precomp_c != 0).
 int msm_run(DeviceCtx& ctx, const uint32_t* d_scalars_ext, const uint32_t* d_xy, const uint8_t* d_inf, size_t n,
-            int c_override, uint64_t out_jac_ext[12], int* out_is_identity, hipStream_t stream) {
+            uint32_t precomp_c, uint64_t out_jac_ext[12], int* out_is_identity, hipStream_t stream) {
   if (n == 0) {
     std::memset(out_jac_ext, 0, 96);
     *out_is_identity = 1;
@@ -744,55 +861,73 @@ int msm_run(DeviceCtx& ctx, const uint32_t* d_scalars_ext, const uint32_t* d_xy,
   }
   if (n >= (1ull << 31)) return hm_fail(HM_ERR_BAD_ARG, "msm: n must be < 2^31");
   // ---- plan ---------------------------------------------------------------------------------
-  int ci = c_override > 0 ? c_override : (g_window_override > 0 ? g_window_override : 0);
-  if (ci == 0) {
+  const bool single_set = precomp_c != 0;     // all windows accumulate into ONE bucket set
+  uint32_t c;
+  if (single_set) {
+    c = precomp_c;
+  } else if (g_window_override > 0) {
+    c = (uint32_t)g_window_override;
+  } else {
     // mean bucket load n / 2^(c-1) ~ 16: short accumulation chains, (almost) no bucket splitting,
-    // fewest (point, bucket) pairs; capped by the 2^15-counter LDS histogram of the sort
-    const int l2 = (int)ilog2(n);
-    ci = l2 - 3;
+    // fewest (point, bucket) pairs; capped by W separate bucket sets and their reduction
+    int ci = (int)ilog2(n) - 3;
     if (ci < 4) ci = 4;
     if (ci > 16) ci = 16;
+    c = (uint32_t)ci;
   }
-  if (ci < 2 || ci > 16) return hm_fail(HM_ERR_BAD_ARG, "msm: window size must be in [2, 16]");
-  const uint32_t c = (uint32_t)ci;
+  if (c < 2 || c > 24) return hm_fail(HM_ERR_BAD_ARG, "msm: window size out of range");
   const uint32_t W = (255 + c - 1) / c;
-  const uint32_t NB = 1u << (c - 1), NBP = NB + 1, NBT = W * NBP;
-  if ((uint64_t)n * W >= (1ull << 32)) return hm_fail(HM_ERR_BAD_ARG, "msm: n * windows must be < 2^32");
-  const double mean = (double)n / (double)NB;
+  const uint32_t SW = single_set ? 1u : W;                 // bucket sets ("sort windows")
+  const size_t sn = single_set ? n * W : n;                // items per bucket set
+  const uint32_t NB = 1u << (c - 1), NBP = NB + 1, NBT = SW * NBP;
+  const uint64_t pairs_max = (uint64_t)n * W;
+  if (pairs_max >= (1ull << 31)) return hm_fail(HM_ERR_BAD_ARG, "msm: n * windows must be < 2^31");
+  const double mean = (double)sn / (double)NB;
   uint32_t L = (uint32_t)(mean + 4.0 * std::sqrt(mean) + 8.0);
   {
     // small inputs: if one task per bucket would leave the chip (256 CUs x 4 SIMDs x ~5 waves x 64
     // lanes) mostly idle, cut the tasks shorter so that the launch still fills it
     const double target_tasks = 327680.0;
-    const double pairs = (double)n * W;
-    if (pairs / (double)L < target_tasks) L = (uint32_t)(pairs / target_tasks);
+    if ((double)pairs_max / (double)L < target_tasks) L = (uint32_t)((double)pairs_max / target_tasks);
   }
   if (L < 16) L = 16;
-  uint32_t G = (uint32_t)((n + 16383) / 16384);
+  // chunks of the first sort level: >= 16 Ki items each, ~64 Ki at scale; G * SW workgroups should
+  // cover the chip several times over (a shared bucket set has SW = 1, so it needs many chunks)
+  uint32_t G = (uint32_t)((sn + 16383) / 16384);
   if (G < 1) G = 1;
-  if (G > 256) G = 256;
-  const size_t chunk = (n + G - 1) / G;
-  const uint64_t pairs_max = (uint64_t)n * W;
+  const uint32_t g_cap = SW >= 8 ? 256u : 4096u;
+  if (G > g_cap) {
+    G = (uint32_t)((sn + 65535) / 65536);
+    if (G > g_cap) G = g_cap;
+    if (G < 256) G = 256;
+  }
+  const size_t chunk = (sn + G - 1) / G;
   const uint64_t T_max = pairs_max / L + NBT + 1;
-  uint32_t SEG = 8;    // running-sum chain per lane in K4a: 2*SEG additions + a <= 15-bit scalar multiple
+  // K4a: running-sum chain of 2*SEG additions per lane + a scalar multiple of <= log2(NB) bits
+  uint32_t SEG = NB > (1u << 16) ? 32u : 8u;
   if (SEG > NB) SEG = NB;
   const uint32_t nseg = (NB + SEG - 1) / SEG;
+  // sort plan: item = [fine bucket bits | sign | item index]
+  uint32_t ib = ilog2(sn) + ((sn & (sn - 1)) ? 1u : 0u);
+  if (ib == 0) ib = 1;
+  bool wide_items = false;
+  uint32_t fb = c - 1 < 31 - ib ? c - 1 : 31 - ib;
+  if (fb < 5 && c - 1 > fb) {            // too few fine bits left in 32: switch to 64-bit items
+    wide_items = true;
+    fb = c - 1 < 9 ? c - 1 : 9;      // few fine runs per region: the region's write sectors must stay in L2
+  }
+  if (sn >= (1u << 15) && (c - 1) - fb < 5) fb = c - 1 > 5 ? c - 1 - 5 : 0;   // >= 32 regions per set: enough workgroups
+  const uint32_t cb = (c - 1) - fb, NC = 1u << cb;
 
   // ---- workspace ----------------------------------------------------------------------------
   auto align = [](size_t v) { return (v + 255) & ~(size_t)255; };
   size_t off = 0;
   auto carve = [&](size_t bytes) { size_t o = off; off += align(bytes); return o; };
   const size_t o_digits = carve((size_t)W * n * 4);
-  // sort plan: item = [fine bucket bits | sign | point index] in 32 bits
-  uint32_t ib = ilog2(n) + ((n & (n - 1)) ? 1u : 0u);
-  if (ib == 0) ib = 1;
-  uint32_t fb = c - 1 < 31 - ib ? c - 1 : 31 - ib;
-  if (n >= (1u << 15) && (c - 1) - fb < 5) fb = c - 1 > 5 ? c - 1 - 5 : 0;   // >= 32 regions per window: enough workgroups
-  const uint32_t cb = (c - 1) - fb, NC = 1u << cb;
-  const size_t o_chist = carve((size_t)W * G * NC * 4);
-  const size_t o_ctot = carve((size_t)W * NC * 4);
-  const size_t o_cstart = carve(((size_t)W * NC + 1) * 4);
-  const size_t o_tmp = carve(cb ? pairs_max * 4 : 4);
+  const size_t o_chist = carve((size_t)SW * G * NC * 4);
+  const size_t o_ctot = carve((size_t)SW * NC * 4);
+  const size_t o_cstart = carve(((size_t)SW * NC + 1) * 4);
+  const size_t o_tmp = carve(cb ? pairs_max * (wide_items ? 8 : 4) : 4);
   const size_t o_bcnt = carve((size_t)NBT * 4);
   const size_t o_boff = carve((size_t)NBT * 4);
   const size_t o_toff = carve(((size_t)NBT + 1) * 4);
@@ -802,8 +937,9 @@ int msm_run(DeviceCtx& ctx, const uint32_t* d_scalars_ext, const uint32_t* d_xy,
   const size_t o_tb = carve(T_max * 4);
   const size_t o_partial = carve(T_max * PT_WORDS * 4);
   const size_t o_bucket = carve((size_t)NBT * PT_WORDS * 4);
-  const size_t o_seg = carve((size_t)W * nseg * PT_WORDS * 4);
-  const size_t o_win = carve((size_t)W * 32 * 4);
+  const size_t o_seg = carve((size_t)SW * nseg * PT_WORDS * 4);
+  const size_t o_seg2 = carve(((size_t)SW * (nseg / SUM_SPAN + 1)) * PT_WORDS * 4);
+  const size_t o_win = carve((size_t)SW * 32 * 4);
   const size_t o_big = carve(((size_t)NBT + 4) * 4);
   uint8_t* ws = (uint8_t*)ctx.msm_ws.ensure(off);
   if (!ws) return hm_fail(HM_ERR_HIP, "msm: workspace allocation failed");
@@ -811,7 +947,7 @@ int msm_run(DeviceCtx& ctx, const uint32_t* d_scalars_ext, const uint32_t* d_xy,
   uint32_t* d_chist = (uint32_t*)(ws + o_chist);
   uint32_t* d_ctot = (uint32_t*)(ws + o_ctot);
   uint32_t* d_cstart = (uint32_t*)(ws + o_cstart);
-  uint32_t* d_tmp = (uint32_t*)(ws + o_tmp);
+  void* d_tmp = (void*)(ws + o_tmp);
   uint32_t* d_bcnt = (uint32_t*)(ws + o_bcnt);
   uint32_t* d_boff = (uint32_t*)(ws + o_boff);
   uint32_t* d_toff = (uint32_t*)(ws + o_toff);
@@ -822,19 +958,25 @@ int msm_run(DeviceCtx& ctx, const uint32_t* d_scalars_ext, const uint32_t* d_xy,
   uint32_t* d_partial = (uint32_t*)(ws + o_partial);
   uint32_t* d_bucket = (uint32_t*)(ws + o_bucket);
   uint32_t* d_seg = (uint32_t*)(ws + o_seg);
+  uint32_t* d_seg2 = (uint32_t*)(ws + o_seg2);
   uint32_t* d_win = (uint32_t*)(ws + o_win);
   uint32_t* d_big_count = (uint32_t*)(ws + o_big);
   uint32_t* d_big_list = d_big_count + 4;
 
   if (!ctx.msm_attr_set) {   // per device: a process may drive several GPUs
-    HM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(msm_part2_hist_kernel<true>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 32768 * 4));
-    HM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(msm_part2_hist_kernel<false>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 32768 * 4));
-    HM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(msm_part2_scatter_kernel<true>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 32768 * 4));
-    HM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(msm_part2_scatter_kernel<false>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 32768 * 4));
+    const int lds_max = 32768 * 4;
+    HM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(msm_part2_hist_kernel<true, uint32_t>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+    HM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(msm_part2_hist_kernel<false, uint32_t>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+    HM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(msm_part2_hist_kernel<false, uint64_t>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+    HM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(msm_part2_scatter_kernel<true, uint32_t>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+    HM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(msm_part2_scatter_kernel<false, uint32_t>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+    HM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(msm_part2_scatter_kernel<false, uint64_t>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
     ctx.msm_attr_set = true;
   }
   hipEvent_t* ev = ctx.msm_events;
@@ -851,23 +993,14 @@ int msm_run(DeviceCtx& ctx, const uint32_t* d_scalars_ext, const uint32_t* d_xy,
   HM_HIP_CHECK(hipEventRecord(ev[1], stream));
 
   // ---- K2 ------------------------------------------------------------------------------------
-  const size_t lds_fine = (size_t)4 << fb;
-  if (cb) {
-    const size_t lds_coarse = (size_t)NC * 4;
-    hipLaunchKernelGGL(msm_part1_hist_kernel, dim3(G, W), dim3(SORT_THREADS), lds_coarse, stream, (const int32_t*)d_digits,
-                       d_chist, n, chunk, fb, NC);
-    hipLaunchKernelGGL(msm_part1_scan_kernel, dim3((W * NC + 255) / 256), dim3(256), 0, stream, d_chist, d_ctot, G, NC, W);
-    hipLaunchKernelGGL(msm_part1_starts_kernel, dim3(1), dim3(1024), 0, stream, (const uint32_t*)d_ctot, d_cstart, W * NC);
-    hipLaunchKernelGGL(msm_part1_scatter_kernel, dim3(G, W), dim3(SORT_THREADS), lds_coarse, stream,
-                       (const int32_t*)d_digits, (const uint32_t*)d_chist, (const uint32_t*)d_cstart, d_tmp, n, chunk, fb, ib,
-                       NC);
-    hipLaunchKernelGGL(msm_part2_hist_kernel<false>, dim3(NC, W), dim3(SORT_THREADS), lds_fine, stream,
-                       (const uint32_t*)d_tmp, (const int32_t*)d_digits, (const uint32_t*)d_cstart, d_bcnt, n, fb, ib, NC, NBP);
-  } else {
-    hipLaunchKernelGGL(msm_part2_hist_kernel<true>, dim3(1, W), dim3(SORT_THREADS), lds_fine, stream,
-                       (const uint32_t*)d_tmp, (const int32_t*)d_digits, (const uint32_t*)d_cstart, d_bcnt, n, fb, ib, NC, NBP);
+  {
+    const int rc = wide_items
+                       ? launch_sort<uint64_t>(d_digits, d_chist, d_ctot, d_cstart, d_tmp, d_bcnt, sn, chunk, G, SW, fb, ib, cb,
+                                               NC, NBP, stream)
+                       : launch_sort<uint32_t>(d_digits, d_chist, d_ctot, d_cstart, d_tmp, d_bcnt, sn, chunk, G, SW, fb, ib, cb,
+                                               NC, NBP, stream);
+    if (rc != HM_OK) return rc;
   }
-  HM_HIP_CHECK(hipGetLastError());
   {
     const uint32_t nblocks = (NBT + SCAN_BLOCK - 1) / SCAN_BLOCK;
     hipLaunchKernelGGL(msm_scan_partial_kernel, dim3(nblocks), dim3(SCAN_THREADS), 0, stream, (const uint32_t*)d_bcnt,
@@ -877,16 +1010,13 @@ int msm_run(DeviceCtx& ctx, const uint32_t* d_scalars_ext, const uint32_t* d_xy,
                        (const uint32_t*)d_bsum, d_boff, d_toff, (const uint32_t*)d_tot, NBT, L);
     HM_HIP_CHECK(hipGetLastError());
   }
-  if (cb) {
-    hipLaunchKernelGGL(msm_part2_scatter_kernel<false>, dim3(NC, W), dim3(SORT_THREADS), lds_fine, stream,
-                       (const uint32_t*)d_tmp, (const int32_t*)d_digits, (const uint32_t*)d_cstart, (const uint32_t*)d_boff,
-                       d_sorted, n, fb, ib, NC, NBP);
-  } else {
-    hipLaunchKernelGGL(msm_part2_scatter_kernel<true>, dim3(1, W), dim3(SORT_THREADS), lds_fine, stream,
-                       (const uint32_t*)d_tmp, (const int32_t*)d_digits, (const uint32_t*)d_cstart, (const uint32_t*)d_boff,
-                       d_sorted, n, fb, ib, NC, NBP);
+  {
+    const int rc = wide_items ? launch_sort_scatter<uint64_t>(d_digits, d_cstart, d_tmp, d_boff, d_sorted, sn, SW, fb, ib, cb, NC,
+                                                              NBP, stream)
+                              : launch_sort_scatter<uint32_t>(d_digits, d_cstart, d_tmp, d_boff, d_sorted, sn, SW, fb, ib, cb, NC,
+                                                              NBP, stream);
+    if (rc != HM_OK) return rc;
   }
-  HM_HIP_CHECK(hipGetLastError());
   hipLaunchKernelGGL(msm_task_fill_kernel, dim3((NBT + 255) / 256), dim3(256), 0, stream, (const uint32_t*)d_toff, d_tb,
                      NBT);
   HM_HIP_CHECK(hipGetLastError());
@@ -921,17 +1051,30 @@ int msm_run(DeviceCtx& ctx, const uint32_t* d_scalars_ext, const uint32_t* d_xy,
   HM_HIP_CHECK(hipEventRecord(ev[3], stream));
 
   // ---- K4 ------------------------------------------------------------------------------------
-  hipLaunchKernelGGL(msm_reduce_segments_kernel, dim3((W * nseg + ACC_THREADS - 1) / ACC_THREADS), dim3(ACC_THREADS), 0,
-                     stream, (const uint32_t*)d_bucket, d_seg, W, NB, NBP, SEG, nseg);
+  hipLaunchKernelGGL(msm_reduce_segments_kernel, dim3((SW * nseg + ACC_THREADS - 1) / ACC_THREADS), dim3(ACC_THREADS), 0,
+                     stream, (const uint32_t*)d_bucket, d_seg, SW, NB, NBP, SEG, nseg);
   HM_HIP_CHECK(hipGetLastError());
-  hipLaunchKernelGGL(msm_reduce_windows_kernel, dim3(W), dim3(WIN_THREADS), 0, stream, (const uint32_t*)d_seg, nseg, d_win);
-  HM_HIP_CHECK(hipGetLastError());
-  std::vector<uint32_t> win((size_t)W * 32);
+  {
+    uint32_t* cur = d_seg;
+    uint32_t* nxt = d_seg2;
+    uint32_t count = nseg;
+    while (count > 1) {
+      const uint32_t out_count = (count + SUM_SPAN - 1) / SUM_SPAN;
+      hipLaunchKernelGGL(msm_sum_points_kernel, dim3(out_count, SW), dim3(WIN_THREADS), 0, stream, (const uint32_t*)cur, count, nxt,
+                         out_count);
+      HM_HIP_CHECK(hipGetLastError());
+      uint32_t* t = cur; cur = nxt; nxt = t;
+      count = out_count;
+    }
+    hipLaunchKernelGGL(msm_windows_to_ext_kernel, dim3((SW + 63) / 64), dim3(64), 0, stream, (const uint32_t*)cur, SW, d_win);
+    HM_HIP_CHECK(hipGetLastError());
+  }
+  std::vector<uint32_t> win((size_t)SW * 32);
   HM_HIP_CHECK(hipMemcpyAsync(win.data(), d_win, win.size() * 4, hipMemcpyDeviceToHost, stream));
   HM_HIP_CHECK(hipEventRecord(ev[4], stream));
   HM_HIP_CHECK(hipStreamSynchronize(stream));
 
-  host_fold(win.data(), W, c, out_jac_ext, out_is_identity);
+  host_fold(win.data(), SW, c, out_jac_ext, out_is_identity);   // SW == 1: no Horner, just the normalisation
 
   float ms[4] = {0, 0, 0, 0}, total = 0;
   for (int i = 0; i < 4; ++i) (void)hipEventElapsedTime(&ms[i], ev[i], ev[i + 1]);

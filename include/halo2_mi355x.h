@@ -75,6 +75,14 @@ int hm_release_bases(uint64_t handle);
 int hm_msm_bn256_g1_h(uint64_t handle, size_t offset, const uint64_t* scalars, size_t n, uint64_t out_xy[8],
                       int* out_is_identity);
 
+/* Fixed-base variant for long-lived SRS sets: additionally precomputes 2^(c*j) * P_i for every
+ * window j (W x the memory: 12 GiB for 2^24 points -- sized for 288 GB of HBM), so that all windows
+ * share one bucket set, the window grows from 16 to 22 bits and a quarter of the mixed additions
+ * disappears.  MSMs that cover the whole set (offset 0, n = set size) use the table; other slices
+ * fall back to the plain path on the same handle.  Results are identical either way. */
+int hm_register_bases_precomp(const uint64_t* bases, size_t n, uint64_t* out_handle);
+int hm_register_bases_precomp_dev(const void* d_bases, size_t n, void* stream, uint64_t* out_handle);
+
 /* Device-pointer forms (inputs already in HBM; `stream` is a hipStream_t or NULL).  The result is
  * written to host memory, so the call synchronises `stream` before returning. */
 int hm_register_bases_dev(const void* d_bases, size_t n, void* stream, uint64_t* out_handle);

@@ -178,3 +178,62 @@ def test_commit_lagrange_equals_commit(cref, pyref):
     c2 = h.best_multiexp(ev, h.register_bases(gl))
     assert np.array_equal(c1, c2) and c1[8:].any()
     assert g1_equal(c1, cref.g1_mul(o.fr_array([o.poly_eval(f, xv)])[0], gen))
+
+
+# ---- fixed-base mode: precomputed 2^(c*j) * P_i, one shared bucket set --------------------------
+
+def test_precomputed_bases_golden_and_slices(cref, golden):
+    g = golden["msm"]
+    for name in ("n1024_uniform", "n1024_prover", "n1024_one", "n1024_rminus1", "n255_uniform", "n1024_small"):
+        s, b = g[f"{name}_s"], g[f"{name}_b"]
+        hd = h.register_bases(b, precompute=True)
+        try:
+            assert g1_equal(h.best_multiexp(s, hd), g[f"{name}_r"]), name
+            if s.shape[0] == 1024:                 # a slice of the set falls back to the plain path on the same handle
+                exp = cref.g1_to_affine(cref.best_multiexp(s[10:700], b[10:700], 4))[0]
+                assert g1_equal(h.best_multiexp(s[10:700], hd, offset=10), exp), name
+        finally:
+            h.release_bases(hd)
+
+
+@pytest.mark.parametrize("log_n,kind", [(12, "uniform"), (15, "prover"), (16, "uniform"), (17, "one")])
+def test_precomputed_bases_match_oracle(cref, pyref, log_n, kind):
+    o = pyref
+    n = 1 << log_n
+    gen = cref.g1_generator()
+    bases = h.g1_fixed_base_mul(rand_fr_gpu(n, 5 * log_n), gen).cpu().numpy().view(np.uint64).copy()
+    bases[2] = 0                      # identity base
+    bases[5] = bases[6]               # duplicate points
+    bases[9] = bases[8].copy()
+    if kind == "uniform":
+        s = rand_fr_gpu(n, log_n + 100).cpu().numpy().view(np.uint64)
+    else:
+        s = np.tile(o.fr_array(o.rand_scalars(4096, log_n, kind)), (n // 4096, 1))
+    exp = cref.g1_to_affine(cref.best_multiexp(s, bases, 8))[0]
+    hd = h.register_bases(bases, precompute=True)
+    try:
+        assert g1_equal(h.best_multiexp(s, hd), exp)
+        plain = h.best_multiexp(s, bases)
+        assert g1_equal(plain, exp)
+    finally:
+        h.release_bases(hd)
+
+
+def test_precomputed_full_size_kzg_known_answer(cref, pyref):
+    import torch
+    o = pyref
+    log_n = 22
+    n = 1 << log_n
+    x = o.fr_array([0x48324D4933353558])[0]
+    powers = torch.from_numpy(cref.fr_powers(x, n).view(np.int64)).cuda()
+    srs = h.g1_fixed_base_mul(powers, cref.g1_generator())
+    hd = h.register_bases(srs, precompute=True)
+    try:
+        f = rand_fr_gpu(n, 777)
+        got = h.best_multiexp(f, hd)
+        st = h.msm_stats()
+        assert st["window_bits"] > 16                       # the shared-bucket-set plan was used
+        fx = cref.fr_horner(f.cpu().numpy().view(np.uint64), x)
+        assert g1_equal(got, cref.g1_mul(fx, cref.g1_generator()))
+    finally:
+        h.release_bases(hd)

@@ -17,7 +17,10 @@ sizes = [int(a) for a in sys.argv[1].split(",")] if len(sys.argv) > 1 else [12, 
 windows = [int(a) for a in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0]
 for k in sizes:
     n = 1 << k
-    hd = h.register_bases(h.g1_fixed_base_mul(rand_fr(n, 11), G1_GENERATOR))
+    pre = os.environ.get("PRECOMP", "0") == "1"
+    t0 = time.perf_counter()
+    hd = h.register_bases(h.g1_fixed_base_mul(rand_fr(n, 11), G1_GENERATOR), precompute=pre)
+    torch.cuda.synchronize(); print(f"  register(precompute={pre}) {(time.perf_counter()-t0)*1e3:.1f} ms")
     s = rand_fr(n, 12)
     for c in windows:
         _lib.check(_lib.load().hm_msm_set_window(c))
