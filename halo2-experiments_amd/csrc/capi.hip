@@ -317,12 +317,46 @@ int hm_get_msm_stats(hm_msm_stats* out) {
 
 // ---- NTT -------------------------------------------------------------------------------------
 
+static int small_consts(DeviceCtx& ctx, const uint64_t* ext, uint32_t count, hipStream_t stream, uint32_t** d_int) {
+  // small buffer layout: [0, 4096) reserved for the fixed-base table header; constants live after it
+  uint8_t* sm = (uint8_t*)ctx.small.ensure(64 + (size_t)64 * 15 * 28 * 4 + 4096);
+  if (!sm) return hm_fail(HM_ERR_HIP, "constant buffer allocation failed");
+  uint8_t* area = sm + 64 + (size_t)64 * 15 * 28 * 4;
+  uint32_t* d_ext = (uint32_t*)area;
+  *d_int = (uint32_t*)(area + 1024);
+  HM_HIP_CHECK(hipMemcpyAsync(d_ext, ext, (size_t)count * 32, hipMemcpyHostToDevice, stream));
+  return fr_ext_to_int_run(d_ext, *d_int, count, stream);
+}
+
 int hm_ntt_bn256_fr_dev(void* d_a, const uint64_t omega[4], uint32_t log_n, void* stream) {
   if (!d_a || !omega) return hm_fail(HM_ERR_BAD_ARG, "hm_ntt_bn256_fr_dev: null argument");
   DeviceCtx* ctx = ctx_for_current_device();
   if (!ctx) return HM_ERR_NO_DEVICE;
   std::lock_guard<std::mutex> lk(ctx->mu);
-  return ntt_run(*ctx, (uint32_t*)d_a, omega, log_n, nullptr, nullptr, (hipStream_t)stream);
+  return ntt_run(*ctx, (uint32_t*)d_a, omega, log_n, 1, nullptr, nullptr, (hipStream_t)stream);
+}
+
+int hm_ntt_batch_bn256_fr_dev(void* d_a, size_t batch, const uint64_t omega[4], uint32_t log_n, const uint64_t* scale,
+                              const uint64_t* coset, void* stream) {
+  if ((batch && !d_a) || !omega) return hm_fail(HM_ERR_BAD_ARG, "hm_ntt_batch_bn256_fr_dev: null argument");
+  if (batch > 65535) return hm_fail(HM_ERR_BAD_ARG, "hm_ntt_batch_bn256_fr_dev: batch > 65535");
+  DeviceCtx* ctx = ctx_for_current_device();
+  if (!ctx) return HM_ERR_NO_DEVICE;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  uint32_t* d_scale = nullptr;
+  uint32_t* d_coset = nullptr;
+  if (scale || coset) {
+    uint64_t ext[16];
+    std::memset(ext, 0, sizeof ext);
+    if (scale) std::memcpy(ext, scale, 32);
+    if (coset) std::memcpy(ext + 4, coset, 96);
+    uint32_t* d_int = nullptr;
+    int rc = small_consts(*ctx, ext, 4, (hipStream_t)stream, &d_int);
+    if (rc != HM_OK) return rc;
+    if (scale) d_scale = d_int;
+    if (coset) d_coset = d_int + 9;
+  }
+  return ntt_run(*ctx, (uint32_t*)d_a, omega, log_n, (uint32_t)batch, d_scale, d_coset, (hipStream_t)stream);
 }
 
 int hm_ntt_bn256_fr(uint64_t* a, const uint64_t omega[4], uint32_t log_n) {
@@ -335,22 +369,12 @@ int hm_ntt_bn256_fr(uint64_t* a, const uint64_t omega[4], uint32_t log_n) {
   void* d_a = ctx->io.ensure(bytes);
   if (!d_a) return hm_fail(HM_ERR_HIP, "hm_ntt_bn256_fr: staging allocation failed");
   HM_HIP_CHECK(hipMemcpy(d_a, a, bytes, hipMemcpyHostToDevice));
-  int rc = ntt_run(*ctx, (uint32_t*)d_a, omega, log_n, nullptr, nullptr, nullptr);
+  int rc = ntt_run(*ctx, (uint32_t*)d_a, omega, log_n, 1, nullptr, nullptr, nullptr);
   if (rc != HM_OK) return rc;
   HM_HIP_CHECK(hipMemcpy(a, d_a, bytes, hipMemcpyDeviceToHost));
   return HM_OK;
 }
 
-static int small_consts(DeviceCtx& ctx, const uint64_t* ext, uint32_t count, hipStream_t stream, uint32_t** d_int) {
-  // small buffer layout: [0, 4096) reserved for the fixed-base table header; constants live after it
-  uint8_t* sm = (uint8_t*)ctx.small.ensure(64 + (size_t)64 * 15 * 28 * 4 + 4096);
-  if (!sm) return hm_fail(HM_ERR_HIP, "constant buffer allocation failed");
-  uint8_t* area = sm + 64 + (size_t)64 * 15 * 28 * 4;
-  uint32_t* d_ext = (uint32_t*)area;
-  *d_int = (uint32_t*)(area + 1024);
-  HM_HIP_CHECK(hipMemcpyAsync(d_ext, ext, (size_t)count * 32, hipMemcpyHostToDevice, stream));
-  return fr_ext_to_int_run(d_ext, *d_int, count, stream);
-}
 
 int hm_ifft_bn256_fr_dev(void* d_a, const uint64_t omega_inv[4], uint32_t log_n, const uint64_t divisor[4], void* stream) {
   if (!d_a || !omega_inv || !divisor) return hm_fail(HM_ERR_BAD_ARG, "hm_ifft_bn256_fr_dev: null argument");
@@ -360,7 +384,7 @@ int hm_ifft_bn256_fr_dev(void* d_a, const uint64_t omega_inv[4], uint32_t log_n,
   uint32_t* d_int = nullptr;
   int rc = small_consts(*ctx, divisor, 1, (hipStream_t)stream, &d_int);
   if (rc != HM_OK) return rc;
-  return ntt_run(*ctx, (uint32_t*)d_a, omega_inv, log_n, d_int, nullptr, (hipStream_t)stream);
+  return ntt_run(*ctx, (uint32_t*)d_a, omega_inv, log_n, 1, d_int, nullptr, (hipStream_t)stream);
 }
 
 int hm_coset_ntt_bn256_fr_dev(void* d_a, const uint64_t omega[4], uint32_t log_n, const uint64_t coset[12], void* stream) {
@@ -371,7 +395,7 @@ int hm_coset_ntt_bn256_fr_dev(void* d_a, const uint64_t omega[4], uint32_t log_n
   uint32_t* d_int = nullptr;
   int rc = small_consts(*ctx, coset, 3, (hipStream_t)stream, &d_int);
   if (rc != HM_OK) return rc;
-  return ntt_run(*ctx, (uint32_t*)d_a, omega, log_n, nullptr, d_int, (hipStream_t)stream);
+  return ntt_run(*ctx, (uint32_t*)d_a, omega, log_n, 1, nullptr, d_int, (hipStream_t)stream);
 }
 
 int hm_fr_scale_dev(void* d_a, size_t n, const uint64_t c[4], void* stream) {

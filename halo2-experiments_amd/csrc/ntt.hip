@@ -166,6 +166,9 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(const uint32_t* i
   const uint32_t tile_elems = 1u << (s + log_c);  // <= 2^LOG_TILE
   const uint32_t cmask = (1u << log_c) - 1u;
   const uint64_t tile = blockIdx.x;
+  // batched transforms: blockIdx.y selects one of `gridDim.y` back-to-back arrays of n elements
+  in += ((size_t)blockIdx.y << pp.log_n) * 8;
+  out += ((size_t)blockIdx.y << pp.log_n) * 8;
 
   // ---- tile -> global index mapping ---------------------------------------------------------
   // non-last: element (d, c) lives at  o*m + d*stride + i0 + c        (m = R*stride)
@@ -385,11 +388,13 @@ NttTables* ntt_get_tables(DeviceCtx& ctx, const uint64_t omega_ext[4], uint32_t 
   return ctx.ntt_tables.back().get();
 }
 
-// d_a: n x 32 B device buffer, transformed in place.  d_scale_int / d_coset_int: optional 9-limb
+// d_a: `batch` back-to-back arrays of n x 32 B on the device, each transformed in place.  d_scale_int / d_coset_int: optional 9-limb
 // internal-form constants already on the device.
-int ntt_run(DeviceCtx& ctx, uint32_t* d_a, const uint64_t omega_ext[4], uint32_t log_n, const uint32_t* d_scale_int,
-            const uint32_t* d_coset_int, hipStream_t stream) {
+int ntt_run(DeviceCtx& ctx, uint32_t* d_a, const uint64_t omega_ext[4], uint32_t log_n, uint32_t batch,
+            const uint32_t* d_scale_int, const uint32_t* d_coset_int, hipStream_t stream) {
   if (log_n > 28) return hm_fail(HM_ERR_BAD_ARG, "ntt: log_n > 28 (Fr has 2-adicity 28)");
+  if (batch == 0) return HM_OK;
+  if (batch > 65535) return hm_fail(HM_ERR_BAD_ARG, "ntt: batch > 65535");
   NttTables* tab = ntt_get_tables(ctx, omega_ext, log_n, stream);
   if (!tab) return hm_fail(HM_ERR_HIP, "ntt: twiddle table allocation failed");
   uint32_t digits[3] = {0, 0, 0};
@@ -397,7 +402,7 @@ int ntt_run(DeviceCtx& ctx, uint32_t* d_a, const uint64_t omega_ext[4], uint32_t
   const uint64_t n = 1ull << log_n;
   uint32_t* scratch = nullptr;
   if (passes > 1) {
-    scratch = (uint32_t*)ctx.ensure_scratch(n * 32);
+    scratch = (uint32_t*)ctx.ensure_scratch(n * 32 * batch);
     if (!scratch) return hm_fail(HM_ERR_HIP, "ntt: scratch allocation failed");
   }
   const size_t lds_bytes = (size_t)9 * sizeof(uint32_t) << LOG_TILE;
@@ -437,7 +442,7 @@ int ntt_run(DeviceCtx& ctx, uint32_t* d_a, const uint64_t omega_ext[4], uint32_t
       }
       (void)log_m;
     }
-    hipLaunchKernelGGL(ntt_pass_kernel<LOG_TILE>, dim3((uint32_t)tiles), dim3(NTT_THREADS), lds_bytes, stream, src, dst, pp,
+    hipLaunchKernelGGL(ntt_pass_kernel<LOG_TILE>, dim3((uint32_t)tiles, batch), dim3(NTT_THREADS), lds_bytes, stream, src, dst, pp,
                        (const uint32_t*)tab->d_stage[pp.s], lo_tab, (const uint32_t*)tab->d_hi, d_scale_int, d_coset_int);
     HM_HIP_CHECK(hipGetLastError());
   }

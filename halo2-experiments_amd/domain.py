@@ -62,42 +62,51 @@ class EvaluationDomain:
     def extended_len(self) -> int:
         return 1 << self.extended_k
 
+    @staticmethod
+    def _batch_of(a, n: int, name: str) -> int:
+        """Rows of `a` must be a whole number of n-element polynomials: (n, 4) or (batch, n, 4)."""
+        rows = _tensor_rows(a, 4, name)
+        if rows == 0 or rows % n:
+            raise ValueError(f"{name}: expected (batch, {n}, 4) words")
+        return rows // n
+
     def _ifft(self, a, omega_inv: int, log_n: int, divisor: int) -> None:
-        n = _tensor_rows(a, 4, "a")
-        if n != 1 << log_n:
-            raise ValueError("ifft: a.len() != 1 << log_n")
-        _lib.check(_lib.load().hm_ifft_bn256_fr_dev(ctypes.c_void_p(a.data_ptr()), _ptr(fr_words(omega_inv)), log_n,
-                                                     _ptr(fr_words(divisor)), ctypes.c_void_p(_stream_ptr(a))))
+        batch = self._batch_of(a, 1 << log_n, "ifft")
+        _lib.check(_lib.load().hm_ntt_batch_bn256_fr_dev(ctypes.c_void_p(a.data_ptr()), batch, _ptr(fr_words(omega_inv)), log_n,
+                                                          _ptr(fr_words(divisor)), None, ctypes.c_void_p(_stream_ptr(a))))
 
     # -- the reference's methods --------------------------------------------------------------
     def lagrange_to_coeff(self, a):
-        """In place on a (n, 4) GPU tensor; returns it."""
+        """In place on a (n, 4) or (batch, n, 4) GPU tensor (one set of launches for the batch); returns it."""
         self._ifft(a, self.omega_inv, self.k, self.ifft_divisor)
         return a
 
     def coeff_to_extended(self, a):
-        """(n, 4) coefficient tensor -> new (2^extended_k, 4) tensor of evaluations on the zeta-coset."""
+        """(n, 4) or (batch, n, 4) coefficient tensor -> new (2^extended_k, 4) / (batch, 2^extended_k, 4)
+        tensor of evaluations on the zeta-coset."""
         import torch
 
-        n = _tensor_rows(a, 4, "a")
-        if n != self.n:
-            raise ValueError("coeff_to_extended: a.len() != n")
-        ext = torch.zeros((self.extended_len(), 4), dtype=a.dtype, device=a.device)
-        ext[:n] = a.reshape(n, 4)
+        batch = self._batch_of(a, self.n, "coeff_to_extended")
+        en = self.extended_len()
+        ext = torch.zeros((batch, en, 4), dtype=a.dtype, device=a.device)
+        ext[:, : self.n] = a.reshape(batch, self.n, 4)
         r = FR_MODULUS
         coset = np.concatenate([fr_words(1), fr_words(self.g_coset), fr_words(self.g_coset * self.g_coset % r)])
-        _lib.check(_lib.load().hm_coset_ntt_bn256_fr_dev(ctypes.c_void_p(ext.data_ptr()), _ptr(fr_words(self.extended_omega)),
-                                                          self.extended_k, _ptr(coset), ctypes.c_void_p(_stream_ptr(ext))))
-        return ext
+        _lib.check(_lib.load().hm_ntt_batch_bn256_fr_dev(ctypes.c_void_p(ext.data_ptr()), batch, _ptr(fr_words(self.extended_omega)),
+                                                          self.extended_k, None, _ptr(coset), ctypes.c_void_p(_stream_ptr(ext))))
+        return ext if a.dim() == 3 else ext[0]
 
     def extended_to_coeff(self, a):
-        """In place on a (2^extended_k, 4) tensor; returns the first n*(j-1) rows (a view)."""
-        n = _tensor_rows(a, 4, "a")
-        if n != self.extended_len():
-            raise ValueError("extended_to_coeff: a.len() != extended_len()")
+        """In place on a (2^extended_k, 4) or (batch, 2^extended_k, 4) tensor; returns the first
+        n*(j-1) rows of each polynomial (a view)."""
+        en = self.extended_len()
+        batch = self._batch_of(a, en, "extended_to_coeff")
         self._ifft(a, self.extended_omega_inv, self.extended_k, self.extended_ifft_divisor)
         r = FR_MODULUS
         c3 = np.concatenate([fr_words(1), fr_words(self.g_coset_inv), fr_words(self.g_coset_inv * self.g_coset_inv % r)])
-        _lib.check(_lib.load().hm_fr_distribute_powers_dev(ctypes.c_void_p(a.data_ptr()), n, _ptr(c3),
-                                                            ctypes.c_void_p(_stream_ptr(a))))
-        return a.reshape(n, 4)[: self.n * self.quotient_poly_degree]
+        flat = a.reshape(batch, en, 4)
+        for b in range(batch):     # the i % 3 pattern restarts with every polynomial
+            _lib.check(_lib.load().hm_fr_distribute_powers_dev(ctypes.c_void_p(flat[b].data_ptr()), en, _ptr(c3),
+                                                                ctypes.c_void_p(_stream_ptr(a))))
+        out = flat[:, : self.n * self.quotient_poly_degree]
+        return out if a.dim() == 3 else out[0]

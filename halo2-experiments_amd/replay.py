@@ -110,6 +110,7 @@ def run_replay(shape_name: str, device=None, group=None, include_host_pointer_es
     g_h = register_bases(g1_fixed_base_mul(_rand_fr(hi - lo, 17 + rank, device), gen))
     gl_h = register_bases(g1_fixed_base_mul(_rand_fr(hi - lo, 1717 + rank, device), gen))
     dense = [_rand_fr(n, 100 + i, device) for i in range(2)]
+    ntt_batch = _rand_fr(8 * n, 300, device).reshape(8, n, 4)
     sparse = [_sparse_column(n, shape.used_rows, 200 + i, device) for i in range(2)]
 
     def msm(col, handle):
@@ -127,13 +128,21 @@ def run_replay(shape_name: str, device=None, group=None, include_host_pointer_es
         t["msm"] = time.perf_counter() - t0
         t0 = time.perf_counter()
         if rank == 0:                                   # NTT stays single-GPU (north star)
-            for i in range(counts["intt_n"]):
-                dom.lagrange_to_coeff(dense[i & 1])
+            # same-size transforms of one prover phase go through one batched call (<= 8 polynomials at a
+            # time here, bounding the extended-domain buffers)
+            todo = counts["intt_n"]
+            while todo > 0:
+                b = min(8, todo)
+                dom.lagrange_to_coeff(ntt_batch[:b])
+                todo -= b
             ext = None
-            for i in range(counts["coset_ntt_ext"]):
-                ext = dom.coeff_to_extended(dense[i & 1])
+            todo = counts["coset_ntt_ext"]
+            while todo > 0:
+                b = min(8, todo)
+                ext = dom.coeff_to_extended(ntt_batch[:b])
+                todo -= b
             for _ in range(counts["intt_ext"]):
-                dom.extended_to_coeff(ext)
+                dom.extended_to_coeff(ext[0])
         torch.cuda.synchronize()
         t["ntt"] = time.perf_counter() - t0
         return t

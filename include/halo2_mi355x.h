@@ -106,6 +106,12 @@ int hm_ntt_bn256_fr(uint64_t* a, const uint64_t omega[4], uint32_t log_n);
 /* Device-pointer form, in place, asynchronous on `stream`. */
 int hm_ntt_bn256_fr_dev(void* d_a, const uint64_t omega[4], uint32_t log_n, void* stream);
 
+/* `batch` back-to-back arrays of 2^log_n elements transformed by ONE set of launches (the ~48
+ * same-size transforms of a proof).  scale (4 words) and coset (12 words) are
+ * optional (NULL): the fused EvaluationDomain::ifft divisor and the coeff_to_extended coset shift. */
+int hm_ntt_batch_bn256_fr_dev(void* d_a, size_t batch, const uint64_t omega[4], uint32_t log_n, const uint64_t* scale,
+                              const uint64_t* coset, void* stream);
+
 /* ---- next rows: the EvaluationDomain steps either side of best_fft ----------- */
 
 /* EvaluationDomain::ifft: best_fft(a, omega_inv, log_n) then a[i] *= divisor, with the scaling

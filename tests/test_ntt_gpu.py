@@ -131,3 +131,18 @@ def test_evaluation_domain_steps(cref, pyref):
     bh = back.cpu().numpy().view(np.uint64)
     assert bh.shape[0] == n * 6
     assert np.array_equal(bh[:n], exp) and not bh[n:].any()
+
+
+def test_batched_transforms_equal_single_ones(pyref):
+    """(batch, n, 4) tensors go through one set of launches and must equal per-polynomial calls."""
+    import torch
+    d = EvaluationDomain(j=7, k=12)
+    a = rand_fr_gpu(5 * d.n, 4242).reshape(5, d.n, 4)
+    single = torch.stack([d.lagrange_to_coeff(a[i].clone()) for i in range(5)])
+    batched = d.lagrange_to_coeff(a.clone())
+    assert torch.equal(single, batched)
+    ext_single = torch.stack([d.coeff_to_extended(single[i]) for i in range(5)])
+    ext_batched = d.coeff_to_extended(batched)
+    assert torch.equal(ext_single, ext_batched)
+    back = d.extended_to_coeff(ext_batched.clone())
+    assert torch.equal(back[:, : d.n], batched) and not back[:, d.n:].any()
