@@ -1,0 +1,54 @@
+// arithmetic.hpp -- C++ mirror of halo2_proofs::arithmetic for BN256 (the crate pinned at
+// /root/reference/Cargo.toml:10, tag v2023_02_02), over the C ABI of libhalo2_mi355x.so:
+//
+//     pub fn best_multiexp<C: CurveAffine>(coeffs: &[C::Scalar], bases: &[C]) -> C::Curve
+//     pub fn best_fft<G: Group>(a: &mut [G], omega: G::Scalar, log_n: u32)
+//
+// Same names, argument meaning and failure behaviour: upstream `assert_eq!`s on the lengths (a
+// panic); here that is std::invalid_argument.  A backend failure (no gfx950 device, HIP error) is
+// std::runtime_error carrying hm_last_error() -- there is no CPU fallback in this library.
+#pragma once
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/halo2_mi355x.h"
+#include "bn256.hpp"
+
+namespace halo2 {
+namespace arithmetic {
+
+using bn256::Fr;
+using bn256::G1;
+using bn256::G1Affine;
+
+inline void check(int rc, const char* what) {
+  if (rc != HM_OK) throw std::runtime_error(std::string(what) + ": " + hm_last_error());
+}
+
+inline G1 best_multiexp(const Fr* coeffs, size_t n_coeffs, const G1Affine* bases, size_t n_bases) {
+  if (n_coeffs != n_bases) throw std::invalid_argument("best_multiexp: coeffs.len() != bases.len()");
+  G1 out;
+  check(hm_msm_bn256_g1_jacobian(reinterpret_cast<const uint64_t*>(coeffs), reinterpret_cast<const uint64_t*>(bases), n_coeffs,
+                                 reinterpret_cast<uint64_t*>(&out)),
+        "best_multiexp");
+  return out;
+}
+inline G1 best_multiexp(const std::vector<Fr>& coeffs, const std::vector<G1Affine>& bases) {
+  return best_multiexp(coeffs.data(), coeffs.size(), bases.data(), bases.size());
+}
+
+inline void best_fft(Fr* a, size_t len, const Fr& omega, uint32_t log_n) {
+  if (log_n > 63 || len != ((size_t)1 << log_n)) throw std::invalid_argument("best_fft: a.len() != 1 << log_n");
+  check(hm_ntt_bn256_fr(reinterpret_cast<uint64_t*>(a), omega.l, log_n), "best_fft");
+}
+inline void best_fft(std::vector<Fr>& a, const Fr& omega, uint32_t log_n) { best_fft(a.data(), a.size(), omega, log_n); }
+
+// affine normalisation of a G1 the library returned: it is already (x, y, 1) or the identity
+inline G1Affine to_affine(const G1& p) {
+  if (p.is_identity()) return G1Affine::identity();
+  return G1Affine{p.x, p.y};
+}
+
+}  // namespace arithmetic
+}  // namespace halo2

@@ -1,0 +1,161 @@
+// domain.hpp -- C++ mirror of halo2_proofs::poly::EvaluationDomain<bn256::Fr> and of the two
+// ParamsKZG commit functions, the callers either side of best_fft / best_multiexp in create_proof
+// (upstream poly/domain.rs and poly/kzg/commitment.rs at the pinned tag).
+// Polynomials live in device buffers (hipMalloc) between calls, the "next row" mode; the scale /
+// coset passes are fused into the transforms and same-size transforms can be batched.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <vector>
+
+#include "arithmetic.hpp"
+
+namespace halo2 {
+namespace poly {
+
+using bn256::Fr;
+using bn256::G1;
+using bn256::G1Affine;
+
+// `batch` polynomials of `len` Fr each, resident in HBM
+struct DevicePolys {
+  Fr* d = nullptr;
+  size_t len = 0, batch = 0;
+  DevicePolys() = default;
+  DevicePolys(size_t len_, size_t batch_) : len(len_), batch(batch_) {
+    if (hipMalloc((void**)&d, len * batch * sizeof(Fr)) != hipSuccess) throw std::runtime_error("hipMalloc failed");
+  }
+  DevicePolys(const DevicePolys&) = delete;
+  DevicePolys& operator=(const DevicePolys&) = delete;
+  DevicePolys(DevicePolys&& o) noexcept : d(o.d), len(o.len), batch(o.batch) { o.d = nullptr; }
+  DevicePolys& operator=(DevicePolys&& o) noexcept {
+    if (this != &o) { release(); d = o.d; len = o.len; batch = o.batch; o.d = nullptr; }
+    return *this;
+  }
+  ~DevicePolys() { release(); }
+  void release() { if (d) (void)hipFree(d); d = nullptr; }
+  void upload(const std::vector<Fr>& h) {
+    if (h.size() != len * batch) throw std::invalid_argument("DevicePolys::upload: size mismatch");
+    if (hipMemcpy(d, h.data(), h.size() * sizeof(Fr), hipMemcpyHostToDevice) != hipSuccess) throw std::runtime_error("H2D failed");
+  }
+  std::vector<Fr> download() const {
+    std::vector<Fr> h(len * batch);
+    if (hipMemcpy(h.data(), d, h.size() * sizeof(Fr), hipMemcpyDeviceToHost) != hipSuccess) throw std::runtime_error("D2H failed");
+    return h;
+  }
+  Fr* poly(size_t i) const { return d + i * len; }
+};
+
+class EvaluationDomain {
+ public:
+  uint32_t k, extended_k;
+  size_t n, quotient_poly_degree;
+  Fr omega, omega_inv, extended_omega, extended_omega_inv, g_coset, g_coset_inv, ifft_divisor, extended_ifft_divisor;
+
+  // EvaluationDomain::new(j, k): j = maximum constraint degree
+  EvaluationDomain(uint32_t j, uint32_t k_) : k(k_) {
+    if (j < 2) throw std::invalid_argument("EvaluationDomain: j must be >= 2");
+    n = (size_t)1 << k;
+    quotient_poly_degree = j - 1;
+    extended_k = k;
+    while (((size_t)1 << extended_k) < n * quotient_poly_degree) ++extended_k;
+    if (extended_k > bn256::FR_S) throw std::invalid_argument("EvaluationDomain: extended_k exceeds the two-adicity");
+    extended_omega = bn256::fr_root_of_unity();
+    for (uint32_t i = extended_k; i < bn256::FR_S; ++i) extended_omega = extended_omega.square();
+    extended_omega_inv = extended_omega.invert();
+    omega = extended_omega;
+    for (uint32_t i = k; i < extended_k; ++i) omega = omega.square();
+    omega_inv = omega.invert();
+    g_coset = bn256::fr_zeta();
+    g_coset_inv = g_coset.square();
+    ifft_divisor = Fr::from_u64((uint64_t)n).invert();
+    extended_ifft_divisor = Fr::from_u64((uint64_t)1 << extended_k).invert();
+  }
+  size_t extended_len() const { return (size_t)1 << extended_k; }
+
+  // lagrange_to_coeff: ifft(a, omega_inv, k, 1/n), in place, the whole batch in one set of launches
+  void lagrange_to_coeff(DevicePolys& a, hipStream_t stream = nullptr) const {
+    if (a.len != n) throw std::invalid_argument("lagrange_to_coeff: a.len() != n");
+    arithmetic::check(hm_ntt_batch_bn256_fr_dev(a.d, a.batch, omega_inv.l, k, ifft_divisor.l, nullptr, stream), "lagrange_to_coeff");
+  }
+  // coeff_to_extended: zero-pad, distribute_powers_zeta, best_fft(extended_omega)
+  DevicePolys coeff_to_extended(const DevicePolys& a, hipStream_t stream = nullptr) const {
+    if (a.len != n) throw std::invalid_argument("coeff_to_extended: a.len() != n");
+    DevicePolys ext(extended_len(), a.batch);
+    if (hipMemsetAsync(ext.d, 0, ext.len * ext.batch * sizeof(Fr), stream) != hipSuccess) throw std::runtime_error("memset failed");
+    if (hipMemcpy2DAsync(ext.d, ext.len * sizeof(Fr), a.d, a.len * sizeof(Fr), a.len * sizeof(Fr), a.batch, hipMemcpyDeviceToDevice,
+                         stream) != hipSuccess)
+      throw std::runtime_error("pad copy failed");
+    const Fr coset[3] = {Fr::one(), g_coset, g_coset.square()};
+    arithmetic::check(hm_ntt_batch_bn256_fr_dev(ext.d, ext.batch, extended_omega.l, extended_k, nullptr, coset[0].l, stream),
+                      "coeff_to_extended");
+    return ext;
+  }
+  // extended_to_coeff: ifft over the extended domain, undo the coset shift (caller truncates to n*(j-1))
+  void extended_to_coeff(DevicePolys& a, hipStream_t stream = nullptr) const {
+    if (a.len != extended_len()) throw std::invalid_argument("extended_to_coeff: a.len() != extended_len()");
+    arithmetic::check(hm_ntt_batch_bn256_fr_dev(a.d, a.batch, extended_omega_inv.l, extended_k, extended_ifft_divisor.l, nullptr, stream),
+                      "extended_to_coeff");
+    const Fr c3[3] = {Fr::one(), g_coset_inv, g_coset_inv.square()};
+    for (size_t b = 0; b < a.batch; ++b)
+      arithmetic::check(hm_fr_distribute_powers_dev(a.poly(b), a.len, c3[0].l, stream), "extended_to_coeff");
+  }
+};
+
+// ParamsKZG<Bn256>: g = [s^i]G, g_lagrange = [L_i(s)]G, device resident; commit / commit_lagrange
+class ParamsKZG {
+ public:
+  uint32_t k;
+  size_t n;
+  uint64_t g_handle = 0, g_lagrange_handle = 0;
+
+  // setup with a caller-provided trapdoor s (the reference draws it from OsRng, utils.rs:28)
+  ParamsKZG(uint32_t k_, const Fr& s, bool precompute = false) : k(k_), n((size_t)1 << k_) {
+    const EvaluationDomain dom(2, k);
+    std::vector<Fr> pw(n), lag(n);
+    Fr acc = Fr::one();
+    for (size_t i = 0; i < n; ++i) { pw[i] = acc; acc = acc * s; }
+    // L_i(s) = (s^n - 1)/n * omega^i / (s - omega^i), denominators inverted in one batch
+    const Fr zn = (acc - Fr::one()) * dom.ifft_divisor;
+    std::vector<Fr> den(n), pre(n);
+    Fr w = Fr::one(), run = Fr::one();
+    for (size_t i = 0; i < n; ++i) { den[i] = s - w; pre[i] = run; run = run * den[i]; lag[i] = zn * w; w = w * dom.omega; }
+    Fr inv = run.invert();
+    for (size_t i = n; i-- > 0;) { const Fr di = inv * pre[i]; inv = inv * den[i]; lag[i] = lag[i] * di; }
+    g_handle = fixed_base_set(pw, precompute);
+    g_lagrange_handle = fixed_base_set(lag, precompute);
+  }
+  ParamsKZG(const ParamsKZG&) = delete;
+  ParamsKZG& operator=(const ParamsKZG&) = delete;
+  ~ParamsKZG() {
+    if (g_handle) (void)hm_release_bases(g_handle);
+    if (g_lagrange_handle) (void)hm_release_bases(g_lagrange_handle);
+  }
+  // commit(poly in coefficient form) / commit_lagrange(poly in evaluation form): one best_multiexp each
+  G1 commit(const Fr* d_poly) const { return msm(g_handle, d_poly); }
+  G1 commit_lagrange(const Fr* d_poly) const { return msm(g_lagrange_handle, d_poly); }
+
+ private:
+  G1 msm(uint64_t handle, const Fr* d_poly) const {
+    G1 out;
+    arithmetic::check(hm_msm_bn256_g1_dev(handle, 0, d_poly, n, nullptr, reinterpret_cast<uint64_t*>(&out)), "commit");
+    return out;
+  }
+  uint64_t fixed_base_set(const std::vector<Fr>& scalars, bool precompute) const {
+    DevicePolys ds(n, 1);
+    ds.upload(scalars);
+    G1Affine* d_pts = nullptr;
+    if (hipMalloc((void**)&d_pts, n * sizeof(G1Affine)) != hipSuccess) throw std::runtime_error("hipMalloc failed");
+    const G1Affine gen = G1Affine::generator();
+    uint64_t handle = 0;
+    int rc = hm_g1_fixed_base_mul_dev(ds.d, n, reinterpret_cast<const uint64_t*>(&gen), d_pts, nullptr);
+    if (rc == HM_OK)
+      rc = precompute ? hm_register_bases_precomp_dev(d_pts, n, nullptr, &handle) : hm_register_bases_dev(d_pts, n, nullptr, &handle);
+    (void)hipFree(d_pts);
+    arithmetic::check(rc, "ParamsKZG::setup");
+    return handle;
+  }
+};
+
+}  // namespace poly
+}  // namespace halo2

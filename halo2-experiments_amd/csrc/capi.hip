@@ -256,8 +256,16 @@ static int msm_host(const uint64_t* scalars, const uint64_t* bases, size_t n, ui
   if (!ctx) return HM_ERR_NO_DEVICE;
   std::lock_guard<std::mutex> lk(ctx->mu);
   if (n == 0) return msm_run(*ctx, nullptr, nullptr, nullptr, 0, 0, jac, is_id, nullptr);
-  // base cache: same pointer, same length, same first/last words => reuse the converted copy
-  uint64_t probe[4] = {bases[0], bases[4], bases[(n - 1) * 8 + 3], bases[(n - 1) * 8 + 7]};
+  // base cache: same pointer, same length and the same fingerprint of 64 sampled points => reuse the
+  // converted copy (create_proof passes the same params.g / g_lagrange slices to every commitment)
+  uint64_t probe[4] = {bases[0], bases[(n - 1) * 8 + 7], 0x9E3779B97F4A7C15ULL, n};
+  for (size_t k = 0; k < 64; ++k) {
+    const size_t i = (n * k) / 64;
+    for (int w = 0; w < 8; ++w) {
+      probe[2] = (probe[2] ^ bases[i * 8 + w]) * 0x100000001B3ULL;
+      probe[3] = ((probe[3] << 7) | (probe[3] >> 57)) ^ bases[i * 8 + w];
+    }
+  }
   const bool hit = ctx->cached_host_bases == (const void*)bases && ctx->cached_host_n == n &&
                    std::memcmp(probe, ctx->cached_probe, sizeof probe) == 0;
   uint32_t* d_xy = (uint32_t*)ctx->conv_bases.ensure(n * 64);

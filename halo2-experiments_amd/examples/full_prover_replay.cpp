@@ -1,0 +1,186 @@
+// full_prover_replay.cpp -- the counterpart of the reference's one real-prover harness,
+// full_prover (/root/reference/src/circuits/utils.rs:22-70): KZG setup -> keygen_vk -> keygen_pk ->
+// create_proof -> verify, with the four wall-clock lines it prints (utils.rs:66-69).
+//
+// The Rust prover cannot be built here, so the MSM / NTT CALL TRACE those steps issue for a circuit
+// of the given shape is replayed on synthetic polynomials through the C++ mirror
+// of halo2_proofs (cpp/arithmetic.hpp, cpp/domain.hpp) -- everything else in create_proof is
+// CPU-side Rust and is not part of these numbers.  "Verify" is the algebraic check the KZG commitments
+// must satisfy: commit(f) == commit_lagrange(NTT(f)) == [f(s)]G for a random f.
+//
+//   full_prover_replay [k=9] [advice=20] [lookups=8] [equality=12] [max_degree=7] [fixed=8]
+// Defaults are test_full_prover's k = 9 (/root/reference/src/circuits/merkle_sum_tree.rs:347) with the
+// MerkleSumTree column counts.
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+
+#include "../cpp/domain.hpp"
+
+using namespace halo2;
+using bn256::Fq;
+using bn256::Fr;
+using bn256::G1;
+using bn256::G1Affine;
+using Clock = std::chrono::steady_clock;
+
+static double secs(Clock::time_point a, Clock::time_point b) { return std::chrono::duration<double>(b - a).count(); }
+
+// host-side group law, only for the final check [f(s)]G
+static G1 g1_double(const G1& p) {
+  if (p.is_identity()) return p;
+  const Fq A = p.x.square(), B = p.y.square(), C = B.square();
+  Fq D = p.x * B; D = D + D; D = D + D;
+  const Fq E = A + A + A;
+  G1 r;
+  r.x = E.square() - (D + D);
+  Fq c8 = C + C; c8 = c8 + c8; c8 = c8 + c8;
+  r.y = E * (D - r.x) - c8;
+  r.z = p.y * p.z; r.z = r.z + r.z;
+  return r;
+}
+static G1 g1_add(const G1& p, const G1& q) {
+  if (p.is_identity()) return q;
+  if (q.is_identity()) return p;
+  const Fq z1z1 = p.z.square(), z2z2 = q.z.square();
+  const Fq u1 = p.x * z2z2, u2 = q.x * z1z1, s1 = p.y * q.z * z2z2, s2 = q.y * p.z * z1z1;
+  if (u1 == u2) return s1 == s2 ? g1_double(p) : G1::identity();
+  const Fq h = u2 - u1;
+  Fq i = h + h; i = i.square();
+  const Fq j = h * i;
+  Fq r = s2 - s1; r = r + r;
+  const Fq v = u1 * i;
+  G1 o;
+  o.x = r.square() - j - (v + v);
+  Fq t = s1 * j; t = t + t;
+  o.y = r * (v - o.x) - t;
+  o.z = p.z * q.z * h; o.z = o.z + o.z;
+  return o;
+}
+static G1Affine g1_mul_generator(const Fr& k_mont) {
+  const Fr one_raw{{1, 0, 0, 0}};
+  const Fr k = k_mont * one_raw;                        // Montgomery -> canonical
+  const G1Affine g = G1Affine::generator();
+  const G1 base{g.x, g.y, Fq::one()};
+  G1 acc = G1::identity();
+  for (int i = 255; i >= 0; --i) {
+    acc = g1_double(acc);
+    if ((k.l[i >> 6] >> (i & 63)) & 1) acc = g1_add(acc, base);
+  }
+  if (acc.is_identity()) return G1Affine::identity();
+  const Fq zi = acc.z.invert(), zi2 = zi.square();
+  return G1Affine{acc.x * zi2, acc.y * zi2 * zi};
+}
+
+static Fr random_fr(std::mt19937_64& rng) {
+  uint64_t raw[4] = {rng(), rng(), rng(), rng() & 0x0FFFFFFFFFFFFFFFULL};   // < 2^252 < r
+  return Fr::from_raw(raw);
+}
+
+int main(int argc, char** argv) {
+  const uint32_t k = argc > 1 ? (uint32_t)atoi(argv[1]) : 9;
+  const uint32_t advice = argc > 2 ? (uint32_t)atoi(argv[2]) : 20;
+  const uint32_t lookups = argc > 3 ? (uint32_t)atoi(argv[3]) : 8;
+  const uint32_t equality = argc > 4 ? (uint32_t)atoi(argv[4]) : 12;
+  const uint32_t max_degree = argc > 5 ? (uint32_t)atoi(argv[5]) : 7;
+  const uint32_t fixed = argc > 6 ? (uint32_t)atoi(argv[6]) : 8;
+  if (k < 4 || k > 22 || max_degree < 3) { std::fprintf(stderr, "unsupported shape\n"); return 2; }
+  try {
+    if (hm_device_count() <= 0) { std::fprintf(stderr, "no gfx950 device: %s\n", "this path has no CPU fallback"); return 3; }
+    std::mt19937_64 rng(0x48324D4933353558ULL);
+    const size_t n = (size_t)1 << k;
+    const poly::EvaluationDomain dom(max_degree, k);
+    const uint32_t zp = (equality + max_degree - 3) / (max_degree - 2);
+    const size_t used_rows = n / 4 < 1100 ? n / 4 : 1100;
+
+    // ParamsKZG::<Bn256>::setup(k, OsRng)  (utils.rs:28)
+    const auto t_setup0 = Clock::now();
+    const Fr s = random_fr(rng);
+    const poly::ParamsKZG params(k, s);
+    const auto t_setup1 = Clock::now();
+
+    // synthetic columns: dense = uniform; sparse = used_rows small values + 6 blinding rows
+    std::vector<Fr> dense(n), sparse(n, Fr::zero());
+    for (auto& x : dense) x = random_fr(rng);
+    for (size_t i = 0; i < used_rows; ++i) sparse[i] = Fr::from_u64(i % 2 ? 1 : (rng() & 0xFFFF));
+    for (size_t i = n - 6; i < n; ++i) sparse[i] = random_fr(rng);
+    poly::DevicePolys d_dense(n, 1), d_sparse(n, 1);
+    d_dense.upload(dense);
+    d_sparse.upload(sparse);
+
+    // keygen_vk (utils.rs:31): commit_lagrange per fixed column and per permutation sigma
+    const auto t_vk0 = Clock::now();
+    for (uint32_t i = 0; i < fixed; ++i) (void)params.commit_lagrange(d_sparse.d);
+    for (uint32_t i = 0; i < equality; ++i) (void)params.commit_lagrange(d_dense.d);
+    const auto t_vk1 = Clock::now();
+
+    // keygen_pk (utils.rs:35): lagrange_to_coeff + coeff_to_extended of fixed, sigma, l0 / l_last / l_active
+    const auto t_pk0 = Clock::now();
+    {
+      const size_t polys = fixed + equality + 3;
+      for (size_t done = 0; done < polys; done += 8) {
+        const size_t b = polys - done < 8 ? polys - done : 8;
+        poly::DevicePolys batch(n, b);
+        for (size_t i = 0; i < b; ++i) (void)hipMemcpy(batch.poly(i), d_dense.d, n * sizeof(Fr), hipMemcpyDeviceToDevice);
+        dom.lagrange_to_coeff(batch);
+        poly::DevicePolys ext = dom.coeff_to_extended(batch);
+      }
+      (void)hipDeviceSynchronize();
+    }
+    const auto t_pk1 = Clock::now();
+
+    // create_proof (utils.rs:40-48): the MSM / NTT trace of SURVEY.md §3.2
+    const auto t_pr0 = Clock::now();
+    size_t n_msm = 0, n_ntt = 0;
+    for (uint32_t i = 0; i < advice + 2 * lookups; ++i, ++n_msm) (void)params.commit_lagrange(d_sparse.d);       // advice, permuted
+    for (uint32_t i = 0; i < zp + lookups + 1; ++i, ++n_msm) (void)params.commit_lagrange(d_dense.d);           // grand products, random poly
+    {
+      const size_t polys = advice + 1 + 3 * lookups + zp;
+      for (size_t done = 0; done < polys; done += 8) {
+        const size_t b = polys - done < 8 ? polys - done : 8;
+        poly::DevicePolys batch(n, b);
+        for (size_t i = 0; i < b; ++i) (void)hipMemcpy(batch.poly(i), d_dense.d, n * sizeof(Fr), hipMemcpyDeviceToDevice);
+        dom.lagrange_to_coeff(batch);                              // lagrange_to_coeff per polynomial
+        poly::DevicePolys ext = dom.coeff_to_extended(batch);      // coeff_to_extended per polynomial
+        n_ntt += 2 * b;
+        if (done + b >= polys) {                                   // h(X): back to coefficients once
+          poly::DevicePolys h(ext.len, 1);
+          (void)hipMemcpy(h.d, ext.d, ext.len * sizeof(Fr), hipMemcpyDeviceToDevice);
+          dom.extended_to_coeff(h);
+          ++n_ntt;
+        }
+      }
+    }
+    for (uint32_t i = 0; i < (max_degree - 1) + 2; ++i, ++n_msm) (void)params.commit(d_dense.d);               // h pieces, SHPLONK
+    (void)hipDeviceSynchronize();
+    const auto t_pr1 = Clock::now();
+
+    // verify: commit(f) == commit_lagrange(NTT(f)) == [f(s)]G
+    const auto t_v0 = Clock::now();
+    poly::DevicePolys f(n, 1);
+    f.upload(dense);
+    const G1 c_coeff = params.commit(f.d);
+    arithmetic::check(hm_ntt_bn256_fr_dev(f.d, dom.omega.l, k, nullptr), "best_fft");
+    const G1 c_lagrange = params.commit_lagrange(f.d);
+    Fr fs = Fr::zero();
+    for (size_t i = n; i-- > 0;) fs = fs * s + dense[i];
+    const G1Affine expect = g1_mul_generator(fs);
+    const bool ok = arithmetic::to_affine(c_coeff) == expect && arithmetic::to_affine(c_lagrange) == expect;
+    const auto t_v1 = Clock::now();
+
+    std::printf("shape: k=%u advice=%u lookups=%u equality=%u max_degree=%u fixed=%u extended_k=%u  (%zu MSMs, %zu NTTs in create_proof)\n",
+                k, advice, lookups, equality, max_degree, fixed, dom.extended_k, n_msm, n_ntt);
+    std::printf("Time to generate params %.6fs\n", secs(t_setup0, t_setup1));
+    std::printf("Time to generate vk %.6fs\n", secs(t_vk0, t_vk1));
+    std::printf("Time to generate pk %.6fs\n", secs(t_pk0, t_pk1));
+    std::printf("Prover Time %.6fs\n", secs(t_pr0, t_pr1));
+    std::printf("Verifier Time %.6fs\n", secs(t_v0, t_v1));
+    std::printf("%s\n", ok ? "commitments verified" : "COMMITMENT MISMATCH");
+    (void)hm_shutdown();
+    return ok ? 0 : 1;
+  } catch (const std::exception& e) {
+    std::fprintf(stderr, "error: %s\n", e.what());
+    return 4;
+  }
+}

@@ -1,0 +1,43 @@
+"""The C++ host-side mirror of the reference's interface (halo2-experiments_amd/cpp/*.hpp) and the
+full_prover counterpart built on it (examples/full_prover_replay.cpp)."""
+import os
+import re
+import subprocess
+
+import pytest
+
+from halo2_experiments_amd import _lib
+
+EX = os.path.join(os.path.dirname(_lib.CSRC), "examples")
+
+
+@pytest.fixture(scope="module")
+def built():
+    subprocess.run(["make", "-C", _lib.CSRC, "-j4", "all"], check=True, capture_output=True)
+    return EX
+
+
+def test_mirror_selftest_runs_without_gpu(built):
+    """Field / domain constants, the EIP-196 value of 2G, and the mirror's error behaviour."""
+    r = subprocess.run([os.path.join(built, "mirror_selftest")], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "mirror selftest ok" in r.stdout
+
+
+def test_full_prover_replay_refuses_to_run_without_device(built):
+    if _lib.load().hm_device_count() > 0:
+        pytest.skip("a GPU is present")
+    r = subprocess.run([os.path.join(built, "full_prover_replay")], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 3 and "no CPU fallback" in r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("args", [[], ["12", "8", "0", "6", "7", "4"], ["14", "20", "8", "12", "7", "8"]])
+def test_full_prover_replay_verifies(built, args):
+    """Like the reference's test_full_prover (merkle_sum_tree.rs:345-358): prove, then verify; the four
+    timings full_prover prints (utils.rs:66-69) must be there."""
+    r = subprocess.run([os.path.join(built, "full_prover_replay")] + args, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "commitments verified" in r.stdout
+    for line in ("Time to generate vk", "Time to generate pk", "Prover Time", "Verifier Time"):
+        assert re.search(line + r" \d+\.\d+s", r.stdout), r.stdout

@@ -237,3 +237,33 @@ def test_precomputed_full_size_kzg_known_answer(cref, pyref):
         assert g1_equal(got, cref.g1_mul(fx, cref.g1_generator()))
     finally:
         h.release_bases(hd)
+
+
+@pytest.mark.parametrize("n", [16385, 65537, (1 << 17) + 5, 100003])
+def test_sizes_off_the_power_of_two_grid(cref, pyref, n):
+    """Chunk / vector-load boundaries of the sort and ragged last chunks: n is arbitrary for an MSM."""
+    o = pyref
+    gen = cref.g1_generator()
+    bases = h.g1_fixed_base_mul(rand_fr_gpu(n, n % 1000), gen).cpu().numpy().view(np.uint64).copy()
+    tile = o.fr_array(o.rand_scalars(4099, n, "prover"))
+    s = np.concatenate([np.tile(tile, (n // 4099, 1)), tile[: n % 4099]])
+    s[::7] = rand_fr_gpu((n + 6) // 7, n).cpu().numpy().view(np.uint64)
+    exp = cref.g1_to_affine(cref.best_multiexp(s, bases, 8))[0]
+    assert g1_equal(h.best_multiexp(s, bases), exp)
+    hd = h.register_bases(bases, precompute=True)
+    try:
+        assert g1_equal(h.best_multiexp(s, hd), exp)
+    finally:
+        h.release_bases(hd)
+
+
+def test_host_pointer_base_cache_notices_changed_bases(cref, golden):
+    """The drop-in call caches the converted base array by (pointer, length, fingerprint): mutating the
+    array in place must not return the stale result."""
+    g = golden["msm"]
+    s, b = g["n1024_uniform_s"].copy(), g["n1024_uniform_b"].copy()
+    assert g1_equal(h.best_multiexp(s, b), g["n1024_uniform_r"])
+    assert g1_equal(h.best_multiexp(s, b), g["n1024_uniform_r"])       # cache hit
+    b[0], b[512] = b[512].copy(), b[0].copy()                         # same buffer, different contents
+    exp = cref.g1_to_affine(cref.best_multiexp(s, b, 4))[0]
+    assert g1_equal(h.best_multiexp(s, b), exp)
