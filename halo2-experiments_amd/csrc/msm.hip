@@ -333,6 +333,98 @@ __global__ __launch_bounds__(SORT_THREADS) void msm_part2_scatter_kernel(const I
   }
 }
 
+// part 2, second half, tiled form (regions read from tmp): the region is processed in tiles of
+// 4096 items that are first counting-sorted by fine bucket inside LDS, so that consecutive lanes write
+// consecutive addresses of a bucket run -- every 32-byte sector of the final array is written by one
+// wave instruction (or two adjacent tiles) instead of by eight separate 4-byte stores spread over the
+// workgroup's lifetime, which is what kept missing L2 once a region had more than ~128 runs.
+constexpr int P2_IPT = 4;
+constexpr int P2_TILE = SORT_THREADS * P2_IPT;
+template <class ITEM>
+__global__ __launch_bounds__(SORT_THREADS) void msm_part2_scatter_tiled_kernel(const ITEM* __restrict__ tmp,
+                                                                               const uint32_t* __restrict__ cstart,
+                                                                               const uint32_t* __restrict__ boff,
+                                                                               uint32_t* __restrict__ sorted, uint32_t fb,
+                                                                               uint32_t ib, uint32_t NC, uint32_t NBP) {
+  extern __shared__ uint32_t sm[];
+  const uint32_t hb = blockIdx.x, w = blockIdx.y, tid = threadIdx.x;
+  const uint32_t NF = 1u << fb;                       // <= 2048
+  uint32_t* gcur = sm;                                // global cursor of every fine bucket
+  uint32_t* tcnt = gcur + NF;                         // items of the current tile per bucket
+  uint32_t* tstart = tcnt + NF;                       // exclusive prefix of tcnt
+  uint32_t* wsum = tstart + NF;                       // 32 wave totals of the scan
+  uint32_t* st_pay = wsum + 32;                       // tile items in bucket order
+  uint32_t* st_bin = st_pay + P2_TILE;
+  const uint32_t* bo = boff + (size_t)w * NBP + 1 + ((size_t)hb << fb);
+  for (uint32_t b = tid; b < NF; b += SORT_THREADS) { gcur[b] = bo[b]; tcnt[b] = 0; }
+  __syncthreads();
+  const uint32_t lo = cstart[w * NC + hb], hi = cstart[w * NC + hb + 1];
+  const ITEM imask = ((ITEM)1 << ib) - 1;
+  const uint32_t per = (NF + SORT_THREADS - 1) / SORT_THREADS;   // scan entries per lane (1 or 2)
+  for (uint32_t t0 = lo; t0 < hi; t0 += P2_TILE) {
+    const uint32_t tile_n = hi - t0 < (uint32_t)P2_TILE ? hi - t0 : (uint32_t)P2_TILE;
+    uint32_t pay[P2_IPT], bin[P2_IPT], rank[P2_IPT];
+#pragma unroll
+    for (int k = 0; k < P2_IPT; ++k) {
+      const uint32_t e = (uint32_t)k * SORT_THREADS + tid;
+      if (e < tile_n) {
+        const ITEM item = tmp[t0 + e];
+        bin[k] = (uint32_t)(item >> (ib + 1));
+        pay[k] = (uint32_t)(item & imask) | ((uint32_t)((item >> ib) & 1) << 31);
+        rank[k] = atomicAdd(&tcnt[bin[k]], 1u);
+      }
+    }
+    __syncthreads();
+    // exclusive scan of tcnt[0 .. NF): lane-serial over `per` entries, wave scan, then wave totals
+    {
+      const uint32_t b0 = tid * per;
+      uint32_t v[2] = {0, 0}, sum = 0;
+      for (uint32_t k = 0; k < per; ++k)
+        if (b0 + k < NF) { v[k] = tcnt[b0 + k]; sum += v[k]; }
+      uint32_t incl = sum;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t u = __shfl_up(incl, off, 64);
+        if ((tid & 63) >= (uint32_t)off) incl += u;
+      }
+      if ((tid & 63) == 63) wsum[tid >> 6] = incl;
+      __syncthreads();
+      if (tid < 64) {
+        const uint32_t ws = tid < (SORT_THREADS / 64) ? wsum[tid] : 0;
+        uint32_t wi = ws;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+          const uint32_t u = __shfl_up(wi, off, 64);
+          if (tid >= (uint32_t)off) wi += u;
+        }
+        if (tid < (SORT_THREADS / 64)) wsum[tid] = wi - ws;   // exclusive wave offsets
+      }
+      __syncthreads();
+      uint32_t run = wsum[tid >> 6] + incl - sum;
+      for (uint32_t k = 0; k < per; ++k)
+        if (b0 + k < NF) { tstart[b0 + k] = run; run += v[k]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < P2_IPT; ++k) {
+      const uint32_t e = (uint32_t)k * SORT_THREADS + tid;
+      if (e < tile_n) {
+        const uint32_t pos = tstart[bin[k]] + rank[k];
+        st_pay[pos] = pay[k];
+        st_bin[pos] = bin[k];
+      }
+    }
+    __syncthreads();
+    for (uint32_t e = tid; e < tile_n; e += SORT_THREADS) {
+      const uint32_t b = st_bin[e];
+      sorted[gcur[b] + (e - tstart[b])] = st_pay[e];
+    }
+    __syncthreads();
+    for (uint32_t b = tid; b < NF; b += SORT_THREADS) { gcur[b] += tcnt[b]; tcnt[b] = 0; }
+    __syncthreads();
+  }
+}
+
 // bucket offsets (exclusive scan of counts) and task offsets (exclusive scan of ceil(count / L)):
 // three small launches -- per-block sums, a one-block scan of those, per-block rescan + offset.
 constexpr int SCAN_THREADS = 256;
@@ -840,7 +932,11 @@ static int launch_sort_scatter(const int32_t* d_digits, const uint32_t* d_cstart
                                uint32_t* d_sorted, size_t sn, uint32_t SW, uint32_t fb, uint32_t ib, uint32_t cb, uint32_t NC,
                                uint32_t NBP, hipStream_t stream) {
   const size_t lds_fine = (size_t)4 << fb;
-  if (cb) {
+  if (cb && fb <= 11) {
+    const size_t lds_tiled = ((size_t)3 * (1u << fb) + 32 + 2 * P2_TILE) * 4;
+    hipLaunchKernelGGL(msm_part2_scatter_tiled_kernel<ITEM>, dim3(NC, SW), dim3(SORT_THREADS), lds_tiled, stream,
+                       (const ITEM*)d_tmp, d_cstart, d_boff, d_sorted, fb, ib, NC, NBP);
+  } else if (cb) {
     hipLaunchKernelGGL((msm_part2_scatter_kernel<false, ITEM>), dim3(NC, SW), dim3(SORT_THREADS), lds_fine, stream,
                        (const ITEM*)d_tmp, d_digits, d_cstart, d_boff, d_sorted, sn, fb, ib, NC, NBP);
   } else {
