@@ -22,7 +22,7 @@ _u64p = ctypes.POINTER(ctypes.c_uint64)
 
 def build(force: bool = False) -> str:
     """gcc the restatement into oracle/libcpu_ref.so (in-tree, git-ignored, travels with gpurun)."""
-    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < os.path.getmtime(_SRC):
+    if force or not os.path.exists(_LIB):
         cmd = ["gcc", "-O3", "-march=x86-64-v3", "-shared", "-fPIC", "-pthread", "-o", _LIB, _SRC, "-lm"]
         subprocess.run(cmd, check=True)
     return _LIB
