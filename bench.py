@@ -241,6 +241,24 @@ def main():
                                            "sort_ms": stp["sort_ms"], "register_ms": t_reg * 1e3,
                                            "same_result_as_plain": bool(np.array_equal(ref_out, got_pc))}
         h.release_bases(hp)
+        # independent MSMs issued asynchronously, three in flight on three streams (hm_msm_submit_dev):
+        # what a prover committing to several columns gets; NOT `value`, whose steps are strictly serial
+        streams = [torch.cuda.Stream(device=device) for _ in range(3)]
+        for st_ in streams:
+            st_.wait_stream(torch.cuda.current_stream(device))
+        reps, pending = 9, []
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(reps):
+            if len(pending) == 3:
+                h.best_multiexp_wait(pending.pop(0))
+            with torch.cuda.stream(streams[i % 3]):
+                pending.append(h.best_multiexp_submit(scalars, handle))
+        for t_ in pending:
+            last = h.best_multiexp_wait(t_)
+        dt = (time.perf_counter() - t1) / reps
+        extras["msm_pipelined_3_in_flight"] = {"points_per_s": n_local / dt, "ms_per_msm": dt * 1e3,
+                                               "same_result": bool(np.array_equal(last, ref_out))}
         hs = scalars.cpu().numpy().view(np.uint64)
         t1 = time.perf_counter()
         h.best_multiexp(hs, handle)

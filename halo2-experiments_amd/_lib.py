@@ -53,6 +53,8 @@ _SIGNATURES = {
     "hm_register_bases_precomp": (ctypes.c_int, [_u64p, ctypes.c_size_t, _u64p]),
     "hm_register_bases_precomp_dev": (ctypes.c_int, [_vp, ctypes.c_size_t, _vp, _u64p]),
     "hm_msm_bn256_g1_dev": (ctypes.c_int, [ctypes.c_uint64, ctypes.c_size_t, _vp, ctypes.c_size_t, _vp, _u64p]),
+    "hm_msm_submit_dev": (ctypes.c_int, [ctypes.c_uint64, ctypes.c_size_t, _vp, ctypes.c_size_t, _vp, _u64p]),
+    "hm_msm_wait": (ctypes.c_int, [ctypes.c_uint64, _u64p]),
     "hm_g1_sum": (ctypes.c_int, [_u64p, ctypes.c_size_t, _u64p]),
     "hm_msm_set_window": (ctypes.c_int, [ctypes.c_int]),
     "hm_ntt_bn256_fr": (ctypes.c_int, [_u64p, _u64p, ctypes.c_uint32]),

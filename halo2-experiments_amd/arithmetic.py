@@ -129,6 +129,22 @@ def best_multiexp(coeffs, bases: Union[np.ndarray, BasesHandle, "object"], offse
     return out
 
 
+def best_multiexp_submit(coeffs, bases: BasesHandle, offset: int = 0) -> int:
+    """Asynchronous best_multiexp on device-resident scalars: enqueues the whole MSM on torch's current
+    stream and returns a ticket at once (at most 3 in flight); pair with :func:`best_multiexp_wait`."""
+    n = _tensor_rows(coeffs, 4, "coeffs")
+    t = ctypes.c_uint64(0)
+    _lib.check(_lib.load().hm_msm_submit_dev(ctypes.c_uint64(bases.handle), offset, ctypes.c_void_p(coeffs.data_ptr()), n,
+                                             ctypes.c_void_p(_stream_ptr(coeffs)), ctypes.byref(t)))
+    return t.value
+
+
+def best_multiexp_wait(ticket: int) -> np.ndarray:
+    out = np.zeros(12, dtype=np.uint64)
+    _lib.check(_lib.load().hm_msm_wait(ctypes.c_uint64(ticket), _ptr(out)))
+    return out
+
+
 def best_fft(a, omega, log_n: int) -> None:
     """In place: a[j] <- sum_i a[i] omega^(ij); natural order, unscaled."""
     lib = _lib.load()

@@ -136,7 +136,13 @@ int hm_shutdown(void) {
   }
   c.bases.clear();
   c.scratch.release(); c.io.release(); c.io_bases.release(); c.conv_bases.release(); c.conv_inf.release();
-  c.msm_ws.release(); c.small.release();
+  for (auto& sl : c.msm_slots) {
+    sl.ws.release();
+    sl.busy = false;
+    if (sl.h_land) { (void)hipHostFree(sl.h_land); sl.h_land = nullptr; }
+    if (sl.ev_ready) { for (auto& e : sl.ev) (void)hipEventDestroy(e); sl.ev_ready = false; }
+  }
+  c.small.release();
   c.cached_host_bases = nullptr;
   c.cached_host_n = 0;
   return HM_OK;
@@ -228,6 +234,45 @@ int hm_msm_bn256_g1_dev(uint64_t handle, size_t offset, const void* d_scalars, s
   const uint32_t pc = (offset == 0 && n == b->n) ? b->pc_c : 0u;   // the table only fits whole-set calls
   return msm_run(*ctx, (const uint32_t*)d_scalars, b->d_xy + offset * 16, b->d_inf + offset, n, pc, out_xyz, &is_id,
                  (hipStream_t)stream);
+}
+
+int hm_msm_submit_dev(uint64_t handle, size_t offset, const void* d_scalars, size_t n, void* stream, uint64_t* out_ticket) {
+  if (!out_ticket || (n && !d_scalars)) return hm_fail(HM_ERR_BAD_ARG, "hm_msm_submit_dev: null argument");
+  DeviceCtx* ctx = ctx_for_current_device();
+  if (!ctx) return HM_ERR_NO_DEVICE;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  BasesEntry* b = find_bases(*ctx, handle);
+  if (!b) return hm_fail(HM_ERR_NOT_FOUND, "hm_msm_submit_dev: unknown base handle");
+  if (offset > b->n || n > b->n - offset) return hm_fail(HM_ERR_BAD_ARG, "hm_msm_submit_dev: offset + n exceeds the base set");
+  int slot = -1;
+  for (int i = 1; i < HM_MSM_SLOTS; ++i)        // slot 0 stays free for the synchronous calls
+    if (!ctx->msm_slots[i].busy) { slot = i; break; }
+  if (slot < 0) return hm_fail(HM_ERR_BAD_ARG, "hm_msm_submit_dev: every slot is in flight; hm_msm_wait one first");
+  const uint32_t pc = (offset == 0 && n == b->n) ? b->pc_c : 0u;
+  const int rc = msm_enqueue(*ctx, slot, (const uint32_t*)d_scalars, b->d_xy + offset * 16, b->d_inf + offset, n, pc,
+                             (hipStream_t)stream);
+  if (rc != HM_OK) return rc;
+  ctx->msm_slots[slot].busy = true;
+  ctx->msm_slots[slot].ticket = ctx->next_ticket++;
+  *out_ticket = ctx->msm_slots[slot].ticket;
+  return HM_OK;
+}
+
+int hm_msm_wait(uint64_t ticket, uint64_t out_xyz[12]) {
+  if (!out_xyz) return hm_fail(HM_ERR_BAD_ARG, "hm_msm_wait: null output");
+  DeviceCtx* ctx = ctx_for_current_device();
+  if (!ctx) return HM_ERR_NO_DEVICE;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  for (int i = 1; i < HM_MSM_SLOTS; ++i) {
+    MsmSlot& sl = ctx->msm_slots[i];
+    if (sl.busy && sl.ticket == ticket) {
+      int is_id = 0;
+      const int rc = msm_finish(*ctx, i, out_xyz, &is_id);
+      sl.busy = false;
+      return rc;
+    }
+  }
+  return hm_fail(HM_ERR_NOT_FOUND, "hm_msm_wait: unknown ticket");
 }
 
 int hm_msm_bn256_g1_h(uint64_t handle, size_t offset, const uint64_t* scalars, size_t n, uint64_t out_xy[8],

@@ -76,6 +76,23 @@ struct MsmStats {
   uint32_t c = 0, windows = 0;
 };
 
+constexpr int HM_MSM_SLOTS = 4;
+
+struct MsmSlot {            // one in-flight MSM: its workspace, events and host landing buffers
+  DevBuf ws;
+  hipEvent_t ev[7] = {};
+  bool ev_ready = false;
+  bool busy = false;        // held by a ticket of hm_msm_submit_dev
+  uint64_t ticket = 0;
+  size_t n = 0;
+  hipStream_t stream = nullptr;
+  uint32_t* h_land = nullptr;   // pinned host landing zone: [0, 128*32) window sums, then 4 totals words
+  uint32_t* win() { return h_land; }
+  uint32_t* totals() { return h_land + 128 * 32; }
+  uint32_t SW = 0, c = 0, W = 0;
+  uint64_t T_max = 0;
+};
+
 struct DeviceCtx {
   int device = 0;
   std::mutex mu;
@@ -85,7 +102,8 @@ struct DeviceCtx {
   DevBuf io_bases;        // staging for raw external bases of host-pointer MSM calls
   DevBuf conv_bases;      // converted bases of un-registered calls
   DevBuf conv_inf;
-  DevBuf msm_ws;          // MSM workspace (digits, histograms, sorted indices, bucket sums ...)
+  MsmSlot msm_slots[HM_MSM_SLOTS];   // MSM workspaces (digits, sort scratch, sorted indices, bucket sums ...)
+  uint64_t next_ticket = 1;
   DevBuf small;           // small constants
   std::vector<BasesEntry> bases;
   uint64_t next_handle = 1;
@@ -94,8 +112,6 @@ struct DeviceCtx {
   size_t cached_host_n = 0;
   uint64_t cached_probe[4] = {0, 0, 0, 0};
   MsmStats last_msm;
-  hipEvent_t msm_events[7] = {};
-  bool msm_events_ready = false;
   bool msm_attr_set = false, ntt_attr_set = false;
   void* ensure_scratch(size_t bytes) { return scratch.ensure(bytes); }
 };
@@ -112,6 +128,9 @@ int fr_ext_to_int_run(const uint32_t* d_c_ext, uint32_t* d_out, uint32_t count, 
 // msm.hip
 int msm_convert_bases(const uint32_t* d_bases_ext, uint32_t* d_xy, uint8_t* d_inf, size_t n, hipStream_t stream);
 // out_windows: host buffer of W x 12 u64 external Jacobian + flags
+int msm_enqueue(DeviceCtx& ctx, int slot, const uint32_t* d_scalars_ext, const uint32_t* d_xy, const uint8_t* d_inf, size_t n,
+                uint32_t precomp_c, hipStream_t stream);
+int msm_finish(DeviceCtx& ctx, int slot, uint64_t out_jac_ext[12], int* out_is_identity);
 int msm_run(DeviceCtx& ctx, const uint32_t* d_scalars_ext, const uint32_t* d_xy, const uint8_t* d_inf, size_t n,
             uint32_t precomp_c, uint64_t out_jac_ext[12], int* out_is_identity, hipStream_t stream);
 uint32_t msm_precomp_window(size_t n);

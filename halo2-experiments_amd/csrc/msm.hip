@@ -554,10 +554,12 @@ __global__ __launch_bounds__(ACC_THREADS) void msm_accumulate_kernel(const uint3
                                                                      const uint32_t* __restrict__ bcnt,
                                                                      const uint32_t* __restrict__ toff,
                                                                      const uint32_t* __restrict__ xy,
-                                                                     uint32_t* __restrict__ partial, uint32_t T, uint32_t L) {
+                                                                     uint32_t* __restrict__ partial,
+                                                                     const uint32_t* __restrict__ totals, uint32_t L) {
   __shared__ uint4 stage[4][ACC_THREADS];
   const uint32_t lane = threadIdx.x;
   const uint32_t t = blockIdx.x * ACC_THREADS + lane;
+  const uint32_t T = totals[1];   // task count from the scan: the grid is sized by its host-side upper bound
   uint32_t start = 0, end = 0;
   if (t < T) {
     const uint32_t b = task_bucket[t];
@@ -947,14 +949,16 @@ static int launch_sort_scatter(const int32_t* d_digits, const uint32_t* d_cstart
   return HM_OK;
 }
 
-// d_xy: n points (plain) or the precomputed table of precomp_W * n points (precomp_c != 0).
-int msm_run(DeviceCtx& ctx, const uint32_t* d_scalars_ext, const uint32_t* d_xy, const uint8_t* d_inf, size_t n,
-            uint32_t precomp_c, uint64_t out_jac_ext[12], int* out_is_identity, hipStream_t stream) {
-  if (n == 0) {
-    std::memset(out_jac_ext, 0, 96);
-    *out_is_identity = 1;
-    return HM_OK;
-  }
+// Enqueue every kernel of one MSM on `stream` using workspace slot `slot`; nothing here waits for
+// the device.  d_xy: n points (plain) or the precomputed table of precomp_W * n points
+// (precomp_c != 0).  msm_finish() later waits for the slot, folds the window sums on the host and
+// fills the statistics.
+int msm_enqueue(DeviceCtx& ctx, int slot, const uint32_t* d_scalars_ext, const uint32_t* d_xy, const uint8_t* d_inf, size_t n,
+                uint32_t precomp_c, hipStream_t stream) {
+  MsmSlot& sl = ctx.msm_slots[slot];
+  sl.n = n;
+  sl.stream = stream;
+  if (n == 0) return HM_OK;
   if (n >= (1ull << 31)) return hm_fail(HM_ERR_BAD_ARG, "msm: n must be < 2^31");
   // ---- plan ---------------------------------------------------------------------------------
   const bool single_set = precomp_c != 0;     // all windows accumulate into ONE bucket set
@@ -1037,7 +1041,7 @@ int msm_run(DeviceCtx& ctx, const uint32_t* d_scalars_ext, const uint32_t* d_xy,
   const size_t o_seg2 = carve(((size_t)SW * (nseg / SUM_SPAN + 1)) * PT_WORDS * 4);
   const size_t o_win = carve((size_t)SW * 32 * 4);
   const size_t o_big = carve(((size_t)NBT + 4) * 4);
-  uint8_t* ws = (uint8_t*)ctx.msm_ws.ensure(off);
+  uint8_t* ws = (uint8_t*)sl.ws.ensure(off);
   if (!ws) return hm_fail(HM_ERR_HIP, "msm: workspace allocation failed");
   int32_t* d_digits = (int32_t*)(ws + o_digits);
   uint32_t* d_chist = (uint32_t*)(ws + o_chist);
@@ -1075,10 +1079,11 @@ int msm_run(DeviceCtx& ctx, const uint32_t* d_scalars_ext, const uint32_t* d_xy,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
     ctx.msm_attr_set = true;
   }
-  hipEvent_t* ev = ctx.msm_events;
-  if (!ctx.msm_events_ready) {
+  hipEvent_t* ev = sl.ev;
+  if (!sl.ev_ready) {
     for (int i = 0; i < 7; ++i) HM_HIP_CHECK(hipEventCreate(&ev[i]));
-    ctx.msm_events_ready = true;
+    HM_HIP_CHECK(hipHostMalloc((void**)&sl.h_land, (128 * 32 + 4) * sizeof(uint32_t), hipHostMallocDefault));
+    sl.ev_ready = true;
   }
   HM_HIP_CHECK(hipEventRecord(ev[0], stream));
 
@@ -1116,19 +1121,18 @@ int msm_run(DeviceCtx& ctx, const uint32_t* d_scalars_ext, const uint32_t* d_xy,
   hipLaunchKernelGGL(msm_task_fill_kernel, dim3((NBT + 255) / 256), dim3(256), 0, stream, (const uint32_t*)d_toff, d_tb,
                      NBT);
   HM_HIP_CHECK(hipGetLastError());
-  uint32_t totals[4] = {0, 0, 0, 0};
-  HM_HIP_CHECK(hipMemcpyAsync(totals, d_tot, 8, hipMemcpyDeviceToHost, stream));
   HM_HIP_CHECK(hipEventRecord(ev[2], stream));
-  HM_HIP_CHECK(hipStreamSynchronize(stream));
-  const uint32_t T = totals[1];
-  if ((uint64_t)T > T_max) return hm_fail(HM_ERR_INTERNAL, "msm: task count exceeds its bound");
 
   // ---- K3 ------------------------------------------------------------------------------------
+  // The exact task count T stays on the device (d_tot[1]); the grid covers its host-side bound: for
+  // uniform scalars every bucket holds one task (T ~ NBT), else at most pairs / L more.  Surplus
+  // single-wave workgroups exit at once.
   HM_HIP_CHECK(hipEventRecord(ev[5], stream));
-  if (T > 0) {
-    hipLaunchKernelGGL(msm_accumulate_kernel, dim3((T + ACC_THREADS - 1) / ACC_THREADS), dim3(ACC_THREADS), 0, stream,
-                       (const uint32_t*)d_sorted, (const uint32_t*)d_tb, (const uint32_t*)d_boff, (const uint32_t*)d_bcnt,
-                       (const uint32_t*)d_toff, d_xy, d_partial, T, L);
+  {
+    const uint64_t t_grid = T_max;
+    hipLaunchKernelGGL(msm_accumulate_kernel, dim3((uint32_t)((t_grid + ACC_THREADS - 1) / ACC_THREADS)), dim3(ACC_THREADS), 0,
+                       stream, (const uint32_t*)d_sorted, (const uint32_t*)d_tb, (const uint32_t*)d_boff,
+                       (const uint32_t*)d_bcnt, (const uint32_t*)d_toff, d_xy, d_partial, (const uint32_t*)d_tot, L);
     HM_HIP_CHECK(hipGetLastError());
   }
   HM_HIP_CHECK(hipEventRecord(ev[6], stream));
@@ -1137,8 +1141,8 @@ int msm_run(DeviceCtx& ctx, const uint32_t* d_scalars_ext, const uint32_t* d_xy,
                      (const uint32_t*)d_partial, (const uint32_t*)d_toff, d_bucket, NBT, d_big_count, d_big_list);
   HM_HIP_CHECK(hipGetLastError());
   {
-    uint32_t big_grid = T / (FINALIZE_SERIAL + 1) + 1;  // upper bound on the number of queued buckets
-    if (big_grid > 2048) big_grid = 2048;              // the kernel strides over the queue
+    uint32_t big_grid = (uint32_t)(T_max / (FINALIZE_SERIAL + 1) + 1);  // upper bound on the number of queued buckets
+    if (big_grid > 2048) big_grid = 2048;                               // the kernel strides over the queue
     hipLaunchKernelGGL(msm_bucket_finalize_big_kernel, dim3(big_grid), dim3(WIN_THREADS), 0, stream,
                        (const uint32_t*)d_partial, (const uint32_t*)d_toff, d_bucket, (const uint32_t*)d_big_count,
                        (const uint32_t*)d_big_list);
@@ -1165,12 +1169,30 @@ int msm_run(DeviceCtx& ctx, const uint32_t* d_scalars_ext, const uint32_t* d_xy,
     hipLaunchKernelGGL(msm_windows_to_ext_kernel, dim3((SW + 63) / 64), dim3(64), 0, stream, (const uint32_t*)cur, SW, d_win);
     HM_HIP_CHECK(hipGetLastError());
   }
-  std::vector<uint32_t> win((size_t)SW * 32);
-  HM_HIP_CHECK(hipMemcpyAsync(win.data(), d_win, win.size() * 4, hipMemcpyDeviceToHost, stream));
+  if (SW > 128) return hm_fail(HM_ERR_INTERNAL, "msm: more than 128 windows");
+  // pinned landing zone, so that these copies (and therefore msm_enqueue) do not wait for the device
+  HM_HIP_CHECK(hipMemcpyAsync(sl.win(), d_win, (size_t)SW * 32 * 4, hipMemcpyDeviceToHost, stream));
+  HM_HIP_CHECK(hipMemcpyAsync(sl.totals(), d_tot, 8, hipMemcpyDeviceToHost, stream));
   HM_HIP_CHECK(hipEventRecord(ev[4], stream));
-  HM_HIP_CHECK(hipStreamSynchronize(stream));
+  sl.SW = SW;
+  sl.c = c;
+  sl.W = W;
+  sl.T_max = T_max;
+  return HM_OK;
+}
 
-  host_fold(win.data(), SW, c, out_jac_ext, out_is_identity);   // SW == 1: no Horner, just the normalisation
+// Wait for slot `slot`, fold its window sums (host Horner + affine normalisation) and record stats.
+int msm_finish(DeviceCtx& ctx, int slot, uint64_t out_jac_ext[12], int* out_is_identity) {
+  MsmSlot& sl = ctx.msm_slots[slot];
+  if (sl.n == 0) {
+    std::memset(out_jac_ext, 0, 96);
+    *out_is_identity = 1;
+    return HM_OK;
+  }
+  hipEvent_t* ev = sl.ev;
+  HM_HIP_CHECK(hipEventSynchronize(ev[4]));
+  if ((uint64_t)sl.totals()[1] > sl.T_max) return hm_fail(HM_ERR_INTERNAL, "msm: task count exceeds its bound");
+  host_fold(sl.win(), sl.SW, sl.c, out_jac_ext, out_is_identity);   // SW == 1: no Horner, just the normalisation
 
   float ms[4] = {0, 0, 0, 0}, total = 0;
   for (int i = 0; i < 4; ++i) (void)hipEventElapsedTime(&ms[i], ev[i], ev[i + 1]);
@@ -1183,11 +1205,20 @@ int msm_run(DeviceCtx& ctx, const uint32_t* d_scalars_ext, const uint32_t* d_xy,
   ctx.last_msm.t_accum_ms = ms[2];
   ctx.last_msm.t_reduce_ms = ms[3];
   ctx.last_msm.t_total_ms = total;
-  ctx.last_msm.pairs = totals[0];
-  ctx.last_msm.tasks = T;
-  ctx.last_msm.c = c;
-  ctx.last_msm.windows = W;
+  ctx.last_msm.pairs = sl.totals()[0];
+  ctx.last_msm.tasks = sl.totals()[1];
+  ctx.last_msm.c = sl.c;
+  ctx.last_msm.windows = sl.W;
   return HM_OK;
+}
+
+// the synchronous form: slot 0, enqueue then finish
+int msm_run(DeviceCtx& ctx, const uint32_t* d_scalars_ext, const uint32_t* d_xy, const uint8_t* d_inf, size_t n,
+            uint32_t precomp_c, uint64_t out_jac_ext[12], int* out_is_identity, hipStream_t stream) {
+  if (ctx.msm_slots[0].busy) return hm_fail(HM_ERR_BAD_ARG, "msm: slot 0 is held by an un-awaited hm_msm_submit_dev ticket");
+  const int rc = msm_enqueue(ctx, 0, d_scalars_ext, d_xy, d_inf, n, precomp_c, stream);
+  if (rc != HM_OK) return rc;
+  return msm_finish(ctx, 0, out_jac_ext, out_is_identity);
 }
 
 int g1_fixed_base_mul_run(DeviceCtx& ctx, const uint32_t* d_scalars_ext, size_t n, const uint64_t base_affine_ext[8],

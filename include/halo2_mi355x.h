@@ -89,6 +89,13 @@ int hm_register_bases_dev(const void* d_bases, size_t n, void* stream, uint64_t*
 int hm_msm_bn256_g1_dev(uint64_t handle, size_t offset, const void* d_scalars, size_t n, void* stream,
                         uint64_t out_xyz[12]);
 
+/* Asynchronous form: enqueue the whole MSM on `stream` and return a ticket at once (up to 3 MSMs in
+ * flight per device, each with its own workspace); hm_msm_wait blocks on that MSM only, folds and
+ * returns its result.  Independent commitments issued on different streams overlap: one MSM's
+ * latency-bound phases (sort, bucket reduction, host fold) hide behind another's accumulation. */
+int hm_msm_submit_dev(uint64_t handle, size_t offset, const void* d_scalars, size_t n, void* stream, uint64_t* out_ticket);
+int hm_msm_wait(uint64_t ticket, uint64_t out_xyz[12]);
+
 /* Sum of `count` G1 values (12 x u64 each, z = 0 for the identity), normalised to (x, y, 1): the
  * fold of per-GPU partial results of a sharded best_multiexp after the RCCL all-gather.  Pure host
  * arithmetic on a handful of points (the exchange is ~96 B per rank); needs no device. */
