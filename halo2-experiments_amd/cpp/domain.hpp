@@ -134,8 +134,22 @@ class ParamsKZG {
   // commit(poly in coefficient form) / commit_lagrange(poly in evaluation form): one best_multiexp each
   G1 commit(const Fr* d_poly) const { return msm(g_handle, d_poly); }
   G1 commit_lagrange(const Fr* d_poly) const { return msm(g_lagrange_handle, d_poly); }
+  // asynchronous forms: the commitments of one prover phase are independent, so up to three are kept
+  // in flight on different streams (hm_msm_submit_dev) and awaited in order
+  uint64_t commit_submit(const Fr* d_poly, hipStream_t stream) const { return submit(g_handle, d_poly, stream); }
+  uint64_t commit_lagrange_submit(const Fr* d_poly, hipStream_t stream) const { return submit(g_lagrange_handle, d_poly, stream); }
+  static G1 commit_wait(uint64_t ticket) {
+    G1 out;
+    arithmetic::check(hm_msm_wait(ticket, reinterpret_cast<uint64_t*>(&out)), "commit_wait");
+    return out;
+  }
 
  private:
+  uint64_t submit(uint64_t handle, const Fr* d_poly, hipStream_t stream) const {
+    uint64_t ticket = 0;
+    arithmetic::check(hm_msm_submit_dev(handle, 0, d_poly, n, stream, &ticket), "commit_submit");
+    return ticket;
+  }
   G1 msm(uint64_t handle, const Fr* d_poly) const {
     G1 out;
     arithmetic::check(hm_msm_bn256_g1_dev(handle, 0, d_poly, n, nullptr, reinterpret_cast<uint64_t*>(&out)), "commit");

@@ -130,11 +130,28 @@ int main(int argc, char** argv) {
     }
     const auto t_pk1 = Clock::now();
 
-    // create_proof (utils.rs:40-48): the MSM / NTT trace of SURVEY.md §3.2
+    // create_proof (utils.rs:40-48): the MSM / NTT trace of SURVEY.md §3.2.  The commitments of one
+    // phase are independent: three are kept in flight on three streams.
+    hipStream_t streams[3];
+    for (auto& st : streams) (void)hipStreamCreate(&st);
+    (void)hipDeviceSynchronize();
+    auto commit_phase = [&](uint32_t count, const Fr* d_poly, bool lagrange) {
+      uint64_t pending[3];
+      uint32_t head = 0, inflight = 0;
+      for (uint32_t i = 0; i < count; ++i) {
+        if (inflight == 3) { (void)poly::ParamsKZG::commit_wait(pending[head]); head = (head + 1) % 3; --inflight; }
+        const uint32_t slot = (head + inflight) % 3;
+        pending[slot] = lagrange ? params.commit_lagrange_submit(d_poly, streams[i % 3]) : params.commit_submit(d_poly, streams[i % 3]);
+        ++inflight;
+      }
+      while (inflight) { (void)poly::ParamsKZG::commit_wait(pending[head]); head = (head + 1) % 3; --inflight; }
+    };
+    commit_phase(3, d_dense.d, true);                              // warm-up: allocates the three asynchronous workspaces
     const auto t_pr0 = Clock::now();
     size_t n_msm = 0, n_ntt = 0;
-    for (uint32_t i = 0; i < advice + 2 * lookups; ++i, ++n_msm) (void)params.commit_lagrange(d_sparse.d);       // advice, permuted
-    for (uint32_t i = 0; i < zp + lookups + 1; ++i, ++n_msm) (void)params.commit_lagrange(d_dense.d);           // grand products, random poly
+    commit_phase(advice + 2 * lookups, d_sparse.d, true);          // advice, permuted lookup columns
+    commit_phase(zp + lookups + 1, d_dense.d, true);               // grand products, random poly
+    n_msm += advice + 2 * lookups + zp + lookups + 1;
     {
       const size_t polys = advice + 1 + 3 * lookups + zp;
       for (size_t done = 0; done < polys; done += 8) {
@@ -152,9 +169,11 @@ int main(int argc, char** argv) {
         }
       }
     }
-    for (uint32_t i = 0; i < (max_degree - 1) + 2; ++i, ++n_msm) (void)params.commit(d_dense.d);               // h pieces, SHPLONK
+    commit_phase((max_degree - 1) + 2, d_dense.d, false);          // h pieces, SHPLONK
+    n_msm += (max_degree - 1) + 2;
     (void)hipDeviceSynchronize();
     const auto t_pr1 = Clock::now();
+    for (auto& st : streams) (void)hipStreamDestroy(st);
 
     // verify: commit(f) == commit_lagrange(NTT(f)) == [f(s)]G
     const auto t_v0 = Clock::now();

@@ -30,7 +30,7 @@ import numpy as np
 from .arithmetic import (G1_GENERATOR, best_multiexp, best_multiexp_submit, best_multiexp_wait, g1_fixed_base_mul,
                          register_bases, release_bases)
 from .domain import EvaluationDomain, FR_MODULUS, fr_words
-from .sharding import shard_range, sharded_multiexp
+from .sharding import shard_range, sharded_multiexp, sharded_multiexp_batch
 
 
 @dataclass(frozen=True)
@@ -117,28 +117,14 @@ def run_replay(shape_name: str, device=None, group=None, include_host_pointer_es
     def msm(col, handle):
         return sharded_multiexp(col[lo:hi].contiguous() if world > 1 else col, handle, group=group)
 
-    streams = [torch.cuda.Stream(device=device) for _ in range(3)] if world == 1 else []
+    streams = [torch.cuda.Stream(device=device) for _ in range(3)]
 
     def msm_phase(jobs):
-        """The commitments of one prover phase are independent: on one GPU they are issued
-        asynchronously, three in flight on three streams, so that one MSM's sort / bucket reduction /
-        host fold hides behind another's accumulation.  (Sharded runs keep the simple form: every MSM
-        ends in an all-gather.)"""
-        if world > 1:
-            for col, handle in jobs:
-                msm(col, handle)
-            return
-        cur = torch.cuda.current_stream(device)
-        for st in streams:
-            st.wait_stream(cur)
-        pending = []
-        for i, (col, handle) in enumerate(jobs):
-            if len(pending) == len(streams):
-                best_multiexp_wait(pending.pop(0))
-            with torch.cuda.stream(streams[i % len(streams)]):
-                pending.append(best_multiexp_submit(col, handle))
-        for t in pending:
-            best_multiexp_wait(t)
+        """The commitments of one prover phase are independent: every rank keeps three of its local
+        MSMs in flight on three streams (one MSM's sort / bucket reduction / host fold hides behind
+        another's accumulation), then the partials of the whole phase cross xGMI in ONE all-gather."""
+        local = [((col[lo:hi].contiguous() if world > 1 else col), handle) for col, handle in jobs]
+        sharded_multiexp_batch(local, group=group, streams=streams)
 
     def proof_once():
         t = {"msm": 0.0, "ntt": 0.0}

@@ -52,3 +52,45 @@ def sharded_multiexp(local_coeffs, local_bases, group=None,
     dist.all_gather(gathered, mine, group=group)
     pts = torch.stack(gathered).cpu().numpy().view(np.uint64)
     return g1_sum(pts)
+
+
+def sharded_multiexp_batch(jobs, group=None, streams=None, local_batch: Optional[Callable] = None) -> np.ndarray:
+    """Several independent MSMs (the commitments of one prover phase): ``jobs`` = [(local_coeffs,
+    local_bases_handle), ...], every rank passing ITS shards.  Each rank keeps up to three of its
+    local MSMs in flight (``hm_msm_submit_dev`` on different streams), then ALL partials travel in one
+    all-gather of len(jobs) x 96 B per rank and are folded per job.  Returns (len(jobs), 12) words.
+    ``local_batch`` replaces the GPU part in CPU-only tests."""
+    import torch
+    import torch.distributed as dist
+
+    from .arithmetic import best_multiexp_submit, best_multiexp_wait
+
+    if local_batch is not None:
+        partials = np.stack([np.asarray(p, dtype=np.uint64).reshape(12) for p in local_batch(jobs)]) if jobs else np.zeros((0, 12), np.uint64)
+    else:
+        partials = np.zeros((len(jobs), 12), dtype=np.uint64)
+        if jobs:
+            dev = jobs[0][0].device
+            cur = torch.cuda.current_stream(dev)
+            streams = streams or [torch.cuda.Stream(device=dev) for _ in range(3)]
+            for st in streams:
+                st.wait_stream(cur)
+            pending = []
+            for i, (col, handle) in enumerate(jobs):
+                if len(pending) == min(3, len(streams)):
+                    j, t = pending.pop(0)
+                    partials[j] = best_multiexp_wait(t)
+                with torch.cuda.stream(streams[i % len(streams)]):
+                    pending.append((i, best_multiexp_submit(col, handle)))
+            for j, t in pending:
+                partials[j] = best_multiexp_wait(t)
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return np.stack([g1_sum(p.reshape(1, 12)) for p in partials]) if len(partials) else partials
+    world = dist.get_world_size(group)
+    backend = dist.get_backend(group)
+    dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+    mine = torch.from_numpy(partials.view(np.int64).copy()).to(dev)
+    gathered = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(gathered, mine, group=group)
+    pts = torch.stack(gathered).cpu().numpy().view(np.uint64)          # (world, jobs, 12)
+    return np.stack([g1_sum(pts[:, j, :]) for j in range(len(jobs))]) if len(jobs) else partials
