@@ -246,6 +246,12 @@ def main():
         streams = [torch.cuda.Stream(device=device) for _ in range(3)]
         for st_ in streams:
             st_.wait_stream(torch.cuda.current_stream(device))
+        warm = []
+        for i in range(3):                                     # warm-up: the three asynchronous workspaces get allocated here
+            with torch.cuda.stream(streams[i]):
+                warm.append(h.best_multiexp_submit(scalars, handle))
+        for t_ in warm:
+            h.best_multiexp_wait(t_)
         reps, pending = 9, []
         torch.cuda.synchronize()
         t1 = time.perf_counter()

@@ -273,6 +273,102 @@ __global__ __launch_bounds__(SORT_THREADS) void msm_part1_scatter_kernel(const i
   });
 }
 
+// part 1 scatter, tiled form: the chunk is processed in tiles of 4096 digits that are first
+// counting-sorted by coarse bin inside LDS, so that consecutive lanes append to the same coarse run
+// (sector-complete stores, as in the tiled part-2 scatter below).  Used while NC <= 4096.
+constexpr int P1_IPT = 4;
+constexpr int P1_TILE = SORT_THREADS * P1_IPT;
+template <class ITEM>
+__global__ __launch_bounds__(SORT_THREADS) void msm_part1_scatter_tiled_kernel(const int32_t* __restrict__ digits,
+                                                                               const uint32_t* __restrict__ chist,
+                                                                               const uint32_t* __restrict__ cstart,
+                                                                               ITEM* __restrict__ tmp, size_t n, size_t chunk,
+                                                                               uint32_t fb, uint32_t ib, uint32_t NC) {
+  extern __shared__ uint32_t sm[];
+  const uint32_t g = blockIdx.x, w = blockIdx.y, G = gridDim.x, tid = threadIdx.x;
+  uint32_t* gcur = sm;                 // global cursor of every coarse bin for this chunk
+  uint32_t* tcnt = gcur + NC;
+  uint32_t* tstart = tcnt + NC;
+  uint32_t* wsum = tstart + NC;
+  uint32_t* st_bin = wsum + 32;
+  ITEM* st_item = reinterpret_cast<ITEM*>(st_bin + P1_TILE);
+  const uint32_t* pre = chist + ((size_t)w * G + g) * NC;
+  const uint32_t* cs = cstart + (size_t)w * NC;
+  for (uint32_t b = tid; b < NC; b += SORT_THREADS) { gcur[b] = cs[b] + pre[b]; tcnt[b] = 0; }
+  __syncthreads();
+  const size_t lo = (size_t)g * chunk, hi = lo + chunk < n ? lo + chunk : n;
+  const int32_t* dw = digits + (size_t)w * n;
+  const uint32_t fmask = (1u << fb) - 1u;
+  const uint32_t per = (NC + SORT_THREADS - 1) / SORT_THREADS;
+  for (size_t t0 = lo; t0 < hi; t0 += P1_TILE) {
+    const uint32_t tile_n = hi - t0 < (size_t)P1_TILE ? (uint32_t)(hi - t0) : (uint32_t)P1_TILE;
+    ITEM item[P1_IPT];
+    uint32_t bin[P1_IPT], rank[P1_IPT];
+#pragma unroll
+    for (int k = 0; k < P1_IPT; ++k) {
+      const uint32_t e = (uint32_t)k * SORT_THREADS + tid;
+      bin[k] = 0xffffffffu;
+      if (e < tile_n) {
+        const int32_t d = dw[t0 + e];
+        if (d != 0) {
+          const uint32_t b1 = (uint32_t)(d < 0 ? -d : d) - 1u;
+          bin[k] = b1 >> fb;
+          item[k] = ((ITEM)(b1 & fmask) << (ib + 1)) | ((ITEM)(d < 0 ? 1u : 0u) << ib) | (ITEM)(t0 + e);
+          rank[k] = atomicAdd(&tcnt[bin[k]], 1u);
+        }
+      }
+    }
+    __syncthreads();
+    {   // exclusive scan of tcnt[0 .. NC)
+      const uint32_t b0 = tid * per;
+      uint32_t v[4] = {0, 0, 0, 0}, sum = 0;
+      for (uint32_t k = 0; k < per; ++k)
+        if (b0 + k < NC) { v[k] = tcnt[b0 + k]; sum += v[k]; }
+      uint32_t incl = sum;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t u = __shfl_up(incl, off, 64);
+        if ((tid & 63) >= (uint32_t)off) incl += u;
+      }
+      if ((tid & 63) == 63) wsum[tid >> 6] = incl;
+      __syncthreads();
+      if (tid < 64) {
+        const uint32_t ws = tid < (SORT_THREADS / 64) ? wsum[tid] : 0;
+        uint32_t wi = ws;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+          const uint32_t u = __shfl_up(wi, off, 64);
+          if (tid >= (uint32_t)off) wi += u;
+        }
+        if (tid < (SORT_THREADS / 64)) wsum[tid] = wi - ws;
+      }
+      __syncthreads();
+      uint32_t run = wsum[tid >> 6] + incl - sum;
+      for (uint32_t k = 0; k < per; ++k)
+        if (b0 + k < NC) { tstart[b0 + k] = run; run += v[k]; }
+    }
+    __syncthreads();
+    uint32_t kept = 0;
+#pragma unroll
+    for (int k = 0; k < P1_IPT; ++k) {
+      if (bin[k] != 0xffffffffu) {
+        const uint32_t pos = tstart[bin[k]] + rank[k];
+        st_item[pos] = item[k];
+        st_bin[pos] = bin[k];
+      }
+    }
+    __syncthreads();
+    kept = tstart[NC - 1] + tcnt[NC - 1];      // non-zero digits of this tile
+    for (uint32_t e = tid; e < kept; e += SORT_THREADS) {
+      const uint32_t b = st_bin[e];
+      tmp[gcur[b] + (e - tstart[b])] = st_item[e];
+    }
+    __syncthreads();
+    for (uint32_t b = tid; b < NC; b += SORT_THREADS) { gcur[b] += tcnt[b]; tcnt[b] = 0; }
+    __syncthreads();
+  }
+}
+
 // part 2, first half: fine histogram of one (coarse bin, window) region -> bucket counts.
 // FROM_DIGITS (cb = 0): the "region" is the whole window and items are read from the digit array.
 template <bool FROM_DIGITS, class ITEM>
@@ -917,8 +1013,14 @@ static int launch_sort(const int32_t* d_digits, uint32_t* d_chist, uint32_t* d_c
                        fb, NC);
     hipLaunchKernelGGL(msm_part1_scan_kernel, dim3(SW * NC), dim3(64), 0, stream, d_chist, d_ctot, G, NC, SW);
     hipLaunchKernelGGL(msm_part1_starts_kernel, dim3(1), dim3(1024), 0, stream, (const uint32_t*)d_ctot, d_cstart, SW * NC);
-    hipLaunchKernelGGL(msm_part1_scatter_kernel<ITEM>, dim3(G, SW), dim3(SORT_THREADS), lds_coarse, stream, d_digits,
-                       (const uint32_t*)d_chist, (const uint32_t*)d_cstart, (ITEM*)d_tmp, sn, chunk, fb, ib, NC);
+    if (NC <= 4096) {
+      const size_t lds_p1 = ((size_t)3 * NC + 32 + P1_TILE) * 4 + (size_t)P1_TILE * sizeof(ITEM);
+      hipLaunchKernelGGL(msm_part1_scatter_tiled_kernel<ITEM>, dim3(G, SW), dim3(SORT_THREADS), lds_p1, stream, d_digits,
+                         (const uint32_t*)d_chist, (const uint32_t*)d_cstart, (ITEM*)d_tmp, sn, chunk, fb, ib, NC);
+    } else {
+      hipLaunchKernelGGL(msm_part1_scatter_kernel<ITEM>, dim3(G, SW), dim3(SORT_THREADS), lds_coarse, stream, d_digits,
+                         (const uint32_t*)d_chist, (const uint32_t*)d_cstart, (ITEM*)d_tmp, sn, chunk, fb, ib, NC);
+    }
     hipLaunchKernelGGL((msm_part2_hist_kernel<false, ITEM>), dim3(NC, SW), dim3(SORT_THREADS), lds_fine, stream,
                        (const ITEM*)d_tmp, d_digits, (const uint32_t*)d_cstart, d_bcnt, sn, fb, ib, NC, NBP);
   } else {
@@ -1076,6 +1178,10 @@ int msm_enqueue(DeviceCtx& ctx, int slot, const uint32_t* d_scalars_ext, const u
     HM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(msm_part2_scatter_kernel<false, uint32_t>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
     HM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(msm_part2_scatter_kernel<false, uint64_t>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+    HM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(msm_part1_scatter_tiled_kernel<uint32_t>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+    HM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(msm_part1_scatter_tiled_kernel<uint64_t>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
     ctx.msm_attr_set = true;
   }
