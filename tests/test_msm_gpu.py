@@ -295,3 +295,23 @@ def test_async_submit_wait_overlapping_streams(cref, golden):
         assert g1_equal(h.best_multiexp_wait(t), g["n1024_uniform_r"])
     finally:
         h.release_bases(hd)
+
+
+def test_config5_size_2_26_fits_one_gpu_and_is_additive():
+    """BASELINE config 5's 2^26-point MSM on ONE GPU (2^30 (point, bucket) pairs, 4 + 4 GiB of
+    bases, ~20 GiB of workspace): the whole equals the sum of its four 2^24 quarters."""
+    import torch
+    from halo2_experiments_amd.arithmetic import G1_GENERATOR
+    from halo2_experiments_amd.sharding import g1_sum
+    n = 1 << 26
+    hd = h.register_bases(h.g1_fixed_base_mul(rand_fr_gpu(n, 2601), G1_GENERATOR))
+    try:
+        s = rand_fr_gpu(n, 2602)
+        whole = h.best_multiexp(s, hd)
+        assert whole[8:].any()
+        q = n // 4
+        parts = np.stack([h.best_multiexp(s[i * q:(i + 1) * q].contiguous(), hd, offset=i * q) for i in range(4)])
+        assert np.array_equal(g1_sum(parts), whole)
+    finally:
+        h.release_bases(hd)
+        torch.cuda.empty_cache()
