@@ -5,14 +5,14 @@ The reference repository holds no MSM/FFT vectors, so these fix
 by independent mathematics: naive double-and-add / known discrete logs for the MSM, the O(n^2)
 DFT definition for small NTTs and the recursive restatement cross-checked against it for larger
 ones.  Everything is stored in the reference's memory layout (little-endian u64 Montgomery limbs).
-Run:  python tools/gen_golden.py      (deterministic; ~1 minute)
+Run:  python tests/golden/gen_golden.py      (deterministic; ~1 minute)
 """
 import os
 import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle import bn256_ref as o  # noqa: E402
 

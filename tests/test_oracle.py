@@ -120,7 +120,7 @@ def test_c_mid_size_known_answer(cref, pyref):
 
 
 def test_golden_regenerates(pyref, golden):
-    """The committed fixtures are what tools/gen_golden.py produces (spot check, fast subset)."""
+    """The committed fixtures are what tests/golden/gen_golden.py produces (spot check, fast subset)."""
     o = pyref
     g = golden["ntt"]
     for k in (1, 4, 6):
