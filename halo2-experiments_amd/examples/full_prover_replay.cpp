@@ -8,7 +8,9 @@
 // CPU-side Rust and is not part of these numbers.  "Verify" is the algebraic check the KZG commitments
 // must satisfy: commit(f) == commit_lagrange(NTT(f)) == [f(s)]G for a random f.
 //
-//   full_prover_replay [k=9] [advice=20] [lookups=8] [equality=12] [max_degree=7] [fixed=8]
+//   full_prover_replay [k=9] [advice=20] [lookups=8] [equality=12] [max_degree=7] [fixed=8] [tamper=0]
+// tamper=1 changes one evaluation between the two commitments, as the reference's tests tamper with
+// a witness and expect `verify()` to fail: the run must then report a mismatch and exit 1.
 // Defaults are test_full_prover's k = 9 (/root/reference/src/circuits/merkle_sum_tree.rs:347) with the
 // MerkleSumTree column counts.
 #include <chrono>
@@ -85,6 +87,7 @@ int main(int argc, char** argv) {
   const uint32_t equality = argc > 4 ? (uint32_t)atoi(argv[4]) : 12;
   const uint32_t max_degree = argc > 5 ? (uint32_t)atoi(argv[5]) : 7;
   const uint32_t fixed = argc > 6 ? (uint32_t)atoi(argv[6]) : 8;
+  const bool tamper = argc > 7 && atoi(argv[7]) != 0;
   if (k < 4 || k > 22 || max_degree < 3) { std::fprintf(stderr, "unsupported shape\n"); return 2; }
   try {
     if (hm_device_count() <= 0) { std::fprintf(stderr, "no gfx950 device: %s\n", "this path has no CPU fallback"); return 3; }
@@ -181,6 +184,12 @@ int main(int argc, char** argv) {
     f.upload(dense);
     const G1 c_coeff = params.commit(f.d);
     arithmetic::check(hm_ntt_bn256_fr_dev(f.d, dom.omega.l, k, nullptr), "best_fft");
+    if (tamper) {                                           // one evaluation off by one
+      Fr e;
+      (void)hipMemcpy(&e, f.d + 3, sizeof(Fr), hipMemcpyDeviceToHost);
+      e = e + Fr::one();
+      (void)hipMemcpy(f.d + 3, &e, sizeof(Fr), hipMemcpyHostToDevice);
+    }
     const G1 c_lagrange = params.commit_lagrange(f.d);
     Fr fs = Fr::zero();
     for (size_t i = n; i-- > 0;) fs = fs * s + dense[i];

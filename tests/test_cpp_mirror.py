@@ -45,3 +45,13 @@ def test_full_prover_replay_verifies(built, args):
     assert "commitments verified" in r.stdout
     for line in ("Time to generate vk", "Time to generate pk", "Prover Time", "Verifier Time"):
         assert re.search(line + r" \d+\.\d+s", r.stdout), r.stdout
+
+
+@pytest.mark.gpu
+def test_full_prover_replay_rejects_a_tampered_evaluation(built):
+    """The reference's tests tamper with the witness and expect verification to fail
+    (e.g. merkle_sum_tree.rs:214-343); here one evaluation changes between the two commitments."""
+    r = subprocess.run([os.path.join(built, "full_prover_replay"), "10", "4", "0", "3", "5", "2", "1"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 1, r.stdout + r.stderr
+    assert "COMMITMENT MISMATCH" in r.stdout
