@@ -149,7 +149,7 @@ int hm_shutdown(void) {
 }
 
 int hm_msm_set_window(int c) {
-  if (c != 0 && (c < 2 || c > 16)) return hm_fail(HM_ERR_BAD_ARG, "hm_msm_set_window: c must be 0 or in [2, 16]");
+  if (c != 0 && (c < 2 || c > 22)) return hm_fail(HM_ERR_BAD_ARG, "hm_msm_set_window: c must be 0 or in [2, 22]");
   msm_set_window_override(c);
   return HM_OK;
 }

@@ -1071,10 +1071,14 @@ int msm_enqueue(DeviceCtx& ctx, int slot, const uint32_t* d_scalars_ext, const u
     c = (uint32_t)g_window_override;
   } else {
     // mean bucket load n / 2^(c-1) ~ 16: short accumulation chains, (almost) no bucket splitting,
-    // fewest (point, bucket) pairs; capped by W separate bucket sets and their reduction
+    // fewest (point, bucket) pairs.  Cap: c = 17 gives W = 15 windows that cover the 255 digit bits
+    // exactly (measured at 2^24: 25.9 ms vs 28.1 ms for c = 16).  Larger c would need fewer windows
+    // still, but 18, 19 and 21 leave a top window of 3-8 bits whose few buckets receive all n points
+    // (one sort region, one workgroup), and c = 20's 6.8 M buckets cost more to reduce than they save.
     int ci = (int)ilog2(n) - 3;
     if (ci < 4) ci = 4;
-    if (ci > 16) ci = 16;
+    const int cap = n >= (1u << 21) ? 17 : 16;
+    if (ci > cap) ci = cap;
     c = (uint32_t)ci;
   }
   if (c < 2 || c > 24) return hm_fail(HM_ERR_BAD_ARG, "msm: window size out of range");
@@ -1114,6 +1118,7 @@ int msm_enqueue(DeviceCtx& ctx, int slot, const uint32_t* d_scalars_ext, const u
   if (ib == 0) ib = 1;
   bool wide_items = false;
   uint32_t fb = c - 1 < 31 - ib ? c - 1 : 31 - ib;
+  if (fb > 15) fb = 15;                  // 2^15 LDS counters = 128 KiB is what a workgroup may hold
   if (fb < 5 && c - 1 > fb) {            // too few fine bits left in 32: switch to 64-bit items
     wide_items = true;
     fb = c - 1 < 9 ? c - 1 : 9;      // few fine runs per region: the region's write sectors must stay in L2

@@ -43,7 +43,7 @@ def test_empty_and_identity_results(golden):
     assert is_id.value == 1 and not xy.any()
 
 
-@pytest.mark.parametrize("window", [0, 4, 7, 11, 13, 16])
+@pytest.mark.parametrize("window", [0, 4, 7, 11, 13, 16, 17, 19, 22])
 def test_every_window_size(golden, window):
     g = golden["msm"]
     lib = _lib.load()
