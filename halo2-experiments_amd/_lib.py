@@ -7,7 +7,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(CSRC, "libhalo2_mi355x.so")
+LIB_PATH = os.environ.get("HALO2_MI355X_LIB") or os.path.join(CSRC, "libhalo2_mi355x.so")   # override: A/B builds
 HOSTCHECK_PATH = os.path.join(CSRC, "libhm_hostcheck.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "halo2_mi355x.h")
 

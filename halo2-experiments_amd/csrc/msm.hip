@@ -154,6 +154,26 @@ __global__ void msm_digits_kernel(const uint32_t* __restrict__ scalars, const ui
 // ---------------------------------------------------------------------------------------------
 constexpr int SORT_THREADS = 1024;
 
+// cnt[bin]++ in LDS, returning the old value.  Lanes of a wave that hit the SAME counter serialise
+// in the LDS atomic unit, and constant or flag columns (every scalar equal, or 0/1) put whole waves
+// on one counter.  One cheap wave-uniform test catches exactly that case and replaces the wave's
+// atomics by a single one; any other wave takes the plain per-lane atomic.
+__device__ __forceinline__ uint32_t lds_inc(uint32_t* cnt, uint32_t bin) {
+#ifndef HM_NO_AGG
+  const uint32_t v = (uint32_t)__builtin_amdgcn_readfirstlane((int)bin);
+  const uint64_t active = __ballot(1);
+  if (__ballot(bin == v) == active) {                      // every active lane wants the same counter
+    const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const uint32_t before = (uint32_t)__popcll(active & ((1ull << lane) - 1ull));
+    uint32_t base = 0;
+    if (before == 0) base = atomicAdd(&cnt[v], (uint32_t)__popcll(active));
+    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+    return base + before;
+  }
+#endif
+  return atomicAdd(&cnt[bin], 1u);
+}
+
 // Apply f(index, word) to base[lo .. hi) with the whole workgroup, 16 bytes per lane per load:
 // one 4-byte load in flight per lane keeps only ~1 MB outstanding chip-wide (latency-bound at
 // ~0.5 TB/s); four words per load quadruple the bytes in flight.
@@ -187,7 +207,7 @@ __global__ __launch_bounds__(SORT_THREADS) void msm_part1_hist_kernel(const int3
   const size_t lo = (size_t)g * chunk, hi = lo + chunk < n ? lo + chunk : n;
   const int32_t* dw = digits + (size_t)w * n;
   block_for_each_word(dw, lo, hi, [&](size_t, int32_t d) {
-    if (d != 0) atomicAdd(&hist[((uint32_t)(d < 0 ? -d : d) - 1u) >> fb], 1u);
+    if (d != 0) (void)lds_inc(hist, ((uint32_t)(d < 0 ? -d : d) - 1u) >> fb);
   });
   __syncthreads();
   uint32_t* out = chist + ((size_t)w * G + g) * NC;
@@ -267,7 +287,7 @@ __global__ __launch_bounds__(SORT_THREADS) void msm_part1_scatter_kernel(const i
   block_for_each_word(dw, lo, hi, [&](size_t i, int32_t d) {
     if (d != 0) {
       const uint32_t b1 = (uint32_t)(d < 0 ? -d : d) - 1u;
-      const uint32_t pos = atomicAdd(&cursor[b1 >> fb], 1u);
+      const uint32_t pos = lds_inc(cursor, b1 >> fb);
       tmp[pos] = ((ITEM)(b1 & fmask) << (ib + 1)) | ((ITEM)(d < 0 ? 1u : 0u) << ib) | (ITEM)i;
     }
   });
@@ -314,7 +334,7 @@ __global__ __launch_bounds__(SORT_THREADS) void msm_part1_scatter_tiled_kernel(c
           const uint32_t b1 = (uint32_t)(d < 0 ? -d : d) - 1u;
           bin[k] = b1 >> fb;
           item[k] = ((ITEM)(b1 & fmask) << (ib + 1)) | ((ITEM)(d < 0 ? 1u : 0u) << ib) | (ITEM)(t0 + e);
-          rank[k] = atomicAdd(&tcnt[bin[k]], 1u);
+          rank[k] = lds_inc(tcnt, bin[k]);
         }
       }
     }
@@ -371,30 +391,64 @@ __global__ __launch_bounds__(SORT_THREADS) void msm_part1_scatter_tiled_kernel(c
 
 // part 2, first half: fine histogram of one (coarse bin, window) region -> bucket counts.
 // FROM_DIGITS (cb = 0): the "region" is the whole window and items are read from the digit array.
-template <bool FROM_DIGITS, class ITEM>
+// Regions larger than `big` items (a hot bucket: constant or flag columns send a whole window to one
+// region) are left to the COOP instantiation, which many workgroups run on slices of such a region
+// (work list built by msm_big_regions_kernel) and which ADDS its counts to bcnt with global atomics.
+template <bool FROM_DIGITS, class ITEM, bool COOP = false>
 __global__ __launch_bounds__(SORT_THREADS) void msm_part2_hist_kernel(const ITEM* __restrict__ tmp,
                                                                       const int32_t* __restrict__ digits,
                                                                       const uint32_t* __restrict__ cstart,
                                                                       uint32_t* __restrict__ bcnt, size_t n, uint32_t fb,
-                                                                      uint32_t ib, uint32_t NC, uint32_t NBP) {
+                                                                      uint32_t ib, uint32_t NC, uint32_t NBP, uint32_t big,
+                                                                      uint32_t slice, const uint2* __restrict__ list,
+                                                                      const uint32_t* __restrict__ list_count) {
   extern __shared__ uint32_t fine[];
-  const uint32_t hb = blockIdx.x, w = blockIdx.y;
+  uint32_t hb = blockIdx.x, w = blockIdx.y, sl = 0;
+  if (COOP) {
+    if (blockIdx.x >= *list_count) return;
+    const uint2 it = list[blockIdx.x];
+    w = it.x / NC;
+    hb = it.x - w * NC;
+    sl = it.y;
+  }
   const uint32_t NF = 1u << fb;
+  if (!FROM_DIGITS && !COOP && cstart[w * NC + hb + 1] - cstart[w * NC + hb] > big) return;   // bcnt was zeroed
   for (uint32_t b = threadIdx.x; b < NF; b += SORT_THREADS) fine[b] = 0;
   __syncthreads();
   if (FROM_DIGITS) {
     const int32_t* dw = digits + (size_t)w * n;
     block_for_each_word(dw, 0, n, [&](size_t, int32_t d) {
-      if (d != 0) atomicAdd(&fine[(uint32_t)(d < 0 ? -d : d) - 1u], 1u);
+      if (d != 0) (void)lds_inc(fine, (uint32_t)(d < 0 ? -d : d) - 1u);
     });
   } else {
-    const uint32_t lo = cstart[w * NC + hb], hi = cstart[w * NC + hb + 1];
-    block_for_each_word(tmp, lo, hi, [&](size_t, ITEM item) { atomicAdd(&fine[(uint32_t)(item >> (ib + 1))], 1u); });
+    uint32_t lo = cstart[w * NC + hb], hi = cstart[w * NC + hb + 1];
+    if (COOP) {
+      lo += sl * slice;
+      hi = lo + slice < hi ? lo + slice : hi;
+    }
+    block_for_each_word(tmp, lo, hi, [&](size_t, ITEM item) { (void)lds_inc(fine, (uint32_t)(item >> (ib + 1))); });
   }
   __syncthreads();
   uint32_t* out = bcnt + (size_t)w * NBP + 1 + ((size_t)hb << fb);
-  for (uint32_t b = threadIdx.x; b < NF; b += SORT_THREADS) out[b] = fine[b];
-  if (hb == 0 && threadIdx.x == 0) bcnt[(size_t)w * NBP] = 0;   // bucket 0 (digit 0) is never used
+  if (COOP) {
+    for (uint32_t b = threadIdx.x; b < NF; b += SORT_THREADS)
+      if (fine[b]) atomicAdd(&out[b], fine[b]);
+  } else {
+    for (uint32_t b = threadIdx.x; b < NF; b += SORT_THREADS) out[b] = fine[b];
+    if (hb == 0 && threadIdx.x == 0) bcnt[(size_t)w * NBP] = 0;   // bucket 0 (digit 0) is never used
+  }
+}
+
+// work list of (region, slice) pairs for regions with more than `big` items
+__global__ void msm_big_regions_kernel(const uint32_t* __restrict__ cstart, uint32_t nregions, uint32_t big, uint32_t slice,
+                                       uint2* __restrict__ list, uint32_t* __restrict__ list_count, uint32_t capacity) {
+  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= nregions) return;
+  const uint32_t size = cstart[r + 1] - cstart[r];
+  if (size <= big) return;
+  const uint32_t nsl = (size + slice - 1) / slice;
+  const uint32_t at = atomicAdd(list_count, nsl);
+  for (uint32_t i = 0; i < nsl && at + i < capacity; ++i) list[at + i] = make_uint2(r, i);
 }
 
 // part 2, second half: scatter the region's items to their final places (boff = global bucket offsets)
@@ -415,7 +469,7 @@ __global__ __launch_bounds__(SORT_THREADS) void msm_part2_scatter_kernel(const I
     const int32_t* dw = digits + (size_t)w * n;
     block_for_each_word(dw, 0, n, [&](size_t i, int32_t d) {
       if (d != 0) {
-        const uint32_t pos = atomicAdd(&cursor[(uint32_t)(d < 0 ? -d : d) - 1u], 1u);
+        const uint32_t pos = lds_inc(cursor, (uint32_t)(d < 0 ? -d : d) - 1u);
         sorted[pos] = (uint32_t)i | (d < 0 ? 0x80000000u : 0u);
       }
     });
@@ -423,7 +477,7 @@ __global__ __launch_bounds__(SORT_THREADS) void msm_part2_scatter_kernel(const I
     const uint32_t lo = cstart[w * NC + hb], hi = cstart[w * NC + hb + 1];
     const ITEM imask = ((ITEM)1 << ib) - 1;
     block_for_each_word(tmp, lo, hi, [&](size_t, ITEM item) {
-      const uint32_t pos = atomicAdd(&cursor[(uint32_t)(item >> (ib + 1))], 1u);
+      const uint32_t pos = lds_inc(cursor, (uint32_t)(item >> (ib + 1)));
       sorted[pos] = (uint32_t)(item & imask) | ((uint32_t)((item >> ib) & 1) << 31);
     });
   }
@@ -436,14 +490,29 @@ __global__ __launch_bounds__(SORT_THREADS) void msm_part2_scatter_kernel(const I
 // workgroup's lifetime, which is what kept missing L2 once a region had more than ~128 runs.
 constexpr int P2_IPT = 4;
 constexpr int P2_TILE = SORT_THREADS * P2_IPT;
-template <class ITEM>
+// COOP: slices of big regions (work list); the per-bucket cursors then live in global memory
+// (`gcursor`, a copy of boff) and every tile reserves its runs with one atomicAdd per non-empty bucket.
+template <class ITEM, bool COOP = false>
 __global__ __launch_bounds__(SORT_THREADS) void msm_part2_scatter_tiled_kernel(const ITEM* __restrict__ tmp,
                                                                                const uint32_t* __restrict__ cstart,
                                                                                const uint32_t* __restrict__ boff,
                                                                                uint32_t* __restrict__ sorted, uint32_t fb,
-                                                                               uint32_t ib, uint32_t NC, uint32_t NBP) {
+                                                                               uint32_t ib, uint32_t NC, uint32_t NBP, uint32_t big,
+                                                                               uint32_t slice, const uint2* __restrict__ list,
+                                                                               const uint32_t* __restrict__ list_count,
+                                                                               uint32_t* __restrict__ gcursor) {
   extern __shared__ uint32_t sm[];
-  const uint32_t hb = blockIdx.x, w = blockIdx.y, tid = threadIdx.x;
+  uint32_t hb = blockIdx.x, w = blockIdx.y, sl = 0;
+  const uint32_t tid = threadIdx.x;
+  if (COOP) {
+    if (blockIdx.x >= *list_count) return;
+    const uint2 it = list[blockIdx.x];
+    w = it.x / NC;
+    hb = it.x - w * NC;
+    sl = it.y;
+  } else if (cstart[w * NC + hb + 1] - cstart[w * NC + hb] > big) {
+    return;
+  }
   const uint32_t NF = 1u << fb;                       // <= 2048
   uint32_t* gcur = sm;                                // global cursor of every fine bucket
   uint32_t* tcnt = gcur + NF;                         // items of the current tile per bucket
@@ -452,9 +521,14 @@ __global__ __launch_bounds__(SORT_THREADS) void msm_part2_scatter_tiled_kernel(c
   uint32_t* st_pay = wsum + 32;                       // tile items in bucket order
   uint32_t* st_bin = st_pay + P2_TILE;
   const uint32_t* bo = boff + (size_t)w * NBP + 1 + ((size_t)hb << fb);
+  uint32_t* gc = gcursor + (size_t)w * NBP + 1 + ((size_t)hb << fb);
   for (uint32_t b = tid; b < NF; b += SORT_THREADS) { gcur[b] = bo[b]; tcnt[b] = 0; }
   __syncthreads();
-  const uint32_t lo = cstart[w * NC + hb], hi = cstart[w * NC + hb + 1];
+  uint32_t lo = cstart[w * NC + hb], hi = cstart[w * NC + hb + 1];
+  if (COOP) {
+    lo += sl * slice;
+    hi = lo + slice < hi ? lo + slice : hi;
+  }
   const ITEM imask = ((ITEM)1 << ib) - 1;
   const uint32_t per = (NF + SORT_THREADS - 1) / SORT_THREADS;   // scan entries per lane (1 or 2)
   for (uint32_t t0 = lo; t0 < hi; t0 += P2_TILE) {
@@ -467,7 +541,7 @@ __global__ __launch_bounds__(SORT_THREADS) void msm_part2_scatter_tiled_kernel(c
         const ITEM item = tmp[t0 + e];
         bin[k] = (uint32_t)(item >> (ib + 1));
         pay[k] = (uint32_t)(item & imask) | ((uint32_t)((item >> ib) & 1) << 31);
-        rank[k] = atomicAdd(&tcnt[bin[k]], 1u);
+        rank[k] = lds_inc(tcnt, bin[k]);
       }
     }
     __syncthreads();
@@ -510,13 +584,19 @@ __global__ __launch_bounds__(SORT_THREADS) void msm_part2_scatter_tiled_kernel(c
         st_bin[pos] = bin[k];
       }
     }
+    if (COOP)      // reserve this tile's run in every non-empty bucket
+      for (uint32_t b = tid; b < NF; b += SORT_THREADS)
+        if (tcnt[b]) gcur[b] = atomicAdd(&gc[b], tcnt[b]);
     __syncthreads();
     for (uint32_t e = tid; e < tile_n; e += SORT_THREADS) {
       const uint32_t b = st_bin[e];
       sorted[gcur[b] + (e - tstart[b])] = st_pay[e];
     }
     __syncthreads();
-    for (uint32_t b = tid; b < NF; b += SORT_THREADS) { gcur[b] += tcnt[b]; tcnt[b] = 0; }
+    for (uint32_t b = tid; b < NF; b += SORT_THREADS) {
+      if (!COOP) gcur[b] += tcnt[b];
+      tcnt[b] = 0;
+    }
     __syncthreads();
   }
 }
@@ -1002,10 +1082,19 @@ int msm_precompute(uint32_t* d_table, const uint8_t* d_inf, size_t n, uint32_t c
   return HM_OK;
 }
 
+struct BigRegionPlan {      // cooperative handling of sort regions that hold far more than their share
+  uint32_t big = 0;         // regions above this many items are split
+  uint32_t slice = 0;       // ... into slices of this many items, one workgroup each
+  uint32_t capacity = 0;    // entries of the work list
+  uint2* list = nullptr;
+  uint32_t* count = nullptr;
+  uint32_t* gcursor = nullptr;   // copy of boff: global per-bucket cursors of the cooperative scatter
+};
+
 template <class ITEM>
 static int launch_sort(const int32_t* d_digits, uint32_t* d_chist, uint32_t* d_ctot, uint32_t* d_cstart, void* d_tmp,
                        uint32_t* d_bcnt, size_t sn, size_t chunk, uint32_t G, uint32_t SW, uint32_t fb, uint32_t ib, uint32_t cb,
-                       uint32_t NC, uint32_t NBP, hipStream_t stream) {
+                       uint32_t NC, uint32_t NBP, const BigRegionPlan& br, hipStream_t stream) {
   const size_t lds_fine = (size_t)4 << fb;
   if (cb) {
     const size_t lds_coarse = (size_t)NC * 4;
@@ -1021,11 +1110,20 @@ static int launch_sort(const int32_t* d_digits, uint32_t* d_chist, uint32_t* d_c
       hipLaunchKernelGGL(msm_part1_scatter_kernel<ITEM>, dim3(G, SW), dim3(SORT_THREADS), lds_coarse, stream, d_digits,
                          (const uint32_t*)d_chist, (const uint32_t*)d_cstart, (ITEM*)d_tmp, sn, chunk, fb, ib, NC);
     }
-    hipLaunchKernelGGL((msm_part2_hist_kernel<false, ITEM>), dim3(NC, SW), dim3(SORT_THREADS), lds_fine, stream,
-                       (const ITEM*)d_tmp, d_digits, (const uint32_t*)d_cstart, d_bcnt, sn, fb, ib, NC, NBP);
+    // regions far above their share go to the cooperative kernels: list them, then count in both forms
+    HM_HIP_CHECK(hipMemsetAsync(br.count, 0, 16, stream));
+    hipLaunchKernelGGL(msm_big_regions_kernel, dim3((SW * NC + 255) / 256), dim3(256), 0, stream, (const uint32_t*)d_cstart,
+                       SW * NC, br.big, br.slice, br.list, br.count, br.capacity);
+    hipLaunchKernelGGL((msm_part2_hist_kernel<false, ITEM, false>), dim3(NC, SW), dim3(SORT_THREADS), lds_fine, stream,
+                       (const ITEM*)d_tmp, d_digits, (const uint32_t*)d_cstart, d_bcnt, sn, fb, ib, NC, NBP, br.big, br.slice,
+                       (const uint2*)br.list, (const uint32_t*)br.count);
+    hipLaunchKernelGGL((msm_part2_hist_kernel<false, ITEM, true>), dim3(br.capacity), dim3(SORT_THREADS), lds_fine, stream,
+                       (const ITEM*)d_tmp, d_digits, (const uint32_t*)d_cstart, d_bcnt, sn, fb, ib, NC, NBP, br.big, br.slice,
+                       (const uint2*)br.list, (const uint32_t*)br.count);
   } else {
-    hipLaunchKernelGGL((msm_part2_hist_kernel<true, ITEM>), dim3(1, SW), dim3(SORT_THREADS), lds_fine, stream,
-                       (const ITEM*)d_tmp, d_digits, (const uint32_t*)d_cstart, d_bcnt, sn, fb, ib, NC, NBP);
+    hipLaunchKernelGGL((msm_part2_hist_kernel<true, ITEM, false>), dim3(1, SW), dim3(SORT_THREADS), lds_fine, stream,
+                       (const ITEM*)d_tmp, d_digits, (const uint32_t*)d_cstart, d_bcnt, sn, fb, ib, NC, NBP, 0xffffffffu, 0u,
+                       (const uint2*)nullptr, (const uint32_t*)nullptr);
   }
   HM_HIP_CHECK(hipGetLastError());
   return HM_OK;
@@ -1034,12 +1132,17 @@ static int launch_sort(const int32_t* d_digits, uint32_t* d_chist, uint32_t* d_c
 template <class ITEM>
 static int launch_sort_scatter(const int32_t* d_digits, const uint32_t* d_cstart, const void* d_tmp, const uint32_t* d_boff,
                                uint32_t* d_sorted, size_t sn, uint32_t SW, uint32_t fb, uint32_t ib, uint32_t cb, uint32_t NC,
-                               uint32_t NBP, hipStream_t stream) {
+                               uint32_t NBP, uint32_t NBT, const BigRegionPlan& br, hipStream_t stream) {
   const size_t lds_fine = (size_t)4 << fb;
   if (cb && fb <= 11) {
     const size_t lds_tiled = ((size_t)3 * (1u << fb) + 32 + 2 * P2_TILE) * 4;
-    hipLaunchKernelGGL(msm_part2_scatter_tiled_kernel<ITEM>, dim3(NC, SW), dim3(SORT_THREADS), lds_tiled, stream,
-                       (const ITEM*)d_tmp, d_cstart, d_boff, d_sorted, fb, ib, NC, NBP);
+    HM_HIP_CHECK(hipMemcpyAsync(br.gcursor, d_boff, (size_t)NBT * 4, hipMemcpyDeviceToDevice, stream));
+    hipLaunchKernelGGL((msm_part2_scatter_tiled_kernel<ITEM, false>), dim3(NC, SW), dim3(SORT_THREADS), lds_tiled, stream,
+                       (const ITEM*)d_tmp, d_cstart, d_boff, d_sorted, fb, ib, NC, NBP, br.big, br.slice, (const uint2*)br.list,
+                       (const uint32_t*)br.count, br.gcursor);
+    hipLaunchKernelGGL((msm_part2_scatter_tiled_kernel<ITEM, true>), dim3(br.capacity), dim3(SORT_THREADS), lds_tiled, stream,
+                       (const ITEM*)d_tmp, d_cstart, d_boff, d_sorted, fb, ib, NC, NBP, br.big, br.slice, (const uint2*)br.list,
+                       (const uint32_t*)br.count, br.gcursor);
   } else if (cb) {
     hipLaunchKernelGGL((msm_part2_scatter_kernel<false, ITEM>), dim3(NC, SW), dim3(SORT_THREADS), lds_fine, stream,
                        (const ITEM*)d_tmp, d_digits, d_cstart, d_boff, d_sorted, sn, fb, ib, NC, NBP);
@@ -1148,6 +1251,20 @@ int msm_enqueue(DeviceCtx& ctx, int slot, const uint32_t* d_scalars_ext, const u
   const size_t o_seg2 = carve(((size_t)SW * (nseg / SUM_SPAN + 1)) * PT_WORDS * 4);
   const size_t o_win = carve((size_t)SW * 32 * 4);
   const size_t o_big = carve(((size_t)NBT + 4) * 4);
+  // cooperative sort of oversized regions (hot buckets): split anything above 4x the mean region
+  BigRegionPlan br;
+  {
+    const uint64_t mean_region = pairs_max / ((uint64_t)NC * SW) + 1;
+    uint64_t slice = (mean_region + P2_TILE - 1) / P2_TILE * P2_TILE;
+    if (slice < 4 * (uint64_t)P2_TILE) slice = 4 * (uint64_t)P2_TILE;
+    br.slice = (uint32_t)slice;
+    br.big = (uint32_t)(4 * slice);
+    br.capacity = (uint32_t)(pairs_max / slice + pairs_max / br.big + 2);
+  }
+  const bool coop_sort = cb != 0 && fb <= 11;
+  const size_t o_brlist = carve(coop_sort ? (size_t)br.capacity * 8 : 8);
+  const size_t o_brcount = carve(16);
+  const size_t o_gcur = carve(coop_sort ? (size_t)NBT * 4 : 4);
   uint8_t* ws = (uint8_t*)sl.ws.ensure(off);
   if (!ws) return hm_fail(HM_ERR_HIP, "msm: workspace allocation failed");
   int32_t* d_digits = (int32_t*)(ws + o_digits);
@@ -1169,14 +1286,22 @@ int msm_enqueue(DeviceCtx& ctx, int slot, const uint32_t* d_scalars_ext, const u
   uint32_t* d_win = (uint32_t*)(ws + o_win);
   uint32_t* d_big_count = (uint32_t*)(ws + o_big);
   uint32_t* d_big_list = d_big_count + 4;
+  br.list = (uint2*)(ws + o_brlist);
+  br.count = (uint32_t*)(ws + o_brcount);
+  br.gcursor = (uint32_t*)(ws + o_gcur);
+  if (!coop_sort) br.big = 0xffffffffu;    // the non-tiled scatter has no cooperative form: nothing is "big"
 
   if (!ctx.msm_attr_set) {   // per device: a process may drive several GPUs
     const int lds_max = 32768 * 4;
-    HM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(msm_part2_hist_kernel<true, uint32_t>),
+    HM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(msm_part2_hist_kernel<true, uint32_t, false>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
-    HM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(msm_part2_hist_kernel<false, uint32_t>),
+    HM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(msm_part2_hist_kernel<false, uint32_t, false>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
-    HM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(msm_part2_hist_kernel<false, uint64_t>),
+    HM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(msm_part2_hist_kernel<false, uint64_t, false>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+    HM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(msm_part2_hist_kernel<false, uint32_t, true>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+    HM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(msm_part2_hist_kernel<false, uint64_t, true>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
     HM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(msm_part2_scatter_kernel<true, uint32_t>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
@@ -1206,11 +1331,12 @@ int msm_enqueue(DeviceCtx& ctx, int slot, const uint32_t* d_scalars_ext, const u
 
   // ---- K2 ------------------------------------------------------------------------------------
   {
+    HM_HIP_CHECK(hipMemsetAsync(d_bcnt, 0, (size_t)NBT * 4, stream));   // the cooperative histogram adds into it
     const int rc = wide_items
                        ? launch_sort<uint64_t>(d_digits, d_chist, d_ctot, d_cstart, d_tmp, d_bcnt, sn, chunk, G, SW, fb, ib, cb,
-                                               NC, NBP, stream)
+                                               NC, NBP, br, stream)
                        : launch_sort<uint32_t>(d_digits, d_chist, d_ctot, d_cstart, d_tmp, d_bcnt, sn, chunk, G, SW, fb, ib, cb,
-                                               NC, NBP, stream);
+                                               NC, NBP, br, stream);
     if (rc != HM_OK) return rc;
   }
   {
@@ -1224,9 +1350,9 @@ int msm_enqueue(DeviceCtx& ctx, int slot, const uint32_t* d_scalars_ext, const u
   }
   {
     const int rc = wide_items ? launch_sort_scatter<uint64_t>(d_digits, d_cstart, d_tmp, d_boff, d_sorted, sn, SW, fb, ib, cb, NC,
-                                                              NBP, stream)
+                                                              NBP, NBT, br, stream)
                               : launch_sort_scatter<uint32_t>(d_digits, d_cstart, d_tmp, d_boff, d_sorted, sn, SW, fb, ib, cb, NC,
-                                                              NBP, stream);
+                                                              NBP, NBT, br, stream);
     if (rc != HM_OK) return rc;
   }
   hipLaunchKernelGGL(msm_task_fill_kernel, dim3((NBT + 255) / 256), dim3(256), 0, stream, (const uint32_t*)d_toff, d_tb,

@@ -315,3 +315,33 @@ def test_config5_size_2_26_fits_one_gpu_and_is_additive():
     finally:
         h.release_bases(hd)
         torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("kind", ["constant", "ones", "flags", "two_values"])
+def test_skewed_columns_use_the_cooperative_sort(cref, kind):
+    """Selector / flag / constant columns send a whole window to one sort region and one bucket: the
+    region is then sorted by many workgroups (work list + global per-bucket cursors) and the bucket is
+    accumulated as many tasks.  Results must still match the oracle."""
+    import torch
+    n = 1 << 19
+    gen = cref.g1_generator()
+    bases = h.g1_fixed_base_mul(rand_fr_gpu(n, 1900), gen)
+    one = cref.fr_to_mont(np.array([[1, 0, 0, 0]], dtype=np.uint64))
+    if kind == "constant":
+        s = rand_fr_gpu(1, 1901).cpu().numpy().view(np.uint64).repeat(n, axis=0)
+    elif kind == "ones":
+        s = one.repeat(n, axis=0)
+    elif kind == "flags":
+        s = np.where((np.arange(n) % 3 == 0)[:, None], one.repeat(n, axis=0), np.zeros((n, 4), dtype=np.uint64))
+    else:
+        two = rand_fr_gpu(2, 1902).cpu().numpy().view(np.uint64)
+        s = two[(np.arange(n) * 2654435761 >> 7) & 1]
+    s = np.ascontiguousarray(s)
+    bh = bases.cpu().numpy().view(np.uint64)
+    exp = cref.g1_to_affine(cref.best_multiexp(s, bh, 8))[0]
+    hd = h.register_bases(bases)
+    try:
+        assert g1_equal(h.best_multiexp(torch.from_numpy(s.view(np.int64)).cuda(), hd), exp)
+        assert h.msm_stats()["tasks"] > 1000
+    finally:
+        h.release_bases(hd)
