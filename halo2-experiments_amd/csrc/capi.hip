@@ -68,10 +68,11 @@ static int register_from_device(DeviceCtx& ctx, const uint32_t* d_ext, size_t n,
   HM_HIP_CHECK(hipMalloc((void**)&e.d_xy, n ? n * 64 * copies : 64));
   HM_HIP_CHECK(hipMalloc((void**)&e.d_inf, n ? n : 1));
   int rc = msm_convert_bases(d_ext, e.d_xy, e.d_inf, n, stream);
-  if (rc != HM_OK) return rc;
-  if (e.pc_c) {
-    rc = msm_precompute(e.d_xy, e.d_inf, n, e.pc_c, e.pc_W, stream);
-    if (rc != HM_OK) return rc;
+  if (rc == HM_OK && e.pc_c) rc = msm_precompute(e.d_xy, e.d_inf, n, e.pc_c, e.pc_W, stream);
+  if (rc != HM_OK) {
+    (void)hipFree(e.d_xy);
+    (void)hipFree(e.d_inf);
+    return rc;
   }
   e.handle = ctx.next_handle++;
   ctx.bases.push_back(e);

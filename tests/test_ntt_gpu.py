@@ -70,7 +70,7 @@ def test_edge_values(cref, pyref):
     assert not z.any()
 
 
-@pytest.mark.parametrize("k", [20, 24])
+@pytest.mark.parametrize("k", [20, 24, 25, 26])
 def test_full_size_properties(cref, pyref, k):
     """At sizes no oracle brute-forces: inverse(forward(x)) * n^-1 == x bit-exactly, linearity, and
     spot checks of single outputs by Horner evaluation X_j = f(omega^j)."""
