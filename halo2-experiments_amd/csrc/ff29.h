@@ -416,6 +416,31 @@ HM_HD Fe<F> fe_canonical(const Fe<F>& a) {
   return cur;
 }
 
+// a: normalised limbs, any value < 2^261  ->  normalised limbs, value < 3*MOD, same residue.
+// Quotient estimate from the top limb (q <= floor(a / MOD), short by at most 2), then a - q*MOD with
+// signed 64-bit carries: ~50 instructions, against ~215 for a Montgomery product by ONE.
+template <class F>
+HM_HD Fe<F> fe_reduce_small(const Fe<F>& a) {
+#ifdef HM_BOUNDS
+  HM_CHECK(a.lb <= MASK29 && a.tb < (1ull << 29), "fe_reduce_small needs normalised limbs and a value < 2^261");
+#endif
+  const uint32_t q = (uint32_t)(((uint64_t)a.l[8] * F::QK) >> 53);   // floor(top / (TOPMOD + 1)), possibly one less
+  Fe<F> r;
+  int64_t carry = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int64_t t = (int64_t)a.l[i] - (int64_t)((uint64_t)q * F::MOD[i]) + carry;
+    r.l[i] = (uint32_t)t & MASK29;
+    carry = t >> 29;
+  }
+  r.l[8] = (uint32_t)((int64_t)a.l[8] - (int64_t)((uint64_t)q * F::MOD[8]) + carry);
+#ifdef HM_BOUNDS
+  set_bounds(r, 3.0, MASK29, top_bound_from_value<F>(3.0));
+  HM_CHECK(r.l[8] <= r.tb, "fe_reduce_small result exceeds 3*MOD");
+#endif
+  return r;
+}
+
 // ---------------------------------------------------------------------------------------------
 // packing: 8 x u32 little-endian (the reference's 4 x u64 limbs) <-> 9 x 29-bit limbs
 // ---------------------------------------------------------------------------------------------

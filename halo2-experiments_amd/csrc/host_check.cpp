@@ -72,6 +72,12 @@ void field_op(int op, const uint64_t* a, const uint64_t* b, uint64_t* o, size_t 
         r = fe_norm(fe_add(fe_mul(s, fe_norm(d)), fe_sqr(x)));
         break;
       }
+      case 5: {  // x + 40*y accumulated lazily (value up to ~82 MOD), then the cheap reduction
+        Fe<F> acc = x;
+        for (int k = 0; k < 40; ++k) acc = fe_norm(fe_add(acc, y));
+        r = fe_reduce_small(acc);
+        break;
+      }
       default: r = x;
     }
     store_ext(o + 4 * i, r);

@@ -133,6 +133,15 @@ __device__ __forceinline__ void ntt_round(uint32_t* lds, const NttTileCtx& cx, u
             x[j] = fe_add(a, b);
             x[j + (1 << t)] = fe_sub<6, 29>(a, b);
           }
+        } else if (m == 0 && q0 == 0) {   // first round, later stage, twiddle omega^0 = 1: no product
+#pragma unroll
+          for (int h = 0; h < (1 << (RB - t - 1)); ++h) {
+            const int j = m + (h << (t + 1));
+            const Fr a = x[j];
+            const Fr tt = fe_norm(x[j + (1 << t)]);       // a lazy stage-0 output, value < 12r
+            x[j] = fe_add(a, tt);
+            x[j + (1 << t)] = fe_sub<13, 29>(a, tt);
+          }
         } else {
           const Fr w = load_tw(stage_tw, (base_lo + ((uint32_t)m << q0)) << (s - 1 - q));
 #pragma unroll
@@ -268,7 +277,9 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(const uint32_t* i
     }
     for (uint32_t e = tid; e < tile_elems; e += NTT_THREADS) {
       const uint32_t c = e & cmask, k = e >> log_c;
-      const Fr y = fe_canonical(fe_mul(lds_load<LOG_TILE>(lds, e), fin));
+      const Fr x = lds_load<LOG_TILE>(lds, e);
+      // with a fused scale the product reduces; without one the cheap quotient-estimate reduction does
+      const Fr y = fe_canonical(pp.has_scale ? fe_mul(x, fin) : fe_reduce_small(x));
       uint32_t w[8];
       fe_pack(w, y);
       const uint64_t g = (dest_lo0 + c) + ((uint64_t)k << pp.log_rows);

@@ -48,6 +48,31 @@ def test_lazy_chain_matches_oracle(hc, cref, golden):
     assert np.array_equal(field_op(hc, 1, 4, a, b), exp)
 
 
+@pytest.mark.parametrize("name,field", [("fq", 0), ("fr", 1)])
+def test_cheap_reduction_of_lazy_sums(hc, cref, golden, name, field):
+    """fe_reduce_small (quotient estimate from the top limb) on sums that were never reduced."""
+    g = golden["field"]
+    a, b = g[f"{name}_a"], g[f"{name}_b"]
+    got = field_op(hc, field, 5, a, b)
+    if field == 1:
+        exp = a
+        for _ in range(40):
+            exp = cref.fr_add(exp, b)
+        assert np.array_equal(got, exp)
+    else:
+        # 41 = x + 40 y through the oracle's multiplication by small constants: compare via fq_mul by 1-limbs
+        forty = np.tile(cref.fq_mul(np.array([[40, 0, 0, 0]], dtype=np.uint64),
+                                    np.array([[0xf32cfc5b538afa89, 0xb5e71911d44501fb, 0x47ab1eff0a417ff6, 0x06d89f71cab8351f]], dtype=np.uint64)), (a.shape[0], 1))
+        # forty = Montgomery form of 40; 40*y = mont_mul(forty, y); the sum needs Fq addition, done in Python ints
+        from oracle import bn256_ref as o
+        inv = pow(o.MONT, -1, o.P)
+        ya = [o.from_limbs(r) * inv % o.P for r in b]
+        xa = [o.from_limbs(r) * inv % o.P for r in a]
+        exp = np.array([o.to_limbs((x + 40 * y) % o.P * o.MONT % o.P) for x, y in zip(xa, ya)], dtype=np.uint64)
+        assert np.array_equal(got, exp)
+        assert forty.shape == a.shape
+
+
 def test_raw_256bit_words_reduce(hc, pyref):
     o = pyref
     raw = np.array([[2**64 - 1] * 4, [0, 0, 0, 2**63], o.to_limbs(o.R), o.to_limbs(o.R - 1), o.to_limbs(2 * o.R + 5)], dtype=np.uint64)
