@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 
 #include <map>
+#include <thread>
+#include <vector>
 
 #include "hm_internal.h"
 
@@ -11,6 +13,8 @@ namespace hm {
 static thread_local std::string g_last_error;
 static std::mutex g_ctx_mu;
 static std::map<int, std::unique_ptr<DeviceCtx>> g_ctx;
+static std::vector<int> g_msm_devices;             // hm_set_msm_devices; empty = the calling thread's device
+static constexpr size_t kMinShardPoints = 1 << 14; // below this many points per device a split only adds latency
 
 int hm_fail(int code, const std::string& what) {
   g_last_error = what;
@@ -296,8 +300,7 @@ int hm_msm_bn256_g1_h(uint64_t handle, size_t offset, const uint64_t* scalars, s
   return jac_to_affine_out(jac, is_id, out_xy, out_is_identity);
 }
 
-static int msm_host(const uint64_t* scalars, const uint64_t* bases, size_t n, uint64_t jac[12], int* is_id) {
-  if (n && (!scalars || !bases)) return hm_fail(HM_ERR_BAD_ARG, "hm_msm_bn256_g1: null argument");
+static int msm_host_one(const uint64_t* scalars, const uint64_t* bases, size_t n, uint64_t jac[12], int* is_id) {
   DeviceCtx* ctx = ctx_for_current_device();
   if (!ctx) return HM_ERR_NO_DEVICE;
   std::lock_guard<std::mutex> lk(ctx->mu);
@@ -332,6 +335,65 @@ static int msm_host(const uint64_t* scalars, const uint64_t* bases, size_t n, ui
   if (!d_s) return hm_fail(HM_ERR_HIP, "hm_msm_bn256_g1: staging allocation failed");
   HM_HIP_CHECK(hipMemcpy(d_s, scalars, n * 32, hipMemcpyHostToDevice));
   return msm_run(*ctx, (const uint32_t*)d_s, d_xy, d_inf, n, 0, jac, is_id, nullptr);
+}
+
+// Single-process multi-GPU form (hm_set_msm_devices): contiguous index ranges, one host thread per
+// device, each running the ordinary one-device path on its slice (so the per-device base cache holds
+// that device's slice of the SRS), partial sums folded on the host.  No inter-GPU traffic: the only
+// thing that leaves a device is a 96-byte point.
+static int msm_host(const uint64_t* scalars, const uint64_t* bases, size_t n, uint64_t jac[12], int* is_id) {
+  if (n && (!scalars || !bases)) return hm_fail(HM_ERR_BAD_ARG, "hm_msm_bn256_g1: null argument");
+  std::vector<int> devs;
+  {
+    std::lock_guard<std::mutex> lk(g_ctx_mu);
+    devs = g_msm_devices;
+  }
+  const size_t parts = devs.size();
+  if (parts < 2 || n < parts * kMinShardPoints) {
+    if (parts >= 2) {   // too small to be worth splitting: the first listed device takes it whole
+      int prev = 0;
+      HM_HIP_CHECK(hipGetDevice(&prev));
+      HM_HIP_CHECK(hipSetDevice(devs[0]));
+      const int rc = msm_host_one(scalars, bases, n, jac, is_id);
+      (void)hipSetDevice(prev);
+      return rc;
+    }
+    return msm_host_one(scalars, bases, n, jac, is_id);
+  }
+  std::vector<uint64_t> partial(parts * 12, 0);
+  std::vector<int> rcs(parts, HM_OK);
+  std::vector<std::string> errs(parts);
+  std::vector<std::thread> workers;
+  workers.reserve(parts);
+  for (size_t r = 0; r < parts; ++r) {
+    const size_t lo = n * r / parts, hi = n * (r + 1) / parts;
+    workers.emplace_back([&, r, lo, hi] {
+      int id = 0;
+      if (hipSetDevice(devs[r]) != hipSuccess) {
+        rcs[r] = HM_ERR_HIP;
+        errs[r] = "hm_msm_bn256_g1: hipSetDevice failed for device " + std::to_string(devs[r]);
+        return;
+      }
+      rcs[r] = msm_host_one(scalars + lo * 4, bases + lo * 8, hi - lo, &partial[r * 12], &id);
+      if (rcs[r] != HM_OK) errs[r] = g_last_error;   // thread-local: carry it back to the caller's thread
+    });
+  }
+  for (auto& w : workers) w.join();
+  for (size_t r = 0; r < parts; ++r)
+    if (rcs[r] != HM_OK) return hm_fail(rcs[r], errs[r]);
+  host_sum_points(partial.data(), parts, jac, is_id);
+  return HM_OK;
+}
+
+int hm_set_msm_devices(const int* devices, int count) {
+  if (count < 0 || count > 64 || (count && !devices)) return hm_fail(HM_ERR_BAD_ARG, "hm_set_msm_devices: bad device list");
+  const int visible = hm_device_count();
+  if (count && visible <= 0) return hm_fail(HM_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU fallback)");
+  for (int i = 0; i < count; ++i)
+    if (devices[i] < 0 || devices[i] >= visible) return hm_fail(HM_ERR_BAD_ARG, "hm_set_msm_devices: device index out of range");
+  std::lock_guard<std::mutex> lk(g_ctx_mu);
+  g_msm_devices.assign(devices, devices + count);
+  return HM_OK;
 }
 
 int hm_msm_bn256_g1(const uint64_t* scalars, const uint64_t* bases, size_t n, uint64_t out_xy[8], int* out_is_identity) {

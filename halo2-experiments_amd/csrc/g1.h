@@ -184,4 +184,114 @@ HM_HD G1Jac g1_add(const G1Jac& p, const G1Jac& q) {
   return g1_add_nz(p, q);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Extended Jacobian ("XYZZ") accumulator for the bucket chains: x = X/ZZ, y = Y/ZZZ, ZZ^3 = ZZZ^2.
+// The mixed addition (madd-2008-s) needs no Z1^2 / Z1^3 recomputation, so it is 6M + 2S + one
+// fused double product -- one square (~170 instructions) less than the Jacobian form -- at the
+// price of a fourth stored coordinate.  Class bounds: X < HM_XYZZ_XB*p, Y < HM_XYZZ_YB*p
+// (normalised limbs), ZZ and ZZZ product outputs (< 2p).
+// ---------------------------------------------------------------------------------------------
+struct G1Xyzz {
+  Fq x, y, zz, zzz;
+  bool inf;
+};
+#define HM_XYZZ_XB 8.0
+#define HM_XYZZ_YB 3.0
+
+#ifdef HM_BOUNDS
+inline void g1_check_class(const G1Xyzz& p, const char* what) {
+  HM_CHECK(p.x.lb <= MASK29 && p.y.lb <= MASK29 && p.zz.lb <= MASK29 && p.zzz.lb <= MASK29, what);
+  HM_CHECK(p.x.vb <= HM_XYZZ_XB && p.y.vb <= HM_XYZZ_YB && p.zz.vb <= 2.0 && p.zzz.vb <= 2.0, what);
+}
+#endif
+
+HM_HD G1Xyzz g1x_identity() {
+  G1Xyzz r;
+  r.x = fe_zero<FqParams>();
+  r.y = fe_zero<FqParams>();
+  r.zz = fe_zero<FqParams>();
+  r.zzz = fe_zero<FqParams>();
+  r.inf = true;
+  return r;
+}
+
+HM_HD G1Xyzz g1x_from_affine(const G1Aff& p) {
+  G1Xyzz r;
+  r.x = p.x;
+  r.y = p.y;
+  r.zz = fe_one<FqParams>();
+  r.zzz = fe_one<FqParams>();
+  r.inf = false;
+  return r;
+}
+
+// (X, Y, ZZ, ZZZ) -> Jacobian (X*ZZ^2, Y*ZZZ^2, ZZZ): every output a product, so inside the Jacobian class
+HM_HD G1Jac g1x_to_jac(const G1Xyzz& p) {
+  G1Jac r;
+  if (p.inf) return g1_identity();
+  HM_G1_CHECK(p, "g1x_to_jac input outside class");
+  r.x = fe_mul(p.x, fe_sqr(p.zz));
+  r.y = fe_mul(p.y, fe_sqr(p.zzz));
+  r.z = p.zzz;
+  r.inf = false;
+  return r;
+}
+
+HM_HD G1Xyzz g1x_from_jac(const G1Jac& p) {
+  G1Xyzz r;
+  if (p.inf) return g1x_identity();
+  HM_G1_CHECK(p, "g1x_from_jac input outside class");
+  r.zz = fe_sqr(p.z);
+  r.zzz = fe_mul(p.z, r.zz);
+  // X, Y: a product by ONE keeps the residue and brings a Jacobian-class value (X < 12p, Y < 5p)
+  // under the tighter XYZZ bounds (rare path: only after an in-bucket doubling)
+  r.x = fe_mul(p.x, fe_one<FqParams>());
+  r.y = fe_mul(p.y, fe_one<FqParams>());
+  r.inf = false;
+  return r;
+}
+
+// acc += (neg ? -q : q) by the ordinary law, for acc != identity.  Returns false and leaves acc
+// untouched in the exceptional case X1 = U2 (a repeated base in one bucket, or a base and its
+// negative): the caller finishes such a chain with the general Jacobian law.  Keeping that case OUT
+// of this function keeps the hot loop free of its code and of the register merge of its result.
+HM_HD bool g1x_madd_fast(G1Xyzz& acc, const G1Aff& q, bool neg) {
+  HM_G1_CHECK(acc, "g1x_madd_fast input outside class");
+  const Fq u2 = fe_mul(q.x, acc.zz);
+  const Fq pp0 = fe_norm(fe_sub<9, 29>(u2, acc.x));          // P = U2 - X1
+  const Fq pp = fe_sqr(pp0);                                  // PP
+  if (fe_is_zero_mod(pp)) return false;
+  const Fq s2p = fe_mul(q.y, acc.zzz);
+  Fq s2;                                                      // +-S2, limbs <= 2^30
+  {
+    const Fq s2n = fe_sub<3, 29>(fe_zero<FqParams>(), s2p);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) s2.l[i] = neg ? s2n.l[i] : s2p.l[i];
+#ifdef HM_BOUNDS
+    s2.vb = s2n.vb; s2.lb = s2n.lb; s2.tb = s2n.tb;
+#endif
+  }
+  const Fq r = fe_norm(fe_sub<4, 29>(s2, acc.y));             // R = +-S2 - Y1
+  const Fq ppp = fe_mul(pp0, pp);
+  const Fq qq = fe_mul(acc.x, pp);                            // Q = X1 * PP
+  const Fq rr = fe_sqr(r);
+  const Fq t2 = fe_add(ppp, fe_dbl(qq));                      // PPP + 2Q  (limbs < 3*2^29)
+  const Fq x3 = fe_norm(fe_sub<6, 31>(rr, t2));               // R^2 - PPP - 2Q
+  const Fq vx = fe_norm(fe_sub<9, 29>(qq, x3));               // Q - X3
+  const Fq ny = fe_sub<4, 29>(fe_zero<FqParams>(), acc.y);    // -Y1 (limbs < 2^30)
+  acc.y = fe_mul2(r, vx, ny, ppp);                            // R (Q - X3) - Y1 PPP
+  acc.x = x3;
+  acc.zz = fe_mul(acc.zz, pp);
+  acc.zzz = fe_mul(acc.zzz, ppp);
+  return true;
+}
+
+// general form (host checks, cold paths): identity operands and the exceptional cases included
+HM_HD G1Xyzz g1x_madd(const G1Xyzz& p, const G1Aff& q, bool neg = false) {
+  if (p.inf) return g1x_from_affine(neg ? g1_neg_affine(q) : q);
+  G1Xyzz r = p;
+  if (g1x_madd_fast(r, q, neg)) return r;
+  return g1x_from_jac(g1_madd_nz(g1x_to_jac(p), q, neg));
+}
+
 }  // namespace hm

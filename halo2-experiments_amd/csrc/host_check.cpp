@@ -131,6 +131,44 @@ void hc_g1_chain(const uint64_t* q_aff, int k, int dbl, uint64_t* out, int* out_
   store_jac(out, out_inf, acc);
 }
 
+// the bucket accumulator's XYZZ chain: k mixed additions of q (alternating sign pattern given by the
+// bits of `signs`), optionally starting from a doubling-triggering repeat, converted to Jacobian
+void hc_g1x_chain(const uint64_t* q_affs, int k, uint64_t signs, uint64_t* out, int* out_inf) {
+  G1Xyzz acc = g1x_identity();
+  for (int i = 0; i < k; ++i) {
+    G1Aff q;
+    q.x = load_ext<FqParams>(q_affs + 8 * i);
+    q.y = load_ext<FqParams>(q_affs + 8 * i + 4);
+    acc = g1x_madd(acc, q, ((signs >> (i & 63)) & 1) != 0);
+  }
+  store_jac(out, out_inf, g1x_to_jac(acc));
+}
+
+// XYZZ class closure: madd with the accumulator DECLARED at its class maxima must land inside the
+// class again, and its conversion to Jacobian inside the Jacobian class.
+int hc_xyzz_bounds_closure(const uint64_t* pj, const uint64_t* q_aff, double* report) {
+  G1Jac pjac = load_jac(pj, 0);
+  G1Xyzz p = g1x_from_jac(pjac);
+  force_bounds(p.x, HM_XYZZ_XB);
+  force_bounds(p.y, HM_XYZZ_YB);
+  force_bounds(p.zz, 2.0);
+  force_bounds(p.zzz, 2.0);
+  G1Aff q;
+  q.x = load_ext<FqParams>(q_aff);
+  q.y = load_ext<FqParams>(q_aff + 4);
+  force_bounds(q.x, 2.0);
+  force_bounds(q.y, 2.0);
+  G1Xyzz r = p;
+  if (!g1x_madd_fast(r, q, true)) return 0;
+  const G1Jac j = g1x_to_jac(p);
+  report[0] = r.x.vb; report[1] = r.y.vb; report[2] = r.zz.vb; report[3] = r.zzz.vb;
+  report[4] = j.x.vb; report[5] = j.y.vb; report[6] = j.z.vb;
+  int ok = 1;
+  if (r.x.vb > HM_XYZZ_XB || r.y.vb > HM_XYZZ_YB || r.zz.vb > 2.0 || r.zzz.vb > 2.0) ok = 0;
+  if (j.x.vb > HM_G1_XB || j.y.vb > HM_G1_YB || j.z.vb > HM_G1_ZB) ok = 0;
+  return ok;
+}
+
 // Run every curve formula with inputs DECLARED at the class maxima; any precondition violation
 // aborts.  Writes the resulting output bounds (x.vb, y.vb, z.vb per formula) for the report.
 int hc_bounds_closure(const uint64_t* pj, const uint64_t* qj, const uint64_t* q_aff, double* report) {

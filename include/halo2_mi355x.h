@@ -96,6 +96,16 @@ int hm_msm_bn256_g1_dev(uint64_t handle, size_t offset, const void* d_scalars, s
 int hm_msm_submit_dev(uint64_t handle, size_t offset, const void* d_scalars, size_t n, void* stream, uint64_t* out_ticket);
 int hm_msm_wait(uint64_t ticket, uint64_t out_xyz[12]);
 
+/* Single-process multi-GPU best_multiexp (the form a Rust prover, one process for the whole node,
+ * binds): after hm_set_msm_devices(devices, count >= 2) every hm_msm_bn256_g1 /
+ * hm_msm_bn256_g1_jacobian call splits [0, n) into `count` contiguous index ranges, runs one range per
+ * listed device from its own host thread (each device caches its slice of the SRS exactly as the
+ * one-device path does) and folds the 96-byte partial results on the host -- the data path has no
+ * inter-GPU exchange.  Inputs below 2^14 points per device go whole to devices[0].  count == 0
+ * restores the default (the calling thread's current device).  Replaces the same call sites as
+ * hm_msm_bn256_g1 (halo2_proofs::arithmetic::best_multiexp). */
+int hm_set_msm_devices(const int* devices, int count);
+
 /* Sum of `count` G1 values (12 x u64 each, z = 0 for the identity), normalised to (x, y, 1): the
  * fold of per-GPU partial results of a sharded best_multiexp after the RCCL all-gather.  Pure host
  * arithmetic on a handful of points (the exchange is ~96 B per rank); needs no device. */

@@ -41,6 +41,9 @@ def test_argument_errors_are_reported_not_thrown():
     assert lib.hm_msm_set_window(99) == -1
     assert lib.hm_msm_set_window(0) == 0
     assert lib.hm_g1_sum(None, 0, None) == -1
+    assert lib.hm_set_msm_devices(None, 2) == -1
+    assert lib.hm_set_msm_devices(None, -1) == -1
+    assert lib.hm_set_msm_devices(None, 0) == 0
 
 
 def test_no_device_means_error_not_fallback():

@@ -124,3 +124,35 @@ def test_bound_closure_proof(hc, pyref):
     ok = hc.hc_bounds_closure(p(jac_words(o, pts[0], 5)), p(jac_words(o, pts[1], 7)), p(o.g1_affine_array([pts[2]])[0]), rep)
     assert ok == 1, list(rep)
     assert max(rep[0], rep[3], rep[6]) <= 12.0 and max(rep[1], rep[4], rep[7]) <= 5.0 and max(rep[2], rep[5], rep[8]) <= 2.0
+
+
+def test_xyzz_accumulator_chain_and_closure(hc, pyref):
+    """The bucket accumulator's extended-Jacobian mixed addition: random chains with signs, the
+    in-bucket doubling (same point twice), cancellation (P then -P) and restart after the identity --
+    against the oracle's group law; then the class-closure proof at the declared maxima."""
+    o = pyref
+    rng = np.random.default_rng(5)
+    pts = [o.g1_mul(int(k), o.G1_GEN) for k in rng.integers(1, 2**62, 12)]
+    out = np.zeros(12, dtype=np.uint64)
+    oi = ctypes.c_int(0)
+
+    def run(seq, signs):
+        arr = np.ascontiguousarray(o.g1_affine_array(seq))
+        hc.hc_g1x_chain(p(arr), len(seq), ctypes.c_uint64(signs), p(out), ctypes.byref(oi))
+        exp = None
+        for i, q in enumerate(seq):
+            exp = o.g1_add(exp, o.g1_neg(q) if (signs >> i) & 1 else q)
+        got = None if oi.value else o.g1_jacobian_from_array(out)[0]
+        assert got == exp, (len(seq), signs)
+
+    run(pts, 0)
+    run(pts, 0b101101001011)
+    run([pts[0], pts[0], pts[1]], 0)                    # doubling inside the chain
+    run([pts[0], pts[1], pts[0], pts[1]], 0b1100)       # (a + b) - a - b: passes through a, then the identity
+    run([pts[2], pts[2], pts[3], pts[3]], 0b1010)       # a - a = identity, then restart from it
+    run([pts[4]] * 9, 0)                                # 9a: doubling first, ordinary additions after
+    run([pts[5]], 1)
+    rep = (ctypes.c_double * 7)()
+    a, b = o.g1_mul(77, o.G1_GEN), o.g1_mul(91, o.G1_GEN)
+    ok = hc.hc_xyzz_bounds_closure(p(jac_words(o, a, 9)), p(o.g1_affine_array([b])[0]), rep)
+    assert ok == 1, list(rep)

@@ -345,3 +345,63 @@ def test_skewed_columns_use_the_cooperative_sort(cref, kind):
         assert h.msm_stats()["tasks"] > 1000
     finally:
         h.release_bases(hd)
+
+
+def test_single_process_multi_device_split(cref, pyref, golden):
+    """hm_set_msm_devices: the one-process, many-GPU form of best_multiexp.  With one card on the box the
+    list names device 0 three times -- same splitting, threads, per-slice base cache and host fold as on
+    a node with three cards (the slices then simply queue on one device)."""
+    lib = _lib.load()
+    o = pyref
+    n = 3 * (1 << 14) + 7                                   # just above the split threshold, ragged thirds
+    gen = cref.g1_generator()
+    bases = h.g1_fixed_base_mul(rand_fr_gpu(n, 31), gen).cpu().numpy().view(np.uint64).copy()
+    s = rand_fr_gpu(n, 32).cpu().numpy().view(np.uint64).copy()
+    single = h.best_multiexp(s, bases)[:8]
+    assert g1_equal(np.concatenate([single, np.ones(4, dtype=np.uint64)]), cref.g1_to_affine(cref.best_multiexp(s, bases, 8))[0])
+    devs = (ctypes.c_int * 3)(0, 0, 0)
+    _lib.check(lib.hm_set_msm_devices(devs, 3))
+    try:
+        assert g1_equal(h.best_multiexp(s, bases), single)
+        assert g1_equal(h.best_multiexp(s, bases), single)              # second call: per-slice caches in play
+        g = golden["msm"]                                               # small input: goes whole to devices[0]
+        assert g1_equal(h.best_multiexp(g["n1024_uniform_s"], g["n1024_uniform_b"]), g["n1024_uniform_r"])
+        s[: n // 3] = 0                                                 # first slice sums to the identity
+        exp = cref.g1_to_affine(cref.best_multiexp(s, bases, 8))[0]
+        assert g1_equal(h.best_multiexp(s, bases), exp)
+        bad = (ctypes.c_int * 2)(0, 99)
+        assert lib.hm_set_msm_devices(bad, 2) == -1                     # out of range: list unchanged
+        assert g1_equal(h.best_multiexp(s, bases), exp)
+    finally:
+        _lib.check(lib.hm_set_msm_devices(None, 0))
+    assert g1_equal(h.best_multiexp(s, bases), exp)
+
+
+@pytest.mark.parametrize("pattern", ["P,P,-P,P", "P,-P,P,-P", "P,P,P,P,P,-P,-P,-P"])
+def test_repeated_and_opposite_bases_inside_bucket_chains(cref, pyref, pattern):
+    """The bucket chain's fast law has no equal-x case: a lane that meets one (same point again =>
+    doubling, its negative => identity, then a restart) finishes its chain with the general law.
+    Runs of one point and its negative under one scalar land next to each other in every bucket."""
+    o = pyref
+    signs = [1 if t == "P" else -1 for t in pattern.split(",")]
+    m, groups = len(signs), 1 << 12
+    n = m * groups
+    gen = cref.g1_generator()
+    pts = h.g1_fixed_base_mul(rand_fr_gpu(groups, 77), gen).cpu().numpy().view(np.uint64).copy()
+    neg = pts.copy()
+    P = o.P
+    for i in range(groups):
+        y = o.from_limbs(pts[i, 4:])
+        neg[i, 4:] = o.to_limbs((P - y) % P)
+    bases = np.empty((n, 8), dtype=np.uint64)
+    for j, sg in enumerate(signs):
+        bases[j::m] = pts if sg > 0 else neg
+    sc = rand_fr_gpu(groups, 78).cpu().numpy().view(np.uint64)
+    s = np.repeat(sc, m, axis=0)
+    exp = cref.g1_to_affine(cref.best_multiexp(s, bases, 8))[0]
+    assert g1_equal(h.best_multiexp(s, bases), exp)
+    hd = h.register_bases(bases, precompute=True)
+    try:
+        assert g1_equal(h.best_multiexp(s, hd), exp)
+    finally:
+        h.release_bases(hd)
