@@ -312,7 +312,7 @@ def main():
                          "traffic_note": "raw FETCH_SIZE+WRITE_SIZE (64-byte gathers: gfx950 x2 read correction not calibrated for this "
                                          "shape); every base is gathered once per window (W = 16), inherent to bucketed Pippenger",
                          "kernel": "msm_accumulate_kernel", "kernel_ms": acc,
-                         "note": "integer-VALU bound (SURVEY.md §8d): ~2.7e8 mixed additions x ~2.9e3 32-bit ops per launch"},
+                         "note": "integer-VALU bound (SURVEY.md §8d): ~2.5e8 mixed additions x ~2.35e3 32-bit ops per launch"},
             "msm_phase_ms": {"sort": float(np.mean(sort_ms)), "accumulate_kernel": acc, "device_total": float(np.mean(tot_ms))},
             "result_is_identity": bool(not result[8:].any()),
         }

@@ -99,6 +99,17 @@ __global__ void msm_convert_bases_kernel(const uint32_t* __restrict__ ext, uint3
 // ---------------------------------------------------------------------------------------------
 // K0: signed window digits.  digits[w*n + i] in [-2^(c-1)+1, 2^(c-1)], 0 = skip.
 // ---------------------------------------------------------------------------------------------
+// Tasks are cut to at most L pairs.  The host picks L for the worst case (every digit non-zero); the
+// first sort level counts the pairs that really exist, and when they are far fewer (zero or repeated
+// digits: flag and selector-like columns) every later kernel derives the same shorter L from that
+// count, so that K3 still gets >= TARGET_TASKS chains to fill the chip with.
+constexpr uint32_t TARGET_TASKS = 327680;   // 256 CUs x 4 SIMDs x 5 waves x 64 lanes
+__device__ __forceinline__ uint32_t effective_task_len(const uint32_t* __restrict__ pairs, uint32_t L_host) {
+  const uint32_t by_fill = pairs[0] / TARGET_TASKS;
+  const uint32_t L = L_host < by_fill ? L_host : by_fill;
+  return L < 16u ? 16u : L;
+}
+
 __global__ void msm_digits_kernel(const uint32_t* __restrict__ scalars, const uint8_t* __restrict__ inf,
                                   int32_t* __restrict__ digits, size_t n, uint32_t c, uint32_t W) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -627,8 +638,9 @@ __device__ __forceinline__ void block_scan_pair(uint32_t& p, uint32_t& t, uint32
 
 __global__ __launch_bounds__(SCAN_THREADS) void msm_scan_partial_kernel(const uint32_t* __restrict__ bcnt,
                                                                         uint32_t* __restrict__ blocksums, uint32_t NBT,
-                                                                        uint32_t L) {
+                                                                        const uint32_t* __restrict__ pairs, uint32_t L_host) {
   __shared__ uint32_t s_p[SCAN_THREADS], s_t[SCAN_THREADS];
+  const uint32_t L = effective_task_len(pairs, L_host);
   const uint32_t base = blockIdx.x * SCAN_BLOCK + threadIdx.x * SCAN_ITEMS;
   uint32_t sp = 0, st = 0;
 #pragma unroll
@@ -672,8 +684,9 @@ __global__ __launch_bounds__(SCAN_THREADS) void msm_scan_final_kernel(const uint
                                                                       const uint32_t* __restrict__ blocksums,
                                                                       uint32_t* __restrict__ boff, uint32_t* __restrict__ toff,
                                                                       const uint32_t* __restrict__ totals, uint32_t NBT,
-                                                                      uint32_t L) {
+                                                                      const uint32_t* __restrict__ pairs, uint32_t L_host) {
   __shared__ uint32_t s_p[SCAN_THREADS], s_t[SCAN_THREADS];
+  const uint32_t L = effective_task_len(pairs, L_host);
   const uint32_t base = blockIdx.x * SCAN_BLOCK + threadIdx.x * SCAN_ITEMS;
   uint32_t c[SCAN_ITEMS];
   uint32_t sp = 0, st = 0;
@@ -698,6 +711,18 @@ __global__ __launch_bounds__(SCAN_THREADS) void msm_scan_final_kernel(const uint
   if (blockIdx.x == 0 && threadIdx.x == 0) toff[NBT] = totals[1];
 }
 
+// bucket order (small inputs): task t runs in slot t
+__global__ void msm_task_fill_kernel(const uint32_t* __restrict__ toff, uint32_t* __restrict__ task_bucket,
+                                     uint32_t* __restrict__ task_order, uint32_t NBT) {
+  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= NBT) return;
+  const uint32_t lo = toff[b], hi = toff[b + 1];
+  for (uint32_t t = lo; t < hi; ++t) {
+    task_bucket[t] = b;
+    task_order[t] = t;
+  }
+}
+
 // Task list in order of decreasing chain length.  The 64 lanes of a K3 wave run in lockstep until the
 // longest of their chains ends, so a wave of tasks taken in bucket order costs max-of-64 bucket sizes
 // (for uniform scalars: mean + ~2.4 sigma, 12 % of the lane-cycles idle).  A counting sort of the tasks
@@ -707,15 +732,18 @@ __global__ __launch_bounds__(SCAN_THREADS) void msm_scan_final_kernel(const uint
 constexpr uint32_t TASK_KEYS = 1024;
 constexpr int ORDER_THREADS = 1024;   // == TASK_KEYS: one LDS counter per lane
 constexpr int ORDER_ITEMS = 4;        // buckets per lane
+constexpr uint32_t ORDER_HOT = 32;    // hot buckets a workgroup fills cooperatively (more fall back to their lane)
 
 __device__ __forceinline__ uint32_t task_key(uint32_t len, uint32_t L) {   // len in [1, L]; key 0 = longest
   const uint32_t k = L < TASK_KEYS ? len : (uint32_t)(((uint64_t)len * (TASK_KEYS - 1)) / L);
   return (TASK_KEYS - 1) - k;
 }
 
-__global__ __launch_bounds__(ORDER_THREADS) void msm_task_hist_kernel(const uint32_t* __restrict__ bcnt, uint32_t NBT, uint32_t L,
+__global__ __launch_bounds__(ORDER_THREADS) void msm_task_hist_kernel(const uint32_t* __restrict__ bcnt, uint32_t NBT,
+                                                                      const uint32_t* __restrict__ pairs, uint32_t L_host,
                                                                       uint32_t* __restrict__ khist) {
   __shared__ uint32_t h[TASK_KEYS];
+  const uint32_t L = effective_task_len(pairs, L_host);
   h[threadIdx.x] = 0;
   __syncthreads();
 #pragma unroll
@@ -748,11 +776,13 @@ __global__ __launch_bounds__(ORDER_THREADS) void msm_task_keyscan_kernel(const u
 }
 
 __global__ __launch_bounds__(ORDER_THREADS) void msm_task_order_kernel(const uint32_t* __restrict__ bcnt,
-                                                                       const uint32_t* __restrict__ toff, uint32_t NBT, uint32_t L,
+                                                                       const uint32_t* __restrict__ toff, uint32_t NBT,
+                                                                       const uint32_t* __restrict__ pairs, uint32_t L_host,
                                                                        uint32_t* __restrict__ kcursor,
                                                                        uint32_t* __restrict__ task_bucket,
                                                                        uint32_t* __restrict__ task_order) {
   __shared__ uint32_t h[TASK_KEYS], base[TASK_KEYS];
+  const uint32_t L = effective_task_len(pairs, L_host);
   h[threadIdx.x] = 0;
   __syncthreads();
   uint32_t cnt[ORDER_ITEMS];
@@ -771,6 +801,10 @@ __global__ __launch_bounds__(ORDER_THREADS) void msm_task_order_kernel(const uin
     h[threadIdx.x] = 0;
   }
   __syncthreads();
+  // a bucket cut into many full-length tasks (a hot bucket) is written by the whole workgroup
+  __shared__ uint32_t hot_n, hot[ORDER_HOT][4];
+  if (threadIdx.x == 0) hot_n = 0;
+  __syncthreads();
 #pragma unroll
   for (int k = 0; k < ORDER_ITEMS; ++k) {
     const uint32_t b = (blockIdx.x * ORDER_ITEMS + k) * ORDER_THREADS + threadIdx.x;
@@ -779,15 +813,29 @@ __global__ __launch_bounds__(ORDER_THREADS) void msm_task_order_kernel(const uin
     const uint32_t t0 = toff[b];
     if (full) {
       const uint32_t key = task_key(L, L), at = base[key] + atomicAdd(&h[key], full);
-      for (uint32_t i = 0; i < full; ++i) {
-        task_bucket[t0 + i] = b;
-        task_order[at + i] = t0 + i;
+      const uint32_t slot = full > 64 ? atomicAdd(&hot_n, 1u) : ORDER_HOT;
+      if (slot < ORDER_HOT) {
+        hot[slot][0] = b; hot[slot][1] = t0; hot[slot][2] = full; hot[slot][3] = at;
+      } else {
+        for (uint32_t i = 0; i < full; ++i) {
+          task_bucket[t0 + i] = b;
+          task_order[at + i] = t0 + i;
+        }
       }
     }
     if (rem) {
       const uint32_t key = task_key(rem, L);
       task_bucket[t0 + full] = b;
       task_order[base[key] + atomicAdd(&h[key], 1u)] = t0 + full;
+    }
+  }
+  __syncthreads();
+  const uint32_t nh = hot_n < ORDER_HOT ? hot_n : ORDER_HOT;
+  for (uint32_t e = 0; e < nh; ++e) {
+    const uint32_t b = hot[e][0], t0 = hot[e][1], full = hot[e][2], at = hot[e][3];
+    for (uint32_t i = threadIdx.x; i < full; i += ORDER_THREADS) {
+      task_bucket[t0 + i] = b;
+      task_order[at + i] = t0 + i;
     }
   }
 }
@@ -819,8 +867,10 @@ __global__ __launch_bounds__(ACC_THREADS) void msm_accumulate_kernel(const uint3
                                                                      const uint32_t* __restrict__ toff,
                                                                      const uint32_t* __restrict__ xy,
                                                                      uint32_t* __restrict__ partial,
-                                                                     const uint32_t* __restrict__ totals, uint32_t L) {
+                                                                     const uint32_t* __restrict__ totals,
+                                                                     const uint32_t* __restrict__ pairs, uint32_t L_host) {
   __shared__ uint4 stage[4][ACC_THREADS];
+  const uint32_t L = effective_task_len(pairs, L_host);
   const uint32_t lane = threadIdx.x;
   const uint32_t slot = blockIdx.x * ACC_THREADS + lane;
   const uint32_t T = totals[1];   // task count from the scan: the grid is sized by its host-side upper bound
@@ -901,16 +951,23 @@ __device__ __forceinline__ G1Jac block_sum_points(uint32_t* tree, G1Jac acc) {
 // summed by one lane; longer ones (hot buckets that K3 split into many tasks) are queued for
 // the workgroup-per-bucket kernel below so that no single lane walks a long chain.
 constexpr uint32_t FINALIZE_SERIAL = 8;
+constexpr uint32_t FINALIZE_SLICE = 2048;   // partials one workgroup sums in the first level of a very hot bucket
 __global__ __launch_bounds__(ACC_THREADS) void msm_bucket_finalize_kernel(const uint32_t* __restrict__ partial,
                                                                           const uint32_t* __restrict__ toff,
                                                                           uint32_t* __restrict__ bucket, uint32_t NBT,
                                                                           uint32_t* __restrict__ big_count,
-                                                                          uint32_t* __restrict__ big_list) {
+                                                                          uint32_t* __restrict__ big_list,
+                                                                          uint2* __restrict__ slice_list) {
   const uint32_t b = blockIdx.x * ACC_THREADS + threadIdx.x;
   if (b >= NBT) return;
   const uint32_t lo = toff[b], hi = toff[b + 1];
   if (hi - lo > FINALIZE_SERIAL) {
     big_list[atomicAdd(big_count, 1u)] = b;
+    if (hi - lo > FINALIZE_SLICE) {   // very hot: its partials are first summed slice by slice, many workgroups
+      const uint32_t nsl = (hi - lo + FINALIZE_SLICE - 1) / FINALIZE_SLICE;
+      const uint32_t at = atomicAdd(big_count + 1, nsl);
+      for (uint32_t k = 0; k < nsl; ++k) slice_list[at + k] = make_uint2(b, k);
+    }
     return;
   }
   G1Jac acc = g1_identity();
@@ -918,6 +975,27 @@ __global__ __launch_bounds__(ACC_THREADS) void msm_bucket_finalize_kernel(const 
   store_jac(bucket + (size_t)b * PT_WORDS, acc);
 }
 
+// first level for very hot buckets: slice k of bucket b = partials [lo + k*SLICE, +SLICE) -> their sum,
+// written over the slice's first partial (each slice belongs to one workgroup)
+__global__ __launch_bounds__(WIN_THREADS) void msm_bucket_finalize_slices_kernel(uint32_t* __restrict__ partial,
+                                                                                 const uint32_t* __restrict__ toff,
+                                                                                 const uint32_t* __restrict__ big_count,
+                                                                                 const uint2* __restrict__ slice_list) {
+  __shared__ uint32_t tree[WIN_THREADS * PT_WORDS];
+  const uint32_t count = big_count[1];
+  for (uint32_t item = blockIdx.x; item < count; item += gridDim.x) {
+    const uint2 e = slice_list[item];
+    const uint32_t lo = toff[e.x] + e.y * FINALIZE_SLICE;
+    const uint32_t end = toff[e.x + 1], hi = lo + FINALIZE_SLICE < end ? lo + FINALIZE_SLICE : end;
+    G1Jac acc = g1_identity();
+    for (uint32_t t = lo + threadIdx.x; t < hi; t += WIN_THREADS) acc = g1_add(acc, load_jac(partial + (size_t)t * PT_WORDS));
+    const G1Jac r = block_sum_points(tree, acc);   // ends with a barrier: every read of the slice is done
+    if (threadIdx.x == 0) store_jac(partial + (size_t)lo * PT_WORDS, r);
+    __syncthreads();
+  }
+}
+
+// one workgroup per hot bucket: all of its partials, or the slice sums the first level left behind
 __global__ __launch_bounds__(WIN_THREADS) void msm_bucket_finalize_big_kernel(const uint32_t* __restrict__ partial,
                                                                               const uint32_t* __restrict__ toff,
                                                                               uint32_t* __restrict__ bucket,
@@ -928,8 +1006,10 @@ __global__ __launch_bounds__(WIN_THREADS) void msm_bucket_finalize_big_kernel(co
   for (uint32_t item = blockIdx.x; item < count; item += gridDim.x) {
     const uint32_t b = big_list[item];
     const uint32_t lo = toff[b], hi = toff[b + 1];
+    const uint32_t step = hi - lo > FINALIZE_SLICE ? FINALIZE_SLICE : 1u;
     G1Jac acc = g1_identity();
-    for (uint32_t t = lo + threadIdx.x; t < hi; t += WIN_THREADS) acc = g1_add(acc, load_jac(partial + (size_t)t * PT_WORDS));
+    for (uint32_t t = lo + threadIdx.x * step; t < hi; t += WIN_THREADS * step)
+      acc = g1_add(acc, load_jac(partial + (size_t)t * PT_WORDS));
     const G1Jac r = block_sum_points(tree, acc);
     if (threadIdx.x == 0) store_jac(bucket + (size_t)b * PT_WORDS, r);
     __syncthreads();
@@ -1298,7 +1378,13 @@ int msm_enqueue(DeviceCtx& ctx, int slot, const uint32_t* d_scalars_ext, const u
   const uint64_t pairs_max = (uint64_t)n * W;
   if (pairs_max >= (1ull << 31)) return hm_fail(HM_ERR_BAD_ARG, "msm: n * windows must be < 2^31");
   const double mean = (double)sn / (double)NB;
-  uint32_t L = (uint32_t)(mean + 4.0 * std::sqrt(mean) + 8.0);
+#ifndef HM_L_MEAN_SCALE      // measurement knobs (tools/ab_build.sh); the defaults are the tuned values
+#define HM_L_MEAN_SCALE 1.0
+#endif
+#ifndef HM_L_SIGMAS
+#define HM_L_SIGMAS 4.0
+#endif
+  uint32_t L = (uint32_t)(HM_L_MEAN_SCALE * mean + HM_L_SIGMAS * std::sqrt(mean) + 8.0);
   {
     // small inputs: if one task per bucket would leave the chip (256 CUs x 4 SIMDs x ~5 waves x 64
     // lanes) mostly idle, cut the tasks shorter so that the launch still fills it
@@ -1317,7 +1403,9 @@ int msm_enqueue(DeviceCtx& ctx, int slot, const uint32_t* d_scalars_ext, const u
     if (G < 256) G = 256;
   }
   const size_t chunk = (sn + G - 1) / G;
-  const uint64_t T_max = pairs_max / L + NBT + 1;
+  // the device may shorten L (effective_task_len): then tasks <= 2 * TARGET_TASKS + one per bucket
+  // (and never more than one per pair)
+  const uint64_t T_max = std::min<uint64_t>(pairs_max, std::max<uint64_t>(pairs_max / L, 2ull * TARGET_TASKS) + NBT) + 1;
   // K4a: running-sum chain of 2*SEG additions per lane + a scalar multiple of <= log2(NB) bits
   uint32_t SEG = NB > (1u << 16) ? 32u : 8u;
   if (SEG > NB) SEG = NB;
@@ -1359,6 +1447,7 @@ int msm_enqueue(DeviceCtx& ctx, int slot, const uint32_t* d_scalars_ext, const u
   const size_t o_seg2 = carve(((size_t)SW * (nseg / SUM_SPAN + 1)) * PT_WORDS * 4);
   const size_t o_win = carve((size_t)SW * 32 * 4);
   const size_t o_big = carve(((size_t)NBT + 4) * 4);
+  const size_t o_slices = carve((T_max / FINALIZE_SLICE + T_max / (FINALIZE_SERIAL + 1) + 2) * 8);
   // cooperative sort of oversized regions (hot buckets): split anything above 4x the mean region
   BigRegionPlan br;
   {
@@ -1397,6 +1486,7 @@ int msm_enqueue(DeviceCtx& ctx, int slot, const uint32_t* d_scalars_ext, const u
   uint32_t* d_win = (uint32_t*)(ws + o_win);
   uint32_t* d_big_count = (uint32_t*)(ws + o_big);
   uint32_t* d_big_list = d_big_count + 4;
+  uint2* d_slices = (uint2*)(ws + o_slices);
   br.list = (uint2*)(ws + o_brlist);
   br.count = (uint32_t*)(ws + o_brcount);
   br.gcursor = (uint32_t*)(ws + o_gcur);
@@ -1450,13 +1540,17 @@ int msm_enqueue(DeviceCtx& ctx, int slot, const uint32_t* d_scalars_ext, const u
                                                NC, NBP, br, stream);
     if (rc != HM_OK) return rc;
   }
+  // pair count for effective_task_len: the first sort level leaves it behind its region starts; an
+  // input small enough to need no first level keeps the host's L (the count is set to its bound)
+  const uint32_t* d_pairs = cb ? d_cstart + (size_t)SW * NC : d_tot + 2;
+  if (!cb) HM_HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)(d_tot + 2), (int)pairs_max, 1, stream));
   {
     const uint32_t nblocks = (NBT + SCAN_BLOCK - 1) / SCAN_BLOCK;
     hipLaunchKernelGGL(msm_scan_partial_kernel, dim3(nblocks), dim3(SCAN_THREADS), 0, stream, (const uint32_t*)d_bcnt,
-                       d_bsum, NBT, L);
+                       d_bsum, NBT, d_pairs, L);
     hipLaunchKernelGGL(msm_scan_blocksums_kernel, dim3(1), dim3(SCAN_THREADS), 0, stream, d_bsum, nblocks, d_tot);
     hipLaunchKernelGGL(msm_scan_final_kernel, dim3(nblocks), dim3(SCAN_THREADS), 0, stream, (const uint32_t*)d_bcnt,
-                       (const uint32_t*)d_bsum, d_boff, d_toff, (const uint32_t*)d_tot, NBT, L);
+                       (const uint32_t*)d_bsum, d_boff, d_toff, (const uint32_t*)d_tot, NBT, d_pairs, L);
     HM_HIP_CHECK(hipGetLastError());
   }
   {
@@ -1466,13 +1560,18 @@ int msm_enqueue(DeviceCtx& ctx, int slot, const uint32_t* d_scalars_ext, const u
                                                               NBP, NBT, br, stream);
     if (rc != HM_OK) return rc;
   }
-  {
+  if (pairs_max < (1u << 19)) {
+    // small inputs: three more launches cost more than the idle lanes they would save
+    hipLaunchKernelGGL(msm_task_fill_kernel, dim3((NBT + 255) / 256), dim3(256), 0, stream, (const uint32_t*)d_toff, d_tb, d_torder,
+                       NBT);
+  } else {
     const uint32_t og = (NBT + ORDER_THREADS * ORDER_ITEMS - 1) / (ORDER_THREADS * ORDER_ITEMS);
     HM_HIP_CHECK(hipMemsetAsync(d_khist, 0, TASK_KEYS * 4, stream));
-    hipLaunchKernelGGL(msm_task_hist_kernel, dim3(og), dim3(ORDER_THREADS), 0, stream, (const uint32_t*)d_bcnt, NBT, L, d_khist);
+    hipLaunchKernelGGL(msm_task_hist_kernel, dim3(og), dim3(ORDER_THREADS), 0, stream, (const uint32_t*)d_bcnt, NBT,
+                       d_pairs, L, d_khist);
     hipLaunchKernelGGL(msm_task_keyscan_kernel, dim3(1), dim3(ORDER_THREADS), 0, stream, (const uint32_t*)d_khist, d_kcursor);
     hipLaunchKernelGGL(msm_task_order_kernel, dim3(og), dim3(ORDER_THREADS), 0, stream, (const uint32_t*)d_bcnt,
-                       (const uint32_t*)d_toff, NBT, L, d_kcursor, d_tb, d_torder);
+                       (const uint32_t*)d_toff, NBT, d_pairs, L, d_kcursor, d_tb, d_torder);
   }
   HM_HIP_CHECK(hipGetLastError());
   HM_HIP_CHECK(hipEventRecord(ev[2], stream));
@@ -1486,17 +1585,21 @@ int msm_enqueue(DeviceCtx& ctx, int slot, const uint32_t* d_scalars_ext, const u
     const uint64_t t_grid = T_max;
     hipLaunchKernelGGL(msm_accumulate_kernel, dim3((uint32_t)((t_grid + ACC_THREADS - 1) / ACC_THREADS)), dim3(ACC_THREADS), 0,
                        stream, (const uint32_t*)d_sorted, (const uint32_t*)d_tb, (const uint32_t*)d_torder, (const uint32_t*)d_boff,
-                       (const uint32_t*)d_bcnt, (const uint32_t*)d_toff, d_xy, d_partial, (const uint32_t*)d_tot, L);
+                       (const uint32_t*)d_bcnt, (const uint32_t*)d_toff, d_xy, d_partial, (const uint32_t*)d_tot, d_pairs, L);
     HM_HIP_CHECK(hipGetLastError());
   }
   HM_HIP_CHECK(hipEventRecord(ev[6], stream));
   HM_HIP_CHECK(hipMemsetAsync(d_big_count, 0, 16, stream));
   hipLaunchKernelGGL(msm_bucket_finalize_kernel, dim3((NBT + ACC_THREADS - 1) / ACC_THREADS), dim3(ACC_THREADS), 0, stream,
-                     (const uint32_t*)d_partial, (const uint32_t*)d_toff, d_bucket, NBT, d_big_count, d_big_list);
+                     (const uint32_t*)d_partial, (const uint32_t*)d_toff, d_bucket, NBT, d_big_count, d_big_list, d_slices);
   HM_HIP_CHECK(hipGetLastError());
   {
+    uint32_t slice_grid = (uint32_t)(T_max / FINALIZE_SLICE + 1);       // upper bound on the number of full slices
+    if (slice_grid > 2048) slice_grid = 2048;                           // both kernels stride over their queues
+    hipLaunchKernelGGL(msm_bucket_finalize_slices_kernel, dim3(slice_grid), dim3(WIN_THREADS), 0, stream, d_partial,
+                       (const uint32_t*)d_toff, (const uint32_t*)d_big_count, (const uint2*)d_slices);
     uint32_t big_grid = (uint32_t)(T_max / (FINALIZE_SERIAL + 1) + 1);  // upper bound on the number of queued buckets
-    if (big_grid > 2048) big_grid = 2048;                               // the kernel strides over the queue
+    if (big_grid > 2048) big_grid = 2048;
     hipLaunchKernelGGL(msm_bucket_finalize_big_kernel, dim3(big_grid), dim3(WIN_THREADS), 0, stream,
                        (const uint32_t*)d_partial, (const uint32_t*)d_toff, d_bucket, (const uint32_t*)d_big_count,
                        (const uint32_t*)d_big_list);
