@@ -33,6 +33,13 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
+# The real ceiling of both hot kernels: VALU issue.  256 CUs x 4 SIMD16 units, one
+# wave64 VALU instruction per 4 cycles, at the 2.4 GHz peak engine clock (the chip holds ~2.07-2.2 GHz
+# under these kernels).  Instructions per unit are a property of the build, measured with
+# SQ_INSTS_VALU (profiles/r01_e_sq_counters.txt, tools/pmc_sq.sh): re-measure when the kernels change.
+VALU_PEAK_WAVE_INST_PER_S = 256 * 4 * 2.4e9 / 4
+K3_VALU_INST_PER_ADDITION = 8803917569 / (251656262 / 64)      # wave-instructions per 64 mixed additions
+NTT_VALU_INST_PER_ELEMENT_PASS = 336571051 / (1 << 24)           # wave-instructions per element and pass (x 64 lanes)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 MSM_BYTES_PER_POINT = 96
 NTT_BYTES_PER_ELEM = 64
@@ -88,6 +95,15 @@ def pmc_traffic(kernel, corrected):
         return (d["FETCH_SIZE_KiB_per_launch"] + d["WRITE_SIZE_KiB_per_launch"]) * 1024.0
     except (OSError, KeyError, ValueError):
         return None
+
+
+def valu_issue(wave_instructions: float, kernel_ms: float) -> dict:
+    """The binding resource of the hot kernels, next to the contract's HBM roofline: VALU wave-instructions
+    issued per second against what 1024 SIMD16 units can issue at the peak clock."""
+    achieved = wave_instructions / (kernel_ms * 1e-3)
+    return {"achieved": achieved, "peak": VALU_PEAK_WAVE_INST_PER_S, "unit": "wave-instr/s",
+            "frac": achieved / VALU_PEAK_WAVE_INST_PER_S,
+            "note": "instruction counts from SQ_INSTS_VALU (profiles/r01_e_sq_counters.txt); peak = 1024 SIMDs x 2.4 GHz / 4"}
 
 
 def main():
@@ -194,7 +210,9 @@ def main():
                "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                             "traffic": (pmc_traffic("hm::ntt_pass_kernel<11>", True) if k == 24 else None),
                             "note": "traffic is per pass launch; 3 digit passes => 3x the algorithmic 64 B/element per transform; "
-                                    "VALU-issue bound (~4.9e3 32-bit ops per element)"}}
+                                    "VALU-issue bound (~3.9e3 32-bit ops per element)",
+                            "valu_issue": valu_issue(NTT_VALU_INST_PER_ELEMENT_PASS * (1 << k) * (3 if k > 21 else 2 if k > 11 else 1),
+                                                     ms)}}
         del a
 
     # ---- side measurements: prover-like scalars; the PCIe-inclusive drop-in call ----
@@ -310,9 +328,10 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": (pmc_traffic("hm::msm_accumulate_kernel", False) if args.log_points == 24 else None),
                          "traffic_note": "raw FETCH_SIZE+WRITE_SIZE (64-byte gathers: gfx950 x2 read correction not calibrated for this "
-                                         "shape); every base is gathered once per window (W = 16), inherent to bucketed Pippenger",
+                                         "shape); every base is gathered once per window (W = 15), inherent to bucketed Pippenger",
                          "kernel": "msm_accumulate_kernel", "kernel_ms": acc,
-                         "note": "integer-VALU bound (SURVEY.md §8d): ~2.5e8 mixed additions x ~2.35e3 32-bit ops per launch"},
+                         "note": "integer-VALU bound (SURVEY.md §8d): ~2.5e8 mixed additions x ~2.35e3 32-bit ops per launch",
+                         "valu_issue": valu_issue(st["pairs"] / 64.0 * K3_VALU_INST_PER_ADDITION, acc)},
             "msm_phase_ms": {"sort": float(np.mean(sort_ms)), "accumulate_kernel": acc, "device_total": float(np.mean(tot_ms))},
             "result_is_identity": bool(not result[8:].any()),
         }

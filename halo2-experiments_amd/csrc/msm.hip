@@ -307,7 +307,10 @@ __global__ __launch_bounds__(SORT_THREADS) void msm_part1_scatter_kernel(const i
 // part 1 scatter, tiled form: the chunk is processed in tiles of 4096 digits that are first
 // counting-sorted by coarse bin inside LDS, so that consecutive lanes append to the same coarse run
 // (sector-complete stores, as in the tiled part-2 scatter below).  Used while NC <= 4096.
-constexpr int P1_IPT = 4;
+#ifndef HM_P1_IPT
+#define HM_P1_IPT 4
+#endif
+constexpr int P1_IPT = HM_P1_IPT;
 constexpr int P1_TILE = SORT_THREADS * P1_IPT;
 template <class ITEM>
 __global__ __launch_bounds__(SORT_THREADS) void msm_part1_scatter_tiled_kernel(const int32_t* __restrict__ digits,
@@ -499,7 +502,10 @@ __global__ __launch_bounds__(SORT_THREADS) void msm_part2_scatter_kernel(const I
 // consecutive addresses of a bucket run -- every 32-byte sector of the final array is written by one
 // wave instruction (or two adjacent tiles) instead of by eight separate 4-byte stores spread over the
 // workgroup's lifetime, which is what kept missing L2 once a region had more than ~128 runs.
-constexpr int P2_IPT = 4;
+#ifndef HM_P2_IPT
+#define HM_P2_IPT 4
+#endif
+constexpr int P2_IPT = HM_P2_IPT;
 constexpr int P2_TILE = SORT_THREADS * P2_IPT;
 // COOP: slices of big regions (work list); the per-bucket cursors then live in global memory
 // (`gcursor`, a copy of boff) and every tile reserves its runs with one atomicAdd per non-empty bucket.
