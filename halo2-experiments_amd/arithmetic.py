@@ -131,7 +131,7 @@ def best_multiexp(coeffs, bases: Union[np.ndarray, BasesHandle, "object"], offse
 
 def best_multiexp_submit(coeffs, bases: BasesHandle, offset: int = 0) -> int:
     """Asynchronous best_multiexp on device-resident scalars: enqueues the whole MSM on torch's current
-    stream and returns a ticket at once (at most 3 in flight); pair with :func:`best_multiexp_wait`."""
+    stream and returns a ticket at once (at most 8 in flight); pair with :func:`best_multiexp_wait`."""
     n = _tensor_rows(coeffs, 4, "coeffs")
     t = ctypes.c_uint64(0)
     _lib.check(_lib.load().hm_msm_submit_dev(ctypes.c_uint64(bases.handle), offset, ctypes.c_void_p(coeffs.data_ptr()), n,

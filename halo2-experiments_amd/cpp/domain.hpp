@@ -134,7 +134,7 @@ class ParamsKZG {
   // commit(poly in coefficient form) / commit_lagrange(poly in evaluation form): one best_multiexp each
   G1 commit(const Fr* d_poly) const { return msm(g_handle, d_poly); }
   G1 commit_lagrange(const Fr* d_poly) const { return msm(g_lagrange_handle, d_poly); }
-  // asynchronous forms: the commitments of one prover phase are independent, so up to three are kept
+  // asynchronous forms: the commitments of one prover phase are independent, so up to eight are kept
   // in flight on different streams (hm_msm_submit_dev) and awaited in order
   uint64_t commit_submit(const Fr* d_poly, hipStream_t stream) const { return submit(g_handle, d_poly, stream); }
   uint64_t commit_lagrange_submit(const Fr* d_poly, hipStream_t stream) const { return submit(g_lagrange_handle, d_poly, stream); }

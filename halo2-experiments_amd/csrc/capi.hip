@@ -141,7 +141,9 @@ int hm_shutdown(void) {
   }
   c.bases.clear();
   c.scratch.release(); c.io.release(); c.io_bases.release(); c.conv_bases.release(); c.conv_inf.release();
+  if (c.capture_stream) { (void)hipStreamDestroy(c.capture_stream); c.capture_stream = nullptr; }
   for (auto& sl : c.msm_slots) {
+    msm_slot_release_graph(sl);
     sl.ws.release();
     sl.busy = false;
     if (sl.h_land) { (void)hipHostFree(sl.h_land); sl.h_land = nullptr; }
@@ -150,6 +152,11 @@ int hm_shutdown(void) {
   c.small.release();
   c.cached_host_bases = nullptr;
   c.cached_host_n = 0;
+  return HM_OK;
+}
+
+int hm_msm_use_graphs(int enable) {
+  msm_set_use_graphs(enable != 0);
   return HM_OK;
 }
 

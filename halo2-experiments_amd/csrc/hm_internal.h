@@ -76,10 +76,32 @@ struct MsmStats {
   uint32_t c = 0, windows = 0;
 };
 
-constexpr int HM_MSM_SLOTS = 4;
+constexpr int HM_MSM_SLOTS = 9;   // slot 0: synchronous calls; 1..8: asynchronous tickets (workspaces allocated on first use)
+
+struct MsmGraphKey {        // what the captured launch sequence (everything after the digit kernel) depends on
+  size_t n = 0;
+  const void* d_xy = nullptr;
+  uint32_t precomp_c = 0;
+  int window_override = 0;
+  const void* ws = nullptr;
+  bool operator==(const MsmGraphKey& o) const {
+    return n == o.n && d_xy == o.d_xy && precomp_c == o.precomp_c && window_override == o.window_override && ws == o.ws;
+  }
+};
 
 struct MsmSlot {            // one in-flight MSM: its workspace, events and host landing buffers
   DevBuf ws;
+  struct Graph {                     // captured launch sequence of one small-MSM shape on this slot
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    MsmGraphKey key;
+    uint64_t last_use = 0;
+  };
+  static constexpr int kGraphs = 1;  // ONE per slot: replaying a slot's graph after a different graph had run on the
+                                     // same workspace faulted on ROCm 7.2 (tools/graph_probe2.py); a key change recaptures
+  Graph graphs[kGraphs];
+  uint64_t graph_clock = 0;
+  bool timed = false;                // per-phase events were recorded for the MSM in flight
   hipEvent_t ev[7] = {};
   bool ev_ready = false;
   bool busy = false;        // held by a ticket of hm_msm_submit_dev
@@ -113,6 +135,7 @@ struct DeviceCtx {
   uint64_t cached_probe[4] = {0, 0, 0, 0};
   MsmStats last_msm;
   bool msm_attr_set = false, ntt_attr_set = false;
+  hipStream_t capture_stream = nullptr;   // launch sequences are captured here, replayed on the caller's stream
   void* ensure_scratch(size_t bytes) { return scratch.ensure(bytes); }
 };
 
@@ -133,6 +156,8 @@ int msm_enqueue(DeviceCtx& ctx, int slot, const uint32_t* d_scalars_ext, const u
 int msm_finish(DeviceCtx& ctx, int slot, uint64_t out_jac_ext[12], int* out_is_identity);
 int msm_run(DeviceCtx& ctx, const uint32_t* d_scalars_ext, const uint32_t* d_xy, const uint8_t* d_inf, size_t n,
             uint32_t precomp_c, uint64_t out_jac_ext[12], int* out_is_identity, hipStream_t stream);
+void msm_set_use_graphs(bool on);
+void msm_slot_release_graph(MsmSlot& sl);
 uint32_t msm_precomp_window(size_t n);
 int msm_precompute(uint32_t* d_table, const uint8_t* d_inf, size_t n, uint32_t c, uint32_t W, hipStream_t stream);
 void host_sum_points(const uint64_t* pts, size_t count, uint64_t out_jac_ext[12], int* out_is_identity);

@@ -1350,11 +1350,16 @@ static int launch_sort_scatter(const int32_t* d_digits, const uint32_t* d_cstart
 // the device.  d_xy: n points (plain) or the precomputed table of precomp_W * n points
 // (precomp_c != 0).  msm_finish() later waits for the slot, folds the window sums on the host and
 // fills the statistics.
-int msm_enqueue(DeviceCtx& ctx, int slot, const uint32_t* d_scalars_ext, const uint32_t* d_xy, const uint8_t* d_inf, size_t n,
-                uint32_t precomp_c, hipStream_t stream) {
+// phase: MSM_PREPARE = plan, workspace and first-use set-up only (everything a stream capture must not
+// contain); MSM_ISSUE = prepare + every launch, with the per-phase timing events; MSM_DIGITS = prepare
+// (idempotent) + the digit kernel alone, the only consumer of the per-call scalar pointer;
+// MSM_AFTER_DIGITS = prepare + everything after it and nothing else, the form that is captured into a
+// graph (it depends on the size, the window, the base set and the workspace only).
+enum MsmPhase { MSM_PREPARE, MSM_ISSUE, MSM_DIGITS, MSM_AFTER_DIGITS };
+static int msm_issue(DeviceCtx& ctx, int slot, const uint32_t* d_scalars_ext, const uint32_t* d_xy, const uint8_t* d_inf, size_t n,
+                     uint32_t precomp_c, hipStream_t stream, MsmPhase phase) {
   MsmSlot& sl = ctx.msm_slots[slot];
-  sl.n = n;
-  sl.stream = stream;
+  const bool timing = phase == MSM_ISSUE;
   if (n == 0) return HM_OK;
   if (n >= (1ull << 31)) return hm_fail(HM_ERR_BAD_ARG, "msm: n must be < 2^31");
   // ---- plan ---------------------------------------------------------------------------------
@@ -1528,13 +1533,20 @@ int msm_enqueue(DeviceCtx& ctx, int slot, const uint32_t* d_scalars_ext, const u
     HM_HIP_CHECK(hipHostMalloc((void**)&sl.h_land, (128 * 32 + 4) * sizeof(uint32_t), hipHostMallocDefault));
     sl.ev_ready = true;
   }
-  HM_HIP_CHECK(hipEventRecord(ev[0], stream));
+  sl.SW = SW;
+  sl.c = c;
+  sl.W = W;
+  sl.T_max = T_max;
+  if (phase == MSM_PREPARE) return HM_OK;
 
   // ---- K0 ------------------------------------------------------------------------------------
-  hipLaunchKernelGGL(msm_digits_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, stream, d_scalars_ext, d_inf,
-                     d_digits, n, c, W);
-  HM_HIP_CHECK(hipGetLastError());
-  HM_HIP_CHECK(hipEventRecord(ev[1], stream));
+  if (phase != MSM_AFTER_DIGITS) {
+    hipLaunchKernelGGL(msm_digits_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, stream, d_scalars_ext, d_inf,
+                       d_digits, n, c, W);
+    HM_HIP_CHECK(hipGetLastError());
+  }
+  if (phase == MSM_DIGITS) return HM_OK;
+  if (timing) HM_HIP_CHECK(hipEventRecord(ev[1], stream));
 
   // ---- K2 ------------------------------------------------------------------------------------
   {
@@ -1580,13 +1592,13 @@ int msm_enqueue(DeviceCtx& ctx, int slot, const uint32_t* d_scalars_ext, const u
                        (const uint32_t*)d_toff, NBT, d_pairs, L, d_kcursor, d_tb, d_torder);
   }
   HM_HIP_CHECK(hipGetLastError());
-  HM_HIP_CHECK(hipEventRecord(ev[2], stream));
+  if (timing) HM_HIP_CHECK(hipEventRecord(ev[2], stream));
 
   // ---- K3 ------------------------------------------------------------------------------------
   // The exact task count T stays on the device (d_tot[1]); the grid covers its host-side bound: for
   // uniform scalars every bucket holds one task (T ~ NBT), else at most pairs / L more.  Surplus
   // single-wave workgroups exit at once.
-  HM_HIP_CHECK(hipEventRecord(ev[5], stream));
+  if (timing) HM_HIP_CHECK(hipEventRecord(ev[5], stream));
   {
     const uint64_t t_grid = T_max;
     hipLaunchKernelGGL(msm_accumulate_kernel, dim3((uint32_t)((t_grid + ACC_THREADS - 1) / ACC_THREADS)), dim3(ACC_THREADS), 0,
@@ -1594,7 +1606,7 @@ int msm_enqueue(DeviceCtx& ctx, int slot, const uint32_t* d_scalars_ext, const u
                        (const uint32_t*)d_bcnt, (const uint32_t*)d_toff, d_xy, d_partial, (const uint32_t*)d_tot, d_pairs, L);
     HM_HIP_CHECK(hipGetLastError());
   }
-  HM_HIP_CHECK(hipEventRecord(ev[6], stream));
+  if (timing) HM_HIP_CHECK(hipEventRecord(ev[6], stream));
   HM_HIP_CHECK(hipMemsetAsync(d_big_count, 0, 16, stream));
   hipLaunchKernelGGL(msm_bucket_finalize_kernel, dim3((NBT + ACC_THREADS - 1) / ACC_THREADS), dim3(ACC_THREADS), 0, stream,
                      (const uint32_t*)d_partial, (const uint32_t*)d_toff, d_bucket, NBT, d_big_count, d_big_list, d_slices);
@@ -1611,7 +1623,7 @@ int msm_enqueue(DeviceCtx& ctx, int slot, const uint32_t* d_scalars_ext, const u
                        (const uint32_t*)d_big_list);
     HM_HIP_CHECK(hipGetLastError());
   }
-  HM_HIP_CHECK(hipEventRecord(ev[3], stream));
+  if (timing) HM_HIP_CHECK(hipEventRecord(ev[3], stream));
 
   // ---- K4 ------------------------------------------------------------------------------------
   hipLaunchKernelGGL(msm_reduce_segments_kernel, dim3((SW * nseg + ACC_THREADS - 1) / ACC_THREADS), dim3(ACC_THREADS), 0,
@@ -1636,11 +1648,90 @@ int msm_enqueue(DeviceCtx& ctx, int slot, const uint32_t* d_scalars_ext, const u
   // pinned landing zone, so that these copies (and therefore msm_enqueue) do not wait for the device
   HM_HIP_CHECK(hipMemcpyAsync(sl.win(), d_win, (size_t)SW * 32 * 4, hipMemcpyDeviceToHost, stream));
   HM_HIP_CHECK(hipMemcpyAsync(sl.totals(), d_tot, 8, hipMemcpyDeviceToHost, stream));
-  HM_HIP_CHECK(hipEventRecord(ev[4], stream));
-  sl.SW = SW;
-  sl.c = c;
-  sl.W = W;
-  sl.T_max = T_max;
+  return HM_OK;
+}
+
+// EXPERIMENTAL, off by default (hm_msm_use_graphs).  Small MSMs (the sizes of the reference's own circuits,
+// k <= 18) are launch-bound: ~30 launches, memsets and copies per call (128 us of host time at 2^18; 24 us
+// as a graph).  Everything after the digit kernel depends only on (size, window, base set, workspace), so
+// that sequence can be captured once per such key and slot into a hipGraph and replayed with one
+// hipGraphLaunch; the digit kernel, the only consumer of the per-call scalar pointer, is launched
+// directly in front of it.  Why it is not the default: on ROCm 7.2 replays produced GPU memory faults in
+// two situations that direct launches of the very same sequence never do -- a slot holding two graphs
+// (the second replayed after the first had run on the same workspace; hence ONE graph per slot), and,
+// with one graph per slot, somewhere in bench.py's full flow (2^24 MSMs on slots 1-3, then the proof
+// replays on slots 1-8).  tools/graph_probe.py and graph_probe2.py are the reproducers.
+static bool g_use_graphs = false;
+void msm_set_use_graphs(bool on) { g_use_graphs = on; }
+constexpr size_t MSM_GRAPH_MAX_N = 1u << 20;
+
+static void msm_graph_drop(MsmSlot::Graph& g) {
+  if (g.exec) (void)hipGraphExecDestroy(g.exec);
+  if (g.graph) (void)hipGraphDestroy(g.graph);
+  g = MsmSlot::Graph{};
+  (void)hipGetLastError();   // a failed capture must not surface later as somebody else's launch error
+}
+void msm_slot_release_graph(MsmSlot& sl) {
+  for (auto& g : sl.graphs) msm_graph_drop(g);
+}
+
+static int msm_graph_launch(DeviceCtx& ctx, int slot, const uint32_t* d_scalars_ext, const uint32_t* d_xy, const uint8_t* d_inf,
+                            size_t n, uint32_t precomp_c, hipStream_t stream, bool* done) {
+  MsmSlot& sl = ctx.msm_slots[slot];
+  *done = false;
+  if (!ctx.capture_stream) HM_HIP_CHECK(hipStreamCreateWithFlags(&ctx.capture_stream, hipStreamNonBlocking));
+  const MsmGraphKey key{n, d_xy, precomp_c, g_window_override, sl.ws.p};
+  MsmSlot::Graph* g = nullptr;
+  for (auto& cand : sl.graphs) {
+    if (cand.exec && cand.key.ws != sl.ws.p) msm_graph_drop(cand);   // the workspace moved: its pointers are stale
+    if (cand.exec && cand.key == key) g = &cand;
+  }
+  if (!g) {
+    g = &sl.graphs[0];
+    for (auto& cand : sl.graphs) {
+      if (!cand.exec) { g = &cand; break; }            // a free entry
+      if (cand.last_use < g->last_use) g = &cand;      // else the least recently used
+    }
+    msm_graph_drop(*g);
+    HM_HIP_CHECK(hipStreamBeginCapture(ctx.capture_stream, hipStreamCaptureModeThreadLocal));
+    const int rc = msm_issue(ctx, slot, d_scalars_ext, d_xy, d_inf, n, precomp_c, ctx.capture_stream, MSM_AFTER_DIGITS);
+    const hipError_t ce = hipStreamEndCapture(ctx.capture_stream, &g->graph);
+    if (rc != HM_OK || ce != hipSuccess || !g->graph || hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0) != hipSuccess) {
+      g->exec = nullptr;
+      msm_graph_drop(*g);
+      return rc != HM_OK ? rc : HM_OK;            // capture unavailable: the caller issues the launches directly
+    }
+    g->key = key;
+  }
+  const int rc = msm_issue(ctx, slot, d_scalars_ext, d_xy, d_inf, n, precomp_c, stream, MSM_DIGITS);
+  if (rc != HM_OK) return rc;
+  g->last_use = ++sl.graph_clock;
+  HM_HIP_CHECK(hipGraphLaunch(g->exec, stream));
+  *done = true;
+  return HM_OK;
+}
+
+int msm_enqueue(DeviceCtx& ctx, int slot, const uint32_t* d_scalars_ext, const uint32_t* d_xy, const uint8_t* d_inf, size_t n,
+                uint32_t precomp_c, hipStream_t stream) {
+  MsmSlot& sl = ctx.msm_slots[slot];
+  sl.n = n;
+  sl.stream = stream;
+  sl.timed = false;
+  if (n == 0) return HM_OK;
+  int rc = msm_issue(ctx, slot, d_scalars_ext, d_xy, d_inf, n, precomp_c, stream, MSM_PREPARE);
+  if (rc != HM_OK) return rc;
+  HM_HIP_CHECK(hipEventRecord(sl.ev[0], stream));
+  bool done = false;
+  if (g_use_graphs && n <= MSM_GRAPH_MAX_N) {
+    rc = msm_graph_launch(ctx, slot, d_scalars_ext, d_xy, d_inf, n, precomp_c, stream, &done);
+    if (rc != HM_OK) return rc;
+  }
+  if (!done) {
+    rc = msm_issue(ctx, slot, d_scalars_ext, d_xy, d_inf, n, precomp_c, stream, MSM_ISSUE);
+    if (rc != HM_OK) return rc;
+    sl.timed = true;
+  }
+  HM_HIP_CHECK(hipEventRecord(sl.ev[4], stream));
   return HM_OK;
 }
 
@@ -1658,10 +1749,12 @@ int msm_finish(DeviceCtx& ctx, int slot, uint64_t out_jac_ext[12], int* out_is_i
   host_fold(sl.win(), sl.SW, sl.c, out_jac_ext, out_is_identity);   // SW == 1: no Horner, just the normalisation
 
   float ms[4] = {0, 0, 0, 0}, total = 0;
-  for (int i = 0; i < 4; ++i) (void)hipEventElapsedTime(&ms[i], ev[i], ev[i + 1]);
-  (void)hipEventElapsedTime(&total, ev[0], ev[4]);
   float acc_kernel = 0;
-  (void)hipEventElapsedTime(&acc_kernel, ev[5], ev[6]);
+  (void)hipEventElapsedTime(&total, ev[0], ev[4]);
+  if (sl.timed) {   // a graph replay carries no per-phase events: only the total is known
+    for (int i = 0; i < 4; ++i) (void)hipEventElapsedTime(&ms[i], ev[i], ev[i + 1]);
+    (void)hipEventElapsedTime(&acc_kernel, ev[5], ev[6]);
+  }
   ctx.last_msm.t_accum_kernel_ms = acc_kernel;
   ctx.last_msm.t_digits_ms = ms[0];
   ctx.last_msm.t_sort_ms = ms[1];

@@ -134,22 +134,24 @@ int main(int argc, char** argv) {
     const auto t_pk1 = Clock::now();
 
     // create_proof (utils.rs:40-48): the MSM / NTT trace of SURVEY.md §3.2.  The commitments of one
-    // phase are independent: three are kept in flight on three streams.
-    hipStream_t streams[3];
+    // phase are independent: eight (every asynchronous slot of the library) are kept in flight on four streams.
+    constexpr uint32_t kInFlight = 8, kStreams = 4;
+    hipStream_t streams[kStreams];
     for (auto& st : streams) (void)hipStreamCreate(&st);
     (void)hipDeviceSynchronize();
     auto commit_phase = [&](uint32_t count, const Fr* d_poly, bool lagrange) {
-      uint64_t pending[3];
+      uint64_t pending[kInFlight];
       uint32_t head = 0, inflight = 0;
       for (uint32_t i = 0; i < count; ++i) {
-        if (inflight == 3) { (void)poly::ParamsKZG::commit_wait(pending[head]); head = (head + 1) % 3; --inflight; }
-        const uint32_t slot = (head + inflight) % 3;
-        pending[slot] = lagrange ? params.commit_lagrange_submit(d_poly, streams[i % 3]) : params.commit_submit(d_poly, streams[i % 3]);
+        if (inflight == kInFlight) { (void)poly::ParamsKZG::commit_wait(pending[head]); head = (head + 1) % kInFlight; --inflight; }
+        const uint32_t slot = (head + inflight) % kInFlight;
+        pending[slot] = lagrange ? params.commit_lagrange_submit(d_poly, streams[i % kStreams])
+                                 : params.commit_submit(d_poly, streams[i % kStreams]);
         ++inflight;
       }
-      while (inflight) { (void)poly::ParamsKZG::commit_wait(pending[head]); head = (head + 1) % 3; --inflight; }
+      while (inflight) { (void)poly::ParamsKZG::commit_wait(pending[head]); head = (head + 1) % kInFlight; --inflight; }
     };
-    commit_phase(3, d_dense.d, true);                              // warm-up: allocates the three asynchronous workspaces
+    commit_phase(kInFlight, d_dense.d, true);                      // warm-up: allocates the asynchronous workspaces
     const auto t_pr0 = Clock::now();
     size_t n_msm = 0, n_ntt = 0;
     commit_phase(advice + 2 * lookups, d_sparse.d, true);          // advice, permuted lookup columns

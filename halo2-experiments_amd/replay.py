@@ -87,7 +87,8 @@ def _sparse_column(n, used_rows, seed, device):
     return col
 
 
-def run_replay(shape_name: str, device=None, group=None, include_host_pointer_estimate: bool = True) -> dict:
+def run_replay(shape_name: str, device=None, group=None, include_host_pointer_estimate: bool = True,
+               in_flight: int = 8) -> dict:
     import torch
     import torch.distributed as dist
 
@@ -117,11 +118,11 @@ def run_replay(shape_name: str, device=None, group=None, include_host_pointer_es
     def msm(col, handle):
         return sharded_multiexp(col[lo:hi].contiguous() if world > 1 else col, handle, group=group)
 
-    streams = [torch.cuda.Stream(device=device) for _ in range(3)]
+    streams = [torch.cuda.Stream(device=device) for _ in range(in_flight)]
 
     def msm_phase(jobs):
-        """The commitments of one prover phase are independent: every rank keeps three of its local
-        MSMs in flight on three streams (one MSM's sort / bucket reduction / host fold hides behind
+        """The commitments of one prover phase are independent: every rank keeps `in_flight` of its local
+        MSMs in flight on as many streams (one MSM's sort / bucket reduction / host fold hides behind
         another's accumulation), then the partials of the whole phase cross xGMI in ONE all-gather."""
         local = [((col[lo:hi].contiguous() if world > 1 else col), handle) for col, handle in jobs]
         sharded_multiexp_batch(local, group=group, streams=streams)

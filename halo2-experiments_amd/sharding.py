@@ -54,9 +54,12 @@ def sharded_multiexp(local_coeffs, local_bases, group=None,
     return g1_sum(pts)
 
 
+MAX_IN_FLIGHT = 8      # asynchronous MSM slots per device (csrc/hm_internal.h: HM_MSM_SLOTS - 1)
+
+
 def sharded_multiexp_batch(jobs, group=None, streams=None, local_batch: Optional[Callable] = None) -> np.ndarray:
     """Several independent MSMs (the commitments of one prover phase): ``jobs`` = [(local_coeffs,
-    local_bases_handle), ...], every rank passing ITS shards.  Each rank keeps up to three of its
+    local_bases_handle), ...], every rank passing ITS shards.  Each rank keeps up to MAX_IN_FLIGHT of its
     local MSMs in flight (``hm_msm_submit_dev`` on different streams), then ALL partials travel in one
     all-gather of len(jobs) x 96 B per rank and are folded per job.  Returns (len(jobs), 12) words.
     ``local_batch`` replaces the GPU part in CPU-only tests."""
@@ -77,7 +80,7 @@ def sharded_multiexp_batch(jobs, group=None, streams=None, local_batch: Optional
                 st.wait_stream(cur)
             pending = []
             for i, (col, handle) in enumerate(jobs):
-                if len(pending) == min(3, len(streams)):
+                if len(pending) == min(MAX_IN_FLIGHT, len(streams)):
                     j, t = pending.pop(0)
                     partials[j] = best_multiexp_wait(t)
                 with torch.cuda.stream(streams[i % len(streams)]):

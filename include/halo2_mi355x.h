@@ -89,7 +89,7 @@ int hm_register_bases_dev(const void* d_bases, size_t n, void* stream, uint64_t*
 int hm_msm_bn256_g1_dev(uint64_t handle, size_t offset, const void* d_scalars, size_t n, void* stream,
                         uint64_t out_xyz[12]);
 
-/* Asynchronous form: enqueue the whole MSM on `stream` and return a ticket at once (up to 3 MSMs in
+/* Asynchronous form: enqueue the whole MSM on `stream` and return a ticket at once (up to 8 MSMs in
  * flight per device, each with its own workspace); hm_msm_wait blocks on that MSM only, folds and
  * returns its result.  Independent commitments issued on different streams overlap: one MSM's
  * latency-bound phases (sort, bucket reduction, host fold) hide behind another's accumulation. */
@@ -113,6 +113,13 @@ int hm_g1_sum(const uint64_t* points_xyz, size_t count, uint64_t out_xyz[12]);
 
 /* Window-size override for experiments (0 = automatic). */
 int hm_msm_set_window(int c);
+
+/* EXPERIMENTAL, off by default.  enable != 0: MSMs of up to 2^20 points replay everything after their digit
+ * kernel from a hipGraph captured on first use per (workspace slot, size, window, base set): one
+ * hipGraphLaunch instead of ~30 launches (host cost per call 128 us -> 24 us at 2^18); hm_get_msm_stats
+ * then reports only the total time of such calls.  Not the default because replays faulted on ROCm 7.2 in
+ * flows that direct launches of the same sequence run cleanly (see csrc/msm.hip). */
+int hm_msm_use_graphs(int enable);
 
 /* ---- NTT: stands in for halo2_proofs::arithmetic::best_fft::<bn256::Fr> --------------------- */
 

@@ -270,27 +270,30 @@ def test_host_pointer_base_cache_notices_changed_bases(cref, golden):
 
 
 def test_async_submit_wait_overlapping_streams(cref, golden):
-    """Three MSMs in flight on three streams; results identical to the synchronous calls, a fourth
-    submit is refused until a ticket has been awaited, unknown tickets are errors."""
+    """Eight MSMs in flight (every asynchronous slot) on three streams; results identical to the
+    synchronous calls, a ninth submit is refused until a ticket has been awaited, unknown tickets are
+    errors.  Two rounds: every slot is used again with other scalar buffers."""
     import torch
+    from halo2_experiments_amd.sharding import MAX_IN_FLIGHT
     g = golden["msm"]
-    names = ["n1024_uniform", "n1024_prover", "n1024_small"]
+    names = [["n1024_uniform", "n1024_prover", "n1024_small"][i % 3] for i in range(MAX_IN_FLIGHT)]
     hd = h.register_bases(g["n1024_uniform_b"])
     try:
-        streams = [torch.cuda.Stream() for _ in names]
-        tickets, keep = [], []
-        for name, st in zip(names, streams):
-            with torch.cuda.stream(st):
-                s_dev = torch.from_numpy(g[f"{name}_s"].view(np.int64).copy()).cuda()
-                keep.append(s_dev)
-                tickets.append(h.best_multiexp_submit(s_dev, hd))
-        with pytest.raises(_lib.Halo2Mi355xError):
-            h.best_multiexp_submit(keep[0], hd)                      # all three asynchronous slots are busy
-        assert g1_equal(h.best_multiexp(g["n255_uniform_s"], g["n255_uniform_b"]), g["n255_uniform_r"])   # sync path still free
-        for name, t in reversed(list(zip(names, tickets))):         # await out of order
-            assert g1_equal(h.best_multiexp_wait(t), g[f"{name}_r"]), name
-        with pytest.raises(_lib.Halo2Mi355xError):
-            h.best_multiexp_wait(tickets[0])
+        streams = [torch.cuda.Stream() for _ in range(3)]
+        for round_ in range(2):
+            tickets, keep = [], []
+            for i, name in enumerate(names):
+                with torch.cuda.stream(streams[i % 3]):
+                    s_dev = torch.from_numpy(g[f"{name}_s"].view(np.int64).copy()).cuda()
+                    keep.append(s_dev)
+                    tickets.append(h.best_multiexp_submit(s_dev, hd))
+            with pytest.raises(_lib.Halo2Mi355xError):
+                h.best_multiexp_submit(keep[0], hd)                  # every asynchronous slot is busy
+            assert g1_equal(h.best_multiexp(g["n255_uniform_s"], g["n255_uniform_b"]), g["n255_uniform_r"])   # sync path still free
+            for name, t in reversed(list(zip(names, tickets))):     # await out of order
+                assert g1_equal(h.best_multiexp_wait(t), g[f"{name}_r"]), (round_, name)
+            with pytest.raises(_lib.Halo2Mi355xError):
+                h.best_multiexp_wait(tickets[0])
         t = h.best_multiexp_submit(keep[0], hd)
         assert g1_equal(h.best_multiexp_wait(t), g["n1024_uniform_r"])
     finally:
