@@ -1,14 +1,16 @@
 // msm.hip -- Pippenger bucket MSM over BN256 G1 for gfx950 (replaces
 // halo2_proofs::arithmetic::best_multiexp, SURVEY.md §3.3: sum_i coeffs[i] * bases[i]).
 //
-// Pipeline (all device-resident; one mid-pipeline 8-byte readback to size the task grid):
+// Pipeline (all device-resident, nothing is read back before the final window sums):
 //   K0  digits      scalar (radix-2^256 Montgomery) -> canonical -> W signed c-bit digits
 //   K2  sort        two-level counting sort through LDS (coarse partition, then one workgroup per
 //                   region: fine histogram -> bucket counts; global scan -> bucket + task offsets;
 //                   in-region scatter) -> point indices grouped by bucket
+//   K2b task order  counting sort of the tasks by chain length, longest first: the 64 lanes of a
+//                   K3 wave run chains of equal length
 //   K3  accumulate  one lane per task (a bucket, or a <= L-long slice of a long bucket): a serial
-//                   chain of mixed additions, the accumulator living in registers
-//   K3b finalize    per bucket: sum of its task partials
+//                   chain of extended-Jacobian mixed additions, the accumulator living in registers
+//   K3b finalize    per bucket: sum of its task partials (lane / workgroup / sliced workgroups)
 //   K4a/K4b reduce  per window sum_b b*B_b by segmented running sums, then a tree in LDS
 //   host            Horner over the W window sums (c doublings each) and affine normalisation
 // Differences from the reference's CPU algorithm that do not change the (canonical) result:
