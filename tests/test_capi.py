@@ -96,3 +96,10 @@ def test_evaluation_domain_constants(pyref):
     assert d.g_coset == o.FR_ZETA and d.g_coset * d.g_coset_inv % o.R == 1
     assert EvaluationDomain(j=3, k=4).extended_k == 5 and EvaluationDomain(j=2, k=4).extended_k == 4
     assert fr_words(5).tolist() == o.fr_array([5])[0].tolist()
+
+
+def test_integration_doc_binds_every_entry_point():
+    """INTEGRATION.md shows the reference-side (Rust) `extern "C"` block: one item per header entry."""
+    text = open(os.path.join(os.path.dirname(os.path.abspath(_lib.HEADER_PATH)), "..", "INTEGRATION.md")).read()
+    for name in declared_symbols():
+        assert f"pub fn {name}(" in text, f"{name} has no binding in INTEGRATION.md"
