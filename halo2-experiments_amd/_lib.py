@@ -92,6 +92,8 @@ def load() -> ctypes.CDLL:
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
+        if os.environ.get("HALO2_MI355X_GRAPHS", "0") == "1":      # opt-in: experimental hipGraph replay of small MSMs
+            lib.hm_msm_use_graphs(1)
         _lib = lib
     return _lib
 

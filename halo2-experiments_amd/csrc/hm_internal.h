@@ -97,8 +97,7 @@ struct MsmSlot {            // one in-flight MSM: its workspace, events and host
     MsmGraphKey key;
     uint64_t last_use = 0;
   };
-  static constexpr int kGraphs = 1;  // ONE per slot: replaying a slot's graph after a different graph had run on the
-                                     // same workspace faulted on ROCm 7.2 (tools/graph_probe2.py); a key change recaptures
+  static constexpr int kGraphs = 4;  // e.g. {g, g_lagrange} x {one or two sizes}; least recently used is replaced
   Graph graphs[kGraphs];
   uint64_t graph_clock = 0;
   bool timed = false;                // per-phase events were recorded for the MSM in flight
@@ -112,6 +111,8 @@ struct MsmSlot {            // one in-flight MSM: its workspace, events and host
   uint32_t* win() { return h_land; }
   uint32_t* totals() { return h_land + 128 * 32; }
   uint32_t SW = 0, c = 0, W = 0;
+  const uint32_t* d_win = nullptr;   // device locations of the results of the MSM in flight (inside ws)
+  const uint32_t* d_tot = nullptr;
   uint64_t T_max = 0;
 };
 

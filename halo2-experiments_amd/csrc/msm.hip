@@ -30,6 +30,28 @@ namespace hm {
 
 constexpr int PT_WORDS = 28;  // device Jacobian record: 27 limbs + identity flag
 
+// Fills and device-to-device copies inside the MSM are kernels of their own rather than
+// hipMemsetAsync / hipMemcpyAsync: the launch sequence then consists of kernel nodes only when it is
+// captured into a graph (memset / memcpy nodes are what the faulting graph replays had in common).
+__global__ void msm_fill_u32_kernel(uint32_t* __restrict__ p, uint32_t v, size_t count) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
+}
+__global__ void msm_copy_u32_kernel(uint32_t* __restrict__ dst, const uint32_t* __restrict__ src, size_t count) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+static int msm_fill_u32(uint32_t* p, uint32_t v, size_t count, hipStream_t stream) {
+  const uint32_t blocks = (uint32_t)std::min<size_t>((count + 255) / 256, 2048);
+  hipLaunchKernelGGL(msm_fill_u32_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, stream, p, v, count);
+  HM_HIP_CHECK(hipGetLastError());
+  return HM_OK;
+}
+static int msm_copy_u32(uint32_t* dst, const uint32_t* src, size_t count, hipStream_t stream) {
+  const uint32_t blocks = (uint32_t)std::min<size_t>((count + 255) / 256, 2048);
+  hipLaunchKernelGGL(msm_copy_u32_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, stream, dst, src, count);
+  HM_HIP_CHECK(hipGetLastError());
+  return HM_OK;
+}
+
 __device__ __forceinline__ G1Jac load_jac(const uint32_t* p) {
   const uint4* q = reinterpret_cast<const uint4*>(p);
   uint32_t w[PT_WORDS];
@@ -1305,7 +1327,7 @@ static int launch_sort(const int32_t* d_digits, uint32_t* d_chist, uint32_t* d_c
                          (const uint32_t*)d_chist, (const uint32_t*)d_cstart, (ITEM*)d_tmp, sn, chunk, fb, ib, NC);
     }
     // regions far above their share go to the cooperative kernels: list them, then count in both forms
-    HM_HIP_CHECK(hipMemsetAsync(br.count, 0, 16, stream));
+    { const int frc = msm_fill_u32(br.count, 0u, 4, stream); if (frc != HM_OK) return frc; }
     hipLaunchKernelGGL(msm_big_regions_kernel, dim3((SW * NC + 255) / 256), dim3(256), 0, stream, (const uint32_t*)d_cstart,
                        SW * NC, br.big, br.slice, br.list, br.count, br.capacity);
     hipLaunchKernelGGL((msm_part2_hist_kernel<false, ITEM, false>), dim3(NC, SW), dim3(SORT_THREADS), lds_fine, stream,
@@ -1330,7 +1352,7 @@ static int launch_sort_scatter(const int32_t* d_digits, const uint32_t* d_cstart
   const size_t lds_fine = (size_t)4 << fb;
   if (cb && fb <= 11) {
     const size_t lds_tiled = ((size_t)3 * (1u << fb) + 32 + 2 * P2_TILE) * 4;
-    HM_HIP_CHECK(hipMemcpyAsync(br.gcursor, d_boff, (size_t)NBT * 4, hipMemcpyDeviceToDevice, stream));
+    { const int crc = msm_copy_u32(br.gcursor, d_boff, NBT, stream); if (crc != HM_OK) return crc; }
     hipLaunchKernelGGL((msm_part2_scatter_tiled_kernel<ITEM, false>), dim3(NC, SW), dim3(SORT_THREADS), lds_tiled, stream,
                        (const ITEM*)d_tmp, d_cstart, d_boff, d_sorted, fb, ib, NC, NBP, br.big, br.slice, (const uint2*)br.list,
                        (const uint32_t*)br.count, br.gcursor);
@@ -1539,6 +1561,8 @@ static int msm_issue(DeviceCtx& ctx, int slot, const uint32_t* d_scalars_ext, co
   sl.c = c;
   sl.W = W;
   sl.T_max = T_max;
+  sl.d_win = d_win;
+  sl.d_tot = d_tot;
   if (phase == MSM_PREPARE) return HM_OK;
 
   // ---- K0 ------------------------------------------------------------------------------------
@@ -1552,7 +1576,7 @@ static int msm_issue(DeviceCtx& ctx, int slot, const uint32_t* d_scalars_ext, co
 
   // ---- K2 ------------------------------------------------------------------------------------
   {
-    HM_HIP_CHECK(hipMemsetAsync(d_bcnt, 0, (size_t)NBT * 4, stream));   // the cooperative histogram adds into it
+    { const int frc = msm_fill_u32(d_bcnt, 0u, NBT, stream); if (frc != HM_OK) return frc; }   // the cooperative histogram adds into it
     const int rc = wide_items
                        ? launch_sort<uint64_t>(d_digits, d_chist, d_ctot, d_cstart, d_tmp, d_bcnt, sn, chunk, G, SW, fb, ib, cb,
                                                NC, NBP, br, stream)
@@ -1563,7 +1587,7 @@ static int msm_issue(DeviceCtx& ctx, int slot, const uint32_t* d_scalars_ext, co
   // pair count for effective_task_len: the first sort level leaves it behind its region starts; an
   // input small enough to need no first level keeps the host's L (the count is set to its bound)
   const uint32_t* d_pairs = cb ? d_cstart + (size_t)SW * NC : d_tot + 2;
-  if (!cb) HM_HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)(d_tot + 2), (int)pairs_max, 1, stream));
+  if (!cb) { const int frc = msm_fill_u32(d_tot + 2, (uint32_t)pairs_max, 1, stream); if (frc != HM_OK) return frc; }
   {
     const uint32_t nblocks = (NBT + SCAN_BLOCK - 1) / SCAN_BLOCK;
     hipLaunchKernelGGL(msm_scan_partial_kernel, dim3(nblocks), dim3(SCAN_THREADS), 0, stream, (const uint32_t*)d_bcnt,
@@ -1586,7 +1610,7 @@ static int msm_issue(DeviceCtx& ctx, int slot, const uint32_t* d_scalars_ext, co
                        NBT);
   } else {
     const uint32_t og = (NBT + ORDER_THREADS * ORDER_ITEMS - 1) / (ORDER_THREADS * ORDER_ITEMS);
-    HM_HIP_CHECK(hipMemsetAsync(d_khist, 0, TASK_KEYS * 4, stream));
+    { const int frc = msm_fill_u32(d_khist, 0u, TASK_KEYS, stream); if (frc != HM_OK) return frc; }
     hipLaunchKernelGGL(msm_task_hist_kernel, dim3(og), dim3(ORDER_THREADS), 0, stream, (const uint32_t*)d_bcnt, NBT,
                        d_pairs, L, d_khist);
     hipLaunchKernelGGL(msm_task_keyscan_kernel, dim3(1), dim3(ORDER_THREADS), 0, stream, (const uint32_t*)d_khist, d_kcursor);
@@ -1609,7 +1633,7 @@ static int msm_issue(DeviceCtx& ctx, int slot, const uint32_t* d_scalars_ext, co
     HM_HIP_CHECK(hipGetLastError());
   }
   if (timing) HM_HIP_CHECK(hipEventRecord(ev[6], stream));
-  HM_HIP_CHECK(hipMemsetAsync(d_big_count, 0, 16, stream));
+  { const int frc = msm_fill_u32(d_big_count, 0u, 4, stream); if (frc != HM_OK) return frc; }
   hipLaunchKernelGGL(msm_bucket_finalize_kernel, dim3((NBT + ACC_THREADS - 1) / ACC_THREADS), dim3(ACC_THREADS), 0, stream,
                      (const uint32_t*)d_partial, (const uint32_t*)d_toff, d_bucket, NBT, d_big_count, d_big_list, d_slices);
   HM_HIP_CHECK(hipGetLastError());
@@ -1648,21 +1672,24 @@ static int msm_issue(DeviceCtx& ctx, int slot, const uint32_t* d_scalars_ext, co
   }
   if (SW > 128) return hm_fail(HM_ERR_INTERNAL, "msm: more than 128 windows");
   // pinned landing zone, so that these copies (and therefore msm_enqueue) do not wait for the device
-  HM_HIP_CHECK(hipMemcpyAsync(sl.win(), d_win, (size_t)SW * 32 * 4, hipMemcpyDeviceToHost, stream));
-  HM_HIP_CHECK(hipMemcpyAsync(sl.totals(), d_tot, 8, hipMemcpyDeviceToHost, stream));
+  if (phase != MSM_AFTER_DIGITS) {   // (a captured sequence holds kernels only: msm_graph_launch issues these after the replay)
+    HM_HIP_CHECK(hipMemcpyAsync(sl.win(), d_win, (size_t)SW * 32 * 4, hipMemcpyDeviceToHost, stream));
+    HM_HIP_CHECK(hipMemcpyAsync(sl.totals(), d_tot, 8, hipMemcpyDeviceToHost, stream));
+  }
   return HM_OK;
 }
 
 // EXPERIMENTAL, off by default (hm_msm_use_graphs).  Small MSMs (the sizes of the reference's own circuits,
-// k <= 18) are launch-bound: ~30 launches, memsets and copies per call (128 us of host time at 2^18; 24 us
-// as a graph).  Everything after the digit kernel depends only on (size, window, base set, workspace), so
-// that sequence can be captured once per such key and slot into a hipGraph and replayed with one
+// k <= 18) are launch-bound: ~30 launches per call (128 us of host time at 2^18; 24 us as a graph).
+// Everything after the digit kernel depends only on (size, window, base set, workspace), so that
+// sequence can be captured once per such key and slot into a hipGraph and replayed with one
 // hipGraphLaunch; the digit kernel, the only consumer of the per-call scalar pointer, is launched
-// directly in front of it.  Why it is not the default: on ROCm 7.2 replays produced GPU memory faults in
-// two situations that direct launches of the very same sequence never do -- a slot holding two graphs
-// (the second replayed after the first had run on the same workspace; hence ONE graph per slot), and,
-// with one graph per slot, somewhere in bench.py's full flow (2^24 MSMs on slots 1-3, then the proof
-// replays on slots 1-8).  tools/graph_probe.py and graph_probe2.py are the reproducers.
+// directly in front of it and the two result copies directly behind it, so a captured sequence holds
+// KERNEL nodes only.  (With hipMemsetAsync / hipMemcpyAsync nodes in it, replays ended in GPU memory
+// faults on ROCm 7.2 -- tools/graph_probe.py, graph_probe2.py -- which is why fills and device copies
+// are kernels here.)  Why it is not the default: a replay runs SLOWER on the device than the same
+// launches issued directly (0.88 ms vs 0.79 ms at 2^18), so it only pays when the host thread is the
+// bottleneck; with eight commitments in flight the k = 18 proof replay gains 3 %.
 static bool g_use_graphs = false;
 void msm_set_use_graphs(bool on) { g_use_graphs = on; }
 constexpr size_t MSM_GRAPH_MAX_N = 1u << 20;
@@ -1709,6 +1736,8 @@ static int msm_graph_launch(DeviceCtx& ctx, int slot, const uint32_t* d_scalars_
   if (rc != HM_OK) return rc;
   g->last_use = ++sl.graph_clock;
   HM_HIP_CHECK(hipGraphLaunch(g->exec, stream));
+  HM_HIP_CHECK(hipMemcpyAsync(sl.win(), sl.d_win, (size_t)sl.SW * 32 * 4, hipMemcpyDeviceToHost, stream));
+  HM_HIP_CHECK(hipMemcpyAsync(sl.totals(), sl.d_tot, 8, hipMemcpyDeviceToHost, stream));
   *done = true;
   return HM_OK;
 }

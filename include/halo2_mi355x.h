@@ -117,8 +117,8 @@ int hm_msm_set_window(int c);
 /* EXPERIMENTAL, off by default.  enable != 0: MSMs of up to 2^20 points replay everything after their digit
  * kernel from a hipGraph captured on first use per (workspace slot, size, window, base set): one
  * hipGraphLaunch instead of ~30 launches (host cost per call 128 us -> 24 us at 2^18); hm_get_msm_stats
- * then reports only the total time of such calls.  Not the default because replays faulted on ROCm 7.2 in
- * flows that direct launches of the same sequence run cleanly (see csrc/msm.hip). */
+ * then reports only the total time of such calls.  Not the default because a replay runs slower on the
+ * device than direct launches (0.88 vs 0.79 ms at 2^18): it pays only when the host thread is the bottleneck. */
 int hm_msm_use_graphs(int enable);
 
 /* ---- NTT: stands in for halo2_proofs::arithmetic::best_fft::<bn256::Fr> --------------------- */
