@@ -158,18 +158,23 @@ def run_replay(shape_name: str, device=None, group=None, include_host_pointer_es
         return t
 
     proof_once()                                        # warm-up: tables, workspaces
-    if world > 1:
-        dist.barrier(group)
-    t0 = time.perf_counter()
-    phases = proof_once()
-    if world > 1:
-        dist.barrier(group)
-    wall = time.perf_counter() - t0
-    if world > 1:
-        comm_dev = device if dist.get_backend(group) == "nccl" else torch.device("cpu")
-        tt = torch.tensor([wall], dtype=torch.float64, device=comm_dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX, group=group)
-        wall = float(tt.item())
+    # launch-bound work on a shared host: the best of three replays (every rank runs all three)
+    wall, phases = None, None
+    for _ in range(3):
+        if world > 1:
+            dist.barrier(group)
+        t0 = time.perf_counter()
+        ph = proof_once()
+        if world > 1:
+            dist.barrier(group)
+        w = time.perf_counter() - t0
+        if world > 1:
+            comm_dev = device if dist.get_backend(group) == "nccl" else torch.device("cpu")
+            tt = torch.tensor([w], dtype=torch.float64, device=comm_dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX, group=group)
+            w = float(tt.item())
+        if wall is None or w < wall:
+            wall, phases = w, ph
 
     out = {
         "circuit": shape.name, "k": k, "extended_k": dom.extended_k, "n_gpus": world,
@@ -177,7 +182,8 @@ def run_replay(shape_name: str, device=None, group=None, include_host_pointer_es
                   "source": shape.source},
         "calls": counts,
         "device_resident_s": {"msm": phases["msm"], "ntt": phases["ntt"], "total": wall},
-        "note": "MSM/NTT trace replay on synthetic polynomials (no Rust toolchain here); CPU-side parts of create_proof excluded",
+        "note": "MSM/NTT trace replay on synthetic polynomials (no Rust toolchain here); CPU-side parts of create_proof "
+                "excluded; best of three replays",
     }
     if include_host_pointer_estimate and world == 1:
         # the drop-in (host-pointer) cost of the same trace: one representative call of each kind
