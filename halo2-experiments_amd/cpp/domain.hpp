@@ -78,16 +78,13 @@ class EvaluationDomain {
     if (a.len != n) throw std::invalid_argument("lagrange_to_coeff: a.len() != n");
     arithmetic::check(hm_ntt_batch_bn256_fr_dev(a.d, a.batch, omega_inv.l, k, ifft_divisor.l, nullptr, stream), "lagrange_to_coeff");
   }
-  // coeff_to_extended: zero-pad, distribute_powers_zeta, best_fft(extended_omega)
+  // coeff_to_extended: zero-pad, distribute_powers_zeta, best_fft(extended_omega) -- one call; the padded
+  // array is never materialised (the first pass reads the n coefficients only)
   DevicePolys coeff_to_extended(const DevicePolys& a, hipStream_t stream = nullptr) const {
     if (a.len != n) throw std::invalid_argument("coeff_to_extended: a.len() != n");
     DevicePolys ext(extended_len(), a.batch);
-    if (hipMemsetAsync(ext.d, 0, ext.len * ext.batch * sizeof(Fr), stream) != hipSuccess) throw std::runtime_error("memset failed");
-    if (hipMemcpy2DAsync(ext.d, ext.len * sizeof(Fr), a.d, a.len * sizeof(Fr), a.len * sizeof(Fr), a.batch, hipMemcpyDeviceToDevice,
-                         stream) != hipSuccess)
-      throw std::runtime_error("pad copy failed");
     const Fr coset[3] = {Fr::one(), g_coset, g_coset.square()};
-    arithmetic::check(hm_ntt_batch_bn256_fr_dev(ext.d, ext.batch, extended_omega.l, extended_k, nullptr, coset[0].l, stream),
+    arithmetic::check(hm_coeff_to_extended_bn256_fr_dev(a.d, ext.d, a.batch, extended_omega.l, k, extended_k, coset[0].l, stream),
                       "coeff_to_extended");
     return ext;
   }

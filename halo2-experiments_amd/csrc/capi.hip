@@ -482,6 +482,39 @@ int hm_ntt_batch_bn256_fr_dev(void* d_a, size_t batch, const uint64_t omega[4], 
   return ntt_run(*ctx, (uint32_t*)d_a, omega, log_n, (uint32_t)batch, d_scale, d_coset, (hipStream_t)stream);
 }
 
+int hm_coeff_to_extended_bn256_fr_dev(const void* d_coeffs, void* d_ext, size_t batch, const uint64_t extended_omega[4],
+                                      uint32_t log_n, uint32_t log_ext, const uint64_t* coset, void* stream) {
+  if ((batch && (!d_coeffs || !d_ext)) || !extended_omega)
+    return hm_fail(HM_ERR_BAD_ARG, "hm_coeff_to_extended_bn256_fr_dev: null argument");
+  if (log_ext < log_n || log_ext > 28) return hm_fail(HM_ERR_BAD_ARG, "hm_coeff_to_extended_bn256_fr_dev: need log_n <= log_ext <= 28");
+  if (batch > 65535) return hm_fail(HM_ERR_BAD_ARG, "hm_coeff_to_extended_bn256_fr_dev: batch > 65535");
+  if (batch == 0) return HM_OK;
+  DeviceCtx* ctx = ctx_for_current_device();
+  if (!ctx) return HM_ERR_NO_DEVICE;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  uint32_t* d_coset = nullptr;
+  if (coset) {
+    uint64_t ext[16];
+    std::memset(ext, 0, sizeof ext);
+    std::memcpy(ext + 4, coset, 96);
+    uint32_t* d_int = nullptr;
+    int rc = small_consts(*ctx, ext, 4, (hipStream_t)stream, &d_int);
+    if (rc != HM_OK) return rc;
+    d_coset = d_int + 9;
+  }
+  const uint32_t log_z = log_ext - log_n;
+  int passes = 0;
+  const int first_digit = ntt_plan_first_digit(log_ext, &passes);
+  if (log_z > 0 && passes >= 2 && (int)log_z <= first_digit)    // the zero part is never written or read
+    return ntt_run(*ctx, (uint32_t*)d_ext, extended_omega, log_ext, (uint32_t)batch, nullptr, d_coset, (hipStream_t)stream,
+                   (const uint32_t*)d_coeffs, log_z);
+  // small or un-extended domains: materialise the padded arrays, then the ordinary in-place transform
+  const size_t row_in = (size_t)32 << log_n, row_out = (size_t)32 << log_ext;
+  if (log_z) HM_HIP_CHECK(hipMemsetAsync(d_ext, 0, row_out * batch, (hipStream_t)stream));
+  HM_HIP_CHECK(hipMemcpy2DAsync(d_ext, row_out, d_coeffs, row_in, row_in, batch, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return ntt_run(*ctx, (uint32_t*)d_ext, extended_omega, log_ext, (uint32_t)batch, nullptr, d_coset, (hipStream_t)stream);
+}
+
 int hm_ntt_bn256_fr(uint64_t* a, const uint64_t omega[4], uint32_t log_n) {
   if (!a || !omega) return hm_fail(HM_ERR_BAD_ARG, "hm_ntt_bn256_fr: null argument");
   if (log_n > 28) return hm_fail(HM_ERR_BAD_ARG, "hm_ntt_bn256_fr: log_n > 28");

@@ -144,7 +144,9 @@ DeviceCtx* ctx_for_current_device();
 
 // ntt.hip
 int ntt_run(DeviceCtx& ctx, uint32_t* d_a, const uint64_t omega_ext[4], uint32_t log_n, uint32_t batch,
-            const uint32_t* d_scale_int, const uint32_t* d_coset_int, hipStream_t stream);
+            const uint32_t* d_scale_int, const uint32_t* d_coset_int, hipStream_t stream, const uint32_t* d_in = nullptr,
+            uint32_t log_z = 0);
+int ntt_plan_first_digit(uint32_t log_n, int* passes);
 int fr_scale_run(uint32_t* d_a, const uint32_t* d_c_ext, uint64_t n, hipStream_t stream);
 int fr_mul_pattern3_run(uint32_t* d_a, const uint32_t* d_c3_ext, uint64_t n, hipStream_t stream);
 int fr_ext_to_int_run(const uint32_t* d_c_ext, uint32_t* d_out, uint32_t count, hipStream_t stream);

@@ -94,6 +94,8 @@ struct NttPassParams {
   uint32_t has_scale;    // last pass: multiply by `scale` (internal-form constant) instead of ONE
   uint32_t has_coset;    // first pass: multiply a[i] by coset[i % 3] on load
   uint32_t direct_tw;    // non-last pass: tw_lo holds omega_m^e for every e < m (no forming product)
+  uint32_t log_z;        // first pass of an extending transform: the input holds only the first n >> log_z
+                         // coefficients (the rest are zero by definition); 0 = ordinary transform
 };
 
 // everything a register round needs
@@ -176,7 +178,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(const uint32_t* i
   const uint32_t cmask = (1u << log_c) - 1u;
   const uint64_t tile = blockIdx.x;
   // batched transforms: blockIdx.y selects one of `gridDim.y` back-to-back arrays of n elements
-  in += ((size_t)blockIdx.y << pp.log_n) * 8;
+  in += ((size_t)blockIdx.y << (pp.log_n - pp.log_z)) * 8;   // an extending first pass reads compact input arrays
   out += ((size_t)blockIdx.y << pp.log_n) * 8;
 
   // ---- tile -> global index mapping ---------------------------------------------------------
@@ -202,7 +204,12 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(const uint32_t* i
   };
 
   // ---- load: unpack to 29-bit limbs, scatter to the bit-reversed digit position -------------
-  for (uint32_t e = tid; e < tile_elems; e += NTT_THREADS) {
+  // Extending first pass (log_z > 0, EvaluationDomain::coeff_to_extended): only digit values
+  // d < R >> log_z carry coefficients, the rest of the zero-padded array is never read.  Their
+  // bit-reversed positions are multiples of 2^log_z, and DIT stages 0 .. log_z-1 pair each of them with
+  // zeros only -- (a, 0) -> (a, a), no product -- so the value is stored to the 2^log_z positions of its
+  // group at once and the rounds start at stage log_z.
+  for (uint32_t e = tid; e < (tile_elems >> pp.log_z); e += NTT_THREADS) {
     uint32_t d, c;
     uint64_t g;
     if (!pp.last) {
@@ -226,7 +233,13 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(const uint32_t* i
       HM_DECLARE(cz, 2.0);
       x = fe_mul(x, cz);
     }
-    lds_store<LOG_TILE>(lds, (bitrev(d, s) << log_c) + c, x);
+    if (pp.log_z == 0) {
+      lds_store<LOG_TILE>(lds, (bitrev(d, s) << log_c) + c, x);
+    } else {
+      if (!pp.has_coset) x = fe_reduce_small(x);              // raw 256-bit words: bring below 3r like a product
+      const uint32_t p0 = bitrev(d, s);                        // low log_z bits are zero
+      for (uint32_t t = 0; t < (1u << pp.log_z); ++t) lds_store<LOG_TILE>(lds, ((p0 + t) << log_c) + c, x);
+    }
   }
   __syncthreads();
 
@@ -235,7 +248,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(const uint32_t* i
   cx.tid = tid; cx.s = s; cx.log_c = log_c; cx.cmask = cmask; cx.tile_elems = tile_elems;
   cx.i0 = i0; cx.base = base; cx.dest_lo0 = dest_lo0;
   // split s into rounds of 3 stages, ending 3 / 2+2 / 3+2 so that no round is a single stage unless s == 1
-  uint32_t q0 = 0;
+  uint32_t q0 = pp.log_z;
   while (q0 < s) {
     uint32_t r = s - q0;
     if (r > 2) r = 2;
@@ -365,6 +378,12 @@ static int plan_digits(uint32_t log_n, uint32_t digits[3]) {
   return passes;
 }
 
+int ntt_plan_first_digit(uint32_t log_n, int* passes) {
+  uint32_t digits[3] = {0, 0, 0};
+  *passes = plan_digits(log_n, digits);
+  return (int)digits[0];
+}
+
 NttTables* ntt_get_tables(DeviceCtx& ctx, const uint64_t omega_ext[4], uint32_t log_n, hipStream_t stream) {
   for (auto& t : ctx.ntt_tables)
     if (t->log_n == log_n && std::memcmp(t->omega, omega_ext, 32) == 0) return t.get();
@@ -406,8 +425,12 @@ NttTables* ntt_get_tables(DeviceCtx& ctx, const uint64_t omega_ext[4], uint32_t 
 
 // d_a: `batch` back-to-back arrays of n x 32 B on the device, each transformed in place.  d_scale_int / d_coset_int: optional 9-limb
 // internal-form constants already on the device.
+// d_in != nullptr: an extending transform (EvaluationDomain::coeff_to_extended): `batch` compact arrays of
+// n >> log_z coefficients at d_in, zero-padded to n by definition, transformed into d_a (out of place;
+// the zero part is never materialised and the first log_z stages of the first pass cost nothing).
 int ntt_run(DeviceCtx& ctx, uint32_t* d_a, const uint64_t omega_ext[4], uint32_t log_n, uint32_t batch,
-            const uint32_t* d_scale_int, const uint32_t* d_coset_int, hipStream_t stream) {
+            const uint32_t* d_scale_int, const uint32_t* d_coset_int, hipStream_t stream, const uint32_t* d_in,
+            uint32_t log_z) {
   if (log_n > 28) return hm_fail(HM_ERR_BAD_ARG, "ntt: log_n > 28 (Fr has 2-adicity 28)");
   if (batch == 0) return HM_OK;
   if (batch > 65535) return hm_fail(HM_ERR_BAD_ARG, "ntt: batch > 65535");
@@ -427,6 +450,8 @@ int ntt_run(DeviceCtx& ctx, uint32_t* d_a, const uint64_t omega_ext[4], uint32_t
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     ctx.ntt_attr_set = true;
   }
+  if (d_in && (passes < 2 || log_z == 0 || log_z > digits[0]))
+    return hm_fail(HM_ERR_INTERNAL, "ntt: extending form needs a multi-pass plan and log_z <= first digit");
   uint32_t log_stride = log_n;
   for (int p = 0; p < passes; ++p) {
     NttPassParams pp{};
@@ -440,12 +465,13 @@ int ntt_run(DeviceCtx& ctx, uint32_t* d_a, const uint64_t omega_ext[4], uint32_t
     pp.log_r0 = (pp.last && passes == 3) ? digits[0] : 0u;
     pp.has_scale = (pp.last && d_scale_int) ? 1u : 0u;
     pp.has_coset = (p == 0 && d_coset_int) ? 1u : 0u;
+    pp.log_z = (p == 0 && d_in) ? log_z : 0u;
     uint32_t log_c = (uint32_t)LOG_TILE > pp.s ? (uint32_t)LOG_TILE - pp.s : 0u;
     const uint32_t avail = pp.last ? pp.log_rows : pp.log_stride;  // columns / rows that exist
     if (log_c > avail) log_c = avail;
     pp.log_c = log_c;
     const uint64_t tiles = n >> (pp.s + log_c);
-    const uint32_t* src = (p == 0) ? d_a : scratch;
+    const uint32_t* src = (p == 0) ? (d_in ? d_in : d_a) : scratch;
     uint32_t* dst = (p == passes - 1) ? d_a : scratch;
     const uint32_t* lo_tab = tab->d_lo;
     if (!pp.last) {

@@ -88,12 +88,13 @@ class EvaluationDomain:
 
         batch = self._batch_of(a, self.n, "coeff_to_extended")
         en = self.extended_len()
-        ext = torch.zeros((batch, en, 4), dtype=a.dtype, device=a.device)
-        ext[:, : self.n] = a.reshape(batch, self.n, 4)
+        a = a.contiguous()
+        ext = torch.empty((batch, en, 4), dtype=a.dtype, device=a.device)      # the zero part is never materialised
         r = FR_MODULUS
         coset = np.concatenate([fr_words(1), fr_words(self.g_coset), fr_words(self.g_coset * self.g_coset % r)])
-        _lib.check(_lib.load().hm_ntt_batch_bn256_fr_dev(ctypes.c_void_p(ext.data_ptr()), batch, _ptr(fr_words(self.extended_omega)),
-                                                          self.extended_k, None, _ptr(coset), ctypes.c_void_p(_stream_ptr(ext))))
+        _lib.check(_lib.load().hm_coeff_to_extended_bn256_fr_dev(
+            ctypes.c_void_p(a.data_ptr()), ctypes.c_void_p(ext.data_ptr()), batch, _ptr(fr_words(self.extended_omega)), self.k,
+            self.extended_k, _ptr(coset), ctypes.c_void_p(_stream_ptr(ext))))
         return ext if a.dim() == 3 else ext[0]
 
     def extended_to_coeff(self, a):

@@ -145,6 +145,15 @@ int hm_ifft_bn256_fr_dev(void* d_a, const uint64_t omega_inv[4], uint32_t log_n,
  * with coset = {1, g, g^2}) fused into the first pass of best_fft(a, omega_ext, log_n).
  * The caller has already zero-padded a to 2^log_n. */
 int hm_coset_ntt_bn256_fr_dev(void* d_a, const uint64_t omega[4], uint32_t log_n, const uint64_t coset[12], void* stream);
+/* EvaluationDomain::coeff_to_extended in one call (halo2_proofs poly/domain.rs: resize to the extended
+ * domain with zeros, distribute_powers_zeta, best_fft with extended_omega): `batch` compact coefficient
+ * arrays of 2^log_n x 32 B at d_coeffs -> `batch` arrays of 2^log_ext evaluations at d_ext (out of
+ * place, d_ext need not be initialised).  coset = {1, zeta, zeta^2} as for hm_coset_ntt_bn256_fr_dev,
+ * or NULL.  The zero-padded part is never materialised: the first pass reads only the coefficients, and
+ * the log_ext - log_n butterfly stages that would pair them with zeros cost nothing. */
+int hm_coeff_to_extended_bn256_fr_dev(const void* d_coeffs, void* d_ext, size_t batch, const uint64_t extended_omega[4],
+                                      uint32_t log_n, uint32_t log_ext, const uint64_t* coset, void* stream);
+
 /* a[i] *= c element-wise (device pointer, in place). */
 int hm_fr_scale_dev(void* d_a, size_t n, const uint64_t c[4], void* stream);
 /* EvaluationDomain::distribute_powers_zeta on its own: a[i] *= c3[i % 3] (device pointer, in place). */

@@ -146,3 +146,37 @@ def test_batched_transforms_equal_single_ones(pyref):
     assert torch.equal(ext_single, ext_batched)
     back = d.extended_to_coeff(ext_batched.clone())
     assert torch.equal(back[:, : d.n], batched) and not back[:, d.n:].any()
+
+
+@pytest.mark.parametrize("k,j", [(3, 7), (6, 3), (8, 7), (9, 2), (11, 4), (13, 10), (14, 7), (18, 7), (19, 7), (20, 3)])
+def test_coeff_to_extended_never_materialises_the_zero_part(k, j):
+    """hm_coeff_to_extended_bn256_fr_dev (compact input, first log_z butterfly stages skipped) against the
+    plain composition it replaces: zero-pad, coset shift fused into an ordinary in-place NTT.  Covers the
+    single-pass fallback, two- and three-pass plans, log_z = 0 .. 4, batches, and the coset-less form."""
+    import ctypes
+    import torch
+    from halo2_experiments_amd import _lib
+    from halo2_experiments_amd.arithmetic import _ptr, _stream_ptr
+    from halo2_experiments_amd.domain import FR_MODULUS
+    d = EvaluationDomain(j=j, k=k)
+    n, en = d.n, d.extended_len()
+    batch = 3 if k <= 14 else 2
+    a = rand_fr_gpu(batch * n, 7000 + 31 * k + j).reshape(batch, n, 4)
+    lib = _lib.load()
+    coset = np.concatenate([fr_words(1), fr_words(d.g_coset), fr_words(d.g_coset * d.g_coset % FR_MODULUS)])
+    for with_coset in (True, False):
+        padded = torch.zeros((batch, en, 4), dtype=a.dtype, device=a.device)
+        padded[:, :n] = a
+        _lib.check(lib.hm_ntt_batch_bn256_fr_dev(ctypes.c_void_p(padded.data_ptr()), batch, _ptr(fr_words(d.extended_omega)),
+                                                  d.extended_k, None, _ptr(coset) if with_coset else None,
+                                                  ctypes.c_void_p(_stream_ptr(padded))))
+        ext = torch.full((batch, en, 4), -1, dtype=a.dtype, device=a.device)      # garbage: the call must overwrite all of it
+        _lib.check(lib.hm_coeff_to_extended_bn256_fr_dev(ctypes.c_void_p(a.data_ptr()), ctypes.c_void_p(ext.data_ptr()), batch,
+                                                          _ptr(fr_words(d.extended_omega)), d.k, d.extended_k,
+                                                          _ptr(coset) if with_coset else None, ctypes.c_void_p(_stream_ptr(ext))))
+        torch.cuda.synchronize()
+        assert torch.equal(ext, padded), (k, j, with_coset)
+    if k == 8:
+        assert lib.hm_coeff_to_extended_bn256_fr_dev(None, None, 1, _ptr(fr_words(d.extended_omega)), 8, 11, None, None) == -1
+        assert lib.hm_coeff_to_extended_bn256_fr_dev(ctypes.c_void_p(a.data_ptr()), ctypes.c_void_p(ext.data_ptr()), 1,
+                                                     _ptr(fr_words(d.extended_omega)), 12, 11, None, None) == -1
