@@ -129,6 +129,7 @@ __global__ void msm_convert_bases_kernel(const uint32_t* __restrict__ ext, uint3
 // count, so that K3 still gets >= TARGET_TASKS chains to fill the chip with.
 constexpr uint32_t TARGET_TASKS = 327680;   // 256 CUs x 4 SIMDs x 5 waves x 64 lanes
 __device__ __forceinline__ uint32_t effective_task_len(const uint32_t* __restrict__ pairs, uint32_t L_host) {
+  if (pairs == nullptr) return L_host;
   const uint32_t by_fill = pairs[0] / TARGET_TASKS;
   const uint32_t L = L_host < by_fill ? L_host : by_fill;
   return L < 16u ? 16u : L;
@@ -1080,7 +1081,10 @@ __global__ __launch_bounds__(ACC_THREADS) void msm_reduce_segments_kernel(const 
 
 // K4b: sum `count` points per window down to ceil(count / SUM_SPAN) (one workgroup per span: strided
 // serial sums then an LDS tree); applied until one point per window is left.
-constexpr uint32_t SUM_SPAN = WIN_THREADS * 16;
+#ifndef HM_SUM_PER_LANE
+#define HM_SUM_PER_LANE 4     // measured: 4 beats 16 by 0.06-0.07 ms at every size (more workgroups, shorter serial sums)
+#endif
+constexpr uint32_t SUM_SPAN = WIN_THREADS * HM_SUM_PER_LANE;
 __global__ __launch_bounds__(WIN_THREADS) void msm_sum_points_kernel(const uint32_t* __restrict__ in, uint32_t count,
                                                                      uint32_t* __restrict__ out, uint32_t out_count) {
   __shared__ uint32_t tree[WIN_THREADS * PT_WORDS];
@@ -1394,15 +1398,15 @@ static int msm_issue(DeviceCtx& ctx, int slot, const uint32_t* d_scalars_ext, co
   } else if (g_window_override > 0) {
     c = (uint32_t)g_window_override;
   } else {
-    // mean bucket load n / 2^(c-1) ~ 16: short accumulation chains, (almost) no bucket splitting,
-    // fewest (point, bucket) pairs.  Cap: c = 17 gives W = 15 windows that cover the 255 digit bits
-    // exactly (measured at 2^24: 25.9 ms vs 28.1 ms for c = 16).  Larger c would need fewer windows
-    // still, but 18, 19 and 21 leave a top window of 3-8 bits whose few buckets receive all n points
-    // (one sort region, one workgroup), and c = 20's 6.8 M buckets cost more to reduce than they save.
-    int ci = (int)ilog2(n) - 3;
-    if (ci < 4) ci = 4;
-    const int cap = n >= (1u << 21) ? 17 : 16;
-    if (ci > cap) ci = cap;
+    // Rule of thumb: log2(n) - 3 (mean bucket load ~16: short chains, almost no bucket splitting, few
+    // (point, bucket) pairs), capped at c = 17, whose W = 15 windows cover the 255 digit bits exactly
+    // (18, 19 and 21 leave a top window of 3-8 bits whose few buckets receive all n points, and c = 20's
+    // 6.8 M buckets cost more to reduce than they save).  The table is the measured optimum per size
+    // (tools/msm_sweep.py <k> <c,c,...>): between 2^15 and 2^17 the fixed costs of the sort and of the
+    // bucket reduction move it up to c = 15.
+    static const int8_t kWindow[21] = {4, 4, 4, 4, 4, 4, 4, 4, 5, 6, 7, 8, 9, 10, 10, 13, 15, 15, 15, 16, 17};
+    const uint32_t lg = ilog2(n);
+    int ci = lg <= 20 ? kWindow[lg] : 17;
     c = (uint32_t)ci;
   }
   if (c < 2 || c > 24) return hm_fail(HM_ERR_BAD_ARG, "msm: window size out of range");
@@ -1422,7 +1426,8 @@ static int msm_issue(DeviceCtx& ctx, int slot, const uint32_t* d_scalars_ext, co
   uint32_t L = (uint32_t)(HM_L_MEAN_SCALE * mean + HM_L_SIGMAS * std::sqrt(mean) + 8.0);
   {
     // small inputs: if one task per bucket would leave the chip (256 CUs x 4 SIMDs x ~5 waves x 64
-    // lanes) mostly idle, cut the tasks shorter so that the launch still fills it
+    // lanes) mostly idle, cut the tasks shorter so that the launch still fills it (measured: a wave per
+    // SIMD is not enough -- K3 at 2^16..2^18 is 15-40 % slower with one task per bucket)
     const double target_tasks = 327680.0;
     if ((double)pairs_max / (double)L < target_tasks) L = (uint32_t)((double)pairs_max / target_tasks);
   }
@@ -1442,7 +1447,13 @@ static int msm_issue(DeviceCtx& ctx, int slot, const uint32_t* d_scalars_ext, co
   // (and never more than one per pair)
   const uint64_t T_max = std::min<uint64_t>(pairs_max, std::max<uint64_t>(pairs_max / L, 2ull * TARGET_TASKS) + NBT) + 1;
   // K4a: running-sum chain of 2*SEG additions per lane + a scalar multiple of <= log2(NB) bits
-  uint32_t SEG = NB > (1u << 16) ? 32u : 8u;
+  // Segment length of K4a, measured per bucket count (the kernel is latency-bound: a lane's chain is
+  // 2*SEG additions plus a log2(NB/SEG)-bit multiple, and the number of lanes decides how well the chip hides it)
+#ifdef HM_SEG_SMALL
+  uint32_t SEG = NB > (1u << 16) ? 32u : HM_SEG_SMALL;
+#else
+  uint32_t SEG = NB > (1u << 16) ? 32u : NB == (1u << 15) ? 16u : NB <= (1u << 13) ? 4u : 8u;
+#endif
   if (SEG > NB) SEG = NB;
   const uint32_t nseg = (NB + SEG - 1) / SEG;
   // sort plan: item = [fine bucket bits | sign | item index]
@@ -1585,9 +1596,8 @@ static int msm_issue(DeviceCtx& ctx, int slot, const uint32_t* d_scalars_ext, co
     if (rc != HM_OK) return rc;
   }
   // pair count for effective_task_len: the first sort level leaves it behind its region starts; an
-  // input small enough to need no first level keeps the host's L (the count is set to its bound)
-  const uint32_t* d_pairs = cb ? d_cstart + (size_t)SW * NC : d_tot + 2;
-  if (!cb) { const int frc = msm_fill_u32(d_tot + 2, (uint32_t)pairs_max, 1, stream); if (frc != HM_OK) return frc; }
+  // input small enough to need no first level keeps the host's L
+  const uint32_t* d_pairs = cb ? (const uint32_t*)(d_cstart + (size_t)SW * NC) : (const uint32_t*)nullptr;
   {
     const uint32_t nblocks = (NBT + SCAN_BLOCK - 1) / SCAN_BLOCK;
     hipLaunchKernelGGL(msm_scan_partial_kernel, dim3(nblocks), dim3(SCAN_THREADS), 0, stream, (const uint32_t*)d_bcnt,
