@@ -408,3 +408,18 @@ def test_repeated_and_opposite_bases_inside_bucket_chains(cref, pyref, pattern):
         assert g1_equal(h.best_multiexp(s, hd), exp)
     finally:
         h.release_bases(hd)
+
+
+@pytest.mark.parametrize("n", [257, 600, 1500, 2049, 4097, 6000, 8191, 12000, 20000, 40000, 70000])
+def test_ragged_small_sizes_across_the_window_table(cref, pyref, n):
+    """One size inside every entry of the window table below 2^17 (and the bucket-reduction segment
+    rule that goes with it), none of them a power of two; uniform and prover-like scalars."""
+    o = pyref
+    gen = cref.g1_generator()
+    bases = h.g1_fixed_base_mul(rand_fr_gpu(n, 4000 + n % 97), gen).cpu().numpy().view(np.uint64).copy()
+    uni = rand_fr_gpu(n, 5000 + n % 89).cpu().numpy().view(np.uint64)
+    tile = o.fr_array(o.rand_scalars(257, n, "prover"))
+    pro = np.concatenate([np.tile(tile, (n // 257, 1)), tile[: n % 257]])
+    for s in (uni, pro):
+        exp = cref.g1_to_affine(cref.best_multiexp(s, bases, 4))[0]
+        assert g1_equal(h.best_multiexp(s, bases), exp)
