@@ -188,7 +188,10 @@ __global__ void msm_digits_kernel(const uint32_t* __restrict__ scalars, const ui
 // When fine bits + sign + index bits fit 32 bits with cb = 0 (n <= 2^19) part 1 disappears and
 // part 2 reads the digits directly.
 // ---------------------------------------------------------------------------------------------
-constexpr int SORT_THREADS = 1024;
+#ifndef HM_SORT_THREADS
+#define HM_SORT_THREADS 1024
+#endif
+constexpr int SORT_THREADS = HM_SORT_THREADS;
 
 // cnt[bin]++ in LDS, returning the old value.  Lanes of a wave that hit the SAME counter serialise
 // in the LDS atomic unit, and constant or flag columns (every scalar equal, or 0/1) put whole waves
@@ -380,7 +383,7 @@ __global__ __launch_bounds__(SORT_THREADS) void msm_part1_scatter_tiled_kernel(c
     __syncthreads();
     {   // exclusive scan of tcnt[0 .. NC)
       const uint32_t b0 = tid * per;
-      uint32_t v[4] = {0, 0, 0, 0}, sum = 0;
+      uint32_t v[4096 / SORT_THREADS] = {}, sum = 0;
       for (uint32_t k = 0; k < per; ++k)
         if (b0 + k < NC) { v[k] = tcnt[b0 + k]; sum += v[k]; }
       uint32_t incl = sum;
@@ -590,7 +593,7 @@ __global__ __launch_bounds__(SORT_THREADS) void msm_part2_scatter_tiled_kernel(c
     // exclusive scan of tcnt[0 .. NF): lane-serial over `per` entries, wave scan, then wave totals
     {
       const uint32_t b0 = tid * per;
-      uint32_t v[2] = {0, 0}, sum = 0;
+      uint32_t v[2048 / SORT_THREADS] = {}, sum = 0;
       for (uint32_t k = 0; k < per; ++k)
         if (b0 + k < NF) { v[k] = tcnt[b0 + k]; sum += v[k]; }
       uint32_t incl = sum;
