@@ -22,7 +22,10 @@
 
 namespace hm {
 
-constexpr int NTT_THREADS = 512;
+#ifndef HM_NTT_THREADS
+#define HM_NTT_THREADS 512
+#endif
+constexpr int NTT_THREADS = HM_NTT_THREADS;
 
 // ---------------------------------------------------------------------------------------------
 // twiddle tables
@@ -356,7 +359,10 @@ __global__ void fr_ext_to_int_kernel(const uint32_t* __restrict__ c_ext, uint32_
 // ---------------------------------------------------------------------------------------------
 // host side: plan + launch
 // ---------------------------------------------------------------------------------------------
-constexpr int LOG_TILE = 11;
+#ifndef HM_NTT_LOG_TILE
+#define HM_NTT_LOG_TILE 11
+#endif
+constexpr int LOG_TILE = HM_NTT_LOG_TILE;
 constexpr uint32_t NTT_DIRECT_LOG = 16;   // sub-problems up to 2^16 get a direct inter-pass twiddle table (2.4 MB)
 
 static int plan_digits(uint32_t log_n, uint32_t digits[3]) {
