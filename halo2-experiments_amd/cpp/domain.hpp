@@ -81,12 +81,18 @@ class EvaluationDomain {
   // coeff_to_extended: zero-pad, distribute_powers_zeta, best_fft(extended_omega) -- one call; the padded
   // array is never materialised (the first pass reads the n coefficients only)
   DevicePolys coeff_to_extended(const DevicePolys& a, hipStream_t stream = nullptr) const {
-    if (a.len != n) throw std::invalid_argument("coeff_to_extended: a.len() != n");
     DevicePolys ext(extended_len(), a.batch);
+    coeff_to_extended(a, ext, stream);
+    return ext;
+  }
+  // ... into a caller-owned buffer (a prover keeps its extended-domain buffers for the whole proof:
+  // hipMalloc / hipFree per polynomial cost more than the transform); the first a.batch rows of ext are written
+  void coeff_to_extended(const DevicePolys& a, DevicePolys& ext, hipStream_t stream = nullptr) const {
+    if (a.len != n) throw std::invalid_argument("coeff_to_extended: a.len() != n");
+    if (ext.len != extended_len() || ext.batch < a.batch) throw std::invalid_argument("coeff_to_extended: ext too small");
     const Fr coset[3] = {Fr::one(), g_coset, g_coset.square()};
     arithmetic::check(hm_coeff_to_extended_bn256_fr_dev(a.d, ext.d, a.batch, extended_omega.l, k, extended_k, coset[0].l, stream),
                       "coeff_to_extended");
-    return ext;
   }
   // extended_to_coeff: ifft over the extended domain, undo the coset shift (caller truncates to n*(j-1))
   void extended_to_coeff(DevicePolys& a, hipStream_t stream = nullptr) const {

@@ -134,8 +134,8 @@ int main(int argc, char** argv) {
     const auto t_pk1 = Clock::now();
 
     // create_proof (utils.rs:40-48): the MSM / NTT trace of SURVEY.md §3.2.  The commitments of one
-    // phase are independent: eight (every asynchronous slot of the library) are kept in flight on four streams.
-    constexpr uint32_t kInFlight = 8, kStreams = 4;
+    // phase are independent: eight (every asynchronous slot of the library) are kept in flight on eight streams.
+    constexpr uint32_t kInFlight = 8, kStreams = 8;
     hipStream_t streams[kStreams];
     for (auto& st : streams) (void)hipStreamCreate(&st);
     (void)hipDeviceSynchronize();
@@ -152,6 +152,8 @@ int main(int argc, char** argv) {
       while (inflight) { (void)poly::ParamsKZG::commit_wait(pending[head]); head = (head + 1) % kInFlight; --inflight; }
     };
     commit_phase(kInFlight, d_dense.d, true);                      // warm-up: allocates the asynchronous workspaces
+    // the prover's polynomial buffers live for the whole proof (as halo2's Vec<Polynomial> do)
+    poly::DevicePolys batch(n, 8), ext(dom.extended_len(), 8), hpoly(dom.extended_len(), 1);
     const auto t_pr0 = Clock::now();
     size_t n_msm = 0, n_ntt = 0;
     commit_phase(advice + 2 * lookups, d_sparse.d, true);          // advice, permuted lookup columns
@@ -161,18 +163,19 @@ int main(int argc, char** argv) {
       const size_t polys = advice + 1 + 3 * lookups + zp;
       for (size_t done = 0; done < polys; done += 8) {
         const size_t b = polys - done < 8 ? polys - done : 8;
-        poly::DevicePolys batch(n, b);
-        for (size_t i = 0; i < b; ++i) (void)hipMemcpy(batch.poly(i), d_dense.d, n * sizeof(Fr), hipMemcpyDeviceToDevice);
+        batch.batch = b;                                           // a view of the first b rows
+        for (size_t i = 0; i < b; ++i)
+          (void)hipMemcpyAsync(batch.poly(i), d_dense.d, n * sizeof(Fr), hipMemcpyDeviceToDevice, nullptr);
         dom.lagrange_to_coeff(batch);                              // lagrange_to_coeff per polynomial
-        poly::DevicePolys ext = dom.coeff_to_extended(batch);      // coeff_to_extended per polynomial
+        dom.coeff_to_extended(batch, ext);                         // coeff_to_extended per polynomial
         n_ntt += 2 * b;
         if (done + b >= polys) {                                   // h(X): back to coefficients once
-          poly::DevicePolys h(ext.len, 1);
-          (void)hipMemcpy(h.d, ext.d, ext.len * sizeof(Fr), hipMemcpyDeviceToDevice);
-          dom.extended_to_coeff(h);
+          (void)hipMemcpyAsync(hpoly.d, ext.d, ext.len * sizeof(Fr), hipMemcpyDeviceToDevice, nullptr);
+          dom.extended_to_coeff(hpoly);
           ++n_ntt;
         }
       }
+      batch.batch = 8;
     }
     commit_phase((max_degree - 1) + 2, d_dense.d, false);          // h pieces, SHPLONK
     n_msm += (max_degree - 1) + 2;
