@@ -30,26 +30,21 @@ namespace hm {
 
 constexpr int PT_WORDS = 28;  // device Jacobian record: 27 limbs + identity flag
 
-// Fills and device-to-device copies inside the MSM are kernels of their own rather than
-// hipMemsetAsync / hipMemcpyAsync: the launch sequence then consists of kernel nodes only when it is
-// captured into a graph (memset / memcpy nodes are what the faulting graph replays had in common).
-__global__ void msm_fill_u32_kernel(uint32_t* __restrict__ p, uint32_t v, size_t count) {
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
-}
-__global__ void msm_copy_u32_kernel(uint32_t* __restrict__ dst, const uint32_t* __restrict__ src, size_t count) {
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
-}
-static int msm_fill_u32(uint32_t* p, uint32_t v, size_t count, hipStream_t stream) {
-  const uint32_t blocks = (uint32_t)std::min<size_t>((count + 255) / 256, 2048);
-  hipLaunchKernelGGL(msm_fill_u32_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, stream, p, v, count);
-  HM_HIP_CHECK(hipGetLastError());
-  return HM_OK;
-}
-static int msm_copy_u32(uint32_t* dst, const uint32_t* src, size_t count, hipStream_t stream) {
-  const uint32_t blocks = (uint32_t)std::min<size_t>((count + 255) / 256, 2048);
-  hipLaunchKernelGGL(msm_copy_u32_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, stream, dst, src, count);
-  HM_HIP_CHECK(hipGetLastError());
-  return HM_OK;
+// Counters are cleared by a kernel of the MSM's own rather than hipMemsetAsync (and the one device-to-device
+// copy the sort needs is folded into the scan that produces its source): the launch sequence then
+// consists of kernel nodes only when it is captured into a graph -- memset / memcpy nodes are what the
+// faulting graph replays had in common.  Every counter an MSM starts from zero goes in ONE launch: the
+// bucket counts (the cooperative histogram adds into them), the big-region list count, the task-length
+// key histogram, the hot-bucket queue counts.
+__global__ void msm_init_counters_kernel(uint32_t* __restrict__ bcnt, size_t nbt, uint32_t* __restrict__ br_count,
+                                         uint32_t* __restrict__ khist, uint32_t nkeys, uint32_t* __restrict__ big_count) {
+  const size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = i0; i < nbt; i += stride) bcnt[i] = 0;
+  if (i0 < nkeys) khist[i0] = 0;
+  if (i0 < 4) {
+    if (br_count) br_count[i0] = 0;
+    big_count[i0] = 0;
+  }
 }
 
 __device__ __forceinline__ G1Jac load_jac(const uint32_t* p) {
@@ -718,7 +713,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void msm_scan_final_kernel(const uint
                                                                       const uint32_t* __restrict__ blocksums,
                                                                       uint32_t* __restrict__ boff, uint32_t* __restrict__ toff,
                                                                       const uint32_t* __restrict__ totals, uint32_t NBT,
-                                                                      const uint32_t* __restrict__ pairs, uint32_t L_host) {
+                                                                      const uint32_t* __restrict__ pairs, uint32_t L_host,
+                                                                      uint32_t* __restrict__ gcursor) {
   __shared__ uint32_t s_p[SCAN_THREADS], s_t[SCAN_THREADS];
   const uint32_t L = effective_task_len(pairs, L_host);
   const uint32_t base = blockIdx.x * SCAN_BLOCK + threadIdx.x * SCAN_ITEMS;
@@ -738,6 +734,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void msm_scan_final_kernel(const uint
     if (base + k < NBT) {
       boff[base + k] = rp;
       toff[base + k] = rt;
+      if (gcursor) gcursor[base + k] = rp;   // the cooperative scatter's global per-bucket cursors start at the offsets
     }
     rp += c[k];
     rt += (c[k] + L - 1) / L;
@@ -1334,7 +1331,6 @@ static int launch_sort(const int32_t* d_digits, uint32_t* d_chist, uint32_t* d_c
                          (const uint32_t*)d_chist, (const uint32_t*)d_cstart, (ITEM*)d_tmp, sn, chunk, fb, ib, NC);
     }
     // regions far above their share go to the cooperative kernels: list them, then count in both forms
-    { const int frc = msm_fill_u32(br.count, 0u, 4, stream); if (frc != HM_OK) return frc; }
     hipLaunchKernelGGL(msm_big_regions_kernel, dim3((SW * NC + 255) / 256), dim3(256), 0, stream, (const uint32_t*)d_cstart,
                        SW * NC, br.big, br.slice, br.list, br.count, br.capacity);
     hipLaunchKernelGGL((msm_part2_hist_kernel<false, ITEM, false>), dim3(NC, SW), dim3(SORT_THREADS), lds_fine, stream,
@@ -1359,7 +1355,6 @@ static int launch_sort_scatter(const int32_t* d_digits, const uint32_t* d_cstart
   const size_t lds_fine = (size_t)4 << fb;
   if (cb && fb <= 11) {
     const size_t lds_tiled = ((size_t)3 * (1u << fb) + 32 + 2 * P2_TILE) * 4;
-    { const int crc = msm_copy_u32(br.gcursor, d_boff, NBT, stream); if (crc != HM_OK) return crc; }
     hipLaunchKernelGGL((msm_part2_scatter_tiled_kernel<ITEM, false>), dim3(NC, SW), dim3(SORT_THREADS), lds_tiled, stream,
                        (const ITEM*)d_tmp, d_cstart, d_boff, d_sorted, fb, ib, NC, NBP, br.big, br.slice, (const uint2*)br.list,
                        (const uint32_t*)br.count, br.gcursor);
@@ -1590,7 +1585,12 @@ static int msm_issue(DeviceCtx& ctx, int slot, const uint32_t* d_scalars_ext, co
 
   // ---- K2 ------------------------------------------------------------------------------------
   {
-    { const int frc = msm_fill_u32(d_bcnt, 0u, NBT, stream); if (frc != HM_OK) return frc; }   // the cooperative histogram adds into it
+    {
+      const uint32_t blocks = (uint32_t)std::min<size_t>(((size_t)NBT + 255) / 256, 2048);
+      hipLaunchKernelGGL(msm_init_counters_kernel, dim3(blocks < 4 ? 4 : blocks), dim3(256), 0, stream, d_bcnt, (size_t)NBT,
+                         cb ? br.count : (uint32_t*)nullptr, d_khist, TASK_KEYS, d_big_count);
+      HM_HIP_CHECK(hipGetLastError());
+    }
     const int rc = wide_items
                        ? launch_sort<uint64_t>(d_digits, d_chist, d_ctot, d_cstart, d_tmp, d_bcnt, sn, chunk, G, SW, fb, ib, cb,
                                                NC, NBP, br, stream)
@@ -1607,7 +1607,8 @@ static int msm_issue(DeviceCtx& ctx, int slot, const uint32_t* d_scalars_ext, co
                        d_bsum, NBT, d_pairs, L);
     hipLaunchKernelGGL(msm_scan_blocksums_kernel, dim3(1), dim3(SCAN_THREADS), 0, stream, d_bsum, nblocks, d_tot);
     hipLaunchKernelGGL(msm_scan_final_kernel, dim3(nblocks), dim3(SCAN_THREADS), 0, stream, (const uint32_t*)d_bcnt,
-                       (const uint32_t*)d_bsum, d_boff, d_toff, (const uint32_t*)d_tot, NBT, d_pairs, L);
+                       (const uint32_t*)d_bsum, d_boff, d_toff, (const uint32_t*)d_tot, NBT, d_pairs, L,
+                       coop_sort ? br.gcursor : (uint32_t*)nullptr);
     HM_HIP_CHECK(hipGetLastError());
   }
   {
@@ -1623,7 +1624,6 @@ static int msm_issue(DeviceCtx& ctx, int slot, const uint32_t* d_scalars_ext, co
                        NBT);
   } else {
     const uint32_t og = (NBT + ORDER_THREADS * ORDER_ITEMS - 1) / (ORDER_THREADS * ORDER_ITEMS);
-    { const int frc = msm_fill_u32(d_khist, 0u, TASK_KEYS, stream); if (frc != HM_OK) return frc; }
     hipLaunchKernelGGL(msm_task_hist_kernel, dim3(og), dim3(ORDER_THREADS), 0, stream, (const uint32_t*)d_bcnt, NBT,
                        d_pairs, L, d_khist);
     hipLaunchKernelGGL(msm_task_keyscan_kernel, dim3(1), dim3(ORDER_THREADS), 0, stream, (const uint32_t*)d_khist, d_kcursor);
@@ -1646,7 +1646,6 @@ static int msm_issue(DeviceCtx& ctx, int slot, const uint32_t* d_scalars_ext, co
     HM_HIP_CHECK(hipGetLastError());
   }
   if (timing) HM_HIP_CHECK(hipEventRecord(ev[6], stream));
-  { const int frc = msm_fill_u32(d_big_count, 0u, 4, stream); if (frc != HM_OK) return frc; }
   hipLaunchKernelGGL(msm_bucket_finalize_kernel, dim3((NBT + ACC_THREADS - 1) / ACC_THREADS), dim3(ACC_THREADS), 0, stream,
                      (const uint32_t*)d_partial, (const uint32_t*)d_toff, d_bucket, NBT, d_big_count, d_big_list, d_slices);
   HM_HIP_CHECK(hipGetLastError());
