@@ -107,9 +107,9 @@ struct MsmSlot {            // one in-flight MSM: its workspace, events and host
   uint64_t ticket = 0;
   size_t n = 0;
   hipStream_t stream = nullptr;
-  uint32_t* h_land = nullptr;   // pinned host landing zone: [0, 128*32) window sums, then 4 totals words
-  uint32_t* win() { return h_land; }
-  uint32_t* totals() { return h_land + 128 * 32; }
+  uint32_t* h_land = nullptr;   // pinned host landing zone: 4 totals words, then the window sums (as on the device)
+  uint32_t* totals() { return h_land; }
+  uint32_t* win() { return h_land + 4; }
   uint32_t SW = 0, c = 0, W = 0;
   const uint32_t* d_win = nullptr;   // device locations of the results of the MSM in flight (inside ws)
   const uint32_t* d_tot = nullptr;

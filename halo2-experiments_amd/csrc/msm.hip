@@ -1479,7 +1479,6 @@ static int msm_issue(DeviceCtx& ctx, int slot, const uint32_t* d_scalars_ext, co
   const size_t o_bcnt = carve((size_t)NBT * 4);
   const size_t o_boff = carve((size_t)NBT * 4);
   const size_t o_toff = carve(((size_t)NBT + 1) * 4);
-  const size_t o_tot = carve(16);
   const size_t o_bsum = carve(((size_t)NBT / SCAN_BLOCK + 2) * 8);
   const size_t o_sorted = carve(pairs_max * 4);
   const size_t o_tb = carve(T_max * 4);
@@ -1489,7 +1488,7 @@ static int msm_issue(DeviceCtx& ctx, int slot, const uint32_t* d_scalars_ext, co
   const size_t o_bucket = carve((size_t)NBT * PT_WORDS * 4);
   const size_t o_seg = carve((size_t)SW * nseg * PT_WORDS * 4);
   const size_t o_seg2 = carve(((size_t)SW * (nseg / SUM_SPAN + 1)) * PT_WORDS * 4);
-  const size_t o_win = carve((size_t)SW * 32 * 4);
+  const size_t o_res = carve((4 + (size_t)SW * 32) * 4);   // results: 4 totals words, then the window sums (one D2H copy)
   const size_t o_big = carve(((size_t)NBT + 4) * 4);
   const size_t o_slices = carve((T_max / FINALIZE_SLICE + T_max / (FINALIZE_SERIAL + 1) + 2) * 8);
   // cooperative sort of oversized regions (hot buckets): split anything above 4x the mean region
@@ -1516,7 +1515,6 @@ static int msm_issue(DeviceCtx& ctx, int slot, const uint32_t* d_scalars_ext, co
   uint32_t* d_bcnt = (uint32_t*)(ws + o_bcnt);
   uint32_t* d_boff = (uint32_t*)(ws + o_boff);
   uint32_t* d_toff = (uint32_t*)(ws + o_toff);
-  uint32_t* d_tot = (uint32_t*)(ws + o_tot);
   uint32_t* d_bsum = (uint32_t*)(ws + o_bsum);
   uint32_t* d_sorted = (uint32_t*)(ws + o_sorted);
   uint32_t* d_tb = (uint32_t*)(ws + o_tb);
@@ -1527,7 +1525,8 @@ static int msm_issue(DeviceCtx& ctx, int slot, const uint32_t* d_scalars_ext, co
   uint32_t* d_bucket = (uint32_t*)(ws + o_bucket);
   uint32_t* d_seg = (uint32_t*)(ws + o_seg);
   uint32_t* d_seg2 = (uint32_t*)(ws + o_seg2);
-  uint32_t* d_win = (uint32_t*)(ws + o_win);
+  uint32_t* d_tot = (uint32_t*)(ws + o_res);
+  uint32_t* d_win = d_tot + 4;
   uint32_t* d_big_count = (uint32_t*)(ws + o_big);
   uint32_t* d_big_list = d_big_count + 4;
   uint2* d_slices = (uint2*)(ws + o_slices);
@@ -1685,8 +1684,7 @@ static int msm_issue(DeviceCtx& ctx, int slot, const uint32_t* d_scalars_ext, co
   if (SW > 128) return hm_fail(HM_ERR_INTERNAL, "msm: more than 128 windows");
   // pinned landing zone, so that these copies (and therefore msm_enqueue) do not wait for the device
   if (phase != MSM_AFTER_DIGITS) {   // (a captured sequence holds kernels only: msm_graph_launch issues these after the replay)
-    HM_HIP_CHECK(hipMemcpyAsync(sl.win(), d_win, (size_t)SW * 32 * 4, hipMemcpyDeviceToHost, stream));
-    HM_HIP_CHECK(hipMemcpyAsync(sl.totals(), d_tot, 8, hipMemcpyDeviceToHost, stream));
+    HM_HIP_CHECK(hipMemcpyAsync(sl.totals(), d_tot, (4 + (size_t)SW * 32) * 4, hipMemcpyDeviceToHost, stream));
   }
   return HM_OK;
 }
@@ -1748,8 +1746,7 @@ static int msm_graph_launch(DeviceCtx& ctx, int slot, const uint32_t* d_scalars_
   if (rc != HM_OK) return rc;
   g->last_use = ++sl.graph_clock;
   HM_HIP_CHECK(hipGraphLaunch(g->exec, stream));
-  HM_HIP_CHECK(hipMemcpyAsync(sl.win(), sl.d_win, (size_t)sl.SW * 32 * 4, hipMemcpyDeviceToHost, stream));
-  HM_HIP_CHECK(hipMemcpyAsync(sl.totals(), sl.d_tot, 8, hipMemcpyDeviceToHost, stream));
+  HM_HIP_CHECK(hipMemcpyAsync(sl.totals(), sl.d_tot, (4 + (size_t)sl.SW * 32) * 4, hipMemcpyDeviceToHost, stream));
   *done = true;
   return HM_OK;
 }
