@@ -28,6 +28,15 @@ class MsmStats(ctypes.Structure):
                 ("tasks", ctypes.c_uint64), ("window_bits", ctypes.c_uint32), ("windows", ctypes.c_uint32)]
 
 
+class Stats(ctypes.Structure):
+    """hm_stats: per-call counters since start / hm_reset_stats (include/halo2_mi355x.h)."""
+    _fields_ = [("msm_calls", ctypes.c_uint64), ("msm_points", ctypes.c_uint64), ("ntt_calls", ctypes.c_uint64),
+                ("ntt_elements", ctypes.c_uint64), ("msm_calls_by_log2", ctypes.c_uint64 * 32),
+                ("ntt_calls_by_log2", ctypes.c_uint64 * 32), ("msm_h2d_us", ctypes.c_double), ("msm_device_us", ctypes.c_double),
+                ("msm_host_us", ctypes.c_double), ("ntt_h2d_us", ctypes.c_double), ("ntt_device_us", ctypes.c_double),
+                ("ntt_d2h_us", ctypes.c_double), ("h2d_bytes", ctypes.c_uint64), ("d2h_bytes", ctypes.c_uint64)]
+
+
 def build(force: bool = False) -> str:
     """Compile every HIP source for gfx950 into csrc/libhalo2_mi355x.so (in-tree) with hipcc."""
     args = ["make", "-C", CSRC, "-j4"]
@@ -59,7 +68,6 @@ _SIGNATURES = {
     "hm_coeff_to_extended_bn256_fr_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, _u64p, ctypes.c_uint32,
                                                          ctypes.c_uint32, _u64p, ctypes.c_void_p]),
     "hm_msm_set_window": (ctypes.c_int, [ctypes.c_int]),
-    "hm_msm_use_graphs": (ctypes.c_int, [ctypes.c_int]),
     "hm_set_msm_devices": (ctypes.c_int, [ctypes.POINTER(ctypes.c_int), ctypes.c_int]),
     "hm_ntt_bn256_fr": (ctypes.c_int, [_u64p, _u64p, ctypes.c_uint32]),
     "hm_ntt_bn256_fr_dev": (ctypes.c_int, [_vp, _u64p, ctypes.c_uint32, _vp]),
@@ -69,7 +77,10 @@ _SIGNATURES = {
     "hm_fr_scale_dev": (ctypes.c_int, [_vp, ctypes.c_size_t, _u64p, _vp]),
     "hm_fr_distribute_powers_dev": (ctypes.c_int, [_vp, ctypes.c_size_t, _u64p, _vp]),
     "hm_g1_fixed_base_mul_dev": (ctypes.c_int, [_vp, ctypes.c_size_t, _u64p, _vp, _vp]),
+    "hm_extended_to_coeff_bn256_fr_dev": (ctypes.c_int, [_vp, ctypes.c_size_t, _u64p, ctypes.c_uint32, _u64p, _u64p, _vp]),
     "hm_get_msm_stats": (ctypes.c_int, [ctypes.POINTER(MsmStats)]),
+    "hm_get_stats": (ctypes.c_int, [ctypes.POINTER(Stats)]),
+    "hm_reset_stats": (ctypes.c_int, []),
 }
 
 _lib = None
@@ -94,8 +105,6 @@ def load() -> ctypes.CDLL:
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
-        if os.environ.get("HALO2_MI355X_GRAPHS", "0") == "1":      # opt-in: experimental hipGraph replay of small MSMs
-            lib.hm_msm_use_graphs(1)
         _lib = lib
     return _lib
 

@@ -97,11 +97,10 @@ class EvaluationDomain {
   // extended_to_coeff: ifft over the extended domain, undo the coset shift (caller truncates to n*(j-1))
   void extended_to_coeff(DevicePolys& a, hipStream_t stream = nullptr) const {
     if (a.len != extended_len()) throw std::invalid_argument("extended_to_coeff: a.len() != extended_len()");
-    arithmetic::check(hm_ntt_batch_bn256_fr_dev(a.d, a.batch, extended_omega_inv.l, extended_k, extended_ifft_divisor.l, nullptr, stream),
-                      "extended_to_coeff");
     const Fr c3[3] = {Fr::one(), g_coset_inv, g_coset_inv.square()};
-    for (size_t b = 0; b < a.batch; ++b)
-      arithmetic::check(hm_fr_distribute_powers_dev(a.poly(b), a.len, c3[0].l, stream), "extended_to_coeff");
+    arithmetic::check(hm_extended_to_coeff_bn256_fr_dev(a.d, a.batch, extended_omega_inv.l, extended_k, extended_ifft_divisor.l,
+                                                        c3[0].l, stream),
+                      "extended_to_coeff");
   }
 };
 

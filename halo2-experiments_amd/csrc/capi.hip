@@ -2,6 +2,7 @@
 // Host pointers in, host results out; device staging, base-set caching and locking live here.
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <map>
 #include <thread>
 #include <vector>
@@ -22,6 +23,32 @@ int hm_fail(int code, const std::string& what) {
 }
 
 void msm_set_window_override(int c);  // msm.hip
+
+static double now_us() {
+  return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+static void count_msm(DeviceCtx& ctx, size_t n) {
+  uint32_t lg = 0;
+  while ((n >> (lg + 1)) != 0) ++lg;
+  ctx.calls.msm_calls += 1;
+  ctx.calls.msm_points += n;
+  ctx.calls.msm_by_log[lg & 31] += 1;
+  ctx.calls.msm_device_us += ctx.last_msm.t_total_ms * 1e3;
+}
+
+static void free_bases_entry(DeviceCtx& ctx, BasesEntry& b) {
+  // no kernel reads these buffers any more (synchronous calls have returned, tickets were awaited):
+  // park them for the next registration of that size instead of hipFree (which waits for the whole device)
+  if (ctx.free_bases.size() < 4) {
+    ctx.free_bases.push_back(FreeBases{b.d_xy, b.d_inf, b.xy_bytes, b.inf_bytes});
+  } else {
+    if (b.d_xy) (void)hipFree(b.d_xy);
+    if (b.d_inf) (void)hipFree(b.d_inf);
+  }
+  b.d_xy = nullptr;
+  b.d_inf = nullptr;
+}
 
 DeviceCtx* ctx_for_current_device() {
   int count = 0;
@@ -69,11 +96,30 @@ static int register_from_device(DeviceCtx& ctx, const uint32_t* d_ext, size_t n,
     if ((uint64_t)n * e.pc_W >= (1ull << 31)) { e.pc_c = 0; e.pc_W = 0; }
   }
   const size_t copies = e.pc_c ? e.pc_W : 1;
-  HM_HIP_CHECK(hipMalloc((void**)&e.d_xy, n ? n * 64 * copies : 64));
-  HM_HIP_CHECK(hipMalloc((void**)&e.d_inf, n ? n : 1));
+  const size_t xy_bytes = n ? n * 64 * copies : 64, inf_bytes = n ? n : 1;
+  // buffers of a released set of the same size are reused (a caller that registers per call -- the
+  // tensor form of best_multiexp -- then never reaches hipMalloc / hipFree and their device-wide waits)
+  for (size_t i = 0; i < ctx.free_bases.size(); ++i) {
+    if (ctx.free_bases[i].xy_bytes == xy_bytes && ctx.free_bases[i].inf_bytes == inf_bytes) {
+      e.d_xy = ctx.free_bases[i].d_xy;
+      e.d_inf = ctx.free_bases[i].d_inf;
+      ctx.free_bases.erase(ctx.free_bases.begin() + i);
+      break;
+    }
+  }
+  if (!e.d_xy) {
+    HM_HIP_CHECK(hipMalloc((void**)&e.d_xy, xy_bytes));
+    if (hipMalloc((void**)&e.d_inf, inf_bytes) != hipSuccess) {
+      (void)hipFree(e.d_xy);
+      return hm_fail(HM_ERR_HIP, "register bases: allocation failed");
+    }
+  }
+  e.xy_bytes = xy_bytes;
+  e.inf_bytes = inf_bytes;
   int rc = msm_convert_bases(d_ext, e.d_xy, e.d_inf, n, stream);
   if (rc == HM_OK && e.pc_c) rc = msm_precompute(e.d_xy, e.d_inf, n, e.pc_c, e.pc_W, stream);
   if (rc != HM_OK) {
+    (void)hipStreamSynchronize(stream);
     (void)hipFree(e.d_xy);
     (void)hipFree(e.d_inf);
     return rc;
@@ -126,37 +172,33 @@ int hm_shutdown(void) {
   DeviceCtx& c = *it->second;
   std::lock_guard<std::mutex> lk2(c.mu);
   (void)hipDeviceSynchronize();
-  for (auto& t : c.ntt_tables) {
-    if (t->d_omega) (void)hipFree(t->d_omega);
-    if (t->d_lo) (void)hipFree(t->d_lo);
-    if (t->d_hi) (void)hipFree(t->d_hi);
-    if (t->d_mid) (void)hipFree(t->d_mid);
-    for (auto& s : t->d_stage)
-      if (s) (void)hipFree(s);
-  }
+  for (auto& t : c.ntt_tables) ntt_tables_release(*t);
   c.ntt_tables.clear();
-  for (auto& b : c.bases) {
-    if (b.d_xy) (void)hipFree(b.d_xy);
-    if (b.d_inf) (void)hipFree(b.d_inf);
+  for (auto* list : {&c.bases, &c.zombie_bases}) {
+    for (auto& b : *list) {
+      if (b.d_xy) (void)hipFree(b.d_xy);
+      if (b.d_inf) (void)hipFree(b.d_inf);
+    }
+    list->clear();
   }
-  c.bases.clear();
-  c.scratch.release(); c.io.release(); c.io_bases.release(); c.conv_bases.release(); c.conv_inf.release();
-  if (c.capture_stream) { (void)hipStreamDestroy(c.capture_stream); c.capture_stream = nullptr; }
+  for (auto& f : c.free_bases) {
+    if (f.d_xy) (void)hipFree(f.d_xy);
+    if (f.d_inf) (void)hipFree(f.d_inf);
+  }
+  c.free_bases.clear();
+  c.io.release(); c.io_bases.release(); c.conv_bases.release(); c.conv_inf.release();
+  for (auto& a : c.aux) {
+    a.scratch.release();
+    a.table.release();
+    if (a.done) (void)hipEventDestroy(a.done);
+    a = AuxSlot{};
+  }
   for (auto& sl : c.msm_slots) {
-    msm_slot_release_graph(sl);
     sl.ws.release();
     sl.busy = false;
     if (sl.h_land) { (void)hipHostFree(sl.h_land); sl.h_land = nullptr; }
     if (sl.ev_ready) { for (auto& e : sl.ev) (void)hipEventDestroy(e); sl.ev_ready = false; }
   }
-  c.small.release();
-  c.cached_host_bases = nullptr;
-  c.cached_host_n = 0;
-  return HM_OK;
-}
-
-int hm_msm_use_graphs(int enable) {
-  msm_set_use_graphs(enable != 0);
   return HM_OK;
 }
 
@@ -224,9 +266,13 @@ int hm_release_bases(uint64_t handle) {
   std::lock_guard<std::mutex> lk(ctx->mu);
   for (size_t i = 0; i < ctx->bases.size(); ++i) {
     if (ctx->bases[i].handle == handle) {
-      (void)hipDeviceSynchronize();
-      if (ctx->bases[i].d_xy) (void)hipFree(ctx->bases[i].d_xy);
-      if (ctx->bases[i].d_inf) (void)hipFree(ctx->bases[i].d_inf);
+      // Every synchronous user has returned by now; only an un-awaited ticket can still read the set.
+      // Then the buffers outlive the handle until that ticket's hm_msm_wait -- never a device-wide wait.
+      bool in_flight = false;
+      for (int k = 1; k < HM_MSM_SLOTS; ++k)
+        if (ctx->msm_slots[k].busy && ctx->msm_slots[k].bases_handle == handle) in_flight = true;
+      if (in_flight) ctx->zombie_bases.push_back(ctx->bases[i]);
+      else free_bases_entry(*ctx, ctx->bases[i]);
       ctx->bases.erase(ctx->bases.begin() + i);
       return HM_OK;
     }
@@ -244,8 +290,10 @@ int hm_msm_bn256_g1_dev(uint64_t handle, size_t offset, const void* d_scalars, s
   if (offset > b->n || n > b->n - offset) return hm_fail(HM_ERR_BAD_ARG, "hm_msm_bn256_g1_dev: offset + n exceeds the base set");
   int is_id = 0;
   const uint32_t pc = (offset == 0 && n == b->n) ? b->pc_c : 0u;   // the table only fits whole-set calls
-  return msm_run(*ctx, (const uint32_t*)d_scalars, b->d_xy + offset * 16, b->d_inf + offset, n, pc, out_xyz, &is_id,
-                 (hipStream_t)stream);
+  const int rc = msm_run(*ctx, (const uint32_t*)d_scalars, b->d_xy + offset * 16, b->d_inf + offset, n, pc, out_xyz, &is_id,
+                         (hipStream_t)stream);
+  if (rc == HM_OK) count_msm(*ctx, n);
+  return rc;
 }
 
 int hm_msm_submit_dev(uint64_t handle, size_t offset, const void* d_scalars, size_t n, void* stream, uint64_t* out_ticket) {
@@ -265,6 +313,7 @@ int hm_msm_submit_dev(uint64_t handle, size_t offset, const void* d_scalars, siz
                              (hipStream_t)stream);
   if (rc != HM_OK) return rc;
   ctx->msm_slots[slot].busy = true;
+  ctx->msm_slots[slot].bases_handle = handle;
   ctx->msm_slots[slot].ticket = ctx->next_ticket++;
   *out_ticket = ctx->msm_slots[slot].ticket;
   return HM_OK;
@@ -281,6 +330,16 @@ int hm_msm_wait(uint64_t ticket, uint64_t out_xyz[12]) {
       int is_id = 0;
       const int rc = msm_finish(*ctx, i, out_xyz, &is_id);
       sl.busy = false;
+      if (rc == HM_OK) count_msm(*ctx, sl.n);
+      // a base set released while this ticket was in flight: free it once no other ticket reads it
+      for (size_t z = 0; z < ctx->zombie_bases.size();) {
+        bool used = false;
+        for (int k = 1; k < HM_MSM_SLOTS; ++k)
+          if (ctx->msm_slots[k].busy && ctx->msm_slots[k].bases_handle == ctx->zombie_bases[z].handle) used = true;
+        if (used) { ++z; continue; }
+        free_bases_entry(*ctx, ctx->zombie_bases[z]);
+        ctx->zombie_bases.erase(ctx->zombie_bases.begin() + z);
+      }
       return rc;
     }
   }
@@ -298,55 +357,48 @@ int hm_msm_bn256_g1_h(uint64_t handle, size_t offset, const uint64_t* scalars, s
   if (offset > b->n || n > b->n - offset) return hm_fail(HM_ERR_BAD_ARG, "hm_msm_bn256_g1_h: offset + n exceeds the base set");
   void* d_s = ctx->io.ensure(n ? n * 32 : 32);
   if (!d_s) return hm_fail(HM_ERR_HIP, "hm_msm_bn256_g1_h: staging allocation failed");
+  const double t0 = now_us();
   HM_HIP_CHECK(hipMemcpy(d_s, scalars, n * 32, hipMemcpyHostToDevice));
+  ctx->calls.msm_h2d_us += now_us() - t0;
+  ctx->calls.h2d_bytes += n * 32;
   uint64_t jac[12];
   int is_id = 0;
   const uint32_t pc = (offset == 0 && n == b->n) ? b->pc_c : 0u;
   int rc = msm_run(*ctx, (const uint32_t*)d_s, b->d_xy + offset * 16, b->d_inf + offset, n, pc, jac, &is_id, nullptr);
   if (rc != HM_OK) return rc;
+  count_msm(*ctx, n);
   return jac_to_affine_out(jac, is_id, out_xy, out_is_identity);
 }
 
+// The drop-in form of best_multiexp: both arrays are host memory and both cross PCIe in the call.  The
+// library keeps NO pointer-keyed cache of the bases: a caller that reuses a buffer (a Rust Vec freed and
+// re-allocated at the same address with the same length, as the verifier's MSMs do) must never get a
+// commitment against stale points.  Callers that own a long-lived SRS use hm_register_bases once.
 static int msm_host_one(const uint64_t* scalars, const uint64_t* bases, size_t n, uint64_t jac[12], int* is_id) {
   DeviceCtx* ctx = ctx_for_current_device();
   if (!ctx) return HM_ERR_NO_DEVICE;
   std::lock_guard<std::mutex> lk(ctx->mu);
   if (n == 0) return msm_run(*ctx, nullptr, nullptr, nullptr, 0, 0, jac, is_id, nullptr);
-  // base cache: same pointer, same length and the same fingerprint of 64 sampled points => reuse the
-  // converted copy (create_proof passes the same params.g / g_lagrange slices to every commitment)
-  uint64_t probe[4] = {bases[0], bases[(n - 1) * 8 + 7], 0x9E3779B97F4A7C15ULL, n};
-  for (size_t k = 0; k < 64; ++k) {
-    const size_t i = (n * k) / 64;
-    for (int w = 0; w < 8; ++w) {
-      probe[2] = (probe[2] ^ bases[i * 8 + w]) * 0x100000001B3ULL;
-      probe[3] = ((probe[3] << 7) | (probe[3] >> 57)) ^ bases[i * 8 + w];
-    }
-  }
-  const bool hit = ctx->cached_host_bases == (const void*)bases && ctx->cached_host_n == n &&
-                   std::memcmp(probe, ctx->cached_probe, sizeof probe) == 0;
   uint32_t* d_xy = (uint32_t*)ctx->conv_bases.ensure(n * 64);
   uint8_t* d_inf = (uint8_t*)ctx->conv_inf.ensure(n);
-  if (!d_xy || !d_inf) return hm_fail(HM_ERR_HIP, "hm_msm_bn256_g1: base buffer allocation failed");
-  if (!hit) {
-    ctx->cached_host_bases = nullptr;
-    void* stage = ctx->io_bases.ensure(n * 64);
-    if (!stage) return hm_fail(HM_ERR_HIP, "hm_msm_bn256_g1: staging allocation failed");
-    HM_HIP_CHECK(hipMemcpy(stage, bases, n * 64, hipMemcpyHostToDevice));
-    int rc = msm_convert_bases((const uint32_t*)stage, d_xy, d_inf, n, nullptr);
-    if (rc != HM_OK) return rc;
-    ctx->cached_host_bases = bases;
-    ctx->cached_host_n = n;
-    std::memcpy(ctx->cached_probe, probe, sizeof probe);
-  }
+  void* stage = ctx->io_bases.ensure(n * 64);
   void* d_s = ctx->io.ensure(n * 32);
-  if (!d_s) return hm_fail(HM_ERR_HIP, "hm_msm_bn256_g1: staging allocation failed");
+  if (!d_xy || !d_inf || !stage || !d_s) return hm_fail(HM_ERR_HIP, "hm_msm_bn256_g1: staging allocation failed");
+  const double t0 = now_us();
+  HM_HIP_CHECK(hipMemcpy(stage, bases, n * 64, hipMemcpyHostToDevice));
+  int rc = msm_convert_bases((const uint32_t*)stage, d_xy, d_inf, n, nullptr);
+  if (rc != HM_OK) return rc;
   HM_HIP_CHECK(hipMemcpy(d_s, scalars, n * 32, hipMemcpyHostToDevice));
-  return msm_run(*ctx, (const uint32_t*)d_s, d_xy, d_inf, n, 0, jac, is_id, nullptr);
+  ctx->calls.msm_h2d_us += now_us() - t0;
+  ctx->calls.h2d_bytes += n * 96;
+  rc = msm_run(*ctx, (const uint32_t*)d_s, d_xy, d_inf, n, 0, jac, is_id, nullptr);
+  if (rc == HM_OK) count_msm(*ctx, n);
+  return rc;
 }
 
 // Single-process multi-GPU form (hm_set_msm_devices): contiguous index ranges, one host thread per
-// device, each running the ordinary one-device path on its slice (so the per-device base cache holds
-// that device's slice of the SRS), partial sums folded on the host.  No inter-GPU traffic: the only
+// device, each running the ordinary one-device path on its slice (its own uploads, no shared state),
+// partial sums folded on the host.  No inter-GPU traffic: the only
 // thing that leaves a device is a 96-byte point.
 static int msm_host(const uint64_t* scalars, const uint64_t* bases, size_t n, uint64_t jac[12], int* is_id) {
   if (n && (!scalars || !bases)) return hm_fail(HM_ERR_BAD_ARG, "hm_msm_bn256_g1: null argument");
@@ -438,17 +490,36 @@ int hm_get_msm_stats(hm_msm_stats* out) {
   return HM_OK;
 }
 
+int hm_get_stats(hm_stats* out) {
+  if (!out) return hm_fail(HM_ERR_BAD_ARG, "hm_get_stats: null output");
+  DeviceCtx* ctx = ctx_for_current_device();
+  if (!ctx) return HM_ERR_NO_DEVICE;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  const CallStats& c = ctx->calls;
+  std::memset(out, 0, sizeof *out);
+  out->msm_calls = c.msm_calls; out->msm_points = c.msm_points;
+  out->ntt_calls = c.ntt_calls; out->ntt_elements = c.ntt_elements;
+  for (int i = 0; i < 32; ++i) { out->msm_calls_by_log2[i] = c.msm_by_log[i]; out->ntt_calls_by_log2[i] = c.ntt_by_log[i]; }
+  out->msm_h2d_us = c.msm_h2d_us; out->msm_device_us = c.msm_device_us; out->msm_host_us = c.msm_host_us;
+  out->ntt_h2d_us = c.ntt_h2d_us; out->ntt_device_us = c.ntt_device_us; out->ntt_d2h_us = c.ntt_d2h_us;
+  out->h2d_bytes = c.h2d_bytes; out->d2h_bytes = c.d2h_bytes;
+  return HM_OK;
+}
+
+int hm_reset_stats(void) {
+  DeviceCtx* ctx = ctx_for_current_device();
+  if (!ctx) return HM_ERR_NO_DEVICE;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  ctx->calls = CallStats{};
+  return HM_OK;
+}
+
 // ---- NTT -------------------------------------------------------------------------------------
 
-static int small_consts(DeviceCtx& ctx, const uint64_t* ext, uint32_t count, hipStream_t stream, uint32_t** d_int) {
-  // small buffer layout: [0, 4096) reserved for the fixed-base table header; constants live after it
-  uint8_t* sm = (uint8_t*)ctx.small.ensure(64 + (size_t)64 * 15 * 28 * 4 + 4096);
-  if (!sm) return hm_fail(HM_ERR_HIP, "constant buffer allocation failed");
-  uint8_t* area = sm + 64 + (size_t)64 * 15 * 28 * 4;
-  uint32_t* d_ext = (uint32_t*)area;
-  *d_int = (uint32_t*)(area + 1024);
-  HM_HIP_CHECK(hipMemcpyAsync(d_ext, ext, (size_t)count * 32, hipMemcpyHostToDevice, stream));
-  return fr_ext_to_int_run(d_ext, *d_int, count, stream);
+static void count_ntt(DeviceCtx& ctx, uint32_t log_n, size_t batch) {
+  ctx.calls.ntt_calls += batch;
+  ctx.calls.ntt_elements += (uint64_t)batch << log_n;
+  ctx.calls.ntt_by_log[log_n & 31] += batch;
 }
 
 int hm_ntt_bn256_fr_dev(void* d_a, const uint64_t omega[4], uint32_t log_n, void* stream) {
@@ -456,7 +527,9 @@ int hm_ntt_bn256_fr_dev(void* d_a, const uint64_t omega[4], uint32_t log_n, void
   DeviceCtx* ctx = ctx_for_current_device();
   if (!ctx) return HM_ERR_NO_DEVICE;
   std::lock_guard<std::mutex> lk(ctx->mu);
-  return ntt_run(*ctx, (uint32_t*)d_a, omega, log_n, 1, nullptr, nullptr, (hipStream_t)stream);
+  const int rc = ntt_run(*ctx, (uint32_t*)d_a, omega, log_n, 1, NttFused{}, (hipStream_t)stream);
+  if (rc == HM_OK) count_ntt(*ctx, log_n, 1);
+  return rc;
 }
 
 int hm_ntt_batch_bn256_fr_dev(void* d_a, size_t batch, const uint64_t omega[4], uint32_t log_n, const uint64_t* scale,
@@ -466,20 +539,12 @@ int hm_ntt_batch_bn256_fr_dev(void* d_a, size_t batch, const uint64_t omega[4], 
   DeviceCtx* ctx = ctx_for_current_device();
   if (!ctx) return HM_ERR_NO_DEVICE;
   std::lock_guard<std::mutex> lk(ctx->mu);
-  uint32_t* d_scale = nullptr;
-  uint32_t* d_coset = nullptr;
-  if (scale || coset) {
-    uint64_t ext[16];
-    std::memset(ext, 0, sizeof ext);
-    if (scale) std::memcpy(ext, scale, 32);
-    if (coset) std::memcpy(ext + 4, coset, 96);
-    uint32_t* d_int = nullptr;
-    int rc = small_consts(*ctx, ext, 4, (hipStream_t)stream, &d_int);
-    if (rc != HM_OK) return rc;
-    if (scale) d_scale = d_int;
-    if (coset) d_coset = d_int + 9;
-  }
-  return ntt_run(*ctx, (uint32_t*)d_a, omega, log_n, (uint32_t)batch, d_scale, d_coset, (hipStream_t)stream);
+  NttFused f;
+  f.scale = scale;
+  f.coset = coset;
+  const int rc = ntt_run(*ctx, (uint32_t*)d_a, omega, log_n, (uint32_t)batch, f, (hipStream_t)stream);
+  if (rc == HM_OK) count_ntt(*ctx, log_n, batch);
+  return rc;
 }
 
 int hm_coeff_to_extended_bn256_fr_dev(const void* d_coeffs, void* d_ext, size_t batch, const uint64_t extended_omega[4],
@@ -492,27 +557,40 @@ int hm_coeff_to_extended_bn256_fr_dev(const void* d_coeffs, void* d_ext, size_t 
   DeviceCtx* ctx = ctx_for_current_device();
   if (!ctx) return HM_ERR_NO_DEVICE;
   std::lock_guard<std::mutex> lk(ctx->mu);
-  uint32_t* d_coset = nullptr;
-  if (coset) {
-    uint64_t ext[16];
-    std::memset(ext, 0, sizeof ext);
-    std::memcpy(ext + 4, coset, 96);
-    uint32_t* d_int = nullptr;
-    int rc = small_consts(*ctx, ext, 4, (hipStream_t)stream, &d_int);
-    if (rc != HM_OK) return rc;
-    d_coset = d_int + 9;
-  }
+  NttFused f;
+  f.coset = coset;
   const uint32_t log_z = log_ext - log_n;
   int passes = 0;
   const int first_digit = ntt_plan_first_digit(log_ext, &passes);
-  if (log_z > 0 && passes >= 2 && (int)log_z <= first_digit)    // the zero part is never written or read
-    return ntt_run(*ctx, (uint32_t*)d_ext, extended_omega, log_ext, (uint32_t)batch, nullptr, d_coset, (hipStream_t)stream,
-                   (const uint32_t*)d_coeffs, log_z);
-  // small or un-extended domains: materialise the padded arrays, then the ordinary in-place transform
-  const size_t row_in = (size_t)32 << log_n, row_out = (size_t)32 << log_ext;
-  if (log_z) HM_HIP_CHECK(hipMemsetAsync(d_ext, 0, row_out * batch, (hipStream_t)stream));
-  HM_HIP_CHECK(hipMemcpy2DAsync(d_ext, row_out, d_coeffs, row_in, row_in, batch, hipMemcpyDeviceToDevice, (hipStream_t)stream));
-  return ntt_run(*ctx, (uint32_t*)d_ext, extended_omega, log_ext, (uint32_t)batch, nullptr, d_coset, (hipStream_t)stream);
+  int rc;
+  if (log_z > 0 && passes >= 2 && (int)log_z <= first_digit) {   // the zero part is never written or read
+    rc = ntt_run(*ctx, (uint32_t*)d_ext, extended_omega, log_ext, (uint32_t)batch, f, (hipStream_t)stream,
+                 (const uint32_t*)d_coeffs, log_z);
+  } else {
+    // small or un-extended domains: materialise the padded arrays, then the ordinary in-place transform
+    const size_t row_in = (size_t)32 << log_n, row_out = (size_t)32 << log_ext;
+    if (log_z) HM_HIP_CHECK(hipMemsetAsync(d_ext, 0, row_out * batch, (hipStream_t)stream));
+    HM_HIP_CHECK(hipMemcpy2DAsync(d_ext, row_out, d_coeffs, row_in, row_in, batch, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    rc = ntt_run(*ctx, (uint32_t*)d_ext, extended_omega, log_ext, (uint32_t)batch, f, (hipStream_t)stream);
+  }
+  if (rc == HM_OK) count_ntt(*ctx, log_ext, batch);
+  return rc;
+}
+
+int hm_extended_to_coeff_bn256_fr_dev(void* d_a, size_t batch, const uint64_t extended_omega_inv[4], uint32_t log_ext,
+                                      const uint64_t divisor[4], const uint64_t coset_inv[12], void* stream) {
+  if ((batch && !d_a) || !extended_omega_inv || !divisor || !coset_inv)
+    return hm_fail(HM_ERR_BAD_ARG, "hm_extended_to_coeff_bn256_fr_dev: null argument");
+  if (batch > 65535) return hm_fail(HM_ERR_BAD_ARG, "hm_extended_to_coeff_bn256_fr_dev: batch > 65535");
+  DeviceCtx* ctx = ctx_for_current_device();
+  if (!ctx) return HM_ERR_NO_DEVICE;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  NttFused f;
+  f.scale = divisor;
+  f.post3 = coset_inv;
+  const int rc = ntt_run(*ctx, (uint32_t*)d_a, extended_omega_inv, log_ext, (uint32_t)batch, f, (hipStream_t)stream);
+  if (rc == HM_OK) count_ntt(*ctx, log_ext, batch);
+  return rc;
 }
 
 int hm_ntt_bn256_fr(uint64_t* a, const uint64_t omega[4], uint32_t log_n) {
@@ -524,23 +602,34 @@ int hm_ntt_bn256_fr(uint64_t* a, const uint64_t omega[4], uint32_t log_n) {
   const size_t bytes = ((size_t)32) << log_n;
   void* d_a = ctx->io.ensure(bytes);
   if (!d_a) return hm_fail(HM_ERR_HIP, "hm_ntt_bn256_fr: staging allocation failed");
+  const double t0 = now_us();
   HM_HIP_CHECK(hipMemcpy(d_a, a, bytes, hipMemcpyHostToDevice));
-  int rc = ntt_run(*ctx, (uint32_t*)d_a, omega, log_n, 1, nullptr, nullptr, nullptr);
+  const double t1 = now_us();
+  int rc = ntt_run(*ctx, (uint32_t*)d_a, omega, log_n, 1, NttFused{}, nullptr);
   if (rc != HM_OK) return rc;
+  HM_HIP_CHECK(hipStreamSynchronize(nullptr));
+  const double t2 = now_us();
   HM_HIP_CHECK(hipMemcpy(a, d_a, bytes, hipMemcpyDeviceToHost));
+  const double t3 = now_us();
+  count_ntt(*ctx, log_n, 1);
+  ctx->calls.ntt_h2d_us += t1 - t0;
+  ctx->calls.ntt_device_us += t2 - t1;
+  ctx->calls.ntt_d2h_us += t3 - t2;
+  ctx->calls.h2d_bytes += bytes;
+  ctx->calls.d2h_bytes += bytes;
   return HM_OK;
 }
-
 
 int hm_ifft_bn256_fr_dev(void* d_a, const uint64_t omega_inv[4], uint32_t log_n, const uint64_t divisor[4], void* stream) {
   if (!d_a || !omega_inv || !divisor) return hm_fail(HM_ERR_BAD_ARG, "hm_ifft_bn256_fr_dev: null argument");
   DeviceCtx* ctx = ctx_for_current_device();
   if (!ctx) return HM_ERR_NO_DEVICE;
   std::lock_guard<std::mutex> lk(ctx->mu);
-  uint32_t* d_int = nullptr;
-  int rc = small_consts(*ctx, divisor, 1, (hipStream_t)stream, &d_int);
-  if (rc != HM_OK) return rc;
-  return ntt_run(*ctx, (uint32_t*)d_a, omega_inv, log_n, 1, d_int, nullptr, (hipStream_t)stream);
+  NttFused f;
+  f.scale = divisor;
+  const int rc = ntt_run(*ctx, (uint32_t*)d_a, omega_inv, log_n, 1, f, (hipStream_t)stream);
+  if (rc == HM_OK) count_ntt(*ctx, log_n, 1);
+  return rc;
 }
 
 int hm_coset_ntt_bn256_fr_dev(void* d_a, const uint64_t omega[4], uint32_t log_n, const uint64_t coset[12], void* stream) {
@@ -548,36 +637,27 @@ int hm_coset_ntt_bn256_fr_dev(void* d_a, const uint64_t omega[4], uint32_t log_n
   DeviceCtx* ctx = ctx_for_current_device();
   if (!ctx) return HM_ERR_NO_DEVICE;
   std::lock_guard<std::mutex> lk(ctx->mu);
-  uint32_t* d_int = nullptr;
-  int rc = small_consts(*ctx, coset, 3, (hipStream_t)stream, &d_int);
-  if (rc != HM_OK) return rc;
-  return ntt_run(*ctx, (uint32_t*)d_a, omega, log_n, 1, nullptr, d_int, (hipStream_t)stream);
+  NttFused f;
+  f.coset = coset;
+  const int rc = ntt_run(*ctx, (uint32_t*)d_a, omega, log_n, 1, f, (hipStream_t)stream);
+  if (rc == HM_OK) count_ntt(*ctx, log_n, 1);
+  return rc;
 }
 
 int hm_fr_scale_dev(void* d_a, size_t n, const uint64_t c[4], void* stream) {
   if ((n && !d_a) || !c) return hm_fail(HM_ERR_BAD_ARG, "hm_fr_scale_dev: null argument");
   DeviceCtx* ctx = ctx_for_current_device();
   if (!ctx) return HM_ERR_NO_DEVICE;
-  std::lock_guard<std::mutex> lk(ctx->mu);
   if (n == 0) return HM_OK;
-  uint8_t* sm = (uint8_t*)ctx->small.ensure(64 + (size_t)64 * 15 * 28 * 4 + 4096);
-  if (!sm) return hm_fail(HM_ERR_HIP, "hm_fr_scale_dev: constant buffer allocation failed");
-  uint32_t* d_c = (uint32_t*)(sm + 64 + (size_t)64 * 15 * 28 * 4 + 2048);
-  HM_HIP_CHECK(hipMemcpyAsync(d_c, c, 32, hipMemcpyHostToDevice, (hipStream_t)stream));
-  return fr_scale_run((uint32_t*)d_a, d_c, n, (hipStream_t)stream);
+  return fr_scale_run((uint32_t*)d_a, c, n, (hipStream_t)stream);     // the constant travels by value: no shared state
 }
 
 int hm_fr_distribute_powers_dev(void* d_a, size_t n, const uint64_t c3[12], void* stream) {
   if ((n && !d_a) || !c3) return hm_fail(HM_ERR_BAD_ARG, "hm_fr_distribute_powers_dev: null argument");
   DeviceCtx* ctx = ctx_for_current_device();
   if (!ctx) return HM_ERR_NO_DEVICE;
-  std::lock_guard<std::mutex> lk(ctx->mu);
   if (n == 0) return HM_OK;
-  uint8_t* sm = (uint8_t*)ctx->small.ensure(64 + (size_t)64 * 15 * 28 * 4 + 4096);
-  if (!sm) return hm_fail(HM_ERR_HIP, "hm_fr_distribute_powers_dev: constant buffer allocation failed");
-  uint32_t* d_c = (uint32_t*)(sm + 64 + (size_t)64 * 15 * 28 * 4 + 3072);
-  HM_HIP_CHECK(hipMemcpyAsync(d_c, c3, 96, hipMemcpyHostToDevice, (hipStream_t)stream));
-  return fr_mul_pattern3_run((uint32_t*)d_a, d_c, n, (hipStream_t)stream);
+  return fr_mul_pattern3_run((uint32_t*)d_a, c3, n, (hipStream_t)stream);
 }
 
 int hm_g1_fixed_base_mul_dev(const void* d_scalars, size_t n, const uint64_t base_xy[8], void* d_out_xy, void* stream) {
@@ -585,8 +665,6 @@ int hm_g1_fixed_base_mul_dev(const void* d_scalars, size_t n, const uint64_t bas
   DeviceCtx* ctx = ctx_for_current_device();
   if (!ctx) return HM_ERR_NO_DEVICE;
   std::lock_guard<std::mutex> lk(ctx->mu);
-  // make sure the shared small buffer has its full size before the table is carved from it
-  if (!ctx->small.ensure(64 + (size_t)64 * 15 * 28 * 4 + 4096)) return hm_fail(HM_ERR_HIP, "small buffer allocation failed");
   return g1_fixed_base_mul_run(*ctx, (const uint32_t*)d_scalars, n, base_xy, (uint32_t*)d_out_xy, (hipStream_t)stream);
 }
 

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -34,7 +35,11 @@ struct NttTables {
   uint32_t log_n = 0;
   uint64_t omega[4] = {0, 0, 0, 0};
   uint32_t log_lb = 0;
-  void* d_omega = nullptr;
+  // The table kernels run on the stream of the call that first needed them.  `ready` is recorded behind
+  // them; until it has completed (`published`), a caller on another stream waits for it on the device.
+  hipStream_t build_stream = nullptr;
+  hipEvent_t ready = nullptr;
+  bool published = false;
   uint32_t* d_lo = nullptr;
   uint32_t* d_hi = nullptr;
   uint32_t* d_mid = nullptr;   // direct twiddles of the middle pass of a 3-pass plan
@@ -68,6 +73,7 @@ struct BasesEntry {          // device-resident, converted base set (hm_register
   uint8_t* d_inf = nullptr;  // n flags: base is the identity
   uint32_t pc_c = 0;         // != 0: d_xy holds pc_W * n points, entry j*n + i = 2^(pc_c * j) * P_i
   uint32_t pc_W = 0;
+  size_t xy_bytes = 0, inf_bytes = 0;
 };
 
 struct MsmStats {
@@ -78,33 +84,13 @@ struct MsmStats {
 
 constexpr int HM_MSM_SLOTS = 9;   // slot 0: synchronous calls; 1..8: asynchronous tickets (workspaces allocated on first use)
 
-struct MsmGraphKey {        // what the captured launch sequence (everything after the digit kernel) depends on
-  size_t n = 0;
-  const void* d_xy = nullptr;
-  uint32_t precomp_c = 0;
-  int window_override = 0;
-  const void* ws = nullptr;
-  bool operator==(const MsmGraphKey& o) const {
-    return n == o.n && d_xy == o.d_xy && precomp_c == o.precomp_c && window_override == o.window_override && ws == o.ws;
-  }
-};
-
 struct MsmSlot {            // one in-flight MSM: its workspace, events and host landing buffers
   DevBuf ws;
-  struct Graph {                     // captured launch sequence of one small-MSM shape on this slot
-    hipGraph_t graph = nullptr;
-    hipGraphExec_t exec = nullptr;
-    MsmGraphKey key;
-    uint64_t last_use = 0;
-  };
-  static constexpr int kGraphs = 4;  // e.g. {g, g_lagrange} x {one or two sizes}; least recently used is replaced
-  Graph graphs[kGraphs];
-  uint64_t graph_clock = 0;
-  bool timed = false;                // per-phase events were recorded for the MSM in flight
   hipEvent_t ev[7] = {};
   bool ev_ready = false;
   bool busy = false;        // held by a ticket of hm_msm_submit_dev
   uint64_t ticket = 0;
+  uint64_t bases_handle = 0;   // base set the MSM in flight reads (a released set is freed only after its last ticket)
   size_t n = 0;
   hipStream_t stream = nullptr;
   uint32_t* h_land = nullptr;   // pinned host landing zone: 4 totals words, then the window sums (as on the device)
@@ -116,40 +102,76 @@ struct MsmSlot {            // one in-flight MSM: its workspace, events and host
   uint64_t T_max = 0;
 };
 
+// Transient device state of the stream-asynchronous entry points (NTT ping-pong buffer, fixed-base
+// table): one slot per stream in use, so that calls on different streams never share a buffer.  A slot
+// is handed to a new stream only behind the event recorded after its previous user's launches.
+struct AuxSlot {
+  DevBuf scratch;                 // NTT ping-pong buffer
+  DevBuf table;                   // multiples table of hm_g1_fixed_base_mul_dev
+  hipStream_t stream = nullptr;   // stream of the last user
+  hipEvent_t done = nullptr;      // recorded behind the last user's launches
+  bool used = false;
+  uint64_t last_use = 0;
+};
+constexpr int HM_AUX_SLOTS = 4;
+
+struct FreeBases {          // buffers of a released base set, kept for the next registration of that size
+  uint32_t* d_xy = nullptr;
+  uint8_t* d_inf = nullptr;
+  size_t xy_bytes = 0, inf_bytes = 0;
+};
+
+// per-call counters (hm_get_stats): what the shim of INTEGRATION.md reads to replace call-trace estimates
+struct CallStats {
+  uint64_t msm_calls = 0, msm_points = 0, ntt_calls = 0, ntt_elements = 0;
+  uint64_t msm_by_log[32] = {}, ntt_by_log[32] = {};
+  double msm_h2d_us = 0, msm_device_us = 0, msm_host_us = 0, ntt_h2d_us = 0, ntt_device_us = 0, ntt_d2h_us = 0;
+  uint64_t h2d_bytes = 0, d2h_bytes = 0;
+};
+
 struct DeviceCtx {
   int device = 0;
   std::mutex mu;
   std::vector<std::unique_ptr<NttTables>> ntt_tables;
-  DevBuf scratch;         // NTT ping-pong buffer
+  AuxSlot aux[HM_AUX_SLOTS];
+  uint64_t aux_clock = 0;
   DevBuf io;              // staging for host-pointer calls (scalars / NTT array)
   DevBuf io_bases;        // staging for raw external bases of host-pointer MSM calls
   DevBuf conv_bases;      // converted bases of un-registered calls
   DevBuf conv_inf;
   MsmSlot msm_slots[HM_MSM_SLOTS];   // MSM workspaces (digits, sort scratch, sorted indices, bucket sums ...)
   uint64_t next_ticket = 1;
-  DevBuf small;           // small constants
   std::vector<BasesEntry> bases;
+  std::vector<BasesEntry> zombie_bases;   // released while a ticket still reads them: freed by the last hm_msm_wait
+  std::vector<FreeBases> free_bases;      // recycled buffers (no hipFree => no device-wide synchronisation)
   uint64_t next_handle = 1;
-  // host-pointer MSM: cache of the last converted un-registered base array (keyed by ptr,len,probe)
-  const void* cached_host_bases = nullptr;
-  size_t cached_host_n = 0;
-  uint64_t cached_probe[4] = {0, 0, 0, 0};
   MsmStats last_msm;
+  CallStats calls;
   bool msm_attr_set = false, ntt_attr_set = false;
-  hipStream_t capture_stream = nullptr;   // launch sequences are captured here, replayed on the caller's stream
-  void* ensure_scratch(size_t bytes) { return scratch.ensure(bytes); }
 };
+
+// Slot for a call on `stream` (ctx.mu held): the stream's own slot, else a free or finished one, else the
+// least recently used one behind a device-side wait for its event.  aux_release records the event.
+AuxSlot* aux_acquire(DeviceCtx& ctx, hipStream_t stream);
+int aux_release(DeviceCtx& ctx, AuxSlot* slot, hipStream_t stream);
 
 DeviceCtx* ctx_for_current_device();
 
 // ntt.hip
+// scale / coset: optional external (4 x u64 Montgomery) constants on the HOST; they travel to the kernels
+// by value, so no call shares a constants buffer with another.  post3: optional {1, c, c^2}-style pattern
+// multiplied into element i of every output array by i % 3 (EvaluationDomain::extended_to_coeff).
+struct NttFused {
+  const uint64_t* scale = nullptr;   // 4 words: multiply every output (ifft divisor)
+  const uint64_t* coset = nullptr;   // 12 words: input element i *= coset[i % 3] (coeff_to_extended)
+  const uint64_t* post3 = nullptr;   // 12 words: output element i *= post3[i % 3] (extended_to_coeff)
+};
 int ntt_run(DeviceCtx& ctx, uint32_t* d_a, const uint64_t omega_ext[4], uint32_t log_n, uint32_t batch,
-            const uint32_t* d_scale_int, const uint32_t* d_coset_int, hipStream_t stream, const uint32_t* d_in = nullptr,
-            uint32_t log_z = 0);
+            const NttFused& fused, hipStream_t stream, const uint32_t* d_in = nullptr, uint32_t log_z = 0);
 int ntt_plan_first_digit(uint32_t log_n, int* passes);
-int fr_scale_run(uint32_t* d_a, const uint32_t* d_c_ext, uint64_t n, hipStream_t stream);
-int fr_mul_pattern3_run(uint32_t* d_a, const uint32_t* d_c3_ext, uint64_t n, hipStream_t stream);
-int fr_ext_to_int_run(const uint32_t* d_c_ext, uint32_t* d_out, uint32_t count, hipStream_t stream);
+int fr_scale_run(uint32_t* d_a, const uint64_t c_ext[4], uint64_t n, hipStream_t stream);
+int fr_mul_pattern3_run(uint32_t* d_a, const uint64_t c3_ext[12], uint64_t n, hipStream_t stream);
+void ntt_tables_release(NttTables& t);
 
 // msm.hip
 int msm_convert_bases(const uint32_t* d_bases_ext, uint32_t* d_xy, uint8_t* d_inf, size_t n, hipStream_t stream);
@@ -159,8 +181,6 @@ int msm_enqueue(DeviceCtx& ctx, int slot, const uint32_t* d_scalars_ext, const u
 int msm_finish(DeviceCtx& ctx, int slot, uint64_t out_jac_ext[12], int* out_is_identity);
 int msm_run(DeviceCtx& ctx, const uint32_t* d_scalars_ext, const uint32_t* d_xy, const uint8_t* d_inf, size_t n,
             uint32_t precomp_c, uint64_t out_jac_ext[12], int* out_is_identity, hipStream_t stream);
-void msm_set_use_graphs(bool on);
-void msm_slot_release_graph(MsmSlot& sl);
 uint32_t msm_precomp_window(size_t n);
 int msm_precompute(uint32_t* d_table, const uint8_t* d_inf, size_t n, uint32_t c, uint32_t W, hipStream_t stream);
 void host_sum_points(const uint64_t* pts, size_t count, uint64_t out_jac_ext[12], int* out_is_identity);

@@ -20,6 +20,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 
 #include "g1.h"
@@ -30,12 +31,9 @@ namespace hm {
 
 constexpr int PT_WORDS = 28;  // device Jacobian record: 27 limbs + identity flag
 
-// Counters are cleared by a kernel of the MSM's own rather than hipMemsetAsync (and the one device-to-device
-// copy the sort needs is folded into the scan that produces its source): the launch sequence then
-// consists of kernel nodes only when it is captured into a graph -- memset / memcpy nodes are what the
-// faulting graph replays had in common.  Every counter an MSM starts from zero goes in ONE launch: the
-// bucket counts (the cooperative histogram adds into them), the big-region list count, the task-length
-// key histogram, the hot-bucket queue counts.
+// Every counter an MSM starts from zero is cleared by ONE launch of its own (instead of four
+// hipMemsetAsync calls): the bucket counts (the cooperative histogram adds into them), the big-region
+// list count, the task-length key histogram, the hot-bucket queue counts.
 __global__ void msm_init_counters_kernel(uint32_t* __restrict__ bcnt, size_t nbt, uint32_t* __restrict__ br_count,
                                          uint32_t* __restrict__ khist, uint32_t nkeys, uint32_t* __restrict__ big_count) {
   const size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
@@ -685,9 +683,12 @@ __global__ __launch_bounds__(SCAN_THREADS) void msm_scan_partial_kernel(const ui
   }
 }
 
-// one block: exclusive scan of the per-block sums in place; totals[0] = pairs, totals[1] = tasks
+// one block: exclusive scan of the per-block sums in place; totals[0] = pairs, totals[1] = tasks.
+// totals[2] = 1 and totals[1] = 0 if the task count exceeds the capacity of the task arrays (a host-side
+// bound that cannot be reached; if it ever were, every later kernel sees the flag and touches nothing,
+// and msm_finish reports the error -- no out-of-bounds write happens first).
 __global__ __launch_bounds__(SCAN_THREADS) void msm_scan_blocksums_kernel(uint32_t* __restrict__ blocksums, uint32_t nblocks,
-                                                                          uint32_t* __restrict__ totals) {
+                                                                          uint32_t* __restrict__ totals, uint32_t task_capacity) {
   __shared__ uint32_t s_p[SCAN_THREADS], s_t[SCAN_THREADS];
   uint32_t carry_p = 0, carry_t = 0;
   for (uint32_t start = 0; start < nblocks; start += SCAN_THREADS) {
@@ -704,8 +705,10 @@ __global__ __launch_bounds__(SCAN_THREADS) void msm_scan_blocksums_kernel(uint32
     __syncthreads();
   }
   if (threadIdx.x == 0) {
+    const bool over = carry_t > task_capacity;
     totals[0] = carry_p;
-    totals[1] = carry_t;
+    totals[1] = over ? 0u : carry_t;
+    totals[2] = over ? 1u : 0u;
   }
 }
 
@@ -741,12 +744,13 @@ __global__ __launch_bounds__(SCAN_THREADS) void msm_scan_final_kernel(const uint
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) toff[NBT] = totals[1];
 }
+// (with the overflow flag set toff keeps the unclamped offsets, so every consumer of toff checks totals[2] first)
 
 // bucket order (small inputs): task t runs in slot t
 __global__ void msm_task_fill_kernel(const uint32_t* __restrict__ toff, uint32_t* __restrict__ task_bucket,
-                                     uint32_t* __restrict__ task_order, uint32_t NBT) {
+                                     uint32_t* __restrict__ task_order, uint32_t NBT, const uint32_t* __restrict__ totals) {
   const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= NBT) return;
+  if (b >= NBT || totals[2]) return;
   const uint32_t lo = toff[b], hi = toff[b + 1];
   for (uint32_t t = lo; t < hi; ++t) {
     task_bucket[t] = b;
@@ -811,8 +815,10 @@ __global__ __launch_bounds__(ORDER_THREADS) void msm_task_order_kernel(const uin
                                                                        const uint32_t* __restrict__ pairs, uint32_t L_host,
                                                                        uint32_t* __restrict__ kcursor,
                                                                        uint32_t* __restrict__ task_bucket,
-                                                                       uint32_t* __restrict__ task_order) {
+                                                                       uint32_t* __restrict__ task_order,
+                                                                       const uint32_t* __restrict__ totals) {
   __shared__ uint32_t h[TASK_KEYS], base[TASK_KEYS];
+  if (totals[2]) return;                   // task arrays too small (see msm_scan_blocksums_kernel): write nothing
   const uint32_t L = effective_task_len(pairs, L_host);
   h[threadIdx.x] = 0;
   __syncthreads();
@@ -988,9 +994,14 @@ __global__ __launch_bounds__(ACC_THREADS) void msm_bucket_finalize_kernel(const 
                                                                           uint32_t* __restrict__ bucket, uint32_t NBT,
                                                                           uint32_t* __restrict__ big_count,
                                                                           uint32_t* __restrict__ big_list,
-                                                                          uint2* __restrict__ slice_list) {
+                                                                          uint2* __restrict__ slice_list,
+                                                                          const uint32_t* __restrict__ totals) {
   const uint32_t b = blockIdx.x * ACC_THREADS + threadIdx.x;
   if (b >= NBT) return;
+  if (totals[2]) {                         // overflow flag: no partial was written; leave an identity in every bucket
+    store_jac(bucket + (size_t)b * PT_WORDS, g1_identity());
+    return;
+  }
   const uint32_t lo = toff[b], hi = toff[b + 1];
   if (hi - lo > FINALIZE_SERIAL) {
     big_list[atomicAdd(big_count, 1u)] = b;
@@ -1126,13 +1137,16 @@ __global__ void msm_windows_to_ext_kernel(const uint32_t* __restrict__ in, uint3
 // out[i] = [k_i] B, affine external.  One lane per scalar: 4-bit fixed windows over a 64 x 15
 // table of multiples of B built by the first kernel; final inversion by Fermat per lane.
 // ---------------------------------------------------------------------------------------------
-__global__ void g1_fixed_table_kernel(const uint32_t* __restrict__ base_ext, uint32_t* __restrict__ table) {
+struct G1AffineWords {     // one external affine point, passed to the table kernel by value
+  uint32_t w[16];
+};
+__global__ void g1_fixed_table_kernel(G1AffineWords base_ext, uint32_t* __restrict__ table) {
   // table[w][d-1] = [d * 16^w] B as Jacobian records, w < 64, d in 1..15.  One lane per window.
   const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
   if (w >= 64) return;
   uint32_t wx[8], wy[8];
 #pragma unroll
-  for (int k = 0; k < 8; ++k) { wx[k] = base_ext[k]; wy[k] = base_ext[8 + k]; }
+  for (int k = 0; k < 8; ++k) { wx[k] = base_ext.w[k]; wy[k] = base_ext.w[8 + k]; }
   G1Aff b;
   b.x = fe_from_ext<FqParams>(wx);
   b.y = fe_from_ext<FqParams>(wy);
@@ -1278,8 +1292,8 @@ void host_sum_points(const uint64_t* pts, size_t count, uint64_t out_jac_ext[12]
   host_fold(win.data(), (uint32_t)count, 0, out_jac_ext, out_is_identity);
 }
 
-static int g_window_override = 0;
-void msm_set_window_override(int c) { g_window_override = c; }
+static std::atomic<int> g_window_override{0};   // process-wide knob, read once per MSM
+void msm_set_window_override(int c) { g_window_override.store(c, std::memory_order_relaxed); }
 
 // Window size for a precomputed (single bucket set) base set of n points: minimise
 // n * W(c) mixed additions + ~3 * 2^(c-1) addition-equivalents of bucket reduction.
@@ -1376,25 +1390,19 @@ static int launch_sort_scatter(const int32_t* d_digits, const uint32_t* d_cstart
 // the device.  d_xy: n points (plain) or the precomputed table of precomp_W * n points
 // (precomp_c != 0).  msm_finish() later waits for the slot, folds the window sums on the host and
 // fills the statistics.
-// phase: MSM_PREPARE = plan, workspace and first-use set-up only (everything a stream capture must not
-// contain); MSM_ISSUE = prepare + every launch, with the per-phase timing events; MSM_DIGITS = prepare
-// (idempotent) + the digit kernel alone, the only consumer of the per-call scalar pointer;
-// MSM_AFTER_DIGITS = prepare + everything after it and nothing else, the form that is captured into a
-// graph (it depends on the size, the window, the base set and the workspace only).
-enum MsmPhase { MSM_PREPARE, MSM_ISSUE, MSM_DIGITS, MSM_AFTER_DIGITS };
 static int msm_issue(DeviceCtx& ctx, int slot, const uint32_t* d_scalars_ext, const uint32_t* d_xy, const uint8_t* d_inf, size_t n,
-                     uint32_t precomp_c, hipStream_t stream, MsmPhase phase) {
+                     uint32_t precomp_c, hipStream_t stream) {
   MsmSlot& sl = ctx.msm_slots[slot];
-  const bool timing = phase == MSM_ISSUE;
   if (n == 0) return HM_OK;
   if (n >= (1ull << 31)) return hm_fail(HM_ERR_BAD_ARG, "msm: n must be < 2^31");
   // ---- plan ---------------------------------------------------------------------------------
   const bool single_set = precomp_c != 0;     // all windows accumulate into ONE bucket set
+  const int window_override = g_window_override.load(std::memory_order_relaxed);
   uint32_t c;
   if (single_set) {
     c = precomp_c;
-  } else if (g_window_override > 0) {
-    c = (uint32_t)g_window_override;
+  } else if (window_override > 0) {
+    c = (uint32_t)window_override;
   } else {
     // Rule of thumb: log2(n) - 3 (mean bucket load ~16: short chains, almost no bucket splitting, few
     // (point, bucket) pairs), capped at c = 17, whose W = 15 windows cover the 255 digit bits exactly
@@ -1571,16 +1579,13 @@ static int msm_issue(DeviceCtx& ctx, int slot, const uint32_t* d_scalars_ext, co
   sl.T_max = T_max;
   sl.d_win = d_win;
   sl.d_tot = d_tot;
-  if (phase == MSM_PREPARE) return HM_OK;
+  HM_HIP_CHECK(hipEventRecord(ev[0], stream));
 
   // ---- K0 ------------------------------------------------------------------------------------
-  if (phase != MSM_AFTER_DIGITS) {
-    hipLaunchKernelGGL(msm_digits_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, stream, d_scalars_ext, d_inf,
-                       d_digits, n, c, W);
-    HM_HIP_CHECK(hipGetLastError());
-  }
-  if (phase == MSM_DIGITS) return HM_OK;
-  if (timing) HM_HIP_CHECK(hipEventRecord(ev[1], stream));
+  hipLaunchKernelGGL(msm_digits_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, stream, d_scalars_ext, d_inf,
+                     d_digits, n, c, W);
+  HM_HIP_CHECK(hipGetLastError());
+  HM_HIP_CHECK(hipEventRecord(ev[1], stream));
 
   // ---- K2 ------------------------------------------------------------------------------------
   {
@@ -1604,7 +1609,8 @@ static int msm_issue(DeviceCtx& ctx, int slot, const uint32_t* d_scalars_ext, co
     const uint32_t nblocks = (NBT + SCAN_BLOCK - 1) / SCAN_BLOCK;
     hipLaunchKernelGGL(msm_scan_partial_kernel, dim3(nblocks), dim3(SCAN_THREADS), 0, stream, (const uint32_t*)d_bcnt,
                        d_bsum, NBT, d_pairs, L);
-    hipLaunchKernelGGL(msm_scan_blocksums_kernel, dim3(1), dim3(SCAN_THREADS), 0, stream, d_bsum, nblocks, d_tot);
+    hipLaunchKernelGGL(msm_scan_blocksums_kernel, dim3(1), dim3(SCAN_THREADS), 0, stream, d_bsum, nblocks, d_tot,
+                       (uint32_t)std::min<uint64_t>(T_max, 0xffffffffull));
     hipLaunchKernelGGL(msm_scan_final_kernel, dim3(nblocks), dim3(SCAN_THREADS), 0, stream, (const uint32_t*)d_bcnt,
                        (const uint32_t*)d_bsum, d_boff, d_toff, (const uint32_t*)d_tot, NBT, d_pairs, L,
                        coop_sort ? br.gcursor : (uint32_t*)nullptr);
@@ -1620,23 +1626,23 @@ static int msm_issue(DeviceCtx& ctx, int slot, const uint32_t* d_scalars_ext, co
   if (pairs_max < (1u << 19)) {
     // small inputs: three more launches cost more than the idle lanes they would save
     hipLaunchKernelGGL(msm_task_fill_kernel, dim3((NBT + 255) / 256), dim3(256), 0, stream, (const uint32_t*)d_toff, d_tb, d_torder,
-                       NBT);
+                       NBT, (const uint32_t*)d_tot);
   } else {
     const uint32_t og = (NBT + ORDER_THREADS * ORDER_ITEMS - 1) / (ORDER_THREADS * ORDER_ITEMS);
     hipLaunchKernelGGL(msm_task_hist_kernel, dim3(og), dim3(ORDER_THREADS), 0, stream, (const uint32_t*)d_bcnt, NBT,
                        d_pairs, L, d_khist);
     hipLaunchKernelGGL(msm_task_keyscan_kernel, dim3(1), dim3(ORDER_THREADS), 0, stream, (const uint32_t*)d_khist, d_kcursor);
     hipLaunchKernelGGL(msm_task_order_kernel, dim3(og), dim3(ORDER_THREADS), 0, stream, (const uint32_t*)d_bcnt,
-                       (const uint32_t*)d_toff, NBT, d_pairs, L, d_kcursor, d_tb, d_torder);
+                       (const uint32_t*)d_toff, NBT, d_pairs, L, d_kcursor, d_tb, d_torder, (const uint32_t*)d_tot);
   }
   HM_HIP_CHECK(hipGetLastError());
-  if (timing) HM_HIP_CHECK(hipEventRecord(ev[2], stream));
+  HM_HIP_CHECK(hipEventRecord(ev[2], stream));
 
   // ---- K3 ------------------------------------------------------------------------------------
   // The exact task count T stays on the device (d_tot[1]); the grid covers its host-side bound: for
   // uniform scalars every bucket holds one task (T ~ NBT), else at most pairs / L more.  Surplus
   // single-wave workgroups exit at once.
-  if (timing) HM_HIP_CHECK(hipEventRecord(ev[5], stream));
+  HM_HIP_CHECK(hipEventRecord(ev[5], stream));
   {
     const uint64_t t_grid = T_max;
     hipLaunchKernelGGL(msm_accumulate_kernel, dim3((uint32_t)((t_grid + ACC_THREADS - 1) / ACC_THREADS)), dim3(ACC_THREADS), 0,
@@ -1644,9 +1650,10 @@ static int msm_issue(DeviceCtx& ctx, int slot, const uint32_t* d_scalars_ext, co
                        (const uint32_t*)d_bcnt, (const uint32_t*)d_toff, d_xy, d_partial, (const uint32_t*)d_tot, d_pairs, L);
     HM_HIP_CHECK(hipGetLastError());
   }
-  if (timing) HM_HIP_CHECK(hipEventRecord(ev[6], stream));
+  HM_HIP_CHECK(hipEventRecord(ev[6], stream));
   hipLaunchKernelGGL(msm_bucket_finalize_kernel, dim3((NBT + ACC_THREADS - 1) / ACC_THREADS), dim3(ACC_THREADS), 0, stream,
-                     (const uint32_t*)d_partial, (const uint32_t*)d_toff, d_bucket, NBT, d_big_count, d_big_list, d_slices);
+                     (const uint32_t*)d_partial, (const uint32_t*)d_toff, d_bucket, NBT, d_big_count, d_big_list, d_slices,
+                     (const uint32_t*)d_tot);
   HM_HIP_CHECK(hipGetLastError());
   {
     uint32_t slice_grid = (uint32_t)(T_max / FINALIZE_SLICE + 1);       // upper bound on the number of full slices
@@ -1660,7 +1667,7 @@ static int msm_issue(DeviceCtx& ctx, int slot, const uint32_t* d_scalars_ext, co
                        (const uint32_t*)d_big_list);
     HM_HIP_CHECK(hipGetLastError());
   }
-  if (timing) HM_HIP_CHECK(hipEventRecord(ev[3], stream));
+  HM_HIP_CHECK(hipEventRecord(ev[3], stream));
 
   // ---- K4 ------------------------------------------------------------------------------------
   hipLaunchKernelGGL(msm_reduce_segments_kernel, dim3((SW * nseg + ACC_THREADS - 1) / ACC_THREADS), dim3(ACC_THREADS), 0,
@@ -1682,72 +1689,9 @@ static int msm_issue(DeviceCtx& ctx, int slot, const uint32_t* d_scalars_ext, co
     HM_HIP_CHECK(hipGetLastError());
   }
   if (SW > 128) return hm_fail(HM_ERR_INTERNAL, "msm: more than 128 windows");
-  // pinned landing zone, so that these copies (and therefore msm_enqueue) do not wait for the device
-  if (phase != MSM_AFTER_DIGITS) {   // (a captured sequence holds kernels only: msm_graph_launch issues these after the replay)
-    HM_HIP_CHECK(hipMemcpyAsync(sl.totals(), d_tot, (4 + (size_t)SW * 32) * 4, hipMemcpyDeviceToHost, stream));
-  }
-  return HM_OK;
-}
-
-// EXPERIMENTAL, off by default (hm_msm_use_graphs).  Small MSMs (the sizes of the reference's own circuits,
-// k <= 18) are launch-bound: ~30 launches per call (128 us of host time at 2^18; 24 us as a graph).
-// Everything after the digit kernel depends only on (size, window, base set, workspace), so that
-// sequence can be captured once per such key and slot into a hipGraph and replayed with one
-// hipGraphLaunch; the digit kernel, the only consumer of the per-call scalar pointer, is launched
-// directly in front of it and the two result copies directly behind it, so a captured sequence holds
-// KERNEL nodes only.  (With hipMemsetAsync / hipMemcpyAsync nodes in it, replays ended in GPU memory
-// faults on ROCm 7.2 -- tools/graph_probe.py, graph_probe2.py -- which is why fills and device copies
-// are kernels here.)  Why it is not the default: a replay runs SLOWER on the device than the same
-// launches issued directly (0.88 ms vs 0.79 ms at 2^18), so it only pays when the host thread is the
-// bottleneck; with eight commitments in flight the k = 18 proof replay gains 3 %.
-static bool g_use_graphs = false;
-void msm_set_use_graphs(bool on) { g_use_graphs = on; }
-constexpr size_t MSM_GRAPH_MAX_N = 1u << 20;
-
-static void msm_graph_drop(MsmSlot::Graph& g) {
-  if (g.exec) (void)hipGraphExecDestroy(g.exec);
-  if (g.graph) (void)hipGraphDestroy(g.graph);
-  g = MsmSlot::Graph{};
-  (void)hipGetLastError();   // a failed capture must not surface later as somebody else's launch error
-}
-void msm_slot_release_graph(MsmSlot& sl) {
-  for (auto& g : sl.graphs) msm_graph_drop(g);
-}
-
-static int msm_graph_launch(DeviceCtx& ctx, int slot, const uint32_t* d_scalars_ext, const uint32_t* d_xy, const uint8_t* d_inf,
-                            size_t n, uint32_t precomp_c, hipStream_t stream, bool* done) {
-  MsmSlot& sl = ctx.msm_slots[slot];
-  *done = false;
-  if (!ctx.capture_stream) HM_HIP_CHECK(hipStreamCreateWithFlags(&ctx.capture_stream, hipStreamNonBlocking));
-  const MsmGraphKey key{n, d_xy, precomp_c, g_window_override, sl.ws.p};
-  MsmSlot::Graph* g = nullptr;
-  for (auto& cand : sl.graphs) {
-    if (cand.exec && cand.key.ws != sl.ws.p) msm_graph_drop(cand);   // the workspace moved: its pointers are stale
-    if (cand.exec && cand.key == key) g = &cand;
-  }
-  if (!g) {
-    g = &sl.graphs[0];
-    for (auto& cand : sl.graphs) {
-      if (!cand.exec) { g = &cand; break; }            // a free entry
-      if (cand.last_use < g->last_use) g = &cand;      // else the least recently used
-    }
-    msm_graph_drop(*g);
-    HM_HIP_CHECK(hipStreamBeginCapture(ctx.capture_stream, hipStreamCaptureModeThreadLocal));
-    const int rc = msm_issue(ctx, slot, d_scalars_ext, d_xy, d_inf, n, precomp_c, ctx.capture_stream, MSM_AFTER_DIGITS);
-    const hipError_t ce = hipStreamEndCapture(ctx.capture_stream, &g->graph);
-    if (rc != HM_OK || ce != hipSuccess || !g->graph || hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0) != hipSuccess) {
-      g->exec = nullptr;
-      msm_graph_drop(*g);
-      return rc != HM_OK ? rc : HM_OK;            // capture unavailable: the caller issues the launches directly
-    }
-    g->key = key;
-  }
-  const int rc = msm_issue(ctx, slot, d_scalars_ext, d_xy, d_inf, n, precomp_c, stream, MSM_DIGITS);
-  if (rc != HM_OK) return rc;
-  g->last_use = ++sl.graph_clock;
-  HM_HIP_CHECK(hipGraphLaunch(g->exec, stream));
-  HM_HIP_CHECK(hipMemcpyAsync(sl.totals(), sl.d_tot, (4 + (size_t)sl.SW * 32) * 4, hipMemcpyDeviceToHost, stream));
-  *done = true;
+  // pinned landing zone, so that this copy (and therefore msm_enqueue) does not wait for the device
+  HM_HIP_CHECK(hipMemcpyAsync(sl.totals(), d_tot, (4 + (size_t)SW * 32) * 4, hipMemcpyDeviceToHost, stream));
+  HM_HIP_CHECK(hipEventRecord(ev[4], stream));
   return HM_OK;
 }
 
@@ -1756,23 +1700,8 @@ int msm_enqueue(DeviceCtx& ctx, int slot, const uint32_t* d_scalars_ext, const u
   MsmSlot& sl = ctx.msm_slots[slot];
   sl.n = n;
   sl.stream = stream;
-  sl.timed = false;
   if (n == 0) return HM_OK;
-  int rc = msm_issue(ctx, slot, d_scalars_ext, d_xy, d_inf, n, precomp_c, stream, MSM_PREPARE);
-  if (rc != HM_OK) return rc;
-  HM_HIP_CHECK(hipEventRecord(sl.ev[0], stream));
-  bool done = false;
-  if (g_use_graphs && n <= MSM_GRAPH_MAX_N) {
-    rc = msm_graph_launch(ctx, slot, d_scalars_ext, d_xy, d_inf, n, precomp_c, stream, &done);
-    if (rc != HM_OK) return rc;
-  }
-  if (!done) {
-    rc = msm_issue(ctx, slot, d_scalars_ext, d_xy, d_inf, n, precomp_c, stream, MSM_ISSUE);
-    if (rc != HM_OK) return rc;
-    sl.timed = true;
-  }
-  HM_HIP_CHECK(hipEventRecord(sl.ev[4], stream));
-  return HM_OK;
+  return msm_issue(ctx, slot, d_scalars_ext, d_xy, d_inf, n, precomp_c, stream);
 }
 
 // Wait for slot `slot`, fold its window sums (host Horner + affine normalisation) and record stats.
@@ -1785,16 +1714,16 @@ int msm_finish(DeviceCtx& ctx, int slot, uint64_t out_jac_ext[12], int* out_is_i
   }
   hipEvent_t* ev = sl.ev;
   HM_HIP_CHECK(hipEventSynchronize(ev[4]));
-  if ((uint64_t)sl.totals()[1] > sl.T_max) return hm_fail(HM_ERR_INTERNAL, "msm: task count exceeds its bound");
+  if (sl.totals()[2] != 0) return hm_fail(HM_ERR_INTERNAL, "msm: task count exceeds its bound");
+  const auto f0 = std::chrono::steady_clock::now();
   host_fold(sl.win(), sl.SW, sl.c, out_jac_ext, out_is_identity);   // SW == 1: no Horner, just the normalisation
+  ctx.calls.msm_host_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - f0).count();
 
   float ms[4] = {0, 0, 0, 0}, total = 0;
   float acc_kernel = 0;
   (void)hipEventElapsedTime(&total, ev[0], ev[4]);
-  if (sl.timed) {   // a graph replay carries no per-phase events: only the total is known
-    for (int i = 0; i < 4; ++i) (void)hipEventElapsedTime(&ms[i], ev[i], ev[i + 1]);
-    (void)hipEventElapsedTime(&acc_kernel, ev[5], ev[6]);
-  }
+  for (int i = 0; i < 4; ++i) (void)hipEventElapsedTime(&ms[i], ev[i], ev[i + 1]);
+  (void)hipEventElapsedTime(&acc_kernel, ev[5], ev[6]);
   ctx.last_msm.t_accum_kernel_ms = acc_kernel;
   ctx.last_msm.t_digits_ms = ms[0];
   ctx.last_msm.t_sort_ms = ms[1];
@@ -1820,17 +1749,18 @@ int msm_run(DeviceCtx& ctx, const uint32_t* d_scalars_ext, const uint32_t* d_xy,
 int g1_fixed_base_mul_run(DeviceCtx& ctx, const uint32_t* d_scalars_ext, size_t n, const uint64_t base_affine_ext[8],
                           uint32_t* d_out_affine_ext, hipStream_t stream) {
   if (n == 0) return HM_OK;
-  uint8_t* sm = (uint8_t*)ctx.small.ensure(64 + (size_t)64 * 15 * PT_WORDS * 4);
-  if (!sm) return hm_fail(HM_ERR_HIP, "fixed-base: table allocation failed");
-  uint32_t* d_base = (uint32_t*)sm;
-  uint32_t* d_table = (uint32_t*)(sm + 64);
-  HM_HIP_CHECK(hipMemcpyAsync(d_base, base_affine_ext, 64, hipMemcpyHostToDevice, stream));
-  hipLaunchKernelGGL(g1_fixed_table_kernel, dim3(1), dim3(64), 0, stream, (const uint32_t*)d_base, d_table);
+  AuxSlot* slot = aux_acquire(ctx, stream);          // the multiples table is per stream in use
+  if (!slot) return HM_ERR_HIP;
+  uint32_t* d_table = (uint32_t*)slot->table.ensure((size_t)64 * 15 * PT_WORDS * 4);
+  if (!d_table) return hm_fail(HM_ERR_HIP, "fixed-base: table allocation failed");
+  G1AffineWords base;
+  std::memcpy(base.w, base_affine_ext, 64);
+  hipLaunchKernelGGL(g1_fixed_table_kernel, dim3(1), dim3(64), 0, stream, base, d_table);
   HM_HIP_CHECK(hipGetLastError());
   hipLaunchKernelGGL(g1_fixed_base_mul_kernel, dim3((uint32_t)((n + ACC_THREADS - 1) / ACC_THREADS)), dim3(ACC_THREADS), 0,
                      stream, d_scalars_ext, (const uint32_t*)d_table, d_out_affine_ext, n);
   HM_HIP_CHECK(hipGetLastError());
-  return HM_OK;
+  return aux_release(ctx, slot, stream);
 }
 
 }  // namespace hm

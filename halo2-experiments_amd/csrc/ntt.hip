@@ -19,6 +19,7 @@
 
 #include "g1.h"
 #include "hm_internal.h"
+#include "host_fr.h"
 
 namespace hm {
 
@@ -31,13 +32,19 @@ constexpr int NTT_THREADS = HM_NTT_THREADS;
 // twiddle tables
 // ---------------------------------------------------------------------------------------------
 // out[j] = base^(j << shift), internal form, normalised, value < 2r.   9 x u32 per entry.
-__global__ void ntt_pow_table_kernel(const uint32_t* __restrict__ omega_ext, uint32_t* __restrict__ out,
-                                     uint32_t count, uint32_t shift) {
+struct FrWords {       // one external field element, passed to kernels by value
+  uint32_t w[8];
+};
+struct FrWords3 {
+  uint32_t w[24];
+};
+
+__global__ void ntt_pow_table_kernel(FrWords omega_ext, uint32_t* __restrict__ out, uint32_t count, uint32_t shift) {
   const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= count) return;
   uint32_t w[8];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) w[i] = omega_ext[i];
+  for (int i = 0; i < 8; ++i) w[i] = omega_ext.w[i];
   const Fr base = fe_from_ext<FrParams>(w);
   const uint64_t e = (uint64_t)j << shift;
   Fr acc = fe_one<FrParams>();
@@ -94,11 +101,15 @@ struct NttPassParams {
   uint32_t log_r0;       // last pass of a 3-pass plan: log2 R0 (else 0)
   uint32_t log_rows;     // last pass: log2 of the number of rows = log_n - s
   uint32_t log_lb;       // split point of the two-level inter-pass twiddle table
-  uint32_t has_scale;    // last pass: multiply by `scale` (internal-form constant) instead of ONE
+  uint32_t fin_mode;     // last pass: 0 = canonicalise only, 1 = multiply by fin[0], 2 = output i *= fin[i % 3]
   uint32_t has_coset;    // first pass: multiply a[i] by coset[i % 3] on load
   uint32_t direct_tw;    // non-last pass: tw_lo holds omega_m^e for every e < m (no forming product)
   uint32_t log_z;        // first pass of an extending transform: the input holds only the first n >> log_z
                          // coefficients (the rest are zero by definition); 0 = ordinary transform
+  // fused constants, 9-limb internal form, BY VALUE (a call never shares a constants buffer with another
+  // call on another stream): coset[3] for the first pass, fin[3] for the last
+  uint32_t coset[27];
+  uint32_t fin[27];
 };
 
 // everything a register round needs
@@ -171,11 +182,20 @@ template <int LOG_TILE>
 __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(const uint32_t* in, uint32_t* out,
                                                                NttPassParams pp, const uint32_t* __restrict__ stage_tw,
                                                                const uint32_t* __restrict__ tw_lo,
-                                                               const uint32_t* __restrict__ tw_hi,
-                                                               const uint32_t* __restrict__ scale_int,
-                                                               const uint32_t* __restrict__ coset_int) {
+                                                               const uint32_t* __restrict__ tw_hi) {
   extern __shared__ uint32_t lds[];
+  __shared__ uint32_t s_const[54];   // [0, 27): coset pattern, [27, 54): final constants (indexed per element)
   const uint32_t tid = threadIdx.x;
+  if (pp.has_coset | pp.fin_mode) {
+    if (tid == 0) {
+#pragma unroll
+      for (int i = 0; i < 27; ++i) {
+        s_const[i] = pp.coset[i];
+        s_const[27 + i] = pp.fin[i];
+      }
+    }
+    __syncthreads();
+  }
   const uint32_t s = pp.s, log_c = pp.log_c;
   const uint32_t tile_elems = 1u << (s + log_c);  // <= 2^LOG_TILE
   const uint32_t cmask = (1u << log_c) - 1u;
@@ -230,7 +250,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(const uint32_t* i
     Fr x = fe_unpack<FrParams>(w);
     if (pp.has_coset) {
       Fr cz;
-      const uint32_t* cp = coset_int + (uint32_t)(g % 3) * 9;
+      const uint32_t* cp = s_const + (uint32_t)(g % 3) * 9;
 #pragma unroll
       for (int i = 0; i < 9; ++i) cz.l[i] = cp[i];
       HM_DECLARE(cz, 2.0);
@@ -285,20 +305,24 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(const uint32_t* i
       dst[1] = make_uint4(w[4], w[5], w[6], w[7]);
     }
   } else {
-    Fr fin = fe_one<FrParams>();
-    if (pp.has_scale) {
-#pragma unroll
-      for (int i = 0; i < 9; ++i) fin.l[i] = scale_int[i];
-      HM_DECLARE(fin, 2.0);
-    }
     for (uint32_t e = tid; e < tile_elems; e += NTT_THREADS) {
       const uint32_t c = e & cmask, k = e >> log_c;
       const Fr x = lds_load<LOG_TILE>(lds, e);
-      // with a fused scale the product reduces; without one the cheap quotient-estimate reduction does
-      const Fr y = fe_canonical(pp.has_scale ? fe_mul(x, fin) : fe_reduce_small(x));
+      const uint64_t g = (dest_lo0 + c) + ((uint64_t)k << pp.log_rows);
+      // with a fused constant the product reduces; without one the cheap quotient-estimate reduction does
+      Fr y;
+      if (pp.fin_mode) {
+        Fr fin;
+        const uint32_t* fp = s_const + 27 + (pp.fin_mode == 2 ? (uint32_t)(g % 3) * 9 : 0u);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) fin.l[i] = fp[i];
+        HM_DECLARE(fin, 1.0);
+        y = fe_canonical(fe_mul(x, fin));
+      } else {
+        y = fe_canonical(fe_reduce_small(x));
+      }
       uint32_t w[8];
       fe_pack(w, y);
-      const uint64_t g = (dest_lo0 + c) + ((uint64_t)k << pp.log_rows);
       uint4* dst = reinterpret_cast<uint4*>(out + g * 8);
       dst[0] = make_uint4(w[0], w[1], w[2], w[3]);
       dst[1] = make_uint4(w[4], w[5], w[6], w[7]);
@@ -307,12 +331,12 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(const uint32_t* i
 }
 
 // element-wise a[i] *= c (external canonical in/out); used by the domain helpers
-__global__ void fr_scale_kernel(uint32_t* __restrict__ a, const uint32_t* __restrict__ c_ext, uint64_t n) {
+__global__ void fr_scale_kernel(uint32_t* __restrict__ a, FrWords c_ext, uint64_t n) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   uint32_t cw[8];
 #pragma unroll
-  for (int k = 0; k < 8; ++k) cw[k] = c_ext[k];
+  for (int k = 0; k < 8; ++k) cw[k] = c_ext.w[k];
   // c_int = c * 2^261; a_ext * c_int * 2^-261 = (a*c) in external form
   const Fr c_int = fe_from_ext<FrParams>(cw);
   uint4* p = reinterpret_cast<uint4*>(a + i * 8);
@@ -326,13 +350,13 @@ __global__ void fr_scale_kernel(uint32_t* __restrict__ a, const uint32_t* __rest
 }
 
 // a[i] *= c3[i % 3] (EvaluationDomain::distribute_powers_zeta); c3: 3 external constants
-__global__ void fr_mul_pattern3_kernel(uint32_t* a, const uint32_t* __restrict__ c3_ext, uint64_t n) {
+__global__ void fr_mul_pattern3_kernel(uint32_t* a, FrWords3 c3_ext, uint64_t n) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   uint32_t cw[8];
-  const uint32_t* cp = c3_ext + (uint32_t)(i % 3) * 8;
+  const uint32_t sel = (uint32_t)(i % 3);
 #pragma unroll
-  for (int k = 0; k < 8; ++k) cw[k] = cp[k];
+  for (int k = 0; k < 8; ++k) cw[k] = sel == 0 ? c3_ext.w[k] : sel == 1 ? c3_ext.w[8 + k] : c3_ext.w[16 + k];
   const Fr c_int = fe_from_ext<FrParams>(cw);
   uint4* p = reinterpret_cast<uint4*>(a + i * 8);
   const uint4 lo = p[0], hi = p[1];
@@ -342,18 +366,6 @@ __global__ void fr_mul_pattern3_kernel(uint32_t* a, const uint32_t* __restrict__
   fe_pack(o, y);
   p[0] = make_uint4(o[0], o[1], o[2], o[3]);
   p[1] = make_uint4(o[4], o[5], o[6], o[7]);
-}
-
-// c_ext (external canonical) -> 9-limb internal form, for scale / coset constants
-__global__ void fr_ext_to_int_kernel(const uint32_t* __restrict__ c_ext, uint32_t* __restrict__ out, uint32_t count) {
-  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= count) return;
-  uint32_t w[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) w[i] = c_ext[j * 8 + i];
-  const Fr x = fe_from_ext<FrParams>(w);
-#pragma unroll
-  for (int i = 0; i < 9; ++i) out[j * 9 + i] = x.l[i];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -390,64 +402,135 @@ int ntt_plan_first_digit(uint32_t log_n, int* passes) {
   return (int)digits[0];
 }
 
+void ntt_tables_release(NttTables& t) {
+  if (t.d_lo) (void)hipFree(t.d_lo);
+  if (t.d_hi) (void)hipFree(t.d_hi);
+  if (t.d_mid) (void)hipFree(t.d_mid);
+  for (auto& s : t.d_stage)
+    if (s) (void)hipFree(s);
+  if (t.ready) (void)hipEventDestroy(t.ready);
+  t = NttTables{};
+}
+
+// Tables for (omega, log_n): built once on the first caller's stream.  Later callers on OTHER streams
+// wait on the device for the `ready` event until it has been seen complete (stream-safe publication).
 NttTables* ntt_get_tables(DeviceCtx& ctx, const uint64_t omega_ext[4], uint32_t log_n, hipStream_t stream) {
-  for (auto& t : ctx.ntt_tables)
-    if (t->log_n == log_n && std::memcmp(t->omega, omega_ext, 32) == 0) return t.get();
+  for (auto& t : ctx.ntt_tables) {
+    if (t->log_n == log_n && std::memcmp(t->omega, omega_ext, 32) == 0) {
+      if (!t->published) {
+        if (hipEventQuery(t->ready) == hipSuccess) {
+          t->published = true;
+        } else if (stream != t->build_stream) {
+          HM_HIP_CHECK_PTR(hipStreamWaitEvent(stream, t->ready, 0));
+        }
+      }
+      return t.get();
+    }
+  }
   auto t = std::make_unique<NttTables>();
   t->log_n = log_n;
   std::memcpy(t->omega, omega_ext, 32);
   uint32_t digits[3] = {0, 0, 0};
   const int passes = plan_digits(log_n, digits);
   t->log_lb = (log_n + 1) / 2;
-  HM_HIP_CHECK_PTR(hipMalloc(&t->d_omega, 32));
-  HM_HIP_CHECK_PTR(hipMemcpyAsync(t->d_omega, omega_ext, 32, hipMemcpyHostToDevice, stream));
-  auto make = [&](uint32_t count, uint32_t shift, uint32_t** dst) -> bool {
-    if (hipMalloc(dst, (size_t)count * 36) != hipSuccess) return false;
-    hipLaunchKernelGGL(ntt_pow_table_kernel, dim3((count + 127) / 128), dim3(128), 0, stream,
-                       (const uint32_t*)t->d_omega, *dst, count, shift);
-    return hipGetLastError() == hipSuccess;
+  FrWords om;
+  std::memcpy(om.w, omega_ext, 32);
+  bool ok = true;
+  auto make = [&](uint32_t count, uint32_t shift, uint32_t** dst) {
+    if (!ok) return;
+    if (hipMalloc(dst, (size_t)count * 36) != hipSuccess) { *dst = nullptr; ok = false; return; }
+    hipLaunchKernelGGL(ntt_pow_table_kernel, dim3((count + 127) / 128), dim3(128), 0, stream, om, *dst, count, shift);
+    if (hipGetLastError() != hipSuccess) ok = false;
   };
   if (passes > 1) {
     if (log_n <= NTT_DIRECT_LOG) {
-      if (!make(1u << log_n, 0, &t->d_lo)) return nullptr;                       // omega_n^e for every e < n
+      make(1u << log_n, 0, &t->d_lo);                                              // omega_n^e for every e < n
     } else {
-      if (!make(1u << t->log_lb, 0, &t->d_lo)) return nullptr;
-      if (!make(1u << (log_n - t->log_lb), t->log_lb, &t->d_hi)) return nullptr;
-      const uint32_t log_m1 = log_n - digits[0];                                 // size of the middle pass's sub-problem
-      if (passes == 3 && log_m1 <= NTT_DIRECT_LOG)
-        if (!make(1u << log_m1, digits[0], &t->d_mid)) return nullptr;           // omega_m1^e = omega_n^(e << s0)
+      make(1u << t->log_lb, 0, &t->d_lo);
+      make(1u << (log_n - t->log_lb), t->log_lb, &t->d_hi);
+      const uint32_t log_m1 = log_n - digits[0];                                   // size of the middle pass's sub-problem
+      if (passes == 3 && log_m1 <= NTT_DIRECT_LOG) make(1u << log_m1, digits[0], &t->d_mid);   // omega_m1^e = omega_n^(e << s0)
     }
   }
   for (int p = 0; p < passes; ++p) {
     const uint32_t s = digits[p];
     if (t->d_stage[s] == nullptr) {
       const uint32_t count = s == 0 ? 1 : (1u << (s - 1));
-      if (!make(count == 0 ? 1 : count, log_n - s, &t->d_stage[s])) return nullptr;
+      make(count == 0 ? 1 : count, log_n - s, &t->d_stage[s]);
     }
   }
+  if (ok && hipEventCreateWithFlags(&t->ready, hipEventDisableTiming) != hipSuccess) ok = false;
+  if (ok && hipEventRecord(t->ready, stream) != hipSuccess) ok = false;
+  if (!ok) {
+    (void)hipStreamSynchronize(stream);      // kernels already enqueued may still write the tables being freed
+    ntt_tables_release(*t);
+    hm_fail(HM_ERR_HIP, "ntt: twiddle table allocation failed");
+    return nullptr;
+  }
+  t->build_stream = stream;
   ctx.ntt_tables.push_back(std::move(t));
   return ctx.ntt_tables.back().get();
 }
 
-// d_a: `batch` back-to-back arrays of n x 32 B on the device, each transformed in place.  d_scale_int / d_coset_int: optional 9-limb
-// internal-form constants already on the device.
+AuxSlot* aux_acquire(DeviceCtx& ctx, hipStream_t stream) {
+  AuxSlot* pick = nullptr;
+  for (auto& s : ctx.aux)
+    if (s.used && s.stream == stream) pick = &s;        // stream order already protects its buffers
+  if (!pick)
+    for (auto& s : ctx.aux)
+      if (!s.used) { pick = &s; break; }
+  if (!pick) {
+    for (auto& s : ctx.aux)                              // a slot whose last user has finished
+      if (hipEventQuery(s.done) == hipSuccess && (!pick || s.last_use < pick->last_use)) pick = &s;
+  }
+  if (!pick) {                                           // all busy on other streams: queue behind the oldest
+    pick = &ctx.aux[0];
+    for (auto& s : ctx.aux)
+      if (s.last_use < pick->last_use) pick = &s;
+    if (hipStreamWaitEvent(stream, pick->done, 0) != hipSuccess) {
+      hm_fail(HM_ERR_HIP, "aux slot: hipStreamWaitEvent failed");
+      return nullptr;
+    }
+  }
+  if (!pick->done && hipEventCreateWithFlags(&pick->done, hipEventDisableTiming) != hipSuccess) {
+    hm_fail(HM_ERR_HIP, "aux slot: event creation failed");
+    return nullptr;
+  }
+  pick->used = true;
+  pick->stream = stream;
+  pick->last_use = ++ctx.aux_clock;
+  return pick;
+}
+
+int aux_release(DeviceCtx& ctx, AuxSlot* slot, hipStream_t stream) {
+  (void)ctx;
+  HM_HIP_CHECK(hipEventRecord(slot->done, stream));
+  return HM_OK;
+}
+
+static void fill_internal9(const uint64_t ext[4], uint32_t out[9]) { host::fr_to_internal9(host::fr_load(ext), out); }
+
+// d_a: `batch` back-to-back arrays of n x 32 B on the device, each transformed in place.  `fused`: optional
+// constants (host pointers, external words) multiplied in by the first / last pass.
 // d_in != nullptr: an extending transform (EvaluationDomain::coeff_to_extended): `batch` compact arrays of
 // n >> log_z coefficients at d_in, zero-padded to n by definition, transformed into d_a (out of place;
 // the zero part is never materialised and the first log_z stages of the first pass cost nothing).
-int ntt_run(DeviceCtx& ctx, uint32_t* d_a, const uint64_t omega_ext[4], uint32_t log_n, uint32_t batch,
-            const uint32_t* d_scale_int, const uint32_t* d_coset_int, hipStream_t stream, const uint32_t* d_in,
-            uint32_t log_z) {
+int ntt_run(DeviceCtx& ctx, uint32_t* d_a, const uint64_t omega_ext[4], uint32_t log_n, uint32_t batch, const NttFused& fused,
+            hipStream_t stream, const uint32_t* d_in, uint32_t log_z) {
   if (log_n > 28) return hm_fail(HM_ERR_BAD_ARG, "ntt: log_n > 28 (Fr has 2-adicity 28)");
   if (batch == 0) return HM_OK;
   if (batch > 65535) return hm_fail(HM_ERR_BAD_ARG, "ntt: batch > 65535");
   NttTables* tab = ntt_get_tables(ctx, omega_ext, log_n, stream);
-  if (!tab) return hm_fail(HM_ERR_HIP, "ntt: twiddle table allocation failed");
+  if (!tab) return HM_ERR_HIP;
   uint32_t digits[3] = {0, 0, 0};
   const int passes = plan_digits(log_n, digits);
   const uint64_t n = 1ull << log_n;
   uint32_t* scratch = nullptr;
+  AuxSlot* slot = nullptr;
   if (passes > 1) {
-    scratch = (uint32_t*)ctx.ensure_scratch(n * 32 * batch);
+    slot = aux_acquire(ctx, stream);
+    if (!slot) return HM_ERR_HIP;
+    scratch = (uint32_t*)slot->scratch.ensure(n * 32 * batch);
     if (!scratch) return hm_fail(HM_ERR_HIP, "ntt: scratch allocation failed");
   }
   const size_t lds_bytes = (size_t)9 * sizeof(uint32_t) << LOG_TILE;
@@ -458,6 +541,22 @@ int ntt_run(DeviceCtx& ctx, uint32_t* d_a, const uint64_t omega_ext[4], uint32_t
   }
   if (d_in && (passes < 2 || log_z == 0 || log_z > digits[0]))
     return hm_fail(HM_ERR_INTERNAL, "ntt: extending form needs a multi-pass plan and log_z <= first digit");
+  // fused constants -> internal 9-limb form on the host (a handful of 4 x u64 products)
+  uint32_t coset9[27] = {}, fin9[27] = {};
+  uint32_t fin_mode = 0;
+  if (fused.coset)
+    for (int j = 0; j < 3; ++j) fill_internal9(fused.coset + 4 * j, coset9 + 9 * j);
+  if (fused.post3) {
+    fin_mode = 2;
+    for (int j = 0; j < 3; ++j) {
+      host::Fr4 c = host::fr_load(fused.post3 + 4 * j);
+      if (fused.scale) c = host::fr_mul(c, host::fr_load(fused.scale));
+      host::fr_to_internal9(c, fin9 + 9 * j);
+    }
+  } else if (fused.scale) {
+    fin_mode = 1;
+    fill_internal9(fused.scale, fin9);
+  }
   uint32_t log_stride = log_n;
   for (int p = 0; p < passes; ++p) {
     NttPassParams pp{};
@@ -469,8 +568,10 @@ int ntt_run(DeviceCtx& ctx, uint32_t* d_a, const uint64_t omega_ext[4], uint32_t
     pp.log_lb = tab->log_lb;
     pp.log_rows = log_n - pp.s;
     pp.log_r0 = (pp.last && passes == 3) ? digits[0] : 0u;
-    pp.has_scale = (pp.last && d_scale_int) ? 1u : 0u;
-    pp.has_coset = (p == 0 && d_coset_int) ? 1u : 0u;
+    pp.fin_mode = pp.last ? fin_mode : 0u;
+    pp.has_coset = (p == 0 && fused.coset) ? 1u : 0u;
+    if (pp.has_coset) std::memcpy(pp.coset, coset9, sizeof coset9);
+    if (pp.fin_mode) std::memcpy(pp.fin, fin9, sizeof fin9);
     pp.log_z = (p == 0 && d_in) ? log_z : 0u;
     uint32_t log_c = (uint32_t)LOG_TILE > pp.s ? (uint32_t)LOG_TILE - pp.s : 0u;
     const uint32_t avail = pp.last ? pp.log_rows : pp.log_stride;  // columns / rows that exist
@@ -481,36 +582,33 @@ int ntt_run(DeviceCtx& ctx, uint32_t* d_a, const uint64_t omega_ext[4], uint32_t
     uint32_t* dst = (p == passes - 1) ? d_a : scratch;
     const uint32_t* lo_tab = tab->d_lo;
     if (!pp.last) {
-      const uint32_t log_m = pp.s + pp.log_stride;
       if (log_n <= NTT_DIRECT_LOG) {
         pp.direct_tw = 1;            // d_lo = omega_n^e; omega_m^e = omega_n^(e << (log_n - log_m)) only for p == 0 (m = n)
       } else if (p == 1 && tab->d_mid) {
         pp.direct_tw = 1;
         lo_tab = tab->d_mid;
       }
-      (void)log_m;
     }
     hipLaunchKernelGGL(ntt_pass_kernel<LOG_TILE>, dim3((uint32_t)tiles, batch), dim3(NTT_THREADS), lds_bytes, stream, src, dst, pp,
-                       (const uint32_t*)tab->d_stage[pp.s], lo_tab, (const uint32_t*)tab->d_hi, d_scale_int, d_coset_int);
+                       (const uint32_t*)tab->d_stage[pp.s], lo_tab, (const uint32_t*)tab->d_hi);
     HM_HIP_CHECK(hipGetLastError());
   }
+  if (slot) return aux_release(ctx, slot, stream);
   return HM_OK;
 }
 
-int fr_scale_run(uint32_t* d_a, const uint32_t* d_c_ext, uint64_t n, hipStream_t stream) {
-  hipLaunchKernelGGL(fr_scale_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, stream, d_a, d_c_ext, n);
+int fr_scale_run(uint32_t* d_a, const uint64_t c_ext[4], uint64_t n, hipStream_t stream) {
+  FrWords c;
+  std::memcpy(c.w, c_ext, 32);
+  hipLaunchKernelGGL(fr_scale_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, stream, d_a, c, n);
   HM_HIP_CHECK(hipGetLastError());
   return HM_OK;
 }
 
-int fr_mul_pattern3_run(uint32_t* d_a, const uint32_t* d_c3_ext, uint64_t n, hipStream_t stream) {
-  hipLaunchKernelGGL(fr_mul_pattern3_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, stream, d_a, d_c3_ext, n);
-  HM_HIP_CHECK(hipGetLastError());
-  return HM_OK;
-}
-
-int fr_ext_to_int_run(const uint32_t* d_c_ext, uint32_t* d_out, uint32_t count, hipStream_t stream) {
-  hipLaunchKernelGGL(fr_ext_to_int_kernel, dim3((count + 63) / 64), dim3(64), 0, stream, d_c_ext, d_out, count);
+int fr_mul_pattern3_run(uint32_t* d_a, const uint64_t c3_ext[12], uint64_t n, hipStream_t stream) {
+  FrWords3 c;
+  std::memcpy(c.w, c3_ext, 96);
+  hipLaunchKernelGGL(fr_mul_pattern3_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, stream, d_a, c, n);
   HM_HIP_CHECK(hipGetLastError());
   return HM_OK;
 }

@@ -8,7 +8,8 @@ side of every ``best_fft`` call in ``create_proof`` (upst
     coeff_to_extended(a)  zero-pad to 2^extended_k, a[i] *= {1, zeta, zeta^2}[i % 3], best_fft(extended_omega)
     extended_to_coeff(a)  ifft(extended), a[i] *= {1, zeta^-1, zeta^-2}[i % 3], truncate to n*(j-1)
 
-The scale-by-divisor and the coset shift are fused into the last / first NTT pass on the GPU.
+The scale-by-divisor and the coset shifts (forward and inverse) are fused into the last / first NTT
+pass on the GPU.
 Arrays are GPU tensors (int64 views of 4-limb Montgomery words); constants are derived here with
 Python integers from the field's definition.
 """
@@ -102,12 +103,12 @@ class EvaluationDomain:
         n*(j-1) rows of each polynomial (a view)."""
         en = self.extended_len()
         batch = self._batch_of(a, en, "extended_to_coeff")
-        self._ifft(a, self.extended_omega_inv, self.extended_k, self.extended_ifft_divisor)
         r = FR_MODULUS
         c3 = np.concatenate([fr_words(1), fr_words(self.g_coset_inv), fr_words(self.g_coset_inv * self.g_coset_inv % r)])
+        # one call: the ifft divisor and the zeta^-(i % 3) pattern are folded into the last NTT pass
+        _lib.check(_lib.load().hm_extended_to_coeff_bn256_fr_dev(
+            ctypes.c_void_p(a.data_ptr()), batch, _ptr(fr_words(self.extended_omega_inv)), self.extended_k,
+            _ptr(fr_words(self.extended_ifft_divisor)), _ptr(c3), ctypes.c_void_p(_stream_ptr(a))))
         flat = a.reshape(batch, en, 4)
-        for b in range(batch):     # the i % 3 pattern restarts with every polynomial
-            _lib.check(_lib.load().hm_fr_distribute_powers_dev(ctypes.c_void_p(flat[b].data_ptr()), en, _ptr(c3),
-                                                                ctypes.c_void_p(_stream_ptr(a))))
         out = flat[:, : self.n * self.quotient_poly_degree]
         return out if a.dim() == 3 else out[0]

@@ -61,15 +61,19 @@ const char* hm_version(void);
 /* sum_i scalars[i] * bases[i].  scalars: n x 4 u64 (Fr), bases: n x 8 u64 (G1Affine), both host
  * memory.  Result as an affine point (out_xy, Montgomery) plus an identity flag, which is the
  * canonical form of the G1 value best_multiexp returns; n == 0 yields the identity.
- * The converted base array is cached on the device keyed by (pointer, n, content probe), because
- * create_proof passes the same params.g / params.g_lagrange slices to every commitment. */
+ * Both arrays cross PCIe in every call: the library keeps no pointer-keyed cache of converted bases (a
+ * buffer reused at the same address with other contents must never yield a stale commitment).  A caller
+ * that owns a long-lived base array -- ParamsKZG::g / g_lagrange -- registers it once (below). */
 int hm_msm_bn256_g1(const uint64_t* scalars, const uint64_t* bases, size_t n, uint64_t out_xy[8], int* out_is_identity);
 
 /* Same, Jacobian output (x, y, 1) / (0, 0, 0): the `C::Curve` value itself. */
 int hm_msm_bn256_g1_jacobian(const uint64_t* scalars, const uint64_t* bases, size_t n, uint64_t out_xyz[12]);
 
 /* Device-resident base sets (ParamsKZG::g / g_lagrange live for the whole proof):
- * upload + convert once, then run MSMs against bases[offset .. offset + n). */
+ * upload + convert once, then run MSMs against bases[offset .. offset + n).
+ * hm_release_bases never waits for the device: a set that an un-awaited hm_msm_submit_dev ticket still
+ * reads is freed when that ticket is awaited, and the buffers of a released set are recycled by the next
+ * registration of the same size. */
 int hm_register_bases(const uint64_t* bases, size_t n, uint64_t* out_handle);
 int hm_release_bases(uint64_t handle);
 int hm_msm_bn256_g1_h(uint64_t handle, size_t offset, const uint64_t* scalars, size_t n, uint64_t out_xy[8],
@@ -114,20 +118,17 @@ int hm_g1_sum(const uint64_t* points_xyz, size_t count, uint64_t out_xyz[12]);
 /* Window-size override for experiments (0 = automatic). */
 int hm_msm_set_window(int c);
 
-/* EXPERIMENTAL, off by default.  enable != 0: MSMs of up to 2^20 points replay everything after their digit
- * kernel from a hipGraph captured on first use per (workspace slot, size, window, base set): one
- * hipGraphLaunch instead of ~30 launches (host cost per call 128 us -> 24 us at 2^18); hm_get_msm_stats
- * then reports only the total time of such calls.  Not the default because a replay runs slower on the
- * device than direct launches (0.88 vs 0.79 ms at 2^18): it pays only when the host thread is the bottleneck. */
-int hm_msm_use_graphs(int enable);
-
 /* ---- NTT: stands in for halo2_proofs::arithmetic::best_fft::<bn256::Fr> --------------------- */
 
 /* In place on host memory: a[j] <- sum_i a[i] * omega^(i*j), natural order in and out, unscaled.
  * a: 2^log_n x 4 u64 (Fr); omega: 4 u64 (Fr), a 2^log_n-th root of unity; log_n <= 28. */
 int hm_ntt_bn256_fr(uint64_t* a, const uint64_t omega[4], uint32_t log_n);
 
-/* Device-pointer form, in place, asynchronous on `stream`. */
+/* Device-pointer form, in place, asynchronous on `stream`.  Every *_dev NTT entry point may be called
+ * concurrently on different streams (and from different threads): the ping-pong buffer of a multi-pass
+ * transform belongs to the stream in use (a small pool, handed over behind an event), fused constants
+ * travel to the kernels by value, and twiddle tables built on one stream are published to the others
+ * behind an event. */
 int hm_ntt_bn256_fr_dev(void* d_a, const uint64_t omega[4], uint32_t log_n, void* stream);
 
 /* `batch` back-to-back arrays of 2^log_n elements transformed by ONE set of launches (the ~48
@@ -154,6 +155,15 @@ int hm_coset_ntt_bn256_fr_dev(void* d_a, const uint64_t omega[4], uint32_t log_n
 int hm_coeff_to_extended_bn256_fr_dev(const void* d_coeffs, void* d_ext, size_t batch, const uint64_t extended_omega[4],
                                       uint32_t log_n, uint32_t log_ext, const uint64_t* coset, void* stream);
 
+/* EvaluationDomain::extended_to_coeff's arithmetic in one call (halo2_proofs poly/domain.rs: ifft over the
+ * extended domain, then distribute_powers_zeta with the INVERSE coset powers): `batch` arrays of 2^log_ext
+ * evaluations, in place; best_fft(a, extended_omega_inv, log_ext), then a[i] *= divisor * coset_inv[i % 3]
+ * with coset_inv = {1, zeta^-1, zeta^-2} -- divisor and pattern are folded into three constants that the
+ * LAST NTT pass multiplies in, so no separate sweep over the 2^log_ext elements remains.  The caller
+ * truncates to n * (j - 1) coefficients. */
+int hm_extended_to_coeff_bn256_fr_dev(void* d_a, size_t batch, const uint64_t extended_omega_inv[4], uint32_t log_ext,
+                                      const uint64_t divisor[4], const uint64_t coset_inv[12], void* stream);
+
 /* a[i] *= c element-wise (device pointer, in place). */
 int hm_fr_scale_dev(void* d_a, size_t n, const uint64_t c[4], void* stream);
 /* EvaluationDomain::distribute_powers_zeta on its own: a[i] *= c3[i % 3] (device pointer, in place). */
@@ -172,6 +182,21 @@ typedef struct hm_msm_stats {
   uint32_t window_bits, windows;
 } hm_msm_stats;
 int hm_get_msm_stats(hm_msm_stats* out);
+
+/* Per-call counters of the current device since start / hm_reset_stats: what a build of the Rust shim
+ *  reads after create_proof to get the MEASURED call trace -- how many best_multiexp /
+ * best_fft calls of which size, and where their time went. */
+typedef struct hm_stats {
+  uint64_t msm_calls, msm_points;         /* best_multiexp-equivalent calls (every form) and the points they covered */
+  uint64_t ntt_calls, ntt_elements;       /* best_fft-equivalent transforms (a batched call of b arrays counts b) */
+  uint64_t msm_calls_by_log2[32];         /* histogram over floor(log2 n) */
+  uint64_t ntt_calls_by_log2[32];         /* histogram over log_n */
+  double msm_h2d_us, msm_device_us, msm_host_us;  /* host-pointer uploads; hipEvent span of the launches; host fold */
+  double ntt_h2d_us, ntt_device_us, ntt_d2h_us;   /* host-pointer form only (device-pointer calls are not waited for) */
+  uint64_t h2d_bytes, d2h_bytes;          /* bytes the host-pointer forms moved over PCIe */
+} hm_stats;
+int hm_get_stats(hm_stats* out);
+int hm_reset_stats(void);
 
 #ifdef __cplusplus
 }

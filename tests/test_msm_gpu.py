@@ -257,16 +257,120 @@ def test_sizes_off_the_power_of_two_grid(cref, pyref, n):
         h.release_bases(hd)
 
 
-def test_host_pointer_base_cache_notices_changed_bases(cref, golden):
-    """The drop-in call caches the converted base array by (pointer, length, fingerprint): mutating the
-    array in place must not return the stale result."""
+def test_host_pointer_form_never_returns_a_stale_result(cref, golden):
+    """The drop-in call takes both arrays by host pointer and keeps NO pointer-keyed cache of the bases: a
+    buffer that is mutated in place -- at any index -- or re-used at the same address with other contents
+    (a Rust Vec freed and re-allocated, as the verifier's MSMs do) must give the result of its CURRENT
+    contents."""
     g = golden["msm"]
     s, b = g["n1024_uniform_s"].copy(), g["n1024_uniform_b"].copy()
     assert g1_equal(h.best_multiexp(s, b), g["n1024_uniform_r"])
-    assert g1_equal(h.best_multiexp(s, b), g["n1024_uniform_r"])       # cache hit
-    b[0], b[512] = b[512].copy(), b[0].copy()                         # same buffer, different contents
+    assert g1_equal(h.best_multiexp(s, b), g["n1024_uniform_r"])
+    for i, j in ((0, 512), (1, 513), (7, 1000), (1022, 1023)):          # sampled and un-sampled rows alike
+        b[i], b[j] = b[j].copy(), b[i].copy()
+        exp = cref.g1_to_affine(cref.best_multiexp(s, b, 4))[0]
+        assert g1_equal(h.best_multiexp(s, b), exp), (i, j)
+    addr = b.ctypes.data
+    b[:] = g["n1024_prover_b"]                                          # same address, same length, other points
+    assert b.ctypes.data == addr
     exp = cref.g1_to_affine(cref.best_multiexp(s, b, 4))[0]
     assert g1_equal(h.best_multiexp(s, b), exp)
+    b[3] = 0                                                            # one base becomes the identity
+    exp = cref.g1_to_affine(cref.best_multiexp(s, b, 4))[0]
+    assert g1_equal(h.best_multiexp(s, b), exp)
+
+
+def _replay_sparse_column(n, used_rows, seed):
+    from halo2_experiments_amd.replay import _sparse_column
+    import torch
+    return _sparse_column(n, used_rows, seed, torch.device("cuda", torch.cuda.current_device()))
+
+
+@pytest.mark.parametrize("log_n,used_rows", [(18, 1100), (11, 40)])
+def test_baseline_config_sizes_plain_and_eight_in_flight(cref, log_n, used_rows):
+    """BASELINE configs[3] (MerkleSumTree, k = 18) and configs[1] (Poseidon, k = 11) at EXACTLY their MSM
+    sizes: a uniform column and the create_proof replay's sparse column (used_rows small values, half of
+    them the constant 1, six blinding rows) against the C oracle -- through the synchronous call and
+    through hm_msm_submit_dev with all eight asynchronous slots in flight on four streams."""
+    import torch
+    n = 1 << log_n
+    gen = cref.g1_generator()
+    bases = h.g1_fixed_base_mul(rand_fr_gpu(n, 1800 + log_n), gen)
+    bh = bases.cpu().numpy().view(np.uint64)
+    cols = [rand_fr_gpu(n, 1801 + log_n), _replay_sparse_column(n, used_rows, 1802 + log_n)]
+    exps = [cref.g1_to_affine(cref.best_multiexp(c.cpu().numpy().view(np.uint64), bh, 8))[0] for c in cols]
+    assert g1_equal(h.best_multiexp(cols[0].cpu().numpy().view(np.uint64), bh), exps[0])    # host-pointer drop-in form
+    hd = h.register_bases(bases)
+    try:
+        for c, e in zip(cols, exps):
+            assert g1_equal(h.best_multiexp(c, hd), e)
+        st = h.msm_stats()
+        assert st["windows"] * st["window_bits"] >= 255
+        streams = [torch.cuda.Stream() for _ in range(4)]
+        for st_ in streams:
+            st_.wait_stream(torch.cuda.current_stream())
+        for round_ in range(2):
+            tickets = []
+            for i in range(8):
+                with torch.cuda.stream(streams[i % 4]):
+                    tickets.append(h.best_multiexp_submit(cols[(i + round_) & 1], hd))
+            for i, t in enumerate(tickets):
+                assert g1_equal(h.best_multiexp_wait(t), exps[(i + round_) & 1]), (round_, i)
+    finally:
+        h.release_bases(hd)
+
+
+def test_release_with_a_ticket_in_flight_and_buffer_recycling(cref, golden):
+    """hm_release_bases never waits for the device: a set released while a ticket still reads it stays
+    alive until that ticket is awaited, and the next registration of the same size recycles the buffers
+    of a released set (other contents => other result)."""
+    import torch
+    g = golden["msm"]
+    s = torch.from_numpy(g["n1024_uniform_s"].view(np.int64).copy()).cuda()
+    hd = h.register_bases(g["n1024_uniform_b"])
+    t = h.best_multiexp_submit(s, hd)
+    h.release_bases(hd)                                     # ticket still in flight
+    hd2 = h.register_bases(g["n1024_prover_b"])             # must NOT take over the buffers the ticket reads
+    t2 = h.best_multiexp_submit(torch.from_numpy(g["n1024_prover_s"].view(np.int64).copy()).cuda(), hd2)
+    assert g1_equal(h.best_multiexp_wait(t), g["n1024_uniform_r"])
+    assert g1_equal(h.best_multiexp_wait(t2), g["n1024_prover_r"])
+    h.release_bases(hd2)
+    for name in ("n1024_small", "n1024_uniform", "n1024_one"):           # recycled buffers, new contents each time
+        hd3 = h.register_bases(g[f"{name}_b"])
+        assert g1_equal(h.best_multiexp(g[f"{name}_s"], hd3), g[f"{name}_r"]), name
+        h.release_bases(hd3)
+    with pytest.raises(_lib.Halo2Mi355xError):
+        h.release_bases(hd3)
+
+
+def test_call_counters(golden):
+    """hm_get_stats: the measured call trace a build of the Rust shim reads after create_proof."""
+    import torch
+    lib = _lib.load()
+    g = golden["msm"]
+    _lib.check(lib.hm_reset_stats())
+    st = _lib.Stats()
+    _lib.check(lib.hm_get_stats(ctypes.byref(st)))
+    assert st.msm_calls == 0 and st.ntt_calls == 0 and st.h2d_bytes == 0
+    h.best_multiexp(g["n1024_uniform_s"], g["n1024_uniform_b"])          # host-pointer form: 96 B per point cross PCIe
+    hd = h.register_bases(g["n255_uniform_b"])
+    h.best_multiexp(g["n255_uniform_s"], hd)                               # handle form: 32 B per point
+    t = h.best_multiexp_submit(torch.from_numpy(g["n255_uniform_s"].view(np.int64).copy()).cuda(), hd)
+    h.best_multiexp_wait(t)
+    h.release_bases(hd)
+    a = golden["ntt"]["k7_in"].copy()
+    h.best_fft(a, golden["ntt"]["k7_omega"], 7)
+    d = torch.from_numpy(golden["ntt"]["k10_in"].view(np.int64).copy()).cuda().reshape(1, 1024, 4).repeat(3, 1, 1).contiguous()
+    from halo2_experiments_amd.domain import EvaluationDomain
+    EvaluationDomain(3, 10).lagrange_to_coeff(d)
+    torch.cuda.synchronize()
+    _lib.check(lib.hm_get_stats(ctypes.byref(st)))
+    assert st.msm_calls == 3 and st.msm_points == 1024 + 255 + 255
+    assert st.msm_calls_by_log2[10] == 1 and st.msm_calls_by_log2[7] == 2
+    assert st.ntt_calls == 4 and st.ntt_elements == 128 + 3 * 1024
+    assert st.ntt_calls_by_log2[7] == 1 and st.ntt_calls_by_log2[10] == 3
+    assert st.h2d_bytes == 1024 * 96 + 255 * 32 + 128 * 32 and st.d2h_bytes == 128 * 32
+    assert st.msm_device_us > 0 and st.msm_h2d_us > 0 and st.ntt_device_us > 0
 
 
 def test_async_submit_wait_overlapping_streams(cref, golden):
@@ -352,7 +456,7 @@ def test_skewed_columns_use_the_cooperative_sort(cref, kind):
 
 def test_single_process_multi_device_split(cref, pyref, golden):
     """hm_set_msm_devices: the one-process, many-GPU form of best_multiexp.  With one card on the box the
-    list names device 0 three times -- same splitting, threads, per-slice base cache and host fold as on
+    list names device 0 three times -- same splitting, threads, per-slice uploads and host fold as on
     a node with three cards (the slices then simply queue on one device)."""
     lib = _lib.load()
     o = pyref
@@ -366,7 +470,7 @@ def test_single_process_multi_device_split(cref, pyref, golden):
     _lib.check(lib.hm_set_msm_devices(devs, 3))
     try:
         assert g1_equal(h.best_multiexp(s, bases), single)
-        assert g1_equal(h.best_multiexp(s, bases), single)              # second call: per-slice caches in play
+        assert g1_equal(h.best_multiexp(s, bases), single)              # second call: same buffers, same answer
         g = golden["msm"]                                               # small input: goes whole to devices[0]
         assert g1_equal(h.best_multiexp(g["n1024_uniform_s"], g["n1024_uniform_b"]), g["n1024_uniform_r"])
         s[: n // 3] = 0                                                 # first slice sums to the identity

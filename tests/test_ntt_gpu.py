@@ -180,3 +180,91 @@ def test_coeff_to_extended_never_materialises_the_zero_part(k, j):
         assert lib.hm_coeff_to_extended_bn256_fr_dev(None, None, 1, _ptr(fr_words(d.extended_omega)), 8, 11, None, None) == -1
         assert lib.hm_coeff_to_extended_bn256_fr_dev(ctypes.c_void_p(a.data_ptr()), ctypes.c_void_p(ext.data_ptr()), 1,
                                                      _ptr(fr_words(d.extended_omega)), 12, 11, None, None) == -1
+
+
+@pytest.mark.parametrize("k,j", [(8, 7), (13, 7), (19, 7), (18, 3)])
+def test_extended_to_coeff_fused_into_the_last_pass(cref, k, j):
+    """hm_extended_to_coeff_bn256_fr_dev (ifft divisor x zeta^-(i % 3) folded into the last NTT pass) against
+    the composition it replaces -- scaled inverse NTT, then hm_fr_distribute_powers_dev per polynomial -- on
+    arbitrary (not band-limited) extended arrays, one-, two- and three-pass plans, batch 2; and against the
+    oracle's composition at the smallest size."""
+    import ctypes
+    import torch
+    from halo2_experiments_amd import _lib
+    from halo2_experiments_amd.arithmetic import _ptr, _stream_ptr
+    from halo2_experiments_amd.domain import FR_MODULUS
+    d = EvaluationDomain(j=j, k=k)
+    en, ek = d.extended_len(), d.extended_k
+    lib = _lib.load()
+    x = rand_fr_gpu(2 * en, 9100 + k).reshape(2, en, 4)
+    c3 = np.concatenate([fr_words(1), fr_words(d.g_coset_inv), fr_words(d.g_coset_inv * d.g_coset_inv % FR_MODULUS)])
+    ref = x.clone()
+    _lib.check(lib.hm_ntt_batch_bn256_fr_dev(ctypes.c_void_p(ref.data_ptr()), 2, _ptr(fr_words(d.extended_omega_inv)), ek,
+                                              _ptr(fr_words(d.extended_ifft_divisor)), None, ctypes.c_void_p(_stream_ptr(ref))))
+    for b in range(2):
+        _lib.check(lib.hm_fr_distribute_powers_dev(ctypes.c_void_p(ref[b].data_ptr()), en, _ptr(c3), ctypes.c_void_p(_stream_ptr(ref))))
+    got = x.clone()
+    out = d.extended_to_coeff(got)
+    torch.cuda.synchronize()
+    assert torch.equal(got, ref)
+    assert out.shape[1] == d.n * (j - 1)
+    if k == 8:
+        xh = x[1].cpu().numpy().view(np.uint64)
+        inv = cref.fr_mul(cref.best_fft(xh, fr_words(d.extended_omega_inv), ek, 4), np.tile(fr_words(d.extended_ifft_divisor), (en, 1)))
+        zi = [1, d.g_coset_inv, d.g_coset_inv * d.g_coset_inv % FR_MODULUS]
+        exp = cref.fr_mul(inv, np.stack([fr_words(zi[i % 3]) for i in range(en)]))
+        assert np.array_equal(got[1].cpu().numpy().view(np.uint64), exp)
+
+
+def test_concurrent_transforms_on_two_streams(pyref):
+    """Every *_dev NTT entry point is asynchronous on the caller's stream and may run concurrently with
+    another call on another stream: multi-pass transforms of different sizes and flavours (fused inverse,
+    coset NTT, extending transform) are interleaved on two streams -- the first use of each twiddle table
+    included -- and must equal the same calls issued one after the other."""
+    import ctypes
+    import torch
+    from halo2_experiments_amd import _lib
+    from halo2_experiments_amd.arithmetic import _ptr
+    from halo2_experiments_amd.domain import FR_MODULUS
+    lib = _lib.load()
+    da, db = EvaluationDomain(j=7, k=16), EvaluationDomain(j=4, k=13)       # extended: 2^19 (2 passes), 2^15 (2 passes)
+    big = EvaluationDomain(j=3, k=22)                                       # 2^22: three passes
+    xa = rand_fr_gpu(4 * da.n, 1).reshape(4, da.n, 4)
+    xb = rand_fr_gpu(6 * db.n, 2).reshape(6, db.n, 4)
+    xc = rand_fr_gpu(big.n, 3)
+
+    def work_a(t):         # lagrange_to_coeff -> coeff_to_extended -> extended_to_coeff
+        c = da.lagrange_to_coeff(t.clone())
+        e = da.coeff_to_extended(c)
+        return c, e, da.extended_to_coeff(e.clone()).clone()
+
+    def work_b(t):
+        c = db.lagrange_to_coeff(t.clone())
+        e = db.coeff_to_extended(c)
+        return c, e, db.extended_to_coeff(e.clone()).clone()
+
+    def work_c(t):
+        y = t.clone()
+        h.best_fft(y, fr_words(big.omega), big.k)
+        return (y,)
+
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    conc = []
+    for it in range(3):                       # round 0 builds every twiddle table while the other stream runs
+        with torch.cuda.stream(sa):
+            ra = work_a(xa)
+        with torch.cuda.stream(sb):
+            rb = work_b(xb)
+        with torch.cuda.stream(sa):
+            rc = work_c(xc)
+        with torch.cuda.stream(sb):
+            ra2 = work_a(xa)
+        conc.append((ra, rb, rc, ra2))
+    torch.cuda.synchronize()
+    ea, eb, ec = work_a(xa), work_b(xb), work_c(xc)
+    torch.cuda.synchronize()
+    for ra, rb, rc, ra2 in conc:
+        for got, exp in ((ra, ea), (rb, eb), (rc, ec), (ra2, ea)):
+            for g_, e_ in zip(got, exp):
+                assert torch.equal(g_, e_)

@@ -13,8 +13,6 @@ def rand_fr(n, seed):
     x[:, 3] &= 0x0FFFFFFFFFFFFFFF
     return x
 
-if os.environ.get("GRAPHS", "1") == "0":
-    _lib.check(_lib.load().hm_msm_use_graphs(0))
 sizes = [int(a) for a in sys.argv[1].split(",")] if len(sys.argv) > 1 else [12, 14, 16, 18, 20, 22, 24]
 windows = [int(a) for a in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0]
 for k in sizes:
