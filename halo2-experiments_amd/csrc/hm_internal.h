@@ -100,6 +100,8 @@ struct MsmSlot {            // one in-flight MSM: its workspace, events and host
   const uint32_t* d_win = nullptr;   // device locations of the results of the MSM in flight (inside ws)
   const uint32_t* d_tot = nullptr;
   uint64_t T_max = 0;
+  bool balanced = false;             // windows of unequal widths (msm_small.hip): the host fold shifts by win_bits[w]
+  uint8_t win_bits[128] = {};
 };
 
 // Transient device state of the stream-asynchronous entry points (NTT ping-pong buffer, fixed-base
@@ -147,7 +149,7 @@ struct DeviceCtx {
   uint64_t next_handle = 1;
   MsmStats last_msm;
   CallStats calls;
-  bool msm_attr_set = false, ntt_attr_set = false;
+  bool msm_attr_set = false, ntt_attr_set = false, msm_small_attr_set = false;
 };
 
 // Slot for a call on `stream` (ctx.mu held): the stream's own slot, else a free or finished one, else the
@@ -179,6 +181,13 @@ int msm_convert_bases(const uint32_t* d_bases_ext, uint32_t* d_xy, uint8_t* d_in
 int msm_enqueue(DeviceCtx& ctx, int slot, const uint32_t* d_scalars_ext, const uint32_t* d_xy, const uint8_t* d_inf, size_t n,
                 uint32_t precomp_c, hipStream_t stream);
 int msm_finish(DeviceCtx& ctx, int slot, uint64_t out_jac_ext[12], int* out_is_identity);
+int msm_slot_prepare(MsmSlot& sl);   // events + pinned landing zone, on first use
+int msm_launch_digits(const uint32_t* d_scalars_ext, const uint8_t* d_inf, int32_t* d_digits, size_t n, uint32_t c, uint32_t W,
+                      hipStream_t stream);
+// msm_small.hip: the five-launch chain for n < 2^19 (plain base sets, c <= 15)
+bool msm_small_applies(size_t n, uint32_t c, bool single_set);
+int msm_issue_small(DeviceCtx& ctx, int slot, const uint32_t* d_scalars_ext, const uint32_t* d_xy, const uint8_t* d_inf, size_t n,
+                    uint32_t c, hipStream_t stream);
 int msm_run(DeviceCtx& ctx, const uint32_t* d_scalars_ext, const uint32_t* d_xy, const uint8_t* d_inf, size_t n,
             uint32_t precomp_c, uint64_t out_jac_ext[12], int* out_is_identity, hipStream_t stream);
 uint32_t msm_precomp_window(size_t n);

@@ -23,13 +23,12 @@
 #include <chrono>
 #include <cmath>
 
-#include "g1.h"
 #include "hm_internal.h"
 #include "host_fq.h"
+#include "msm_dev.h"
 
 namespace hm {
 
-constexpr int PT_WORDS = 28;  // device Jacobian record: 27 limbs + identity flag
 
 // Every counter an MSM starts from zero is cleared by ONE launch of its own (instead of four
 // hipMemsetAsync calls): the bucket counts (the cooperative histogram adds into them), the big-region
@@ -43,49 +42,6 @@ __global__ void msm_init_counters_kernel(uint32_t* __restrict__ bcnt, size_t nbt
     if (br_count) br_count[i0] = 0;
     big_count[i0] = 0;
   }
-}
-
-__device__ __forceinline__ G1Jac load_jac(const uint32_t* p) {
-  const uint4* q = reinterpret_cast<const uint4*>(p);
-  uint32_t w[PT_WORDS];
-#pragma unroll
-  for (int i = 0; i < 7; ++i) {
-    const uint4 v = q[i];
-    w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
-  }
-  G1Jac r;
-#pragma unroll
-  for (int i = 0; i < 9; ++i) {
-    r.x.l[i] = w[i];
-    r.y.l[i] = w[9 + i];
-    r.z.l[i] = w[18 + i];
-  }
-  r.inf = w[27] != 0;
-  return r;
-}
-__device__ __forceinline__ void store_jac(uint32_t* p, const G1Jac& a) {
-  uint32_t w[PT_WORDS];
-#pragma unroll
-  for (int i = 0; i < 9; ++i) {
-    w[i] = a.x.l[i];
-    w[9 + i] = a.y.l[i];
-    w[18 + i] = a.z.l[i];
-  }
-  w[27] = a.inf ? 1u : 0u;
-  uint4* q = reinterpret_cast<uint4*>(p);
-#pragma unroll
-  for (int i = 0; i < 7; ++i) q[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
-}
-
-__device__ __forceinline__ G1Aff load_base(const uint32_t* xy, uint32_t idx) {
-  const uint4* q = reinterpret_cast<const uint4*>(xy + (size_t)idx * 16);
-  const uint4 a = q[0], b = q[1], c = q[2], d = q[3];
-  const uint32_t wx[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-  const uint32_t wy[8] = {c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w};
-  G1Aff r;
-  r.x = fe_unpack<FqParams>(wx);
-  r.y = fe_unpack<FqParams>(wy);
-  return r;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -185,26 +141,6 @@ __global__ void msm_digits_kernel(const uint32_t* __restrict__ scalars, const ui
 #define HM_SORT_THREADS 1024
 #endif
 constexpr int SORT_THREADS = HM_SORT_THREADS;
-
-// cnt[bin]++ in LDS, returning the old value.  Lanes of a wave that hit the SAME counter serialise
-// in the LDS atomic unit, and constant or flag columns (every scalar equal, or 0/1) put whole waves
-// on one counter.  One cheap wave-uniform test catches exactly that case and replaces the wave's
-// atomics by a single one; any other wave takes the plain per-lane atomic.
-__device__ __forceinline__ uint32_t lds_inc(uint32_t* cnt, uint32_t bin) {
-#ifndef HM_NO_AGG
-  const uint32_t v = (uint32_t)__builtin_amdgcn_readfirstlane((int)bin);
-  const uint64_t active = __ballot(1);
-  if (__ballot(bin == v) == active) {                      // every active lane wants the same counter
-    const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-    const uint32_t before = (uint32_t)__popcll(active & ((1ull << lane) - 1ull));
-    uint32_t base = 0;
-    if (before == 0) base = atomicAdd(&cnt[v], (uint32_t)__popcll(active));
-    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-    return base + before;
-  }
-#endif
-  return atomicAdd(&cnt[bin], 1u);
-}
 
 // Apply f(index, word) to base[lo .. hi) with the whole workgroup, 16 bytes per lane per load:
 // one 4-byte load in flight per lane keeps only ~1 MB outstanding chip-wide (latency-bound at
@@ -880,22 +816,6 @@ __global__ __launch_bounds__(ORDER_THREADS) void msm_task_order_kernel(const uin
 // ---------------------------------------------------------------------------------------------
 // K3: bucket accumulation -- one lane per task, serial chain of mixed additions
 // ---------------------------------------------------------------------------------------------
-constexpr int ACC_THREADS = 64;
-
-typedef __attribute__((address_space(3))) void hm_lds_void;
-typedef __attribute__((address_space(1))) const void hm_gbl_void;
-
-// Start the gather of base `idx` into this lane's staging slots: four 16-byte LDS-DMA pieces
-// (global_load_lds_dwordx4: per-lane source address, destination = M0 base + 16 * lane), so the
-// 64-byte point of the NEXT iteration is in flight while the current mixed addition runs and costs
-// no VGPRs.
-__device__ __forceinline__ void stage_base_async(const uint32_t* xy, uint32_t idx, uint4 (*stage)[ACC_THREADS]) {
-  const uint4* src = reinterpret_cast<const uint4*>(xy + (size_t)idx * 16);
-#pragma unroll
-  for (int k = 0; k < 4; ++k)
-    __builtin_amdgcn_global_load_lds((hm_gbl_void*)(src + k), (hm_lds_void*)&stage[k][0], 16, 0, 0);
-}
-
 __global__ __launch_bounds__(ACC_THREADS) void msm_accumulate_kernel(const uint32_t* __restrict__ sorted,
                                                                      const uint32_t* __restrict__ task_bucket,
                                                                      const uint32_t* __restrict__ task_order,
@@ -921,68 +841,10 @@ __global__ __launch_bounds__(ACC_THREADS) void msm_accumulate_kernel(const uint3
     end = start + L < bucket_end ? start + L : bucket_end;
   }
   if (start >= end) return;       // no task for this lane (the kernel has no barriers)
-  // First point of the chain: a plain load; the accumulator is never the identity inside the hot loop.
-  uint32_t v_cur = sorted[start];
-  G1Xyzz acc;
-  {
-    const G1Aff q0 = load_base(xy, v_cur & 0x7fffffffu);
-    acc = g1x_from_affine((v_cur >> 31) ? g1_neg_affine(q0) : q0);
-  }
-  uint32_t p = start + 1, v_next = 0;
-  if (p < end) {
-    v_cur = sorted[p];
-    stage_base_async(xy, v_cur & 0x7fffffffu, stage);
-    if (p + 1 < end) v_next = sorted[p + 1];
-  }
-  bool general = false;
-  for (; p < end; ++p) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the staged point (and v_next) have landed
-    const uint4 a = stage[0][lane], b4 = stage[1][lane], c4 = stage[2][lane], d4 = stage[3][lane];
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // ... and are in registers before the slots are reused
-    const bool neg = (v_cur >> 31) != 0;
-    if (p + 1 < end) {
-      v_cur = v_next;
-      stage_base_async(xy, v_cur & 0x7fffffffu, stage);       // next point: in flight during this addition
-      if (p + 2 < end) v_next = sorted[p + 2];
-    }
-    const uint32_t wx[8] = {a.x, a.y, a.z, a.w, b4.x, b4.y, b4.z, b4.w};
-    const uint32_t wy[8] = {c4.x, c4.y, c4.z, c4.w, d4.x, d4.y, d4.z, d4.w};
-    G1Aff q;
-    q.x = fe_unpack<FqParams>(wx);
-    q.y = fe_unpack<FqParams>(wy);
-    if (!g1x_madd_fast(acc, q, neg)) {                        // equal x: a repeated base or a base and its negative
-      general = true;
-      break;
-    }
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // no LDS-DMA piece may outlive the loop
-  G1Jac res = g1x_to_jac(acc);                                // task partials stay Jacobian downstream
-  if (general) {
-    // Rare: finish this lane's chain, from the point that hit the exception, with the general
-    // Jacobian law (doubling, cancellation to the identity and restart from it included).
-    for (; p < end; ++p) {
-      const uint32_t v = sorted[p];
-      res = g1_madd(res, load_base(xy, v & 0x7fffffffu), (v >> 31) != 0);
-    }
-  }
+  const G1Jac res = accumulate_chain(sorted, xy, start, end, stage, lane);
   store_jac(partial + (size_t)t * PT_WORDS, res);
 }
 
-// Workgroup-wide sum of one point per lane through an LDS tree; the result is valid in lane 0.
-constexpr int WIN_THREADS = 256;
-__device__ __forceinline__ G1Jac block_sum_points(uint32_t* tree, G1Jac acc) {
-  const uint32_t t = threadIdx.x;
-  store_jac(tree + t * PT_WORDS, acc);
-  __syncthreads();
-  for (uint32_t off = WIN_THREADS / 2; off > 0; off >>= 1) {
-    if (t < off) {
-      const G1Jac a = load_jac(tree + t * PT_WORDS), b = load_jac(tree + (t + off) * PT_WORDS);
-      store_jac(tree + t * PT_WORDS, g1_add(a, b));
-    }
-    __syncthreads();
-  }
-  return load_jac(tree);
-}
 
 // K3b: bucket = sum of its task partials.  Buckets with at most FINALIZE_SERIAL partials are
 // summed by one lane; longer ones (hot buckets that K3 split into many tasks) are queued for
@@ -1112,24 +974,7 @@ __global__ __launch_bounds__(WIN_THREADS) void msm_sum_points_kernel(const uint3
 __global__ void msm_windows_to_ext_kernel(const uint32_t* __restrict__ in, uint32_t W, uint32_t* __restrict__ winres) {
   const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
   if (w >= W) return;
-  const G1Jac r = load_jac(in + (size_t)w * PT_WORDS);
-  uint32_t* o = winres + (size_t)w * 32;
-  uint32_t wx[8], wy[8], wz[8];
-  if (r.inf) {
-#pragma unroll
-    for (int k = 0; k < 8; ++k) wx[k] = wy[k] = wz[k] = 0;
-  } else {
-    fe_to_ext(wx, r.x);
-    fe_to_ext(wy, r.y);
-    fe_to_ext(wz, r.z);
-  }
-#pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    o[k] = wx[k];
-    o[8 + k] = wy[k];
-    o[16 + k] = wz[k];
-  }
-  o[24] = r.inf ? 1u : 0u;
+  store_window_ext(winres + (size_t)w * 32, load_jac(in + (size_t)w * PT_WORDS));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1264,10 +1109,14 @@ static uint32_t ilog2(size_t n) {
 
 // host-side Horner over the window sums and affine normalisation (host_fq.h: native 4 x u64
 // arithmetic on the external-format words the reduction kernel wrote)
-static void host_fold(const uint32_t* winres, uint32_t W, uint32_t c, uint64_t out_jac_ext[12], int* out_is_identity) {
+// result = sum_w 2^(offset of window w) * S_w: Horner from the top window, shifting by the width of window w
+// before its sum is added (widths == nullptr: every window is c bits wide)
+static void host_fold(const uint32_t* winres, uint32_t W, uint32_t c, uint64_t out_jac_ext[12], int* out_is_identity,
+                      const uint8_t* widths = nullptr) {
   host::G1J acc = host::g1_identity();
   for (int w = (int)W - 1; w >= 0; --w) {
-    for (uint32_t k = 0; k < c; ++k) acc = host::g1_double(acc);
+    const uint32_t shift = widths ? widths[w] : c;
+    for (uint32_t k = 0; k < shift; ++k) acc = host::g1_double(acc);
     const uint32_t* o = winres + (size_t)w * 32;
     if (o[24] == 0) {
       host::G1J p;
@@ -1386,6 +1235,23 @@ static int launch_sort_scatter(const int32_t* d_digits, const uint32_t* d_cstart
   return HM_OK;
 }
 
+int msm_launch_digits(const uint32_t* d_scalars_ext, const uint8_t* d_inf, int32_t* d_digits, size_t n, uint32_t c, uint32_t W,
+                      hipStream_t stream) {
+  hipLaunchKernelGGL(msm_digits_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, stream, d_scalars_ext, d_inf, d_digits, n, c,
+                     W);
+  HM_HIP_CHECK(hipGetLastError());
+  return HM_OK;
+}
+
+int msm_slot_prepare(MsmSlot& sl) {
+  if (!sl.ev_ready) {
+    for (int i = 0; i < 7; ++i) HM_HIP_CHECK(hipEventCreate(&sl.ev[i]));
+    HM_HIP_CHECK(hipHostMalloc((void**)&sl.h_land, (128 * 32 + 4) * sizeof(uint32_t), hipHostMallocDefault));
+    sl.ev_ready = true;
+  }
+  return HM_OK;
+}
+
 // Enqueue every kernel of one MSM on `stream` using workspace slot `slot`; nothing here waits for
 // the device.  d_xy: n points (plain) or the precomputed table of precomp_W * n points
 // (precomp_c != 0).  msm_finish() later waits for the slot, folds the window sums on the host and
@@ -1411,11 +1277,16 @@ static int msm_issue(DeviceCtx& ctx, int slot, const uint32_t* d_scalars_ext, co
     // (tools/msm_sweep.py <k> <c,c,...>): between 2^15 and 2^17 the fixed costs of the sort and of the
     // bucket reduction move it up to c = 15.
     static const int8_t kWindow[21] = {4, 4, 4, 4, 4, 4, 4, 4, 5, 6, 7, 8, 9, 10, 10, 13, 15, 15, 15, 16, 17};
+    // the short chain of msm_small.hip (n < 2^19) has cheaper fixed costs per bucket set: its measured optimum is
+    // log2(n) - 3 up to 2^16 (tools/small_tune.sh), then c = 15, whose 17 windows cover the 255 bits exactly
+    static const int8_t kWindowSmall[19] = {4, 4, 4, 4, 4, 4, 4, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 15, 15};
     const uint32_t lg = ilog2(n);
     int ci = lg <= 20 ? kWindow[lg] : 17;
+    if (lg <= 18 && msm_small_applies(n, (uint32_t)kWindowSmall[lg], false)) ci = kWindowSmall[lg];
     c = (uint32_t)ci;
   }
   if (c < 2 || c > 24) return hm_fail(HM_ERR_BAD_ARG, "msm: window size out of range");
+  if (msm_small_applies(n, c, single_set)) return msm_issue_small(ctx, slot, d_scalars_ext, d_xy, d_inf, n, c, stream);
   const uint32_t W = (255 + c - 1) / c;
   const uint32_t SW = single_set ? 1u : W;                 // bucket sets ("sort windows")
   const size_t sn = single_set ? n * W : n;                // items per bucket set
@@ -1568,14 +1439,14 @@ static int msm_issue(DeviceCtx& ctx, int slot, const uint32_t* d_scalars_ext, co
     ctx.msm_attr_set = true;
   }
   hipEvent_t* ev = sl.ev;
-  if (!sl.ev_ready) {
-    for (int i = 0; i < 7; ++i) HM_HIP_CHECK(hipEventCreate(&ev[i]));
-    HM_HIP_CHECK(hipHostMalloc((void**)&sl.h_land, (128 * 32 + 4) * sizeof(uint32_t), hipHostMallocDefault));
-    sl.ev_ready = true;
+  {
+    const int rc = msm_slot_prepare(sl);
+    if (rc != HM_OK) return rc;
   }
   sl.SW = SW;
   sl.c = c;
   sl.W = W;
+  sl.balanced = false;
   sl.T_max = T_max;
   sl.d_win = d_win;
   sl.d_tot = d_tot;
@@ -1716,7 +1587,7 @@ int msm_finish(DeviceCtx& ctx, int slot, uint64_t out_jac_ext[12], int* out_is_i
   HM_HIP_CHECK(hipEventSynchronize(ev[4]));
   if (sl.totals()[2] != 0) return hm_fail(HM_ERR_INTERNAL, "msm: task count exceeds its bound");
   const auto f0 = std::chrono::steady_clock::now();
-  host_fold(sl.win(), sl.SW, sl.c, out_jac_ext, out_is_identity);   // SW == 1: no Horner, just the normalisation
+  host_fold(sl.win(), sl.SW, sl.c, out_jac_ext, out_is_identity, sl.balanced ? sl.win_bits : nullptr);   // SW == 1: just the normalisation
   ctx.calls.msm_host_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - f0).count();
 
   float ms[4] = {0, 0, 0, 0}, total = 0;

@@ -1,0 +1,501 @@
+// msm_small.hip -- the short launch chain for prover-sized MSMs (n < 2^19: the sizes of every circuit
+// in the reference, /root/reference/src/circuits/utils.rs:22-70 -- k = 9 in its own test, k = 11 / 17 / 18
+// in BASELINE.json's configs).
+//
+// At these sizes the general pipeline of msm.hip (~26 launches: digit array, two-level LDS sort, three-
+// launch scan, task sort, three finalize kernels, segment sums, two tree passes) is bound by launch
+// gaps and by the DEPTH of its latency-bound phases, not by throughput: a lone wave issues one VALU
+// instruction per ~4.2 cycles, i.e. ~7 us per Jacobian addition, and the bucket reduction of a 2^18
+// MSM ran ~45 serial additions / doublings per lane in 544 lone waves (0.45 ms of a 1.0 ms call).
+// Here the whole MSM is FIVE launches and one D2H copy, nothing is read back in between:
+//   A  digits    one lane per scalar: canonical form, W signed digits.  The 255 digit bits are spread over
+//                the W windows as evenly as possible (widths c and c - 1) instead of W - 1 full windows and a
+//                short top one, whose few buckets would each receive n / 2^(few bits) points
+//   B  sort      one workgroup per (window, bucket range) does the whole counting sort of its share in LDS:
+//                histogram, scan -> bucket offsets, task offsets and the task list in order of decreasing
+//                chain length, then the scatter with LDS cursors.  Its runs in the global arrays are
+//                reserved with ONE atomic per workgroup, so there is no global scan, no per-item global
+//                atomic (tried first: 4.4 M of them at 2^18 cost 0.17 ms per pass) and nothing to clear
+//   C  K3        the same accumulation chain as the general path (msm_dev.h: accumulate_chain)
+//   D  reduce 1  per (window, range, 256 segments): bucket = sum of its task partials (buckets cut into many
+//                tasks: by groups of lanes, all such buckets of the workgroup at once), running sums over SEG
+//                buckets per lane, short scalar multiple, LDS tree
+//   E  reduce 2  per window: tree over D's outputs -> external format
+// SEG is chosen so that D runs at most one wave per SIMD (the depth of a lane's chain is what costs, not the work).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+
+#include "hm_internal.h"
+#include "msm_dev.h"
+
+namespace hm {
+
+constexpr int SA_THREADS = 256;       // A: one lane per scalar
+constexpr int SS_THREADS = 1024;      // B: one workgroup per (window, bucket range)
+constexpr uint32_t S_TASK_KEYS = 1024;
+constexpr uint32_t S_HOT = 32;
+constexpr uint32_t S_FINALIZE_SERIAL = 12;   // partials of one bucket its own lane sums; more go to a group of lanes
+constexpr uint32_t S_HOT_PER_LANE = 4;       // partials per lane of such a group
+constexpr uint32_t S_HOT_LIST = 64;
+constexpr uint32_t S_MAX_L = 1023;
+
+// ---- A: digits, balanced window widths ----------------------------------------------------------
+// Window w is `wide` bits for w < n_wide, else wide - 1 bits (n_wide * wide + (W - n_wide) * (wide - 1) = 255).
+// The top window holds bit 254, which is zero for every canonical scalar, so its digit never carries out.
+__global__ __launch_bounds__(SA_THREADS) void msm_s_digits_kernel(const uint32_t* __restrict__ scalars,
+                                                                  const uint8_t* __restrict__ inf, int32_t* __restrict__ digits,
+                                                                  uint32_t n, uint32_t wide, uint32_t n_wide, uint32_t W,
+                                                                  uint32_t* __restrict__ gctr) {
+  const uint32_t i = blockIdx.x * SA_THREADS + threadIdx.x;
+  if (i == 0) {                 // the two run-reservation counters of B start from zero (stream order: before B)
+    gctr[0] = 0;
+    gctr[1] = 0;
+  }
+  if (i >= n) return;
+  const uint4* q = reinterpret_cast<const uint4*>(scalars + (size_t)i * 8);
+  const uint4 lo = q[0], hi = q[1];
+  const uint32_t w_in[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+  Fr k32 = fe_zero<FrParams>();
+  k32.l[0] = 32;                // s_mont * 32 * 2^-261 = s_mont * 2^-256 = the canonical scalar (Fr::to_repr)
+  const Fr s = fe_canonical(fe_mul(fe_unpack<FrParams>(w_in), k32));
+  uint32_t v[9];
+  {
+    uint32_t t[8];
+    fe_pack(t, s);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = t[k];
+    v[8] = 0;
+  }
+  const bool skip = inf[i] != 0;
+  uint32_t carry = 0;
+  for (uint32_t w = 0; w < W; ++w) {
+    const uint32_t bits = w < n_wide ? wide : wide - 1;
+    const uint32_t mask = (1u << bits) - 1u, half = 1u << (bits - 1);
+    const uint32_t d = (v[0] & mask) + carry;
+    int32_t sd;
+    if (d > half) {
+      sd = (int32_t)d - (int32_t)(1u << bits);
+      carry = 1;
+    } else {
+      sd = (int32_t)d;
+      carry = 0;
+    }
+    digits[(size_t)w * n + i] = skip ? 0 : sd;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = __funnelshift_r(v[k], v[k + 1], bits);
+  }
+}
+
+// ---- B: sort of one (window, bucket range): histogram, scan, task list, scatter -- in one workgroup's LDS ---
+__device__ __forceinline__ uint32_t s_task_key(uint32_t len) { return (S_TASK_KEYS - 1) - len; }   // len <= S_MAX_L; key 0 = longest
+
+// exclusive scan of one value per thread over the 1024-thread workgroup; `total` gets the sum
+__device__ __forceinline__ uint32_t block_excl_scan_1024(uint32_t v, uint32_t* wsum, uint32_t& total) {
+  const uint32_t tid = threadIdx.x;
+  uint32_t incl = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t u = __shfl_up(incl, off, 64);
+    if ((tid & 63) >= (uint32_t)off) incl += u;
+  }
+  __syncthreads();                       // wsum may still be read by a previous scan
+  if ((tid & 63) == 63) wsum[tid >> 6] = incl;
+  __syncthreads();
+  if (tid < 64) {
+    const uint32_t ws = tid < (SS_THREADS / 64) ? wsum[tid] : 0;
+    uint32_t wi = ws;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t u = __shfl_up(wi, off, 64);
+      if (tid >= (uint32_t)off) wi += u;
+    }
+    if (tid < (SS_THREADS / 64)) wsum[tid] = wi - ws;     // exclusive wave offsets
+    if (tid == (SS_THREADS / 64) - 1) wsum[16] = wi;       // grand total
+  }
+  __syncthreads();
+  total = wsum[16];
+  return wsum[tid >> 6] + incl - v;
+}
+
+// f(index, digit) over the n digits of one window with the whole workgroup: four 16-byte loads in flight
+// per lane (one workgroup streams a whole window, so memory-level parallelism has to come from the lane)
+template <class F>
+__device__ __forceinline__ void window_for_each_digit(const int32_t* __restrict__ dw, uint32_t n, F f) {
+  const uint32_t tid = threadIdx.x;
+  uint32_t a = 0;
+  while (a < n && (reinterpret_cast<uintptr_t>(dw + a) & 15)) ++a;      // <= 3 head words up to 16-byte alignment
+  if (tid < a) f(tid, dw[tid]);
+  const uint32_t nvec = (n - a) / 4, tail = a + nvec * 4;
+  if (tid < n - tail) f(tail + tid, dw[tail + tid]);
+  const int4* vb = reinterpret_cast<const int4*>(dw + a);
+  for (uint32_t v0 = 0; v0 < nvec; v0 += 4 * SS_THREADS) {
+    int4 q[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const uint32_t v = v0 + k * SS_THREADS + tid;
+      q[k] = v < nvec ? vb[v] : make_int4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const uint32_t v = v0 + k * SS_THREADS + tid;
+      if (v < nvec) {
+        const uint32_t i = a + v * 4;
+        f(i, q[k].x);
+        f(i + 1, q[k].y);
+        f(i + 2, q[k].z);
+        f(i + 3, q[k].w);
+      }
+    }
+  }
+}
+
+// Virtual window v = w * H + h owns the buckets |digit| in (h * NBh, (h + 1) * NBh] of window w, locally 1 .. NBh.
+// toff[v * (NBh + 2) + b] = first partial index of local bucket b (global numbering), [NBh + 1] = end.
+// A task descriptor is { start in `sorted`, partial index, chain length, - }; this workgroup's descriptors are
+// written in order of decreasing length.
+__global__ __launch_bounds__(SS_THREADS) void msm_s_sort_kernel(const int32_t* __restrict__ digits, uint32_t* __restrict__ toff,
+                                                                uint32_t* __restrict__ gctr, uint4* __restrict__ desc,
+                                                                uint32_t* __restrict__ sorted, uint32_t n, uint32_t NBh, uint32_t H,
+                                                                uint32_t L) {
+  extern __shared__ uint32_t sm[];
+  const uint32_t NBP = NBh + 1;
+  uint32_t* cnt = sm;                         // bucket counts, then the scatter cursors
+  uint32_t* kh = cnt + ((NBP + 31) & ~31u);   // key histogram, later the per-key local cursors
+  uint32_t* kbase = kh + S_TASK_KEYS;         // first slot of every key
+  uint32_t* wsum = kbase + S_TASK_KEYS;       // 17 words of scan scratch
+  __shared__ uint32_t hot_n, hot[S_HOT][4], base_pt[2];
+  const uint32_t v = blockIdx.x, w = v / H, h = v - w * H, tid = threadIdx.x;
+  const uint32_t blo = h * NBh;               // this range: blo < |digit| <= blo + NBh
+  const int32_t* dw = digits + (size_t)w * n;
+  for (uint32_t b = tid; b < NBP; b += SS_THREADS) cnt[b] = 0;
+  kh[tid] = 0;
+  if (tid == 0) hot_n = 0;
+  __syncthreads();
+  window_for_each_digit(dw, n, [&](uint32_t, int32_t d) {
+    const uint32_t lb = (uint32_t)(d < 0 ? -d : d) - blo;          // wraps for |d| <= blo
+    if (lb - 1u < NBh) (void)lds_inc(cnt, lb);
+  });
+  __syncthreads();
+  const uint32_t per = (NBP + SS_THREADS - 1) / SS_THREADS;
+  const uint32_t b0 = tid * per < NBP ? tid * per : NBP, b1 = b0 + per < NBP ? b0 + per : NBP;
+  uint32_t sp = 0, st = 0;
+  for (uint32_t b = b0; b < b1; ++b) {
+    const uint32_t c = cnt[b], full = c / L, rem = c - full * L;
+    sp += c;
+    st += full + (rem ? 1u : 0u);
+    if (full) atomicAdd(&kh[s_task_key(L)], full);
+    if (rem) atomicAdd(&kh[s_task_key(rem)], 1u);
+  }
+  uint32_t tot_p = 0, tot_t = 0, tot_k = 0;
+  uint32_t rp = block_excl_scan_1024(sp, wsum, tot_p);
+  uint32_t rt = block_excl_scan_1024(st, wsum, tot_t);
+  {
+    const uint32_t kv = kh[tid];
+    const uint32_t ke = block_excl_scan_1024(kv, wsum, tot_k);
+    kbase[tid] = ke;
+    kh[tid] = 0;
+  }
+  if (tid == 0) {               // this workgroup's runs in `sorted` and in the task / partial numbering
+    base_pt[0] = atomicAdd(&gctr[0], tot_p);
+    base_pt[1] = atomicAdd(&gctr[1], tot_t);
+  }
+  __syncthreads();
+  const uint32_t base_p = base_pt[0], base_t = base_pt[1];
+  uint4* dsc = desc + base_t;
+  uint32_t* tw = toff + (size_t)v * (NBh + 2);
+  for (uint32_t b = b0; b < b1; ++b) {
+    const uint32_t c = cnt[b], full = c / L, rem = c - full * L;
+    const uint32_t start = base_p + rp;
+    cnt[b] = rp;                              // the bucket's cursor for the scatter pass (local to this run)
+    tw[b] = base_t + rt;
+    if (full) {
+      const uint32_t key = s_task_key(L), at = kbase[key] + atomicAdd(&kh[key], full);
+      const uint32_t slot = full > 64 ? atomicAdd(&hot_n, 1u) : S_HOT;
+      if (slot < S_HOT) {       // a bucket cut into many tasks: listed by the whole workgroup below
+        hot[slot][0] = start; hot[slot][1] = base_t + rt; hot[slot][2] = full; hot[slot][3] = at;
+      } else {
+        for (uint32_t i = 0; i < full; ++i) dsc[at + i] = make_uint4(start + i * L, base_t + rt + i, L, 0);
+      }
+    }
+    if (rem) {
+      const uint32_t key = s_task_key(rem), at = kbase[key] + atomicAdd(&kh[key], 1u);
+      dsc[at] = make_uint4(start + full * L, base_t + rt + full, rem, 0);
+    }
+    rp += c;
+    rt += full + (rem ? 1u : 0u);
+  }
+  if (tid == SS_THREADS - 1) tw[NBP] = base_t + tot_t;
+  __syncthreads();
+  const uint32_t nh = hot_n < S_HOT ? hot_n : S_HOT;
+  for (uint32_t e = 0; e < nh; ++e) {
+    const uint32_t start = hot[e][0], t0 = hot[e][1], full = hot[e][2], at = hot[e][3];
+    for (uint32_t i = tid; i < full; i += SS_THREADS) dsc[at + i] = make_uint4(start + i * L, t0 + i, L, 0);
+  }
+  uint32_t* sw = sorted + base_p;
+  window_for_each_digit(dw, n, [&](uint32_t i, int32_t d) {
+    const uint32_t lb = (uint32_t)(d < 0 ? -d : d) - blo;
+    if (lb - 1u < NBh) {
+      const uint32_t pos = lds_inc(cnt, lb);
+      sw[pos] = i | (d < 0 ? 0x80000000u : 0u);
+    }
+  });
+}
+
+// ---- C: accumulation ---------------------------------------------------------------------------
+__global__ __launch_bounds__(ACC_THREADS) void msm_s_accumulate_kernel(const uint32_t* __restrict__ sorted,
+                                                                       const uint4* __restrict__ desc,
+                                                                       const uint32_t* __restrict__ gctr,
+                                                                       const uint32_t* __restrict__ xy, uint32_t* __restrict__ partial) {
+  __shared__ uint4 stage[4][ACC_THREADS];
+  const uint32_t lane = threadIdx.x;
+  const uint32_t slot = blockIdx.x * ACC_THREADS + lane;
+  if (slot >= gctr[1]) return;                 // the grid covers the host-side bound on the task count
+  const uint4 d = desc[slot];
+  const G1Jac res = accumulate_chain(sorted, xy, d.x, d.x + d.z, stage, lane);
+  store_jac(partial + (size_t)d.y * PT_WORDS, res);
+}
+
+// ---- D: buckets -> one point per (virtual window, group of 256 segments) ---------------------------
+__global__ __launch_bounds__(WIN_THREADS) void msm_s_reduce1_kernel(uint32_t* __restrict__ partial, const uint32_t* __restrict__ toff,
+                                                                    uint32_t* __restrict__ seg1, uint32_t NBh, uint32_t H, uint32_t SEG,
+                                                                    uint32_t G1n) {
+  __shared__ uint32_t tree[WIN_THREADS * PT_WORDS];
+  __shared__ uint32_t hot_n, hot_b[S_HOT_LIST], hot_lane0[S_HOT_LIST + 1], round_hi, round_maxl;
+  const uint32_t v = blockIdx.y, g = blockIdx.x, tid = threadIdx.x;
+  const uint32_t h = v % H;
+  const uint32_t* tw = toff + (size_t)v * (NBh + 2);
+  const uint32_t sgi = g * WIN_THREADS + tid;
+  const uint32_t lo = sgi * SEG + 1;             // local bucket numbers lo .. hi
+  const bool valid = lo <= NBh;
+  const uint32_t hi = valid ? (lo + SEG - 1 < NBh ? lo + SEG - 1 : NBh) : 0;
+  if (tid == 0) hot_n = 0;
+  __syncthreads();
+  if (valid)
+    for (uint32_t b = lo; b <= hi; ++b)
+      if (tw[b + 1] - tw[b] > S_FINALIZE_SERIAL) {
+        const uint32_t s = atomicAdd(&hot_n, 1u);
+        if (s < S_HOT_LIST) hot_b[s] = b;
+      }
+  __syncthreads();
+  const uint32_t nh = hot_n < S_HOT_LIST ? hot_n : S_HOT_LIST;
+  // Buckets cut into many tasks (hot buckets of skewed columns): a group of ceil(count / 4) lanes (at most the
+  // whole workgroup) each sums a strided share of the partials, then the group is folded by a segmented tree;
+  // as many such buckets as fit 256 lanes are handled per round.  The sum is left in the bucket's first partial.
+  for (uint32_t e0 = 0; e0 < nh;) {
+    if (tid == 0) {
+      uint32_t used = 0, e = e0, maxl = 1;
+      while (e < nh) {
+        const uint32_t cntp = tw[hot_b[e] + 1] - tw[hot_b[e]];
+        uint32_t lanes = (cntp + S_HOT_PER_LANE - 1) / S_HOT_PER_LANE;
+        if (lanes > WIN_THREADS) lanes = WIN_THREADS;
+        if (used + lanes > WIN_THREADS) break;
+        hot_lane0[e] = used;
+        used += lanes;
+        maxl = lanes > maxl ? lanes : maxl;
+        ++e;
+      }
+      hot_lane0[e] = used;
+      round_hi = e;
+      round_maxl = maxl;
+    }
+    __syncthreads();
+    const uint32_t e1 = round_hi, maxl = round_maxl;
+    uint32_t my_e = e1, r = 0, lanes = 0;
+    for (uint32_t e = e0; e < e1; ++e)
+      if (tid >= hot_lane0[e] && tid < hot_lane0[e + 1]) {
+        my_e = e;
+        r = tid - hot_lane0[e];
+        lanes = hot_lane0[e + 1] - hot_lane0[e];
+      }
+    G1Jac acc = g1_identity();
+    uint32_t t0 = 0;
+    if (my_e < e1) {
+      t0 = tw[hot_b[my_e]];
+      const uint32_t t1 = tw[hot_b[my_e] + 1];
+      for (uint32_t t = t0 + r; t < t1; t += lanes) acc = g1_add(acc, load_jac(partial + (size_t)t * PT_WORDS));
+    }
+    store_jac(tree + tid * PT_WORDS, acc);
+    __syncthreads();
+    for (uint32_t off = 1; off < maxl; off <<= 1) {
+      const bool act = my_e < e1 && (r & (2 * off - 1)) == 0 && r + off < lanes;
+      G1Jac s = g1_identity();
+      if (act) s = g1_add(load_jac(tree + tid * PT_WORDS), load_jac(tree + (tid + off) * PT_WORDS));
+      __syncthreads();
+      if (act) store_jac(tree + tid * PT_WORDS, s);
+      __syncthreads();
+    }
+    if (my_e < e1 && r == 0) store_jac(partial + (size_t)t0 * PT_WORDS, load_jac(tree + tid * PT_WORDS));
+    __syncthreads();
+    e0 = e1;
+  }
+  G1Jac run = g1_identity(), acc = g1_identity();
+  if (valid) {
+    for (uint32_t b = hi; b >= lo; --b) {
+      const uint32_t t0 = tw[b], t1 = tw[b + 1];
+      G1Jac val = g1_identity();
+      bool summed = false;
+      if (t1 - t0 > S_FINALIZE_SERIAL)
+        for (uint32_t e = 0; e < nh; ++e)
+          if (hot_b[e] == b) summed = true;
+      if (summed) {
+        val = load_jac(partial + (size_t)t0 * PT_WORDS);
+      } else {
+        for (uint32_t t = t0; t < t1; ++t) val = g1_add(val, load_jac(partial + (size_t)t * PT_WORDS));
+      }
+      run = g1_add(run, val);
+      acc = g1_add(acc, run);
+    }
+    // sum (b - lo + 1) B_b is in acc; the bucket's weight is h * NBh + b, so (h * NBh + lo - 1) * sum B_b remains
+    const uint32_t m = h * NBh + lo - 1;
+    if (m != 0 && !run.inf) {
+      G1Jac rr = g1_identity();
+      for (int bit = 31 - __clz(m); bit >= 0; --bit) {
+        rr = g1_double(rr);
+        if ((m >> bit) & 1) rr = g1_add(rr, run);
+      }
+      acc = g1_add(acc, rr);
+    }
+  }
+  const G1Jac res = block_sum_points(tree, acc);
+  if (tid == 0) store_jac(seg1 + ((size_t)v * G1n + g) * PT_WORDS, res);
+}
+
+// ---- E: one point per window, external format ------------------------------------------------------
+__global__ __launch_bounds__(WIN_THREADS) void msm_s_reduce2_kernel(const uint32_t* __restrict__ seg1, uint32_t per_window,
+                                                                    uint32_t* __restrict__ winres, const uint32_t* __restrict__ gctr,
+                                                                    uint32_t* __restrict__ totals) {
+  __shared__ uint32_t tree[WIN_THREADS * PT_WORDS];
+  const uint32_t w = blockIdx.x, tid = threadIdx.x;
+  G1Jac acc = g1_identity();
+  for (uint32_t t = tid; t < per_window; t += WIN_THREADS) acc = g1_add(acc, load_jac(seg1 + ((size_t)w * per_window + t) * PT_WORDS));
+  const G1Jac r = block_sum_points_upto(tree, acc, per_window < WIN_THREADS ? per_window : WIN_THREADS);
+  if (tid == 0) store_window_ext(winres + (size_t)w * 32, r);
+  if (w == 0 && tid == 0) {
+    totals[0] = gctr[0];
+    totals[1] = gctr[1];
+    totals[2] = 0;
+  }
+}
+
+// ---- host ----------------------------------------------------------------------------------------
+static int env_int(const char* name, int dflt) {
+  const char* v = std::getenv(name);
+  return v && *v ? std::atoi(v) : dflt;
+}
+
+bool msm_small_applies(size_t n, uint32_t c, bool single_set) {
+  static const int enabled = env_int("HALO2_MI355X_SMALL_PLAN", 1);     // 0: measurement only (A/B against the general pipeline)
+  return enabled && !single_set && n >= 1 && n < (1u << 19) && c >= 2 && c <= 15;
+}
+
+int msm_issue_small(DeviceCtx& ctx, int slot, const uint32_t* d_scalars_ext, const uint32_t* d_xy, const uint8_t* d_inf, size_t n,
+                    uint32_t c, hipStream_t stream) {
+  MsmSlot& sl = ctx.msm_slots[slot];
+  static const int env_L = env_int("HALO2_MI355X_SMALL_L", 0), env_seg = env_int("HALO2_MI355X_SMALL_SEG", 0),
+                   env_H = env_int("HALO2_MI355X_SMALL_H", 0);
+  const uint32_t W = (255 + c - 1) / c;
+  if (W > 128) return hm_fail(HM_ERR_INTERNAL, "msm: more than 128 windows");
+  // balanced widths: n_wide windows of `wide` bits, the rest of wide - 1 (wide <= c)
+  const uint32_t base_bits = 255 / W, n_wide_raw = 255 - base_bits * W;
+  const uint32_t wide = n_wide_raw ? base_bits + 1 : base_bits, n_wide = n_wide_raw ? n_wide_raw : W;
+  const uint32_t NB = 1u << (wide - 1);
+  const uint64_t pairs_max = (uint64_t)n * W;
+  // bucket-range splits per window: more sort workgroups once one workgroup per window streams too long
+  uint32_t H = 1;
+  while (H < 8 && (uint64_t)n / H > (1u << 15) && NB / (2 * H) >= 64) H *= 2;
+  if (env_H > 0) H = (uint32_t)env_H;
+  while (H > 1 && NB / H < 2) H /= 2;
+  const uint32_t NBh = NB / H, V = W * H;
+  // Task length.  K3's chain costs L mixed additions, D then sums ~mean/L Jacobian partials per bucket (1.6x
+  // the instructions each): short tasks only pay while they are needed to fill the chip.
+  const double mean = (double)n / (double)NB;
+  uint32_t L = (uint32_t)(mean + 4.0 * std::sqrt(mean) + 8.0);
+  {
+    uint64_t by_fill = pairs_max / 327680;
+    if (by_fill < 16) by_fill = 16;          // measured (tools/small_tune.sh): 12 .. 16 beats 8 at every size below 2^18
+    if (by_fill < L) L = (uint32_t)by_fill;
+  }
+  if (env_L > 0) L = (uint32_t)env_L;
+  if (L < 2) L = 2;
+  if (L > S_MAX_L) L = S_MAX_L;
+  // D's segment length: at most one 256-lane workgroup per CU over all virtual windows -- one wave per SIMD;
+  // what costs is the depth of a lane's chain (2 SEG additions + a log2(NB)-bit multiple), not the work
+  uint32_t SEG = 2;
+  while (SEG < NBh && (uint64_t)V * ((NBh / SEG + WIN_THREADS - 1) / WIN_THREADS) > 256) ++SEG;
+  if (env_seg > 0) SEG = (uint32_t)env_seg;
+  if (SEG > NBh) SEG = NBh;
+  const uint32_t nseg = (NBh + SEG - 1) / SEG;
+  const uint32_t G1n = (nseg + WIN_THREADS - 1) / WIN_THREADS;
+  // sum over all buckets of ceil(cnt / L) <= pairs / L + number of buckets
+  const uint64_t T_max = pairs_max / L + (uint64_t)V * NBh + 64;
+
+  auto align = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  size_t off = 0;
+  auto carve = [&](size_t bytes) { size_t o = off; off += align(bytes); return o; };
+  const size_t o_digits = carve(pairs_max * 4);
+  const size_t o_toff = carve((size_t)V * (NBh + 2) * 4);
+  const size_t o_gctr = carve(16);
+  const size_t o_desc = carve(T_max * 16);
+  const size_t o_sorted = carve(pairs_max * 4);
+  const size_t o_partial = carve(T_max * PT_WORDS * 4);
+  const size_t o_seg1 = carve((size_t)V * G1n * PT_WORDS * 4);
+  const size_t o_res = carve((4 + (size_t)W * 32) * 4);
+  uint8_t* ws = (uint8_t*)sl.ws.ensure(off);
+  if (!ws) return hm_fail(HM_ERR_HIP, "msm (small plan): workspace allocation failed");
+  int32_t* d_digits = (int32_t*)(ws + o_digits);
+  uint32_t* d_toff = (uint32_t*)(ws + o_toff);
+  uint32_t* d_gctr = (uint32_t*)(ws + o_gctr);
+  uint4* d_desc = (uint4*)(ws + o_desc);
+  uint32_t* d_sorted = (uint32_t*)(ws + o_sorted);
+  uint32_t* d_partial = (uint32_t*)(ws + o_partial);
+  uint32_t* d_seg1 = (uint32_t*)(ws + o_seg1);
+  uint32_t* d_tot = (uint32_t*)(ws + o_res);
+  uint32_t* d_win = d_tot + 4;
+
+  const size_t lds_sort = ((size_t)((NBh + 1 + 31) & ~31u) + 2 * S_TASK_KEYS + 32) * 4;
+  if (!ctx.msm_small_attr_set) {
+    HM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(msm_s_sort_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)(((size_t)16416 + 2 * S_TASK_KEYS + 32) * 4)));
+    ctx.msm_small_attr_set = true;
+  }
+  int rc = msm_slot_prepare(sl);
+  if (rc != HM_OK) return rc;
+  hipEvent_t* ev = sl.ev;
+  sl.SW = W;
+  sl.c = wide;
+  sl.W = W;
+  sl.T_max = T_max;
+  sl.d_win = d_win;
+  sl.d_tot = d_tot;
+  sl.balanced = true;
+  for (uint32_t w = 0; w < W; ++w) sl.win_bits[w] = (uint8_t)(w < n_wide ? wide : wide - 1);
+
+  HM_HIP_CHECK(hipEventRecord(ev[0], stream));
+  hipLaunchKernelGGL(msm_s_digits_kernel, dim3((uint32_t)((n + SA_THREADS - 1) / SA_THREADS)), dim3(SA_THREADS), 0, stream,
+                     d_scalars_ext, d_inf, d_digits, (uint32_t)n, wide, n_wide, W, d_gctr);
+  HM_HIP_CHECK(hipGetLastError());
+  HM_HIP_CHECK(hipEventRecord(ev[1], stream));
+  hipLaunchKernelGGL(msm_s_sort_kernel, dim3(V), dim3(SS_THREADS), lds_sort, stream, (const int32_t*)d_digits, d_toff, d_gctr, d_desc,
+                     d_sorted, (uint32_t)n, NBh, H, L);
+  HM_HIP_CHECK(hipGetLastError());
+  HM_HIP_CHECK(hipEventRecord(ev[2], stream));
+  HM_HIP_CHECK(hipEventRecord(ev[5], stream));
+  hipLaunchKernelGGL(msm_s_accumulate_kernel, dim3((uint32_t)((T_max + ACC_THREADS - 1) / ACC_THREADS)), dim3(ACC_THREADS), 0, stream,
+                     (const uint32_t*)d_sorted, (const uint4*)d_desc, (const uint32_t*)d_gctr, d_xy, d_partial);
+  HM_HIP_CHECK(hipGetLastError());
+  HM_HIP_CHECK(hipEventRecord(ev[6], stream));
+  HM_HIP_CHECK(hipEventRecord(ev[3], stream));
+  hipLaunchKernelGGL(msm_s_reduce1_kernel, dim3(G1n, V), dim3(WIN_THREADS), 0, stream, d_partial, (const uint32_t*)d_toff, d_seg1, NBh,
+                     H, SEG, G1n);
+  hipLaunchKernelGGL(msm_s_reduce2_kernel, dim3(W), dim3(WIN_THREADS), 0, stream, (const uint32_t*)d_seg1, H * G1n, d_win,
+                     (const uint32_t*)d_gctr, d_tot);
+  HM_HIP_CHECK(hipGetLastError());
+  HM_HIP_CHECK(hipMemcpyAsync(sl.totals(), d_tot, (4 + (size_t)W * 32) * 4, hipMemcpyDeviceToHost, stream));
+  HM_HIP_CHECK(hipEventRecord(ev[4], stream));
+  return HM_OK;
+}
+
+}  // namespace hm
