@@ -4,9 +4,9 @@ Host-side mirror of ``halo2_proofs::arithmetic`` (``best_multiexp``, ``best_fft`
 ``EvaluationDomain`` steps around them, over the C ABI of ``libhalo2_mi355x.so``.
 """
 from . import _lib  # noqa: F401
-from .arithmetic import (best_fft, best_multiexp, best_multiexp_submit, best_multiexp_wait,  # noqa: F401
+from .arithmetic import (best_fft, best_multiexp, best_multiexp_submit, best_multiexp_wait, eval_polynomial,  # noqa: F401
                          g1_fixed_base_mul, msm_stats, register_bases, release_bases)
 from .domain import EvaluationDomain  # noqa: F401
 
-__all__ = ["best_multiexp", "best_multiexp_submit", "best_multiexp_wait", "best_fft", "register_bases", "release_bases", "g1_fixed_base_mul", "msm_stats",
+__all__ = ["eval_polynomial", "best_multiexp", "best_multiexp_submit", "best_multiexp_wait", "best_fft", "register_bases", "release_bases", "g1_fixed_base_mul", "msm_stats",
            "EvaluationDomain"]

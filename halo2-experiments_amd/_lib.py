@@ -74,10 +74,13 @@ _SIGNATURES = {
     "hm_ntt_batch_bn256_fr_dev": (ctypes.c_int, [_vp, ctypes.c_size_t, _u64p, ctypes.c_uint32, _u64p, _u64p, _vp]),
     "hm_ifft_bn256_fr_dev": (ctypes.c_int, [_vp, _u64p, ctypes.c_uint32, _u64p, _vp]),
     "hm_coset_ntt_bn256_fr_dev": (ctypes.c_int, [_vp, _u64p, ctypes.c_uint32, _u64p, _vp]),
+    "hm_fr_powers_dev": (ctypes.c_int, [_vp, ctypes.c_size_t, _u64p, _vp]),
     "hm_fr_scale_dev": (ctypes.c_int, [_vp, ctypes.c_size_t, _u64p, _vp]),
     "hm_fr_distribute_powers_dev": (ctypes.c_int, [_vp, ctypes.c_size_t, _u64p, _vp]),
     "hm_g1_fixed_base_mul_dev": (ctypes.c_int, [_vp, ctypes.c_size_t, _u64p, _vp, _vp]),
     "hm_extended_to_coeff_bn256_fr_dev": (ctypes.c_int, [_vp, ctypes.c_size_t, _u64p, ctypes.c_uint32, _u64p, _u64p, _vp]),
+    "hm_eval_polynomial_bn256_fr_dev": (ctypes.c_int, [_vp, ctypes.c_size_t, ctypes.POINTER(ctypes.c_uint32), _u64p, ctypes.c_size_t,
+                                                       _u64p, _vp]),
     "hm_get_msm_stats": (ctypes.c_int, [ctypes.POINTER(MsmStats)]),
     "hm_get_stats": (ctypes.c_int, [ctypes.POINTER(Stats)]),
     "hm_reset_stats": (ctypes.c_int, []),

@@ -165,6 +165,31 @@ def best_fft(a, omega, log_n: int) -> None:
     _lib.check(lib.hm_ntt_bn256_fr(_ptr(arr), _ptr(w), log_n))
 
 
+def eval_polynomial(polys, points, poly_index=None) -> np.ndarray:
+    """``halo2_proofs::arithmetic::eval_polynomial`` for device-resident coefficient arrays: ``polys`` is a
+    (n, 4) or (batch, n, 4) GPU tensor, ``points`` (q, 4) Montgomery words; query j evaluates polynomial
+    ``poly_index[j]`` (default j) at ``points[j]``.  Returns (q, 4) words."""
+    lib = _lib.load()
+    if not _is_tensor(polys):
+        raise TypeError("eval_polynomial: polys must be a GPU tensor (coefficients stay in HBM)")
+    pts = _np(points, 4, "points")
+    q = pts.shape[0]
+    n = polys.shape[-2] if polys.dim() >= 2 else _tensor_rows(polys, 4, "polys")
+    batch = _tensor_rows(polys, 4, "polys") // max(n, 1) if n else 0
+    idx = None
+    if poly_index is not None:
+        idx = np.ascontiguousarray(poly_index, dtype=np.uint32)
+        if idx.shape[0] != q or (q and int(idx.max()) >= batch):
+            raise ValueError("eval_polynomial: poly_index must name one existing polynomial per point")
+    elif q > batch:
+        raise ValueError("eval_polynomial: more points than polynomials (pass poly_index)")
+    out = np.zeros((q, 4), dtype=np.uint64)
+    _lib.check(lib.hm_eval_polynomial_bn256_fr_dev(
+        ctypes.c_void_p(polys.data_ptr()), n, idx.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)) if idx is not None else None,
+        _ptr(pts), q, _ptr(out), ctypes.c_void_p(_stream_ptr(polys))))
+    return out
+
+
 def g1_fixed_base_mul(scalars, base_xy: np.ndarray):
     """out[i] = [scalars[i]] * base, affine (ParamsKZG::setup's per-row G1 work).  GPU tensors only."""
     import torch

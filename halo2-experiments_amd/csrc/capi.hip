@@ -644,6 +644,23 @@ int hm_coset_ntt_bn256_fr_dev(void* d_a, const uint64_t omega[4], uint32_t log_n
   return rc;
 }
 
+int hm_eval_polynomial_bn256_fr_dev(const void* d_polys, size_t n, const uint32_t* poly_index, const uint64_t* points, size_t count,
+                                    uint64_t* out, void* stream) {
+  if ((count && (!points || !out)) || (count && n && !d_polys))
+    return hm_fail(HM_ERR_BAD_ARG, "hm_eval_polynomial_bn256_fr_dev: null argument");
+  DeviceCtx* ctx = ctx_for_current_device();
+  if (!ctx) return HM_ERR_NO_DEVICE;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  return fr_eval_polynomial_run(*ctx, (const uint32_t*)d_polys, n, poly_index, points, count, out, (hipStream_t)stream);
+}
+
+int hm_fr_powers_dev(void* d_out, size_t n, const uint64_t x[4], void* stream) {
+  if ((n && !d_out) || !x) return hm_fail(HM_ERR_BAD_ARG, "hm_fr_powers_dev: null argument");
+  DeviceCtx* ctx = ctx_for_current_device();
+  if (!ctx) return HM_ERR_NO_DEVICE;
+  return fr_powers_run((uint32_t*)d_out, n, x, (hipStream_t)stream);
+}
+
 int hm_fr_scale_dev(void* d_a, size_t n, const uint64_t c[4], void* stream) {
   if ((n && !d_a) || !c) return hm_fail(HM_ERR_BAD_ARG, "hm_fr_scale_dev: null argument");
   DeviceCtx* ctx = ctx_for_current_device();

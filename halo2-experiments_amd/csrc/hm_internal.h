@@ -175,6 +175,11 @@ int fr_scale_run(uint32_t* d_a, const uint64_t c_ext[4], uint64_t n, hipStream_t
 int fr_mul_pattern3_run(uint32_t* d_a, const uint64_t c3_ext[12], uint64_t n, hipStream_t stream);
 void ntt_tables_release(NttTables& t);
 
+// poly.hip
+int fr_powers_run(uint32_t* d_out, uint64_t n, const uint64_t x_ext[4], hipStream_t stream);
+int fr_eval_polynomial_run(DeviceCtx& ctx, const uint32_t* d_polys, uint64_t n, const uint32_t* poly_index, const uint64_t* points_ext,
+                           size_t q, uint64_t* out_ext, hipStream_t stream);
+
 // msm.hip
 int msm_convert_bases(const uint32_t* d_bases_ext, uint32_t* d_xy, uint8_t* d_inf, size_t n, hipStream_t stream);
 // out_windows: host buffer of W x 12 u64 external Jacobian + flags

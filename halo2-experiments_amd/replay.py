@@ -17,6 +17,12 @@ extended domain 2^ek with ek = k + ceil(log2(d-1))):
     extended_to_coeff (iNTT 2^ek)                    1
 Everything else in ``create_proof`` (witness synthesis, ``evaluate_h``'s gate arithmetic, Horner
 evaluations, the transcript) stays on the CPU in the reference and is NOT part of this number.
+
+Like the reference's harness (prove, THEN verify: /root/reference/src/circuits/merkle_sum_tree.rs:345-358), a
+replay checks what it computed: the SRS is a real one (g = [s^i]G, g_lagrange = [L_i(s)]G with a known s), and
+every commitment of the timed proofs -- each distinct (column, base set) pair, through the eight-in-flight path
+that produced it -- must equal [f(s)]G, where f(s) comes from an independent route through the library
+(inverse NTT of the column, Horner evaluation on the device, one fixed-base multiplication).  A mismatch raises.
 """
 from __future__ import annotations
 
@@ -27,10 +33,15 @@ from typing import Optional
 
 import numpy as np
 
-from .arithmetic import (G1_GENERATOR, best_multiexp, best_multiexp_submit, best_multiexp_wait, g1_fixed_base_mul,
+from .arithmetic import (G1_GENERATOR, best_multiexp, best_multiexp_submit, best_multiexp_wait, eval_polynomial, g1_fixed_base_mul,
                          register_bases, release_bases)
 from .domain import EvaluationDomain, FR_MODULUS, fr_words
+from .kzg import ParamsKZG
 from .sharding import shard_range, sharded_multiexp, sharded_multiexp_batch
+
+# the replay's SRS trapdoor (the reference draws it from OsRng, utils.rs:28): known here, so that every
+# commitment of the replay can be checked against the KZG identity commit(f) == [f(s)]G
+REPLAY_S = 0x48324D4933353558_0123456789ABCDEF_FEDCBA9876543210 % FR_MODULUS
 
 
 @dataclass(frozen=True)
@@ -106,14 +117,38 @@ def run_replay(shape_name: str, device=None, group=None, include_host_pointer_es
         "intt_n": A + 1 + 3 * L + zp, "coset_ntt_ext": A + 1 + 3 * L + zp, "intt_ext": 1,
     }
 
-    # resident SRS slices for this rank: g and g_lagrange (random points: timing does not depend on them)
+    # a real SRS with a known trapdoor; this rank keeps its slice of g and g_lagrange resident
     lo, hi = shard_range(n, rank, world)
     gen = G1_GENERATOR
-    g_h = register_bases(g1_fixed_base_mul(_rand_fr(hi - lo, 17 + rank, device), gen))
-    gl_h = register_bases(g1_fixed_base_mul(_rand_fr(hi - lo, 1717 + rank, device), gen))
+    params = ParamsKZG.setup(k, REPLAY_S, device=device, keep_points=world > 1)
+    if world > 1:
+        g_h = register_bases(params.g_points[lo:hi].contiguous())
+        gl_h = register_bases(params.g_lagrange_points[lo:hi].contiguous())
+        params.release()
+    else:
+        g_h, gl_h = params.g_handle, params.g_lagrange_handle
     dense = [_rand_fr(n, 100 + i, device) for i in range(2)]
     ntt_batch = _rand_fr(8 * n, 300, device).reshape(8, n, 4)
     sparse = [_sparse_column(n, shape.used_rows, 200 + i, device) for i in range(2)]
+
+    from .arithmetic import FQ_ONE_MONT as _FQ_ONE
+
+    # expected commitments, by a route that shares no kernel with the MSM: f(s) by Horner on the device
+    # (for a column committed in the Lagrange basis: of its inverse NTT), then [f(s)]G
+    def expected_commitment(col, lagrange):
+        coeffs = dom.lagrange_to_coeff(col.clone()) if lagrange else col
+        fs = eval_polynomial(coeffs.reshape(1, n, 4), fr_words(REPLAY_S).reshape(1, 4))
+        pt = g1_fixed_base_mul(torch.from_numpy(fs.view(np.int64)).to(device), gen).cpu().numpy().view(np.uint64)[0]
+        out = np.zeros(12, dtype=np.uint64)
+        if pt.any():
+            out[:8] = pt
+            out[8:] = _FQ_ONE
+        return out
+
+    expected = {("sparse", i): expected_commitment(sparse[i], True) for i in range(2)}
+    expected.update({("dense_l", i): expected_commitment(dense[i], True) for i in range(2)})
+    expected.update({("dense_c", i): expected_commitment(dense[i], False) for i in range(2)})
+    checked = {"commitments": 0}
 
     def msm(col, handle):
         return sharded_multiexp(col[lo:hi].contiguous() if world > 1 else col, handle, group=group)
@@ -124,18 +159,20 @@ def run_replay(shape_name: str, device=None, group=None, include_host_pointer_es
         """The commitments of one prover phase are independent: every rank keeps `in_flight` of its local
         MSMs in flight on as many streams (one MSM's sort / bucket reduction / host fold hides behind
         another's accumulation), then the partials of the whole phase cross xGMI in ONE all-gather."""
-        local = [((col[lo:hi].contiguous() if world > 1 else col), handle) for col, handle in jobs]
-        sharded_multiexp_batch(local, group=group, streams=streams)
+        local = [((col[lo:hi].contiguous() if world > 1 else col), handle) for col, handle, _ in jobs]
+        return sharded_multiexp_batch(local, group=group, streams=streams), [key for _, _, key in jobs]
 
     def proof_once():
         t = {"msm": 0.0, "ntt": 0.0}
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        msm_phase([(sparse[i & 1], gl_h) for i in range(counts["msm_sparse"])])
-        msm_phase([(dense[i & 1], g_h if i >= counts["msm_dense"] - (d - 1) - 2 else gl_h)
-                   for i in range(counts["msm_dense"])])
+        r1 = msm_phase([(sparse[i & 1], gl_h, ("sparse", i & 1)) for i in range(counts["msm_sparse"])])
+        coeff_from = counts["msm_dense"] - (d - 1) - 2          # the last d + 1 commitments are in coefficient form
+        r2 = msm_phase([(dense[i & 1], g_h if i >= coeff_from else gl_h, ("dense_c" if i >= coeff_from else "dense_l", i & 1))
+                        for i in range(counts["msm_dense"])])
         torch.cuda.synchronize()
         t["msm"] = time.perf_counter() - t0
+        t["results"] = (r1, r2)
         t0 = time.perf_counter()
         if rank == 0:                                   # NTT stays single-GPU (north star)
             # same-size transforms of one prover phase go through one batched call (<= 8 polynomials at a
@@ -157,7 +194,7 @@ def run_replay(shape_name: str, device=None, group=None, include_host_pointer_es
         t["ntt"] = time.perf_counter() - t0
         return t
 
-    proof_once()                                        # warm-up: tables, workspaces
+    proof_once().pop("results")                         # warm-up: tables, workspaces
     # launch-bound work on a shared host: the best of three replays (every rank runs all three)
     wall, phases = None, None
     for _ in range(3):
@@ -173,6 +210,11 @@ def run_replay(shape_name: str, device=None, group=None, include_host_pointer_es
             tt = torch.tensor([w], dtype=torch.float64, device=comm_dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX, group=group)
             w = float(tt.item())
+        for res, keys in ph.pop("results"):              # outside the timed region: every commitment against [f(s)]G
+            for got, key in zip(res, keys):
+                if not np.array_equal(got, expected[key]):
+                    raise RuntimeError(f"replay {shape_name}: commitment {key} does not satisfy the KZG identity")
+                checked["commitments"] += 1
         if wall is None or w < wall:
             wall, phases = w, ph
 
@@ -182,6 +224,8 @@ def run_replay(shape_name: str, device=None, group=None, include_host_pointer_es
                   "source": shape.source},
         "calls": counts,
         "device_resident_s": {"msm": phases["msm"], "ntt": phases["ntt"], "total": wall},
+        "verified": {"commitments_checked": checked["commitments"], "distinct_column_base_pairs": len(expected),
+                     "against": "KZG identity commit(f) == [f(s)]G, f(s) by device Horner (+ inverse NTT for Lagrange-basis columns)"},
         "note": "MSM/NTT trace replay on synthetic polynomials (no Rust toolchain here); CPU-side parts of create_proof "
                 "excluded; best of three replays",
     }
@@ -203,6 +247,9 @@ def run_replay(shape_name: str, device=None, group=None, include_host_pointer_es
             "total": t_msm * (counts["msm_sparse"] + counts["msm_dense"]) + t_ntt_n * counts["intt_n"]
                      + t_ntt_e * (counts["coset_ntt_ext"] + counts["intt_ext"]),
             "note": "PCIe-inclusive: every call uploads its scalars / moves its array both ways"}
-    release_bases(g_h)
-    release_bases(gl_h)
+    if world > 1:
+        release_bases(g_h)
+        release_bases(gl_h)
+    else:
+        params.release()
     return out

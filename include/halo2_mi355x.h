@@ -164,6 +164,17 @@ int hm_coeff_to_extended_bn256_fr_dev(const void* d_coeffs, void* d_ext, size_t 
 int hm_extended_to_coeff_bn256_fr_dev(void* d_a, size_t batch, const uint64_t extended_omega_inv[4], uint32_t log_ext,
                                       const uint64_t divisor[4], const uint64_t coset_inv[12], void* stream);
 
+/* halo2_proofs::arithmetic::eval_polynomial (the Horner evaluations create_proof makes of every committed
+ * polynomial at x * omega^rot): out[q] = sum_i poly_q[i] * points[q]^i for q < count, where poly_q is the
+ * coefficient array number poly_index[q] (or q when poly_index is NULL) of the back-to-back arrays of n Fr at
+ * d_polys.  points and out are host memory (count x 4 u64); the call synchronises `stream`. */
+int hm_eval_polynomial_bn256_fr_dev(const void* d_polys, size_t n, const uint32_t* poly_index, const uint64_t* points, size_t count,
+                                    uint64_t* out, void* stream);
+
+/* out[i] = x^i for i < n (device pointer, n x 4 u64): the ladder 1, s, s^2, ... of ParamsKZG::setup, whose
+ * fixed-base multiples are g, and whose scaled inverse NTT gives the Lagrange-basis scalars of g_lagrange. */
+int hm_fr_powers_dev(void* d_out, size_t n, const uint64_t x[4], void* stream);
+
 /* a[i] *= c element-wise (device pointer, in place). */
 int hm_fr_scale_dev(void* d_a, size_t n, const uint64_t c[4], void* stream);
 /* EvaluationDomain::distribute_powers_zeta on its own: a[i] *= c3[i % 3] (device pointer, in place). */

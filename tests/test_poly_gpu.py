@@ -1,0 +1,72 @@
+"""GPU suite: eval_polynomial (the Horner evaluations of create_proof) and the power ladder of
+ParamsKZG::setup, through the C ABI, bit-exact against the oracle."""
+import ctypes
+
+import numpy as np
+import pytest
+
+import halo2_experiments_amd as h
+from halo2_experiments_amd import _lib
+from halo2_experiments_amd.arithmetic import _ptr, _stream_ptr
+from halo2_experiments_amd.domain import FR_MODULUS, fr_words
+
+pytestmark = pytest.mark.gpu
+
+
+def rand_fr_gpu(n, seed):
+    import torch
+    g = torch.Generator(device="cuda")
+    g.manual_seed(seed)
+    x = torch.randint(-(2 ** 63), 2 ** 63 - 1, (n, 4), dtype=torch.int64, device="cuda", generator=g)
+    x[:, 3] &= 0x0FFFFFFFFFFFFFFF
+    return x
+
+
+@pytest.mark.parametrize("n", [1, 2, 5, 255, 256, 257, 4095, 4096, 4097, (1 << 14) + 3, 1 << 16, (1 << 18) - 1, 1 << 18])
+def test_eval_polynomial_matches_oracle_horner(cref, pyref, n):
+    """Every block plan boundary (one partial block, exactly one, CH growing) and ragged tails; points: random,
+    0 (the constant coefficient), 1 (the sum of the coefficients) and r - 1."""
+    o = pyref
+    polys = rand_fr_gpu(3 * n, 700 + n % 101).reshape(3, n, 4)
+    ph = polys.cpu().numpy().view(np.uint64)
+    pts_int = [o.rand_scalars(1, n)[0], 0, 1, o.R - 1, 0x48324D4933353558]
+    idx = [0, 1, 2, 1, 2]
+    pts = np.stack([fr_words(v) for v in pts_int])
+    got = h.eval_polynomial(polys, pts, poly_index=idx)
+    for j, (i, v) in enumerate(zip(idx, pts_int)):
+        assert np.array_equal(got[j], cref.fr_horner(ph[i], pts[j])), (n, j)
+    assert np.array_equal(got[1], ph[1][0])                    # f(0) = a_0
+    # default indexing: query j -> polynomial j
+    got3 = h.eval_polynomial(polys, pts[:3])
+    for j in range(3):
+        assert np.array_equal(got3[j], cref.fr_horner(ph[j], pts[j]))
+
+
+def test_eval_polynomial_many_queries_and_errors(cref, pyref):
+    """More queries than one launch carries (48); rotations x * omega^rot of one polynomial, as create_proof asks."""
+    o = pyref
+    k, n = 12, 1 << 12
+    poly = rand_fr_gpu(n, 4321).reshape(1, n, 4)
+    ph = poly.cpu().numpy().view(np.uint64)[0]
+    w = o.fr_omega(k)
+    x = 0x1234567890ABCDEF1234567890ABCDEF % o.R
+    pts_int = [x * pow(w, rot, o.R) % o.R for rot in range(-30, 31)]
+    pts = np.stack([fr_words(v) for v in pts_int])
+    got = h.eval_polynomial(poly, pts, poly_index=[0] * len(pts_int))
+    for j in range(len(pts_int)):
+        assert np.array_equal(got[j], cref.fr_horner(ph, pts[j])), j
+    with pytest.raises(ValueError):
+        h.eval_polynomial(poly, pts)                       # 61 points, one polynomial, no index
+    with pytest.raises(ValueError):
+        h.eval_polynomial(poly, pts[:2], poly_index=[0, 1])
+
+
+def test_power_ladder(cref, pyref):
+    import torch
+    o = pyref
+    lib = _lib.load()
+    for n, s in ((1, 5), (2, o.R - 1), (1000, 0x48324D4933353558), (1 << 16, 987654321987654321 % o.R)):
+        out = torch.empty((n, 4), dtype=torch.int64, device="cuda")
+        _lib.check(lib.hm_fr_powers_dev(ctypes.c_void_p(out.data_ptr()), n, _ptr(fr_words(s)), ctypes.c_void_p(_stream_ptr(out))))
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy().view(np.uint64), cref.fr_powers(fr_words(s), n)), n
