@@ -44,6 +44,23 @@ inline void best_fft(Fr* a, size_t len, const Fr& omega, uint32_t log_n) {
 }
 inline void best_fft(std::vector<Fr>& a, const Fr& omega, uint32_t log_n) { best_fft(a.data(), a.size(), omega, log_n); }
 
+// eval_polynomial(poly, point) for a coefficient array resident in HBM (upstream: halo2_proofs::arithmetic::
+// eval_polynomial on a host slice); `queries` polynomials / points at once through one pair of launches
+inline std::vector<Fr> eval_polynomial(const Fr* d_polys, size_t n, const std::vector<uint32_t>& poly_index,
+                                       const std::vector<Fr>& points, void* stream = nullptr) {
+  if (!poly_index.empty() && poly_index.size() != points.size())
+    throw std::invalid_argument("eval_polynomial: one polynomial index per point");
+  std::vector<Fr> out(points.size());
+  check(hm_eval_polynomial_bn256_fr_dev(d_polys, n, poly_index.empty() ? nullptr : poly_index.data(),
+                                        reinterpret_cast<const uint64_t*>(points.data()), points.size(),
+                                        reinterpret_cast<uint64_t*>(out.data()), stream),
+        "eval_polynomial");
+  return out;
+}
+inline Fr eval_polynomial(const Fr* d_poly, size_t n, const Fr& point, void* stream = nullptr) {
+  return eval_polynomial(d_poly, n, std::vector<uint32_t>{}, std::vector<Fr>{point}, stream)[0];
+}
+
 // affine normalisation of a G1 the library returned: it is already (x, y, 1) or the identity
 inline G1Affine to_affine(const G1& p) {
   if (p.is_identity()) return G1Affine::identity();

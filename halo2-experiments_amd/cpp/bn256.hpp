@@ -142,6 +142,61 @@ struct G1 {
 };
 static_assert(sizeof(Fr) == 32 && sizeof(G1Affine) == 64 && sizeof(G1) == 96, "layout must match halo2curves");
 
+// Fq2 = Fq[u] / (u^2 + 1) and G2 (y^2 = x^3 + 3 / (9 + u)), host only: ParamsKZG::setup needs ONE scalar
+// multiple of the G2 generator (s_g2); layout of G2Affine as halo2curves holds it: x.c0, x.c1, y.c0, y.c1.
+struct Fq2 {
+  Fq c0, c1;
+  static Fq2 zero() { return Fq2{Fq::zero(), Fq::zero()}; }
+  bool is_zero() const { return c0.is_zero() && c1.is_zero(); }
+  bool operator==(const Fq2& o) const { return c0 == o.c0 && c1 == o.c1; }
+  Fq2 operator+(const Fq2& o) const { return Fq2{c0 + o.c0, c1 + o.c1}; }
+  Fq2 operator-(const Fq2& o) const { return Fq2{c0 - o.c0, c1 - o.c1}; }
+  Fq2 operator*(const Fq2& o) const { return Fq2{c0 * o.c0 - c1 * o.c1, c0 * o.c1 + c1 * o.c0}; }
+  Fq2 square() const { return *this * *this; }
+  Fq2 invert() const {
+    const Fq d = (c0.square() + c1.square()).invert();
+    return Fq2{c0 * d, -(c1 * d)};
+  }
+};
+struct G2Affine {
+  Fq2 x, y;                                   // the identity is (0, 0)
+  static G2Affine identity() { return G2Affine{Fq2::zero(), Fq2::zero()}; }
+  bool is_identity() const { return x.is_zero() && y.is_zero(); }
+  bool operator==(const G2Affine& o) const { return x == o.x && y == o.y; }
+  static G2Affine generator() {               // the alt_bn128 G2 generator (EIP-197)
+    const uint64_t x0[4] = {0x46debd5cd992f6edULL, 0x674322d4f75edaddULL, 0x426a00665e5c4479ULL, 0x1800deef121f1e76ULL};
+    const uint64_t x1[4] = {0x97e485b7aef312c2ULL, 0xf1aa493335a9e712ULL, 0x7260bfb731fb5d25ULL, 0x198e9393920d483aULL};
+    const uint64_t y0[4] = {0x4ce6cc0166fa7daaULL, 0xe3d1e7690c43d37bULL, 0x4aab71808dcb408fULL, 0x12c85ea5db8c6debULL};
+    const uint64_t y1[4] = {0x55acdadcd122975bULL, 0xbc4b313370b38ef3ULL, 0xec9e99ad690c3395ULL, 0x090689d0585ff075ULL};
+    return G2Affine{Fq2{Fq::from_raw(x0), Fq::from_raw(x1)}, Fq2{Fq::from_raw(y0), Fq::from_raw(y1)}};
+  }
+  G2Affine add(const G2Affine& q) const {     // affine law with one inversion: setup does ~380 of these
+    if (is_identity()) return q;
+    if (q.is_identity()) return *this;
+    Fq2 lam;
+    if (x == q.x) {
+      if (!(y == q.y) || y.is_zero()) return identity();
+      const Fq2 xx = x.square();
+      lam = (xx + xx + xx) * (y + y).invert();
+    } else {
+      lam = (q.y - y) * (q.x - x).invert();
+    }
+    const Fq2 x3 = lam.square() - x - q.x;
+    return G2Affine{x3, lam * (x - x3) - y};
+  }
+  G2Affine mul(const Field<FrParams>& k_mont) const {
+    const Field<FrParams> one_raw{{1, 0, 0, 0}};
+    const Field<FrParams> k = k_mont * one_raw;             // Montgomery -> canonical
+    G2Affine acc = identity();
+    for (int i = 255; i >= 0; --i) {
+      acc = acc.add(acc);
+      if ((k.l[i >> 6] >> (i & 63)) & 1) acc = acc.add(*this);
+    }
+    return acc;
+  }
+};
+static_assert(sizeof(G2Affine) == 128, "layout must match halo2curves");
+
 // Fr constants of halo2curves::bn256 (FieldExt / PrimeField): S, ROOT_OF_UNITY = 7^((r-1)/2^28), ZETA
 constexpr uint32_t FR_S = 28;
 inline Fr fr_root_of_unity() {

@@ -6,6 +6,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
+#include <string>
 #include <vector>
 
 #include "arithmetic.hpp"
@@ -104,28 +106,58 @@ class EvaluationDomain {
   }
 };
 
-// ParamsKZG<Bn256>: g = [s^i]G, g_lagrange = [L_i(s)]G, device resident; commit / commit_lagrange
+// ParamsKZG<Bn256>: g = [s^i]G, g_lagrange = [L_i(s)]G, device resident; g2, s_g2; commit / commit_lagrange;
+// write / read of the on-disk SRS (u32 k | n x 64 B g | n x 64 B g_lagrange | 128 B g2 | 128 B s_g2 -- the bytes
+// the Rust types hold, the field order of upstream's ParamsKZG::write with raw points)
 class ParamsKZG {
  public:
   uint32_t k;
   size_t n;
   uint64_t g_handle = 0, g_lagrange_handle = 0;
+  bn256::G2Affine g2, s_g2;
+  std::vector<G1Affine> g_points, g_lagrange_points;      // host copies, kept only for write()
 
-  // setup with a caller-provided trapdoor s (the reference draws it from OsRng, utils.rs:28)
-  ParamsKZG(uint32_t k_, const Fr& s, bool precompute = false) : k(k_), n((size_t)1 << k_) {
+  // setup with a caller-provided trapdoor s (the reference draws it from OsRng, utils.rs:28).  All G1 work is on
+  // the device: the ladder s^i, its scaled inverse NTT (= the Lagrange scalars L_i(s)), 2 n fixed-base multiples.
+  ParamsKZG(uint32_t k_, const Fr& s, bool precompute = false, bool keep_points = false) : k(k_), n((size_t)1 << k_) {
     const EvaluationDomain dom(2, k);
-    std::vector<Fr> pw(n), lag(n);
-    Fr acc = Fr::one();
-    for (size_t i = 0; i < n; ++i) { pw[i] = acc; acc = acc * s; }
-    // L_i(s) = (s^n - 1)/n * omega^i / (s - omega^i), denominators inverted in one batch
-    const Fr zn = (acc - Fr::one()) * dom.ifft_divisor;
-    std::vector<Fr> den(n), pre(n);
-    Fr w = Fr::one(), run = Fr::one();
-    for (size_t i = 0; i < n; ++i) { den[i] = s - w; pre[i] = run; run = run * den[i]; lag[i] = zn * w; w = w * dom.omega; }
-    Fr inv = run.invert();
-    for (size_t i = n; i-- > 0;) { const Fr di = inv * pre[i]; inv = inv * den[i]; lag[i] = lag[i] * di; }
-    g_handle = fixed_base_set(pw, precompute);
-    g_lagrange_handle = fixed_base_set(lag, precompute);
+    DevicePolys ladder(n, 1);
+    arithmetic::check(hm_fr_powers_dev(ladder.d, n, s.l, nullptr), "ParamsKZG::setup");
+    g_handle = fixed_base_set(ladder, precompute, keep_points ? &g_points : nullptr);
+    dom.lagrange_to_coeff(ladder);                         // n^-1 NTT_{omega^-1}(s^i) = L_i(s)
+    g_lagrange_handle = fixed_base_set(ladder, precompute, keep_points ? &g_lagrange_points : nullptr);
+    g2 = bn256::G2Affine::generator();
+    s_g2 = g2.mul(s);
+  }
+  // read(): load instead of regenerate
+  explicit ParamsKZG(const std::string& path, bool precompute = false) {
+    FILE* f = std::fopen(path.c_str(), "rb");
+    if (!f) throw std::runtime_error("ParamsKZG::read: cannot open " + path);
+    uint32_t kk = 0;
+    bool ok = std::fread(&kk, 4, 1, f) == 1 && kk <= 28;
+    k = kk;
+    n = (size_t)1 << (ok ? kk : 0);
+    if (ok) {
+      g_points.resize(n);
+      g_lagrange_points.resize(n);
+      ok = std::fread(g_points.data(), 64, n, f) == n && std::fread(g_lagrange_points.data(), 64, n, f) == n &&
+           std::fread(&g2, 128, 1, f) == 1 && std::fread(&s_g2, 128, 1, f) == 1;
+    }
+    std::fclose(f);
+    if (!ok) throw std::runtime_error("ParamsKZG::read: truncated or malformed file " + path);
+    const auto reg = precompute ? hm_register_bases_precomp : hm_register_bases;
+    arithmetic::check(reg(reinterpret_cast<const uint64_t*>(g_points.data()), n, &g_handle), "ParamsKZG::read");
+    arithmetic::check(reg(reinterpret_cast<const uint64_t*>(g_lagrange_points.data()), n, &g_lagrange_handle), "ParamsKZG::read");
+  }
+  void write(const std::string& path) const {
+    if (g_points.size() != n || g_lagrange_points.size() != n)
+      throw std::runtime_error("ParamsKZG::write: the affine points were not kept (keep_points)");
+    FILE* f = std::fopen(path.c_str(), "wb");
+    if (!f) throw std::runtime_error("ParamsKZG::write: cannot open " + path);
+    const bool ok = std::fwrite(&k, 4, 1, f) == 1 && std::fwrite(g_points.data(), 64, n, f) == n &&
+                    std::fwrite(g_lagrange_points.data(), 64, n, f) == n && std::fwrite(&g2, 128, 1, f) == 1 &&
+                    std::fwrite(&s_g2, 128, 1, f) == 1;
+    if (std::fclose(f) != 0 || !ok) throw std::runtime_error("ParamsKZG::write: short write to " + path);
   }
   ParamsKZG(const ParamsKZG&) = delete;
   ParamsKZG& operator=(const ParamsKZG&) = delete;
@@ -157,16 +189,18 @@ class ParamsKZG {
     arithmetic::check(hm_msm_bn256_g1_dev(handle, 0, d_poly, n, nullptr, reinterpret_cast<uint64_t*>(&out)), "commit");
     return out;
   }
-  uint64_t fixed_base_set(const std::vector<Fr>& scalars, bool precompute) const {
-    DevicePolys ds(n, 1);
-    ds.upload(scalars);
+  uint64_t fixed_base_set(const DevicePolys& scalars, bool precompute, std::vector<G1Affine>* keep) const {
     G1Affine* d_pts = nullptr;
     if (hipMalloc((void**)&d_pts, n * sizeof(G1Affine)) != hipSuccess) throw std::runtime_error("hipMalloc failed");
     const G1Affine gen = G1Affine::generator();
     uint64_t handle = 0;
-    int rc = hm_g1_fixed_base_mul_dev(ds.d, n, reinterpret_cast<const uint64_t*>(&gen), d_pts, nullptr);
+    int rc = hm_g1_fixed_base_mul_dev(scalars.d, n, reinterpret_cast<const uint64_t*>(&gen), d_pts, nullptr);
     if (rc == HM_OK)
       rc = precompute ? hm_register_bases_precomp_dev(d_pts, n, nullptr, &handle) : hm_register_bases_dev(d_pts, n, nullptr, &handle);
+    if (rc == HM_OK && keep) {
+      keep->resize(n);
+      if (hipMemcpy(keep->data(), d_pts, n * sizeof(G1Affine), hipMemcpyDeviceToHost) != hipSuccess) rc = HM_ERR_HIP;
+    }
     (void)hipFree(d_pts);
     arithmetic::check(rc, "ParamsKZG::setup");
     return handle;

@@ -6,17 +6,24 @@
 // of the given shape is replayed on synthetic polynomials through the C++ mirror
 // of halo2_proofs (cpp/arithmetic.hpp, cpp/domain.hpp) -- everything else in create_proof is
 // CPU-side Rust and is not part of these numbers.  "Verify" is the algebraic check the KZG commitments
-// must satisfy: commit(f) == commit_lagrange(NTT(f)) == [f(s)]G for a random f.
+// must satisfy: EVERY commitment create_proof's trace produced -- each (column, base set) pair, through the
+// eight-in-flight path that computed it -- equals [f(s)]G, with f(s) from the device Horner kernel (of the
+// inverse NTT for Lagrange-basis columns); plus commit(f) == commit_lagrange(NTT(f)) for a random f.
+// The run ends with the MEASURED call trace of the library's counters (hm_get_stats): what a Rust build of the
+// shim reads after create_proof instead of SURVEY.md §3.2's estimates.
 //
-//   full_prover_replay [k=9] [advice=20] [lookups=8] [equality=12] [max_degree=7] [fixed=8] [tamper=0]
+//   full_prover_replay [k=9] [advice=20] [lookups=8] [equality=12] [max_degree=7] [fixed=8] [tamper=0] [srs_path]
 // tamper=1 changes one evaluation between the two commitments, as the reference's tests tamper with
 // a witness and expect `verify()` to fail: the run must then report a mismatch and exit 1.
+// srs_path: load the SRS from that file if it exists (ParamsKZG::read), else generate it and write it there.
 // Defaults are test_full_prover's k = 9 (/root/reference/src/circuits/merkle_sum_tree.rs:347) with the
 // MerkleSumTree column counts.
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <memory>
 #include <random>
+#include <string>
 
 #include "../cpp/domain.hpp"
 
@@ -88,6 +95,7 @@ int main(int argc, char** argv) {
   const uint32_t max_degree = argc > 5 ? (uint32_t)atoi(argv[5]) : 7;
   const uint32_t fixed = argc > 6 ? (uint32_t)atoi(argv[6]) : 8;
   const bool tamper = argc > 7 && atoi(argv[7]) != 0;
+  const std::string srs_path = argc > 8 ? argv[8] : "";
   if (k < 4 || k > 22 || max_degree < 3) { std::fprintf(stderr, "unsupported shape\n"); return 2; }
   try {
     if (hm_device_count() <= 0) { std::fprintf(stderr, "no gfx950 device: %s\n", "this path has no CPU fallback"); return 3; }
@@ -97,10 +105,26 @@ int main(int argc, char** argv) {
     const uint32_t zp = (equality + max_degree - 3) / (max_degree - 2);
     const size_t used_rows = n / 4 < 1100 ? n / 4 : 1100;
 
-    // ParamsKZG::<Bn256>::setup(k, OsRng)  (utils.rs:28)
+    // ParamsKZG::<Bn256>::setup(k, OsRng)  (utils.rs:28) -- or loaded from disk instead of regenerated
     const auto t_setup0 = Clock::now();
     const Fr s = random_fr(rng);
-    const poly::ParamsKZG params(k, s);
+    std::unique_ptr<poly::ParamsKZG> params_ptr;
+    bool srs_loaded = false;
+    if (!srs_path.empty()) {
+      if (FILE* probe = std::fopen(srs_path.c_str(), "rb")) {
+        std::fclose(probe);
+        params_ptr.reset(new poly::ParamsKZG(srs_path));
+        srs_loaded = true;
+        if (params_ptr->k != k) throw std::runtime_error("SRS file holds another k");
+        if (!(params_ptr->s_g2 == params_ptr->g2.mul(s))) throw std::runtime_error("SRS file was made with another trapdoor");
+      } else {
+        params_ptr.reset(new poly::ParamsKZG(k, s, false, true));
+        params_ptr->write(srs_path);
+      }
+    } else {
+      params_ptr.reset(new poly::ParamsKZG(k, s));
+    }
+    const poly::ParamsKZG& params = *params_ptr;
     const auto t_setup1 = Clock::now();
 
     // synthetic columns: dense = uniform; sparse = used_rows small values + 6 blinding rows
@@ -139,25 +163,31 @@ int main(int argc, char** argv) {
     hipStream_t streams[kStreams];
     for (auto& st : streams) (void)hipStreamCreate(&st);
     (void)hipDeviceSynchronize();
-    auto commit_phase = [&](uint32_t count, const Fr* d_poly, bool lagrange) {
+    // every commitment of the trace is kept and checked after the timed region: (which column, which base set, result)
+    struct Made { int pair; G1 c; };
+    std::vector<Made> made;
+    made.reserve(256);
+    auto commit_phase = [&](uint32_t count, const Fr* d_poly, bool lagrange, int pair) {
       uint64_t pending[kInFlight];
       uint32_t head = 0, inflight = 0;
       for (uint32_t i = 0; i < count; ++i) {
-        if (inflight == kInFlight) { (void)poly::ParamsKZG::commit_wait(pending[head]); head = (head + 1) % kInFlight; --inflight; }
+        if (inflight == kInFlight) { made.push_back(Made{pair, poly::ParamsKZG::commit_wait(pending[head])}); head = (head + 1) % kInFlight; --inflight; }
         const uint32_t slot = (head + inflight) % kInFlight;
         pending[slot] = lagrange ? params.commit_lagrange_submit(d_poly, streams[i % kStreams])
                                  : params.commit_submit(d_poly, streams[i % kStreams]);
         ++inflight;
       }
-      while (inflight) { (void)poly::ParamsKZG::commit_wait(pending[head]); head = (head + 1) % kInFlight; --inflight; }
+      while (inflight) { made.push_back(Made{pair, poly::ParamsKZG::commit_wait(pending[head])}); head = (head + 1) % kInFlight; --inflight; }
     };
-    commit_phase(kInFlight, d_dense.d, true);                      // warm-up: allocates the asynchronous workspaces
+    commit_phase(kInFlight, d_dense.d, true, 1);                   // warm-up: allocates the asynchronous workspaces
+    made.clear();
+    (void)hm_reset_stats();                                        // the measured call trace covers create_proof only
     // the prover's polynomial buffers live for the whole proof (as halo2's Vec<Polynomial> do)
     poly::DevicePolys batch(n, 8), ext(dom.extended_len(), 8), hpoly(dom.extended_len(), 1);
     const auto t_pr0 = Clock::now();
     size_t n_msm = 0, n_ntt = 0;
-    commit_phase(advice + 2 * lookups, d_sparse.d, true);          // advice, permuted lookup columns
-    commit_phase(zp + lookups + 1, d_dense.d, true);               // grand products, random poly
+    commit_phase(advice + 2 * lookups, d_sparse.d, true, 0);       // advice, permuted lookup columns
+    commit_phase(zp + lookups + 1, d_dense.d, true, 1);            // grand products, random poly
     n_msm += advice + 2 * lookups + zp + lookups + 1;
     {
       const size_t polys = advice + 1 + 3 * lookups + zp;
@@ -177,11 +207,13 @@ int main(int argc, char** argv) {
       }
       batch.batch = 8;
     }
-    commit_phase((max_degree - 1) + 2, d_dense.d, false);          // h pieces, SHPLONK
+    commit_phase((max_degree - 1) + 2, d_dense.d, false, 2);       // h pieces, SHPLONK
     n_msm += (max_degree - 1) + 2;
     (void)hipDeviceSynchronize();
     const auto t_pr1 = Clock::now();
     for (auto& st : streams) (void)hipStreamDestroy(st);
+    hm_stats trace;
+    arithmetic::check(hm_get_stats(&trace), "hm_get_stats");
 
     // verify: commit(f) == commit_lagrange(NTT(f)) == [f(s)]G
     const auto t_v0 = Clock::now();
@@ -199,7 +231,25 @@ int main(int argc, char** argv) {
     Fr fs = Fr::zero();
     for (size_t i = n; i-- > 0;) fs = fs * s + dense[i];
     const G1Affine expect = g1_mul_generator(fs);
-    const bool ok = arithmetic::to_affine(c_coeff) == expect && arithmetic::to_affine(c_lagrange) == expect;
+    bool ok = arithmetic::to_affine(c_coeff) == expect && arithmetic::to_affine(c_lagrange) == expect;
+    // ... and every commitment the trace made: pair 0 = (sparse column, g_lagrange), 1 = (dense, g_lagrange),
+    // 2 = (dense, g).  f(s) by the device Horner kernel -- for a Lagrange-basis column, of its inverse NTT.
+    G1Affine want[3];
+    {
+      poly::DevicePolys tmp(n, 1);
+      (void)hipMemcpy(tmp.d, d_sparse.d, n * sizeof(Fr), hipMemcpyDeviceToDevice);
+      dom.lagrange_to_coeff(tmp);
+      want[0] = g1_mul_generator(arithmetic::eval_polynomial(tmp.d, n, s));
+      (void)hipMemcpy(tmp.d, d_dense.d, n * sizeof(Fr), hipMemcpyDeviceToDevice);
+      dom.lagrange_to_coeff(tmp);
+      want[1] = g1_mul_generator(arithmetic::eval_polynomial(tmp.d, n, s));
+      want[2] = g1_mul_generator(arithmetic::eval_polynomial(d_dense.d, n, s));
+      if (!(want[2] == expect)) ok = false;            // device Horner vs the host Horner above
+    }
+    size_t bad = 0;
+    for (const Made& m : made)
+      if (!(arithmetic::to_affine(m.c) == want[m.pair])) ++bad;
+    if (bad || made.size() != n_msm) ok = false;
     const auto t_v1 = Clock::now();
 
     std::printf("shape: k=%u advice=%u lookups=%u equality=%u max_degree=%u fixed=%u extended_k=%u  (%zu MSMs, %zu NTTs in create_proof)\n",
@@ -209,6 +259,15 @@ int main(int argc, char** argv) {
     std::printf("Time to generate pk %.6fs\n", secs(t_pk0, t_pk1));
     std::printf("Prover Time %.6fs\n", secs(t_pr0, t_pr1));
     std::printf("Verifier Time %.6fs\n", secs(t_v0, t_v1));
+    std::printf("SRS: %s\n", srs_loaded ? "loaded from disk" : (srs_path.empty() ? "generated" : "generated and written to disk"));
+    std::printf("measured call trace (hm_get_stats): %llu MSMs / %llu points, %llu NTTs / %llu elements; MSM device %.3f ms, host fold %.3f ms\n",
+                (unsigned long long)trace.msm_calls, (unsigned long long)trace.msm_points, (unsigned long long)trace.ntt_calls,
+                (unsigned long long)trace.ntt_elements, trace.msm_device_us / 1e3, trace.msm_host_us / 1e3);
+    for (int lg = 0; lg < 32; ++lg)
+      if (trace.msm_calls_by_log2[lg] || trace.ntt_calls_by_log2[lg])
+        std::printf("  2^%-2d  MSM calls %4llu   NTT calls %4llu\n", lg, (unsigned long long)trace.msm_calls_by_log2[lg],
+                    (unsigned long long)trace.ntt_calls_by_log2[lg]);
+    std::printf("checked %zu commitments of the trace against [f(s)]G: %zu mismatches\n", made.size(), bad);
     std::printf("%s\n", ok ? "commitments verified" : "COMMITMENT MISMATCH");
     (void)hm_shutdown();
     return ok ? 0 : 1;

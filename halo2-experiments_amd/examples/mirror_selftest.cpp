@@ -35,6 +35,20 @@ int main() {
   const uint64_t ex[4] = {0xd3c208c16d87cfd3ULL, 0xd97816a916871ca8ULL, 0x9b85045b68181585ULL, 0x030644e72e131a02ULL};
   const uint64_t ey[4] = {0xff3ebf7a5a18a2c4ULL, 0x68a6a449e3538fc7ULL, 0xe7845f96b2ae9c0aULL, 0x15ed738c0e0a7c92ULL};
   CHECK(x2 == Fq::from_raw(ex) && y2 == Fq::from_raw(ey));
+  // G2: the generator is on y^2 = x^3 + 3 / (9 + u), (r - 1) G2 = -G2, scalar multiples add up
+  {
+    using bn256::Fq2;
+    using bn256::G2Affine;
+    const G2Affine g2 = G2Affine::generator();
+    const Fq2 b = Fq2{three, Fq::zero()} * Fq2{Fq::from_u64(9), one}.invert();
+    CHECK(g2.y.square() == g2.x.square() * g2.x + b);
+    const G2Affine m = g2.mul(-Fr::one());
+    const Fq2 neg_y{-g2.y.c0, -g2.y.c1};
+    CHECK(m.x == g2.x && m.y == neg_y);
+    CHECK(m.add(g2).is_identity());
+    CHECK(g2.mul(Fr::from_u64(5)).add(g2.mul(Fr::from_u64(7))) == g2.mul(Fr::from_u64(12)));
+    CHECK(g2.mul(Fr::from_u64(2)) == g2.add(g2));
+  }
   // EvaluationDomain::new(7, 9): MerkleSumTree at test_full_prover's k
   const poly::EvaluationDomain d(7, 9);
   CHECK(d.extended_k == 12 && d.quotient_poly_degree == 6);

@@ -45,6 +45,26 @@ def test_full_prover_replay_verifies(built, args):
     assert "commitments verified" in r.stdout
     for line in ("Time to generate vk", "Time to generate pk", "Prover Time", "Verifier Time"):
         assert re.search(line + r" \d+\.\d+s", r.stdout), r.stdout
+    # every commitment of the trace was checked, and the library's counters saw exactly the trace's calls
+    shape = re.search(r"\((\d+) MSMs, (\d+) NTTs in create_proof\)", r.stdout)
+    checked = re.search(r"checked (\d+) commitments of the trace against \[f\(s\)\]G: 0 mismatches", r.stdout)
+    trace = re.search(r"measured call trace \(hm_get_stats\): (\d+) MSMs / (\d+) points, (\d+) NTTs", r.stdout)
+    assert shape and checked and trace, r.stdout
+    assert int(checked.group(1)) == int(shape.group(1)) == int(trace.group(1))
+    assert int(trace.group(3)) == int(shape.group(2))
+
+
+@pytest.mark.gpu
+def test_full_prover_replay_loads_the_srs_from_disk(built, tmp_path):
+    """ParamsKZG::write / read: the first run generates the SRS and writes it, the second loads it instead of
+    regenerating (the reference regenerates on every run, utils.rs:28) and verifies the same commitments."""
+    path = str(tmp_path / "k10.srs")
+    args = [os.path.join(built, "full_prover_replay"), "10", "4", "0", "3", "5", "2", "0", path]
+    r1 = subprocess.run(args, capture_output=True, text=True, timeout=600)
+    assert r1.returncode == 0 and "generated and written to disk" in r1.stdout, r1.stdout + r1.stderr
+    assert os.path.getsize(path) == 4 + (1 << 10) * 128 + 256
+    r2 = subprocess.run(args, capture_output=True, text=True, timeout=600)
+    assert r2.returncode == 0 and "loaded from disk" in r2.stdout and "commitments verified" in r2.stdout, r2.stdout + r2.stderr
 
 
 @pytest.mark.gpu
