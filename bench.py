@@ -9,6 +9,8 @@ A "step" is one best_multiexp over the global array: every rank runs the MSM of 
 shard (2^24 points per GPU, inputs resident in HBM before the timed region), the 96-byte partial
 results are all-gathered over RCCL and folded on every rank.  Weak scaling: N=1 is the north
 star's 2^24 headline, N=4 is BASELINE config 5's 2^26.  Rank 0 prints ONE JSON line.
+Inputs follow SURVEY.md §8d (uniform scalars from xoshiro256**, bases [a + i b]G); the result of the timed
+steps is checked against the known answer [sum s_i (a + i b)]G outside the timed loop.
 
 Extra objects on that line:
   roofline      dominant kernel = msm_accumulate_kernel; achieved = 96 B/point (SURVEY.md §8d:
@@ -59,34 +61,92 @@ def fq_mont_words(v):
     return [(m >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)]
 
 
+def cpu_model() -> str:
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(log_sample, device):
     """Time the oracle's best_multiexp on a bounded sample (the only use of oracle/ in this file)."""
     import halo2_experiments_amd as h
     from oracle import cpu_ref
     cpu_ref.build()
     n = 1 << log_sample
-    gen = np.array(fq_mont_words(1) + fq_mont_words(2), dtype=np.uint64)
-    bases = h.g1_fixed_base_mul(rand_fr(n, 4242, device), gen).cpu().numpy().view(np.uint64)
-    scalars = rand_fr(n, 4243, device).cpu().numpy().view(np.uint64)
-    threads = min(cpu_ref.default_threads(), 64)
+    scalars_d, bases_d, _ = bench_inputs(n, 0, 4242, device)
+    bases = bases_d.cpu().numpy().view(np.uint64)
+    scalars = scalars_d.cpu().numpy().view(np.uint64)
+    threads = cpu_ref.default_threads()            # every core the box gives this process (HALO2_CPU_THREADS overrides)
     t0 = time.perf_counter()
     ref = cpu_ref.best_multiexp(scalars, bases, threads)
     dt = time.perf_counter() - t0
     got = h.best_multiexp(scalars, bases)
     ok = bool(np.array_equal(cpu_ref.g1_to_affine(ref)[0], got[:8]))
-    return {"value": n / dt, "unit": "points/s", "cores": threads, "kind": "port",
-            "sample": f"one 2^{log_sample}-point MSM, same distributions, {dt:.2f} s wall; "
+    return {"value": n / dt, "unit": "points/s", "cores": threads, "cpu_model": cpu_model(), "kind": "port",
+            "sample": f"one 2^{log_sample}-point MSM, same input construction as the timed steps, {dt:.2f} s wall; "
                       "C restatement of halo2_proofs v2023_02_02 best_multiexp (not the Rust binary)",
             "agrees_with_gpu": ok}
 
 
+BENCH_SEED = 0x48324D4933353558          # "H2MI355X" (SURVEY.md §8d)
+
+
+def bench_inputs(n, first_index, seed, device):
+    """scalars uniform in [0, r) from xoshiro256** (one stream per element, seeded from `seed`), bases
+    P_i = [a + i b]G with a, b derived from seed + 1 (distinct, never the identity, and the MSM's answer is known:
+    [sum_i s_i (a + i b)]G).  Everything is produced on the device; returns (scalars, bases, t) tensors."""
+    import ctypes
+    import halo2_experiments_amd as h
+    from halo2_experiments_amd import _lib
+    from halo2_experiments_amd.arithmetic import G1_GENERATOR, _ptr, _stream_ptr
+    from halo2_experiments_amd.domain import FR_MODULUS, fr_words
+    lib = _lib.load()
+    a = pow(seed + 1, 3, FR_MODULUS) or 1
+    b = pow(seed + 1, 5, FR_MODULUS) or 1
+    scalars = torch.empty((n, 4), dtype=torch.int64, device=device)
+    t = torch.empty((n, 4), dtype=torch.int64, device=device)
+    st = ctypes.c_void_p(_stream_ptr(scalars))
+    _lib.check(lib.hm_fr_random_dev(ctypes.c_void_p(scalars.data_ptr()), n, seed + first_index, st))
+    _lib.check(lib.hm_fr_affine_sequence_dev(ctypes.c_void_p(t.data_ptr()), n, _ptr(fr_words((a + first_index * b) % FR_MODULUS)),
+                                              _ptr(fr_words(b)), st))
+    bases = h.g1_fixed_base_mul(t, G1_GENERATOR)
+    return scalars, bases, t
+
+
+def known_answer(scalars, t, device):
+    """[sum_i s_i t_i]G as 12 words (x, y, 1), through the device inner product and one fixed-base multiplication."""
+    import ctypes
+    import halo2_experiments_amd as h
+    from halo2_experiments_amd import _lib
+    from halo2_experiments_amd.arithmetic import FQ_ONE_MONT, G1_GENERATOR, _ptr, _stream_ptr
+    dot = np.zeros(4, dtype=np.uint64)
+    _lib.check(_lib.load().hm_fr_dot_bn256_dev(ctypes.c_void_p(scalars.data_ptr()), ctypes.c_void_p(t.data_ptr()), scalars.shape[0],
+                                                _ptr(dot), ctypes.c_void_p(_stream_ptr(scalars))))
+    pt = h.g1_fixed_base_mul(torch.from_numpy(dot.view(np.int64).reshape(1, 4)).to(device), G1_GENERATOR).cpu().numpy().view(np.uint64)[0]
+    out = np.zeros(12, dtype=np.uint64)
+    if pt.any():
+        out[:8] = pt
+        out[8:] = FQ_ONE_MONT
+    return out
+
+
+PMC_TRAFFIC_FILE = "profiles/r02_pmc_traffic.json"      # falls back to round 1's file; the line names which one it used
+SQ_COUNTER_FILE = "profiles/r01_e_sq_counters.txt"        # K3 / NTT instruction counts (kernels unchanged since)
+
+
 def pmc_traffic(kernel, corrected):
     """HBM bytes per launch from the committed rocprofv3 --pmc summary (tools/pmc_traffic.sh, separate
-    FETCH_SIZE / WRITE_SIZE passes of this same command).  `corrected` applies the gfx950 x2 on
-    FETCH_SIZE, which MI355X_MICROARCH.md calibrates for wide coalesced streams only (true for the NTT
-    passes, checked: 2 x 258 MiB + 512 MiB = one read + one write of the array); the MSM accumulation
-    kernel reads by 64-byte gathers, an uncalibrated shape, so its raw counter sum is reported."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    FETCH_SIZE / WRITE_SIZE passes of this same command).  NOT measured in this run: the bench line names
+    the profiles/ file the figure comes from.  `corrected` applies the gfx950 x2 on FETCH_SIZE (calibrated for
+    wide coalesced streams and, this round, for 64-byte gathers: tools/ubench/gather64.hip)."""
+    path = os.path.join(ROOT, PMC_TRAFFIC_FILE)
+    if not os.path.exists(path):
+        path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
     try:
         with open(path) as f:
             d = json.load(f)[kernel]
@@ -103,7 +163,8 @@ def valu_issue(wave_instructions: float, kernel_ms: float) -> dict:
     achieved = wave_instructions / (kernel_ms * 1e-3)
     return {"achieved": achieved, "peak": VALU_PEAK_WAVE_INST_PER_S, "unit": "wave-instr/s",
             "frac": achieved / VALU_PEAK_WAVE_INST_PER_S,
-            "note": "instruction counts from SQ_INSTS_VALU (profiles/r01_e_sq_counters.txt); peak = 1024 SIMDs x 2.4 GHz / 4"}
+            "note": f"NOT measured in this run: instruction counts per unit are SQ_INSTS_VALU figures from {SQ_COUNTER_FILE} "
+                    "(same kernel source); peak = 1024 SIMDs x 2.4 GHz / 4"}
 
 
 def main():
@@ -119,6 +180,7 @@ def main():
     ap.add_argument("--replay", default="poseidon_k11,merkle_v3_k17,merkle_sum_tree_k18",
                     help="comma-separated create_proof MSM/NTT traces to replay after the timed MSM steps ('none' to skip)")
     ap.add_argument("--no-extras", action="store_true", help="skip the prover-like and host-pointer MSM side measurements")
+    ap.add_argument("--no-2-26", action="store_true", help="skip the 2^26-point one-GPU side measurement")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -152,13 +214,13 @@ def main():
     lo, hi = shard_range(n_global, rank, world)
     assert hi - lo == n_local
 
-    # ---- synthetic inputs, resident in HBM before the timed region -----------------------------
+    # ---- synthetic inputs, resident in HBM before the timed region -----------------
     gen = np.array(fq_mont_words(1) + fq_mont_words(2), dtype=np.uint64)        # G = (1, 2)
-    ks = rand_fr(n_local, 0x48324D49 + rank, device)                            # bases P_i = [k_i] G
-    bases = h.g1_fixed_base_mul(ks, gen)
+    scalars, bases, t_local = bench_inputs(n_local, lo, BENCH_SEED, device)     # this rank's index range of the global arrays
     handle = h.register_bases(bases)                                            # device-resident SRS slice
-    del ks, bases
-    scalars = rand_fr(n_local, 0x33353558 + rank, device)                       # uniform in [0, r)
+    del bases
+    expected_local = known_answer(scalars, t_local, device)                     # [sum_i s_i (a + i b)]G over this rank's range
+    del t_local
     torch.cuda.synchronize()
 
     def step():
@@ -166,13 +228,26 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    # known answer, once, outside the timed loop: this rank's partial, and the folded global result
+    local_result = h.best_multiexp(scalars, handle)
+    answer_ok = bool(np.array_equal(local_result, expected_local))
+    if world > 1:
+        from halo2_experiments_amd.sharding import g1_sum
+        mine = torch.from_numpy(expected_local.view(np.int64).copy()).to(comm_device)
+        gathered = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine)
+        expected_global = g1_sum(torch.stack(gathered).cpu().numpy().view(np.uint64))
+    else:
+        expected_global = expected_local
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    acc_ms, sort_ms, tot_ms = [], [], []
+    acc_ms, sort_ms, tot_ms, step_ms = [], [], [], []
     t0 = time.perf_counter()
     for _ in range(args.steps):
+        ts = time.perf_counter()
         result = step()
+        step_ms.append((time.perf_counter() - ts) * 1e3)          # a step returns its result to the host: it is synchronous
         st = h.msm_stats()
         acc_ms.append(st["accumulate_kernel_ms"])
         sort_ms.append(st["sort_ms"])
@@ -186,6 +261,9 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     st = h.msm_stats()
+    answer_ok = answer_ok and bool(np.array_equal(result, expected_global))     # the timed steps' own result
+    if not answer_ok:
+        raise SystemExit("bench.py: the MSM result does not match the known answer [sum s_i (a + i b)]G")
 
     # ---- NTT (single GPU by design: "replicas only") -------------------------------------------
     ntt = None
@@ -231,6 +309,7 @@ def main():
                                                ctypes.c_void_p(_stream_ptr(pl))))
         uni = u >= 0.95
         pl[uni] = scalars[uni]
+        del uni
         h.best_multiexp(pl, handle)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
@@ -239,9 +318,9 @@ def main():
         dt = (time.perf_counter() - t1) / 3
         extras["msm_prover_like"] = {"points_per_s": n_local / dt, "ms": dt * 1e3, "pairs": h.msm_stats()["pairs"],
                                      "scalars": "90 % zero, 5 % < 2^16, 5 % uniform"}
-        del pl, u, uni
+        del pl, u
         # fixed-base mode: precomputed 2^(c*j) * P_i table (12x the base memory), one shared bucket set
-        bases2 = h.g1_fixed_base_mul(rand_fr(n_local, 0x48324D49 + rank, device), gen)
+        _, bases2, _ = bench_inputs(n_local, lo, BENCH_SEED, device)
         t1 = time.perf_counter()
         hp = h.register_bases(bases2, precompute=True)
         torch.cuda.synchronize()
@@ -289,11 +368,37 @@ def main():
         extras["msm_host_pointer"] = {"ms": (time.perf_counter() - t1) * 1e3,
                                       "note": "hm_msm_bn256_g1_h: scalars cross PCIe in the call (pageable host memory); never `value`"}
         del hs
+        if args.log_points == 24 and not args.no_2_26:
+            # BASELINE configs[4] names a 2^26 MSM: on ONE GPU as a side measurement (4 GiB bases, 2 GiB scalars)
+            h.release_bases(handle)
+            handle = None
+            torch.cuda.empty_cache()
+            n26 = 1 << 26
+            s26, b26, t26 = bench_inputs(n26, 0, BENCH_SEED + 26, device)
+            h26 = h.register_bases(b26)
+            del b26
+            exp26 = known_answer(s26, t26, device)
+            del t26
+            r26 = h.best_multiexp(s26, h26)
+            times = []
+            for _ in range(3):
+                t1 = time.perf_counter()
+                h.best_multiexp(s26, h26)
+                times.append(time.perf_counter() - t1)
+            st26 = h.msm_stats()
+            dt = float(np.median(times))
+            extras["msm_2_26_one_gpu"] = {"points_per_s": n26 / dt, "ms": dt * 1e3, "accumulate_kernel_ms": st26["accumulate_kernel_ms"],
+                                          "window_bits": st26["window_bits"], "windows": st26["windows"],
+                                          "known_answer_ok": bool(np.array_equal(r26, exp26))}
+            h.release_bases(h26)
+            del s26
+            torch.cuda.empty_cache()
 
     replay = None
     if args.replay != "none":
         from halo2_experiments_amd.replay import run_replay
-        h.release_bases(handle)
+        if handle is not None:
+            h.release_bases(handle)
         del scalars
         torch.cuda.empty_cache()
         replay = [run_replay(name, device=device) for name in args.replay.split(",")]   # every rank takes part
@@ -303,7 +408,7 @@ def main():
         cpu = cpu_baseline(args.cpu_log_sample, device)
 
     if rank == 0:
-        acc = float(np.mean(acc_ms))
+        acc = float(np.median(acc_ms))
         achieved = MSM_BYTES_PER_POINT * n_local / (acc * 1e-3) / 1e9
         line = {
             "metric": "BN256 G1 MSM throughput",
@@ -313,6 +418,7 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step_median": float(np.median(step_ms)),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -321,19 +427,20 @@ def main():
             "config": {"workload": f"standalone BN256 G1 MSM, 2^{args.log_points} points per GPU "
                                    f"(global 2^{args.log_points} x {world}; BASELINE configs[4] microbench, north-star headline size)",
                        "points_per_gpu": n_local, "global_points": n_global,
-                       "scalars": "uniform in [0, r), torch Philox per rank", "bases": "[k_i]G, k_i uniform, device-resident",
+                       "scalars": "uniform in [0, r), xoshiro256** per element, seed 0x48324d4933353558 (SURVEY.md §8d)",
+                       "bases": "P_i = [a + i b]G, device-resident; result checked against [sum s_i (a + i b)]G outside the timed loop",
                        "window_bits": st["window_bits"], "windows": st["windows"], "parallelism": f"index-range shards x{world}, "
                        "all-gather of 96 B partials (RCCL) + host fold"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": (pmc_traffic("hm::msm_accumulate_kernel", False) if args.log_points == 24 else None),
-                         "traffic_note": "raw FETCH_SIZE+WRITE_SIZE (64-byte gathers: gfx950 x2 read correction not calibrated for this "
-                                         "shape); every base is gathered once per window (W = 15), inherent to bucketed Pippenger",
+                         "traffic_note": f"NOT measured in this run: rocprofv3 --pmc figure from {PMC_TRAFFIC_FILE} (same kernel source); "
+                                         "every base is gathered once per window (W = 15), inherent to bucketed Pippenger",
                          "kernel": "msm_accumulate_kernel", "kernel_ms": acc,
                          "note": "integer-VALU bound (SURVEY.md §8d): ~2.5e8 mixed additions x ~2.35e3 32-bit ops per launch",
                          "valu_issue": valu_issue(st["pairs"] / 64.0 * K3_VALU_INST_PER_ADDITION, acc)},
-            "msm_phase_ms": {"sort": float(np.mean(sort_ms)), "accumulate_kernel": acc, "device_total": float(np.mean(tot_ms))},
-            "result_is_identity": bool(not result[8:].any()),
+            "msm_phase_ms": {"sort": float(np.median(sort_ms)), "accumulate_kernel": acc, "device_total": float(np.median(tot_ms))},
+            "known_answer_ok": answer_ok,
         }
         if ntt is not None:
             line["ntt"] = ntt

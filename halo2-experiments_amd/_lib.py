@@ -75,6 +75,9 @@ _SIGNATURES = {
     "hm_ifft_bn256_fr_dev": (ctypes.c_int, [_vp, _u64p, ctypes.c_uint32, _u64p, _vp]),
     "hm_coset_ntt_bn256_fr_dev": (ctypes.c_int, [_vp, _u64p, ctypes.c_uint32, _u64p, _vp]),
     "hm_fr_powers_dev": (ctypes.c_int, [_vp, ctypes.c_size_t, _u64p, _vp]),
+    "hm_fr_random_dev": (ctypes.c_int, [_vp, ctypes.c_size_t, ctypes.c_uint64, _vp]),
+    "hm_fr_affine_sequence_dev": (ctypes.c_int, [_vp, ctypes.c_size_t, _u64p, _u64p, _vp]),
+    "hm_fr_dot_bn256_dev": (ctypes.c_int, [_vp, _vp, ctypes.c_size_t, _u64p, _vp]),
     "hm_fr_scale_dev": (ctypes.c_int, [_vp, ctypes.c_size_t, _u64p, _vp]),
     "hm_fr_distribute_powers_dev": (ctypes.c_int, [_vp, ctypes.c_size_t, _u64p, _vp]),
     "hm_g1_fixed_base_mul_dev": (ctypes.c_int, [_vp, ctypes.c_size_t, _u64p, _vp, _vp]),

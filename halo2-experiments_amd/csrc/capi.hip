@@ -661,6 +661,28 @@ int hm_fr_powers_dev(void* d_out, size_t n, const uint64_t x[4], void* stream) {
   return fr_powers_run((uint32_t*)d_out, n, x, (hipStream_t)stream);
 }
 
+int hm_fr_dot_bn256_dev(const void* d_a, const void* d_b, size_t n, uint64_t out[4], void* stream) {
+  if (!out || (n && (!d_a || !d_b))) return hm_fail(HM_ERR_BAD_ARG, "hm_fr_dot_bn256_dev: null argument");
+  DeviceCtx* ctx = ctx_for_current_device();
+  if (!ctx) return HM_ERR_NO_DEVICE;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  return fr_dot_run(*ctx, (const uint32_t*)d_a, (const uint32_t*)d_b, n, out, (hipStream_t)stream);
+}
+
+int hm_fr_affine_sequence_dev(void* d_out, size_t n, const uint64_t a[4], const uint64_t b[4], void* stream) {
+  if ((n && !d_out) || !a || !b) return hm_fail(HM_ERR_BAD_ARG, "hm_fr_affine_sequence_dev: null argument");
+  DeviceCtx* ctx = ctx_for_current_device();
+  if (!ctx) return HM_ERR_NO_DEVICE;
+  return fr_affine_sequence_run((uint32_t*)d_out, n, a, b, (hipStream_t)stream);
+}
+
+int hm_fr_random_dev(void* d_out, size_t n, uint64_t seed, void* stream) {
+  if (n && !d_out) return hm_fail(HM_ERR_BAD_ARG, "hm_fr_random_dev: null argument");
+  DeviceCtx* ctx = ctx_for_current_device();
+  if (!ctx) return HM_ERR_NO_DEVICE;
+  return fr_random_run((uint32_t*)d_out, n, seed, (hipStream_t)stream);
+}
+
 int hm_fr_scale_dev(void* d_a, size_t n, const uint64_t c[4], void* stream) {
   if ((n && !d_a) || !c) return hm_fail(HM_ERR_BAD_ARG, "hm_fr_scale_dev: null argument");
   DeviceCtx* ctx = ctx_for_current_device();

@@ -177,6 +177,9 @@ void ntt_tables_release(NttTables& t);
 
 // poly.hip
 int fr_powers_run(uint32_t* d_out, uint64_t n, const uint64_t x_ext[4], hipStream_t stream);
+int fr_dot_run(DeviceCtx& ctx, const uint32_t* d_a, const uint32_t* d_b, uint64_t n, uint64_t out_ext[4], hipStream_t stream);
+int fr_affine_sequence_run(uint32_t* d_out, uint64_t n, const uint64_t a_ext[4], const uint64_t b_ext[4], hipStream_t stream);
+int fr_random_run(uint32_t* d_out, uint64_t n, uint64_t seed, hipStream_t stream);
 int fr_eval_polynomial_run(DeviceCtx& ctx, const uint32_t* d_polys, uint64_t n, const uint32_t* poly_index, const uint64_t* points_ext,
                            size_t q, uint64_t* out_ext, hipStream_t stream);
 

@@ -175,6 +175,16 @@ int hm_eval_polynomial_bn256_fr_dev(const void* d_polys, size_t n, const uint32_
  * fixed-base multiples are g, and whose scaled inverse NTT gives the Lagrange-basis scalars of g_lagrange. */
 int hm_fr_powers_dev(void* d_out, size_t n, const uint64_t x[4], void* stream);
 
+/* Inputs and known answer of the benchmark of SURVEY.md §8d, without leaving the device:
+ *   hm_fr_random_dev           out[i] uniform in [0, r) (Fr::random): one xoshiro256** stream per element, seeded by
+ *                              splitmix64 from (seed, i), 254-bit candidates rejected until below r
+ *   hm_fr_affine_sequence_dev  out[i] = a + i * b -- the scalars t_i of the bases P_i = [a + i b]G
+ *   hm_fr_dot_bn256_dev        out = sum_i a[i] * b[i] (host, 4 u64; synchronises `stream`) -- sum_i s_i t_i, whose
+ *                              multiple of G is the MSM's expected result */
+int hm_fr_random_dev(void* d_out, size_t n, uint64_t seed, void* stream);
+int hm_fr_affine_sequence_dev(void* d_out, size_t n, const uint64_t a[4], const uint64_t b[4], void* stream);
+int hm_fr_dot_bn256_dev(const void* d_a, const void* d_b, size_t n, uint64_t out[4], void* stream);
+
 /* a[i] *= c element-wise (device pointer, in place). */
 int hm_fr_scale_dev(void* d_a, size_t n, const uint64_t c[4], void* stream);
 /* EvaluationDomain::distribute_powers_zeta on its own: a[i] *= c3[i % 3] (device pointer, in place). */

@@ -70,3 +70,39 @@ def test_power_ladder(cref, pyref):
         _lib.check(lib.hm_fr_powers_dev(ctypes.c_void_p(out.data_ptr()), n, _ptr(fr_words(s)), ctypes.c_void_p(_stream_ptr(out))))
         torch.cuda.synchronize()
         assert np.array_equal(out.cpu().numpy().view(np.uint64), cref.fr_powers(fr_words(s), n)), n
+
+
+def test_benchmark_input_kernels(cref, pyref):
+    """hm_fr_random_dev / hm_fr_affine_sequence_dev / hm_fr_dot_bn256_dev: the inputs and the known answer of
+    bench.py against the oracle's field arithmetic."""
+    import torch
+    o = pyref
+    lib = _lib.load()
+    R = o.R
+    for n in (1, 77, 4096, (1 << 16) + 9):
+        sc = torch.empty((n, 4), dtype=torch.int64, device="cuda")
+        _lib.check(lib.hm_fr_random_dev(ctypes.c_void_p(sc.data_ptr()), n, 0x48324D4933353558, ctypes.c_void_p(_stream_ptr(sc))))
+        a, b = 0x1122334455667788_99AABBCCDDEEFF00 % R, (R - 12345)
+        seq = torch.empty((n, 4), dtype=torch.int64, device="cuda")
+        _lib.check(lib.hm_fr_affine_sequence_dev(ctypes.c_void_p(seq.data_ptr()), n, _ptr(fr_words(a)), _ptr(fr_words(b)),
+                                                  ctypes.c_void_p(_stream_ptr(seq))))
+        torch.cuda.synchronize()
+        sh, qh = sc.cpu().numpy().view(np.uint64), seq.cpu().numpy().view(np.uint64)
+        vals = [o.from_limbs(row) for row in sh[: min(n, 200)]]
+        assert all(v < R for v in vals) and (n < 50 or len(set(vals)) == len(vals))            # in range, no repeats
+        for i in sorted({0, min(1, n - 1), n // 2, n - 1}):
+            assert np.array_equal(qh[i], fr_words((a + i * b) % R)), (n, i)
+        out = np.zeros(4, dtype=np.uint64)
+        _lib.check(lib.hm_fr_dot_bn256_dev(ctypes.c_void_p(sc.data_ptr()), ctypes.c_void_p(seq.data_ptr()), n, _ptr(out),
+                                            ctypes.c_void_p(_stream_ptr(sc))))
+        assert np.array_equal(out, cref.fr_dot(sh, qh)), n
+    # the same seed gives the same stream; another seed another one
+    x1 = torch.empty((64, 4), dtype=torch.int64, device="cuda")
+    x2 = torch.empty((64, 4), dtype=torch.int64, device="cuda")
+    _lib.check(lib.hm_fr_random_dev(ctypes.c_void_p(x1.data_ptr()), 64, 7, None))
+    _lib.check(lib.hm_fr_random_dev(ctypes.c_void_p(x2.data_ptr()), 64, 7, None))
+    torch.cuda.synchronize()
+    assert torch.equal(x1, x2)
+    _lib.check(lib.hm_fr_random_dev(ctypes.c_void_p(x2.data_ptr()), 64, 8, None))
+    torch.cuda.synchronize()
+    assert not torch.equal(x1, x2)
