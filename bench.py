@@ -40,8 +40,8 @@ import torch.distributed as dist  # noqa: E402
 # under these kernels).  Instructions per unit are a property of the build, measured with
 # SQ_INSTS_VALU (profiles/r01_e_sq_counters.txt, tools/pmc_sq.sh): re-measure when the kernels change.
 VALU_PEAK_WAVE_INST_PER_S = 256 * 4 * 2.4e9 / 4
-K3_VALU_INST_PER_ADDITION = 8803917569 / (251656262 / 64)      # wave-instructions per 64 mixed additions
-NTT_VALU_INST_PER_ELEMENT_PASS = 336571051 / (1 << 24)           # wave-instructions per element and pass (x 64 lanes)
+K3_VALU_INST_PER_ADDITION = 8807130936 / (251658240 / 64)      # wave-instructions per 64 mixed additions (profiles/r02_a_sq_counters.txt)
+NTT_VALU_INST_PER_ELEMENT_PASS = 344894123 / (1 << 24)           # wave-instructions per element and pass (x 64 lanes)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 MSM_BYTES_PER_POINT = 96
 NTT_BYTES_PER_ELEM = 64
@@ -136,7 +136,7 @@ def known_answer(scalars, t, device):
 
 
 PMC_TRAFFIC_FILE = "profiles/r02_pmc_traffic.json"      # falls back to round 1's file; the line names which one it used
-SQ_COUNTER_FILE = "profiles/r01_e_sq_counters.txt"        # K3 / NTT instruction counts (kernels unchanged since)
+SQ_COUNTER_FILE = "profiles/r02_a_sq_counters.txt"        # K3 / NTT instruction counts per launch (tools/pmc_sq.sh)
 
 
 def pmc_traffic(kernel, corrected):
