@@ -37,7 +37,7 @@ from .arithmetic import (G1_GENERATOR, best_multiexp, best_multiexp_submit, best
                          register_bases, release_bases)
 from .domain import EvaluationDomain, FR_MODULUS, fr_words
 from .kzg import ParamsKZG
-from .sharding import shard_range, sharded_multiexp, sharded_multiexp_batch
+from .sharding import job_parallel_multiexp_batch, shard_range, sharded_multiexp, sharded_multiexp_batch
 
 # the replay's SRS trapdoor (the reference draws it from OsRng, utils.rs:28): known here, so that every
 # commitment of the replay can be checked against the KZG identity commit(f) == [f(s)]G
@@ -117,11 +117,15 @@ def run_replay(shape_name: str, device=None, group=None, include_host_pointer_es
         "intt_n": A + 1 + 3 * L + zp, "coset_ntt_ext": A + 1 + 3 * L + zp, "intt_ext": 1,
     }
 
-    # a real SRS with a known trapdoor; this rank keeps its slice of g and g_lagrange resident
-    lo, hi = shard_range(n, rank, world)
+    # Multi-GPU split: prover-sized MSMs go to the ranks as WHOLE commitments (every rank holds the
+    # full SRS; a 2^15-point index-range shard would be pure latency), and so do the transforms; index-range
+    # shards are for n >= 2^22.
+    job_mode = world > 1 and k < 22
+    # a real SRS with a known trapdoor; in index-range mode this rank keeps its slice of g and g_lagrange resident
+    lo, hi = (0, n) if job_mode else shard_range(n, rank, world)
     gen = G1_GENERATOR
-    params = ParamsKZG.setup(k, REPLAY_S, device=device, keep_points=world > 1)
-    if world > 1:
+    params = ParamsKZG.setup(k, REPLAY_S, device=device, keep_points=world > 1 and not job_mode)
+    if world > 1 and not job_mode:
         g_h = register_bases(params.g_points[lo:hi].contiguous())
         gl_h = register_bases(params.g_lagrange_points[lo:hi].contiguous())
         params.release()
@@ -159,8 +163,11 @@ def run_replay(shape_name: str, device=None, group=None, include_host_pointer_es
         """The commitments of one prover phase are independent: every rank keeps `in_flight` of its local
         MSMs in flight on as many streams (one MSM's sort / bucket reduction / host fold hides behind
         another's accumulation), then the partials of the whole phase cross xGMI in ONE all-gather."""
+        keys = [key for _, _, key in jobs]
+        if job_mode:
+            return job_parallel_multiexp_batch([(col, handle) for col, handle, _ in jobs], group=group, streams=streams), keys
         local = [((col[lo:hi].contiguous() if world > 1 else col), handle) for col, handle, _ in jobs]
-        return sharded_multiexp_batch(local, group=group, streams=streams), [key for _, _, key in jobs]
+        return sharded_multiexp_batch(local, group=group, streams=streams), keys
 
     def proof_once():
         t = {"msm": 0.0, "ntt": 0.0}
@@ -174,22 +181,26 @@ def run_replay(shape_name: str, device=None, group=None, include_host_pointer_es
         t["msm"] = time.perf_counter() - t0
         t["results"] = (r1, r2)
         t0 = time.perf_counter()
-        if rank == 0:                                   # NTT stays single-GPU (north star)
+        # each transform stays on ONE GPU (north star); in job mode the independent transforms of a phase are dealt
+        # to the ranks like the commitments, otherwise rank 0 runs them all
+        share = (lambda c: len(range(rank, c, world))) if job_mode else (lambda c: c if rank == 0 else 0)
+        if share(counts["intt_n"]) or share(counts["coset_ntt_ext"]):
             # same-size transforms of one prover phase go through one batched call (<= 8 polynomials at a
             # time here, bounding the extended-domain buffers)
-            todo = counts["intt_n"]
+            todo = share(counts["intt_n"])
             while todo > 0:
                 b = min(8, todo)
                 dom.lagrange_to_coeff(ntt_batch[:b])
                 todo -= b
             ext = None
-            todo = counts["coset_ntt_ext"]
+            todo = share(counts["coset_ntt_ext"])
             while todo > 0:
                 b = min(8, todo)
                 ext = dom.coeff_to_extended(ntt_batch[:b])
                 todo -= b
-            for _ in range(counts["intt_ext"]):
-                dom.extended_to_coeff(ext[0])
+            if rank == 0 and ext is not None:
+                for _ in range(counts["intt_ext"]):
+                    dom.extended_to_coeff(ext[0])
         torch.cuda.synchronize()
         t["ntt"] = time.perf_counter() - t0
         return t
@@ -220,6 +231,8 @@ def run_replay(shape_name: str, device=None, group=None, include_host_pointer_es
 
     out = {
         "circuit": shape.name, "k": k, "extended_k": dom.extended_k, "n_gpus": world,
+        "multi_gpu_split": "whole commitments / transforms per rank (full SRS on every GPU)" if job_mode else
+                           ("index-range shards" if world > 1 else "none"),
         "shape": {"advice": A, "lookups": L, "equality_columns": shape.equality_columns, "max_degree": d,
                   "source": shape.source},
         "calls": counts,
@@ -247,7 +260,7 @@ def run_replay(shape_name: str, device=None, group=None, include_host_pointer_es
             "total": t_msm * (counts["msm_sparse"] + counts["msm_dense"]) + t_ntt_n * counts["intt_n"]
                      + t_ntt_e * (counts["coset_ntt_ext"] + counts["intt_ext"]),
             "note": "PCIe-inclusive: every call uploads its scalars / moves its array both ways"}
-    if world > 1:
+    if world > 1 and not job_mode:
         release_bases(g_h)
         release_bases(gl_h)
     else:

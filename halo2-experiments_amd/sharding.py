@@ -1,5 +1,12 @@
 """Multi-GPU MSM: one process per GPU (torch.distributed; backend "nccl" is RCCL on ROCm).
 
+Two ways to split, chosen by size:
+  * index ranges (``sharded_multiexp`` / ``sharded_multiexp_batch``): every MSM is cut into N contiguous shards,
+    for n >= 2^22 or so -- BASELINE configs[4], the 2^24 .. 2^26 microbenchmark;
+  * whole jobs (``job_parallel_multiexp_batch``): the independent commitments of one prover phase are dealt
+    round-robin to the ranks, each rank holding the full SRS -- BASELINE configs[3] (k ~ 18), where a 2^15-point
+    shard would be pure latency.
+
 best_multiexp is a sum over i, so it shards by index range with no data-path collective: rank g
 owns coeffs/bases [lo_g, hi_g), keeps its base slice resident, and produces one partial G1.  The
 only exchange is an all-gather of those partials (12 words = 96 B per rank over xGMI), folded on
@@ -55,6 +62,7 @@ def sharded_multiexp(local_coeffs, local_bases, group=None,
 
 
 MAX_IN_FLIGHT = 8      # asynchronous MSM slots per device (csrc/hm_internal.h: HM_MSM_SLOTS - 1)
+_NO_GROUP = object()   # marker: run the local part only, even inside an initialised process group
 
 
 def sharded_multiexp_batch(jobs, group=None, streams=None, local_batch: Optional[Callable] = None) -> np.ndarray:
@@ -87,7 +95,7 @@ def sharded_multiexp_batch(jobs, group=None, streams=None, local_batch: Optional
                     pending.append((i, best_multiexp_submit(col, handle)))
             for j, t in pending:
                 partials[j] = best_multiexp_wait(t)
-    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if group is _NO_GROUP or not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
         return np.stack([g1_sum(p.reshape(1, 12)) for p in partials]) if len(partials) else partials
     world = dist.get_world_size(group)
     backend = dist.get_backend(group)
@@ -97,3 +105,41 @@ def sharded_multiexp_batch(jobs, group=None, streams=None, local_batch: Optional
     dist.all_gather(gathered, mine, group=group)
     pts = torch.stack(gathered).cpu().numpy().view(np.uint64)          # (world, jobs, 12)
     return np.stack([g1_sum(pts[:, j, :]) for j in range(len(jobs))]) if len(jobs) else partials
+
+
+def job_owner(job: int, world: int) -> int:
+    """Round-robin deal of a phase's independent jobs (commitments, transforms) to the ranks."""
+    return job % world
+
+
+def job_parallel_multiexp_batch(jobs, group=None, streams=None, local_batch: Optional[Callable] = None) -> np.ndarray:
+    """Job-level multi-GPU for prover-sized MSMs: ``jobs`` = [(coeffs, bases_handle), ...], the SAME list on every
+    rank (every rank holds the full SRS and can see every column); rank r computes the whole MSMs j with
+    j % world == r -- up to MAX_IN_FLIGHT of them in flight -- and ONE all-gather of ceil(len(jobs) / world) x 96 B
+    per rank brings every result to every rank.  Returns (len(jobs), 12) words.  A 2^18-point MSM cut into eight
+    2^15-point index-range shards is entirely latency-bound (a 2^16 MSM already takes 0.6 of the time of a 2^18
+    one); whole jobs keep each GPU at its efficient size and need no fold at all.
+    ``local_batch`` replaces the GPU part in CPU-only tests."""
+    import torch
+    import torch.distributed as dist
+
+    distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    world = dist.get_world_size(group) if distributed else 1
+    rank = dist.get_rank(group) if distributed else 0
+    mine_idx = [j for j in range(len(jobs)) if job_owner(j, world) == rank]
+    mine = sharded_multiexp_batch([jobs[j] for j in mine_idx], group=_NO_GROUP, streams=streams, local_batch=local_batch)
+    if not distributed:
+        return mine
+    per_rank = (len(jobs) + world - 1) // world
+    buf = np.zeros((per_rank, 12), dtype=np.uint64)
+    buf[: len(mine_idx)] = mine
+    backend = dist.get_backend(group)
+    dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+    t = torch.from_numpy(buf.view(np.int64).copy()).to(dev)
+    gathered = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(gathered, t, group=group)
+    allr = torch.stack(gathered).cpu().numpy().view(np.uint64)          # (world, per_rank, 12)
+    out = np.zeros((len(jobs), 12), dtype=np.uint64)
+    for j in range(len(jobs)):
+        out[j] = allr[job_owner(j, world), j // world]
+    return out

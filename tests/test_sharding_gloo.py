@@ -44,6 +44,20 @@ def _worker(rank, world, port, q):
     outs = sharded_multiexp_batch(jobs, local_batch=lambda js: [cpu_ref.best_multiexp(c, p, 1) for c, p in js])
     for name, out in zip(names, outs):
         results["batch_" + name] = out
+    # job-level split (prover-sized MSMs): whole commitments dealt round-robin, one all-gather of results
+    from halo2_experiments_amd.sharding import job_parallel_multiexp_batch
+    jnames = ("n255_uniform", "pmone", "n33_edge", "n1_uniform", "n1024_uniform")
+    calls = []
+
+    def local(js):
+        calls.append(len(js))
+        return [cpu_ref.best_multiexp(c, p, 1) for c, p in js]
+
+    outs = job_parallel_multiexp_batch([(g[f"{nm}_s"], g[f"{nm}_b"]) for nm in jnames], local_batch=local)
+    assert calls == [3 if rank == 0 else 2]                       # jobs 0, 2, 4 on rank 0; 1, 3 on rank 1
+    for nm, out in zip(jnames, outs):
+        results["jobs_" + nm] = out
+    assert job_parallel_multiexp_batch([], local_batch=local).shape == (0, 12)
     dist.barrier()
     dist.destroy_process_group()
     q.put((rank, results))
@@ -63,7 +77,7 @@ def test_world_size_2_gloo(cref):
     g = np.load(os.path.join(ROOT, "tests", "golden", "msm.npz"))
     for rank, results in got:
         for name, out in results.items():
-            exp = g[f"{name.replace('batch_', '')}_r"]
+            exp = g[f"{name.replace('batch_', '').replace('jobs_', '')}_r"]
             if exp.any():
                 assert np.array_equal(out[:8], exp), (rank, name)
             else:
