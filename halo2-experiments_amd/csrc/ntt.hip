@@ -178,15 +178,17 @@ __device__ __forceinline__ void ntt_round(uint32_t* lds, const NttTileCtx& cx, u
 
 // One digit pass.  in/out: n x 8 u32 (external words).  stage_tw: omega_R^j, j < R/2.
 // tw_lo/tw_hi: omega_n^j (j < 2^log_lb) and omega_n^(j << log_lb).
-template <int LOG_TILE>
+// FUSED = false: the plain best_fft pass (no constants multiplied in): kept as its own instantiation so that the
+// fused forms' extra state costs it nothing (registers, the constants' LDS copy and barrier).
+template <int LOG_TILE, bool FUSED>
 __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(const uint32_t* in, uint32_t* out,
                                                                NttPassParams pp, const uint32_t* __restrict__ stage_tw,
                                                                const uint32_t* __restrict__ tw_lo,
                                                                const uint32_t* __restrict__ tw_hi) {
   extern __shared__ uint32_t lds[];
-  __shared__ uint32_t s_const[54];   // [0, 27): coset pattern, [27, 54): final constants (indexed per element)
+  __shared__ uint32_t s_const[FUSED ? 54 : 1];   // [0, 27): coset pattern, [27, 54): final constants (indexed per element)
   const uint32_t tid = threadIdx.x;
-  if (pp.has_coset | pp.fin_mode) {
+  if (FUSED && (pp.has_coset | pp.fin_mode)) {
     if (tid == 0) {
 #pragma unroll
       for (int i = 0; i < 27; ++i) {
@@ -248,7 +250,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(const uint32_t* i
     const uint4 lo = src[0], hi = src[1];
     const uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
     Fr x = fe_unpack<FrParams>(w);
-    if (pp.has_coset) {
+    if (FUSED && pp.has_coset) {
       Fr cz;
       const uint32_t* cp = s_const + (uint32_t)(g % 3) * 9;
 #pragma unroll
@@ -259,7 +261,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(const uint32_t* i
     if (pp.log_z == 0) {
       lds_store<LOG_TILE>(lds, (bitrev(d, s) << log_c) + c, x);
     } else {
-      if (!pp.has_coset) x = fe_reduce_small(x);              // raw 256-bit words: bring below 3r like a product
+      if (!(FUSED && pp.has_coset)) x = fe_reduce_small(x);   // raw 256-bit words: bring below 3r like a product
       const uint32_t p0 = bitrev(d, s);                        // low log_z bits are zero
       for (uint32_t t = 0; t < (1u << pp.log_z); ++t) lds_store<LOG_TILE>(lds, ((p0 + t) << log_c) + c, x);
     }
@@ -311,7 +313,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(const uint32_t* i
       const uint64_t g = (dest_lo0 + c) + ((uint64_t)k << pp.log_rows);
       // with a fused constant the product reduces; without one the cheap quotient-estimate reduction does
       Fr y;
-      if (pp.fin_mode) {
+      if (FUSED && pp.fin_mode) {
         Fr fin;
         const uint32_t* fp = s_const + 27 + (pp.fin_mode == 2 ? (uint32_t)(g % 3) * 9 : 0u);
 #pragma unroll
@@ -535,7 +537,9 @@ int ntt_run(DeviceCtx& ctx, uint32_t* d_a, const uint64_t omega_ext[4], uint32_t
   }
   const size_t lds_bytes = (size_t)9 * sizeof(uint32_t) << LOG_TILE;
   if (!ctx.ntt_attr_set) {   // per device: a process may drive several GPUs
-    HM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ntt_pass_kernel<LOG_TILE>),
+    HM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ntt_pass_kernel<LOG_TILE, false>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    HM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ntt_pass_kernel<LOG_TILE, true>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     ctx.ntt_attr_set = true;
   }
@@ -589,8 +593,13 @@ int ntt_run(DeviceCtx& ctx, uint32_t* d_a, const uint64_t omega_ext[4], uint32_t
         lo_tab = tab->d_mid;
       }
     }
-    hipLaunchKernelGGL(ntt_pass_kernel<LOG_TILE>, dim3((uint32_t)tiles, batch), dim3(NTT_THREADS), lds_bytes, stream, src, dst, pp,
-                       (const uint32_t*)tab->d_stage[pp.s], lo_tab, (const uint32_t*)tab->d_hi);
+    if (pp.has_coset | pp.fin_mode) {
+      hipLaunchKernelGGL((ntt_pass_kernel<LOG_TILE, true>), dim3((uint32_t)tiles, batch), dim3(NTT_THREADS), lds_bytes, stream, src, dst,
+                         pp, (const uint32_t*)tab->d_stage[pp.s], lo_tab, (const uint32_t*)tab->d_hi);
+    } else {
+      hipLaunchKernelGGL((ntt_pass_kernel<LOG_TILE, false>), dim3((uint32_t)tiles, batch), dim3(NTT_THREADS), lds_bytes, stream, src, dst,
+                         pp, (const uint32_t*)tab->d_stage[pp.s], lo_tab, (const uint32_t*)tab->d_hi);
+    }
     HM_HIP_CHECK(hipGetLastError());
   }
   if (slot) return aux_release(ctx, slot, stream);
