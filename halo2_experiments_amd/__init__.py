@@ -1,7 +1,21 @@
-"""Import alias: the package directory is named ``halo2-experiments_amd`` (not a valid Python
-identifier), so this shim makes it importable as ``halo2_experiments_amd``."""
+"""MI355X-native backend for the BN256 MSM / Fr-NTT hot path of the PSE halo2 prover.
+
+Host-side mirror of ``halo2_proofs::arithmetic`` (``best_multiexp``, ``best_fft``, ``eval_polynomial``) and of the
+``EvaluationDomain`` / ``ParamsKZG`` steps around them, over the C ABI of ``libhalo2_mi355x.so``.
+
+The sources live in ``halo2-experiments_amd/`` (the directory name the project layout prescribes; not a valid
+Python identifier): this package is the importable name, and its ``__path__`` points there, so every submodule
+(``_lib``, ``arithmetic``, ``domain``, ``kzg``, ``replay``, ``sharding``) is an ordinary module of this package
+with an ordinary ``__spec__`` / ``__file__``.
+"""
 import os as _os
 
-__path__ = [_os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "halo2-experiments_amd")]
-with open(_os.path.join(__path__[0], "__init__.py")) as _f:
-    exec(compile(_f.read(), _os.path.join(__path__[0], "__init__.py"), "exec"))
+__path__.append(_os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "halo2-experiments_amd"))
+
+from . import _lib  # noqa: F401
+from .arithmetic import (best_fft, best_multiexp, best_multiexp_submit, best_multiexp_wait, eval_polynomial,  # noqa: F401
+                         g1_fixed_base_mul, msm_stats, register_bases, release_bases)
+from .domain import EvaluationDomain  # noqa: F401
+
+__all__ = ["eval_polynomial", "best_multiexp", "best_multiexp_submit", "best_multiexp_wait", "best_fft", "register_bases", "release_bases", "g1_fixed_base_mul", "msm_stats",
+           "EvaluationDomain"]
