@@ -74,6 +74,11 @@ _SIGNATURES = {
     "hm_ntt_batch_bn256_fr_dev": (ctypes.c_int, [_vp, ctypes.c_size_t, _u64p, ctypes.c_uint32, _u64p, _u64p, _vp]),
     "hm_ifft_bn256_fr_dev": (ctypes.c_int, [_vp, _u64p, ctypes.c_uint32, _u64p, _vp]),
     "hm_coset_ntt_bn256_fr_dev": (ctypes.c_int, [_vp, _u64p, ctypes.c_uint32, _u64p, _vp]),
+    "hm_graph_create": (ctypes.c_int, [ctypes.POINTER(ctypes.c_uint32), ctypes.c_size_t, _u64p, ctypes.c_size_t, ctypes.c_size_t,
+                                       ctypes.POINTER(ctypes.c_int32), ctypes.c_size_t, ctypes.c_size_t, ctypes.c_uint32, _u64p]),
+    "hm_graph_evaluate_dev": (ctypes.c_int, [ctypes.c_uint64, ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t, _u64p, ctypes.c_size_t,
+                                             ctypes.c_uint32, _vp, _vp]),
+    "hm_graph_destroy": (ctypes.c_int, [ctypes.c_uint64]),
     "hm_fr_powers_dev": (ctypes.c_int, [_vp, ctypes.c_size_t, _u64p, _vp]),
     "hm_fr_random_dev": (ctypes.c_int, [_vp, ctypes.c_size_t, ctypes.c_uint64, _vp]),
     "hm_fr_affine_sequence_dev": (ctypes.c_int, [_vp, ctypes.c_size_t, _u64p, _u64p, _vp]),

@@ -186,6 +186,8 @@ int hm_shutdown(void) {
     if (f.d_inf) (void)hipFree(f.d_inf);
   }
   c.free_bases.clear();
+  for (auto& g : c.graphs) graph_release(*g);
+  c.graphs.clear();
   c.io.release(); c.io_bases.release(); c.conv_bases.release(); c.conv_inf.release();
   for (auto& a : c.aux) {
     a.scratch.release();
@@ -659,6 +661,43 @@ int hm_fr_powers_dev(void* d_out, size_t n, const uint64_t x[4], void* stream) {
   DeviceCtx* ctx = ctx_for_current_device();
   if (!ctx) return HM_ERR_NO_DEVICE;
   return fr_powers_run((uint32_t*)d_out, n, x, (hipStream_t)stream);
+}
+
+int hm_graph_create(const uint32_t* calcs, size_t n_calc, const uint64_t* constants, size_t n_const, size_t n_dynamic,
+                    const int32_t* rotations, size_t n_rot, size_t n_columns, uint32_t n_intermediates, uint64_t* out_handle) {
+  if (!out_handle || (n_calc && !calcs) || (n_const && !constants) || (n_rot && !rotations))
+    return hm_fail(HM_ERR_BAD_ARG, "hm_graph_create: null argument");
+  DeviceCtx* ctx = ctx_for_current_device();
+  if (!ctx) return HM_ERR_NO_DEVICE;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  return graph_create(*ctx, calcs, n_calc, constants, n_const, n_dynamic, rotations, n_rot, n_columns, n_intermediates, out_handle);
+}
+
+int hm_graph_evaluate_dev(uint64_t handle, const void* const* d_columns, size_t n_columns, const uint64_t* dynamic_constants,
+                          size_t n_dynamic, uint32_t log_size, void* d_values, void* stream) {
+  if (!d_values || (n_columns && !d_columns) || (n_dynamic && !dynamic_constants))
+    return hm_fail(HM_ERR_BAD_ARG, "hm_graph_evaluate_dev: null argument");
+  DeviceCtx* ctx = ctx_for_current_device();
+  if (!ctx) return HM_ERR_NO_DEVICE;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  for (auto& g : ctx->graphs)
+    if (g->handle == handle)
+      return graph_evaluate(*ctx, *g, d_columns, n_columns, dynamic_constants, n_dynamic, log_size, d_values, (hipStream_t)stream);
+  return hm_fail(HM_ERR_NOT_FOUND, "hm_graph_evaluate_dev: unknown program handle");
+}
+
+int hm_graph_destroy(uint64_t handle) {
+  DeviceCtx* ctx = ctx_for_current_device();
+  if (!ctx) return HM_ERR_NO_DEVICE;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  for (size_t i = 0; i < ctx->graphs.size(); ++i)
+    if (ctx->graphs[i]->handle == handle) {
+      (void)hipDeviceSynchronize();          // a launch may still read the program (rare call: once per circuit)
+      graph_release(*ctx->graphs[i]);
+      ctx->graphs.erase(ctx->graphs.begin() + i);
+      return HM_OK;
+    }
+  return hm_fail(HM_ERR_NOT_FOUND, "hm_graph_destroy: unknown program handle");
 }
 
 int hm_fr_dot_bn256_dev(const void* d_a, const void* d_b, size_t n, uint64_t out[4], void* stream) {

@@ -1,0 +1,281 @@
+// graph.hip -- evaluate_h's gate arithmetic on the device (second half): the GraphEvaluator of
+// halo2_proofs::plonk::evaluation (the crate pinned at /root/reference/Cargo.toml:10; reached from create_proof,
+// /root/reference/src/circuits/utils.rs:40-48).  Upstream flattens every gate / lookup expression of a circuit
+// into a straight-line program over "value sources" and runs it once per row of the extended domain on the CPU:
+//
+//     ValueSource   Constant(i) | Intermediate(i) | Fixed(col, rot) | Advice(col, rot) | Instance(col, rot)
+//                   | Challenge(i) | Beta | Gamma | Theta | Y | PreviousValue
+//     Calculation   Add | Sub | Mul | Square | Double | Negate | Horner(start, parts, factor) | Store
+//     row index of a rotated query: (idx + rot * 2^(extended_k - k)) mod 2^extended_k
+//
+// Here: one lane per row, all columns resident in HBM (extended-domain arrays, external Montgomery words), the
+// program interpreted instruction by instruction with wave-uniform decode.  Fixed / Advice / Instance are one
+// column table; challenges, beta, gamma, theta, y are constants of the call (the mirror in evaluation.py maps
+// them); Horner is lowered to MulAdd steps.  Intermediates live in a scratch array laid out [slot][word][lane] so
+// that every access is coalesced; the host first maps the program's intermediates to slots by liveness (upstream
+// gives every calculation a fresh index; only a few dozen are live at once), so the scratch stays L2-sized.
+// Values are kept in ff29's internal form (< 3r, normalised limbs); a column word is converted on load.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <map>
+
+#include "g1.h"
+#include "hm_internal.h"
+#include "host_fr.h"
+
+namespace hm {
+
+constexpr int GE_THREADS = 256;
+
+enum GraphOp : uint32_t { GOP_ADD = 0, GOP_SUB = 1, GOP_MUL = 2, GOP_SQUARE = 3, GOP_DOUBLE = 4, GOP_NEGATE = 5, GOP_STORE = 6, GOP_MULADD = 7 };
+enum GraphSrc : uint32_t { GSRC_CONST = 0, GSRC_INTER = 1, GSRC_COLUMN = 2, GSRC_PREV = 3 };
+// a source is one word: kind (bits 30..31) | rotation index (bits 20..29) | index (bits 0..19)
+__host__ __device__ inline uint32_t gsrc_kind(uint32_t s) { return s >> 30; }
+__host__ __device__ inline uint32_t gsrc_rot(uint32_t s) { return (s >> 20) & 1023u; }
+__host__ __device__ inline uint32_t gsrc_index(uint32_t s) { return s & 0xfffffu; }
+
+struct GraphCalc {      // device form: 5 words
+  uint32_t op, a, b, c, target;
+};
+
+__device__ __forceinline__ Fr ge_reduce(const Fr& lazy) { return fe_reduce_small(fe_norm(lazy)); }   // any lazy sum < 2^261 -> < 3r
+
+__device__ __forceinline__ Fr ge_from_ext(const uint32_t* __restrict__ p) {
+  const uint4* q = reinterpret_cast<const uint4*>(p);
+  const uint4 lo = q[0], hi = q[1];
+  const uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+  return fe_mul(fe_unpack<FrParams>(w), fe_const<FrParams>(FrParams::EXT2INT));
+}
+
+constexpr uint32_t GE_MAX_COLUMNS = 384;
+constexpr uint32_t GE_MAX_DYN = 16;
+struct GraphColumns {        // the call's column table and per-call constants, by value (captured at launch)
+  const uint32_t* p[GE_MAX_COLUMNS];
+  uint32_t dyn[GE_MAX_DYN * 9];   // challenges, beta, gamma, theta, y ... of THIS proof, internal form
+  uint32_t n_static;              // constants [0, n_static) come from the program, [n_static, ..) from dyn
+};
+
+__device__ __forceinline__ Fr ge_fetch(uint32_t src, const GraphColumns& columns, const uint32_t* __restrict__ consts,
+                                       const int32_t* __restrict__ rotations, const uint32_t* __restrict__ scratch, uint32_t T,
+                                       uint32_t lane_slot, uint64_t idx, uint64_t mask, const uint32_t* __restrict__ prev) {
+  const uint32_t kind = gsrc_kind(src), index = gsrc_index(src);
+  Fr r;
+  if (kind == GSRC_INTER) {
+    const uint32_t* p = scratch + (size_t)index * 9 * T + lane_slot;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) r.l[i] = p[(size_t)i * T];
+    HM_DECLARE(r, 3.0);
+  } else if (kind == GSRC_CONST) {
+    if (index >= columns.n_static) {
+      const uint32_t d = (index - columns.n_static) * 9;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) r.l[i] = columns.dyn[d + i];
+    } else {
+      const uint32_t* p = consts + (size_t)index * 9;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) r.l[i] = p[i];
+    }
+    HM_DECLARE(r, 1.0);
+  } else if (kind == GSRC_COLUMN) {
+    const uint64_t row = (idx + (uint64_t)(int64_t)rotations[gsrc_rot(src)]) & mask;   // two's complement: a negative rotation wraps
+    r = ge_from_ext(columns.p[index] + row * 8);
+  } else {
+    r = ge_from_ext(prev);
+  }
+  return r;
+}
+
+__global__ __launch_bounds__(GE_THREADS) void graph_evaluate_kernel(const GraphColumns columns,
+                                                                    const uint32_t* __restrict__ consts,
+                                                                    const int32_t* __restrict__ rotations,
+                                                                    const GraphCalc* __restrict__ calcs, uint32_t n_calc, uint32_t result_src,
+                                                                    uint32_t* __restrict__ scratch, uint32_t* __restrict__ values,
+                                                                    uint32_t log_size) {
+  const uint32_t T = gridDim.x * GE_THREADS;
+  const uint32_t lane_slot = blockIdx.x * GE_THREADS + threadIdx.x;
+  const uint64_t size = 1ull << log_size, mask = size - 1;
+  for (uint64_t idx = lane_slot; idx < size; idx += T) {
+    uint32_t* vrow = values + idx * 8;
+    for (uint32_t k = 0; k < n_calc; ++k) {
+      const GraphCalc cc = calcs[k];                       // the same words for every lane: scalar loads
+      const Fr a = ge_fetch(cc.a, columns, consts, rotations, scratch, T, lane_slot, idx, mask, vrow);
+      Fr out;
+      switch (cc.op) {
+        case GOP_ADD:
+          out = ge_reduce(fe_add(a, ge_fetch(cc.b, columns, consts, rotations, scratch, T, lane_slot, idx, mask, vrow)));
+          break;
+        case GOP_SUB:
+          out = ge_reduce(fe_sub<4, 29>(a, ge_fetch(cc.b, columns, consts, rotations, scratch, T, lane_slot, idx, mask, vrow)));
+          break;
+        case GOP_MUL:
+          out = fe_mul(a, ge_fetch(cc.b, columns, consts, rotations, scratch, T, lane_slot, idx, mask, vrow));
+          break;
+        case GOP_SQUARE:
+          out = fe_sqr(a);
+          break;
+        case GOP_DOUBLE:
+          out = ge_reduce(fe_dbl(a));
+          break;
+        case GOP_NEGATE:
+          out = ge_reduce(fe_sub<4, 29>(fe_zero<FrParams>(), a));
+          break;
+        case GOP_MULADD: {   // a * b + c (one Horner step)
+          const Fr b = ge_fetch(cc.b, columns, consts, rotations, scratch, T, lane_slot, idx, mask, vrow);
+          const Fr c = ge_fetch(cc.c, columns, consts, rotations, scratch, T, lane_slot, idx, mask, vrow);
+          out = ge_reduce(fe_add(fe_mul(a, b), c));
+          break;
+        }
+        default:             // GOP_STORE
+          out = a;
+          break;
+      }
+      uint32_t* p = scratch + (size_t)cc.target * 9 * T + lane_slot;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) p[(size_t)i * T] = out.l[i];
+    }
+    // the graph's value: its last calculation (upstream GraphEvaluator::evaluate), or the given source
+    Fr res = fe_zero<FrParams>();
+    if (n_calc != 0 || gsrc_kind(result_src) != GSRC_INTER)
+      res = ge_fetch(result_src, columns, consts, rotations, scratch, T, lane_slot, idx, mask, vrow);
+    uint32_t w[8];
+    fe_to_ext(w, ge_reduce(res));
+    uint4* dst = reinterpret_cast<uint4*>(vrow);
+    dst[0] = make_uint4(w[0], w[1], w[2], w[3]);
+    dst[1] = make_uint4(w[4], w[5], w[6], w[7]);
+  }
+}
+
+// ---- host: program "compilation" (validation, Horner-free device form, liveness slot allocation) and launch ----
+static bool src_ok(uint32_t s, size_t n_const, size_t n_inter, size_t n_cols, size_t n_rot) {
+  switch (gsrc_kind(s)) {
+    case GSRC_CONST: return gsrc_index(s) < n_const;
+    case GSRC_INTER: return gsrc_index(s) < n_inter;
+    case GSRC_COLUMN: return gsrc_index(s) < n_cols && gsrc_rot(s) < n_rot;
+    default: return true;
+  }
+}
+
+int graph_create(DeviceCtx& ctx, const uint32_t* calcs5, size_t n_calc, const uint64_t* constants_ext, size_t n_const_static,
+                 size_t n_dynamic, const int32_t* rotations, size_t n_rot, size_t n_columns, uint32_t n_intermediates,
+                 uint64_t* out_handle) {
+  if (n_dynamic > GE_MAX_DYN) return hm_fail(HM_ERR_BAD_ARG, "graph: more than 16 per-call constants");
+  const size_t n_const = n_const_static + n_dynamic;
+  if (n_calc > (1u << 24) || n_const >= (1u << 20) || n_rot > 1024 || n_columns > GE_MAX_COLUMNS || n_intermediates >= (1u << 20))
+    return hm_fail(HM_ERR_BAD_ARG, "graph: program too large for the instruction encoding");
+  auto g = std::make_unique<GraphProgram>();
+  g->n_columns = n_columns;
+  g->n_static = (uint32_t)n_const_static;
+  g->n_dynamic = (uint32_t)n_dynamic;
+  // validate, find the last use of every intermediate
+  std::vector<uint32_t> last_use(n_intermediates, 0);
+  std::vector<char> defined(n_intermediates, 0);
+  for (size_t k = 0; k < n_calc; ++k) {
+    const uint32_t* c = calcs5 + 5 * k;
+    if (c[0] > GOP_MULADD) return hm_fail(HM_ERR_BAD_ARG, "graph: unknown operation");
+    const int nsrc = c[0] == GOP_MULADD ? 3 : (c[0] <= GOP_MUL ? 2 : 1);
+    for (int j = 0; j < nsrc; ++j) {
+      const uint32_t s = c[1 + j];
+      if (!src_ok(s, n_const, n_intermediates, n_columns, n_rot)) return hm_fail(HM_ERR_BAD_ARG, "graph: source out of range");
+      if (gsrc_kind(s) == GSRC_INTER) {
+        if (!defined[gsrc_index(s)]) return hm_fail(HM_ERR_BAD_ARG, "graph: intermediate read before it is written");
+        last_use[gsrc_index(s)] = (uint32_t)k;
+      }
+    }
+    if (c[4] >= n_intermediates) return hm_fail(HM_ERR_BAD_ARG, "graph: target out of range");
+    if (defined[c[4]]) return hm_fail(HM_ERR_BAD_ARG, "graph: intermediate written twice (every calculation owns its target)");
+    defined[c[4]] = 1;
+  }
+  // the result is the last calculation's target: it must survive to the end
+  uint32_t result_inter = n_calc ? calcs5[5 * (n_calc - 1) + 4] : 0;
+  if (n_calc) last_use[result_inter] = (uint32_t)n_calc;
+  // linear-scan slot allocation: a slot is free again after the last read of the intermediate it holds
+  std::vector<uint32_t> slot_of(n_intermediates, 0xffffffffu), free_slots;
+  std::multimap<uint32_t, uint32_t> expiring;        // last use -> slot
+  std::vector<GraphCalc> dev(n_calc);
+  uint32_t n_slots = 0;
+  auto remap = [&](uint32_t s) -> uint32_t {
+    if (gsrc_kind(s) != GSRC_INTER) return s;
+    return (GSRC_INTER << 30) | slot_of[gsrc_index(s)];
+  };
+  for (size_t k = 0; k < n_calc; ++k) {
+    const uint32_t* c = calcs5 + 5 * k;
+    GraphCalc d{c[0], remap(c[1]), remap(c[2]), remap(c[3]), 0};
+    if (c[0] != GOP_MULADD) d.c = 0;
+    if (c[0] > GOP_MUL && c[0] != GOP_MULADD) d.b = 0;
+    // slots whose value was read for the last time BEFORE this instruction are free (its own operands are read
+    // before its target is written, so a slot expiring AT k may be reused as k's target)
+    while (!expiring.empty() && expiring.begin()->first <= (uint32_t)k) {
+      free_slots.push_back(expiring.begin()->second);
+      expiring.erase(expiring.begin());
+    }
+    const uint32_t t = c[4];
+    uint32_t slot;
+    if (!free_slots.empty()) {
+      slot = free_slots.back();
+      free_slots.pop_back();
+    } else {
+      slot = n_slots++;
+    }
+    slot_of[t] = slot;
+    // a value that is never read again still needs its slot for this one instruction
+    expiring.emplace(last_use[t] > (uint32_t)k ? last_use[t] : (uint32_t)k + 1, slot);
+    d.target = slot;
+    dev[k] = d;
+  }
+  g->n_calc = (uint32_t)n_calc;
+  g->n_slots = n_slots ? n_slots : 1;
+  g->result_src = n_calc ? ((GSRC_INTER << 30) | slot_of[result_inter]) : ((GSRC_INTER << 30) | 0u);
+  // constants -> internal form
+  std::vector<uint32_t> c9(std::max<size_t>(n_const_static, 1) * 9, 0);
+  for (size_t i = 0; i < n_const_static; ++i) host::fr_to_internal9(host::fr_load(constants_ext + 4 * i), &c9[9 * i]);
+  const size_t b_calc = std::max<size_t>(n_calc, 1) * sizeof(GraphCalc), b_const = c9.size() * 4, b_rot = std::max<size_t>(n_rot, 1) * 4;
+  HM_HIP_CHECK(hipMalloc(&g->d_blob, b_calc + b_const + b_rot));
+  uint8_t* blob = (uint8_t*)g->d_blob;
+  g->d_calcs = blob;
+  g->d_consts = (uint32_t*)(blob + b_calc);
+  g->d_rot = (int32_t*)(blob + b_calc + b_const);
+  if (n_calc) HM_HIP_CHECK(hipMemcpy(g->d_calcs, dev.data(), n_calc * sizeof(GraphCalc), hipMemcpyHostToDevice));
+  HM_HIP_CHECK(hipMemcpy(g->d_consts, c9.data(), b_const, hipMemcpyHostToDevice));
+  if (n_rot) HM_HIP_CHECK(hipMemcpy(g->d_rot, rotations, n_rot * 4, hipMemcpyHostToDevice));
+  g->handle = ctx.next_handle++;
+  *out_handle = g->handle;
+  ctx.graphs.push_back(std::move(g));
+  return HM_OK;
+}
+
+void graph_release(GraphProgram& g) {
+  if (g.d_blob) (void)hipFree(g.d_blob);
+  g.d_blob = nullptr;
+}
+
+int graph_evaluate(DeviceCtx& ctx, GraphProgram& g, const void* const* d_columns, size_t n_columns, const uint64_t* dyn_ext,
+                   size_t n_dyn, uint32_t log_size, void* d_values, hipStream_t stream) {
+  if (n_columns != g.n_columns) return hm_fail(HM_ERR_BAD_ARG, "graph: the program was built for another number of columns");
+  if (n_dyn != g.n_dynamic) return hm_fail(HM_ERR_BAD_ARG, "graph: the program was built for another number of per-call constants");
+  if (log_size > 30) return hm_fail(HM_ERR_BAD_ARG, "graph: log_size > 30");
+  const uint64_t size = 1ull << log_size;
+  // enough lanes to fill the chip, few enough that the intermediates' scratch stays cache-sized
+  uint32_t blocks = (uint32_t)std::min<uint64_t>((size + GE_THREADS - 1) / GE_THREADS, 512);
+  const uint32_t T = blocks * GE_THREADS;
+  AuxSlot* slot = aux_acquire(ctx, stream);
+  if (!slot) return HM_ERR_HIP;
+  const size_t b_scratch = (size_t)g.n_slots * 9 * T * 4;
+  uint8_t* buf = (uint8_t*)slot->scratch.ensure(b_scratch);
+  if (!buf) return hm_fail(HM_ERR_HIP, "graph: scratch allocation failed");
+  GraphColumns cols;
+  std::memset(&cols, 0, sizeof cols);
+  for (size_t i = 0; i < n_columns; ++i) {
+    if (!d_columns[i]) return hm_fail(HM_ERR_BAD_ARG, "graph: null column pointer");
+    cols.p[i] = (const uint32_t*)d_columns[i];
+  }
+  cols.n_static = g.n_static;
+  for (size_t i = 0; i < n_dyn; ++i) host::fr_to_internal9(host::fr_load(dyn_ext + 4 * i), &cols.dyn[9 * i]);
+  hipLaunchKernelGGL(graph_evaluate_kernel, dim3(blocks), dim3(GE_THREADS), 0, stream, cols,
+                     (const uint32_t*)g.d_consts, (const int32_t*)g.d_rot, (const GraphCalc*)g.d_calcs, g.n_calc, g.result_src,
+                     (uint32_t*)buf, (uint32_t*)d_values, log_size);
+  HM_HIP_CHECK(hipGetLastError());
+  return aux_release(ctx, slot, stream);
+}
+
+}  // namespace hm

@@ -117,6 +117,16 @@ struct AuxSlot {
 };
 constexpr int HM_AUX_SLOTS = 4;
 
+struct GraphProgram {       // a compiled evaluate_h program (graph.hip): device form + constants + rotations
+  uint64_t handle = 0;
+  void* d_blob = nullptr;
+  void* d_calcs = nullptr;
+  uint32_t* d_consts = nullptr;
+  int32_t* d_rot = nullptr;
+  uint32_t n_calc = 0, n_slots = 1, result_src = 0, n_static = 0, n_dynamic = 0;
+  size_t n_columns = 0;
+};
+
 struct FreeBases {          // buffers of a released base set, kept for the next registration of that size
   uint32_t* d_xy = nullptr;
   uint8_t* d_inf = nullptr;
@@ -146,6 +156,7 @@ struct DeviceCtx {
   std::vector<BasesEntry> bases;
   std::vector<BasesEntry> zombie_bases;   // released while a ticket still reads them: freed by the last hm_msm_wait
   std::vector<FreeBases> free_bases;      // recycled buffers (no hipFree => no device-wide synchronisation)
+  std::vector<std::unique_ptr<GraphProgram>> graphs;
   uint64_t next_handle = 1;
   MsmStats last_msm;
   CallStats calls;
@@ -174,6 +185,14 @@ int ntt_plan_first_digit(uint32_t log_n, int* passes);
 int fr_scale_run(uint32_t* d_a, const uint64_t c_ext[4], uint64_t n, hipStream_t stream);
 int fr_mul_pattern3_run(uint32_t* d_a, const uint64_t c3_ext[12], uint64_t n, hipStream_t stream);
 void ntt_tables_release(NttTables& t);
+
+// graph.hip
+int graph_create(DeviceCtx& ctx, const uint32_t* calcs5, size_t n_calc, const uint64_t* constants_ext, size_t n_const_static,
+                 size_t n_dynamic, const int32_t* rotations, size_t n_rot, size_t n_columns, uint32_t n_intermediates,
+                 uint64_t* out_handle);
+int graph_evaluate(DeviceCtx& ctx, GraphProgram& g, const void* const* d_columns, size_t n_columns, const uint64_t* dyn_ext,
+                   size_t n_dyn, uint32_t log_size, void* d_values, hipStream_t stream);
+void graph_release(GraphProgram& g);
 
 // poly.hip
 int fr_powers_run(uint32_t* d_out, uint64_t n, const uint64_t x_ext[4], hipStream_t stream);

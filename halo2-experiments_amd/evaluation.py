@@ -1,0 +1,307 @@
+"""Host-side mirror of ``halo2_proofs::plonk::evaluation::GraphEvaluator`` (the gate arithmetic of ``evaluate_h``,
+SURVEY.md §8f-4; upstream ``halo2_proofs/src/plonk/evaluation.rs`` and ``plonk/circuit.rs::Expression`` at the tag
+pinned by /root/reference/Cargo.toml:10; reached from ``create_proof``, /root/reference/src/circuits/utils.rs:40-48).
+
+Upstream flattens every gate polynomial of the constraint system into a straight-line program with common
+sub-expressions shared, then evaluates it once per row of the extended domain:
+
+    Expression     Constant | Fixed(query) | Advice(query) | Instance(query) | Challenge | Negated | Sum | Product | Scaled
+    ValueSource    Constant(i) | Intermediate(i) | Fixed(col, rot_idx) | Advice(..) | Instance(..) | Challenge(i)
+                   | Beta | Gamma | Theta | Y | PreviousValue
+    Calculation    Add | Sub | Mul | Square | Double | Negate | Horner(start, parts, factor) | Store
+    add_expression the same peephole rules as upstream: a + (-b) -> Sub, x * 2 -> Double, x * x -> Square, constants
+                   0 / 1 folded, commutative operands ordered, every Calculation deduplicated
+    custom gates   value = Horner(PreviousValue, [gate polynomials...], Y)
+
+``GraphEvaluator.compile`` lowers that program to the five-word device calculations of ``hm_graph_create`` (one column
+table: fixed, then advice, then instance; Challenge / Beta / Gamma / Theta / Y as the per-call constants; Horner as a
+MulAdd chain), and ``evaluate`` runs it on extended-domain columns resident in HBM.  Field elements here are Python
+integers in [0, r).
+"""
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass
+from typing import Dict, List, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib
+from .arithmetic import _ptr, _stream_ptr, _tensor_rows
+from .domain import FR_MODULUS, fr_words
+
+R = FR_MODULUS
+
+
+# ---- Expression (plonk/circuit.rs) -------------------------------------------------------------------
+class Expression:
+    def __add__(self, o):
+        return Sum(self, _lift(o))
+
+    def __radd__(self, o):
+        return Sum(_lift(o), self)
+
+    def __sub__(self, o):
+        return Sum(self, Negated(_lift(o)))
+
+    def __rsub__(self, o):
+        return Sum(_lift(o), Negated(self))
+
+    def __mul__(self, o):
+        if isinstance(o, int):
+            return Scaled(self, o % R)
+        return Product(self, o)
+
+    def __rmul__(self, o):
+        return Scaled(self, o % R)
+
+    def __neg__(self):
+        return Negated(self)
+
+
+def _lift(o) -> "Expression":
+    return o if isinstance(o, Expression) else Constant(o % R)
+
+
+@dataclass(frozen=True)
+class Constant(Expression):
+    value: int
+
+
+@dataclass(frozen=True)
+class Fixed(Expression):
+    column: int
+    rotation: int = 0
+
+
+@dataclass(frozen=True)
+class Advice(Expression):
+    column: int
+    rotation: int = 0
+
+
+@dataclass(frozen=True)
+class Instance(Expression):
+    column: int
+    rotation: int = 0
+
+
+@dataclass(frozen=True)
+class Challenge(Expression):
+    index: int
+
+
+@dataclass(frozen=True)
+class Negated(Expression):
+    a: Expression
+
+
+@dataclass(frozen=True)
+class Sum(Expression):
+    a: Expression
+    b: Expression
+
+
+@dataclass(frozen=True)
+class Product(Expression):
+    a: Expression
+    b: Expression
+
+
+@dataclass(frozen=True)
+class Scaled(Expression):
+    a: Expression
+    factor: int
+
+
+# ---- ValueSource / Calculation (plonk/evaluation.rs) -----------------------------------------------------
+# a value source is a tuple whose first element is its kind; tuples order like upstream's derived Ord (by variant,
+# then fields), which decides the operand order of commutative calculations
+_KINDS = ("Constant", "Intermediate", "Fixed", "Advice", "Instance", "Challenge", "Beta", "Gamma", "Theta", "Y", "PreviousValue")
+_RANK = {k: i for i, k in enumerate(_KINDS)}
+
+
+def _key(vs):
+    return (_RANK[vs[0]],) + tuple(vs[1:])
+
+
+class GraphEvaluator:
+    def __init__(self):
+        self.constants: List[int] = [0, 1, 2]
+        self.rotations: List[int] = []
+        self.calculations: List[Tuple] = []           # (calculation tuple, target)
+        self._calc_index: Dict[Tuple, int] = {}
+        self.num_intermediates = 0
+
+    # -- upstream's builders ------------------------------------------------------------------------------
+    def add_rotation(self, rotation: int) -> int:
+        if rotation in self.rotations:
+            return self.rotations.index(rotation)
+        self.rotations.append(rotation)
+        return len(self.rotations) - 1
+
+    def add_constant(self, c: int):
+        c %= R
+        if c in self.constants:
+            return ("Constant", self.constants.index(c))
+        self.constants.append(c)
+        return ("Constant", len(self.constants) - 1)
+
+    def add_calculation(self, calc: Tuple):
+        if calc in self._calc_index:
+            return ("Intermediate", self._calc_index[calc])
+        target = self.num_intermediates
+        self.calculations.append((calc, target))
+        self._calc_index[calc] = target
+        self.num_intermediates += 1
+        return ("Intermediate", target)
+
+    def add_expression(self, e: Expression):
+        zero, one, two = ("Constant", 0), ("Constant", 1), ("Constant", 2)
+        if isinstance(e, Constant):
+            return self.add_constant(e.value)
+        if isinstance(e, (Fixed, Advice, Instance)):
+            rot = self.add_rotation(e.rotation)
+            return self.add_calculation(("Store", (type(e).__name__, e.column, rot)))
+        if isinstance(e, Challenge):
+            return self.add_calculation(("Store", ("Challenge", e.index)))
+        if isinstance(e, Negated):
+            if isinstance(e.a, Constant):
+                return self.add_constant(-e.a.value)
+            r = self.add_expression(e.a)
+            return r if r == zero else self.add_calculation(("Negate", r))
+        if isinstance(e, Sum):
+            if isinstance(e.b, Negated):                      # undo subtraction stored as a + (-b)
+                ra, rb = self.add_expression(e.a), self.add_expression(e.b.a)
+                if ra == zero:
+                    return self.add_calculation(("Negate", rb))
+                if rb == zero:
+                    return ra
+                return self.add_calculation(("Sub", ra, rb))
+            ra, rb = self.add_expression(e.a), self.add_expression(e.b)
+            if ra == zero:
+                return rb
+            if rb == zero:
+                return ra
+            return self.add_calculation(("Add", ra, rb) if _key(ra) <= _key(rb) else ("Add", rb, ra))
+        if isinstance(e, Product):
+            ra, rb = self.add_expression(e.a), self.add_expression(e.b)
+            if ra == zero or rb == zero:
+                return zero
+            if ra == one:
+                return rb
+            if rb == one:
+                return ra
+            if ra == two:
+                return self.add_calculation(("Double", rb))
+            if rb == two:
+                return self.add_calculation(("Double", ra))
+            if ra == rb:
+                return self.add_calculation(("Square", ra))
+            return self.add_calculation(("Mul", ra, rb) if _key(ra) <= _key(rb) else ("Mul", rb, ra))
+        if isinstance(e, Scaled):
+            if e.factor % R == 0:
+                return zero
+            if e.factor % R == 1:
+                return self.add_expression(e.a)
+            cst = self.add_constant(e.factor)
+            ra = self.add_expression(e.a)
+            return self.add_calculation(("Mul", ra, cst))
+        raise TypeError(f"not an Expression: {e!r}")
+
+    def add_custom_gates(self, polynomials: Sequence[Expression]):
+        """Evaluator::new's custom-gate part: Horner(PreviousValue, parts, Y) over every gate polynomial."""
+        parts = tuple(self.add_expression(p) for p in polynomials)
+        return self.add_calculation(("Horner", ("PreviousValue",), parts, ("Y",)))
+
+    # -- lowering to the device program ----------------------------------------------------------------------
+    def compile(self, num_fixed: int, num_advice: int, num_instance: int, num_challenges: int = 0, rot_scale: int = 1) -> "CompiledGraph":
+        """Column table = fixed | advice | instance.  Per-call constants = challenges..., beta, gamma, theta, y."""
+        n_static = len(self.constants)
+        dyn_index = {("Challenge", i): n_static + i for i in range(num_challenges)}
+        for j, name in enumerate(("Beta", "Gamma", "Theta", "Y")):
+            dyn_index[(name,)] = n_static + num_challenges + j
+        col_base = {"Fixed": 0, "Advice": num_fixed, "Instance": num_fixed + num_advice}
+        n_cols = num_fixed + num_advice + num_instance
+        words: List[int] = []
+        next_inter = [self.num_intermediates]
+
+        def src(vs) -> int:
+            kind = vs[0]
+            if kind == "Constant":
+                return (0 << 30) | vs[1]
+            if kind == "Intermediate":
+                return (1 << 30) | vs[1]
+            if kind in col_base:
+                col = col_base[kind] + vs[1]
+                if not 0 <= vs[1] < {"Fixed": num_fixed, "Advice": num_advice, "Instance": num_instance}[kind]:
+                    raise ValueError(f"{kind} column {vs[1]} out of range")
+                return (2 << 30) | (vs[2] << 20) | col
+            if kind == "PreviousValue":
+                return 3 << 30
+            if vs in dyn_index:
+                return (0 << 30) | dyn_index[vs]
+            raise ValueError(f"value source {vs!r} has no slot in this compilation")
+
+        ops = {"Add": 0, "Sub": 1, "Mul": 2, "Square": 3, "Double": 4, "Negate": 5, "Store": 6}
+        for calc, target in self.calculations:
+            name = calc[0]
+            if name == "Horner":
+                start, parts, factor = calc[1], calc[2], calc[3]
+                cur = src(start)
+                if not parts:
+                    words += [6, cur, 0, 0, target]
+                for i, part in enumerate(parts):          # value = value * factor + part
+                    t = target if i == len(parts) - 1 else next_inter[0]
+                    if t != target:
+                        next_inter[0] += 1
+                    words += [7, cur, src(factor), src(part), t]
+                    cur = (1 << 30) | t
+            elif name in ("Add", "Sub", "Mul"):
+                words += [ops[name], src(calc[1]), src(calc[2]), 0, target]
+            else:
+                words += [ops[name], src(calc[1]), 0, 0, target]
+        return CompiledGraph(np.array(words, dtype=np.uint32).reshape(-1, 5), list(self.constants), num_challenges + 4,
+                             [r * rot_scale for r in self.rotations], n_cols, next_inter[0], num_challenges)
+
+
+class CompiledGraph:
+    """A program uploaded to the device (``hm_graph_create``); ``evaluate`` = upstream's per-row loop of evaluate_h."""
+
+    def __init__(self, calcs: np.ndarray, constants: List[int], n_dynamic: int, rotations: List[int], n_columns: int,
+                 n_intermediates: int, num_challenges: int):
+        self.calcs, self.constants, self.n_dynamic = np.ascontiguousarray(calcs), constants, n_dynamic
+        self.rotations, self.n_columns, self.n_intermediates = rotations, n_columns, n_intermediates
+        self.num_challenges = num_challenges
+        lib = _lib.load()
+        consts = np.stack([fr_words(c) for c in constants]) if constants else np.zeros((0, 4), dtype=np.uint64)
+        rots = np.array(rotations, dtype=np.int32)
+        h = ctypes.c_uint64(0)
+        _lib.check(lib.hm_graph_create(self.calcs.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), self.calcs.shape[0],
+                                       _ptr(consts) if len(constants) else None, len(constants), n_dynamic,
+                                       rots.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)) if len(rotations) else None,
+                                       len(rotations), n_columns, n_intermediates, ctypes.byref(h)))
+        self.handle = h.value
+
+    def evaluate(self, columns: Sequence, values, challenges: Sequence[int] = (), beta: int = 0, gamma: int = 0, theta: int = 0,
+                 y: int = 0) -> None:
+        """``columns``: GPU tensors (size, 4), fixed then advice then instance; ``values``: (size, 4) GPU tensor holding
+        PreviousValue on entry and the program's value on return."""
+        size = _tensor_rows(values, 4, "values")
+        if size & (size - 1) or size == 0:
+            raise ValueError("evaluate: the extended domain size must be a power of two")
+        if len(columns) != self.n_columns or len(challenges) != self.num_challenges:
+            raise ValueError("evaluate: column / challenge count differs from the compiled program's")
+        for c in columns:
+            if _tensor_rows(c, 4, "column") != size:
+                raise ValueError("evaluate: every column must have the extended domain's size")
+        ptrs = (ctypes.c_void_p * max(len(columns), 1))(*[c.data_ptr() for c in columns])
+        dyn = np.stack([fr_words(v) for v in list(challenges) + [beta, gamma, theta, y]])
+        _lib.check(_lib.load().hm_graph_evaluate_dev(ctypes.c_uint64(self.handle), ptrs, len(columns), _ptr(dyn), dyn.shape[0],
+                                                     size.bit_length() - 1, ctypes.c_void_p(values.data_ptr()),
+                                                     ctypes.c_void_p(_stream_ptr(values))))
+
+    def destroy(self) -> None:
+        if self.handle:
+            _lib.check(_lib.load().hm_graph_destroy(ctypes.c_uint64(self.handle)))
+            self.handle = 0

@@ -175,6 +175,26 @@ int hm_eval_polynomial_bn256_fr_dev(const void* d_polys, size_t n, const uint32_
  * fixed-base multiples are g, and whose scaled inverse NTT gives the Lagrange-basis scalars of g_lagrange. */
 int hm_fr_powers_dev(void* d_out, size_t n, const uint64_t x[4], void* stream);
 
+/* evaluate_h's gate arithmetic (halo2_proofs::plonk::evaluation::GraphEvaluator): a circuit's gate / lookup
+ * expressions, flattened into a straight-line program, run once per row of the extended domain with every column
+ * resident in HBM.  A calculation is five words { op, a, b, c, target }:
+ *   op      0 Add  1 Sub  2 Mul  3 Square  4 Double  5 Negate  6 Store  7 MulAdd (a * b + c: one Horner step)
+ *   a b c   value sources: kind << 30 | rotation_index << 20 | index, with kind 0 Constant(index), 1 Intermediate(index),
+ *           2 Column(index) at row (idx + rotations[rotation_index]) mod 2^log_size, 3 PreviousValue (d_values[idx] on entry)
+ *   target  the intermediate this calculation defines (each is written exactly once, as upstream's are)
+ * Upstream's Fixed / Advice / Instance queries are entries of one column table.  Constants [0, n_const) belong to the
+ * program (the circuit's); constants [n_const, n_const + n_dynamic) are given with every call -- upstream's Challenge /
+ * Beta / Gamma / Theta / Y sources, which change with every proof (n_dynamic <= 16).  Horner(start, parts, factor) is a
+ * chain of MulAdd.  rotations are in ROWS (upstream's rot * 2^(extended_k - k)).  The value of the program is its last
+ * calculation's (upstream GraphEvaluator::evaluate); it is written to d_values[idx] (2^log_size x 4 u64, external words).
+ * hm_graph_create validates the program, assigns intermediates to a minimal number of slots by liveness and uploads it;
+ * evaluation is asynchronous on `stream` and may run concurrently on different streams. */
+int hm_graph_create(const uint32_t* calcs, size_t n_calc, const uint64_t* constants, size_t n_const, size_t n_dynamic,
+                    const int32_t* rotations, size_t n_rot, size_t n_columns, uint32_t n_intermediates, uint64_t* out_handle);
+int hm_graph_evaluate_dev(uint64_t handle, const void* const* d_columns, size_t n_columns, const uint64_t* dynamic_constants,
+                          size_t n_dynamic, uint32_t log_size, void* d_values, void* stream);
+int hm_graph_destroy(uint64_t handle);
+
 /* Inputs and known answer of the benchmark of SURVEY.md §8d, without leaving the device:
  *   hm_fr_random_dev           out[i] uniform in [0, r) (Fr::random): one xoshiro256** stream per element, seeded by
  *                              splitmix64 from (seed, i), 254-bit candidates rejected until below r

@@ -1,0 +1,199 @@
+"""evaluate_h's gate arithmetic: the GraphEvaluator mirror against the oracle's restatement and
+against direct evaluation of the expression trees -- builder rules on the CPU, the device interpreter on the GPU."""
+import random
+
+import numpy as np
+import pytest
+
+from halo2_experiments_amd import evaluation as ev
+from halo2_experiments_amd.domain import FR_MODULUS, fr_words
+
+R = FR_MODULUS
+
+
+def poseidon_like_gates(width=3):
+    """Gate polynomials of the shape the reference's Poseidon chip gives halo2 (s * (x^5 + rc) mixed by an MDS row minus the
+    next state; /root/reference/src/chips/poseidon/hash.rs:50-57 configures Pow5Chip): selectors are fixed columns."""
+    s_full, s_partial = ev.Fixed(0), ev.Fixed(1)
+    rc = [ev.Fixed(2 + i) for i in range(width)]
+    state = [ev.Advice(i) for i in range(width)]
+    nxt = [ev.Advice(i, 1) for i in range(width)]
+    mds = [[(3 * i + 7 * j + 11) % R for j in range(width)] for i in range(width)]
+
+    def pow5(x):
+        x2 = x * x
+        return x2 * x2 * x
+
+    polys = []
+    for i in range(width):
+        acc = None
+        for j in range(width):
+            term = pow5(state[j] + rc[j]) * mds[i][j]
+            acc = term if acc is None else acc + term
+        polys.append(s_full * (acc - nxt[i]))
+    polys.append(s_partial * (pow5(state[0] + rc[0]) - ev.Advice(0, -1)))
+    polys.append(s_full * (1 - s_full))                                   # boolean selector
+    polys.append(ev.Challenge(0) * (ev.Instance(0) - state[1]) * s_partial)
+    return polys, 2 + width, width, 1
+
+
+def test_builder_rules_and_cse():
+    """The peephole rules of add_expression and the deduplication of calculations (upstream evaluation.rs)."""
+    g = ev.GraphEvaluator()
+    a, b = ev.Advice(0), ev.Advice(1, 1)
+    r1 = g.add_expression(a * b)
+    r2 = g.add_expression(b * a)                      # commutative operands are ordered: the same calculation
+    assert r1 == r2
+    n = len(g.calculations)
+    assert g.add_expression(a - b)[0] == "Intermediate" and g.calculations[-1][0][0] == "Sub"
+    assert g.add_expression(a * a)[0] == "Intermediate" and g.calculations[-1][0][0] == "Square"
+    assert g.add_expression(a * ev.Constant(2)) == g.add_expression(ev.Constant(2) * a) and g.calculations[-1][0][0] == "Double"
+    assert g.add_expression(a * ev.Constant(1)) == g.add_expression(a)
+    assert g.add_expression(a * ev.Constant(0)) == ("Constant", 0)
+    assert g.add_expression(ev.Constant(0) + a) == g.add_expression(a)
+    assert g.add_expression(-ev.Constant(5)) == ("Constant", g.constants.index(R - 5))
+    assert g.add_expression(ev.Scaled(a, 1)) == g.add_expression(a)
+    assert g.rotations == [0, 1] and g.constants[:3] == [0, 1, 2]
+    assert len(g.calculations) > n
+    before = len(g.calculations)
+    g.add_expression(a * b)                            # already there
+    assert len(g.calculations) == before
+
+
+def test_graph_equals_direct_expression_evaluation(pyref):
+    """Oracle's graph interpreter == direct evaluation of the expression trees, folded by Horner in y."""
+    from oracle import graph_ref
+    rng = random.Random(7)
+    polys, nf, na, ni = poseidon_like_gates()
+    g = ev.GraphEvaluator()
+    g.add_custom_gates(polys)
+    isize, rot_scale = 16, 2
+    cols = lambda c: [[rng.randrange(R) for _ in range(isize)] for _ in range(c)]
+    fixed, advice, instance = cols(nf), cols(na), cols(ni)
+    ch, y = [rng.randrange(R)], rng.randrange(R)
+    prev = [rng.randrange(R) for _ in range(isize)]
+    got = graph_ref.evaluate_graph(g.calculations, g.constants, g.rotations, fixed, advice, instance, ch, 0, 0, 0, y, prev, rot_scale, isize)
+    for idx in range(isize):
+        v = prev[idx]
+        for p in polys:
+            v = (v * y + graph_ref.evaluate_expression(p, fixed, advice, instance, ch, idx, rot_scale, isize)) % R
+        assert got[idx] == v, idx
+
+
+def _random_expression(rng, depth, nf, na, ni):
+    if depth == 0 or rng.random() < 0.2:
+        k = rng.randrange(5)
+        if k == 0:
+            return ev.Constant(rng.choice([0, 1, 2, 3, R - 1, rng.randrange(R)]))
+        if k == 1:
+            return ev.Fixed(rng.randrange(nf), rng.choice([0, 0, 1, -1]))
+        if k == 2:
+            return ev.Instance(rng.randrange(ni), rng.choice([0, 2]))
+        if k == 3:
+            return ev.Challenge(0)
+        return ev.Advice(rng.randrange(na), rng.choice([0, 0, 1, -1, 3, -2]))
+    k = rng.randrange(5)
+    a = _random_expression(rng, depth - 1, nf, na, ni)
+    if k == 0:
+        return -a
+    if k == 1:
+        return ev.Scaled(a, rng.choice([0, 1, 2, rng.randrange(R)]))
+    b = _random_expression(rng, depth - 1, nf, na, ni)
+    return a + b if k == 2 else (a - b if k == 3 else a * b)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["poseidon", "random0", "random1", "random2", "empty"])
+def test_device_graph_matches_oracle(pyref, case):
+    """The device interpreter (lowered program, liveness-allocated slots, rotations with wrap-around, PreviousValue,
+    per-call challenge / y constants) against the oracle's restatement of GraphEvaluator::evaluate."""
+    import torch
+    from oracle import graph_ref
+    rng = random.Random(hash(case) & 0xFFFF)
+    if case == "poseidon":
+        polys, nf, na, ni = poseidon_like_gates()
+    elif case == "empty":
+        polys, nf, na, ni = [], 1, 1, 1
+    else:
+        nf, na, ni = 2, 3, 1
+        polys = [_random_expression(rng, 5, nf, na, ni) for _ in range(6)]
+    g = ev.GraphEvaluator()
+    g.add_custom_gates(polys)
+    k, ek = 5, 7
+    isize, rot_scale = 1 << ek, 1 << (ek - k)
+    mk = lambda c: [[rng.randrange(R) for _ in range(isize)] for _ in range(c)]
+    fixed, advice, instance = mk(nf), mk(na), mk(ni)
+    ch, y = [rng.randrange(R)], rng.randrange(R)
+    prev = [rng.randrange(R) for _ in range(isize)]
+    exp = graph_ref.evaluate_graph(g.calculations, g.constants, g.rotations, fixed, advice, instance, ch, 0, 0, 0, y, prev, rot_scale, isize)
+    to_dev = lambda col: torch.from_numpy(pyref.fr_array(col).view(np.int64)).cuda()
+    cols = [to_dev(c) for c in fixed + advice + instance]
+    values = to_dev(prev)
+    prog = g.compile(nf, na, ni, num_challenges=1, rot_scale=rot_scale)
+    try:
+        prog.evaluate(cols, values, challenges=ch, y=y)
+        torch.cuda.synchronize()
+        got = values.cpu().numpy().view(np.uint64)
+        assert np.array_equal(got, pyref.fr_array(exp)), case
+        # a second proof: other challenges on the same compiled program, chained onto the first result (PreviousValue)
+        ch2, y2 = [rng.randrange(R)], rng.randrange(R)
+        exp2 = graph_ref.evaluate_graph(g.calculations, g.constants, g.rotations, fixed, advice, instance, ch2, 0, 0, 0, y2, exp, rot_scale, isize)
+        prog.evaluate(cols, values, challenges=ch2, y=y2)
+        torch.cuda.synchronize()
+        assert np.array_equal(values.cpu().numpy().view(np.uint64), pyref.fr_array(exp2)), case
+    finally:
+        prog.destroy()
+
+
+@pytest.mark.gpu
+def test_device_graph_at_prover_size_and_argument_checks(pyref):
+    """k = 16 extended to 2^19 rows (grid-stride loop, more rows than lanes): spot rows against the oracle; bad programs
+    and mismatched calls are errors, not faults."""
+    import ctypes
+    import torch
+    from halo2_experiments_amd import _lib
+    from oracle import graph_ref
+    rng = random.Random(99)
+    polys, nf, na, ni = poseidon_like_gates()
+    g = ev.GraphEvaluator()
+    g.add_custom_gates(polys)
+    k, ek = 16, 19
+    isize, rot_scale = 1 << ek, 1 << (ek - k)
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(5)
+    def rand_col():
+        x = torch.randint(-(2 ** 63), 2 ** 63 - 1, (isize, 4), dtype=torch.int64, device="cuda", generator=gen)
+        x[:, 3] &= 0x0FFFFFFFFFFFFFFF
+        return x
+    cols = [rand_col() for _ in range(nf + na + ni)]
+    values = rand_col()
+    prev_h = values.cpu().numpy().view(np.uint64).copy()
+    ch, y = [rng.randrange(R)], rng.randrange(R)
+    prog = g.compile(nf, na, ni, num_challenges=1, rot_scale=rot_scale)
+    try:
+        prog.evaluate(cols, values, challenges=ch, y=y)
+        torch.cuda.synchronize()
+        got = values.cpu().numpy().view(np.uint64)
+        hosts = [c.cpu().numpy().view(np.uint64) for c in cols]
+        mont = lambda w: pyref.from_limbs(w) * pow(1 << 256, -1, R) % R
+        for idx in (0, 1, rot_scale - 1, 131071, 131072, isize - 1):
+            # the oracle on a 1-row window: columns as sparse dicts around idx
+            def view(h):
+                return {j % isize: mont(h[j % isize]) for r in g.rotations for j in [idx + r * rot_scale]}
+            fx = [view(h) for h in hosts[:nf]]
+            ad = [view(h) for h in hosts[nf:nf + na]]
+            ins = [view(h) for h in hosts[nf + na:]]
+            v = mont(prev_h[idx])
+            for p in polys:
+                v = (v * y + graph_ref.evaluate_expression(p, fx, ad, ins, ch, idx, rot_scale, isize)) % R
+            assert np.array_equal(got[idx], fr_words(v)), idx
+        with pytest.raises(ValueError):
+            prog.evaluate(cols[:-1], values, challenges=ch, y=y)
+    finally:
+        prog.destroy()
+    lib = _lib.load()
+    h = ctypes.c_uint64(0)
+    bad = np.array([[2, (1 << 30) | 5, 0, 0, 0]], dtype=np.uint32)            # reads intermediate 5 before any write
+    assert lib.hm_graph_create(bad.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), 1, None, 0, 0, None, 0, 0, 8, ctypes.byref(h)) == -1
+    bad = np.array([[9, 0, 0, 0, 0]], dtype=np.uint32)                        # unknown operation
+    assert lib.hm_graph_create(bad.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), 1, None, 0, 0, None, 0, 0, 8, ctypes.byref(h)) == -1
