@@ -15,8 +15,10 @@ extended domain 2^ek with ek = k + ceil(log2(d-1))):
     lagrange_to_coeff (iNTT n, scale fused)          A + 1 instance + 3L + Zp
     coeff_to_extended (coset NTT 2^ek, shift fused)  A + 1 + 3L + Zp
     extended_to_coeff (iNTT 2^ek)                    1
-Everything else in ``create_proof`` (witness synthesis, ``evaluate_h``'s gate arithmetic, Horner
-evaluations, the transcript) stays on the CPU in the reference and is NOT part of this number.
+    evaluate_h gates  (GraphEvaluator over 2^ek rows)  one Poseidon-like gate program (estimate of the expression graph)
+    eval_polynomial   (Horner, n coefficients)         2A + 3 Zp + 5L + (d-1) queries (estimate)
+Everything else in ``create_proof`` (witness synthesis, the permutation / lookup terms of ``evaluate_h``, the
+transcript) stays on the CPU in the reference and is NOT part of this number.
 
 Like the reference's harness (prove, THEN verify: /root/reference/src/circuits/merkle_sum_tree.rs:345-358), a
 replay checks what it computed: the SRS is a real one (g = [s^i]G, g_lagrange = [L_i(s)]G with a known s), and
@@ -159,6 +161,30 @@ def run_replay(shape_name: str, device=None, group=None, include_host_pointer_es
 
     streams = [torch.cuda.Stream(device=device) for _ in range(in_flight)]
 
+    # evaluate_h gate program (estimate: Poseidon-like S-box / MDS gates over 3 state columns) and the evaluation queries
+    from .evaluation import Advice, Challenge, Fixed, GraphEvaluator, Instance
+    width = 3
+    st, nx = [Advice(i) for i in range(width)], [Advice(i, 1) for i in range(width)]
+    rc = [Fixed(2 + i) for i in range(width)]
+    pow5 = lambda x: (x * x) * (x * x) * x
+    gates = []
+    for i in range(width):
+        acc = None
+        for j in range(width):
+            term = pow5(st[j] + rc[j]) * ((3 * i + 7 * j + 11) % FR_MODULUS)
+            acc = term if acc is None else acc + term
+        gates.append(Fixed(0) * (acc - nx[i]))
+    gates.append(Fixed(1) * (pow5(st[0] + rc[0]) - Advice(0, -1)))
+    gates.append(Challenge(0) * (Instance(0) - st[1]) * Fixed(1))
+    ge = GraphEvaluator()
+    ge.add_custom_gates(gates)
+    gate_prog = ge.compile(2 + width, width, 1, num_challenges=1, rot_scale=1 << (dom.extended_k - k))
+    gate_cols = lambda e: [e[i % e.shape[0]] for i in range(2 + width + width + 1)]
+    h_values = torch.zeros((dom.extended_len(), 4), dtype=torch.int64, device=device)
+    n_queries = 2 * A + 3 * zp + 5 * L + (d - 1)              # advice at ~2 rotations, permutation / lookup products at 3 ...
+    eval_index = np.arange(n_queries, dtype=np.uint32) % 8
+    eval_points = np.stack([fr_words(pow(REPLAY_S, 3 + q, FR_MODULUS)) for q in range(n_queries)])
+
     def msm_phase(jobs):
         """The commitments of one prover phase are independent: every rank keeps `in_flight` of its local
         MSMs in flight on as many streams (one MSM's sort / bucket reduction / host fold hides behind
@@ -203,6 +229,17 @@ def run_replay(shape_name: str, device=None, group=None, include_host_pointer_es
                     dom.extended_to_coeff(ext[0])
         torch.cuda.synchronize()
         t["ntt"] = time.perf_counter() - t0
+        # evaluate_h's gate arithmetic over the extended domain (the device GraphEvaluator on a Poseidon-like gate program:
+        # an estimate of the circuit's real expression graph) and the Horner evaluations at x * omega^rot
+        t0 = time.perf_counter()
+        if rank == 0 and ext is not None:
+            gate_prog.evaluate(gate_cols(ext), h_values, challenges=[12345], y=REPLAY_S)
+        torch.cuda.synchronize()
+        t["evaluate_h_gates"] = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        if rank == 0:
+            eval_polynomial(ntt_batch, eval_points, poly_index=eval_index)
+        t["eval_polynomial"] = time.perf_counter() - t0
         return t
 
     proof_once().pop("results")                         # warm-up: tables, workspaces
@@ -236,7 +273,11 @@ def run_replay(shape_name: str, device=None, group=None, include_host_pointer_es
         "shape": {"advice": A, "lookups": L, "equality_columns": shape.equality_columns, "max_degree": d,
                   "source": shape.source},
         "calls": counts,
-        "device_resident_s": {"msm": phases["msm"], "ntt": phases["ntt"], "total": wall},
+        "device_resident_s": {"msm": phases["msm"], "ntt": phases["ntt"], "evaluate_h_gates": phases["evaluate_h_gates"],
+                              "eval_polynomial": phases["eval_polynomial"], "total": wall},
+        "beyond_msm_ntt": {"evaluate_h_gates": f"{len(gate_prog.calcs)} GraphEvaluator calculations per row over 2^{dom.extended_k} rows "
+                                               "(Poseidon-like gate program: an estimate of the circuit's expression graph)",
+                           "eval_polynomial": f"{n_queries} Horner evaluations of 2^{k}-coefficient polynomials (estimate)"},
         "verified": {"commitments_checked": checked["commitments"], "distinct_column_base_pairs": len(expected),
                      "against": "KZG identity commit(f) == [f(s)]G, f(s) by device Horner (+ inverse NTT for Lagrange-basis columns)"},
         "note": "MSM/NTT trace replay on synthetic polynomials (no Rust toolchain here); CPU-side parts of create_proof "
@@ -260,6 +301,7 @@ def run_replay(shape_name: str, device=None, group=None, include_host_pointer_es
             "total": t_msm * (counts["msm_sparse"] + counts["msm_dense"]) + t_ntt_n * counts["intt_n"]
                      + t_ntt_e * (counts["coset_ntt_ext"] + counts["intt_ext"]),
             "note": "PCIe-inclusive: every call uploads its scalars / moves its array both ways"}
+    gate_prog.destroy()
     if world > 1 and not job_mode:
         release_bases(g_h)
         release_bases(gl_h)
