@@ -17,9 +17,11 @@
 //                reserved with ONE atomic per workgroup, so there is no global scan, no per-item global
 //                atomic (tried first: 4.4 M of them at 2^18 cost 0.17 ms per pass) and nothing to clear
 //   C  K3        the same accumulation chain as the general path (msm_dev.h: accumulate_chain)
-//   D  reduce 1  per (window, range, 256 segments): bucket = sum of its task partials (buckets cut into many
-//                tasks: by groups of lanes, all such buckets of the workgroup at once), running sums over SEG
-//                buckets per lane, short scalar multiple, LDS tree
+//   D  reduce 1  per (window, range): bucket = sum of its task partials (buckets cut into many tasks: by groups of
+//                lanes, all such buckets of the workgroup at once); then a workgroup takes the form its range needs:
+//                DENSE ranges -- running sums over SEG buckets per lane, short scalar multiple, LDS tree; SPARSE ranges
+//                (few non-empty buckets: advice columns) -- one lane per NON-EMPTY bucket, its sum times its weight,
+//                LDS tree, so the work follows the data instead of the bucket count
 //   E  reduce 2  per window: tree over D's outputs -> external format
 // SEG is chosen so that D runs at most one wave per SIMD (the depth of a lane's chain is what costs, not the work).
 #include <hip/hip_runtime.h>
@@ -158,7 +160,8 @@ __device__ __forceinline__ void window_for_each_digit(const int32_t* __restrict_
 // written in order of decreasing length.
 __global__ __launch_bounds__(SS_THREADS) void msm_s_sort_kernel(const int32_t* __restrict__ digits, uint32_t* __restrict__ toff,
                                                                 uint32_t* __restrict__ gctr, uint4* __restrict__ desc,
-                                                                uint32_t* __restrict__ sorted, uint32_t n, uint32_t NBh, uint32_t H,
+                                                                uint32_t* __restrict__ sorted, uint32_t* __restrict__ nz,
+                                                                uint32_t* __restrict__ nzc, uint32_t n, uint32_t NBh, uint32_t H,
                                                                 uint32_t L) {
   extern __shared__ uint32_t sm[];
   const uint32_t NBP = NBh + 1;
@@ -181,17 +184,19 @@ __global__ __launch_bounds__(SS_THREADS) void msm_s_sort_kernel(const int32_t* _
   __syncthreads();
   const uint32_t per = (NBP + SS_THREADS - 1) / SS_THREADS;
   const uint32_t b0 = tid * per < NBP ? tid * per : NBP, b1 = b0 + per < NBP ? b0 + per : NBP;
-  uint32_t sp = 0, st = 0;
+  uint32_t sp = 0, st = 0, sz = 0;
   for (uint32_t b = b0; b < b1; ++b) {
     const uint32_t c = cnt[b], full = c / L, rem = c - full * L;
     sp += c;
     st += full + (rem ? 1u : 0u);
+    sz += c ? 1u : 0u;
     if (full) atomicAdd(&kh[s_task_key(L)], full);
     if (rem) atomicAdd(&kh[s_task_key(rem)], 1u);
   }
-  uint32_t tot_p = 0, tot_t = 0, tot_k = 0;
+  uint32_t tot_p = 0, tot_t = 0, tot_k = 0, tot_z = 0;
   uint32_t rp = block_excl_scan_1024(sp, wsum, tot_p);
   uint32_t rt = block_excl_scan_1024(st, wsum, tot_t);
+  uint32_t rz = block_excl_scan_1024(sz, wsum, tot_z);     // the list of non-empty buckets (reduce 1 picks its form by it)
   {
     const uint32_t kv = kh[tid];
     const uint32_t ke = block_excl_scan_1024(kv, wsum, tot_k);
@@ -211,6 +216,7 @@ __global__ __launch_bounds__(SS_THREADS) void msm_s_sort_kernel(const int32_t* _
     const uint32_t start = base_p + rp;
     cnt[b] = rp;                              // the bucket's cursor for the scatter pass (local to this run)
     tw[b] = base_t + rt;
+    if (c) nz[(size_t)v * NBh + rz++] = b;
     if (full) {
       const uint32_t key = s_task_key(L), at = kbase[key] + atomicAdd(&kh[key], full);
       const uint32_t slot = full > 64 ? atomicAdd(&hot_n, 1u) : S_HOT;
@@ -227,7 +233,10 @@ __global__ __launch_bounds__(SS_THREADS) void msm_s_sort_kernel(const int32_t* _
     rp += c;
     rt += full + (rem ? 1u : 0u);
   }
-  if (tid == SS_THREADS - 1) tw[NBP] = base_t + tot_t;
+  if (tid == SS_THREADS - 1) {
+    tw[NBP] = base_t + tot_t;
+    nzc[v] = tot_z;
+  }
   __syncthreads();
   const uint32_t nh = hot_n < S_HOT ? hot_n : S_HOT;
   for (uint32_t e = 0; e < nh; ++e) {
@@ -258,32 +267,14 @@ __global__ __launch_bounds__(ACC_THREADS) void msm_s_accumulate_kernel(const uin
   store_jac(partial + (size_t)d.y * PT_WORDS, res);
 }
 
-// ---- D: buckets -> one point per (virtual window, group of 256 segments) ---------------------------
-__global__ __launch_bounds__(WIN_THREADS) void msm_s_reduce1_kernel(uint32_t* __restrict__ partial, const uint32_t* __restrict__ toff,
-                                                                    uint32_t* __restrict__ seg1, uint32_t NBh, uint32_t H, uint32_t SEG,
-                                                                    uint32_t G1n) {
-  __shared__ uint32_t tree[WIN_THREADS * PT_WORDS];
-  __shared__ uint32_t hot_n, hot_b[S_HOT_LIST], hot_lane0[S_HOT_LIST + 1], round_hi, round_maxl;
-  const uint32_t v = blockIdx.y, g = blockIdx.x, tid = threadIdx.x;
-  const uint32_t h = v % H;
-  const uint32_t* tw = toff + (size_t)v * (NBh + 2);
-  const uint32_t sgi = g * WIN_THREADS + tid;
-  const uint32_t lo = sgi * SEG + 1;             // local bucket numbers lo .. hi
-  const bool valid = lo <= NBh;
-  const uint32_t hi = valid ? (lo + SEG - 1 < NBh ? lo + SEG - 1 : NBh) : 0;
-  if (tid == 0) hot_n = 0;
-  __syncthreads();
-  if (valid)
-    for (uint32_t b = lo; b <= hi; ++b)
-      if (tw[b + 1] - tw[b] > S_FINALIZE_SERIAL) {
-        const uint32_t s = atomicAdd(&hot_n, 1u);
-        if (s < S_HOT_LIST) hot_b[s] = b;
-      }
-  __syncthreads();
-  const uint32_t nh = hot_n < S_HOT_LIST ? hot_n : S_HOT_LIST;
-  // Buckets cut into many tasks (hot buckets of skewed columns): a group of ceil(count / 4) lanes (at most the
-  // whole workgroup) each sums a strided share of the partials, then the group is folded by a segmented tree;
-  // as many such buckets as fit 256 lanes are handled per round.  The sum is left in the bucket's first partial.
+// ---- D: buckets -> one point per (virtual window, workgroup) ---------------------------------------------
+// Buckets cut into many tasks (hot buckets of skewed columns): a group of ceil(count / 4) lanes (at most the whole
+// workgroup) each sums a strided share of the partials, then the group is folded by a segmented tree; as many such
+// buckets as fit 256 lanes are handled per round.  The sum is left in the bucket's first partial.  hot_b[0 .. nh)
+// lists the workgroup's buckets with more than S_FINALIZE_SERIAL partials (collected by the caller).
+__device__ __forceinline__ void reduce_hot_buckets(uint32_t* __restrict__ partial, const uint32_t* __restrict__ tw, uint32_t* tree,
+                                                   const uint32_t* hot_b, uint32_t nh, uint32_t* hot_lane0, uint32_t* round_info) {
+  const uint32_t tid = threadIdx.x;
   for (uint32_t e0 = 0; e0 < nh;) {
     if (tid == 0) {
       uint32_t used = 0, e = e0, maxl = 1;
@@ -298,11 +289,11 @@ __global__ __launch_bounds__(WIN_THREADS) void msm_s_reduce1_kernel(uint32_t* __
         ++e;
       }
       hot_lane0[e] = used;
-      round_hi = e;
-      round_maxl = maxl;
+      round_info[0] = e;
+      round_info[1] = maxl;
     }
     __syncthreads();
-    const uint32_t e1 = round_hi, maxl = round_maxl;
+    const uint32_t e1 = round_info[0], maxl = round_info[1];
     uint32_t my_e = e1, r = 0, lanes = 0;
     for (uint32_t e = e0; e < e1; ++e)
       if (tid >= hot_lane0[e] && tid < hot_lane0[e + 1]) {
@@ -331,32 +322,93 @@ __global__ __launch_bounds__(WIN_THREADS) void msm_s_reduce1_kernel(uint32_t* __
     __syncthreads();
     e0 = e1;
   }
-  G1Jac run = g1_identity(), acc = g1_identity();
-  if (valid) {
-    for (uint32_t b = hi; b >= lo; --b) {
-      const uint32_t t0 = tw[b], t1 = tw[b + 1];
-      G1Jac val = g1_identity();
-      bool summed = false;
-      if (t1 - t0 > S_FINALIZE_SERIAL)
-        for (uint32_t e = 0; e < nh; ++e)
-          if (hot_b[e] == b) summed = true;
-      if (summed) {
-        val = load_jac(partial + (size_t)t0 * PT_WORDS);
-      } else {
-        for (uint32_t t = t0; t < t1; ++t) val = g1_add(val, load_jac(partial + (size_t)t * PT_WORDS));
+}
+
+// the sum of bucket b's partials (its first partial already holds it if the bucket is in the workgroup's hot list)
+__device__ __forceinline__ G1Jac bucket_value(const uint32_t* __restrict__ partial, const uint32_t* __restrict__ tw, uint32_t b,
+                                              const uint32_t* hot_b, uint32_t nh) {
+  const uint32_t t0 = tw[b], t1 = tw[b + 1];
+  bool summed = false;
+  if (t1 - t0 > S_FINALIZE_SERIAL)
+    for (uint32_t e = 0; e < nh; ++e)
+      if (hot_b[e] == b) summed = true;
+  if (summed) return load_jac(partial + (size_t)t0 * PT_WORDS);
+  G1Jac val = g1_identity();
+  for (uint32_t t = t0; t < t1; ++t) val = g1_add(val, load_jac(partial + (size_t)t * PT_WORDS));
+  return val;
+}
+
+__device__ __forceinline__ G1Jac small_multiple(const G1Jac& p, uint32_t m) {       // m * p by double-and-add, m < 2^31
+  G1Jac rr = g1_identity();
+  if (m == 0 || p.inf) return rr;
+  for (int bit = 31 - __clz(m); bit >= 0; --bit) {
+    rr = g1_double(rr);
+    if ((m >> bit) & 1) rr = g1_add(rr, p);
+  }
+  return rr;
+}
+
+// A virtual window is "sparse" when at most NBh / S_SPARSE_DIV of its buckets hold anything (advice columns: a few
+// hundred small values and six blinding rows in 2^18 rows): then the work is taken per NON-EMPTY bucket (form 2 below)
+// instead of per segment of the whole bucket range.
+constexpr uint32_t S_SPARSE_DIV = 8;
+
+// One launch covers both forms (a workgroup takes the form its range needs, so dense and sparse ranges of one MSM run
+// side by side): form 1 (dense) -- running sums over SEG buckets per lane, short scalar multiple; form 2 (sparse) -- one
+// lane per non-empty bucket, its sum times its weight.  Either way an LDS tree folds the workgroup's lanes.
+__global__ __launch_bounds__(WIN_THREADS) void msm_s_reduce1_kernel(uint32_t* __restrict__ partial, const uint32_t* __restrict__ toff,
+                                                                    const uint32_t* __restrict__ nz, const uint32_t* __restrict__ nzc,
+                                                                    uint32_t* __restrict__ seg1, uint32_t NBh, uint32_t H, uint32_t SEG,
+                                                                    uint32_t G1n) {
+  __shared__ uint32_t tree[WIN_THREADS * PT_WORDS];
+  __shared__ uint32_t hot_n, hot_b[S_HOT_LIST], hot_lane0[S_HOT_LIST + 1], round_info[2];
+  const uint32_t v = blockIdx.y, g = blockIdx.x, tid = threadIdx.x;
+  const uint32_t h = v % H;
+  const uint32_t* tw = toff + (size_t)v * (NBh + 2);
+  const uint32_t count = nzc[v];
+  G1Jac acc = g1_identity();
+  if (count > NBh / S_SPARSE_DIV) {
+    const uint32_t sgi = g * WIN_THREADS + tid;
+    const uint32_t lo = sgi * SEG + 1;             // local bucket numbers lo .. hi
+    const bool valid = lo <= NBh;
+    const uint32_t hi = valid ? (lo + SEG - 1 < NBh ? lo + SEG - 1 : NBh) : 0;
+    if (tid == 0) hot_n = 0;
+    __syncthreads();
+    if (valid)
+      for (uint32_t b = lo; b <= hi; ++b)
+        if (tw[b + 1] - tw[b] > S_FINALIZE_SERIAL) {
+          const uint32_t s = atomicAdd(&hot_n, 1u);
+          if (s < S_HOT_LIST) hot_b[s] = b;
+        }
+    __syncthreads();
+    const uint32_t nh = hot_n < S_HOT_LIST ? hot_n : S_HOT_LIST;
+    reduce_hot_buckets(partial, tw, tree, hot_b, nh, hot_lane0, round_info);
+    G1Jac run = g1_identity();
+    if (valid) {
+      for (uint32_t b = hi; b >= lo; --b) {
+        run = g1_add(run, bucket_value(partial, tw, b, hot_b, nh));
+        acc = g1_add(acc, run);
       }
-      run = g1_add(run, val);
-      acc = g1_add(acc, run);
+      // sum (b - lo + 1) B_b is in acc; the bucket's weight is h * NBh + b, so (h * NBh + lo - 1) * sum B_b remains
+      acc = g1_add(acc, small_multiple(run, h * NBh + lo - 1));
     }
-    // sum (b - lo + 1) B_b is in acc; the bucket's weight is h * NBh + b, so (h * NBh + lo - 1) * sum B_b remains
-    const uint32_t m = h * NBh + lo - 1;
-    if (m != 0 && !run.inf) {
-      G1Jac rr = g1_identity();
-      for (int bit = 31 - __clz(m); bit >= 0; --bit) {
-        rr = g1_double(rr);
-        if ((m >> bit) & 1) rr = g1_add(rr, run);
+  } else {
+    const uint32_t* list = nz + (size_t)v * NBh;
+    const uint32_t stride = G1n * WIN_THREADS;
+    for (uint32_t i0 = g * WIN_THREADS; i0 < count; i0 += stride) {          // one round for every realistic count
+      const uint32_t i = i0 + tid;
+      const uint32_t b = i < count ? list[i] : 0;
+      if (tid == 0) hot_n = 0;
+      __syncthreads();
+      if (b != 0 && tw[b + 1] - tw[b] > S_FINALIZE_SERIAL) {
+        const uint32_t s = atomicAdd(&hot_n, 1u);
+        if (s < S_HOT_LIST) hot_b[s] = b;
       }
-      acc = g1_add(acc, rr);
+      __syncthreads();
+      const uint32_t nh = hot_n < S_HOT_LIST ? hot_n : S_HOT_LIST;
+      reduce_hot_buckets(partial, tw, tree, hot_b, nh, hot_lane0, round_info);
+      if (b != 0) acc = g1_add(acc, small_multiple(bucket_value(partial, tw, b, hot_b, nh), h * NBh + b));
+      __syncthreads();
     }
   }
   const G1Jac res = block_sum_points(tree, acc);
@@ -438,6 +490,8 @@ int msm_issue_small(DeviceCtx& ctx, int slot, const uint32_t* d_scalars_ext, con
   const size_t o_digits = carve(pairs_max * 4);
   const size_t o_toff = carve((size_t)V * (NBh + 2) * 4);
   const size_t o_gctr = carve(16);
+  const size_t o_nz = carve((size_t)V * NBh * 4);
+  const size_t o_nzc = carve((size_t)V * 4);
   const size_t o_desc = carve(T_max * 16);
   const size_t o_sorted = carve(pairs_max * 4);
   const size_t o_partial = carve(T_max * PT_WORDS * 4);
@@ -448,6 +502,8 @@ int msm_issue_small(DeviceCtx& ctx, int slot, const uint32_t* d_scalars_ext, con
   int32_t* d_digits = (int32_t*)(ws + o_digits);
   uint32_t* d_toff = (uint32_t*)(ws + o_toff);
   uint32_t* d_gctr = (uint32_t*)(ws + o_gctr);
+  uint32_t* d_nz = (uint32_t*)(ws + o_nz);
+  uint32_t* d_nzc = (uint32_t*)(ws + o_nzc);
   uint4* d_desc = (uint4*)(ws + o_desc);
   uint32_t* d_sorted = (uint32_t*)(ws + o_sorted);
   uint32_t* d_partial = (uint32_t*)(ws + o_partial);
@@ -479,7 +535,7 @@ int msm_issue_small(DeviceCtx& ctx, int slot, const uint32_t* d_scalars_ext, con
   HM_HIP_CHECK(hipGetLastError());
   HM_HIP_CHECK(hipEventRecord(ev[1], stream));
   hipLaunchKernelGGL(msm_s_sort_kernel, dim3(V), dim3(SS_THREADS), lds_sort, stream, (const int32_t*)d_digits, d_toff, d_gctr, d_desc,
-                     d_sorted, (uint32_t)n, NBh, H, L);
+                     d_sorted, d_nz, d_nzc, (uint32_t)n, NBh, H, L);
   HM_HIP_CHECK(hipGetLastError());
   HM_HIP_CHECK(hipEventRecord(ev[2], stream));
   HM_HIP_CHECK(hipEventRecord(ev[5], stream));
@@ -488,8 +544,8 @@ int msm_issue_small(DeviceCtx& ctx, int slot, const uint32_t* d_scalars_ext, con
   HM_HIP_CHECK(hipGetLastError());
   HM_HIP_CHECK(hipEventRecord(ev[6], stream));
   HM_HIP_CHECK(hipEventRecord(ev[3], stream));
-  hipLaunchKernelGGL(msm_s_reduce1_kernel, dim3(G1n, V), dim3(WIN_THREADS), 0, stream, d_partial, (const uint32_t*)d_toff, d_seg1, NBh,
-                     H, SEG, G1n);
+  hipLaunchKernelGGL(msm_s_reduce1_kernel, dim3(G1n, V), dim3(WIN_THREADS), 0, stream, d_partial, (const uint32_t*)d_toff,
+                     (const uint32_t*)d_nz, (const uint32_t*)d_nzc, d_seg1, NBh, H, SEG, G1n);
   hipLaunchKernelGGL(msm_s_reduce2_kernel, dim3(W), dim3(WIN_THREADS), 0, stream, (const uint32_t*)d_seg1, H * G1n, d_win,
                      (const uint32_t*)d_gctr, d_tot);
   HM_HIP_CHECK(hipGetLastError());
