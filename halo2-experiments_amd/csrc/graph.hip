@@ -30,10 +30,16 @@ constexpr int GE_THREADS = 256;
 
 enum GraphOp : uint32_t { GOP_ADD = 0, GOP_SUB = 1, GOP_MUL = 2, GOP_SQUARE = 3, GOP_DOUBLE = 4, GOP_NEGATE = 5, GOP_STORE = 6, GOP_MULADD = 7 };
 enum GraphSrc : uint32_t { GSRC_CONST = 0, GSRC_INTER = 1, GSRC_COLUMN = 2, GSRC_PREV = 3 };
-// a source is one word: kind (bits 30..31) | rotation index (bits 20..29) | index (bits 0..19)
+// a source is one word: kind (bits 30..31) | rotation index (bits 20..29) | index (bits 0..19); a column source uses
+// index bits 0..13 for the column and bits 14..19 for the column's log2 row count when it is SHORTER than the domain
+// (read at row mod 2^that; 0 = a full-size column).  The period lives in the instruction, not in a per-call table: a byte
+// table inside the by-value argument struct compiled to vector loads from the kernel-argument segment and aborted at run
+// time (ROCm 7.2); everything the kernel takes from its arguments is now reached by scalar loads.
 __host__ __device__ inline uint32_t gsrc_kind(uint32_t s) { return s >> 30; }
 __host__ __device__ inline uint32_t gsrc_rot(uint32_t s) { return (s >> 20) & 1023u; }
 __host__ __device__ inline uint32_t gsrc_index(uint32_t s) { return s & 0xfffffu; }
+__host__ __device__ inline uint32_t gsrc_column(uint32_t s) { return s & 0x3fffu; }
+__host__ __device__ inline uint32_t gsrc_log_rows(uint32_t s) { return (s >> 14) & 63u; }
 
 struct GraphCalc {      // device form: 5 words
   uint32_t op, a, b, c, target;
@@ -48,7 +54,7 @@ __device__ __forceinline__ Fr ge_from_ext(const uint32_t* __restrict__ p) {
   return fe_mul(fe_unpack<FrParams>(w), fe_const<FrParams>(FrParams::EXT2INT));
 }
 
-constexpr uint32_t GE_MAX_COLUMNS = 384;
+constexpr uint32_t GE_MAX_COLUMNS = 256;   // the by-value table must stay well inside the 4 KiB kernel-argument segment
 constexpr uint32_t GE_MAX_DYN = 16;
 struct GraphColumns {        // the call's column table and per-call constants, by value (captured at launch)
   const uint32_t* p[GE_MAX_COLUMNS];
@@ -78,8 +84,10 @@ __device__ __forceinline__ Fr ge_fetch(uint32_t src, const GraphColumns& columns
     }
     HM_DECLARE(r, 1.0);
   } else if (kind == GSRC_COLUMN) {
-    const uint64_t row = (idx + (uint64_t)(int64_t)rotations[gsrc_rot(src)]) & mask;   // two's complement: a negative rotation wraps
-    r = ge_from_ext(columns.p[index] + row * 8);
+    uint64_t row = (idx + (uint64_t)(int64_t)rotations[gsrc_rot(src)]) & mask;   // two's complement: a negative rotation wraps
+    const uint32_t lr = gsrc_log_rows(src);          // a short column (the vanishing polynomial's inverse pattern) is periodic
+    if (lr != 0) row &= (1ull << lr) - 1ull;
+    r = ge_from_ext(columns.p[gsrc_column(src)] + row * 8);
   } else {
     r = ge_from_ext(prev);
   }
@@ -151,7 +159,7 @@ static bool src_ok(uint32_t s, size_t n_const, size_t n_inter, size_t n_cols, si
   switch (gsrc_kind(s)) {
     case GSRC_CONST: return gsrc_index(s) < n_const;
     case GSRC_INTER: return gsrc_index(s) < n_inter;
-    case GSRC_COLUMN: return gsrc_index(s) < n_cols && gsrc_rot(s) < n_rot;
+    case GSRC_COLUMN: return gsrc_column(s) < n_cols && gsrc_rot(s) < n_rot && gsrc_log_rows(s) <= 30;
     default: return true;
   }
 }

@@ -92,6 +92,16 @@ class Challenge(Expression):
 
 
 @dataclass(frozen=True)
+class ProofScalar(Expression):
+    """beta / gamma / theta of the proof as a leaf: upstream has them as ValueSource kinds only (its permutation and
+    lookup terms are hand-written loops); here those terms are expression trees too, so they need a leaf."""
+    name: str        # "Beta" | "Gamma" | "Theta"
+
+
+BETA, GAMMA, THETA = ProofScalar("Beta"), ProofScalar("Gamma"), ProofScalar("Theta")
+
+
+@dataclass(frozen=True)
 class Negated(Expression):
     a: Expression
 
@@ -165,6 +175,8 @@ class GraphEvaluator:
             return self.add_calculation(("Store", (type(e).__name__, e.column, rot)))
         if isinstance(e, Challenge):
             return self.add_calculation(("Store", ("Challenge", e.index)))
+        if isinstance(e, ProofScalar):
+            return self.add_calculation(("Store", (e.name,)))
         if isinstance(e, Negated):
             if isinstance(e.a, Constant):
                 return self.add_constant(-e.a.value)
@@ -214,9 +226,21 @@ class GraphEvaluator:
         parts = tuple(self.add_expression(p) for p in polynomials)
         return self.add_calculation(("Horner", ("PreviousValue",), parts, ("Y",)))
 
+    def add_vanishing_division(self, t_inverse_column: Expression):
+        """EvaluationDomain::divide_by_vanishing_poly as the program's last step: value *= t_inv[idx mod 2^(extended_k - k)],
+        with the inverse pattern given as a (short, periodically read) column."""
+        if not self.calculations:
+            raise ValueError("add_vanishing_division: the program is empty")
+        last = ("Intermediate", self.calculations[-1][1])
+        return self.add_calculation(("Mul", last, self.add_expression(t_inverse_column)))
+
     # -- lowering to the device program ----------------------------------------------------------------------
-    def compile(self, num_fixed: int, num_advice: int, num_instance: int, num_challenges: int = 0, rot_scale: int = 1) -> "CompiledGraph":
-        """Column table = fixed | advice | instance.  Per-call constants = challenges..., beta, gamma, theta, y."""
+    def compile(self, num_fixed: int, num_advice: int, num_instance: int, num_challenges: int = 0, rot_scale: int = 1,
+                short_columns: Dict[int, int] = None) -> "CompiledGraph":
+        """Column table = fixed | advice | instance.  Per-call constants = challenges..., beta, gamma, theta, y.
+        short_columns: {column table index: log2(rows)} for columns shorter than the domain, read periodically (the inverse
+        vanishing-polynomial pattern)."""
+        short_columns = short_columns or {}
         n_static = len(self.constants)
         dyn_index = {("Challenge", i): n_static + i for i in range(num_challenges)}
         for j, name in enumerate(("Beta", "Gamma", "Theta", "Y")):
@@ -236,7 +260,7 @@ class GraphEvaluator:
                 col = col_base[kind] + vs[1]
                 if not 0 <= vs[1] < {"Fixed": num_fixed, "Advice": num_advice, "Instance": num_instance}[kind]:
                     raise ValueError(f"{kind} column {vs[1]} out of range")
-                return (2 << 30) | (vs[2] << 20) | col
+                return (2 << 30) | (vs[2] << 20) | (short_columns.get(col, 0) << 14) | col
             if kind == "PreviousValue":
                 return 3 << 30
             if vs in dyn_index:
@@ -262,14 +286,15 @@ class GraphEvaluator:
             else:
                 words += [ops[name], src(calc[1]), 0, 0, target]
         return CompiledGraph(np.array(words, dtype=np.uint32).reshape(-1, 5), list(self.constants), num_challenges + 4,
-                             [r * rot_scale for r in self.rotations], n_cols, next_inter[0], num_challenges)
+                             [r * rot_scale for r in self.rotations], n_cols, next_inter[0], num_challenges, dict(short_columns))
 
 
 class CompiledGraph:
     """A program uploaded to the device (``hm_graph_create``); ``evaluate`` = upstream's per-row loop of evaluate_h."""
 
     def __init__(self, calcs: np.ndarray, constants: List[int], n_dynamic: int, rotations: List[int], n_columns: int,
-                 n_intermediates: int, num_challenges: int):
+                 n_intermediates: int, num_challenges: int, short_columns: Dict[int, int] = None):
+        self.short_columns = short_columns or {}
         self.calcs, self.constants, self.n_dynamic = np.ascontiguousarray(calcs), constants, n_dynamic
         self.rotations, self.n_columns, self.n_intermediates = rotations, n_columns, n_intermediates
         self.num_challenges = num_challenges
@@ -292,9 +317,10 @@ class CompiledGraph:
             raise ValueError("evaluate: the extended domain size must be a power of two")
         if len(columns) != self.n_columns or len(challenges) != self.num_challenges:
             raise ValueError("evaluate: column / challenge count differs from the compiled program's")
-        for c in columns:
-            if _tensor_rows(c, 4, "column") != size:
-                raise ValueError("evaluate: every column must have the extended domain's size")
+        for i, c in enumerate(columns):
+            want = (1 << self.short_columns[i]) if i in self.short_columns else size
+            if _tensor_rows(c, 4, "column") != want:
+                raise ValueError(f"evaluate: column {i} must hold {want} rows")
         ptrs = (ctypes.c_void_p * max(len(columns), 1))(*[c.data_ptr() for c in columns])
         dyn = np.stack([fr_words(v) for v in list(challenges) + [beta, gamma, theta, y]])
         _lib.check(_lib.load().hm_graph_evaluate_dev(ctypes.c_uint64(self.handle), ptrs, len(columns), _ptr(dyn), dyn.shape[0],
@@ -305,3 +331,54 @@ class CompiledGraph:
         if self.handle:
             _lib.check(_lib.load().hm_graph_destroy(ctypes.c_uint64(self.handle)))
             self.handle = 0
+
+
+# ---- the permutation and lookup arguments of evaluate_h as expression lists ----------------------------------------
+# Upstream writes these terms as explicit loops over the rows (plonk/evaluation.rs::evaluate_h); each term enters the
+# running value as value = value * y + term.  As expression trees over the same column table they go through the same
+# device evaluator as the gates: add_custom_gates(gates + permutation_expressions(...) + lookup_expressions(...)).
+def permutation_expressions(columns: Sequence[Expression], sigmas: Sequence[Expression], z, l0: Expression, l_last: Expression,
+                            l_active: Expression, x_coset: Expression, chunk_len: int, delta: int, last_rotation: int) -> List[Expression]:
+    """columns[j] / sigmas[j]: the j-th permuted column and its sigma polynomial on the extended domain; z[i](rot): the
+    i-th grand-product polynomial at a rotation (one per chunk of chunk_len columns); x_coset: the column zeta * omega_ext^idx
+    (upstream's running `beta_term` times ZETA); last_rotation = -(blinding_factors + 1)."""
+    nsets = (len(columns) + chunk_len - 1) // chunk_len
+    if nsets == 0:
+        return []
+    out = [(1 - z[0](0)) * l0,
+           (z[nsets - 1](0) * z[nsets - 1](0) - z[nsets - 1](0)) * l_last]
+    for i in range(1, nsets):
+        out.append((z[i](0) - z[i - 1](last_rotation)) * l0)
+    current_delta = BETA * x_coset                       # delta_start * beta_term = beta * zeta * omega_ext^idx
+    for i in range(nsets):
+        cols = columns[i * chunk_len:(i + 1) * chunk_len]
+        sigs = sigmas[i * chunk_len:(i + 1) * chunk_len]
+        left = z[i](1)
+        for c, sg in zip(cols, sigs):
+            left = left * (c + BETA * sg + GAMMA)
+        right = z[i](0)
+        for c in cols:
+            right = right * (c + current_delta + GAMMA)
+            current_delta = current_delta * delta
+        out.append((left - right) * l_active)
+    return out
+
+
+def lookup_expressions(inputs: Sequence[Expression], tables: Sequence[Expression], z, permuted_input, permuted_table,
+                       l0: Expression, l_last: Expression, l_active: Expression) -> List[Expression]:
+    """One lookup argument: inputs / tables are its input and table expressions (compressed by Horner in theta), z(rot) its
+    grand product, permuted_input(rot) / permuted_table(rot) the permuted columns A' and S'."""
+    def compress(exprs):
+        acc = Constant(0)
+        for e in exprs:
+            acc = acc * THETA + e
+        return acc
+
+    table_value = (compress(inputs) + BETA) * (compress(tables) + GAMMA)
+    a, sp = permuted_input(0), permuted_table(0)
+    a_minus_s = a - sp
+    return [(1 - z(0)) * l0,
+            (z(0) * z(0) - z(0)) * l_last,
+            (z(1) * (a + BETA) * (sp + GAMMA) - z(0) * table_value) * l_active,
+            a_minus_s * l0,
+            a_minus_s * (a - permuted_input(-1)) * l_active]

@@ -180,13 +180,17 @@ int hm_fr_powers_dev(void* d_out, size_t n, const uint64_t x[4], void* stream);
  * resident in HBM.  A calculation is five words { op, a, b, c, target }:
  *   op      0 Add  1 Sub  2 Mul  3 Square  4 Double  5 Negate  6 Store  7 MulAdd (a * b + c: one Horner step)
  *   a b c   value sources: kind << 30 | rotation_index << 20 | index, with kind 0 Constant(index), 1 Intermediate(index),
- *           2 Column(index) at row (idx + rotations[rotation_index]) mod 2^log_size, 3 PreviousValue (d_values[idx] on entry)
+ *           2 Column(index & 0x3fff) at row (idx + rotations[rotation_index]) mod 2^log_size, 3 PreviousValue (d_values[idx] on entry)
  *   target  the intermediate this calculation defines (each is written exactly once, as upstream's are)
  * Upstream's Fixed / Advice / Instance queries are entries of one column table.  Constants [0, n_const) belong to the
  * program (the circuit's); constants [n_const, n_const + n_dynamic) are given with every call -- upstream's Challenge /
  * Beta / Gamma / Theta / Y sources, which change with every proof (n_dynamic <= 16).  Horner(start, parts, factor) is a
  * chain of MulAdd.  rotations are in ROWS (upstream's rot * 2^(extended_k - k)).  The value of the program is its last
  * calculation's (upstream GraphEvaluator::evaluate); it is written to d_values[idx] (2^log_size x 4 u64, external words).
+ * A Column source may name a column SHORTER than the domain: index = column | log2(rows) << 14 reads it at the row index
+ * modulo its 2^log2(rows) rows (log2(rows) = 0: a full-size column; the table holds at most 256 columns) -- the inverse
+ * vanishing-polynomial pattern of divide_by_vanishing_poly (period 2^(extended_k - k)) is such a column, so the division is
+ * the program's last multiplication.
  * hm_graph_create validates the program, assigns intermediates to a minimal number of slots by liveness and uploads it;
  * evaluation is asynchronous on `stream` and may run concurrently on different streams. */
 int hm_graph_create(const uint32_t* calcs, size_t n_calc, const uint64_t* constants, size_t n_const, size_t n_dynamic,

@@ -76,6 +76,8 @@ def evaluate_expression(e, fixed, advice, instance, challenges, idx: int, rot_sc
         return col[(idx + e.rotation * rot_scale) % isize]
     if name == "Challenge":
         return challenges[e.index]
+    if name == "ProofScalar":
+        return challenges[{"Beta": "beta", "Gamma": "gamma", "Theta": "theta"}[e.name]]     # challenges may be a dict here
     if name == "Negated":
         return -evaluate_expression(e.a, fixed, advice, instance, challenges, idx, rot_scale, isize) % R
     if name == "Sum":
@@ -87,3 +89,59 @@ def evaluate_expression(e, fixed, advice, instance, challenges, idx: int, rot_sc
     if name == "Scaled":
         return evaluate_expression(e.a, fixed, advice, instance, challenges, idx, rot_scale, isize) * e.factor % R
     raise TypeError(name)
+
+
+def evaluate_h_permutation_and_lookups(values, y, beta, gamma, theta, isize, rot_scale, extended_omega, zeta, delta,
+                                        perm_columns, perm_sigmas, perm_z, chunk_len, last_rotation, l0, l_last, l_active,
+                                        lookups, t_inverse=None):
+    """Restatement of the permutation and lookup loops of evaluate_h (upstream plonk/evaluation.rs [UPSTREAM-RECALLED]) on
+    Python integers; columns are lists of isize integers.  lookups: [(input_values, table_values, z, a_perm, s_perm)] where
+    input_values / table_values are lists of already-evaluated input / table expression columns (compressed here by theta).
+    Ends with divide_by_vanishing_poly when t_inverse (the 2^(extended_k - k) inverse evaluations) is given."""
+    values = list(values)
+    rot = lambda idx, r: (idx + r * rot_scale) % isize
+    nsets = len(perm_z)
+    if nsets:
+        for idx in range(isize):
+            beta_term = pow(extended_omega, idx, R)
+            v = values[idx]
+            r_next, r_last = rot(idx, 1), rot(idx, last_rotation)
+            v = (v * y + (1 - perm_z[0][idx]) * l0[idx]) % R
+            zl = perm_z[-1][idx]
+            v = (v * y + (zl * zl - zl) * l_last[idx]) % R
+            for i in range(1, nsets):
+                v = (v * y + (perm_z[i][idx] - perm_z[i - 1][r_last]) * l0[idx]) % R
+            current_delta = beta * zeta % R * beta_term % R
+            for i in range(nsets):
+                cols = perm_columns[i * chunk_len:(i + 1) * chunk_len]
+                sigs = perm_sigmas[i * chunk_len:(i + 1) * chunk_len]
+                left = perm_z[i][r_next]
+                for c, sg in zip(cols, sigs):
+                    left = left * (c[idx] + beta * sg[idx] + gamma) % R
+                right = perm_z[i][idx]
+                for c in cols:
+                    right = right * (c[idx] + current_delta + gamma) % R
+                    current_delta = current_delta * delta % R
+                v = (v * y + (left - right) * l_active[idx]) % R
+            values[idx] = v
+    for input_values, table_values, z, a_perm, s_perm in lookups:
+        for idx in range(isize):
+            ci = 0
+            for col in input_values:
+                ci = (ci * theta + col[idx]) % R
+            ct = 0
+            for col in table_values:
+                ct = (ct * theta + col[idx]) % R
+            table_value = (ci + beta) * (ct + gamma) % R
+            r_next, r_prev = rot(idx, 1), rot(idx, -1)
+            a_minus_s = (a_perm[idx] - s_perm[idx]) % R
+            v = values[idx]
+            v = (v * y + (1 - z[idx]) * l0[idx]) % R
+            v = (v * y + (z[idx] * z[idx] - z[idx]) * l_last[idx]) % R
+            v = (v * y + (z[r_next] * (a_perm[idx] + beta) % R * (s_perm[idx] + gamma) - z[idx] * table_value) * l_active[idx]) % R
+            v = (v * y + a_minus_s * l0[idx]) % R
+            v = (v * y + a_minus_s * (a_perm[idx] - a_perm[r_prev]) % R * l_active[idx]) % R
+            values[idx] = v
+    if t_inverse is not None:
+        values = [v * t_inverse[i % len(t_inverse)] % R for i, v in enumerate(values)]
+    return values

@@ -197,3 +197,59 @@ def test_device_graph_at_prover_size_and_argument_checks(pyref):
     assert lib.hm_graph_create(bad.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), 1, None, 0, 0, None, 0, 0, 8, ctypes.byref(h)) == -1
     bad = np.array([[9, 0, 0, 0, 0]], dtype=np.uint32)                        # unknown operation
     assert lib.hm_graph_create(bad.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), 1, None, 0, 0, None, 0, 0, 8, ctypes.byref(h)) == -1
+
+
+@pytest.mark.gpu
+def test_permutation_and_lookup_arguments_and_vanishing_division(pyref):
+    """The whole of evaluate_h after the gates: the permutation argument (two sets: chunked columns, the delta chain across
+    sets, the rotation to the last usable row), one lookup argument (two-expression input and table compressed by theta),
+    and divide_by_vanishing_poly as a periodically read column -- built as expression trees, run by the device evaluator,
+    against the oracle's restatement of upstream's row loops."""
+    import torch
+    from oracle import graph_ref
+    rng = random.Random(2024)
+    k, ek = 4, 6
+    n, isize, rot_scale = 1 << k, 1 << ek, 1 << (ek - k)
+    w_ext = pyref.fr_omega(ek)
+    zeta, delta = pyref.FR_ZETA if hasattr(pyref, "FR_ZETA") else 0x30644E72E131A029048B6E193FD84104CC37A73FEC2BC5E9B8CA0B2D36636F23, pow(7, 1 << 28, R)
+    col = lambda: [rng.randrange(R) for _ in range(isize)]
+    advice, fixed = [col() for _ in range(3)], [col() for _ in range(2)]
+    sigmas = [col() for _ in range(5)]
+    zs = [col(), col()]                                        # two permutation sets (chunk_len 3: 3 + 2 columns)
+    l0, l_last, l_active = col(), col(), col()
+    x_coset = [zeta * pow(w_ext, i, R) % R for i in range(isize)]
+    lk_z, lk_a, lk_s = col(), col(), col()
+    t_inv = [pow((pow(zeta * pow(w_ext, i, R) % R, n, R) - 1) % R, -1, R) for i in range(rot_scale)]
+    beta, gamma, theta, y = (rng.randrange(R) for _ in range(4))
+    prev = col()
+    chunk_len, last_rotation = 3, -6
+    # column table: fixed = [f0, f1, sigma0..4, z0, z1, l0, l_last, l_active, x_coset, lk_z, lk_a, lk_s, t_inv]; advice = 3
+    F = ev.Fixed
+    fx_all = fixed + sigmas + zs + [l0, l_last, l_active, x_coset, lk_z, lk_a, lk_s, t_inv]
+    i_sig, i_z, i_l0, i_ll, i_la, i_x, i_lz, i_lka, i_lks, i_t = 2, 7, 9, 10, 11, 12, 13, 14, 15, 16
+    perm_cols_e = [ev.Advice(0), ev.Advice(1), ev.Advice(2), F(0), F(1)]
+    perm_cols_v = advice + fixed
+    polys = ev.permutation_expressions(perm_cols_e, [F(i_sig + j) for j in range(5)], [lambda r, i=i: F(i_z + i, r) for i in range(2)],
+                                       F(i_l0), F(i_ll), F(i_la), F(i_x), chunk_len, delta, last_rotation)
+    inputs_e = [ev.Advice(0) * ev.Advice(1), ev.Advice(2) + F(0)]
+    tables_e = [F(1), F(0) * 3]
+    polys += ev.lookup_expressions(inputs_e, tables_e, lambda r: F(i_lz, r), lambda r: F(i_lka, r), lambda r: F(i_lks, r),
+                                   F(i_l0), F(i_ll), F(i_la))
+    g = ev.GraphEvaluator()
+    g.add_custom_gates(polys)
+    g.add_vanishing_division(F(i_t))
+    inputs_v = [[advice[0][i] * advice[1][i] % R for i in range(isize)], [(advice[2][i] + fixed[0][i]) % R for i in range(isize)]]
+    tables_v = [fixed[1], [fixed[0][i] * 3 % R for i in range(isize)]]
+    exp = graph_ref.evaluate_h_permutation_and_lookups(prev, y, beta, gamma, theta, isize, rot_scale, w_ext, zeta, delta, perm_cols_v,
+                                                       sigmas, zs, chunk_len, last_rotation, l0, l_last, l_active,
+                                                       [(inputs_v, tables_v, lk_z, lk_a, lk_s)], t_inverse=t_inv)
+    to_dev = lambda c: torch.from_numpy(pyref.fr_array(c).view(np.int64)).cuda()
+    cols = [to_dev(c) for c in fx_all + advice]
+    values = to_dev(prev)
+    prog = g.compile(len(fx_all), 3, 0, num_challenges=0, rot_scale=rot_scale, short_columns={i_t: ek - k})
+    try:
+        prog.evaluate(cols, values, beta=beta, gamma=gamma, theta=theta, y=y)
+        torch.cuda.synchronize()
+        assert np.array_equal(values.cpu().numpy().view(np.uint64), pyref.fr_array(exp))
+    finally:
+        prog.destroy()
