@@ -277,7 +277,7 @@ HM_HD bool g1x_madd_fast(G1Xyzz& acc, const G1Aff& q, bool neg) {
   const Fq rr = fe_sqr(r);
   const Fq t2 = fe_add(ppp, fe_dbl(qq));                      // PPP + 2Q  (limbs < 3*2^29)
   const Fq x3 = fe_norm(fe_sub<6, 31>(rr, t2));               // R^2 - PPP - 2Q
-  const Fq vx = fe_norm(fe_sub<9, 29>(qq, x3));               // Q - X3
+  const Fq vx = fe_sub<9, 29>(qq, x3);                        // Q - X3, left lazy (limbs < 2^30.6): only a multiplicand of the fused product
   const Fq ny = fe_sub<4, 29>(fe_zero<FqParams>(), acc.y);    // -Y1 (limbs < 2^30)
   acc.y = fe_mul2(r, vx, ny, ppp);                            // R (Q - X3) - Y1 PPP
   acc.x = x3;
