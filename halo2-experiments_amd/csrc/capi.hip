@@ -15,6 +15,7 @@ static thread_local std::string g_last_error;
 static std::mutex g_ctx_mu;
 static std::map<int, std::unique_ptr<DeviceCtx>> g_ctx;
 static std::vector<int> g_msm_devices;             // hm_set_msm_devices; empty = the calling thread's device
+static std::atomic<int> g_host_base_cache{1};      // hm_set_host_base_cache
 static constexpr size_t kMinShardPoints = 1 << 14; // below this many points per device a split only adds latency
 
 int hm_fail(int code, const std::string& what) {
@@ -189,6 +190,8 @@ int hm_shutdown(void) {
   for (auto& g : c.graphs) graph_release(*g);
   c.graphs.clear();
   c.io.release(); c.io_bases.release(); c.conv_bases.release(); c.conv_inf.release();
+  c.cached_host_n = 0;
+  c.cached_xy = nullptr;
   for (auto& a : c.aux) {
     a.scratch.release();
     a.table.release();
@@ -201,6 +204,11 @@ int hm_shutdown(void) {
     if (sl.h_land) { (void)hipHostFree(sl.h_land); sl.h_land = nullptr; }
     if (sl.ev_ready) { for (auto& e : sl.ev) (void)hipEventDestroy(e); sl.ev_ready = false; }
   }
+  return HM_OK;
+}
+
+int hm_set_host_base_cache(int enable) {
+  g_host_base_cache.store(enable != 0, std::memory_order_relaxed);
   return HM_OK;
 }
 
@@ -372,10 +380,47 @@ int hm_msm_bn256_g1_h(uint64_t handle, size_t offset, const uint64_t* scalars, s
   return jac_to_affine_out(jac, is_id, out_xy, out_is_identity);
 }
 
-// The drop-in form of best_multiexp: both arrays are host memory and both cross PCIe in the call.  The
-// library keeps NO pointer-keyed cache of the bases: a caller that reuses a buffer (a Rust Vec freed and
-// re-allocated at the same address with the same length, as the verifier's MSMs do) must never get a
-// commitment against stale points.  Callers that own a long-lived SRS use hm_register_bases once.
+// 256-bit digest of a host array over EVERY word (four independent multiply-rotate lanes, folded at the end).  It keys
+// the converted-base cache of the drop-in call: unlike round 1's 64-point probe it reads the whole array, so a buffer
+// that was mutated at any index -- or re-allocated at the same address with other contents -- hashes differently.  Not
+// cryptographic; the caller is the only party who could construct a collision, against itself.
+static void digest_words(const uint64_t* w, size_t count, uint64_t out[4]) {
+  uint64_t s0 = 0x9E3779B97F4A7C15ULL, s1 = 0xBF58476D1CE4E5B9ULL, s2 = 0x94D049BB133111EBULL, s3 = 0xD6E8FEB86659FD93ULL;
+  auto rotl = [](uint64_t x, int k) { return (x << k) | (x >> (64 - k)); };
+  size_t i = 0;
+  for (; i + 4 <= count; i += 4) {
+    s0 = rotl((s0 ^ w[i]) * 0xFF51AFD7ED558CCDULL, 29);
+    s1 = rotl((s1 ^ w[i + 1]) * 0xC4CEB9FE1A85EC53ULL, 31);
+    s2 = rotl((s2 ^ w[i + 2]) * 0x9FB21C651E98DF25ULL, 27);
+    s3 = rotl((s3 ^ w[i + 3]) * 0xA0761D6478BD642FULL, 33);
+  }
+  for (; i < count; ++i) s0 = rotl((s0 ^ w[i]) * 0xFF51AFD7ED558CCDULL, 29);
+  out[0] = s0 ^ rotl(s1, 17);
+  out[1] = s1 ^ rotl(s2, 23);
+  out[2] = s2 ^ rotl(s3, 41);
+  out[3] = s3 ^ rotl(s0, 11) ^ (uint64_t)count;
+}
+
+static void digest_bases(const uint64_t* bases, size_t n, uint64_t out[4]) {
+  const size_t words = n * 8;
+  const unsigned parts = words >= (1u << 20) ? 4u : 1u;      // >= 8 MiB: four host threads (the digest must stay cheaper than the upload)
+  uint64_t part[4][4];
+  if (parts == 1) {
+    digest_words(bases, words, out);
+    return;
+  }
+  std::thread th[3];
+  for (unsigned p = 1; p < parts; ++p)
+    th[p - 1] = std::thread([&, p] { digest_words(bases + words * p / parts, words * (p + 1) / parts - words * p / parts, part[p]); });
+  digest_words(bases, words / parts, part[0]);
+  for (unsigned p = 1; p < parts; ++p) th[p - 1].join();
+  digest_words(&part[0][0], 16, out);
+}
+
+// The drop-in form of best_multiexp: both arrays are host memory.  The scalars cross PCIe in every call; the converted
+// bases of the previous call are kept per device and reused only when the FULL-CONTENT digest and the length match (the
+// pointer is not part of the key: create_proof passes the same params.g / g_lagrange prefix to every commitment, and a
+// buffer reused with other contents -- the verifier's MSMs -- simply misses).  hm_set_host_base_cache(0) disables it.
 static int msm_host_one(const uint64_t* scalars, const uint64_t* bases, size_t n, uint64_t jac[12], int* is_id) {
   DeviceCtx* ctx = ctx_for_current_device();
   if (!ctx) return HM_ERR_NO_DEVICE;
@@ -383,17 +428,32 @@ static int msm_host_one(const uint64_t* scalars, const uint64_t* bases, size_t n
   if (n == 0) return msm_run(*ctx, nullptr, nullptr, nullptr, 0, 0, jac, is_id, nullptr);
   uint32_t* d_xy = (uint32_t*)ctx->conv_bases.ensure(n * 64);
   uint8_t* d_inf = (uint8_t*)ctx->conv_inf.ensure(n);
-  void* stage = ctx->io_bases.ensure(n * 64);
   void* d_s = ctx->io.ensure(n * 32);
-  if (!d_xy || !d_inf || !stage || !d_s) return hm_fail(HM_ERR_HIP, "hm_msm_bn256_g1: staging allocation failed");
+  if (!d_xy || !d_inf || !d_s) return hm_fail(HM_ERR_HIP, "hm_msm_bn256_g1: staging allocation failed");
   const double t0 = now_us();
-  HM_HIP_CHECK(hipMemcpy(stage, bases, n * 64, hipMemcpyHostToDevice));
-  int rc = msm_convert_bases((const uint32_t*)stage, d_xy, d_inf, n, nullptr);
-  if (rc != HM_OK) return rc;
+  uint64_t dg[4] = {0, 0, 0, 0};
+  const bool use_cache = g_host_base_cache.load(std::memory_order_relaxed) != 0;
+  if (use_cache) digest_bases(bases, n, dg);
+  const bool hit = use_cache && ctx->cached_host_n == n && ctx->cached_xy == d_xy &&
+                   std::memcmp(dg, ctx->cached_digest, sizeof dg) == 0;
+  if (!hit) {
+    ctx->cached_host_n = 0;
+    void* stage = ctx->io_bases.ensure(n * 64);
+    if (!stage) return hm_fail(HM_ERR_HIP, "hm_msm_bn256_g1: staging allocation failed");
+    HM_HIP_CHECK(hipMemcpy(stage, bases, n * 64, hipMemcpyHostToDevice));
+    int rc = msm_convert_bases((const uint32_t*)stage, d_xy, d_inf, n, nullptr);
+    if (rc != HM_OK) return rc;
+    ctx->calls.h2d_bytes += n * 64;
+    if (use_cache) {
+      ctx->cached_host_n = n;
+      ctx->cached_xy = d_xy;                    // a regrown buffer is a miss
+      std::memcpy(ctx->cached_digest, dg, sizeof dg);
+    }
+  }
   HM_HIP_CHECK(hipMemcpy(d_s, scalars, n * 32, hipMemcpyHostToDevice));
   ctx->calls.msm_h2d_us += now_us() - t0;
-  ctx->calls.h2d_bytes += n * 96;
-  rc = msm_run(*ctx, (const uint32_t*)d_s, d_xy, d_inf, n, 0, jac, is_id, nullptr);
+  ctx->calls.h2d_bytes += n * 32;
+  int rc = msm_run(*ctx, (const uint32_t*)d_s, d_xy, d_inf, n, 0, jac, is_id, nullptr);
   if (rc == HM_OK) count_msm(*ctx, n);
   return rc;
 }

@@ -158,6 +158,10 @@ struct DeviceCtx {
   std::vector<FreeBases> free_bases;      // recycled buffers (no hipFree => no device-wide synchronisation)
   std::vector<std::unique_ptr<GraphProgram>> graphs;
   uint64_t next_handle = 1;
+  // drop-in MSM: the converted bases of the previous call, keyed by a digest of the WHOLE host array (capi.hip)
+  size_t cached_host_n = 0;
+  const void* cached_xy = nullptr;
+  uint64_t cached_digest[4] = {0, 0, 0, 0};
   MsmStats last_msm;
   CallStats calls;
   bool msm_attr_set = false, ntt_attr_set = false, msm_small_attr_set = false;

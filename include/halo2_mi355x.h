@@ -61,9 +61,11 @@ const char* hm_version(void);
 /* sum_i scalars[i] * bases[i].  scalars: n x 4 u64 (Fr), bases: n x 8 u64 (G1Affine), both host
  * memory.  Result as an affine point (out_xy, Montgomery) plus an identity flag, which is the
  * canonical form of the G1 value best_multiexp returns; n == 0 yields the identity.
- * Both arrays cross PCIe in every call: the library keeps no pointer-keyed cache of converted bases (a
- * buffer reused at the same address with other contents must never yield a stale commitment).  A caller
- * that owns a long-lived base array -- ParamsKZG::g / g_lagrange -- registers it once (below). */
+ * The scalars cross PCIe in every call.  The converted bases of the previous call are reused only when a
+ * digest of the WHOLE base array (every word, 256 bits) and its length match -- never by pointer: a buffer
+ * mutated at any index, or re-allocated at the same address with other contents, is uploaded again
+ * (hm_set_host_base_cache(0) turns the reuse off altogether).  A caller that owns a long-lived base array --
+ * ParamsKZG::g / g_lagrange -- still does best to register it once (below): that skips the digest too. */
 int hm_msm_bn256_g1(const uint64_t* scalars, const uint64_t* bases, size_t n, uint64_t out_xy[8], int* out_is_identity);
 
 /* Same, Jacobian output (x, y, 1) / (0, 0, 0): the `C::Curve` value itself. */
@@ -114,6 +116,10 @@ int hm_set_msm_devices(const int* devices, int count);
  * fold of per-GPU partial results of a sharded best_multiexp after the RCCL all-gather.  Pure host
  * arithmetic on a handful of points (the exchange is ~96 B per rank); needs no device. */
 int hm_g1_sum(const uint64_t* points_xyz, size_t count, uint64_t out_xyz[12]);
+
+/* enable != 0 (default): hm_msm_bn256_g1* may reuse the previous call's converted bases when the full-content digest
+ * matches; 0: always upload and convert. */
+int hm_set_host_base_cache(int enable);
 
 /* Window-size override for experiments (0 = automatic). */
 int hm_msm_set_window(int c);

@@ -258,11 +258,34 @@ def test_sizes_off_the_power_of_two_grid(cref, pyref, n):
 
 
 def test_host_pointer_form_never_returns_a_stale_result(cref, golden):
-    """The drop-in call takes both arrays by host pointer and keeps NO pointer-keyed cache of the bases: a
-    buffer that is mutated in place -- at any index -- or re-used at the same address with other contents
-    (a Rust Vec freed and re-allocated, as the verifier's MSMs do) must give the result of its CURRENT
-    contents."""
+    """The drop-in call takes both arrays by host pointer and reuses converted bases only on a match of a digest over the
+    WHOLE array (never by pointer): a buffer that is mutated in place -- at any index -- or re-used at the same address
+    with other contents (a Rust Vec freed and re-allocated, as the verifier's MSMs do) must give the result of its CURRENT
+    contents; the same contents at another address may hit.  Checked with the reuse on and off."""
     g = golden["msm"]
+    lib = _lib.load()
+    for mode in (1, 0):
+        _lib.check(lib.hm_set_host_base_cache(mode))
+        try:
+            _stale_result_checks(cref, g)
+        finally:
+            _lib.check(lib.hm_set_host_base_cache(1))
+    # the digest covers the 2^16 x 8 words of a larger array in four host threads: one flipped bit anywhere is a miss
+    n = 1 << 17
+    gen = cref.g1_generator()
+    bases = h.g1_fixed_base_mul(rand_fr_gpu(n, 4711), gen).cpu().numpy().view(np.uint64).copy()
+    s = np.zeros((n, 4), dtype=np.uint64)
+    one = cref.fr_to_mont(np.array([[1, 0, 0, 0]], dtype=np.uint64))[0]
+    for i in (0, 1, n // 4 + 3, n // 2, n - 2, n - 1):
+        s[:] = 0
+        s[i] = one
+        first = h.best_multiexp(s, bases)
+        assert np.array_equal(first[:8], bases[i]), i                       # 1 * P_i
+        bases[i] = bases[(i + 5) % n]                                       # change ONE point in place (any thread's share)
+        assert np.array_equal(h.best_multiexp(s, bases)[:8], bases[i]), i   # the changed array must be seen
+
+
+def _stale_result_checks(cref, g):
     s, b = g["n1024_uniform_s"].copy(), g["n1024_uniform_b"].copy()
     assert g1_equal(h.best_multiexp(s, b), g["n1024_uniform_r"])
     assert g1_equal(h.best_multiexp(s, b), g["n1024_uniform_r"])
@@ -348,6 +371,7 @@ def test_call_counters(golden):
     import torch
     lib = _lib.load()
     g = golden["msm"]
+    _lib.check(lib.hm_set_host_base_cache(0))          # count the drop-in call's full upload (a digest hit would skip the bases)
     _lib.check(lib.hm_reset_stats())
     st = _lib.Stats()
     _lib.check(lib.hm_get_stats(ctypes.byref(st)))
@@ -371,6 +395,12 @@ def test_call_counters(golden):
     assert st.ntt_calls_by_log2[7] == 1 and st.ntt_calls_by_log2[10] == 3
     assert st.h2d_bytes == 1024 * 96 + 255 * 32 + 128 * 32 and st.d2h_bytes == 128 * 32
     assert st.msm_device_us > 0 and st.msm_h2d_us > 0 and st.ntt_device_us > 0
+    _lib.check(lib.hm_set_host_base_cache(1))
+    _lib.check(lib.hm_reset_stats())
+    h.best_multiexp(g["n1024_small_s"], g["n1024_small_b"])               # miss: 96 B per point
+    h.best_multiexp(g["n1024_small_s"], g["n1024_small_b"].copy())        # same contents at another address: 32 B per point
+    _lib.check(lib.hm_get_stats(ctypes.byref(st)))
+    assert st.h2d_bytes == 1024 * 96 + 1024 * 32
 
 
 def test_async_submit_wait_overlapping_streams(cref, golden):
