@@ -81,13 +81,13 @@ def cpu_baseline(log_sample, device):
     scalars_d, bases_d, _ = bench_inputs(n, 0, 4242, device)
     bases = bases_d.cpu().numpy().view(np.uint64)
     scalars = scalars_d.cpu().numpy().view(np.uint64)
-    threads = cpu_ref.default_threads()            # every core the box gives this process (HALO2_CPU_THREADS overrides)
+    threads = cpu_ref.default_threads()            # scheduler affinity capped by the container's CPU quota (HALO2_CPU_THREADS overrides)
     t0 = time.perf_counter()
     ref = cpu_ref.best_multiexp(scalars, bases, threads)
     dt = time.perf_counter() - t0
     got = h.best_multiexp(scalars, bases)
     ok = bool(np.array_equal(cpu_ref.g1_to_affine(ref)[0], got[:8]))
-    return {"value": n / dt, "unit": "points/s", "cores": threads, "cpu_model": cpu_model(), "kind": "port",
+    return {"value": n / dt, "unit": "points/s", "cores": threads, "cpus_visible": os.cpu_count(), "cpu_model": cpu_model(), "kind": "port",
             "sample": f"one 2^{log_sample}-point MSM, same input construction as the timed steps, {dt:.2f} s wall; "
                       "C restatement of halo2_proofs v2023_02_02 best_multiexp (not the Rust binary)",
             "agrees_with_gpu": ok}

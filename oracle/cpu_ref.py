@@ -46,14 +46,41 @@ def _c(a) -> np.ndarray:
     return np.ascontiguousarray(a, dtype=np.uint64)
 
 
+def _cgroup_cpu_quota() -> float:
+    """CPUs the container may use at once (cgroup v2 cpu.max, v1 cfs quota); inf when unlimited."""
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+            if quota != "max":
+                return float(quota) / float(period)
+    except (OSError, ValueError):
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+            quota = float(f.read())
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+            period = float(f.read())
+        if quota > 0:
+            return quota / period
+    except (OSError, ValueError):
+        pass
+    return float("inf")
+
+
 def default_threads() -> int:
+    """Every core this process may actually run on: the scheduler affinity, capped by the container's CPU quota (a box
+    that shows 256 CPUs but grants 16 runs 256 threads slower than 16); HALO2_CPU_THREADS overrides."""
     env = os.environ.get("HALO2_CPU_THREADS")
     if env:
         return max(1, int(env))
     try:
-        return max(1, len(os.sched_getaffinity(0)))
+        n = len(os.sched_getaffinity(0))
     except AttributeError:  # pragma: no cover
-        return os.cpu_count() or 1
+        n = os.cpu_count() or 1
+    quota = _cgroup_cpu_quota()
+    if quota != float("inf"):
+        n = min(n, max(1, int(quota + 0.999)))
+    return max(1, n)
 
 
 def best_multiexp(scalars: np.ndarray, bases: np.ndarray, threads: int | None = None) -> np.ndarray:
