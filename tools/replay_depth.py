@@ -3,7 +3,6 @@
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-    _lib.check(_lib.load().hm_msm_use_graphs(0))
 from halo2_experiments_amd.replay import run_replay
 for shape in sys.argv[1].split(",") if len(sys.argv) > 1 else ["merkle_sum_tree_k18"]:
     for d in [int(x) for x in os.environ.get("DEPTHS", "1,2,3,4,6,8").split(",")]:
