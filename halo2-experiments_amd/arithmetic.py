@@ -139,6 +139,23 @@ def best_multiexp_submit(coeffs, bases: BasesHandle, offset: int = 0) -> int:
     return t.value
 
 
+def best_multiexp_batch(columns, bases: BasesHandle, offset: int = 0) -> np.ndarray:
+    """The commitments of one prover phase in one call: ``columns`` is a list of (n, 4) GPU tensors (or one (count, n, 4)
+    tensor); returns (count, 12) words.  Eight MSMs are kept in flight inside the library."""
+    cols = [columns[i] for i in range(columns.shape[0])] if _is_tensor(columns) and columns.dim() == 3 else list(columns)
+    out = np.zeros((len(cols), 12), dtype=np.uint64)
+    if not cols:
+        return out
+    n = _tensor_rows(cols[0], 4, "columns")
+    for c in cols:
+        if _tensor_rows(c, 4, "columns") != n:
+            raise ValueError("best_multiexp_batch: every column must have the same length")
+    ptrs = (ctypes.c_void_p * len(cols))(*[c.data_ptr() for c in cols])
+    _lib.check(_lib.load().hm_msm_batch_bn256_g1_dev(ctypes.c_uint64(bases.handle), offset, ptrs, n, len(cols),
+                                                     ctypes.c_void_p(_stream_ptr(cols[0])), _ptr(out)))
+    return out
+
+
 def best_multiexp_wait(ticket: int) -> np.ndarray:
     out = np.zeros(12, dtype=np.uint64)
     _lib.check(_lib.load().hm_msm_wait(ctypes.c_uint64(ticket), _ptr(out)))

@@ -189,6 +189,11 @@ int hm_shutdown(void) {
   c.free_bases.clear();
   for (auto& g : c.graphs) graph_release(*g);
   c.graphs.clear();
+  if (c.batch_streams_ready) {
+    for (auto& st : c.batch_streams) (void)hipStreamDestroy(st);
+    (void)hipEventDestroy(c.batch_event);
+    c.batch_streams_ready = false;
+  }
   c.io.release(); c.io_bases.release(); c.conv_bases.release(); c.conv_inf.release();
   c.cached_host_n = 0;
   c.cached_xy = nullptr;
@@ -327,6 +332,47 @@ int hm_msm_submit_dev(uint64_t handle, size_t offset, const void* d_scalars, siz
   ctx->msm_slots[slot].ticket = ctx->next_ticket++;
   *out_ticket = ctx->msm_slots[slot].ticket;
   return HM_OK;
+}
+
+// The commitments of one prover phase in one call: `count` scalar arrays against the same base range, kept eight in
+// flight on the library's own streams (created on first use), results in call order.  What a caller of
+// hm_msm_submit_dev / hm_msm_wait would write by hand.
+int hm_msm_batch_bn256_g1_dev(uint64_t handle, size_t offset, const void* const* d_scalars, size_t n, size_t count, void* stream,
+                              uint64_t* out_xyz) {
+  if ((count && (!d_scalars || !out_xyz))) return hm_fail(HM_ERR_BAD_ARG, "hm_msm_batch_bn256_g1_dev: null argument");
+  DeviceCtx* ctx = ctx_for_current_device();
+  if (!ctx) return HM_ERR_NO_DEVICE;
+  constexpr int kLanes = HM_MSM_SLOTS - 1;
+  {
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (!ctx->batch_streams_ready) {
+      for (int i = 0; i < kLanes; ++i) HM_HIP_CHECK(hipStreamCreateWithFlags(&ctx->batch_streams[i], hipStreamNonBlocking));
+      HM_HIP_CHECK(hipEventCreateWithFlags(&ctx->batch_event, hipEventDisableTiming));
+      ctx->batch_streams_ready = true;
+    }
+    // the scalar arrays are produced on the caller's stream: every lane starts behind it
+    HM_HIP_CHECK(hipEventRecord(ctx->batch_event, (hipStream_t)stream));
+    for (int i = 0; i < kLanes; ++i) HM_HIP_CHECK(hipStreamWaitEvent(ctx->batch_streams[i], ctx->batch_event, 0));
+  }
+  uint64_t tickets[kLanes];
+  size_t issued = 0, done = 0;
+  int rc = HM_OK;
+  while (done < count) {
+    while (rc == HM_OK && issued < count && issued - done < (size_t)kLanes) {
+      if (!d_scalars[issued] && n) { rc = hm_fail(HM_ERR_BAD_ARG, "hm_msm_batch_bn256_g1_dev: null scalar array"); break; }
+      rc = hm_msm_submit_dev(handle, offset, d_scalars[issued], n, ctx->batch_streams[issued % kLanes], &tickets[issued % kLanes]);
+      if (rc == HM_OK) ++issued;
+    }
+    if (done < issued) {                       // await the oldest, even after an error: no ticket is left behind
+      const int wrc = hm_msm_wait(tickets[done % kLanes], out_xyz + 12 * done);
+      if (rc == HM_OK) rc = wrc;
+      ++done;
+    } else {
+      break;                                   // nothing in flight and nothing more could be issued
+    }
+    if (rc != HM_OK && done == issued) break;
+  }
+  return rc;
 }
 
 int hm_msm_wait(uint64_t ticket, uint64_t out_xyz[12]) {

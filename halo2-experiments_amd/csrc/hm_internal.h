@@ -157,6 +157,9 @@ struct DeviceCtx {
   std::vector<BasesEntry> zombie_bases;   // released while a ticket still reads them: freed by the last hm_msm_wait
   std::vector<FreeBases> free_bases;      // recycled buffers (no hipFree => no device-wide synchronisation)
   std::vector<std::unique_ptr<GraphProgram>> graphs;
+  hipStream_t batch_streams[HM_MSM_SLOTS - 1] = {};   // hm_msm_batch_bn256_g1_dev: one per asynchronous slot
+  hipEvent_t batch_event = nullptr;
+  bool batch_streams_ready = false;
   uint64_t next_handle = 1;
   // drop-in MSM: the converted bases of the previous call, keyed by a digest of the WHOLE host array (capi.hip)
   size_t cached_host_n = 0;

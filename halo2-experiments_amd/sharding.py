@@ -74,27 +74,21 @@ def sharded_multiexp_batch(jobs, group=None, streams=None, local_batch: Optional
     import torch
     import torch.distributed as dist
 
-    from .arithmetic import best_multiexp_submit, best_multiexp_wait
-
     if local_batch is not None:
         partials = np.stack([np.asarray(p, dtype=np.uint64).reshape(12) for p in local_batch(jobs)]) if jobs else np.zeros((0, 12), np.uint64)
     else:
         partials = np.zeros((len(jobs), 12), dtype=np.uint64)
-        if jobs:
-            dev = jobs[0][0].device
-            cur = torch.cuda.current_stream(dev)
-            streams = streams or [torch.cuda.Stream(device=dev) for _ in range(3)]
-            for st in streams:
-                st.wait_stream(cur)
-            pending = []
-            for i, (col, handle) in enumerate(jobs):
-                if len(pending) == min(MAX_IN_FLIGHT, len(streams)):
-                    j, t = pending.pop(0)
-                    partials[j] = best_multiexp_wait(t)
-                with torch.cuda.stream(streams[i % len(streams)]):
-                    pending.append((i, best_multiexp_submit(col, handle)))
-            for j, t in pending:
-                partials[j] = best_multiexp_wait(t)
+        # runs of consecutive jobs against the same base set go to the library in one call each
+        # (hm_msm_batch_bn256_g1_dev keeps eight MSMs in flight on its own streams; `streams` is accepted for
+        # compatibility with callers that still pass their own)
+        from .arithmetic import best_multiexp_batch
+        i = 0
+        while i < len(jobs):
+            j = i
+            while j < len(jobs) and jobs[j][1] is jobs[i][1] and jobs[j][0].shape == jobs[i][0].shape:
+                j += 1
+            partials[i:j] = best_multiexp_batch([col for col, _ in jobs[i:j]], jobs[i][1])
+            i = j
     if group is _NO_GROUP or not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
         return np.stack([g1_sum(p.reshape(1, 12)) for p in partials]) if len(partials) else partials
     world = dist.get_world_size(group)

@@ -101,6 +101,12 @@ int hm_msm_bn256_g1_dev(uint64_t handle, size_t offset, const void* d_scalars, s
  * latency-bound phases (sort, bucket reduction, host fold) hide behind another's accumulation. */
 int hm_msm_submit_dev(uint64_t handle, size_t offset, const void* d_scalars, size_t n, void* stream, uint64_t* out_ticket);
 int hm_msm_wait(uint64_t ticket, uint64_t out_xyz[12]);
+/* The commitments of one prover phase in one call (create_proof commits its advice / lookup / permutation columns in
+ * loops of independent commit_lagrange calls): `count` scalar arrays of n elements each (d_scalars: host array of device
+ * pointers, produced on `stream`) against bases[offset .. offset + n); out_xyz: count x 12 u64, in call order.  The library
+ * keeps eight MSMs in flight on streams of its own; the call returns when all results are on the host. */
+int hm_msm_batch_bn256_g1_dev(uint64_t handle, size_t offset, const void* const* d_scalars, size_t n, size_t count, void* stream,
+                              uint64_t* out_xyz);
 
 /* Single-process multi-GPU best_multiexp (the form a Rust prover, one process for the whole node,
  * binds): after hm_set_msm_devices(devices, count >= 2) every hm_msm_bn256_g1 /

@@ -434,6 +434,34 @@ def test_async_submit_wait_overlapping_streams(cref, golden):
         h.release_bases(hd)
 
 
+def test_batched_commitments_equal_single_calls(cref, golden):
+    """hm_msm_batch_bn256_g1_dev: a phase of commitments in one call (more of them than asynchronous slots, dense and
+    sparse columns mixed, a slice of the base set) equals the one-at-a-time results; runs twice (slots are reused)."""
+    import torch
+    n = 1 << 13
+    gen = cref.g1_generator()
+    bases = h.g1_fixed_base_mul(rand_fr_gpu(n + 64, 8100), gen)
+    hd = h.register_bases(bases)
+    try:
+        cols = [rand_fr_gpu(n, 8200 + i) if i % 3 else _replay_sparse_column(n, 300, 8300 + i) for i in range(19)]
+        single = np.stack([h.best_multiexp(c, hd, offset=32) for c in cols])
+        bh = bases.cpu().numpy().view(np.uint64)[32:32 + n]
+        exp0 = cref.g1_to_affine(cref.best_multiexp(cols[1].cpu().numpy().view(np.uint64), bh, 4))[0]
+        assert g1_equal(single[1], exp0)
+        from halo2_experiments_amd.arithmetic import best_multiexp_batch
+        for _ in range(2):
+            got = best_multiexp_batch(cols, hd, offset=32)
+            assert np.array_equal(got, single)
+        stacked = torch.stack(cols[:5])
+        assert np.array_equal(best_multiexp_batch(stacked, hd, offset=32), single[:5])
+        assert best_multiexp_batch([], hd).shape == (0, 12)
+        with pytest.raises(_lib.Halo2Mi355xError):
+            best_multiexp_batch(cols[:2], hd, offset=100)           # offset + n exceeds the set: error, no ticket left behind
+        assert np.array_equal(best_multiexp_batch(cols[:9], hd, offset=32), single[:9])
+    finally:
+        h.release_bases(hd)
+
+
 def test_config5_size_2_26_fits_one_gpu_and_is_additive():
     """BASELINE config 5's 2^26-point MSM on ONE GPU (2^30 (point, bucket) pairs, 4 + 4 GiB of
     bases, ~20 GiB of workspace): the whole equals the sum of its four 2^24 quarters."""
