@@ -83,6 +83,10 @@ _SIGNATURES = {
                                              ctypes.c_uint32, _vp, _vp]),
     "hm_graph_destroy": (ctypes.c_int, [ctypes.c_uint64]),
     "hm_fr_powers_dev": (ctypes.c_int, [_vp, ctypes.c_size_t, _u64p, _vp]),
+    "hm_kate_division_bn256_fr_dev": (ctypes.c_int, [_vp, ctypes.c_size_t, _u64p, _vp, _vp]),
+    "hm_fr_grand_product_dev": (ctypes.c_int, [_vp, ctypes.c_size_t, _u64p, _vp, _vp]),
+    "hm_fr_batch_invert_dev": (ctypes.c_int, [_vp, ctypes.c_size_t, _vp]),
+    "hm_fr_linear_combination_dev": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), _u64p, ctypes.c_size_t, ctypes.c_size_t, _vp, _vp]),
     "hm_fr_random_dev": (ctypes.c_int, [_vp, ctypes.c_size_t, ctypes.c_uint64, _vp]),
     "hm_fr_affine_sequence_dev": (ctypes.c_int, [_vp, ctypes.c_size_t, _u64p, _u64p, _vp]),
     "hm_fr_dot_bn256_dev": (ctypes.c_int, [_vp, _vp, ctypes.c_size_t, _u64p, _vp]),

@@ -207,6 +207,80 @@ def eval_polynomial(polys, points, poly_index=None) -> np.ndarray:
     return out
 
 
+def kate_division(poly, z):
+    """``halo2_proofs::arithmetic::kate_division``: the quotient of ``poly(X) - poly(z)`` by ``X - z`` for a
+    device-resident coefficient tensor (n, 4); returns a new (n - 1, 4) GPU tensor."""
+    import torch
+
+    lib = _lib.load()
+    if not _is_tensor(poly):
+        raise TypeError("kate_division: poly must be a GPU tensor (coefficients stay in HBM)")
+    n = _tensor_rows(poly, 4, "poly")
+    if n == 0:
+        raise ValueError("kate_division: empty polynomial")        # upstream: a.len() - 1 underflows and panics
+    out = torch.empty((n - 1, 4), dtype=torch.int64, device=poly.device)
+    zz = _np(z, 4, "z").reshape(4)
+    _lib.check(lib.hm_kate_division_bn256_fr_dev(ctypes.c_void_p(poly.data_ptr()), n, _ptr(zz), ctypes.c_void_p(out.data_ptr()),
+                                                 ctypes.c_void_p(_stream_ptr(poly))))
+    return out
+
+
+def grand_product(factors, start, out=None):
+    """The running product of the permutation / lookup arguments: ``out[0] = start``, ``out[i] = out[i-1] *
+    factors[i-1]`` for a device-resident (n, 4) tensor; ``out`` may be ``factors`` itself."""
+    import torch
+
+    lib = _lib.load()
+    if not _is_tensor(factors):
+        raise TypeError("grand_product: factors must be a GPU tensor")
+    n = _tensor_rows(factors, 4, "factors")
+    if out is None:
+        out = torch.empty((n, 4), dtype=torch.int64, device=factors.device)
+    elif _tensor_rows(out, 4, "out") != n:
+        raise ValueError("grand_product: out and factors differ in length")
+    st = _np(start, 4, "start").reshape(4)
+    _lib.check(lib.hm_fr_grand_product_dev(ctypes.c_void_p(factors.data_ptr()), n, _ptr(st), ctypes.c_void_p(out.data_ptr()),
+                                           ctypes.c_void_p(_stream_ptr(factors))))
+    return out
+
+
+def batch_invert(values):
+    """``ff::BatchInvert::batch_invert`` in place on a device-resident (n, 4) tensor: zero stays zero."""
+    lib = _lib.load()
+    if not _is_tensor(values):
+        raise TypeError("batch_invert: values must be a GPU tensor")
+    n = _tensor_rows(values, 4, "values")
+    _lib.check(lib.hm_fr_batch_invert_dev(ctypes.c_void_p(values.data_ptr()), n, ctypes.c_void_p(_stream_ptr(values))))
+    return values
+
+
+def linear_combination(polys, coeffs, out=None):
+    """``sum_j coeffs[j] * polys[j]`` (upstream ``Polynomial * scalar`` and ``+``) for a list of device-resident
+    (n, 4) tensors; ``out`` may be one of them."""
+    import torch
+
+    lib = _lib.load()
+    polys = list(polys)
+    cs = _np(coeffs, 4, "coeffs") if len(polys) else np.zeros((0, 4), dtype=np.uint64)
+    if cs.shape[0] != len(polys):
+        raise ValueError("linear_combination: one coefficient per polynomial")
+    if not polys and out is None:
+        raise ValueError("linear_combination: nothing to combine and no output to clear")
+    n = _tensor_rows(polys[0] if polys else out, 4, "polys")
+    for p in polys:
+        if not _is_tensor(p) or _tensor_rows(p, 4, "polys") != n:
+            raise ValueError("linear_combination: polynomials must be GPU tensors of one length")
+    ref = polys[0] if polys else out
+    if out is None:
+        out = torch.empty((n, 4), dtype=torch.int64, device=ref.device)
+    elif _tensor_rows(out, 4, "out") != n:
+        raise ValueError("linear_combination: out differs in length")
+    ptrs = (ctypes.c_void_p * max(len(polys), 1))(*[p.data_ptr() for p in polys])
+    _lib.check(lib.hm_fr_linear_combination_dev(ptrs, _ptr(cs) if len(polys) else None, len(polys), n, ctypes.c_void_p(out.data_ptr()),
+                                                ctypes.c_void_p(_stream_ptr(ref))))
+    return out
+
+
 def g1_fixed_base_mul(scalars, base_xy: np.ndarray):
     """out[i] = [scalars[i]] * base, affine (ParamsKZG::setup's per-row G1 work).  GPU tensors only."""
     import torch

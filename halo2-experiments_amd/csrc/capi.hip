@@ -762,6 +762,45 @@ int hm_eval_polynomial_bn256_fr_dev(const void* d_polys, size_t n, const uint32_
   return fr_eval_polynomial_run(*ctx, (const uint32_t*)d_polys, n, poly_index, points, count, out, (hipStream_t)stream);
 }
 
+int hm_kate_division_bn256_fr_dev(const void* d_poly, size_t n, const uint64_t z[4], void* d_quotient, void* stream) {
+  if (!z || (n >= 2 && (!d_poly || !d_quotient))) return hm_fail(HM_ERR_BAD_ARG, "hm_kate_division_bn256_fr_dev: null argument");
+  if (n >= 2) {
+    const char *a = (const char*)d_poly, *q = (const char*)d_quotient;
+    if (q < a + n * 32 && a < q + (n - 1) * 32)
+      return hm_fail(HM_ERR_BAD_ARG, "hm_kate_division_bn256_fr_dev: quotient overlaps the polynomial");
+  }
+  DeviceCtx* ctx = ctx_for_current_device();
+  if (!ctx) return HM_ERR_NO_DEVICE;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  return fr_kate_division_run(*ctx, (const uint32_t*)d_poly, n, z, (uint32_t*)d_quotient, (hipStream_t)stream);
+}
+
+int hm_fr_grand_product_dev(const void* d_factors, size_t n, const uint64_t start[4], void* d_out, void* stream) {
+  if (!start || (n && (!d_factors || !d_out))) return hm_fail(HM_ERR_BAD_ARG, "hm_fr_grand_product_dev: null argument");
+  DeviceCtx* ctx = ctx_for_current_device();
+  if (!ctx) return HM_ERR_NO_DEVICE;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  return fr_grand_product_run(*ctx, (const uint32_t*)d_factors, n, start, (uint32_t*)d_out, (hipStream_t)stream);
+}
+
+int hm_fr_batch_invert_dev(void* d_values, size_t n, void* stream) {
+  if (n && !d_values) return hm_fail(HM_ERR_BAD_ARG, "hm_fr_batch_invert_dev: null argument");
+  DeviceCtx* ctx = ctx_for_current_device();
+  if (!ctx) return HM_ERR_NO_DEVICE;
+  return fr_batch_invert_run((uint32_t*)d_values, n, (hipStream_t)stream);
+}
+
+int hm_fr_linear_combination_dev(const void* const* d_polys, const uint64_t* coeffs, size_t count, size_t n, void* d_out,
+                                 void* stream) {
+  if ((n && !d_out) || (count && (!d_polys || !coeffs))) return hm_fail(HM_ERR_BAD_ARG, "hm_fr_linear_combination_dev: null argument");
+  if (n)
+    for (size_t j = 0; j < count; ++j)
+      if (!d_polys[j]) return hm_fail(HM_ERR_BAD_ARG, "hm_fr_linear_combination_dev: null polynomial");
+  DeviceCtx* ctx = ctx_for_current_device();
+  if (!ctx) return HM_ERR_NO_DEVICE;
+  return fr_linear_combination_run(d_polys, coeffs, count, n, (uint32_t*)d_out, (hipStream_t)stream);
+}
+
 int hm_fr_powers_dev(void* d_out, size_t n, const uint64_t x[4], void* stream) {
   if ((n && !d_out) || !x) return hm_fail(HM_ERR_BAD_ARG, "hm_fr_powers_dev: null argument");
   DeviceCtx* ctx = ctx_for_current_device();

@@ -209,6 +209,13 @@ int fr_random_run(uint32_t* d_out, uint64_t n, uint64_t seed, hipStream_t stream
 int fr_eval_polynomial_run(DeviceCtx& ctx, const uint32_t* d_polys, uint64_t n, const uint32_t* poly_index, const uint64_t* points_ext,
                            size_t q, uint64_t* out_ext, hipStream_t stream);
 
+// polyops.hip
+int fr_kate_division_run(DeviceCtx& ctx, const uint32_t* d_a, uint64_t n, const uint64_t z_ext[4], uint32_t* d_q, hipStream_t stream);
+int fr_grand_product_run(DeviceCtx& ctx, const uint32_t* d_m, uint64_t n, const uint64_t start_ext[4], uint32_t* d_out, hipStream_t stream);
+int fr_batch_invert_run(uint32_t* d_v, uint64_t n, hipStream_t stream);
+int fr_linear_combination_run(const void* const* d_polys, const uint64_t* coeffs_ext, size_t count, uint64_t n, uint32_t* d_out,
+                              hipStream_t stream);
+
 // msm.hip
 int msm_convert_bases(const uint32_t* d_bases_ext, uint32_t* d_xy, uint8_t* d_inf, size_t n, hipStream_t stream);
 // out_windows: host buffer of W x 12 u64 external Jacobian + flags

@@ -1,0 +1,461 @@
+// polyops.hip -- the Fr vector steps create_proof makes between its NTTs and commitments, device-resident
+// (SURVEY.md §8f-4's neighbours; all upstream halo2_proofs at the tag pinned by /root/reference/Cargo.toml:10, reached
+// from the reference through create_proof, /root/reference/src/circuits/utils.rs:40-48):
+//   kate_division      arithmetic.rs kate_division: q(X) = (a(X) - a(z)) / (X - z), the quotient of every multiopen
+//                      witness polynomial;  q[i] = a[i+1] + z q[i+1]
+//   grand product      plonk/permutation/prover.rs and plonk/lookup/prover.rs build z(X) row by row:
+//                      z[0] = start, z[i+1] = z[i] * m[i]
+//   batch inversion    ff::BatchInvert on the denominators of those products (zero stays zero)
+//   linear combination poly * scalar + poly, the random linear combinations of multiopen and of the h(X) pieces
+// The first two are first-order linear recurrences: a lane owns B consecutive elements, the lanes of a workgroup and
+// then the workgroups are joined by a log-step scan whose multiplier is uniform per step (powers of z^B) or carried
+// with the value (products), and a final launch replays every chunk from its carry-in.
+//
+// Montgomery forms (ff29.h): external words of a are the internal form of a / 32.  Linear maps work on the raw
+// words; a product of two raw values is short by a factor 32, so factors are first multiplied by the internal form
+// of 32 (K32), which makes them true internal values, while the running product stays "external read as internal".
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+
+#include "g1.h"
+#include "hm_internal.h"
+#include "host_fr.h"
+
+namespace hm {
+
+constexpr int PO_THREADS = 256;
+constexpr uint32_t PO_MAX_LANES = 65536;      // 256 workgroups of 256 lanes: one second-level workgroup joins them
+
+struct PoFr {              // one field element in 9 x 29-bit limbs, passed by value
+  uint32_t l[9];
+};
+
+__device__ __forceinline__ Fr po_arg(const PoFr& a, double vb = 1.0) {
+  Fr r;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) r.l[i] = a.l[i];
+  HM_DECLARE(r, vb);
+  return r;
+}
+
+__device__ __forceinline__ Fr po_load_raw(const uint32_t* a, uint64_t idx) {
+  const uint4* src = reinterpret_cast<const uint4*>(a + idx * 8);
+  const uint4 lo = src[0], hi = src[1];
+  const uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+  return fe_unpack<FrParams>(w);
+}
+
+// v: normalised limbs, value < 3r -> canonical external words
+__device__ __forceinline__ void po_store_canonical(uint32_t* out, uint64_t idx, const Fr& v) {
+  const Fr c = fe_canonical(v);
+  uint32_t w[8];
+  fe_pack(w, c);
+  uint4* dst = reinterpret_cast<uint4*>(out + idx * 8);
+  dst[0] = make_uint4(w[0], w[1], w[2], w[3]);
+  dst[1] = make_uint4(w[4], w[5], w[6], w[7]);
+}
+
+__device__ __forceinline__ Fr po_load9(const uint32_t* __restrict__ p, double vb) {
+  Fr r;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) r.l[i] = p[i];
+  HM_DECLARE(r, vb);
+  return r;
+}
+__device__ __forceinline__ void po_store9(uint32_t* __restrict__ p, const Fr& v) {
+#pragma unroll
+  for (int i = 0; i < 9; ++i) p[i] = v.l[i];
+}
+
+__device__ __forceinline__ Fr po_pow_small(const Fr& x, uint32_t e) {
+  Fr acc = fe_one<FrParams>();
+  for (int bit = 31 - __clz(e | 1u); bit >= 0; --bit) {
+    acc = fe_sqr(acc);
+    if ((e >> bit) & 1u) acc = fe_mul(acc, x);
+  }
+  return acc;
+}
+
+__device__ __forceinline__ void po_lds_put(uint32_t* lds, uint32_t t, const Fr& v) {
+#pragma unroll
+  for (int i = 0; i < 9; ++i) lds[i * PO_THREADS + t] = v.l[i];
+}
+__device__ __forceinline__ Fr po_lds_get(const uint32_t* lds, uint32_t t, double vb) {
+  Fr r;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) r.l[i] = lds[i * PO_THREADS + t];
+  HM_DECLARE(r, vb);
+  return r;
+}
+
+// ---------------------------------------------------------------------------------------------
+// kate_division.  Q[i] = sum_{j > i} a[j] z^(j-i-1) for i < n - 1.
+// Lane L owns [L B, (L+1) B).  S_L = sum_{j in chunk} a[j] z^(j - lo); with y = z^B the value entering a chunk from
+// above is T_L = Q[hi - 1] = sum_{L' > L} S_L' y^(L'-L-1).
+// ---------------------------------------------------------------------------------------------
+// inclusive suffix scan over the workgroup with the uniform multiplier y: v_t <- sum_{t' >= t} v_t' y^(t'-t)
+__device__ __forceinline__ Fr po_suffix_scan_uniform(uint32_t* lds, Fr v, Fr y) {
+  const uint32_t t = threadIdx.x;
+  po_lds_put(lds, t, v);
+  __syncthreads();
+#pragma unroll 1
+  for (uint32_t off = 1; off < PO_THREADS; off <<= 1) {
+    Fr add = fe_zero<FrParams>();
+    HM_DECLARE(add, 0.0);
+    const bool has = t + off < PO_THREADS;
+    if (has) add = fe_mul(po_lds_get(lds, t + off, 3.0), y);
+    __syncthreads();
+    if (has) {
+      v = fe_reduce_small(fe_norm(fe_add(v, add)));
+      po_lds_put(lds, t, v);
+    }
+    __syncthreads();
+    y = fe_sqr(y);
+  }
+  return v;
+}
+
+__global__ __launch_bounds__(PO_THREADS) void fr_kate_chunks_kernel(const uint32_t* __restrict__ a, uint64_t n, PoFr z_int, uint32_t B,
+                                                                    uint32_t* __restrict__ incl, uint32_t* __restrict__ wg_total) {
+  __shared__ uint32_t lds[9 * PO_THREADS];
+  const uint32_t t = threadIdx.x;
+  const uint64_t L = (uint64_t)blockIdx.x * PO_THREADS + t;
+  const Fr z = po_arg(z_int);
+  const uint64_t lo = L * B, hi = lo + B < n ? lo + B : n;
+  Fr acc = fe_zero<FrParams>();
+  HM_DECLARE(acc, 0.0);
+  for (uint64_t j = hi; j > lo; --j) acc = fe_add(fe_mul(acc, z), po_load_raw(a, j - 1));   // limbs < 2^30: a valid factor
+  Fr s = fe_reduce_small(fe_norm(acc));
+  const Fr y = po_pow_small(z, B);
+  s = po_suffix_scan_uniform(lds, s, y);
+  po_store9(incl + L * 9, s);
+  if (t == 0) po_store9(wg_total + (size_t)blockIdx.x * 9, s);
+}
+
+// one workgroup: E_g = sum_{g' > g} W_g' Y^(g'-g-1), Y = z^(256 B)
+__global__ __launch_bounds__(PO_THREADS) void fr_kate_join_kernel(const uint32_t* __restrict__ wg_total, uint32_t G, PoFr z_int, uint32_t B,
+                                                                  uint32_t* __restrict__ carry) {
+  __shared__ uint32_t lds[9 * PO_THREADS];
+  const uint32_t t = threadIdx.x;
+  Fr Y = po_pow_small(po_arg(z_int), B);
+#pragma unroll 1
+  for (int k = 0; k < 8; ++k) Y = fe_sqr(Y);
+  Fr v = fe_zero<FrParams>();
+  HM_DECLARE(v, 0.0);
+  if (t + 1 < G) v = po_load9(wg_total + (size_t)(t + 1) * 9, 3.0);     // exclusive: lane g starts from W_{g+1}
+  v = po_suffix_scan_uniform(lds, v, Y);
+  if (t < G) po_store9(carry + (size_t)t * 9, v);
+}
+
+__global__ __launch_bounds__(PO_THREADS) void fr_kate_replay_kernel(const uint32_t* __restrict__ a, uint64_t n, PoFr z_int, uint32_t B,
+                                                                    const uint32_t* __restrict__ incl, const uint32_t* __restrict__ carry,
+                                                                    uint32_t* __restrict__ q) {
+  const uint32_t t = threadIdx.x;
+  const uint64_t L = (uint64_t)blockIdx.x * PO_THREADS + t;
+  const uint64_t lo = L * B;
+  if (lo + 1 >= n) return;                                  // q has n - 1 entries
+  const uint64_t hi = lo + B < n ? lo + B : n;
+  const Fr z = po_arg(z_int);
+  // T_L = (inclusive value of the next lane in this workgroup) + y^(255 - t) * E_g
+  Fr T = fe_mul(po_load9(carry + (size_t)blockIdx.x * 9, 3.0), po_pow_small(po_pow_small(z, B), PO_THREADS - 1 - t));
+  if (t + 1 < PO_THREADS) T = fe_add(T, po_load9(incl + (L + 1) * 9, 3.0));
+  Fr cur = fe_reduce_small(fe_norm(T));                     // Q[hi - 1]
+  if (hi - 1 < n - 1) po_store_canonical(q, hi - 1, cur);
+  for (uint64_t i = hi - 1; i > lo; --i) {                  // Q[i - 1] = a[i] + z Q[i]
+    cur = fe_reduce_small(fe_norm(fe_add(fe_mul(cur, z), po_load_raw(a, i))));
+    po_store_canonical(q, i - 1, cur);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// grand product.  out[i] = start * prod_{j < i} m[j].
+// ---------------------------------------------------------------------------------------------
+// inclusive prefix scan of products over the workgroup (true internal values, < 2r)
+__device__ __forceinline__ Fr po_prefix_scan_product(uint32_t* lds, Fr v) {
+  const uint32_t t = threadIdx.x;
+  po_lds_put(lds, t, v);
+  __syncthreads();
+#pragma unroll 1
+  for (uint32_t off = 1; off < PO_THREADS; off <<= 1) {
+    const bool has = t >= off;
+    Fr nv = v;
+    if (has) nv = fe_mul(v, po_lds_get(lds, t - off, 2.0));
+    __syncthreads();
+    if (has) {
+      v = nv;
+      po_lds_put(lds, t, v);
+    }
+    __syncthreads();
+  }
+  return v;
+}
+
+__global__ __launch_bounds__(PO_THREADS) void fr_product_chunks_kernel(const uint32_t* __restrict__ m, uint64_t n, PoFr k32_int, uint32_t B,
+                                                                       uint32_t* __restrict__ incl, uint32_t* __restrict__ wg_total) {
+  __shared__ uint32_t lds[9 * PO_THREADS];
+  const uint32_t t = threadIdx.x;
+  const uint64_t L = (uint64_t)blockIdx.x * PO_THREADS + t;
+  const Fr k32 = po_arg(k32_int);
+  const uint64_t lo = L * B, hi = lo + B < n ? lo + B : n;
+  Fr p = fe_one<FrParams>();
+  for (uint64_t j = lo; j < hi; ++j) p = fe_mul(p, fe_mul(po_load_raw(m, j), k32));
+  p = po_prefix_scan_product(lds, p);
+  po_store9(incl + L * 9, p);
+  if (t == PO_THREADS - 1) po_store9(wg_total + (size_t)blockIdx.x * 9, p);
+}
+
+// one workgroup: E_g = start_raw * prod_{g' < g} W_g'  ("external read as internal": the form the outputs are stored in)
+__global__ __launch_bounds__(PO_THREADS) void fr_product_join_kernel(const uint32_t* __restrict__ wg_total, uint32_t G, PoFr start_raw,
+                                                                     uint32_t* __restrict__ carry) {
+  __shared__ uint32_t lds[9 * PO_THREADS];
+  const uint32_t t = threadIdx.x;
+  Fr v = fe_one<FrParams>();
+  if (t >= 1 && t - 1 < G) v = po_load9(wg_total + (size_t)(t - 1) * 9, 2.0);   // exclusive: lane g ends at W_{g-1}
+  v = po_prefix_scan_product(lds, v);
+  if (t < G) po_store9(carry + (size_t)t * 9, fe_mul(v, po_arg(start_raw, 6.0)));
+}
+
+__global__ __launch_bounds__(PO_THREADS) void fr_product_replay_kernel(const uint32_t* m, uint64_t n, PoFr k32_int, uint32_t B,
+                                                                       const uint32_t* __restrict__ incl, const uint32_t* __restrict__ carry,
+                                                                       uint32_t* out) {
+  const uint32_t t = threadIdx.x;
+  const uint64_t L = (uint64_t)blockIdx.x * PO_THREADS + t;
+  const uint64_t lo = L * B;
+  if (lo >= n) return;
+  const uint64_t hi = lo + B < n ? lo + B : n;
+  const Fr k32 = po_arg(k32_int);
+  Fr cur = po_load9(carry + (size_t)blockIdx.x * 9, 2.0);
+  if (t > 0) cur = fe_mul(cur, po_load9(incl + (L - 1) * 9, 2.0));
+  for (uint64_t i = lo; i < hi; ++i) {
+    const Fr f = fe_mul(po_load_raw(m, i), k32);             // read before the store: out may be m itself
+    po_store_canonical(out, i, cur);
+    cur = fe_mul(cur, f);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// batch inversion, in place; zero stays zero.  A lane owns 8 consecutive elements (prefix products in registers);
+// the 64 lanes of a wave share one Fermat inversion of the product of their chunks.
+// ---------------------------------------------------------------------------------------------
+constexpr int INV_B = 8;
+
+__device__ __forceinline__ Fr po_shfl(const Fr& v, int src_lane) {
+  Fr r;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) r.l[i] = (uint32_t)__shfl((int)v.l[i], src_lane, 64);
+#ifdef HM_BOUNDS
+  r.vb = v.vb; r.lb = v.lb; r.tb = v.tb;
+#endif
+  return r;
+}
+
+// x^(r - 2), x a true internal value
+__device__ __forceinline__ Fr po_invert(const Fr& x) {
+  const uint64_t e[4] = {0x43e1f593efffffffull, 0x2833e84879b97091ull, 0xb85045b68181585dull, 0x30644e72e131a029ull};
+  Fr acc = x;                                    // bit 253 of r - 2 is its top bit
+#pragma unroll 1
+  for (int bit = 252; bit >= 0; --bit) {
+    acc = fe_sqr(acc);
+    if ((e[bit >> 6] >> (bit & 63)) & 1ull) acc = fe_mul(acc, x);
+  }
+  return acc;
+}
+
+__global__ __launch_bounds__(PO_THREADS) void fr_batch_invert_kernel(uint32_t* __restrict__ v, uint64_t n, PoFr k32_int) {
+  const uint64_t L = (uint64_t)blockIdx.x * PO_THREADS + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const Fr k32 = po_arg(k32_int);
+  const uint64_t lo = L * INV_B;
+  Fr val[INV_B], pre[INV_B];                     // val: true internal values (1 in place of a zero or a missing element)
+  uint32_t zero_mask = 0;
+  Fr run = fe_one<FrParams>();
+#pragma unroll
+  for (int k = 0; k < INV_B; ++k) {
+    val[k] = fe_one<FrParams>();
+    if (lo + k < n) {
+      const Fr raw = po_load_raw(v, lo + k);
+      uint32_t any = 0;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) any |= raw.l[i];
+      if (any == 0) zero_mask |= 1u << k;
+      else val[k] = fe_mul(raw, k32);
+    }
+    pre[k] = run;                                // product of the lane's elements before k
+    run = fe_mul(run, val[k]);
+  }
+  // wave: inclusive prefix and suffix products of the lane totals
+  Fr pfx = run, sfx = run;
+#pragma unroll 1
+  for (int off = 1; off < 64; off <<= 1) {
+    const Fr a = po_shfl(pfx, lane - off < 0 ? lane : lane - off);
+    const Fr b = po_shfl(sfx, lane + off > 63 ? lane : lane + off);
+    if (lane >= off) pfx = fe_mul(pfx, a);
+    if (lane + off <= 63) sfx = fe_mul(sfx, b);
+  }
+  const Fr total = po_shfl(pfx, 63);
+  const Fr inv_total = po_invert(total);
+  // 1 / run_lane = inv_total * (product of the lanes before) * (product of the lanes after)
+  Fr before = po_shfl(pfx, lane == 0 ? 0 : lane - 1), after = po_shfl(sfx, lane == 63 ? 63 : lane + 1);
+  Fr inv_run = inv_total;
+  if (lane > 0) inv_run = fe_mul(inv_run, before);
+  if (lane < 63) inv_run = fe_mul(inv_run, after);
+  const Fr int2ext = fe_const<FrParams>(FrParams::INT2EXT);
+#pragma unroll
+  for (int k = INV_B - 1; k >= 0; --k) {
+    if (lo + k < n) {
+      const Fr inv_k = fe_mul(inv_run, pre[k]);              // 1 / val[k]
+      if (zero_mask & (1u << k)) {
+        uint4* dst = reinterpret_cast<uint4*>(v + (lo + k) * 8);
+        dst[0] = make_uint4(0, 0, 0, 0);
+        dst[1] = make_uint4(0, 0, 0, 0);
+      } else {
+        po_store_canonical(v, lo + k, fe_mul(inv_k, int2ext));
+      }
+    }
+    inv_run = fe_mul(inv_run, val[k]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// linear combination: out[i] = sum_j c_j * poly_j[i], up to LC_MAX terms per launch
+// ---------------------------------------------------------------------------------------------
+constexpr int LC_MAX = 24;
+struct LcArgs {
+  const uint32_t* poly[LC_MAX];
+  PoFr c[LC_MAX];                    // true internal form of the coefficients
+};
+
+__global__ __launch_bounds__(PO_THREADS) void fr_lincomb_kernel(LcArgs args, uint32_t count, uint64_t n, uint32_t* out) {
+  const uint64_t i = (uint64_t)blockIdx.x * PO_THREADS + threadIdx.x;
+  if (i >= n) return;
+  Fr acc = fe_zero<FrParams>();
+  HM_DECLARE(acc, 0.0);
+  for (uint32_t j = 0; j < count; ++j) {
+    const Fr term = fe_mul(po_load_raw(args.poly[j], i), po_arg(args.c[j]));   // < 2r, normalised
+    acc = fe_add(acc, term);
+    if ((j & 3u) == 3u) acc = fe_reduce_small(fe_norm(acc));                    // every four terms (limbs < 5 * 2^29): back below 3r
+  }
+  po_store_canonical(out, i, fe_reduce_small(fe_norm(acc)));
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+static void po_internal(const uint64_t x_ext[4], PoFr& out) { host::fr_to_internal9(host::fr_load(x_ext), out.l); }
+static void po_raw(const uint64_t x_ext[4], PoFr& out) {       // the external words as 29-bit limbs, unconverted
+  const uint32_t* w = reinterpret_cast<const uint32_t*>(x_ext);
+  uint32_t ww[8];
+  std::memcpy(ww, w, 32);
+  const Fr r = fe_unpack<FrParams>(ww);
+  for (int i = 0; i < 9; ++i) out.l[i] = r.l[i];
+}
+
+struct PoPlan {
+  uint32_t B, G;
+  uint64_t lanes;
+};
+static PoPlan po_plan(uint64_t n) {
+  PoPlan p;
+  p.B = (uint32_t)((n + PO_MAX_LANES - 1) / PO_MAX_LANES);
+  if (p.B < 4) p.B = n >= 4 ? 4 : 1;
+  p.lanes = (n + p.B - 1) / p.B;
+  p.G = (uint32_t)((p.lanes + PO_THREADS - 1) / PO_THREADS);
+  return p;
+}
+
+// scratch of a scan: inclusive values of G * 256 lanes (+ one guard lane), G workgroup totals, G carries
+static uint32_t* po_scratch(AuxSlot* slot, const PoPlan& p, uint32_t** wg_total, uint32_t** carry) {
+  const size_t lanes = (size_t)p.G * PO_THREADS + 1;
+  const size_t need = (lanes + 2 * (size_t)p.G) * 36;
+  const size_t keep = (size_t)64 * 15 * 28 * 4;             // never shrink below the fixed-base table (see poly.hip)
+  uint8_t* buf = (uint8_t*)slot->table.ensure(need > keep ? need : keep);
+  if (!buf) return nullptr;
+  *wg_total = (uint32_t*)(buf + lanes * 36);
+  *carry = *wg_total + (size_t)p.G * 9;
+  return (uint32_t*)buf;
+}
+
+int fr_kate_division_run(DeviceCtx& ctx, const uint32_t* d_a, uint64_t n, const uint64_t z_ext[4], uint32_t* d_q, hipStream_t stream) {
+  if (n < 2) return HM_OK;                                   // a constant has the empty quotient
+  const PoPlan p = po_plan(n);
+  if (p.G > PO_THREADS) return hm_fail(HM_ERR_INTERNAL, "kate_division: plan exceeds one joining workgroup");
+  AuxSlot* slot = aux_acquire(ctx, stream);
+  if (!slot) return HM_ERR_HIP;
+  uint32_t *wg_total, *carry;
+  uint32_t* incl = po_scratch(slot, p, &wg_total, &carry);
+  if (!incl) return hm_fail(HM_ERR_HIP, "kate_division: scratch allocation failed");
+  PoFr z;
+  po_internal(z_ext, z);
+  hipLaunchKernelGGL(fr_kate_chunks_kernel, dim3(p.G), dim3(PO_THREADS), 0, stream, d_a, n, z, p.B, incl, wg_total);
+  hipLaunchKernelGGL(fr_kate_join_kernel, dim3(1), dim3(PO_THREADS), 0, stream, (const uint32_t*)wg_total, p.G, z, p.B, carry);
+  hipLaunchKernelGGL(fr_kate_replay_kernel, dim3(p.G), dim3(PO_THREADS), 0, stream, d_a, n, z, p.B, (const uint32_t*)incl,
+                     (const uint32_t*)carry, d_q);
+  HM_HIP_CHECK(hipGetLastError());
+  return aux_release(ctx, slot, stream);
+}
+
+int fr_grand_product_run(DeviceCtx& ctx, const uint32_t* d_m, uint64_t n, const uint64_t start_ext[4], uint32_t* d_out, hipStream_t stream) {
+  if (n == 0) return HM_OK;
+  const PoPlan p = po_plan(n);
+  if (p.G > PO_THREADS) return hm_fail(HM_ERR_INTERNAL, "grand_product: plan exceeds one joining workgroup");
+  AuxSlot* slot = aux_acquire(ctx, stream);
+  if (!slot) return HM_ERR_HIP;
+  uint32_t *wg_total, *carry;
+  uint32_t* incl = po_scratch(slot, p, &wg_total, &carry);
+  if (!incl) return hm_fail(HM_ERR_HIP, "grand_product: scratch allocation failed");
+  PoFr k32, start;
+  host::fr_to_internal9(host::FR_32, k32.l);
+  po_raw(start_ext, start);
+  hipLaunchKernelGGL(fr_product_chunks_kernel, dim3(p.G), dim3(PO_THREADS), 0, stream, d_m, n, k32, p.B, incl, wg_total);
+  hipLaunchKernelGGL(fr_product_join_kernel, dim3(1), dim3(PO_THREADS), 0, stream, (const uint32_t*)wg_total, p.G, start, carry);
+  hipLaunchKernelGGL(fr_product_replay_kernel, dim3(p.G), dim3(PO_THREADS), 0, stream, d_m, n, k32, p.B, (const uint32_t*)incl,
+                     (const uint32_t*)carry, d_out);
+  HM_HIP_CHECK(hipGetLastError());
+  return aux_release(ctx, slot, stream);
+}
+
+int fr_batch_invert_run(uint32_t* d_v, uint64_t n, hipStream_t stream) {
+  if (n == 0) return HM_OK;
+  PoFr k32;
+  host::fr_to_internal9(host::FR_32, k32.l);
+  const uint64_t lanes = (n + INV_B - 1) / INV_B;
+  hipLaunchKernelGGL(fr_batch_invert_kernel, dim3((uint32_t)((lanes + PO_THREADS - 1) / PO_THREADS)), dim3(PO_THREADS), 0, stream, d_v, n, k32);
+  HM_HIP_CHECK(hipGetLastError());
+  return HM_OK;
+}
+
+int fr_linear_combination_run(const void* const* d_polys, const uint64_t* coeffs_ext, size_t count, uint64_t n, uint32_t* d_out,
+                              hipStream_t stream) {
+  if (n == 0) return HM_OK;
+  const uint64_t one_ext[4] = {0xac96341c4ffffffbULL, 0x36fc76959f60cd29ULL, 0x666ea36f7879462eULL, 0x0e0a77c19a07df2fULL};   // R mod r
+  const uint32_t blocks = (uint32_t)((n + PO_THREADS - 1) / PO_THREADS);
+  if (count == 0) {
+    HM_HIP_CHECK(hipMemsetAsync(d_out, 0, n * 32, stream));
+    return HM_OK;
+  }
+  size_t done = 0;
+  bool first = true;
+  while (done < count) {
+    LcArgs args;
+    std::memset(&args, 0, sizeof args);
+    uint32_t k = 0;
+    if (!first) {                                            // the running sum re-enters with coefficient 1
+      args.poly[0] = d_out;
+      po_internal(one_ext, args.c[0]);
+      k = 1;
+    }
+    while (k < (uint32_t)LC_MAX && done < count) {
+      args.poly[k] = (const uint32_t*)d_polys[done];
+      po_internal(coeffs_ext + done * 4, args.c[k]);
+      ++k;
+      ++done;
+    }
+    hipLaunchKernelGGL(fr_lincomb_kernel, dim3(blocks), dim3(PO_THREADS), 0, stream, args, k, n, d_out);
+    first = false;
+  }
+  HM_HIP_CHECK(hipGetLastError());
+  return HM_OK;
+}
+
+}  // namespace hm

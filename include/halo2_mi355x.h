@@ -183,6 +183,28 @@ int hm_extended_to_coeff_bn256_fr_dev(void* d_a, size_t batch, const uint64_t ex
 int hm_eval_polynomial_bn256_fr_dev(const void* d_polys, size_t n, const uint32_t* poly_index, const uint64_t* points, size_t count,
                                     uint64_t* out, void* stream);
 
+/* halo2_proofs::arithmetic::kate_division(a, z): the quotient of a(X) - a(z) by X - z, which multiopen builds for
+ * every opening (upstream poly/kzg/multiopen; reached from /root/reference/src/circuits/utils.rs:40-48).  d_poly: n
+ * coefficients, d_quotient: n - 1 coefficients (q[i] = a[i+1] + z q[i+1]); the two must not overlap.  n < 2 writes
+ * nothing.  Asynchronous on `stream`. */
+int hm_kate_division_bn256_fr_dev(const void* d_poly, size_t n, const uint64_t z[4], void* d_quotient, void* stream);
+
+/* The running products of the permutation and lookup arguments (upstream plonk/permutation/prover.rs and
+ * plonk/lookup/prover.rs: z[0] = start, z[row] = z[row - 1] * factors[row - 1]): d_out[i] = start * prod_{j < i}
+ * d_factors[j] for i < n.  d_out may be d_factors itself.  Asynchronous on `stream`. */
+int hm_fr_grand_product_dev(const void* d_factors, size_t n, const uint64_t start[4], void* d_out, void* stream);
+
+/* ff::BatchInvert::batch_invert on n device-resident elements, in place: every non-zero element is replaced by its
+ * inverse, zero stays zero (the denominators of the grand products above).  Asynchronous on `stream`. */
+int hm_fr_batch_invert_dev(void* d_values, size_t n, void* stream);
+
+/* d_out[i] = sum_{j < count} coeffs[j] * d_polys[j][i] for i < n: `Polynomial * scalar` and `+` of upstream
+ * poly.rs in one pass (the random linear combinations of multiopen, the pieces of h(X)).  d_polys: host array of
+ * `count` device pointers (n x 4 u64 each); coeffs: host, count x 4 u64.  d_out may be one of the inputs.  count = 0
+ * zeroes d_out.  Asynchronous on `stream`. */
+int hm_fr_linear_combination_dev(const void* const* d_polys, const uint64_t* coeffs, size_t count, size_t n, void* d_out,
+                                 void* stream);
+
 /* out[i] = x^i for i < n (device pointer, n x 4 u64): the ladder 1, s, s^2, ... of ParamsKZG::setup, whose
  * fixed-base multiples are g, and whose scaled inverse NTT gives the Lagrange-basis scalars of g_lagrange. */
 int hm_fr_powers_dev(void* d_out, size_t n, const uint64_t x[4], void* stream);

@@ -1,0 +1,197 @@
+"""GPU suite: kate_division, grand product, batch inversion, linear combination through the C ABI, bit-exact against
+oracle/poly_ref.py (sizes the oracle finishes in seconds) and through size-independent identities at 2^20 / 2^22."""
+import ctypes
+import random
+
+import numpy as np
+import pytest
+
+import halo2_experiments_amd as h
+from halo2_experiments_amd import _lib
+from halo2_experiments_amd.domain import fr_words
+from oracle import poly_ref as pr
+
+pytestmark = pytest.mark.gpu
+R = pr.R
+
+
+def to_gpu(pyref, values):
+    import torch
+    return torch.from_numpy(pyref.fr_array(values).view(np.int64)).cuda()
+
+
+def from_gpu(pyref, t):
+    return pyref.fr_from_array(t.cpu().numpy().view(np.uint64))
+
+
+def rand_fr_gpu(n, seed):
+    import torch
+    g = torch.Generator(device="cuda")
+    g.manual_seed(seed)
+    x = torch.randint(-(2 ** 63), 2 ** 63 - 1, (n, 4), dtype=torch.int64, device="cuda", generator=g)
+    x[:, 3] &= 0x0FFFFFFFFFFFFFFF
+    return x
+
+
+SIZES = [1, 2, 3, 4, 5, 255, 256, 257, 1023, 1024, 1025, 4099, (1 << 14) - 1, 1 << 16, (1 << 16) + 1, (1 << 18) + 7]
+
+
+@pytest.mark.parametrize("n", SIZES)
+def test_kate_division_matches_oracle(pyref, n):
+    """Every plan boundary: one lane, one workgroup, several workgroups, ragged last chunks (B = 4 up to 2^18, 5 beyond)."""
+    rng = random.Random(n)
+    a = [rng.randrange(R) for _ in range(n)]
+    if n > 8:
+        a[n - 1] = 0                      # a zero leading coefficient
+        a[3] = R - 1
+    d = to_gpu(pyref, a)
+    for z in ([0, 1, R - 1, rng.randrange(R)] if n <= 4099 else [rng.randrange(R)]):
+        q = h.kate_division(d, fr_words(z))
+        assert q.shape == (n - 1, 4)
+        assert from_gpu(pyref, q) == pr.kate_division(a, z), (n, z)
+
+
+def test_kate_division_large_identity(pyref, cref):
+    """n = 2^22 (B = 64): q(X) (X - z) + a(z) = a(X), checked at random points with the Horner kernel."""
+    import torch
+    n = 1 << 22
+    a = rand_fr_gpu(n, 42)
+    z = 0x1234567890ABCDEF1234567890ABCDEF1234567890ABCDEF % R
+    q = h.kate_division(a, fr_words(z))
+    torch.cuda.synchronize()
+    az = pyref.fr_from_array(h.eval_polynomial(a.reshape(1, n, 4), np.stack([fr_words(z)])))[0]
+    for x in (5, 0xDEADBEEFCAFEBABE, R - 2):
+        ax = pyref.fr_from_array(h.eval_polynomial(a.reshape(1, n, 4), np.stack([fr_words(x)])))[0]
+        qx = pyref.fr_from_array(h.eval_polynomial(q.reshape(1, n - 1, 4), np.stack([fr_words(x)])))[0]
+        assert (qx * (x - z) + az) % R == ax
+
+
+def test_kate_division_errors(pyref):
+    import torch
+    a = rand_fr_gpu(16, 1)
+    lib = _lib.load()
+    rc = lib.hm_kate_division_bn256_fr_dev(ctypes.c_void_p(a.data_ptr()), 16, fr_words(3).ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)),
+                                           ctypes.c_void_p(a.data_ptr() + 32), None)
+    assert rc != 0 and b"overlaps" in lib.hm_last_error()
+    with pytest.raises(ValueError):
+        h.kate_division(torch.empty((0, 4), dtype=torch.int64, device="cuda"), fr_words(3))
+    assert h.kate_division(a[:1], fr_words(3)).shape == (0, 4)
+
+
+@pytest.mark.parametrize("n", SIZES)
+def test_grand_product_matches_oracle(pyref, n):
+    rng = random.Random(1000 + n)
+    m = [rng.randrange(R) for _ in range(n)]
+    if n > 300:
+        m[77] = 1
+        m[n // 2] = R - 1
+    start = rng.randrange(1, R)
+    d = to_gpu(pyref, m)
+    z = h.grand_product(d, fr_words(start))
+    assert from_gpu(pyref, z) == pr.grand_product(m, start), n
+    assert from_gpu(pyref, d) == m                                   # input untouched
+    h.grand_product(d, fr_words(start), out=d)                       # in place
+    assert from_gpu(pyref, d) == pr.grand_product(m, start), n
+
+
+def test_grand_product_with_a_zero_factor(pyref):
+    rng = random.Random(5)
+    m = [rng.randrange(1, R) for _ in range(3000)]
+    m[1234] = 0
+    z = from_gpu(pyref, h.grand_product(to_gpu(pyref, m), fr_words(1)))
+    assert z == pr.grand_product(m, 1) and z[1234] != 0 and all(v == 0 for v in z[1235:])
+
+
+@pytest.mark.parametrize("n", [1, 7, 8, 9, 511, 512, 513, 4099, (1 << 14) + 3, 1 << 16])
+def test_batch_invert_matches_oracle(pyref, n):
+    rng = random.Random(2000 + n)
+    v = [rng.randrange(R) for _ in range(n)]
+    for i in (0, 5, n - 1, n // 2):                                  # zeros: first, last, inside a chunk
+        if n > 16 or i == 0 and n > 1:
+            v[i % n] = 0
+    if n > 20:
+        v[17] = 1
+        v[18] = R - 1
+        for i in range(64, min(n, 72)):                              # one lane's whole chunk zero
+            v[i] = 0
+    d = to_gpu(pyref, v)
+    h.batch_invert(d)
+    assert from_gpu(pyref, d) == pr.batch_invert(v), n
+
+
+def test_batch_invert_large_is_an_involution(pyref):
+    """n = 2^20: inverting twice returns the input, and x * x^-1 = 1 at sampled rows."""
+    import torch
+    n = 1 << 20
+    a = rand_fr_gpu(n, 77)
+    # canonical inputs: reduce the random words below r with a linear combination by 1
+    a = h.linear_combination([a], np.stack([fr_words(1)]))
+    b = a.clone()
+    h.batch_invert(b)
+    rows = [0, 1, 7, 8, 63, 64, 4095, n // 3, n - 9, n - 1]
+    av, bv = from_gpu(pyref, a[rows]), from_gpu(pyref, b[rows])
+    for x, y in zip(av, bv):
+        assert x * y % R == 1
+    h.batch_invert(b)
+    assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("count", [0, 1, 2, 4, 5, 23, 24, 25, 49, 60])
+def test_linear_combination_matches_oracle(pyref, count):
+    """1 .. 60 terms: one launch carries 24; later launches re-read the running sum."""
+    import torch
+    n = 777
+    rng = random.Random(3000 + count)
+    polys = [[rng.randrange(R) for _ in range(n)] for _ in range(count)]
+    cs = [rng.randrange(R) for _ in range(count)]
+    if count > 2:
+        cs[1] = 0
+        cs[2] = R - 1
+    d = [to_gpu(pyref, p) for p in polys]
+    if count == 0:
+        out = torch.full((n, 4), 5, dtype=torch.int64, device="cuda")
+        h.linear_combination([], [], out=out)
+        assert not out.any()
+        return
+    got = h.linear_combination(d, np.stack([fr_words(c) for c in cs]))
+    assert from_gpu(pyref, got) == pr.linear_combination(polys, cs, n)
+    # accumulate into the first input
+    h.linear_combination(d, np.stack([fr_words(c) for c in cs]), out=d[0])
+    assert from_gpu(pyref, d[0]) == pr.linear_combination(polys, cs, n)
+    with pytest.raises(ValueError):
+        h.linear_combination(d, np.stack([fr_words(c) for c in cs])[:-1] if count > 1 else np.zeros((2, 4), dtype=np.uint64))
+
+
+def test_permutation_product_column(pyref):
+    """The z column of the permutation argument for one chunk of three columns, the way upstream's
+    permutation/prover.rs builds it: denominators, batch inversion, numerators, running product -- the factor sweep
+    by linear combinations on the device, the last two steps by the kernels under test."""
+    k, n = 10, 1 << 10
+    rng = random.Random(31)
+    omega = pyref.fr_omega(k)
+    delta = pow(7, 1 << 28, R)
+    beta, gamma = rng.randrange(R), rng.randrange(R)
+    cols = [[rng.randrange(R) for _ in range(n)] for _ in range(3)]
+    perm = list(range(3 * n))
+    rng.shuffle(perm)                                               # a random permutation of the 3n cells
+    ident = [pow(delta, j, R) * pow(omega, i, R) % R for j in range(3) for i in range(n)]
+    sig = [[ident[perm[j * n + i]] for i in range(n)] for j in range(3)]
+    want_mv = pr.permutation_factors(cols, sig, omega, delta, beta, gamma)
+    want_z = pr.grand_product(want_mv, 1)
+    # device: den_j = beta * sigma_j + gamma + v_j, num_j = beta * id_j + gamma + v_j as linear combinations
+    ones = to_gpu(pyref, [1] * n)
+    dc, ds = [to_gpu(pyref, c) for c in cols], [to_gpu(pyref, s) for s in sig]
+    di = [to_gpu(pyref, ident[j * n:(j + 1) * n]) for j in range(3)]
+    w = lambda *v: np.stack([fr_words(x) for x in v])
+    den = [h.linear_combination([ds[j], ones, dc[j]], w(beta, gamma, 1)) for j in range(3)]
+    num = [h.linear_combination([di[j], ones, dc[j]], w(beta, gamma, 1)) for j in range(3)]
+    mul = lambda a, b: to_gpu(pyref, [x * y % R for x, y in zip(from_gpu(pyref, a), from_gpu(pyref, b))])   # host glue of the test
+    d_all = mul(mul(den[0], den[1]), den[2])
+    h.batch_invert(d_all)
+    mv = mul(mul(mul(d_all, num[0]), num[1]), num[2])
+    assert from_gpu(pyref, mv) == want_mv
+    z = h.grand_product(mv, fr_words(1))
+    assert from_gpu(pyref, z) == want_z
+    # a permutation of equal... the product over all rows telescopes to 1 when the columns satisfy the permutation;
+    # with random columns it does not, but z[0] = 1 always
+    assert from_gpu(pyref, z[:1]) == [1]
