@@ -61,6 +61,32 @@ inline Fr eval_polynomial(const Fr* d_poly, size_t n, const Fr& point, void* str
   return eval_polynomial(d_poly, n, std::vector<uint32_t>{}, std::vector<Fr>{point}, stream)[0];
 }
 
+// kate_division(a, z) for a coefficient array resident in HBM: d_quotient receives n - 1 coefficients (upstream returns
+// a new Vec; the two arrays must not overlap).  Upstream panics on an empty slice (a.len() - 1 underflows).
+inline void kate_division(const Fr* d_poly, size_t n, const Fr& z, Fr* d_quotient, void* stream = nullptr) {
+  if (n == 0) throw std::invalid_argument("kate_division: empty polynomial");
+  check(hm_kate_division_bn256_fr_dev(d_poly, n, z.l, d_quotient, stream), "kate_division");
+}
+
+// the z column of the permutation / lookup arguments: out[0] = start, out[i] = out[i - 1] * factors[i - 1]
+inline void grand_product(const Fr* d_factors, size_t n, const Fr& start, Fr* d_out, void* stream = nullptr) {
+  check(hm_fr_grand_product_dev(d_factors, n, start.l, d_out, stream), "grand_product");
+}
+
+// ff::BatchInvert::batch_invert on a device-resident slice: zero stays zero
+inline void batch_invert(Fr* d_values, size_t n, void* stream = nullptr) {
+  check(hm_fr_batch_invert_dev(d_values, n, stream), "batch_invert");
+}
+
+// sum_j coeffs[j] * polys[j] (upstream `Polynomial * F` and `+`); d_out may be one of the inputs
+inline void linear_combination(const std::vector<const Fr*>& d_polys, const std::vector<Fr>& coeffs, size_t n, Fr* d_out,
+                               void* stream = nullptr) {
+  if (d_polys.size() != coeffs.size()) throw std::invalid_argument("linear_combination: one coefficient per polynomial");
+  check(hm_fr_linear_combination_dev(reinterpret_cast<const void* const*>(d_polys.data()), reinterpret_cast<const uint64_t*>(coeffs.data()),
+                                     d_polys.size(), n, d_out, stream),
+        "linear_combination");
+}
+
 // affine normalisation of a G1 the library returned: it is already (x, y, 1) or the identity
 inline G1Affine to_affine(const G1& p) {
   if (p.is_identity()) return G1Affine::identity();

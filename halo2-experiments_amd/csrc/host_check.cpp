@@ -192,4 +192,68 @@ int hc_bounds_closure(const uint64_t* pj, const uint64_t* qj, const uint64_t* q_
   return ok;
 }
 
+// The Fr vector formulas of ntt.hip / poly.hip / polyops.hip, each run once with its inputs DECLARED at the class
+// maxima the kernels rely on (raw 256-bit words: value < 2^256; products: < 2r; reduced sums: < 3r).  Any
+// precondition violation aborts; returns 1 when every result is inside the class its consumer expects.
+int hc_fr_vector_bounds_closure(const uint64_t* a_ext, const uint64_t* b_ext, double* report) {
+  typedef Fe<FrParams> F;
+  uint32_t wa[8], wb[8];
+  std::memcpy(wa, a_ext, 32);
+  std::memcpy(wb, b_ext, 32);
+  F raw = fe_unpack<FrParams>(wa);                 // declared: any 256-bit word pattern
+  raw.l[8] = (1u << 24) - 1;                       // and take the largest one for the run itself
+  for (int i = 0; i < 8; ++i) raw.l[i] = MASK29;
+  F z = load_ext<FrParams>(b_ext);                 // a product output
+  force_bounds(z, 2.0);
+  F k32 = fe_const<FrParams>(FrParams::EXT2INT);   // any canonical constant
+  int ok = 1, r = 0;
+  // 1. Horner step of eval_polynomial / kate_division: acc <- acc * z + raw, iterated at its fixed point
+  F acc = fe_add(fe_mul(raw, z), raw);
+  for (int k = 0; k < 4; ++k) acc = fe_add(fe_mul(acc, z), raw);
+  report[r++] = acc.vb;
+  F s = fe_reduce_small(fe_norm(acc));
+  ok &= s.vb <= 3.0;
+  // 2. scan step with a uniform multiplier: v <- reduce(v + w * y), v, w < 3r, y < 2r
+  F v = s, w = s;
+  force_bounds(v, 3.0);
+  force_bounds(w, 3.0);
+  F t = fe_reduce_small(fe_norm(fe_add(v, fe_mul(w, z))));
+  report[r++] = t.vb;
+  ok &= t.vb <= 3.0;
+  // 3. chunk entry of kate_division: product + stored inclusive value, then the replay step and its canonical store
+  F T = fe_add(fe_mul(v, z), w);
+  F cur = fe_reduce_small(fe_norm(T));
+  cur = fe_reduce_small(fe_norm(fe_add(fe_mul(cur, z), raw)));
+  report[r++] = cur.vb;
+  (void)fe_canonical(cur);
+  // 4. products: factor = raw * K32, running product, scan product, conversion out
+  F f = fe_mul(raw, k32);
+  F p = fe_mul(z, f);
+  p = fe_mul(p, p);
+  report[r++] = p.vb;
+  ok &= p.vb <= 2.0;
+  (void)fe_canonical(p);
+  (void)fe_canonical(fe_mul(p, fe_const<FrParams>(FrParams::INT2EXT)));
+  F start = raw;                                    // the start value enters as raw words
+  (void)fe_mul(p, start);
+  // 5. linear combination: four product terms on a value < 3r between reductions
+  F lc = v;
+  for (int k = 0; k < 4; ++k) lc = fe_add(lc, fe_mul(raw, z));
+  lc = fe_reduce_small(fe_norm(lc));
+  report[r++] = lc.vb;
+  ok &= lc.vb <= 3.0;
+  // 6. NTT butterflies: stage 0 on raw inputs, a later trivial-twiddle stage on lazy outputs, a general stage
+  F x0 = fe_add(raw, raw), x1 = fe_sub<6, 29>(raw, raw);
+  F tt = fe_norm(x1);
+  F y0 = fe_add(x0, tt), y1 = fe_sub<13, 29>(x0, tt);
+  F g = fe_mul(fe_norm(y1), z);
+  F b0 = fe_add(fe_norm(y0), g), b1 = fe_sub<3, 29>(fe_norm(y0), g);
+  F o0 = fe_norm(b0), o1 = fe_norm(b1);
+  report[r++] = o0.vb;
+  report[r++] = o1.vb;
+  (void)fe_canonical(fe_reduce_small(o0));
+  (void)fe_canonical(fe_mul(o1, z));
+  return ok;
+}
+
 }  // extern "C"

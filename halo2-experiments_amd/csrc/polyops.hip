@@ -235,10 +235,11 @@ __global__ __launch_bounds__(PO_THREADS) void fr_product_replay_kernel(const uin
 }
 
 // ---------------------------------------------------------------------------------------------
-// batch inversion, in place; zero stays zero.  A lane owns 8 consecutive elements (prefix products in registers);
-// the 64 lanes of a wave share one Fermat inversion of the product of their chunks.
+// batch inversion, in place; zero stays zero.  A lane owns INV_B consecutive elements (its prefix products live in
+// registers / scratch); the 64 lanes of a wave share one Fermat inversion of the product of their chunks.  Cost per
+// element: 5 products + ~400 / INV_B for the inversion and the wave scans, so large arrays take 32 elements per lane
+// and small ones 8 (more lanes, same ~0.2 ms latency of one inversion chain).
 // ---------------------------------------------------------------------------------------------
-constexpr int INV_B = 8;
 
 __device__ __forceinline__ Fr po_shfl(const Fr& v, int src_lane) {
   Fr r;
@@ -262,6 +263,7 @@ __device__ __forceinline__ Fr po_invert(const Fr& x) {
   return acc;
 }
 
+template <int INV_B>
 __global__ __launch_bounds__(PO_THREADS) void fr_batch_invert_kernel(uint32_t* __restrict__ v, uint64_t n, PoFr k32_int) {
   const uint64_t L = (uint64_t)blockIdx.x * PO_THREADS + threadIdx.x;
   const int lane = threadIdx.x & 63;
@@ -419,8 +421,13 @@ int fr_batch_invert_run(uint32_t* d_v, uint64_t n, hipStream_t stream) {
   if (n == 0) return HM_OK;
   PoFr k32;
   host::fr_to_internal9(host::FR_32, k32.l);
-  const uint64_t lanes = (n + INV_B - 1) / INV_B;
-  hipLaunchKernelGGL(fr_batch_invert_kernel, dim3((uint32_t)((lanes + PO_THREADS - 1) / PO_THREADS)), dim3(PO_THREADS), 0, stream, d_v, n, k32);
+  if (n >= ((uint64_t)1 << 21)) {
+    const uint64_t lanes = (n + 31) / 32;
+    hipLaunchKernelGGL(fr_batch_invert_kernel<32>, dim3((uint32_t)((lanes + PO_THREADS - 1) / PO_THREADS)), dim3(PO_THREADS), 0, stream, d_v, n, k32);
+  } else {
+    const uint64_t lanes = (n + 7) / 8;
+    hipLaunchKernelGGL(fr_batch_invert_kernel<8>, dim3((uint32_t)((lanes + PO_THREADS - 1) / PO_THREADS)), dim3(PO_THREADS), 0, stream, d_v, n, k32);
+  }
   HM_HIP_CHECK(hipGetLastError());
   return HM_OK;
 }

@@ -17,8 +17,11 @@ extended domain 2^ek with ek = k + ceil(log2(d-1))):
     extended_to_coeff (iNTT 2^ek)                    1
     evaluate_h gates  (GraphEvaluator over 2^ek rows)  one Poseidon-like gate program (estimate of the expression graph)
     eval_polynomial   (Horner, n coefficients)         2A + 3 Zp + 5L + (d-1) queries (estimate)
-Everything else in ``create_proof`` (witness synthesis, the permutation / lookup terms of ``evaluate_h``, the
-transcript) stays on the CPU in the reference and is NOT part of this number.
+    grand products    (batch_invert + running product over n rows)   Zp + L  (permutation / lookup z columns)
+    multiopen         (linear combination of the committed polynomials per rotation set, kate_division per opening
+                       point, final combination + division)          4 sets, 5 points (estimate)
+Everything else in ``create_proof`` (witness synthesis, the permutation / lookup terms of ``evaluate_h``, the lookup
+sort, the transcript) stays on the CPU in the reference and is NOT part of this number.
 
 Like the reference's harness (prove, THEN verify: /root/reference/src/circuits/merkle_sum_tree.rs:345-358), a
 replay checks what it computed: the SRS is a real one (g = [s^i]G, g_lagrange = [L_i(s)]G with a known s), and
@@ -35,8 +38,8 @@ from typing import Optional
 
 import numpy as np
 
-from .arithmetic import (G1_GENERATOR, best_multiexp, best_multiexp_submit, best_multiexp_wait, eval_polynomial, g1_fixed_base_mul,
-                         register_bases, release_bases)
+from .arithmetic import (G1_GENERATOR, batch_invert, best_multiexp, best_multiexp_submit, best_multiexp_wait, eval_polynomial,
+                         g1_fixed_base_mul, grand_product, kate_division, linear_combination, register_bases, release_bases)
 from .domain import EvaluationDomain, FR_MODULUS, fr_words
 from .kzg import ParamsKZG
 from .sharding import job_parallel_multiexp_batch, shard_range, sharded_multiexp, sharded_multiexp_batch
@@ -185,6 +188,12 @@ def run_replay(shape_name: str, device=None, group=None, include_host_pointer_es
     eval_index = np.arange(n_queries, dtype=np.uint32) % 8
     eval_points = np.stack([fr_words(pow(REPLAY_S, 3 + q, FR_MODULUS)) for q in range(n_queries)])
 
+    n_open_polys = A + 3 * L + zp + (d - 1)                    # advice, lookup triples, permutation products, h pieces
+    open_coeffs = np.stack([fr_words(pow(REPLAY_S, 17 + j, FR_MODULUS)) for j in range(max(n_open_polys, 4))])
+    open_acc = torch.empty((5, n, 4), dtype=torch.int64, device=device)
+    z_factors = _rand_fr((zp + L) * n, 400, device).reshape(zp + L, n, 4)
+    z_column = torch.empty((n, 4), dtype=torch.int64, device=device)
+
     def msm_phase(jobs):
         """The commitments of one prover phase are independent: every rank keeps `in_flight` of its local
         MSMs in flight on as many streams (one MSM's sort / bucket reduction / host fold hides behind
@@ -240,6 +249,29 @@ def run_replay(shape_name: str, device=None, group=None, include_host_pointer_es
         if rank == 0:
             eval_polynomial(ntt_batch, eval_points, poly_index=eval_index)
         t["eval_polynomial"] = time.perf_counter() - t0
+        # the z columns of the permutation and lookup arguments: denominators inverted in a batch, then the running
+        # product; and multiopen's witness polynomials: per rotation set one combination of the committed polynomials,
+        # a division by (X - point) per opening point, then the final combination and division
+        t0 = time.perf_counter()
+        if rank == 0:
+            batch_invert(z_factors)                 # the denominators of all z columns are independent: one call
+            for i in range(zp + L):                   # the products chain (each starts from the previous column's last value)
+                grand_product(z_factors[i], fr_words(1), out=z_column)
+        torch.cuda.synchronize()
+        t["grand_products"] = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        if rank == 0:
+            per_set = -(-n_open_polys // 4)
+            sets = []
+            for si in range(4):
+                cnt = min(per_set, n_open_polys - si * per_set)
+                sets.append(linear_combination([ntt_batch[j % 8] for j in range(cnt)], open_coeffs[:cnt], out=open_acc[si]))
+            for qi in range(5):
+                kate_division(sets[qi % 4], fr_words(pow(REPLAY_S, 5 + qi, FR_MODULUS)))
+            fin = linear_combination(sets, open_coeffs[:4], out=open_acc[4])
+            kate_division(fin, fr_words(pow(REPLAY_S, 11, FR_MODULUS)))
+        torch.cuda.synchronize()
+        t["multiopen"] = time.perf_counter() - t0
         return t
 
     proof_once().pop("results")                         # warm-up: tables, workspaces
@@ -274,10 +306,13 @@ def run_replay(shape_name: str, device=None, group=None, include_host_pointer_es
                   "source": shape.source},
         "calls": counts,
         "device_resident_s": {"msm": phases["msm"], "ntt": phases["ntt"], "evaluate_h_gates": phases["evaluate_h_gates"],
-                              "eval_polynomial": phases["eval_polynomial"], "total": wall},
+                              "eval_polynomial": phases["eval_polynomial"], "grand_products": phases["grand_products"],
+                              "multiopen": phases["multiopen"], "total": wall},
         "beyond_msm_ntt": {"evaluate_h_gates": f"{len(gate_prog.calcs)} GraphEvaluator calculations per row over 2^{dom.extended_k} rows "
                                                "(Poseidon-like gate program: an estimate of the circuit's expression graph)",
-                           "eval_polynomial": f"{n_queries} Horner evaluations of 2^{k}-coefficient polynomials (estimate)"},
+                           "eval_polynomial": f"{n_queries} Horner evaluations of 2^{k}-coefficient polynomials (estimate)",
+                           "grand_products": f"one batch inversion of {zp + L} x 2^{k} denominators, {zp + L} running products over 2^{k} rows",
+                           "multiopen": f"{n_open_polys} polynomials combined in 4 rotation sets, 6 divisions by X - point (estimate)"},
         "verified": {"commitments_checked": checked["commitments"], "distinct_column_base_pairs": len(expected),
                      "against": "KZG identity commit(f) == [f(s)]G, f(s) by device Horner (+ inverse NTT for Lagrange-basis columns)"},
         "note": "MSM/NTT trace replay on synthetic polynomials (no Rust toolchain here); CPU-side parts of create_proof "

@@ -156,3 +156,15 @@ def test_xyzz_accumulator_chain_and_closure(hc, pyref):
     a, b = o.g1_mul(77, o.G1_GEN), o.g1_mul(91, o.G1_GEN)
     ok = hc.hc_xyzz_bounds_closure(p(jac_words(o, a, 9)), p(o.g1_affine_array([b])[0]), rep)
     assert ok == 1, list(rep)
+
+
+def test_fr_vector_formulas_bound_closure(hc, pyref):
+    """The Horner, scan, product, linear-combination and butterfly steps of ntt.hip / poly.hip / polyops.hip with
+    their inputs declared at the class maxima (raw words < 2^256, products < 2r, reduced sums < 3r)."""
+    o = pyref
+    a, b = o.fr_array([o.R - 1]), o.fr_array([0x1234567890ABCDEF % o.R])
+    rep = (ctypes.c_double * 8)()
+    hc.hc_fr_vector_bounds_closure.restype = ctypes.c_int
+    ok = hc.hc_fr_vector_bounds_closure(p(a[0]), p(b[0]), rep)
+    assert ok == 1, list(rep)
+    assert rep[0] < 8.0 and rep[1] <= 3.0 and rep[4] <= 3.0

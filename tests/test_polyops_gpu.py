@@ -119,19 +119,21 @@ def test_batch_invert_matches_oracle(pyref, n):
     assert from_gpu(pyref, d) == pr.batch_invert(v), n
 
 
-def test_batch_invert_large_is_an_involution(pyref):
-    """n = 2^20: inverting twice returns the input, and x * x^-1 = 1 at sampled rows."""
+@pytest.mark.parametrize("n", [1 << 20, (1 << 21) + 5])
+def test_batch_invert_large_is_an_involution(pyref, n):
+    """2^20 (8 elements per lane) and 2^21 + 5 (32 per lane, ragged tail): x * x^-1 = 1 at sampled rows, planted zeros
+    stay zero, and inverting twice returns the input."""
     import torch
-    n = 1 << 20
     a = rand_fr_gpu(n, 77)
-    # canonical inputs: reduce the random words below r with a linear combination by 1
-    a = h.linear_combination([a], np.stack([fr_words(1)]))
+    zeros = [3, 31, 32, 33, 64 * 32 - 1, n // 2, n - 1]
+    a[zeros] = 0
     b = a.clone()
     h.batch_invert(b)
-    rows = [0, 1, 7, 8, 63, 64, 4095, n // 3, n - 9, n - 1]
+    rows = [0, 1, 7, 8, 30, 34, 63, 64, 4095, n // 3, n - 9, n - 2]
     av, bv = from_gpu(pyref, a[rows]), from_gpu(pyref, b[rows])
     for x, y in zip(av, bv):
         assert x * y % R == 1
+    assert not b[zeros].any()
     h.batch_invert(b)
     assert torch.equal(a, b)
 

@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""kate_division / grand product / batch inversion / linear combination wall time per size: development aid."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import halo2_experiments_amd as h
+from halo2_experiments_amd.domain import fr_words
+
+def rand_fr(n, seed):
+    g = torch.Generator(device="cuda"); g.manual_seed(seed)
+    x = torch.randint(-(2**63), 2**63 - 1, (n, 4), dtype=torch.int64, device="cuda", generator=g)
+    x[:, 3] &= 0x0FFFFFFFFFFFFFFF
+    return x
+
+def timed(fn, reps=10):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+z = fr_words(0x123456789ABCDEF123456789)
+for k in [int(a) for a in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["14", "18", "21", "24"])]:
+    n = 1 << k
+    a = rand_fr(n, k); b = rand_fr(n, k + 1); out = torch.empty_like(a)
+    q = torch.empty((n - 1, 4), dtype=torch.int64, device="cuda")
+    cs = np.stack([fr_words(3 + i) for i in range(24)])
+    print(f"2^{k}: kate {timed(lambda: h.kate_division(a, z)):.4f} ms | grand product {timed(lambda: h.grand_product(a, z, out=out)):.4f} ms | "
+          f"batch invert {timed(lambda: h.batch_invert(b)):.4f} ms | lincomb x2 {timed(lambda: h.linear_combination([a, b], cs[:2], out=out)):.4f} ms "
+          f"x24 {timed(lambda: h.linear_combination([a, b] * 12, cs, out=out)):.4f} ms", flush=True)
