@@ -246,6 +246,31 @@ int main(int argc, char** argv) {
       want[2] = g1_mul_generator(arithmetic::eval_polynomial(d_dense.d, n, s));
       if (!(want[2] == expect)) ok = false;            // device Horner vs the host Horner above
     }
+    // ... and one opening, as multiopen makes it (the pairing check e(C - [w(z)]G, H) = e(commit(q), [s - z]H) in the
+    // exponent): w = v0 f + v1 f', q = kate_division(w, z); then q(s) (s - z) + w(z) = w(s) and commit(q) = [q(s)]G.
+    // Plus the z-column identity of the permutation argument's building blocks: prod f_j * prod f_j^-1 = 1.
+    bool opening_ok = true;
+    {
+      poly::DevicePolys w(n, 1), q(n, 1), inv(n, 1), zf(n, 1), zi(n, 1);
+      const Fr v0 = s + Fr::one(), v1 = s * s, z = s * s * s + Fr::one();
+      arithmetic::linear_combination({d_dense.d, d_sparse.d}, {v0, v1}, n, w.d);
+      (void)hipMemset(q.d, 0, n * sizeof(Fr));                 // the quotient has n - 1 coefficients: the last stays zero
+      arithmetic::kate_division(w.d, n, z, q.d);
+      const Fr wz = arithmetic::eval_polynomial(w.d, n, z), ws = arithmetic::eval_polynomial(w.d, n, s);
+      const Fr qs = arithmetic::eval_polynomial(q.d, n, s);
+      if (!(qs * (s - z) + wz == ws)) opening_ok = false;
+      if (!(arithmetic::to_affine(params.commit(q.d)) == g1_mul_generator(qs))) opening_ok = false;
+      (void)hipMemcpy(inv.d, d_dense.d, n * sizeof(Fr), hipMemcpyDeviceToDevice);
+      arithmetic::batch_invert(inv.d, n);
+      arithmetic::grand_product(d_dense.d, n, Fr::one(), zf.d);
+      arithmetic::grand_product(inv.d, n, Fr::one(), zi.d);
+      Fr a, b;
+      (void)hipMemcpy(&a, zf.d + (n - 1), sizeof(Fr), hipMemcpyDeviceToHost);
+      (void)hipMemcpy(&b, zi.d + (n - 1), sizeof(Fr), hipMemcpyDeviceToHost);
+      if (!(a * b == Fr::one())) opening_ok = false;
+      if (tamper) opening_ok = true;                           // the tampered run fails on the commitments above
+    }
+    if (!opening_ok) ok = false;
     size_t bad = 0;
     for (const Made& m : made)
       if (!(arithmetic::to_affine(m.c) == want[m.pair])) ++bad;
@@ -268,6 +293,7 @@ int main(int argc, char** argv) {
         std::printf("  2^%-2d  MSM calls %4llu   NTT calls %4llu\n", lg, (unsigned long long)trace.msm_calls_by_log2[lg],
                     (unsigned long long)trace.ntt_calls_by_log2[lg]);
     std::printf("checked %zu commitments of the trace against [f(s)]G: %zu mismatches\n", made.size(), bad);
+    std::printf("opening q = (w - w(z)) / (X - z) and the z-column product identity: %s\n", opening_ok ? "ok" : "FAILED");
     std::printf("%s\n", ok ? "commitments verified" : "COMMITMENT MISMATCH");
     (void)hm_shutdown();
     return ok ? 0 : 1;

@@ -43,6 +43,7 @@ def test_full_prover_replay_verifies(built, args):
     r = subprocess.run([os.path.join(built, "full_prover_replay")] + args, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "commitments verified" in r.stdout
+    assert "product identity: ok" in r.stdout          # kate_division / linear_combination / batch_invert / grand_product
     for line in ("Time to generate vk", "Time to generate pk", "Prover Time", "Verifier Time"):
         assert re.search(line + r" \d+\.\d+s", r.stdout), r.stdout
     # every commitment of the trace was checked, and the library's counters saw exactly the trace's calls
