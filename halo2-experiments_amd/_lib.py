@@ -7,6 +7,9 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
+# eight commitments in flight need more than the HIP runtime's default of 4 hardware queues (capi.hip sets the same
+# default when the library is loaded; here it is set as early as the package import, before torch touches the GPU)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 LIB_PATH = os.environ.get("HALO2_MI355X_LIB") or os.path.join(CSRC, "libhalo2_mi355x.so")   # override: A/B builds
 HOSTCHECK_PATH = os.path.join(CSRC, "libhm_hostcheck.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "halo2_mi355x.h")

@@ -2,6 +2,8 @@
 // Host pointers in, host results out; device staging, base-set caching and locking live here.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include <chrono>
 #include <map>
 #include <thread>
@@ -10,6 +12,17 @@
 #include "hm_internal.h"
 
 namespace hm {
+
+// The commitments of a prover phase run eight at a time on eight streams (hm_msm_batch_bn256_g1_dev, hm_msm_submit_dev);
+// the HIP runtime maps streams onto 4 hardware queues unless told otherwise, which caps the kernels actually in flight
+// (measured at k = 18: a sparse column costs 0.215 ms with 4 queues, 0.136 ms with 16; a dense one 0.654 / 0.578 ms).
+// The variable is read when the runtime initialises, so it is set -- without overriding the caller's own choice -- when
+// this library is loaded; a process whose runtime is already up (e.g. torch touched the GPU first) keeps what it has.
+namespace {
+struct HwQueueDefault {
+  HwQueueDefault() { (void)setenv("GPU_MAX_HW_QUEUES", "16", 0); }
+} g_hw_queue_default;
+}  // namespace
 
 static thread_local std::string g_last_error;
 static std::mutex g_ctx_mu;
