@@ -82,6 +82,7 @@ struct MsmStats {
   uint32_t c = 0, windows = 0;
 };
 
+constexpr int HM_MSM_GROUP = 8;   // scalar arrays one launch chain of the five-launch plan carries (msm_small.hip)
 constexpr int HM_MSM_SLOTS = 9;   // slot 0: synchronous calls; 1..8: asynchronous tickets (workspaces allocated on first use)
 
 struct MsmSlot {            // one in-flight MSM: its workspace, events and host landing buffers
@@ -89,6 +90,8 @@ struct MsmSlot {            // one in-flight MSM: its workspace, events and host
   hipEvent_t ev[7] = {};
   bool ev_ready = false;
   bool busy = false;        // held by a ticket of hm_msm_submit_dev
+  bool awaiting = false;    // a thread is inside hm_msm_wait for this ticket (it waits and folds without the context lock)
+  bool phase_timed = false; // the MSM in flight recorded its per-phase events (ev[1..3], ev[5..6]), not only ev[0] / ev[4]
   uint64_t ticket = 0;
   uint64_t bases_handle = 0;   // base set the MSM in flight reads (a released set is freed only after its last ticket)
   size_t n = 0;
@@ -97,6 +100,9 @@ struct MsmSlot {            // one in-flight MSM: its workspace, events and host
   uint32_t* totals() { return h_land; }
   uint32_t* win() { return h_land + 4; }
   uint32_t SW = 0, c = 0, W = 0;
+  uint32_t group = 1;       // MSMs the chain in flight carries (msm_small.hip groups); their results land res_stride words apart
+  uint32_t res_stride = 0;
+  const uint32_t* live_ptr = nullptr;   // where the last five-launch chain left its (zeroed) block counters; null after any other use of ws
   const uint32_t* d_win = nullptr;   // device locations of the results of the MSM in flight (inside ws)
   const uint32_t* d_tot = nullptr;
   uint64_t T_max = 0;
@@ -222,13 +228,23 @@ int msm_convert_bases(const uint32_t* d_bases_ext, uint32_t* d_xy, uint8_t* d_in
 int msm_enqueue(DeviceCtx& ctx, int slot, const uint32_t* d_scalars_ext, const uint32_t* d_xy, const uint8_t* d_inf, size_t n,
                 uint32_t precomp_c, hipStream_t stream);
 int msm_finish(DeviceCtx& ctx, int slot, uint64_t out_jac_ext[12], int* out_is_identity);
+// the two halves of msm_finish: the blocking part touches only the slot (callable without ctx.mu while the slot is
+// busy), the bookkeeping part runs under ctx.mu
+int msm_finish_wait_fold(MsmSlot& sl, uint64_t* out_jac_ext /* 12 words per MSM of the group */, int* out_is_identity /* one per MSM */,
+                         double* host_us);
+void msm_finish_record(DeviceCtx& ctx, int slot, double host_us);
+bool msm_phase_timing(bool small_plan);    // hm_msm_set_phase_timing: -1 auto (general pipeline only), 0 never, 1 always
 int msm_slot_prepare(MsmSlot& sl);   // events + pinned landing zone, on first use
 int msm_launch_digits(const uint32_t* d_scalars_ext, const uint8_t* d_inf, int32_t* d_digits, size_t n, uint32_t c, uint32_t W,
                       hipStream_t stream);
 // msm_small.hip: the five-launch chain for n < 2^19 (plain base sets, c <= 15)
 bool msm_small_applies(size_t n, uint32_t c, bool single_set);
-int msm_issue_small(DeviceCtx& ctx, int slot, const uint32_t* d_scalars_ext, const uint32_t* d_xy, const uint8_t* d_inf, size_t n,
-                    uint32_t c, hipStream_t stream);
+int msm_issue_small(DeviceCtx& ctx, int slot, const uint32_t* const* d_scalars_list, uint32_t group, const uint32_t* d_xy,
+                    const uint8_t* d_inf, size_t n, uint32_t c, hipStream_t stream);
+// a group of MSMs over the same points through one chain (only where the five-launch plan applies: msm_group_applies)
+bool msm_group_applies(size_t n, uint32_t precomp_c);
+int msm_enqueue_group(DeviceCtx& ctx, int slot, const uint32_t* const* d_scalars_list, uint32_t group, const uint32_t* d_xy,
+                      const uint8_t* d_inf, size_t n, hipStream_t stream);
 int msm_run(DeviceCtx& ctx, const uint32_t* d_scalars_ext, const uint32_t* d_xy, const uint8_t* d_inf, size_t n,
             uint32_t precomp_c, uint64_t out_jac_ext[12], int* out_is_identity, hipStream_t stream);
 uint32_t msm_precomp_window(size_t n);

@@ -1142,6 +1142,15 @@ void host_sum_points(const uint64_t* pts, size_t count, uint64_t out_jac_ext[12]
 }
 
 static std::atomic<int> g_window_override{0};   // process-wide knob, read once per MSM
+// Per-phase events (digits / sort / accumulate / reduce, and the accumulate kernel alone) cost seven event records per
+// MSM -- nothing against a 20 ms MSM, a fifth of the host time of a prover-sized one.  -1: the general pipeline records
+// them, the five-launch plan does not; 0 / 1: never / always (hm_msm_set_phase_timing).
+static std::atomic<int> g_phase_timing{-1};
+void msm_set_phase_timing(int mode) { g_phase_timing.store(mode < 0 ? -1 : (mode ? 1 : 0), std::memory_order_relaxed); }
+bool msm_phase_timing(bool small_plan) {
+  const int m = g_phase_timing.load(std::memory_order_relaxed);
+  return m < 0 ? !small_plan : m != 0;
+}
 void msm_set_window_override(int c) { g_window_override.store(c, std::memory_order_relaxed); }
 
 // Window size for a precomputed (single bucket set) base set of n points: minimise
@@ -1246,7 +1255,7 @@ int msm_launch_digits(const uint32_t* d_scalars_ext, const uint8_t* d_inf, int32
 int msm_slot_prepare(MsmSlot& sl) {
   if (!sl.ev_ready) {
     for (int i = 0; i < 7; ++i) HM_HIP_CHECK(hipEventCreate(&sl.ev[i]));
-    HM_HIP_CHECK(hipHostMalloc((void**)&sl.h_land, (128 * 32 + 4) * sizeof(uint32_t), hipHostMallocDefault));
+    HM_HIP_CHECK(hipHostMalloc((void**)&sl.h_land, (size_t)HM_MSM_GROUP * (128 * 32 + 4) * sizeof(uint32_t), hipHostMallocDefault));
     sl.ev_ready = true;
   }
   return HM_OK;
@@ -1286,7 +1295,7 @@ static int msm_issue(DeviceCtx& ctx, int slot, const uint32_t* d_scalars_ext, co
     c = (uint32_t)ci;
   }
   if (c < 2 || c > 24) return hm_fail(HM_ERR_BAD_ARG, "msm: window size out of range");
-  if (msm_small_applies(n, c, single_set)) return msm_issue_small(ctx, slot, d_scalars_ext, d_xy, d_inf, n, c, stream);
+  if (msm_small_applies(n, c, single_set)) return msm_issue_small(ctx, slot, &d_scalars_ext, 1, d_xy, d_inf, n, c, stream);
   const uint32_t W = (255 + c - 1) / c;
   const uint32_t SW = single_set ? 1u : W;                 // bucket sets ("sort windows")
   const size_t sn = single_set ? n * W : n;                // items per bucket set
@@ -1447,6 +1456,10 @@ static int msm_issue(DeviceCtx& ctx, int slot, const uint32_t* d_scalars_ext, co
   sl.c = c;
   sl.W = W;
   sl.balanced = false;
+  sl.group = 1;
+  sl.live_ptr = nullptr;                          // the general pipeline writes all over the workspace
+  sl.phase_timed = msm_phase_timing(false);
+  const bool pt = sl.phase_timed;
   sl.T_max = T_max;
   sl.d_win = d_win;
   sl.d_tot = d_tot;
@@ -1456,7 +1469,7 @@ static int msm_issue(DeviceCtx& ctx, int slot, const uint32_t* d_scalars_ext, co
   hipLaunchKernelGGL(msm_digits_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, stream, d_scalars_ext, d_inf,
                      d_digits, n, c, W);
   HM_HIP_CHECK(hipGetLastError());
-  HM_HIP_CHECK(hipEventRecord(ev[1], stream));
+  if (pt) HM_HIP_CHECK(hipEventRecord(ev[1], stream));
 
   // ---- K2 ------------------------------------------------------------------------------------
   {
@@ -1507,13 +1520,13 @@ static int msm_issue(DeviceCtx& ctx, int slot, const uint32_t* d_scalars_ext, co
                        (const uint32_t*)d_toff, NBT, d_pairs, L, d_kcursor, d_tb, d_torder, (const uint32_t*)d_tot);
   }
   HM_HIP_CHECK(hipGetLastError());
-  HM_HIP_CHECK(hipEventRecord(ev[2], stream));
+  if (pt) HM_HIP_CHECK(hipEventRecord(ev[2], stream));
 
   // ---- K3 ------------------------------------------------------------------------------------
   // The exact task count T stays on the device (d_tot[1]); the grid covers its host-side bound: for
   // uniform scalars every bucket holds one task (T ~ NBT), else at most pairs / L more.  Surplus
   // single-wave workgroups exit at once.
-  HM_HIP_CHECK(hipEventRecord(ev[5], stream));
+  if (pt) HM_HIP_CHECK(hipEventRecord(ev[5], stream));
   {
     const uint64_t t_grid = T_max;
     hipLaunchKernelGGL(msm_accumulate_kernel, dim3((uint32_t)((t_grid + ACC_THREADS - 1) / ACC_THREADS)), dim3(ACC_THREADS), 0,
@@ -1521,7 +1534,7 @@ static int msm_issue(DeviceCtx& ctx, int slot, const uint32_t* d_scalars_ext, co
                        (const uint32_t*)d_bcnt, (const uint32_t*)d_toff, d_xy, d_partial, (const uint32_t*)d_tot, d_pairs, L);
     HM_HIP_CHECK(hipGetLastError());
   }
-  HM_HIP_CHECK(hipEventRecord(ev[6], stream));
+  if (pt) HM_HIP_CHECK(hipEventRecord(ev[6], stream));
   hipLaunchKernelGGL(msm_bucket_finalize_kernel, dim3((NBT + ACC_THREADS - 1) / ACC_THREADS), dim3(ACC_THREADS), 0, stream,
                      (const uint32_t*)d_partial, (const uint32_t*)d_toff, d_bucket, NBT, d_big_count, d_big_list, d_slices,
                      (const uint32_t*)d_tot);
@@ -1538,7 +1551,7 @@ static int msm_issue(DeviceCtx& ctx, int slot, const uint32_t* d_scalars_ext, co
                        (const uint32_t*)d_big_list);
     HM_HIP_CHECK(hipGetLastError());
   }
-  HM_HIP_CHECK(hipEventRecord(ev[3], stream));
+  if (pt) HM_HIP_CHECK(hipEventRecord(ev[3], stream));
 
   // ---- K4 ------------------------------------------------------------------------------------
   hipLaunchKernelGGL(msm_reduce_segments_kernel, dim3((SW * nseg + ACC_THREADS - 1) / ACC_THREADS), dim3(ACC_THREADS), 0,
@@ -1575,26 +1588,60 @@ int msm_enqueue(DeviceCtx& ctx, int slot, const uint32_t* d_scalars_ext, const u
   return msm_issue(ctx, slot, d_scalars_ext, d_xy, d_inf, n, precomp_c, stream);
 }
 
-// Wait for slot `slot`, fold its window sums (host Horner + affine normalisation) and record stats.
-int msm_finish(DeviceCtx& ctx, int slot, uint64_t out_jac_ext[12], int* out_is_identity) {
+// The window plan of the five-launch chain for n points, or 0 when it does not apply (n >= 2^19, a precomputed set,
+// an override outside its range): the same choice msm_issue makes for a single MSM.
+static uint32_t small_plan_window(size_t n, uint32_t precomp_c) {
+  if (precomp_c != 0 || n == 0 || n >= (1u << 19)) return 0;
+  static const int8_t kWindowSmallPlan[19] = {4, 4, 4, 4, 4, 4, 4, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 15, 15};
+  const int window_override = g_window_override.load(std::memory_order_relaxed);
+  const uint32_t c = window_override ? (uint32_t)window_override : (uint32_t)kWindowSmallPlan[ilog2(n)];
+  return msm_small_applies(n, c, false) ? c : 0;
+}
+bool msm_group_applies(size_t n, uint32_t precomp_c) { return small_plan_window(n, precomp_c) != 0; }
+
+// `group` MSMs over the same n points through ONE launch chain (msm_small.hip); the slot then carries `group` results.
+int msm_enqueue_group(DeviceCtx& ctx, int slot, const uint32_t* const* d_scalars_list, uint32_t group, const uint32_t* d_xy,
+                      const uint8_t* d_inf, size_t n, hipStream_t stream) {
   MsmSlot& sl = ctx.msm_slots[slot];
+  const uint32_t c = small_plan_window(n, 0);
+  if (!c) return hm_fail(HM_ERR_INTERNAL, "msm: a group needs the five-launch plan");
+  sl.n = n;
+  sl.stream = stream;
+  return msm_issue_small(ctx, slot, d_scalars_list, group, d_xy, d_inf, n, c, stream);
+}
+
+// Wait for the slot's chain and fold the window sums of each of its MSMs (host Horner + affine normalisation).  Touches
+// only the slot: a busy slot is not handed out again, so this part runs without the context lock.
+int msm_finish_wait_fold(MsmSlot& sl, uint64_t* out_jac_ext, int* out_is_identity, double* host_us) {
+  *host_us = 0;
   if (sl.n == 0) {
     std::memset(out_jac_ext, 0, 96);
     *out_is_identity = 1;
     return HM_OK;
   }
-  hipEvent_t* ev = sl.ev;
-  HM_HIP_CHECK(hipEventSynchronize(ev[4]));
-  if (sl.totals()[2] != 0) return hm_fail(HM_ERR_INTERNAL, "msm: task count exceeds its bound");
+  HM_HIP_CHECK(hipEventSynchronize(sl.ev[4]));
   const auto f0 = std::chrono::steady_clock::now();
-  host_fold(sl.win(), sl.SW, sl.c, out_jac_ext, out_is_identity, sl.balanced ? sl.win_bits : nullptr);   // SW == 1: just the normalisation
-  ctx.calls.msm_host_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - f0).count();
+  for (uint32_t e = 0; e < sl.group; ++e) {
+    const uint32_t* land = sl.h_land + (size_t)e * sl.res_stride;      // group == 1: res_stride is not used
+    if (land[2] != 0) return hm_fail(HM_ERR_INTERNAL, "msm: task count exceeds its bound");
+    host_fold(land + 4, sl.SW, sl.c, out_jac_ext + 12 * e, out_is_identity + e, sl.balanced ? sl.win_bits : nullptr);   // SW == 1: just the normalisation
+  }
+  *host_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - f0).count();
+  return HM_OK;
+}
 
-  float ms[4] = {0, 0, 0, 0}, total = 0;
-  float acc_kernel = 0;
+// statistics of the MSM just finished on `slot` (ctx.mu held)
+void msm_finish_record(DeviceCtx& ctx, int slot, double host_us) {
+  MsmSlot& sl = ctx.msm_slots[slot];
+  if (sl.n == 0) return;
+  ctx.calls.msm_host_us += host_us;
+  hipEvent_t* ev = sl.ev;
+  float ms[4] = {0, 0, 0, 0}, total = 0, acc_kernel = 0;
   (void)hipEventElapsedTime(&total, ev[0], ev[4]);
-  for (int i = 0; i < 4; ++i) (void)hipEventElapsedTime(&ms[i], ev[i], ev[i + 1]);
-  (void)hipEventElapsedTime(&acc_kernel, ev[5], ev[6]);
+  if (sl.phase_timed) {
+    for (int i = 0; i < 4; ++i) (void)hipEventElapsedTime(&ms[i], ev[i], ev[i + 1]);
+    (void)hipEventElapsedTime(&acc_kernel, ev[5], ev[6]);
+  }
   ctx.last_msm.t_accum_kernel_ms = acc_kernel;
   ctx.last_msm.t_digits_ms = ms[0];
   ctx.last_msm.t_sort_ms = ms[1];
@@ -1605,7 +1652,13 @@ int msm_finish(DeviceCtx& ctx, int slot, uint64_t out_jac_ext[12], int* out_is_i
   ctx.last_msm.tasks = sl.totals()[1];
   ctx.last_msm.c = sl.c;
   ctx.last_msm.windows = sl.W;
-  return HM_OK;
+}
+
+int msm_finish(DeviceCtx& ctx, int slot, uint64_t out_jac_ext[12], int* out_is_identity) {
+  double host_us = 0;
+  const int rc = msm_finish_wait_fold(ctx.msm_slots[slot], out_jac_ext, out_is_identity, &host_us);
+  if (rc == HM_OK) msm_finish_record(ctx, slot, host_us);
+  return rc;
 }
 
 // the synchronous form: slot 0, enqueue then finish

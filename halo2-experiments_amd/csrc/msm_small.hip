@@ -24,6 +24,11 @@
 //                LDS tree, so the work follows the data instead of the bucket count
 //   E  reduce 2  per window: tree over D's outputs -> external format
 // SEG is chosen so that D runs at most one wave per SIMD (the depth of a lane's chain is what costs, not the work).
+//
+// GROUPS.  The commitments of one prover phase share n, the window plan and the base set, and each of them alone is
+// bound by launch gaps and chain depth.  So the five launches take a group dimension: up to HM_MSM_GROUP scalar arrays
+// run through ONE chain (grid.y / grid.z = the group element, every workspace pointer advanced by e * ws_stride bytes,
+// results landing back to back for one D2H copy).  A single MSM is the group of one.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -47,17 +52,33 @@ constexpr uint32_t S_MAX_L = 1023;
 // ---- A: digits, balanced window widths ----------------------------------------------------------
 // Window w is `wide` bits for w < n_wide, else wide - 1 bits (n_wide * wide + (W - n_wide) * (wide - 1) = 255).
 // The top window holds bit 254, which is zero for every canonical scalar, so its digit never carries out.
-__global__ __launch_bounds__(SA_THREADS) void msm_s_digits_kernel(const uint32_t* __restrict__ scalars,
-                                                                  const uint8_t* __restrict__ inf, int32_t* __restrict__ digits,
-                                                                  uint32_t n, uint32_t wide, uint32_t n_wide, uint32_t W,
-                                                                  uint32_t* __restrict__ gctr) {
+struct SmallGroupScalars {       // the scalar arrays of one group, by value
+  const uint32_t* s[HM_MSM_GROUP];
+};
+template <class T>
+__device__ __forceinline__ T* ws_at(T* p, size_t ws_stride, uint32_t e) {   // element e's copy of a workspace array
+  return reinterpret_cast<T*>(reinterpret_cast<uintptr_t>(p) + (size_t)e * ws_stride);
+}
+
+__global__ __launch_bounds__(SA_THREADS) void msm_s_digits_kernel(SmallGroupScalars group, const uint8_t* __restrict__ inf,
+                                                                  int32_t* __restrict__ digits, uint32_t n, uint32_t wide,
+                                                                  uint32_t n_wide, uint32_t W, uint32_t* __restrict__ gctr,
+                                                                  uint32_t* __restrict__ blkidx, uint32_t* __restrict__ live_counts,
+                                                                  size_t ws_stride) {
+  const uint32_t e = blockIdx.y;
+  const uint32_t* __restrict__ scalars = group.s[e];
+  digits = ws_at(digits, ws_stride, e);
+  gctr = ws_at(gctr, ws_stride, e);
+  blkidx = ws_at(blkidx, ws_stride, e);
+  uint32_t* live_count = live_counts + e;       // the group's counters lie together (cleared by one memset before this launch)
+  const uint32_t n_pad = (n + SA_THREADS - 1) / SA_THREADS * SA_THREADS;     // row stride of the digit array
   const uint32_t i = blockIdx.x * SA_THREADS + threadIdx.x;
   if (i == 0) {                 // the two run-reservation counters of B start from zero (stream order: before B)
     gctr[0] = 0;
     gctr[1] = 0;
   }
-  if (i >= n) return;
-  const uint4* q = reinterpret_cast<const uint4*>(scalars + (size_t)i * 8);
+  const bool in_range = i < n;
+  const uint4* q = reinterpret_cast<const uint4*>(scalars + (size_t)(in_range ? i : 0) * 8);
   const uint4 lo = q[0], hi = q[1];
   const uint32_t w_in[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
   Fr k32 = fe_zero<FrParams>();
@@ -71,12 +92,27 @@ __global__ __launch_bounds__(SA_THREADS) void msm_s_digits_kernel(const uint32_t
     for (int k = 0; k < 8; ++k) v[k] = t[k];
     v[8] = 0;
   }
-  const bool skip = inf[i] != 0;
+  // Rows with a zero scalar (most rows of an advice column) or an identity base contribute nothing.  The digit array is
+  // written COMPACTED BY BLOCKS of SA_THREADS rows: a workgroup without a surviving row writes nothing, the others take
+  // the next free block (one atomic per workgroup) and note which rows it holds in blkidx -- so the sort streams
+  // m = 256 x (blocks with a survivor) rows per window instead of n, and a dense column pays one table lookup per block.
+  uint32_t any = 0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) any |= v[k];
+  const bool live = in_range && inf[i] == 0 && any != 0;
+  __shared__ uint32_t wg_block;
+  if (!__syncthreads_or(live ? 1 : 0)) return;
+  if (threadIdx.x == 0) {
+    wg_block = atomicAdd(live_count, 1u);
+    blkidx[wg_block] = blockIdx.x;
+  }
+  __syncthreads();
+  const uint32_t j = wg_block * SA_THREADS + threadIdx.x;
   uint32_t carry = 0;
   for (uint32_t w = 0; w < W; ++w) {
     const uint32_t bits = w < n_wide ? wide : wide - 1;
-    const uint32_t mask = (1u << bits) - 1u, half = 1u << (bits - 1);
-    const uint32_t d = (v[0] & mask) + carry;
+    const uint32_t mask_w = (1u << bits) - 1u, half = 1u << (bits - 1);
+    const uint32_t d = (v[0] & mask_w) + carry;
     int32_t sd;
     if (d > half) {
       sd = (int32_t)d - (int32_t)(1u << bits);
@@ -85,7 +121,7 @@ __global__ __launch_bounds__(SA_THREADS) void msm_s_digits_kernel(const uint32_t
       sd = (int32_t)d;
       carry = 0;
     }
-    digits[(size_t)w * n + i] = skip ? 0 : sd;
+    digits[(size_t)w * n_pad + j] = live ? sd : 0;
 #pragma unroll
     for (int k = 0; k < 8; ++k) v[k] = __funnelshift_r(v[k], v[k + 1], bits);
   }
@@ -162,8 +198,26 @@ __global__ __launch_bounds__(SS_THREADS) void msm_s_sort_kernel(const int32_t* _
                                                                 uint32_t* __restrict__ gctr, uint4* __restrict__ desc,
                                                                 uint32_t* __restrict__ sorted, uint32_t* __restrict__ nz,
                                                                 uint32_t* __restrict__ nzc, uint32_t n, uint32_t NBh, uint32_t H,
-                                                                uint32_t L) {
+                                                                uint32_t L, const uint32_t* __restrict__ blkidx,
+                                                                const uint32_t* __restrict__ live_counts, size_t ws_stride) {
   extern __shared__ uint32_t sm[];
+  __shared__ uint32_t blk_tab[(1u << 19) / SA_THREADS];      // compacted block -> first original row / SA_THREADS
+  uint32_t m;                                      // rows of the compacted digit array of this MSM (A)
+  const uint32_t n_pad = (n + SA_THREADS - 1) / SA_THREADS * SA_THREADS;
+  {
+    const uint32_t e = blockIdx.y;
+    const uint32_t nblk = live_counts[e];
+    m = nblk * SA_THREADS;
+    blkidx = ws_at(blkidx, ws_stride, e);
+    for (uint32_t b = threadIdx.x; b < nblk; b += SS_THREADS) blk_tab[b] = blkidx[b];
+    digits = ws_at(digits, ws_stride, e);
+    toff = ws_at(toff, ws_stride, e);
+    gctr = ws_at(gctr, ws_stride, e);
+    desc = ws_at(desc, ws_stride, e);
+    sorted = ws_at(sorted, ws_stride, e);
+    nz = ws_at(nz, ws_stride, e);
+    nzc = ws_at(nzc, ws_stride, e);
+  }
   const uint32_t NBP = NBh + 1;
   uint32_t* cnt = sm;                         // bucket counts, then the scatter cursors
   uint32_t* kh = cnt + ((NBP + 31) & ~31u);   // key histogram, later the per-key local cursors
@@ -172,12 +226,12 @@ __global__ __launch_bounds__(SS_THREADS) void msm_s_sort_kernel(const int32_t* _
   __shared__ uint32_t hot_n, hot[S_HOT][4], base_pt[2];
   const uint32_t v = blockIdx.x, w = v / H, h = v - w * H, tid = threadIdx.x;
   const uint32_t blo = h * NBh;               // this range: blo < |digit| <= blo + NBh
-  const int32_t* dw = digits + (size_t)w * n;
+  const int32_t* dw = digits + (size_t)w * n_pad;
   for (uint32_t b = tid; b < NBP; b += SS_THREADS) cnt[b] = 0;
   kh[tid] = 0;
   if (tid == 0) hot_n = 0;
   __syncthreads();
-  window_for_each_digit(dw, n, [&](uint32_t, int32_t d) {
+  window_for_each_digit(dw, m, [&](uint32_t, int32_t d) {
     const uint32_t lb = (uint32_t)(d < 0 ? -d : d) - blo;          // wraps for |d| <= blo
     if (lb - 1u < NBh) (void)lds_inc(cnt, lb);
   });
@@ -244,10 +298,11 @@ __global__ __launch_bounds__(SS_THREADS) void msm_s_sort_kernel(const int32_t* _
     for (uint32_t i = tid; i < full; i += SS_THREADS) dsc[at + i] = make_uint4(start + i * L, t0 + i, L, 0);
   }
   uint32_t* sw = sorted + base_p;
-  window_for_each_digit(dw, n, [&](uint32_t i, int32_t d) {
+  window_for_each_digit(dw, m, [&](uint32_t j, int32_t d) {
     const uint32_t lb = (uint32_t)(d < 0 ? -d : d) - blo;
     if (lb - 1u < NBh) {
       const uint32_t pos = lds_inc(cnt, lb);
+      const uint32_t i = blk_tab[j / SA_THREADS] * SA_THREADS + (j % SA_THREADS);
       sw[pos] = i | (d < 0 ? 0x80000000u : 0u);
     }
   });
@@ -257,8 +312,16 @@ __global__ __launch_bounds__(SS_THREADS) void msm_s_sort_kernel(const int32_t* _
 __global__ __launch_bounds__(ACC_THREADS) void msm_s_accumulate_kernel(const uint32_t* __restrict__ sorted,
                                                                        const uint4* __restrict__ desc,
                                                                        const uint32_t* __restrict__ gctr,
-                                                                       const uint32_t* __restrict__ xy, uint32_t* __restrict__ partial) {
+                                                                       const uint32_t* __restrict__ xy, uint32_t* __restrict__ partial,
+                                                                       size_t ws_stride) {
   __shared__ uint4 stage[4][ACC_THREADS];
+  {
+    const uint32_t e = blockIdx.y;
+    sorted = ws_at(sorted, ws_stride, e);
+    desc = ws_at(desc, ws_stride, e);
+    gctr = ws_at(gctr, ws_stride, e);
+    partial = ws_at(partial, ws_stride, e);
+  }
   const uint32_t lane = threadIdx.x;
   const uint32_t slot = blockIdx.x * ACC_THREADS + lane;
   if (slot >= gctr[1]) return;                 // the grid covers the host-side bound on the task count
@@ -359,19 +422,32 @@ constexpr uint32_t S_SPARSE_DIV = 8;
 __global__ __launch_bounds__(WIN_THREADS) void msm_s_reduce1_kernel(uint32_t* __restrict__ partial, const uint32_t* __restrict__ toff,
                                                                     const uint32_t* __restrict__ nz, const uint32_t* __restrict__ nzc,
                                                                     uint32_t* __restrict__ seg1, uint32_t NBh, uint32_t H, uint32_t SEG,
-                                                                    uint32_t G1n) {
+                                                                    uint32_t G1n, size_t ws_stride) {
   __shared__ uint32_t tree[WIN_THREADS * PT_WORDS];
   __shared__ uint32_t hot_n, hot_b[S_HOT_LIST], hot_lane0[S_HOT_LIST + 1], round_info[2];
+  {
+    const uint32_t e = blockIdx.z;
+    partial = ws_at(partial, ws_stride, e);
+    toff = ws_at(toff, ws_stride, e);
+    nz = ws_at(nz, ws_stride, e);
+    nzc = ws_at(nzc, ws_stride, e);
+    seg1 = ws_at(seg1, ws_stride, e);
+  }
   const uint32_t v = blockIdx.y, g = blockIdx.x, tid = threadIdx.x;
   const uint32_t h = v % H;
   const uint32_t* tw = toff + (size_t)v * (NBh + 2);
   const uint32_t count = nzc[v];
   G1Jac acc = g1_identity();
+  uint32_t active = WIN_THREADS;                   // leading lanes of this workgroup that hold a term of the sum
   if (count > NBh / S_SPARSE_DIV) {
     const uint32_t sgi = g * WIN_THREADS + tid;
     const uint32_t lo = sgi * SEG + 1;             // local bucket numbers lo .. hi
     const bool valid = lo <= NBh;
     const uint32_t hi = valid ? (lo + SEG - 1 < NBh ? lo + SEG - 1 : NBh) : 0;
+    {
+      const uint32_t nseg = (NBh + SEG - 1) / SEG, first = g * WIN_THREADS;
+      active = nseg > first ? (nseg - first < (uint32_t)WIN_THREADS ? nseg - first : (uint32_t)WIN_THREADS) : 0u;
+    }
     if (tid == 0) hot_n = 0;
     __syncthreads();
     if (valid)
@@ -395,6 +471,11 @@ __global__ __launch_bounds__(WIN_THREADS) void msm_s_reduce1_kernel(uint32_t* __
   } else {
     const uint32_t* list = nz + (size_t)v * NBh;
     const uint32_t stride = G1n * WIN_THREADS;
+    if (g * WIN_THREADS >= count) {                // nothing for this workgroup (the usual case of a sparse range): no tree
+      if (tid == 0) store_jac(seg1 + ((size_t)v * G1n + g) * PT_WORDS, g1_identity());
+      return;
+    }
+    active = count - g * WIN_THREADS < (uint32_t)WIN_THREADS ? count - g * WIN_THREADS : (uint32_t)WIN_THREADS;
     for (uint32_t i0 = g * WIN_THREADS; i0 < count; i0 += stride) {          // one round for every realistic count
       const uint32_t i = i0 + tid;
       const uint32_t b = i < count ? list[i] : 0;
@@ -411,15 +492,25 @@ __global__ __launch_bounds__(WIN_THREADS) void msm_s_reduce1_kernel(uint32_t* __
       __syncthreads();
     }
   }
-  const G1Jac res = block_sum_points(tree, acc);
+  // only the leading `active` lanes hold anything: ceil(log2 active) levels of the tree instead of eight
+  const G1Jac res = active ? block_sum_points_upto(tree, acc, active) : g1_identity();
   if (tid == 0) store_jac(seg1 + ((size_t)v * G1n + g) * PT_WORDS, res);
 }
 
 // ---- E: one point per window, external format ------------------------------------------------------
 __global__ __launch_bounds__(WIN_THREADS) void msm_s_reduce2_kernel(const uint32_t* __restrict__ seg1, uint32_t per_window,
                                                                     uint32_t* __restrict__ winres, const uint32_t* __restrict__ gctr,
-                                                                    uint32_t* __restrict__ totals) {
+                                                                    uint32_t* __restrict__ totals, size_t ws_stride, uint32_t res_stride,
+                                                                    uint32_t* __restrict__ live_counts) {
   __shared__ uint32_t tree[WIN_THREADS * PT_WORDS];
+  {
+    const uint32_t e = blockIdx.y;                 // the results of a group lie back to back: res_stride words per element
+    if (blockIdx.x == 0 && threadIdx.x == 0) live_counts[e] = 0;   // A's block counter: clean for the next chain of this slot
+    seg1 = ws_at(seg1, ws_stride, e);
+    gctr = ws_at(gctr, ws_stride, e);
+    winres += (size_t)e * res_stride;
+    totals += (size_t)e * res_stride;
+  }
   const uint32_t w = blockIdx.x, tid = threadIdx.x;
   G1Jac acc = g1_identity();
   for (uint32_t t = tid; t < per_window; t += WIN_THREADS) acc = g1_add(acc, load_jac(seg1 + ((size_t)w * per_window + t) * PT_WORDS));
@@ -443,9 +534,10 @@ bool msm_small_applies(size_t n, uint32_t c, bool single_set) {
   return enabled && !single_set && n >= 1 && n < (1u << 19) && c >= 2 && c <= 15;
 }
 
-int msm_issue_small(DeviceCtx& ctx, int slot, const uint32_t* d_scalars_ext, const uint32_t* d_xy, const uint8_t* d_inf, size_t n,
-                    uint32_t c, hipStream_t stream) {
+int msm_issue_small(DeviceCtx& ctx, int slot, const uint32_t* const* d_scalars_list, uint32_t group, const uint32_t* d_xy,
+                    const uint8_t* d_inf, size_t n, uint32_t c, hipStream_t stream) {
   MsmSlot& sl = ctx.msm_slots[slot];
+  if (group < 1 || group > (uint32_t)HM_MSM_GROUP) return hm_fail(HM_ERR_INTERNAL, "msm (small plan): bad group size");
   static const int env_L = env_int("HALO2_MI355X_SMALL_L", 0), env_seg = env_int("HALO2_MI355X_SMALL_SEG", 0),
                    env_H = env_int("HALO2_MI355X_SMALL_H", 0);
   const uint32_t W = (255 + c - 1) / c;
@@ -477,6 +569,10 @@ int msm_issue_small(DeviceCtx& ctx, int slot, const uint32_t* d_scalars_ext, con
   // what costs is the depth of a lane's chain (2 SEG additions + a log2(NB)-bit multiple), not the work
   uint32_t SEG = 2;
   while (SEG < NBh && (uint64_t)V * ((NBh / SEG + WIN_THREADS - 1) / WIN_THREADS) > 256) ++SEG;
+  // a group multiplies the workgroups: then count WAVES with a segment to sum -- one per SIMD (1024) over the whole group
+  // (never fewer than one wave per virtual window and element: 64 segments there is the coarsest useful cut)
+  if (group > 1)
+    while (SEG < NBh && (NBh + SEG - 1) / SEG > 64 && (uint64_t)V * group * (((NBh + SEG - 1) / SEG + 63) / 64) > 1024) ++SEG;
   if (env_seg > 0) SEG = (uint32_t)env_seg;
   if (SEG > NBh) SEG = NBh;
   const uint32_t nseg = (NBh + SEG - 1) / SEG;
@@ -487,7 +583,7 @@ int msm_issue_small(DeviceCtx& ctx, int slot, const uint32_t* d_scalars_ext, con
   auto align = [](size_t v) { return (v + 255) & ~(size_t)255; };
   size_t off = 0;
   auto carve = [&](size_t bytes) { size_t o = off; off += align(bytes); return o; };
-  const size_t o_digits = carve(pairs_max * 4);
+  const size_t o_digits = carve((size_t)((n + SA_THREADS - 1) / SA_THREADS * SA_THREADS) * W * 4);   // rows padded to whole blocks
   const size_t o_toff = carve((size_t)V * (NBh + 2) * 4);
   const size_t o_gctr = carve(16);
   const size_t o_nz = carve((size_t)V * NBh * 4);
@@ -496,8 +592,12 @@ int msm_issue_small(DeviceCtx& ctx, int slot, const uint32_t* d_scalars_ext, con
   const size_t o_sorted = carve(pairs_max * 4);
   const size_t o_partial = carve(T_max * PT_WORDS * 4);
   const size_t o_seg1 = carve((size_t)V * G1n * PT_WORDS * 4);
-  const size_t o_res = carve((4 + (size_t)W * 32) * 4);
-  uint8_t* ws = (uint8_t*)sl.ws.ensure(off);
+  const size_t o_blkidx = carve(((n + SA_THREADS - 1) / SA_THREADS) * 4);
+  const size_t ws_stride = off;                                   // one element's arrays; the group's results follow them all
+  const uint32_t res_stride = 4 + W * 32;                         // words per element: totals, then the window sums
+  const size_t o_res = ws_stride * group;
+  const size_t o_live = o_res + (((size_t)group * res_stride * 4 + 255) & ~(size_t)255);     // the group's survivor counters, together
+  uint8_t* ws = (uint8_t*)sl.ws.ensure(o_live + (size_t)HM_MSM_GROUP * 4);
   if (!ws) return hm_fail(HM_ERR_HIP, "msm (small plan): workspace allocation failed");
   int32_t* d_digits = (int32_t*)(ws + o_digits);
   uint32_t* d_toff = (uint32_t*)(ws + o_toff);
@@ -508,6 +608,8 @@ int msm_issue_small(DeviceCtx& ctx, int slot, const uint32_t* d_scalars_ext, con
   uint32_t* d_sorted = (uint32_t*)(ws + o_sorted);
   uint32_t* d_partial = (uint32_t*)(ws + o_partial);
   uint32_t* d_seg1 = (uint32_t*)(ws + o_seg1);
+  uint32_t* d_blkidx = (uint32_t*)(ws + o_blkidx);
+  uint32_t* d_live = (uint32_t*)(ws + o_live);
   uint32_t* d_tot = (uint32_t*)(ws + o_res);
   uint32_t* d_win = d_tot + 4;
 
@@ -527,29 +629,39 @@ int msm_issue_small(DeviceCtx& ctx, int slot, const uint32_t* d_scalars_ext, con
   sl.d_win = d_win;
   sl.d_tot = d_tot;
   sl.balanced = true;
+  sl.group = group;
+  sl.res_stride = res_stride;
+  sl.phase_timed = msm_phase_timing(true);
+  const bool pt = sl.phase_timed;
   for (uint32_t w = 0; w < W; ++w) sl.win_bits[w] = (uint8_t)(w < n_wide ? wide : wide - 1);
 
   HM_HIP_CHECK(hipEventRecord(ev[0], stream));
-  hipLaunchKernelGGL(msm_s_digits_kernel, dim3((uint32_t)((n + SA_THREADS - 1) / SA_THREADS)), dim3(SA_THREADS), 0, stream,
-                     d_scalars_ext, d_inf, d_digits, (uint32_t)n, wide, n_wide, W, d_gctr);
+  if (sl.live_ptr != d_live) {                    // the last chain of this slot left its counters at zero unless the layout moved
+    HM_HIP_CHECK(hipMemsetAsync(d_live, 0, (size_t)HM_MSM_GROUP * 4, stream));
+    sl.live_ptr = d_live;
+  }
+  SmallGroupScalars gs;
+  for (uint32_t e = 0; e < (uint32_t)HM_MSM_GROUP; ++e) gs.s[e] = d_scalars_list[e < group ? e : 0];
+  hipLaunchKernelGGL(msm_s_digits_kernel, dim3((uint32_t)((n + SA_THREADS - 1) / SA_THREADS), group), dim3(SA_THREADS), 0, stream,
+                     gs, d_inf, d_digits, (uint32_t)n, wide, n_wide, W, d_gctr, d_blkidx, d_live, ws_stride);
   HM_HIP_CHECK(hipGetLastError());
-  HM_HIP_CHECK(hipEventRecord(ev[1], stream));
-  hipLaunchKernelGGL(msm_s_sort_kernel, dim3(V), dim3(SS_THREADS), lds_sort, stream, (const int32_t*)d_digits, d_toff, d_gctr, d_desc,
-                     d_sorted, d_nz, d_nzc, (uint32_t)n, NBh, H, L);
+  if (pt) HM_HIP_CHECK(hipEventRecord(ev[1], stream));
+  hipLaunchKernelGGL(msm_s_sort_kernel, dim3(V, group), dim3(SS_THREADS), lds_sort, stream, (const int32_t*)d_digits, d_toff, d_gctr, d_desc,
+                     d_sorted, d_nz, d_nzc, (uint32_t)n, NBh, H, L, (const uint32_t*)d_blkidx, (const uint32_t*)d_live, ws_stride);
   HM_HIP_CHECK(hipGetLastError());
-  HM_HIP_CHECK(hipEventRecord(ev[2], stream));
-  HM_HIP_CHECK(hipEventRecord(ev[5], stream));
-  hipLaunchKernelGGL(msm_s_accumulate_kernel, dim3((uint32_t)((T_max + ACC_THREADS - 1) / ACC_THREADS)), dim3(ACC_THREADS), 0, stream,
-                     (const uint32_t*)d_sorted, (const uint4*)d_desc, (const uint32_t*)d_gctr, d_xy, d_partial);
+  if (pt) HM_HIP_CHECK(hipEventRecord(ev[2], stream));
+  if (pt) HM_HIP_CHECK(hipEventRecord(ev[5], stream));
+  hipLaunchKernelGGL(msm_s_accumulate_kernel, dim3((uint32_t)((T_max + ACC_THREADS - 1) / ACC_THREADS), group), dim3(ACC_THREADS), 0, stream,
+                     (const uint32_t*)d_sorted, (const uint4*)d_desc, (const uint32_t*)d_gctr, d_xy, d_partial, ws_stride);
   HM_HIP_CHECK(hipGetLastError());
-  HM_HIP_CHECK(hipEventRecord(ev[6], stream));
-  HM_HIP_CHECK(hipEventRecord(ev[3], stream));
-  hipLaunchKernelGGL(msm_s_reduce1_kernel, dim3(G1n, V), dim3(WIN_THREADS), 0, stream, d_partial, (const uint32_t*)d_toff,
-                     (const uint32_t*)d_nz, (const uint32_t*)d_nzc, d_seg1, NBh, H, SEG, G1n);
-  hipLaunchKernelGGL(msm_s_reduce2_kernel, dim3(W), dim3(WIN_THREADS), 0, stream, (const uint32_t*)d_seg1, H * G1n, d_win,
-                     (const uint32_t*)d_gctr, d_tot);
+  if (pt) HM_HIP_CHECK(hipEventRecord(ev[6], stream));
+  if (pt) HM_HIP_CHECK(hipEventRecord(ev[3], stream));
+  hipLaunchKernelGGL(msm_s_reduce1_kernel, dim3(G1n, V, group), dim3(WIN_THREADS), 0, stream, d_partial, (const uint32_t*)d_toff,
+                     (const uint32_t*)d_nz, (const uint32_t*)d_nzc, d_seg1, NBh, H, SEG, G1n, ws_stride);
+  hipLaunchKernelGGL(msm_s_reduce2_kernel, dim3(W, group), dim3(WIN_THREADS), 0, stream, (const uint32_t*)d_seg1, H * G1n, d_win,
+                     (const uint32_t*)d_gctr, d_tot, ws_stride, res_stride, d_live);
   HM_HIP_CHECK(hipGetLastError());
-  HM_HIP_CHECK(hipMemcpyAsync(sl.totals(), d_tot, (4 + (size_t)W * 32) * 4, hipMemcpyDeviceToHost, stream));
+  HM_HIP_CHECK(hipMemcpyAsync(sl.totals(), d_tot, (size_t)group * res_stride * 4, hipMemcpyDeviceToHost, stream));
   HM_HIP_CHECK(hipEventRecord(ev[4], stream));
   return HM_OK;
 }

@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstring>
+#include <vector>
 
 #include "g1.h"
 #include "hm_internal.h"
@@ -441,6 +442,15 @@ int fr_linear_combination_run(const void* const* d_polys, const uint64_t* coeffs
     HM_HIP_CHECK(hipMemsetAsync(d_out, 0, n * 32, stream));
     return HM_OK;
   }
+  // terms that read d_out itself must all be consumed by the FIRST launch (later launches see the running sum there)
+  std::vector<size_t> order;
+  order.reserve(count);
+  for (size_t j = 0; j < count; ++j)
+    if (d_polys[j] == (const void*)d_out) order.push_back(j);
+  if (order.size() > (size_t)LC_MAX)
+    return hm_fail(HM_ERR_BAD_ARG, "linear_combination: the output appears among the inputs more than 24 times");
+  for (size_t j = 0; j < count; ++j)
+    if (d_polys[j] != (const void*)d_out) order.push_back(j);
   size_t done = 0;
   bool first = true;
   while (done < count) {
@@ -453,8 +463,8 @@ int fr_linear_combination_run(const void* const* d_polys, const uint64_t* coeffs
       k = 1;
     }
     while (k < (uint32_t)LC_MAX && done < count) {
-      args.poly[k] = (const uint32_t*)d_polys[done];
-      po_internal(coeffs_ext + done * 4, args.c[k]);
+      args.poly[k] = (const uint32_t*)d_polys[order[done]];
+      po_internal(coeffs_ext + order[done] * 4, args.c[k]);
       ++k;
       ++done;
     }

@@ -129,6 +129,10 @@ int hm_set_host_base_cache(int enable);
 
 /* Window-size override for experiments (0 = automatic). */
 int hm_msm_set_window(int c);
+/* Per-phase timing of an MSM (digits / sort / accumulate / reduce and the accumulate kernel alone, reported by
+ * hm_get_msm_stats) costs seven event records per call.  mode -1 (default): the general pipeline (n >= 2^19 and
+ * precomputed sets) records them, the five-launch plan of prover sizes records only the total; 0: never; 1: always. */
+int hm_msm_set_phase_timing(int mode);
 
 /* ---- NTT: stands in for halo2_proofs::arithmetic::best_fft::<bn256::Fr> --------------------- */
 
@@ -200,8 +204,8 @@ int hm_fr_batch_invert_dev(void* d_values, size_t n, void* stream);
 
 /* d_out[i] = sum_{j < count} coeffs[j] * d_polys[j][i] for i < n: `Polynomial * scalar` and `+` of upstream
  * poly.rs in one pass (the random linear combinations of multiopen, the pieces of h(X)).  d_polys: host array of
- * `count` device pointers (n x 4 u64 each); coeffs: host, count x 4 u64.  d_out may be one of the inputs.  count = 0
- * zeroes d_out.  Asynchronous on `stream`. */
+ * `count` device pointers (n x 4 u64 each); coeffs: host, count x 4 u64.  d_out may be one of the inputs (the same
+ * pointer, not a shifted view).  count = 0 zeroes d_out.  Asynchronous on `stream`. */
 int hm_fr_linear_combination_dev(const void* const* d_polys, const uint64_t* coeffs, size_t count, size_t n, void* d_out,
                                  void* stream);
 

@@ -462,6 +462,39 @@ def test_batched_commitments_equal_single_calls(cref, golden):
         h.release_bases(hd)
 
 
+def test_grouped_chains_with_empty_ragged_and_identity_rows(cref, pyref):
+    """The group form of the five-launch plan (one chain carries several commitments) on a length that is not a multiple
+    of the 256-row compaction block: an all-zero column (no surviving block at all), a column whose only non-zero scalar
+    sits in the last, partial block, a column that only meets identity bases, dense columns -- against the oracle."""
+    import torch
+    n = 3001
+    gen = cref.g1_generator()
+    bases = h.g1_fixed_base_mul(rand_fr_gpu(n, 8400), gen)
+    bases[5] = 0                                             # identity bases (0, 0)
+    bases[n - 1] = 0
+    hd = h.register_bases(bases)
+    try:
+        zero = torch.zeros((n, 4), dtype=torch.int64, device="cuda")
+        last = zero.clone()
+        last[n - 2] = rand_fr_gpu(1, 8401)[0]
+        only_identity = zero.clone()
+        only_identity[5] = rand_fr_gpu(1, 8402)[0]
+        only_identity[n - 1] = rand_fr_gpu(1, 8403)[0]
+        cols = [zero, last, rand_fr_gpu(n, 8404), only_identity, rand_fr_gpu(n, 8405), zero, last, rand_fr_gpu(n, 8406), zero]
+        bh = bases.cpu().numpy().view(np.uint64)
+        want = [cref.g1_to_affine(cref.best_multiexp(c.cpu().numpy().view(np.uint64), bh, 4))[0] for c in cols]
+        from halo2_experiments_amd.arithmetic import best_multiexp_batch
+        for _ in range(2):
+            got = best_multiexp_batch(cols, hd)
+            for g, w in zip(got, want):
+                assert g1_equal(g, w)
+        assert not got[0][8:].any() and not got[3][8:].any()  # the identity
+        for c, w in zip(cols[:4], want[:4]):                  # and one at a time
+            assert g1_equal(h.best_multiexp(c, hd), w)
+    finally:
+        h.release_bases(hd)
+
+
 def test_config5_size_2_26_fits_one_gpu_and_is_additive():
     """BASELINE config 5's 2^26-point MSM on ONE GPU (2^30 (point, bucket) pairs, 4 + 4 GiB of
     bases, ~20 GiB of workspace): the whole equals the sum of its four 2^24 quarters."""

@@ -157,9 +157,10 @@ def test_linear_combination_matches_oracle(pyref, count):
         return
     got = h.linear_combination(d, np.stack([fr_words(c) for c in cs]))
     assert from_gpu(pyref, got) == pr.linear_combination(polys, cs, n)
-    # accumulate into the first input
-    h.linear_combination(d, np.stack([fr_words(c) for c in cs]), out=d[0])
-    assert from_gpu(pyref, d[0]) == pr.linear_combination(polys, cs, n)
+    # accumulate into one of the inputs: the first, or (more than one launch) one that a later launch would have read
+    tgt = count - 1 if count > 24 else 0
+    h.linear_combination(d, np.stack([fr_words(c) for c in cs]), out=d[tgt])
+    assert from_gpu(pyref, d[tgt]) == pr.linear_combination(polys, cs, n)
     with pytest.raises(ValueError):
         h.linear_combination(d, np.stack([fr_words(c) for c in cs])[:-1] if count > 1 else np.zeros((2, 4), dtype=np.uint64))
 

@@ -13,6 +13,7 @@ def rand_fr(n, seed):
     x[:, 3] &= 0x0FFFFFFFFFFFFFFF
     return x
 
+_lib.load().hm_msm_set_phase_timing(1)      # per-phase events also for the five-launch plan
 sizes = [int(a) for a in sys.argv[1].split(",")] if len(sys.argv) > 1 else [12, 14, 16, 18, 20, 22, 24]
 windows = [int(a) for a in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0]
 for k in sizes:

@@ -7,6 +7,8 @@ import halo2_experiments_amd as h
 from halo2_experiments_amd.arithmetic import G1_GENERATOR
 from halo2_experiments_amd.replay import _rand_fr, _sparse_column
 from halo2_experiments_amd.sharding import sharded_multiexp_batch
+from halo2_experiments_amd import _lib
+_lib.load().hm_msm_set_phase_timing(1)      # per-phase events also for the five-launch plan
 k = int(sys.argv[1]) if len(sys.argv) > 1 else 18
 n = 1 << k
 dev = torch.device("cuda", 0)
@@ -20,7 +22,7 @@ for name, col in cols.items():
     for _ in range(10): h.best_multiexp(col, hd)
     one = (time.perf_counter() - t) / 10
     st = h.msm_stats()
-    sharded_multiexp_batch([(col, hd)] * 16, streams=streams); torch.cuda.synchronize()
+    sharded_multiexp_batch([(col, hd)] * 32, streams=streams); torch.cuda.synchronize()      # same count as the timed call: the slots' workspaces reach their size here
     t = time.perf_counter()
     sharded_multiexp_batch([(col, hd)] * 32, streams=streams)
     many = (time.perf_counter() - t) / 32
