@@ -87,6 +87,7 @@ _SIGNATURES = {
                                              ctypes.c_uint32, _vp, _vp]),
     "hm_graph_destroy": (ctypes.c_int, [ctypes.c_uint64]),
     "hm_fr_powers_dev": (ctypes.c_int, [_vp, ctypes.c_size_t, _u64p, _vp]),
+    "hm_lookup_permute_bn256_fr_dev": (ctypes.c_int, [_vp, _vp, ctypes.c_size_t, _vp, _vp, _vp]),
     "hm_kate_division_bn256_fr_dev": (ctypes.c_int, [_vp, ctypes.c_size_t, _u64p, _vp, _vp]),
     "hm_fr_grand_product_dev": (ctypes.c_int, [_vp, ctypes.c_size_t, _u64p, _vp, _vp]),
     "hm_fr_batch_invert_dev": (ctypes.c_int, [_vp, ctypes.c_size_t, _vp]),

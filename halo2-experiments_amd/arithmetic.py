@@ -281,6 +281,34 @@ def linear_combination(polys, coeffs, out=None):
     return out
 
 
+def permute_expression_pair(input_column, table_column, usable_rows: int, blinding_seed: int = 0):
+    """``plonk::lookup::prover::permute_expression_pair``: the sorted input column and the arranged table column of one
+    lookup argument, from device-resident (n, 4) columns.  Rows [usable_rows, n) -- upstream's random blinding rows --
+    are drawn on the device from ``blinding_seed``.  Raises ``Halo2Mi355xError`` (code NOT_FOUND) when an input value is
+    missing from the table (upstream: ``Error::ConstraintSystemFailure``)."""
+    import torch
+
+    lib = _lib.load()
+    if not (_is_tensor(input_column) and _is_tensor(table_column)):
+        raise TypeError("permute_expression_pair: columns must be GPU tensors")
+    n = _tensor_rows(input_column, 4, "input_column")
+    if _tensor_rows(table_column, 4, "table_column") != n:
+        raise ValueError("permute_expression_pair: columns differ in length")
+    if not 0 <= usable_rows <= n:
+        raise ValueError("permute_expression_pair: usable_rows out of range")
+    out_a = torch.empty((n, 4), dtype=torch.int64, device=input_column.device)
+    out_s = torch.empty((n, 4), dtype=torch.int64, device=input_column.device)
+    st = ctypes.c_void_p(_stream_ptr(input_column))
+    _lib.check(lib.hm_lookup_permute_bn256_fr_dev(ctypes.c_void_p(input_column.data_ptr()), ctypes.c_void_p(table_column.data_ptr()),
+                                                  usable_rows, ctypes.c_void_p(out_a.data_ptr()), ctypes.c_void_p(out_s.data_ptr()), st))
+    tail = n - usable_rows
+    if tail:
+        _lib.check(lib.hm_fr_random_dev(ctypes.c_void_p(out_a.data_ptr() + usable_rows * 32), tail, ctypes.c_uint64(blinding_seed), st))
+        _lib.check(lib.hm_fr_random_dev(ctypes.c_void_p(out_s.data_ptr() + usable_rows * 32), tail,
+                                        ctypes.c_uint64(blinding_seed ^ 0x9E3779B97F4A7C15), st))
+    return out_a, out_s
+
+
 def g1_fixed_base_mul(scalars, base_xy: np.ndarray):
     """out[i] = [scalars[i]] * base, affine (ParamsKZG::setup's per-row G1 work).  GPU tensors only."""
     import torch

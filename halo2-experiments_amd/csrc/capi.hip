@@ -914,6 +914,17 @@ int hm_fr_linear_combination_dev(const void* const* d_polys, const uint64_t* coe
   return fr_linear_combination_run(d_polys, coeffs, count, n, (uint32_t*)d_out, (hipStream_t)stream);
 }
 
+int hm_lookup_permute_bn256_fr_dev(const void* d_input, const void* d_table, size_t rows, void* d_permuted_input,
+                                   void* d_permuted_table, void* stream) {
+  if (rows && (!d_input || !d_table || !d_permuted_input || !d_permuted_table))
+    return hm_fail(HM_ERR_BAD_ARG, "hm_lookup_permute_bn256_fr_dev: null argument");
+  DeviceCtx* ctx = ctx_for_current_device();
+  if (!ctx) return HM_ERR_NO_DEVICE;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  return lookup_permute_run(*ctx, (const uint32_t*)d_input, (const uint32_t*)d_table, rows, (uint32_t*)d_permuted_input,
+                            (uint32_t*)d_permuted_table, (hipStream_t)stream);
+}
+
 int hm_fr_powers_dev(void* d_out, size_t n, const uint64_t x[4], void* stream) {
   if ((n && !d_out) || !x) return hm_fail(HM_ERR_BAD_ARG, "hm_fr_powers_dev: null argument");
   DeviceCtx* ctx = ctx_for_current_device();

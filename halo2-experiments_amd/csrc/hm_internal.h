@@ -222,6 +222,10 @@ int fr_batch_invert_run(uint32_t* d_v, uint64_t n, hipStream_t stream);
 int fr_linear_combination_run(const void* const* d_polys, const uint64_t* coeffs_ext, size_t count, uint64_t n, uint32_t* d_out,
                               hipStream_t stream);
 
+// lookup.hip
+int lookup_permute_run(DeviceCtx& ctx, const uint32_t* d_input, const uint32_t* d_table, uint64_t rows, uint32_t* d_out_input,
+                       uint32_t* d_out_table, hipStream_t stream);
+
 // msm.hip
 int msm_convert_bases(const uint32_t* d_bases_ext, uint32_t* d_xy, uint8_t* d_inf, size_t n, hipStream_t stream);
 // out_windows: host buffer of W x 12 u64 external Jacobian + flags

@@ -1,0 +1,372 @@
+// lookup.hip -- the lookup argument's permuted columns (upstream halo2_proofs plonk/lookup/prover.rs:
+// permute_expression_pair, at the tag pinned by /root/reference/Cargo.toml:10; reached from the reference through
+// create_proof, /root/reference/src/circuits/utils.rs:40-48 -- the MerkleSumTree circuit's range checks are lookups).
+//
+// Upstream, per lookup: A' = the compressed input column's usable rows sorted by the field's `Ord` (the canonical
+// integer); a BTreeMap counts the table's values; walking A', the first occurrence of every value puts that value into
+// S' at the same row and takes one instance out of the map (a value missing from the table is the error
+// ConstraintSystemFailure); the leftover table values, in ascending order, then fill the rows of repeated inputs
+// from the LAST such row backwards.  The result is a deterministic function of the two multisets, so the device form
+// only has to reproduce it:
+//   1  keys      Montgomery words -> canonical integers (one product by 2^-256), padded to a power of two with keys above r
+//   2  sort      bitonic network on 256-bit keys: stages with a partner inside a 2048-key tile run in LDS, the others
+//                are one launch per stage -- (log n)(log n + 1)/2 compare-exchange stages, independent of the values
+//   3  mark      per row of A': first occurrence?  then its value's first position in the sorted table (binary search)
+//                is marked used -- distinct values mark distinct positions; not found raises the error flag
+//   4  compact   exclusive scans of "repeated row" and "table position unused" -> the two lists upstream walks
+//   5  fill      S'[row] = A'[row] at first occurrences, else the (m - 1 - rank)-th leftover value; back to Montgomery
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+
+#include "g1.h"
+#include "hm_internal.h"
+#include "host_fr.h"
+
+namespace hm {
+
+constexpr int LK_THREADS = 256;
+constexpr uint32_t LK_TILE_LOG = 11, LK_TILE = 1u << LK_TILE_LOG;     // keys per LDS tile: 2048 x 32 B = 64 KiB
+
+struct Key {
+  uint32_t w[8];
+};
+
+__device__ __forceinline__ Key key_load(const uint32_t* p, uint64_t i) {
+  const uint4* q = reinterpret_cast<const uint4*>(p + i * 8);
+  const uint4 a = q[0], b = q[1];
+  return Key{{a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w}};
+}
+__device__ __forceinline__ void key_store(uint32_t* p, uint64_t i, const Key& k) {
+  uint4* q = reinterpret_cast<uint4*>(p + i * 8);
+  q[0] = make_uint4(k.w[0], k.w[1], k.w[2], k.w[3]);
+  q[1] = make_uint4(k.w[4], k.w[5], k.w[6], k.w[7]);
+}
+// -1 / 0 / +1 as a < / == / > b (little-endian words: the top word decides first)
+__device__ __forceinline__ int key_cmp(const Key& a, const Key& b) {
+#pragma unroll
+  for (int k = 7; k >= 0; --k) {
+    if (a.w[k] != b.w[k]) return a.w[k] < b.w[k] ? -1 : 1;
+  }
+  return 0;
+}
+
+struct LkFr {
+  uint32_t l[9];
+};
+
+// Montgomery words <-> canonical integers: one product by `c` (2^-256 resp. 2^256 in the form the raw words need);
+// rows >= live get the all-ones key (above r: sorts behind every field element)
+__global__ __launch_bounds__(LK_THREADS) void lk_convert_kernel(const uint32_t* in, uint32_t* out, uint64_t live, uint64_t total, LkFr c) {
+  const uint64_t i = (uint64_t)blockIdx.x * LK_THREADS + threadIdx.x;
+  if (i >= total) return;
+  if (i >= live) {
+    key_store(out, i, Key{{~0u, ~0u, ~0u, ~0u, ~0u, ~0u, ~0u, ~0u}});
+    return;
+  }
+  const Key k = key_load(in, i);
+  Fr cc;
+#pragma unroll
+  for (int j = 0; j < 9; ++j) cc.l[j] = c.l[j];
+  HM_DECLARE(cc, 1.0);
+  const Fr y = fe_canonical(fe_mul(fe_unpack<FrParams>(k.w), cc));
+  Key o;
+  fe_pack(o.w, y);
+  key_store(out, i, o);
+}
+
+// one compare-exchange stage of the bitonic network with partner distance j >= LK_TILE (phase length k); blockIdx.y
+// selects one of the arrays sorted side by side (the input and the table column: `pitch` words apart)
+__device__ __forceinline__ void lk_cmpx(Key& a, Key& b, bool asc) {
+  const int c = key_cmp(a, b);
+  if (asc ? c > 0 : c < 0) {
+    const Key t = a;
+    a = b;
+    b = t;
+  }
+}
+__global__ __launch_bounds__(LK_THREADS) void lk_sort_global_kernel(uint32_t* keys, uint64_t n, uint64_t k, uint64_t j, uint64_t pitch) {
+  keys += (size_t)blockIdx.y * pitch;
+  const uint64_t t = (uint64_t)blockIdx.x * LK_THREADS + threadIdx.x;      // one lane per pair
+  if (t >= n / 2) return;
+  const uint64_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), l = i | j;
+  Key a = key_load(keys, i), b = key_load(keys, l);
+  const Key a0 = a;
+  lk_cmpx(a, b, (i & k) == 0);
+  if (key_cmp(a, a0) != 0) {
+    key_store(keys, i, a);
+    key_store(keys, l, b);
+  }
+}
+// two consecutive stages (distances j and j / 2, both >= LK_TILE) in one launch: a lane owns the four keys that differ
+// in those two index bits; the direction bit (i & k) is the same for all four
+__global__ __launch_bounds__(LK_THREADS) void lk_sort_global2_kernel(uint32_t* keys, uint64_t n, uint64_t k, uint64_t j, uint64_t pitch) {
+  keys += (size_t)blockIdx.y * pitch;
+  const uint64_t t = (uint64_t)blockIdx.x * LK_THREADS + threadIdx.x;      // one lane per quadruple
+  if (t >= n / 4) return;
+  const uint64_t j2 = j >> 1;
+  const uint64_t i0 = ((t & ~(j2 - 1)) << 2) | (t & (j2 - 1));
+  Key q0 = key_load(keys, i0), q1 = key_load(keys, i0 | j2), q2 = key_load(keys, i0 | j), q3 = key_load(keys, i0 | j | j2);
+  const bool asc = (i0 & k) == 0;
+  lk_cmpx(q0, q2, asc);
+  lk_cmpx(q1, q3, asc);
+  lk_cmpx(q0, q1, asc);
+  lk_cmpx(q2, q3, asc);
+  key_store(keys, i0, q0);
+  key_store(keys, i0 | j2, q1);
+  key_store(keys, i0 | j, q2);
+  key_store(keys, i0 | j | j2, q3);
+}
+
+// every stage with partner distance < LK_TILE of the phases k_first .. k_last (k_first = 2: the whole sort of a tile),
+// for one tile in LDS (structure of arrays: word w of key e at lds[w * LK_TILE + e])
+__global__ __launch_bounds__(LK_THREADS) void lk_sort_tile_kernel(uint32_t* keys, uint64_t n, uint64_t k_first, uint64_t k_last, uint64_t pitch) {
+  extern __shared__ uint32_t lds[];
+  keys += (size_t)blockIdx.y * pitch;
+  const uint64_t base = (uint64_t)blockIdx.x * LK_TILE;
+  const uint32_t tile = n < LK_TILE ? (uint32_t)n : LK_TILE;
+  for (uint32_t e = threadIdx.x; e < tile; e += LK_THREADS) {
+    const Key q = key_load(keys, base + e);
+#pragma unroll
+    for (int w = 0; w < 8; ++w) lds[w * LK_TILE + e] = q.w[w];
+  }
+  __syncthreads();
+  for (uint64_t k = k_first; k <= k_last; k <<= 1) {
+    uint32_t j = (uint32_t)(k / 2 < tile ? k / 2 : tile / 2);
+    for (; j > 0; j >>= 1) {
+      for (uint32_t t = threadIdx.x; t < tile / 2; t += LK_THREADS) {
+        const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), l = i | j;
+        Key a, b;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) {
+          a.w[w] = lds[w * LK_TILE + i];
+          b.w[w] = lds[w * LK_TILE + l];
+        }
+        const bool asc = ((base + i) & k) == 0;
+        const int c = key_cmp(a, b);
+        if (asc ? c > 0 : c < 0) {
+#pragma unroll
+          for (int w = 0; w < 8; ++w) {
+            lds[w * LK_TILE + i] = b.w[w];
+            lds[w * LK_TILE + l] = a.w[w];
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  for (uint32_t e = threadIdx.x; e < tile; e += LK_THREADS) {
+    Key q;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) q.w[w] = lds[w * LK_TILE + e];
+    key_store(keys, base + e, q);
+  }
+}
+
+// flags[i] = 1 for a repeated input row (same value as the row before), 0 for a first occurrence; first occurrences mark
+// used[lower_bound(table, value)] = 1, or raise *missing when the table does not hold the value
+__global__ __launch_bounds__(LK_THREADS) void lk_mark_kernel(const uint32_t* a_sorted, const uint32_t* t_sorted, uint64_t rows,
+                                                             uint32_t* repeated, uint32_t* used, uint32_t* missing) {
+  const uint64_t i = (uint64_t)blockIdx.x * LK_THREADS + threadIdx.x;
+  if (i >= rows) return;
+  const Key v = key_load(a_sorted, i);
+  const bool first = i == 0 || key_cmp(v, key_load(a_sorted, i - 1)) != 0;
+  repeated[i] = first ? 0u : 1u;
+  if (!first) return;
+  uint64_t lo = 0, hi = rows;                       // lower_bound: first position with key >= v
+  while (lo < hi) {
+    const uint64_t mid = (lo + hi) >> 1;
+    if (key_cmp(key_load(t_sorted, mid), v) < 0) lo = mid + 1;
+    else hi = mid;
+  }
+  if (lo < rows && key_cmp(key_load(t_sorted, lo), v) == 0) used[lo] = 1u;
+  else atomicExch(missing, 1u);
+}
+
+// exclusive scan of 0/1 flags (optionally inverted), three launches: block sums, one-block scan of those, apply
+constexpr int SC_ITEMS = 8;
+constexpr int SC_BLOCK = LK_THREADS * SC_ITEMS;
+__device__ __forceinline__ uint32_t lk_block_scan(uint32_t v, uint32_t* s, uint32_t& total) {   // exclusive, 256 lanes
+  const uint32_t t = threadIdx.x;
+  s[t] = v;
+  __syncthreads();
+  for (uint32_t off = 1; off < LK_THREADS; off <<= 1) {
+    const uint32_t a = t >= off ? s[t - off] : 0u;
+    __syncthreads();
+    s[t] += a;
+    __syncthreads();
+  }
+  total = s[LK_THREADS - 1];
+  const uint32_t r = s[t] - v;
+  __syncthreads();
+  return r;
+}
+__global__ __launch_bounds__(LK_THREADS) void lk_scan_sums_kernel(const uint32_t* flags, uint64_t n, uint32_t invert, uint32_t* sums) {
+  __shared__ uint32_t s[LK_THREADS];
+  const uint64_t b0 = (uint64_t)blockIdx.x * SC_BLOCK + (uint64_t)threadIdx.x * SC_ITEMS;
+  uint32_t v = 0;
+  for (int k = 0; k < SC_ITEMS; ++k)
+    if (b0 + k < n) v += flags[b0 + k] ^ invert;
+  uint32_t total;
+  (void)lk_block_scan(v, s, total);
+  if (threadIdx.x == 0) sums[blockIdx.x] = total;
+}
+__global__ __launch_bounds__(LK_THREADS) void lk_scan_top_kernel(uint32_t* sums, uint32_t nblocks, uint32_t* grand_total) {
+  __shared__ uint32_t s[LK_THREADS];
+  const uint32_t per = (nblocks + LK_THREADS - 1) / LK_THREADS;
+  const uint32_t lo = threadIdx.x * per, hi = lo + per < nblocks ? lo + per : nblocks;
+  uint32_t v = 0;
+  for (uint32_t i = lo; i < hi; ++i) v += sums[i];
+  uint32_t total;
+  uint32_t run = lk_block_scan(v, s, total);
+  for (uint32_t i = lo; i < hi; ++i) {
+    const uint32_t c = sums[i];
+    sums[i] = run;
+    run += c;
+  }
+  if (threadIdx.x == 0) *grand_total = total;
+}
+// positions[rank] = index, for every index whose (possibly inverted) flag is set -- the compacted list in index order
+__global__ __launch_bounds__(LK_THREADS) void lk_scan_apply_kernel(const uint32_t* flags, uint64_t n, uint32_t invert, const uint32_t* sums,
+                                                                   uint32_t* rank_of, uint32_t* positions) {
+  __shared__ uint32_t s[LK_THREADS];
+  const uint64_t b0 = (uint64_t)blockIdx.x * SC_BLOCK + (uint64_t)threadIdx.x * SC_ITEMS;
+  uint32_t f[SC_ITEMS], v = 0;
+  for (int k = 0; k < SC_ITEMS; ++k) {
+    f[k] = b0 + k < n ? flags[b0 + k] ^ invert : 0u;
+    v += f[k];
+  }
+  uint32_t total;
+  uint32_t run = sums[blockIdx.x] + lk_block_scan(v, s, total);
+  for (int k = 0; k < SC_ITEMS; ++k) {
+    if (b0 + k < n) {
+      if (rank_of) rank_of[b0 + k] = run;
+      if (f[k]) positions[run] = (uint32_t)(b0 + k);
+    }
+    run += f[k];
+  }
+}
+
+// S'[i] = A'[i] at first occurrences; the repeated row of rank r (ascending) takes the leftover table value of rank
+// m - 1 - r (upstream pops the repeated rows from the back while walking the leftovers upwards).  Both columns return
+// to Montgomery words.
+__global__ __launch_bounds__(LK_THREADS) void lk_fill_kernel(const uint32_t* a_sorted, const uint32_t* t_sorted, uint64_t rows,
+                                                             const uint32_t* repeated, const uint32_t* rep_rank, const uint32_t* left_pos,
+                                                             const uint32_t* counts /* [0] repeated rows, [1] leftovers */, LkFr c,
+                                                             uint32_t* out_a, uint32_t* out_s, uint32_t* mismatch) {
+  const uint64_t i = (uint64_t)blockIdx.x * LK_THREADS + threadIdx.x;
+  if (i >= rows) return;
+  const Key a = key_load(a_sorted, i);
+  Key sv = a;
+  if (repeated[i]) {
+    const uint32_t m = counts[0];
+    if (counts[1] != m) {                          // cannot happen when every first occurrence found its table value
+      atomicExch(mismatch, 1u);
+      return;
+    }
+    sv = key_load(t_sorted, left_pos[m - 1 - rep_rank[i]]);
+  }
+  Fr cc;
+#pragma unroll
+  for (int j = 0; j < 9; ++j) cc.l[j] = c.l[j];
+  HM_DECLARE(cc, 1.0);
+  Key o;
+  fe_pack(o.w, fe_canonical(fe_mul(fe_unpack<FrParams>(a.w), cc)));
+  key_store(out_a, i, o);
+  fe_pack(o.w, fe_canonical(fe_mul(fe_unpack<FrParams>(sv.w), cc)));
+  key_store(out_s, i, o);
+}
+
+// ---------------------------------------------------------------------------------------------
+// sorts `arrays` key arrays of n_pow2 keys each, `pitch` words apart, side by side (grid.y)
+static int lk_sort(uint32_t* d_keys, uint64_t n_pow2, uint32_t arrays, uint64_t pitch, hipStream_t stream) {
+  if (n_pow2 < 2) return HM_OK;
+  const uint32_t tiles = (uint32_t)((n_pow2 + LK_TILE - 1) / LK_TILE);
+  const size_t lds = (size_t)8 * LK_TILE * 4;
+  const uint64_t in_tile = n_pow2 < LK_TILE ? n_pow2 : (uint64_t)LK_TILE;
+  hipLaunchKernelGGL(lk_sort_tile_kernel, dim3(tiles, arrays), dim3(LK_THREADS), lds, stream, d_keys, n_pow2, (uint64_t)2, in_tile, pitch);
+  for (uint64_t k = (uint64_t)LK_TILE * 2; k <= n_pow2; k <<= 1) {
+    uint64_t j = k / 2;
+    for (; j >= 2 * (uint64_t)LK_TILE; j >>= 2)                    // two global stages per launch while two remain
+      hipLaunchKernelGGL(lk_sort_global2_kernel, dim3((uint32_t)((n_pow2 / 4 + LK_THREADS - 1) / LK_THREADS), arrays), dim3(LK_THREADS), 0,
+                         stream, d_keys, n_pow2, k, j, pitch);
+    if (j >= LK_TILE)
+      hipLaunchKernelGGL(lk_sort_global_kernel, dim3((uint32_t)((n_pow2 / 2 + LK_THREADS - 1) / LK_THREADS), arrays), dim3(LK_THREADS), 0,
+                         stream, d_keys, n_pow2, k, j, pitch);
+    hipLaunchKernelGGL(lk_sort_tile_kernel, dim3(tiles, arrays), dim3(LK_THREADS), lds, stream, d_keys, n_pow2, k, k, pitch);
+  }
+  HM_HIP_CHECK(hipGetLastError());
+  return HM_OK;
+}
+
+static int lk_compact(const uint32_t* d_flags, uint64_t n, uint32_t invert, uint32_t* d_sums, uint32_t* d_total, uint32_t* d_rank,
+                      uint32_t* d_positions, hipStream_t stream) {
+  const uint32_t blocks = (uint32_t)((n + SC_BLOCK - 1) / SC_BLOCK);
+  hipLaunchKernelGGL(lk_scan_sums_kernel, dim3(blocks), dim3(LK_THREADS), 0, stream, d_flags, n, invert, d_sums);
+  hipLaunchKernelGGL(lk_scan_top_kernel, dim3(1), dim3(LK_THREADS), 0, stream, d_sums, blocks, d_total);
+  hipLaunchKernelGGL(lk_scan_apply_kernel, dim3(blocks), dim3(LK_THREADS), 0, stream, d_flags, n, invert, (const uint32_t*)d_sums, d_rank,
+                     d_positions);
+  HM_HIP_CHECK(hipGetLastError());
+  return HM_OK;
+}
+
+// d_input, d_table: n-row columns (only the first `rows` are read); d_out_input, d_out_table: rows [0, rows) written.
+// Returns HM_ERR_NOT_FOUND when an input value is missing from the table (upstream: Error::ConstraintSystemFailure).
+int lookup_permute_run(DeviceCtx& ctx, const uint32_t* d_input, const uint32_t* d_table, uint64_t rows, uint32_t* d_out_input,
+                       uint32_t* d_out_table, hipStream_t stream) {
+  if (rows == 0) return HM_OK;
+  if (rows >= ((uint64_t)1 << 31)) return hm_fail(HM_ERR_BAD_ARG, "lookup permute: too many rows");
+  uint64_t n2 = 1;
+  while (n2 < rows) n2 <<= 1;
+  static bool attr_set = false;
+  if (!attr_set) {
+    HM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(lk_sort_tile_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)(8 * LK_TILE * 4)));
+    attr_set = true;
+  }
+  AuxSlot* slot = aux_acquire(ctx, stream);
+  if (!slot) return HM_ERR_HIP;
+  const uint32_t blocks = (uint32_t)((rows + SC_BLOCK - 1) / SC_BLOCK);
+  auto align = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  size_t off = 0;
+  auto carve = [&](size_t bytes) { const size_t o = off; off += align(bytes); return o; };
+  const size_t o_a = carve(n2 * 32), o_t = carve(n2 * 32), o_rep = carve(rows * 4), o_used = carve(rows * 4), o_rank = carve(rows * 4),
+               o_left = carve(rows * 4), o_reppos = carve(rows * 4), o_sums = carve((size_t)blocks * 4 * 2), o_small = carve(64);
+  uint8_t* ws = (uint8_t*)slot->scratch.ensure(off);
+  if (!ws) return hm_fail(HM_ERR_HIP, "lookup permute: scratch allocation failed");
+  uint32_t *a = (uint32_t*)(ws + o_a), *t = (uint32_t*)(ws + o_t), *rep = (uint32_t*)(ws + o_rep), *used = (uint32_t*)(ws + o_used);
+  uint32_t *rank = (uint32_t*)(ws + o_rank), *left = (uint32_t*)(ws + o_left), *reppos = (uint32_t*)(ws + o_reppos);
+  uint32_t *sums = (uint32_t*)(ws + o_sums), *small = (uint32_t*)(ws + o_small);   // small: [0] repeated, [1] leftovers, [2] missing, [3] mismatch
+  HM_HIP_CHECK(hipMemsetAsync(used, 0, rows * 4, stream));
+  HM_HIP_CHECK(hipMemsetAsync(small, 0, 64, stream));
+  // raw words * int(2^-251) ... in ff29 terms: the raw words are the internal form of v / 32; times the internal form of
+  // 32 * 2^-256 gives the internal form of v * 2^-256 / 32, whose raw words are the canonical integer v (as Fr::to_repr)
+  LkFr to_canon, to_mont;
+  {
+    const host::Fr4 one_int = {{1, 0, 0, 0}};                       // the integer 1 read as Montgomery words = 2^-256
+    host::fr_to_internal9(one_int, to_canon.l);
+    const host::Fr4 r2 = {{0x1bb8e645ae216da7ULL, 0x53fe3ab1e35c59e3ULL, 0x8c49833d53bb8085ULL, 0x0216d0b17f4e44a5ULL}};   // 2^512 mod r as words = the element 2^256
+    host::fr_to_internal9(r2, to_mont.l);
+  }
+  const uint32_t cb = (uint32_t)((n2 + LK_THREADS - 1) / LK_THREADS), rb = (uint32_t)((rows + LK_THREADS - 1) / LK_THREADS);
+  hipLaunchKernelGGL(lk_convert_kernel, dim3(cb), dim3(LK_THREADS), 0, stream, d_input, a, rows, n2, to_canon);
+  hipLaunchKernelGGL(lk_convert_kernel, dim3(cb), dim3(LK_THREADS), 0, stream, d_table, t, rows, n2, to_canon);
+  int rc = lk_sort(a, n2, 2, (uint64_t)(t - a), stream);        // both columns side by side
+  if (rc != HM_OK) return rc;
+  hipLaunchKernelGGL(lk_mark_kernel, dim3(rb), dim3(LK_THREADS), 0, stream, (const uint32_t*)a, (const uint32_t*)t, rows, rep, used, small + 2);
+  rc = lk_compact(rep, rows, 0, sums, small + 0, rank, reppos, stream);
+  if (rc == HM_OK) rc = lk_compact(used, rows, 1, sums + blocks, small + 1, nullptr, left, stream);
+  if (rc != HM_OK) return rc;
+  hipLaunchKernelGGL(lk_fill_kernel, dim3(rb), dim3(LK_THREADS), 0, stream, (const uint32_t*)a, (const uint32_t*)t, rows, (const uint32_t*)rep,
+                     (const uint32_t*)rank, (const uint32_t*)left, (const uint32_t*)small, to_mont, d_out_input, d_out_table, small + 3);
+  HM_HIP_CHECK(hipGetLastError());
+  uint32_t h_small[4] = {0, 0, 0, 0};
+  HM_HIP_CHECK(hipMemcpyAsync(h_small, small, 16, hipMemcpyDeviceToHost, stream));
+  HM_HIP_CHECK(hipStreamSynchronize(stream));
+  rc = aux_release(ctx, slot, stream);
+  if (h_small[2]) return hm_fail(HM_ERR_NOT_FOUND, "lookup permute: an input value is missing from the table (ConstraintSystemFailure)");
+  if (h_small[3]) return hm_fail(HM_ERR_INTERNAL, "lookup permute: leftover / repeated counts differ");
+  return rc;
+}
+
+}  // namespace hm

@@ -18,10 +18,11 @@ extended domain 2^ek with ek = k + ceil(log2(d-1))):
     evaluate_h gates  (GraphEvaluator over 2^ek rows)  one Poseidon-like gate program (estimate of the expression graph)
     eval_polynomial   (Horner, n coefficients)         2A + 3 Zp + 5L + (d-1) queries (estimate)
     grand products    (batch_invert + running product over n rows)   Zp + L  (permutation / lookup z columns)
+    lookup permute    (permute_expression_pair: two 256-bit sorts + arrangement over n - 7 rows)   L
     multiopen         (linear combination of the committed polynomials per rotation set, kate_division per opening
                        point, final combination + division)          4 sets, 5 points (estimate)
 Everything else in ``create_proof`` (witness synthesis, the permutation / lookup terms of ``evaluate_h``, the lookup
-sort, the transcript) stays on the CPU in the reference and is NOT part of this number.
+transcript) stays on the CPU in the reference and is NOT part of this number.
 
 Like the reference's harness (prove, THEN verify: /root/reference/src/circuits/merkle_sum_tree.rs:345-358), a
 replay checks what it computed: the SRS is a real one (g = [s^i]G, g_lagrange = [L_i(s)]G with a known s), and
@@ -39,7 +40,8 @@ from typing import Optional
 import numpy as np
 
 from .arithmetic import (G1_GENERATOR, batch_invert, best_multiexp, best_multiexp_submit, best_multiexp_wait, eval_polynomial,
-                         g1_fixed_base_mul, grand_product, kate_division, linear_combination, register_bases, release_bases)
+                         g1_fixed_base_mul, grand_product, kate_division, linear_combination, permute_expression_pair, register_bases,
+                         release_bases)
 from .domain import EvaluationDomain, FR_MODULUS, fr_words
 from .kzg import ParamsKZG
 from .sharding import job_parallel_multiexp_batch, shard_range, sharded_multiexp, sharded_multiexp_batch
@@ -193,6 +195,12 @@ def run_replay(shape_name: str, device=None, group=None, include_host_pointer_es
     open_acc = torch.empty((5, n, 4), dtype=torch.int64, device=device)
     z_factors = _rand_fr((zp + L) * n, 400, device).reshape(zp + L, n, 4)
     z_column = torch.empty((n, 4), dtype=torch.int64, device=device)
+    # a range-check lookup: the table holds 0 .. 2^16 - 1 (repeated), the input column values of that range
+    lookup_table = torch.zeros((n, 4), dtype=torch.int64, device=device)
+    lookup_table[:, 0] = torch.arange(n, device=device) % min(n - 7, 1 << 16)
+    lookup_table = linear_combination([lookup_table], np.stack([fr_words((1 << 256) % FR_MODULUS)]))
+    lookup_input = lookup_table[torch.randperm(n, device=device)].contiguous()
+    lookup_input[n - 7:] = lookup_table[:7]            # (rows beyond the usable ones are not read)
 
     def msm_phase(jobs):
         """The commitments of one prover phase are independent: every rank keeps `in_flight` of its local
@@ -261,6 +269,12 @@ def run_replay(shape_name: str, device=None, group=None, include_host_pointer_es
         t["grand_products"] = time.perf_counter() - t0
         t0 = time.perf_counter()
         if rank == 0:
+            for i in range(L):                        # the permuted input / table columns of every lookup argument
+                permute_expression_pair(lookup_input, lookup_table, n - 7, blinding_seed=i)
+        torch.cuda.synchronize()
+        t["lookup_permute"] = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        if rank == 0:
             per_set = -(-n_open_polys // 4)
             sets = []
             for si in range(4):
@@ -307,7 +321,7 @@ def run_replay(shape_name: str, device=None, group=None, include_host_pointer_es
         "calls": counts,
         "device_resident_s": {"msm": phases["msm"], "ntt": phases["ntt"], "evaluate_h_gates": phases["evaluate_h_gates"],
                               "eval_polynomial": phases["eval_polynomial"], "grand_products": phases["grand_products"],
-                              "multiopen": phases["multiopen"], "total": wall},
+                              "lookup_permute": phases["lookup_permute"], "multiopen": phases["multiopen"], "total": wall},
         "beyond_msm_ntt": {"evaluate_h_gates": f"{len(gate_prog.calcs)} GraphEvaluator calculations per row over 2^{dom.extended_k} rows "
                                                "(Poseidon-like gate program: an estimate of the circuit's expression graph)",
                            "eval_polynomial": f"{n_queries} Horner evaluations of 2^{k}-coefficient polynomials (estimate)",

@@ -209,6 +209,16 @@ int hm_fr_batch_invert_dev(void* d_values, size_t n, void* stream);
 int hm_fr_linear_combination_dev(const void* const* d_polys, const uint64_t* coeffs, size_t count, size_t n, void* d_out,
                                  void* stream);
 
+/* The permuted columns of one lookup argument (upstream plonk/lookup/prover.rs: permute_expression_pair): from the first
+ * `rows` (= usable rows) entries of the compressed input and table columns, d_permuted_input[0 .. rows) = the input values
+ * sorted by their canonical integers, d_permuted_table[0 .. rows) = the table values arranged so that every row where the
+ * sorted input changes holds that input value and the leftover table values fill the repeated rows (ascending values from
+ * the last such row backwards, exactly as upstream walks them).  The blinding rows beyond `rows` are the caller's.  The
+ * outputs must not overlap the inputs.  Returns HM_ERR_NOT_FOUND when an input value does not occur in the table
+ * (upstream: Error::ConstraintSystemFailure).  Synchronises `stream`. */
+int hm_lookup_permute_bn256_fr_dev(const void* d_input, const void* d_table, size_t rows, void* d_permuted_input,
+                                   void* d_permuted_table, void* stream);
+
 /* out[i] = x^i for i < n (device pointer, n x 4 u64): the ladder 1, s, s^2, ... of ParamsKZG::setup, whose
  * fixed-base multiples are g, and whose scaled inverse NTT gives the Lagrange-basis scalars of g_lagrange. */
 int hm_fr_powers_dev(void* d_out, size_t n, const uint64_t x[4], void* stream);

@@ -9,6 +9,7 @@ create_proof, /root/reference/src/circuits/utils.rs:40-48; parity unpinned: the 
                          z[row] = z[row - 1] * modified_values[row - 1] after z[0] = last_z
     linear_combination   halo2_proofs/src/poly.rs  `Polynomial * F` and `Polynomial + &Polynomial`
     permutation_factors  the numerator / denominator sweep of permutation/prover.rs that feeds the two above
+    permute_expression_pair  halo2_proofs/src/plonk/lookup/prover.rs  permute_expression_pair (without the blinding rows)
 
 Values are canonical integers in [0, r); the tests convert to and from the reference's Montgomery words.
 """
@@ -88,3 +89,29 @@ def permutation_factors(values: Sequence[Sequence[int]], sigmas: Sequence[Sequen
             cur = cur * omega % R
         deltaomega = deltaomega * delta % R
     return mv
+
+
+def permute_expression_pair(input_values: Sequence[int], table_values: Sequence[int], usable_rows: int):
+    """Follows upstream: sort the input; count the table's values in an ordered map; the first occurrence of every input
+    value takes that value into the permuted table at its row and one instance out of the map (absent: the error
+    ConstraintSystemFailure, here KeyError); repeated rows are collected; the leftover table values, in ascending
+    order, are written to repeated rows popped from the BACK of that list."""
+    permuted_input = sorted(v % R for v in input_values[:usable_rows])
+    leftover = {}
+    for v in table_values[:usable_rows]:
+        leftover[v % R] = leftover.get(v % R, 0) + 1
+    permuted_table = [0] * usable_rows
+    repeated_rows = []
+    for row, v in enumerate(permuted_input):
+        if row == 0 or v != permuted_input[row - 1]:
+            permuted_table[row] = v
+            if leftover.get(v, 0) == 0:
+                raise KeyError("ConstraintSystemFailure: input value not in the table")
+            leftover[v] -= 1
+        else:
+            repeated_rows.append(row)
+    for coeff in sorted(leftover):
+        for _ in range(leftover[coeff]):
+            permuted_table[repeated_rows.pop()] = coeff
+    assert not repeated_rows
+    return permuted_input, permuted_table

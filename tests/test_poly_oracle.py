@@ -75,3 +75,25 @@ def test_permutation_factors_telescope():
     mv = pr.permutation_factors(cols, sig, omega, delta, rng.randrange(R), rng.randrange(R))
     assert mv == [1] * n
     assert pr.grand_product(mv, 1) == [1] * n
+
+
+def test_permute_expression_pair_properties():
+    """The defining properties of the lookup argument's permuted columns (upstream lookup/prover.rs): A' is the sorted
+    input, S' a permutation of the table, and on every row either A'[i] == S'[i] or A'[i] == A'[i-1]."""
+    rng = random.Random(21)
+    for rows, span in ((1, 1), (7, 3), (100, 16), (1000, 64), (513, 513)):
+        table = [rng.randrange(span) for _ in range(rows)]
+        table[: min(span, rows)] = list(range(min(span, rows)))          # every small value occurs at least once
+        present = sorted(set(table))
+        inp = [rng.choice(present) for _ in range(rows)]
+        if len(set(inp)) > rows:
+            continue
+        a, s = pr.permute_expression_pair(inp, table, rows)
+        assert a == sorted(inp) and sorted(s) == sorted(table)
+        for i in range(rows):
+            assert a[i] == s[i] or (i > 0 and a[i] == a[i - 1])
+    with pytest.raises(KeyError):
+        pr.permute_expression_pair([1, 2, 5], [1, 2, 3], 3)
+    # the leftovers go to the repeated rows from the back: smallest leftover on the last repeated row
+    a, s = pr.permute_expression_pair([4, 4, 4, 4], [4, 9, 7, 8], 4)
+    assert a == [4, 4, 4, 4] and s == [4, 9, 8, 7]

@@ -29,3 +29,8 @@ for k in [int(a) for a in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["14
     print(f"2^{k}: kate {timed(lambda: h.kate_division(a, z)):.4f} ms | grand product {timed(lambda: h.grand_product(a, z, out=out)):.4f} ms | "
           f"batch invert {timed(lambda: h.batch_invert(b)):.4f} ms | lincomb x2 {timed(lambda: h.linear_combination([a, b], cs[:2], out=out)):.4f} ms "
           f"x24 {timed(lambda: h.linear_combination([a, b] * 12, cs, out=out)):.4f} ms", flush=True)
+    if k <= 22:
+        small = torch.zeros((n, 4), dtype=torch.int64, device="cuda"); small[:, 0] = torch.arange(n, device="cuda") % 65536
+        tab = h.linear_combination([small], np.stack([fr_words(pow(2, 256, 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001))]))
+        print(f"        lookup permute_expression_pair: range-check column {timed(lambda: h.permute_expression_pair(tab, tab, n - 7), 3):.4f} ms | "
+              f"random column {timed(lambda: h.permute_expression_pair(a, a, n - 7), 3):.4f} ms", flush=True)
