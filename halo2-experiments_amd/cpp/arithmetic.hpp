@@ -87,6 +87,14 @@ inline void linear_combination(const std::vector<const Fr*>& d_polys, const std:
         "linear_combination");
 }
 
+// plonk::lookup::prover::permute_expression_pair on device-resident columns: rows [0, usable_rows) of d_permuted_input /
+// d_permuted_table are written (the blinding rows beyond are the caller's, as upstream appends random values).  An input
+// value missing from the table is upstream's Error::ConstraintSystemFailure: here std::runtime_error.
+inline void permute_expression_pair(const Fr* d_input, const Fr* d_table, size_t usable_rows, Fr* d_permuted_input, Fr* d_permuted_table,
+                                    void* stream = nullptr) {
+  check(hm_lookup_permute_bn256_fr_dev(d_input, d_table, usable_rows, d_permuted_input, d_permuted_table, stream), "permute_expression_pair");
+}
+
 // affine normalisation of a G1 the library returned: it is already (x, y, 1) or the identity
 inline G1Affine to_affine(const G1& p) {
   if (p.is_identity()) return G1Affine::identity();
