@@ -441,9 +441,15 @@ int hm_msm_batch_bn256_g1_dev(uint64_t handle, size_t offset, const void* const*
       await_chain(d);                          // even after an error: no ticket is left behind
     }
   };
-  const bool threaded = n_chains > 2;
+  bool threaded = n_chains > 2;
   std::thread th;
-  if (threaded) th = std::thread(waiter);
+  if (threaded) {
+    try {
+      th = std::thread(waiter);
+    } catch (...) {                             // no thread to be had: this one awaits between submissions
+      threaded = false;
+    }
+  }
   std::string submit_error;
   for (size_t ch = 0; ch < n_chains; ++ch) {
     while (ch - done.load(std::memory_order_acquire) >= (size_t)kLanes) {      // every lane holds a ticket

@@ -173,7 +173,7 @@ struct DeviceCtx {
   uint64_t cached_digest[4] = {0, 0, 0, 0};
   MsmStats last_msm;
   CallStats calls;
-  bool msm_attr_set = false, ntt_attr_set = false, msm_small_attr_set = false;
+  bool msm_attr_set = false, ntt_attr_set = false, msm_small_attr_set = false, lookup_attr_set = false;
 };
 
 // Slot for a call on `stream` (ctx.mu held): the stream's own slot, else a free or finished one, else the

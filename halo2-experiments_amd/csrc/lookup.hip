@@ -318,11 +318,10 @@ int lookup_permute_run(DeviceCtx& ctx, const uint32_t* d_input, const uint32_t* 
   if (rows >= ((uint64_t)1 << 31)) return hm_fail(HM_ERR_BAD_ARG, "lookup permute: too many rows");
   uint64_t n2 = 1;
   while (n2 < rows) n2 <<= 1;
-  static bool attr_set = false;
-  if (!attr_set) {
+  if (!ctx.lookup_attr_set) {
     HM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(lk_sort_tile_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)(8 * LK_TILE * 4)));
-    attr_set = true;
+    ctx.lookup_attr_set = true;
   }
   AuxSlot* slot = aux_acquire(ctx, stream);
   if (!slot) return HM_ERR_HIP;
