@@ -334,7 +334,8 @@ int hm_msm_bn256_g1_dev(uint64_t handle, size_t offset, const void* d_scalars, s
 
 // One ticket = one launch chain = `group` MSMs over the same base range (group > 1 only where the five-launch plan applies).
 static int submit_chain(DeviceCtx* ctx, uint64_t handle, size_t offset, const void* const* d_scalars_list, uint32_t group, size_t n,
-                        void* stream, uint64_t* out_ticket, const char* who) {
+                        void* stream, uint64_t* out_ticket, const char* who, bool* all_busy = nullptr) {
+  if (all_busy) *all_busy = false;
   std::lock_guard<std::mutex> lk(ctx->mu);
   BasesEntry* b = find_bases(*ctx, handle);
   if (!b) return hm_fail(HM_ERR_NOT_FOUND, std::string(who) + ": unknown base handle");
@@ -342,7 +343,10 @@ static int submit_chain(DeviceCtx* ctx, uint64_t handle, size_t offset, const vo
   int slot = -1;
   for (int i = 1; i < HM_MSM_SLOTS; ++i)        // slot 0 stays free for the synchronous calls
     if (!ctx->msm_slots[i].busy) { slot = i; break; }
-  if (slot < 0) return hm_fail(HM_ERR_BAD_ARG, std::string(who) + ": every slot is in flight; hm_msm_wait one first");
+  if (slot < 0) {
+    if (all_busy) *all_busy = true;             // the batch call retries: another thread's tickets hold the slots
+    return hm_fail(HM_ERR_BAD_ARG, std::string(who) + ": every slot is in flight; hm_msm_wait one first");
+  }
   const uint32_t pc = (offset == 0 && n == b->n) ? b->pc_c : 0u;
   int rc;
   if (group == 1) {
@@ -458,8 +462,17 @@ int hm_msm_batch_bn256_g1_dev(uint64_t handle, size_t offset, const void* const*
     }
     const size_t first = ch * per_chain;
     const uint32_t group = (uint32_t)(count - first < per_chain ? count - first : per_chain);
-    const int rc = submit_chain(ctx, handle, offset, d_scalars + first, group, n, ctx->batch_streams[ch % kLanes], &tickets[ch % kLanes],
-                                "hm_msm_batch_bn256_g1_dev");
+    int rc;
+    const double t_wait0 = now_us();
+    for (;;) {                                  // slots held by other callers' tickets (another thread's batch): wait for one
+      bool all_busy = false;
+      rc = submit_chain(ctx, handle, offset, d_scalars + first, group, n, ctx->batch_streams[ch % kLanes], &tickets[ch % kLanes],
+                        "hm_msm_batch_bn256_g1_dev", &all_busy);
+      if (rc == HM_OK || !all_busy) break;
+      if (now_us() - t_wait0 > 60e6) break;     // nobody awaits the tickets that hold the slots: report instead of spinning
+      if (!threaded && done.load() < issued.load()) await_chain(done.load());     // free one of our own first
+      else std::this_thread::yield();
+    }
     if (rc != HM_OK) {
       submit_rc.store(rc);
       submit_error = hm_last_error();
