@@ -326,6 +326,7 @@ def run_replay(shape_name: str, device=None, group=None, include_host_pointer_es
                                                "(Poseidon-like gate program: an estimate of the circuit's expression graph)",
                            "eval_polynomial": f"{n_queries} Horner evaluations of 2^{k}-coefficient polynomials (estimate)",
                            "grand_products": f"one batch inversion of {zp + L} x 2^{k} denominators, {zp + L} running products over 2^{k} rows",
+                           "lookup_permute": f"{L} x permute_expression_pair over 2^{k} - 7 rows (range-check column: 256-bit bitonic sorts + arrangement)",
                            "multiopen": f"{n_open_polys} polynomials combined in 4 rotation sets, 6 divisions by X - point (estimate)"},
         "verified": {"commitments_checked": checked["commitments"], "distinct_column_base_pairs": len(expected),
                      "against": "KZG identity commit(f) == [f(s)]G, f(s) by device Horner (+ inverse NTT for Lagrange-basis columns)"},
