@@ -88,6 +88,9 @@ _SIGNATURES = {
     "hm_graph_destroy": (ctypes.c_int, [ctypes.c_uint64]),
     "hm_fr_powers_dev": (ctypes.c_int, [_vp, ctypes.c_size_t, _u64p, _vp]),
     "hm_lookup_permute_bn256_fr_dev": (ctypes.c_int, [_vp, _vp, ctypes.c_size_t, _vp, _vp, _vp]),
+    "hm_lookup_permute_batch_bn256_fr_dev": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t,
+                                                          ctypes.c_size_t, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p),
+                                                          ctypes.POINTER(ctypes.c_int), _vp]),
     "hm_kate_division_bn256_fr_dev": (ctypes.c_int, [_vp, ctypes.c_size_t, _u64p, _vp, _vp]),
     "hm_fr_grand_product_dev": (ctypes.c_int, [_vp, ctypes.c_size_t, _u64p, _vp, _vp]),
     "hm_fr_batch_invert_dev": (ctypes.c_int, [_vp, ctypes.c_size_t, _vp]),

@@ -309,6 +309,44 @@ def permute_expression_pair(input_column, table_column, usable_rows: int, blindi
     return out_a, out_s
 
 
+def permute_expression_pairs(input_columns, table_columns, usable_rows: int, blinding_seed: int = 0):
+    """``permute_expression_pair`` for all lookup arguments of a circuit in one call (their sorts run side by side on the
+    device).  Returns a list of (permuted_input, permuted_table) tensors.  A lookup whose input holds a value its table
+    lacks raises ``Halo2Mi355xError`` (NOT_FOUND) carrying the indices in ``.missing``."""
+    import torch
+
+    lib = _lib.load()
+    ins, tabs = list(input_columns), list(table_columns)
+    if len(ins) != len(tabs):
+        raise ValueError("permute_expression_pairs: one table per input")
+    if not ins:
+        return []
+    n = _tensor_rows(ins[0], 4, "input_columns")
+    for c in ins + tabs:
+        if not _is_tensor(c) or _tensor_rows(c, 4, "columns") != n:
+            raise ValueError("permute_expression_pairs: columns must be GPU tensors of one length")
+    if not 0 <= usable_rows <= n:
+        raise ValueError("permute_expression_pairs: usable_rows out of range")
+    outs = [(torch.empty((n, 4), dtype=torch.int64, device=ins[0].device), torch.empty((n, 4), dtype=torch.int64, device=ins[0].device))
+            for _ in ins]
+    arr = lambda ts: (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+    missing = (ctypes.c_int * len(ins))()
+    st = ctypes.c_void_p(_stream_ptr(ins[0]))
+    rc = lib.hm_lookup_permute_batch_bn256_fr_dev(arr(ins), arr(tabs), len(ins), usable_rows, arr([o[0] for o in outs]),
+                                                  arr([o[1] for o in outs]), missing, st)
+    if rc != 0:
+        err = _lib.Halo2Mi355xError(rc, lib.hm_last_error().decode())
+        err.missing = [i for i in range(len(ins)) if missing[i]]
+        raise err
+    tail = n - usable_rows
+    if tail:
+        for i, (oa, os_) in enumerate(outs):
+            _lib.check(lib.hm_fr_random_dev(ctypes.c_void_p(oa.data_ptr() + usable_rows * 32), tail, ctypes.c_uint64(blinding_seed + 2 * i), st))
+            _lib.check(lib.hm_fr_random_dev(ctypes.c_void_p(os_.data_ptr() + usable_rows * 32), tail,
+                                            ctypes.c_uint64((blinding_seed + 2 * i + 1) ^ 0x9E3779B97F4A7C15), st))
+    return outs
+
+
 def g1_fixed_base_mul(scalars, base_xy: np.ndarray):
     """out[i] = [scalars[i]] * base, affine (ParamsKZG::setup's per-row G1 work).  GPU tensors only."""
     import torch

@@ -940,8 +940,21 @@ int hm_lookup_permute_bn256_fr_dev(const void* d_input, const void* d_table, siz
   DeviceCtx* ctx = ctx_for_current_device();
   if (!ctx) return HM_ERR_NO_DEVICE;
   std::lock_guard<std::mutex> lk(ctx->mu);
-  return lookup_permute_run(*ctx, (const uint32_t*)d_input, (const uint32_t*)d_table, rows, (uint32_t*)d_permuted_input,
-                            (uint32_t*)d_permuted_table, (hipStream_t)stream);
+  return lookup_permute_run(*ctx, &d_input, &d_table, 1, rows, &d_permuted_input, &d_permuted_table, nullptr, (hipStream_t)stream);
+}
+
+int hm_lookup_permute_batch_bn256_fr_dev(const void* const* d_inputs, const void* const* d_tables, size_t count, size_t rows,
+                                         void* const* d_permuted_inputs, void* const* d_permuted_tables, int* missing, void* stream) {
+  if (count && (!d_inputs || !d_tables || !d_permuted_inputs || !d_permuted_tables))
+    return hm_fail(HM_ERR_BAD_ARG, "hm_lookup_permute_batch_bn256_fr_dev: null argument");
+  if (rows)
+    for (size_t p = 0; p < count; ++p)
+      if (!d_inputs[p] || !d_tables[p] || !d_permuted_inputs[p] || !d_permuted_tables[p])
+        return hm_fail(HM_ERR_BAD_ARG, "hm_lookup_permute_batch_bn256_fr_dev: null column");
+  DeviceCtx* ctx = ctx_for_current_device();
+  if (!ctx) return HM_ERR_NO_DEVICE;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  return lookup_permute_run(*ctx, d_inputs, d_tables, count, rows, d_permuted_inputs, d_permuted_tables, missing, (hipStream_t)stream);
 }
 
 int hm_fr_powers_dev(void* d_out, size_t n, const uint64_t x[4], void* stream) {

@@ -223,8 +223,8 @@ int fr_linear_combination_run(const void* const* d_polys, const uint64_t* coeffs
                               hipStream_t stream);
 
 // lookup.hip
-int lookup_permute_run(DeviceCtx& ctx, const uint32_t* d_input, const uint32_t* d_table, uint64_t rows, uint32_t* d_out_input,
-                       uint32_t* d_out_table, hipStream_t stream);
+int lookup_permute_run(DeviceCtx& ctx, const void* const* d_inputs, const void* const* d_tables, size_t pairs, uint64_t rows,
+                       void* const* d_out_inputs, void* const* d_out_tables, int* missing, hipStream_t stream);
 
 // msm.hip
 int msm_convert_bases(const uint32_t* d_bases_ext, uint32_t* d_xy, uint8_t* d_inf, size_t n, hipStream_t stream);

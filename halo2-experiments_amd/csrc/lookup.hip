@@ -55,16 +55,25 @@ struct LkFr {
   uint32_t l[9];
 };
 
-// Montgomery words <-> canonical integers: one product by `c` (2^-256 resp. 2^256 in the form the raw words need);
-// rows >= live get the all-ones key (above r: sorts behind every field element)
-__global__ __launch_bounds__(LK_THREADS) void lk_convert_kernel(const uint32_t* in, uint32_t* out, uint64_t live, uint64_t total, LkFr c) {
+// A batch of lookups: pair p has its columns in ptr.in[2p] (input) and ptr.in[2p + 1] (table), its outputs in
+// ptr.out[2p] / ptr.out[2p + 1]; by value, LK_MAX_PAIRS pairs per launch chain
+constexpr int LK_MAX_PAIRS = 8;
+struct LkPtrs {
+  const uint32_t* in[2 * LK_MAX_PAIRS];
+  uint32_t* out[2 * LK_MAX_PAIRS];
+};
+
+// Montgomery words -> canonical integers: one product by `c` (2^-256 in the form the raw words need); rows >= live get
+// the all-ones key (above r: sorts behind every field element).  grid.y = key array (2 per pair).
+__global__ __launch_bounds__(LK_THREADS) void lk_convert_kernel(LkPtrs ptr, uint32_t* keys, uint64_t pitch, uint64_t live, uint64_t total, LkFr c) {
   const uint64_t i = (uint64_t)blockIdx.x * LK_THREADS + threadIdx.x;
   if (i >= total) return;
+  uint32_t* out = keys + (size_t)blockIdx.y * pitch;
   if (i >= live) {
     key_store(out, i, Key{{~0u, ~0u, ~0u, ~0u, ~0u, ~0u, ~0u, ~0u}});
     return;
   }
-  const Key k = key_load(in, i);
+  const Key k = key_load(ptr.in[blockIdx.y], i);
   Fr cc;
 #pragma unroll
   for (int j = 0; j < 9; ++j) cc.l[j] = c.l[j];
@@ -163,10 +172,15 @@ __global__ __launch_bounds__(LK_THREADS) void lk_sort_tile_kernel(uint32_t* keys
   }
 }
 
+// Per-pair work arrays: every array below holds `stride` words per pair (stride >= rows), the block sums `sblocks` per pair.
 // flags[i] = 1 for a repeated input row (same value as the row before), 0 for a first occurrence; first occurrences mark
-// used[lower_bound(table, value)] = 1, or raise *missing when the table does not hold the value
-__global__ __launch_bounds__(LK_THREADS) void lk_mark_kernel(const uint32_t* a_sorted, const uint32_t* t_sorted, uint64_t rows,
-                                                             uint32_t* repeated, uint32_t* used, uint32_t* missing) {
+// used[lower_bound(table, value)] = 1, or raise the pair's `missing` word when the table does not hold the value
+__global__ __launch_bounds__(LK_THREADS) void lk_mark_kernel(const uint32_t* keys, uint64_t pitch, uint64_t rows, uint64_t stride,
+                                                             uint32_t* repeated, uint32_t* used, uint32_t* small) {
+  const uint32_t p = blockIdx.y;
+  const uint32_t *a_sorted = keys + (size_t)(2 * p) * pitch, *t_sorted = keys + (size_t)(2 * p + 1) * pitch;
+  repeated += (size_t)p * stride;
+  used += (size_t)p * stride;
   const uint64_t i = (uint64_t)blockIdx.x * LK_THREADS + threadIdx.x;
   if (i >= rows) return;
   const Key v = key_load(a_sorted, i);
@@ -180,10 +194,10 @@ __global__ __launch_bounds__(LK_THREADS) void lk_mark_kernel(const uint32_t* a_s
     else hi = mid;
   }
   if (lo < rows && key_cmp(key_load(t_sorted, lo), v) == 0) used[lo] = 1u;
-  else atomicExch(missing, 1u);
+  else atomicExch(small + p * 4 + 2, 1u);
 }
 
-// exclusive scan of 0/1 flags (optionally inverted), three launches: block sums, one-block scan of those, apply
+// exclusive scan of 0/1 flags (optionally inverted), three launches: block sums, one-block scan of those, apply; grid.y = pair
 constexpr int SC_ITEMS = 8;
 constexpr int SC_BLOCK = LK_THREADS * SC_ITEMS;
 __device__ __forceinline__ uint32_t lk_block_scan(uint32_t v, uint32_t* s, uint32_t& total) {   // exclusive, 256 lanes
@@ -201,8 +215,11 @@ __device__ __forceinline__ uint32_t lk_block_scan(uint32_t v, uint32_t* s, uint3
   __syncthreads();
   return r;
 }
-__global__ __launch_bounds__(LK_THREADS) void lk_scan_sums_kernel(const uint32_t* flags, uint64_t n, uint32_t invert, uint32_t* sums) {
+__global__ __launch_bounds__(LK_THREADS) void lk_scan_sums_kernel(const uint32_t* flags, uint64_t n, uint64_t stride, uint32_t invert,
+                                                                  uint32_t* sums, uint32_t sblocks) {
   __shared__ uint32_t s[LK_THREADS];
+  flags += (size_t)blockIdx.y * stride;
+  sums += (size_t)blockIdx.y * sblocks;
   const uint64_t b0 = (uint64_t)blockIdx.x * SC_BLOCK + (uint64_t)threadIdx.x * SC_ITEMS;
   uint32_t v = 0;
   for (int k = 0; k < SC_ITEMS; ++k)
@@ -211,10 +228,12 @@ __global__ __launch_bounds__(LK_THREADS) void lk_scan_sums_kernel(const uint32_t
   (void)lk_block_scan(v, s, total);
   if (threadIdx.x == 0) sums[blockIdx.x] = total;
 }
-__global__ __launch_bounds__(LK_THREADS) void lk_scan_top_kernel(uint32_t* sums, uint32_t nblocks, uint32_t* grand_total) {
+// one workgroup per pair; the pair's grand total goes to small[4 p + which]
+__global__ __launch_bounds__(LK_THREADS) void lk_scan_top_kernel(uint32_t* sums, uint32_t nblocks, uint32_t sblocks, uint32_t* small, uint32_t which) {
   __shared__ uint32_t s[LK_THREADS];
+  sums += (size_t)blockIdx.x * sblocks;
   const uint32_t per = (nblocks + LK_THREADS - 1) / LK_THREADS;
-  const uint32_t lo = threadIdx.x * per, hi = lo + per < nblocks ? lo + per : nblocks;
+  const uint32_t lo = threadIdx.x * per < nblocks ? threadIdx.x * per : nblocks, hi = lo + per < nblocks ? lo + per : nblocks;
   uint32_t v = 0;
   for (uint32_t i = lo; i < hi; ++i) v += sums[i];
   uint32_t total;
@@ -224,12 +243,16 @@ __global__ __launch_bounds__(LK_THREADS) void lk_scan_top_kernel(uint32_t* sums,
     sums[i] = run;
     run += c;
   }
-  if (threadIdx.x == 0) *grand_total = total;
+  if (threadIdx.x == 0) small[blockIdx.x * 4 + which] = total;
 }
 // positions[rank] = index, for every index whose (possibly inverted) flag is set -- the compacted list in index order
-__global__ __launch_bounds__(LK_THREADS) void lk_scan_apply_kernel(const uint32_t* flags, uint64_t n, uint32_t invert, const uint32_t* sums,
-                                                                   uint32_t* rank_of, uint32_t* positions) {
+__global__ __launch_bounds__(LK_THREADS) void lk_scan_apply_kernel(const uint32_t* flags, uint64_t n, uint64_t stride, uint32_t invert,
+                                                                   const uint32_t* sums, uint32_t sblocks, uint32_t* rank_of, uint32_t* positions) {
   __shared__ uint32_t s[LK_THREADS];
+  flags += (size_t)blockIdx.y * stride;
+  sums += (size_t)blockIdx.y * sblocks;
+  if (rank_of) rank_of += (size_t)blockIdx.y * stride;
+  positions += (size_t)blockIdx.y * stride;
   const uint64_t b0 = (uint64_t)blockIdx.x * SC_BLOCK + (uint64_t)threadIdx.x * SC_ITEMS;
   uint32_t f[SC_ITEMS], v = 0;
   for (int k = 0; k < SC_ITEMS; ++k) {
@@ -249,19 +272,23 @@ __global__ __launch_bounds__(LK_THREADS) void lk_scan_apply_kernel(const uint32_
 
 // S'[i] = A'[i] at first occurrences; the repeated row of rank r (ascending) takes the leftover table value of rank
 // m - 1 - r (upstream pops the repeated rows from the back while walking the leftovers upwards).  Both columns return
-// to Montgomery words.
-__global__ __launch_bounds__(LK_THREADS) void lk_fill_kernel(const uint32_t* a_sorted, const uint32_t* t_sorted, uint64_t rows,
+// to Montgomery words.  small[4 p + ..]: [0] repeated rows, [1] leftovers, [2] missing, [3] mismatch.
+__global__ __launch_bounds__(LK_THREADS) void lk_fill_kernel(const uint32_t* keys, uint64_t pitch, uint64_t rows, uint64_t stride,
                                                              const uint32_t* repeated, const uint32_t* rep_rank, const uint32_t* left_pos,
-                                                             const uint32_t* counts /* [0] repeated rows, [1] leftovers */, LkFr c,
-                                                             uint32_t* out_a, uint32_t* out_s, uint32_t* mismatch) {
+                                                             uint32_t* small, LkFr c, LkPtrs ptr) {
+  const uint32_t p = blockIdx.y;
+  const uint32_t *a_sorted = keys + (size_t)(2 * p) * pitch, *t_sorted = keys + (size_t)(2 * p + 1) * pitch;
+  repeated += (size_t)p * stride;
+  rep_rank += (size_t)p * stride;
+  left_pos += (size_t)p * stride;
   const uint64_t i = (uint64_t)blockIdx.x * LK_THREADS + threadIdx.x;
   if (i >= rows) return;
   const Key a = key_load(a_sorted, i);
   Key sv = a;
   if (repeated[i]) {
-    const uint32_t m = counts[0];
-    if (counts[1] != m) {                          // cannot happen when every first occurrence found its table value
-      atomicExch(mismatch, 1u);
+    const uint32_t m = small[p * 4 + 0];
+    if (small[p * 4 + 1] != m) {                   // cannot happen when every first occurrence found its table value
+      atomicExch(small + p * 4 + 3, 1u);
       return;
     }
     sv = key_load(t_sorted, left_pos[m - 1 - rep_rank[i]]);
@@ -272,9 +299,9 @@ __global__ __launch_bounds__(LK_THREADS) void lk_fill_kernel(const uint32_t* a_s
   HM_DECLARE(cc, 1.0);
   Key o;
   fe_pack(o.w, fe_canonical(fe_mul(fe_unpack<FrParams>(a.w), cc)));
-  key_store(out_a, i, o);
+  key_store(ptr.out[2 * p], i, o);
   fe_pack(o.w, fe_canonical(fe_mul(fe_unpack<FrParams>(sv.w), cc)));
-  key_store(out_s, i, o);
+  key_store(ptr.out[2 * p + 1], i, o);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -299,22 +326,26 @@ static int lk_sort(uint32_t* d_keys, uint64_t n_pow2, uint32_t arrays, uint64_t 
   return HM_OK;
 }
 
-static int lk_compact(const uint32_t* d_flags, uint64_t n, uint32_t invert, uint32_t* d_sums, uint32_t* d_total, uint32_t* d_rank,
-                      uint32_t* d_positions, hipStream_t stream) {
+static int lk_compact(const uint32_t* d_flags, uint64_t n, uint64_t stride, uint32_t pairs, uint32_t invert, uint32_t* d_sums, uint32_t* d_small,
+                      uint32_t which, uint32_t* d_rank, uint32_t* d_positions, hipStream_t stream) {
   const uint32_t blocks = (uint32_t)((n + SC_BLOCK - 1) / SC_BLOCK);
-  hipLaunchKernelGGL(lk_scan_sums_kernel, dim3(blocks), dim3(LK_THREADS), 0, stream, d_flags, n, invert, d_sums);
-  hipLaunchKernelGGL(lk_scan_top_kernel, dim3(1), dim3(LK_THREADS), 0, stream, d_sums, blocks, d_total);
-  hipLaunchKernelGGL(lk_scan_apply_kernel, dim3(blocks), dim3(LK_THREADS), 0, stream, d_flags, n, invert, (const uint32_t*)d_sums, d_rank,
-                     d_positions);
+  hipLaunchKernelGGL(lk_scan_sums_kernel, dim3(blocks, pairs), dim3(LK_THREADS), 0, stream, d_flags, n, stride, invert, d_sums, blocks);
+  hipLaunchKernelGGL(lk_scan_top_kernel, dim3(pairs), dim3(LK_THREADS), 0, stream, d_sums, blocks, blocks, d_small, which);
+  hipLaunchKernelGGL(lk_scan_apply_kernel, dim3(blocks, pairs), dim3(LK_THREADS), 0, stream, d_flags, n, stride, invert, (const uint32_t*)d_sums,
+                     blocks, d_rank, d_positions);
   HM_HIP_CHECK(hipGetLastError());
   return HM_OK;
 }
 
-// d_input, d_table: n-row columns (only the first `rows` are read); d_out_input, d_out_table: rows [0, rows) written.
-// Returns HM_ERR_NOT_FOUND when an input value is missing from the table (upstream: Error::ConstraintSystemFailure).
-int lookup_permute_run(DeviceCtx& ctx, const uint32_t* d_input, const uint32_t* d_table, uint64_t rows, uint32_t* d_out_input,
-                       uint32_t* d_out_table, hipStream_t stream) {
-  if (rows == 0) return HM_OK;
+// `pairs` lookups of the same length through one launch chain.  d_inputs[p], d_tables[p]: columns of which the first
+// `rows` entries are read; d_out_inputs[p], d_out_tables[p]: rows [0, rows) written.  missing[p] (optional) tells which
+// lookup failed.  Returns HM_ERR_NOT_FOUND when an input value is missing from its table (upstream:
+// Error::ConstraintSystemFailure).
+int lookup_permute_run(DeviceCtx& ctx, const void* const* d_inputs, const void* const* d_tables, size_t pairs, uint64_t rows,
+                       void* const* d_out_inputs, void* const* d_out_tables, int* missing, hipStream_t stream) {
+  if (missing)
+    for (size_t p = 0; p < pairs; ++p) missing[p] = 0;
+  if (rows == 0 || pairs == 0) return HM_OK;
   if (rows >= ((uint64_t)1 << 31)) return hm_fail(HM_ERR_BAD_ARG, "lookup permute: too many rows");
   uint64_t n2 = 1;
   while (n2 < rows) n2 <<= 1;
@@ -326,20 +357,21 @@ int lookup_permute_run(DeviceCtx& ctx, const uint32_t* d_input, const uint32_t* 
   AuxSlot* slot = aux_acquire(ctx, stream);
   if (!slot) return HM_ERR_HIP;
   const uint32_t blocks = (uint32_t)((rows + SC_BLOCK - 1) / SC_BLOCK);
+  const uint32_t P = (uint32_t)(pairs < (size_t)LK_MAX_PAIRS ? pairs : (size_t)LK_MAX_PAIRS);      // pairs per chain
   auto align = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  const uint64_t stride = (rows + 63) & ~(uint64_t)63, pitch = n2 * 8;
   size_t off = 0;
   auto carve = [&](size_t bytes) { const size_t o = off; off += align(bytes); return o; };
-  const size_t o_a = carve(n2 * 32), o_t = carve(n2 * 32), o_rep = carve(rows * 4), o_used = carve(rows * 4), o_rank = carve(rows * 4),
-               o_left = carve(rows * 4), o_reppos = carve(rows * 4), o_sums = carve((size_t)blocks * 4 * 2), o_small = carve(64);
+  const size_t o_keys = carve((size_t)2 * P * n2 * 32), o_rep = carve((size_t)P * stride * 4), o_used = carve((size_t)P * stride * 4),
+               o_rank = carve((size_t)P * stride * 4), o_left = carve((size_t)P * stride * 4), o_reppos = carve((size_t)P * stride * 4),
+               o_sums = carve((size_t)P * blocks * 4 * 2), o_small = carve((size_t)LK_MAX_PAIRS * 16);
   uint8_t* ws = (uint8_t*)slot->scratch.ensure(off);
   if (!ws) return hm_fail(HM_ERR_HIP, "lookup permute: scratch allocation failed");
-  uint32_t *a = (uint32_t*)(ws + o_a), *t = (uint32_t*)(ws + o_t), *rep = (uint32_t*)(ws + o_rep), *used = (uint32_t*)(ws + o_used);
+  uint32_t *keys = (uint32_t*)(ws + o_keys), *rep = (uint32_t*)(ws + o_rep), *used = (uint32_t*)(ws + o_used);
   uint32_t *rank = (uint32_t*)(ws + o_rank), *left = (uint32_t*)(ws + o_left), *reppos = (uint32_t*)(ws + o_reppos);
-  uint32_t *sums = (uint32_t*)(ws + o_sums), *small = (uint32_t*)(ws + o_small);   // small: [0] repeated, [1] leftovers, [2] missing, [3] mismatch
-  HM_HIP_CHECK(hipMemsetAsync(used, 0, rows * 4, stream));
-  HM_HIP_CHECK(hipMemsetAsync(small, 0, 64, stream));
-  // raw words * int(2^-251) ... in ff29 terms: the raw words are the internal form of v / 32; times the internal form of
-  // 32 * 2^-256 gives the internal form of v * 2^-256 / 32, whose raw words are the canonical integer v (as Fr::to_repr)
+  uint32_t *sums = (uint32_t*)(ws + o_sums), *small = (uint32_t*)(ws + o_small);
+  // the raw words are the internal form of v / 32; times the internal form of 32 * 2^-256 (the integer 32 ... see
+  // msm_s_digits_kernel) they become the canonical integer v (as Fr::to_repr); and back with 2^256
   LkFr to_canon, to_mont;
   {
     const host::Fr4 one_int = {{1, 0, 0, 0}};                       // the integer 1 read as Montgomery words = 2^-256
@@ -347,25 +379,46 @@ int lookup_permute_run(DeviceCtx& ctx, const uint32_t* d_input, const uint32_t* 
     const host::Fr4 r2 = {{0x1bb8e645ae216da7ULL, 0x53fe3ab1e35c59e3ULL, 0x8c49833d53bb8085ULL, 0x0216d0b17f4e44a5ULL}};   // 2^512 mod r as words = the element 2^256
     host::fr_to_internal9(r2, to_mont.l);
   }
-  const uint32_t cb = (uint32_t)((n2 + LK_THREADS - 1) / LK_THREADS), rb = (uint32_t)((rows + LK_THREADS - 1) / LK_THREADS);
-  hipLaunchKernelGGL(lk_convert_kernel, dim3(cb), dim3(LK_THREADS), 0, stream, d_input, a, rows, n2, to_canon);
-  hipLaunchKernelGGL(lk_convert_kernel, dim3(cb), dim3(LK_THREADS), 0, stream, d_table, t, rows, n2, to_canon);
-  int rc = lk_sort(a, n2, 2, (uint64_t)(t - a), stream);        // both columns side by side
-  if (rc != HM_OK) return rc;
-  hipLaunchKernelGGL(lk_mark_kernel, dim3(rb), dim3(LK_THREADS), 0, stream, (const uint32_t*)a, (const uint32_t*)t, rows, rep, used, small + 2);
-  rc = lk_compact(rep, rows, 0, sums, small + 0, rank, reppos, stream);
-  if (rc == HM_OK) rc = lk_compact(used, rows, 1, sums + blocks, small + 1, nullptr, left, stream);
-  if (rc != HM_OK) return rc;
-  hipLaunchKernelGGL(lk_fill_kernel, dim3(rb), dim3(LK_THREADS), 0, stream, (const uint32_t*)a, (const uint32_t*)t, rows, (const uint32_t*)rep,
-                     (const uint32_t*)rank, (const uint32_t*)left, (const uint32_t*)small, to_mont, d_out_input, d_out_table, small + 3);
-  HM_HIP_CHECK(hipGetLastError());
-  uint32_t h_small[4] = {0, 0, 0, 0};
-  HM_HIP_CHECK(hipMemcpyAsync(h_small, small, 16, hipMemcpyDeviceToHost, stream));
-  HM_HIP_CHECK(hipStreamSynchronize(stream));
-  rc = aux_release(ctx, slot, stream);
-  if (h_small[2]) return hm_fail(HM_ERR_NOT_FOUND, "lookup permute: an input value is missing from the table (ConstraintSystemFailure)");
-  if (h_small[3]) return hm_fail(HM_ERR_INTERNAL, "lookup permute: leftover / repeated counts differ");
-  return rc;
+  int result = HM_OK;
+  for (size_t p0 = 0; p0 < pairs; p0 += P) {
+    const uint32_t cnt = (uint32_t)(pairs - p0 < (size_t)P ? pairs - p0 : (size_t)P);
+    LkPtrs ptr;
+    std::memset(&ptr, 0, sizeof ptr);
+    for (uint32_t p = 0; p < cnt; ++p) {
+      ptr.in[2 * p] = (const uint32_t*)d_inputs[p0 + p];
+      ptr.in[2 * p + 1] = (const uint32_t*)d_tables[p0 + p];
+      ptr.out[2 * p] = (uint32_t*)d_out_inputs[p0 + p];
+      ptr.out[2 * p + 1] = (uint32_t*)d_out_tables[p0 + p];
+    }
+    HM_HIP_CHECK(hipMemsetAsync(used, 0, (size_t)cnt * stride * 4, stream));
+    HM_HIP_CHECK(hipMemsetAsync(small, 0, (size_t)LK_MAX_PAIRS * 16, stream));
+    const uint32_t cb = (uint32_t)((n2 + LK_THREADS - 1) / LK_THREADS), rb = (uint32_t)((rows + LK_THREADS - 1) / LK_THREADS);
+    hipLaunchKernelGGL(lk_convert_kernel, dim3(cb, 2 * cnt), dim3(LK_THREADS), 0, stream, ptr, keys, pitch, rows, n2, to_canon);
+    int rc = lk_sort(keys, n2, 2 * cnt, pitch, stream);            // every column of the chain side by side
+    if (rc != HM_OK) return rc;
+    hipLaunchKernelGGL(lk_mark_kernel, dim3(rb, cnt), dim3(LK_THREADS), 0, stream, (const uint32_t*)keys, pitch, rows, stride, rep, used, small);
+    rc = lk_compact(rep, rows, stride, cnt, 0, sums, small, 0, rank, reppos, stream);
+    if (rc == HM_OK) rc = lk_compact(used, rows, stride, cnt, 1, sums + (size_t)P * blocks, small, 1, nullptr, left, stream);
+    if (rc != HM_OK) return rc;
+    hipLaunchKernelGGL(lk_fill_kernel, dim3(rb, cnt), dim3(LK_THREADS), 0, stream, (const uint32_t*)keys, pitch, rows, stride, (const uint32_t*)rep,
+                       (const uint32_t*)rank, (const uint32_t*)left, small, to_mont, ptr);
+    HM_HIP_CHECK(hipGetLastError());
+    uint32_t h_small[4 * LK_MAX_PAIRS];
+    HM_HIP_CHECK(hipMemcpyAsync(h_small, small, sizeof h_small, hipMemcpyDeviceToHost, stream));
+    HM_HIP_CHECK(hipStreamSynchronize(stream));
+    for (uint32_t p = 0; p < cnt; ++p) {
+      if (h_small[4 * p + 2]) {
+        if (missing) missing[p0 + p] = 1;
+        if (result == HM_OK) result = HM_ERR_NOT_FOUND;
+      } else if (h_small[4 * p + 3] && result == HM_OK) {
+        result = HM_ERR_INTERNAL;
+      }
+    }
+  }
+  const int rrc = aux_release(ctx, slot, stream);
+  if (result == HM_ERR_NOT_FOUND) return hm_fail(HM_ERR_NOT_FOUND, "lookup permute: an input value is missing from the table (ConstraintSystemFailure)");
+  if (result == HM_ERR_INTERNAL) return hm_fail(HM_ERR_INTERNAL, "lookup permute: leftover / repeated counts differ");
+  return rrc;
 }
 
 }  // namespace hm

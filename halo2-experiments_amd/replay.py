@@ -40,7 +40,7 @@ from typing import Optional
 import numpy as np
 
 from .arithmetic import (G1_GENERATOR, batch_invert, best_multiexp, best_multiexp_submit, best_multiexp_wait, eval_polynomial,
-                         g1_fixed_base_mul, grand_product, kate_division, linear_combination, permute_expression_pair, register_bases,
+                         g1_fixed_base_mul, grand_product, kate_division, linear_combination, permute_expression_pairs, register_bases,
                          release_bases)
 from .domain import EvaluationDomain, FR_MODULUS, fr_words
 from .kzg import ParamsKZG
@@ -269,8 +269,8 @@ def run_replay(shape_name: str, device=None, group=None, include_host_pointer_es
         t["grand_products"] = time.perf_counter() - t0
         t0 = time.perf_counter()
         if rank == 0:
-            for i in range(L):                        # the permuted input / table columns of every lookup argument
-                permute_expression_pair(lookup_input, lookup_table, n - 7, blinding_seed=i)
+            if L:                                     # the permuted input / table columns of every lookup argument, one call
+                permute_expression_pairs([lookup_input] * L, [lookup_table] * L, n - 7, blinding_seed=1)
         torch.cuda.synchronize()
         t["lookup_permute"] = time.perf_counter() - t0
         t0 = time.perf_counter()

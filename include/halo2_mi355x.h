@@ -218,6 +218,11 @@ int hm_fr_linear_combination_dev(const void* const* d_polys, const uint64_t* coe
  * (upstream: Error::ConstraintSystemFailure).  Synchronises `stream`. */
 int hm_lookup_permute_bn256_fr_dev(const void* d_input, const void* d_table, size_t rows, void* d_permuted_input,
                                    void* d_permuted_table, void* stream);
+/* The same for the `count` lookup arguments of a circuit at once (create_proof maps commit_permuted over them): one launch
+ * chain carries up to eight lookups, so their 256-bit sorts run side by side.  Host arrays of `count` device pointers;
+ * missing (optional, count ints) is set to 1 for every lookup whose input holds a value its table lacks. */
+int hm_lookup_permute_batch_bn256_fr_dev(const void* const* d_inputs, const void* const* d_tables, size_t count, size_t rows,
+                                         void* const* d_permuted_inputs, void* const* d_permuted_tables, int* missing, void* stream);
 
 /* out[i] = x^i for i < n (device pointer, n x 4 u64): the ladder 1, s, s^2, ... of ParamsKZG::setup, whose
  * fixed-base multiples are g, and whose scaled inverse NTT gives the Lagrange-basis scalars of g_lagrange. */

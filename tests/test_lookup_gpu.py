@@ -99,3 +99,27 @@ def test_large_lookup_properties(pyref):
     same_as_prev = torch.zeros(rows, dtype=torch.bool, device="cuda")
     same_as_prev[1:] = a_int[1:, 0] == a_int[:-1, 0]
     assert bool((same_as_table | same_as_prev).all())
+
+
+@pytest.mark.parametrize("count", [1, 3, 8, 11])
+def test_batch_of_lookups_equals_single_calls(pyref, count):
+    """All lookup arguments of a circuit in one call (one chain carries eight; eleven = two chains), different kinds and
+    one pair repeated; and a failing lookup among them is reported by index."""
+    k, blinding = 12, 6
+    n, rows = 1 << k, (1 << k) - blinding - 1
+    rng = random.Random(900 + count)
+    kinds = ["range", "compressed", "edge", "permutation"]
+    pairs = [make_pair(rng, n, rows, kinds[i % 4]) for i in range(count)]
+    d_in, d_tab = [to_gpu(pyref, p[0]) for p in pairs], [to_gpu(pyref, p[1]) for p in pairs]
+    outs = h.permute_expression_pairs(d_in, d_tab, rows, blinding_seed=3)
+    assert len(outs) == count
+    for (inp, table), (a, s) in zip(pairs, outs):
+        want_a, want_s = pr.permute_expression_pair(inp, table, rows)
+        assert from_gpu(pyref, a[:rows]) == want_a and from_gpu(pyref, s[:rows]) == want_s
+    if count >= 3:
+        bad = list(pairs[count - 2][0])
+        bad[5] = (max(pairs[count - 2][1]) + 12345) % R
+        d_in[count - 2] = to_gpu(pyref, bad)
+        with pytest.raises(_lib.Halo2Mi355xError) as e:
+            h.permute_expression_pairs(d_in, d_tab, rows)
+        assert e.value.missing == [count - 2]
