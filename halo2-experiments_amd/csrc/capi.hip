@@ -743,6 +743,7 @@ int hm_get_stats(hm_stats* out) {
   out->msm_h2d_us = c.msm_h2d_us; out->msm_device_us = c.msm_device_us; out->msm_host_us = c.msm_host_us;
   out->ntt_h2d_us = c.ntt_h2d_us; out->ntt_device_us = c.ntt_device_us; out->ntt_d2h_us = c.ntt_d2h_us;
   out->h2d_bytes = c.h2d_bytes; out->d2h_bytes = c.d2h_bytes;
+  for (int i = 0; i < 8; ++i) { out->vector_calls[i] = c.vector_calls[i]; out->vector_elements[i] = c.vector_elements[i]; }
   return HM_OK;
 }
 
@@ -755,6 +756,11 @@ int hm_reset_stats(void) {
 }
 
 // ---- NTT -------------------------------------------------------------------------------------
+
+static void count_vector(DeviceCtx& ctx, int kind, uint64_t calls, uint64_t elements) {   // ctx.mu held
+  ctx.calls.vector_calls[kind] += calls;
+  ctx.calls.vector_elements[kind] += elements;
+}
 
 static void count_ntt(DeviceCtx& ctx, uint32_t log_n, size_t batch) {
   ctx.calls.ntt_calls += batch;
@@ -891,6 +897,7 @@ int hm_eval_polynomial_bn256_fr_dev(const void* d_polys, size_t n, const uint32_
   DeviceCtx* ctx = ctx_for_current_device();
   if (!ctx) return HM_ERR_NO_DEVICE;
   std::lock_guard<std::mutex> lk(ctx->mu);
+  count_vector(*ctx, HM_STAT_EVAL_POLYNOMIAL, count, (uint64_t)count * n);
   return fr_eval_polynomial_run(*ctx, (const uint32_t*)d_polys, n, poly_index, points, count, out, (hipStream_t)stream);
 }
 
@@ -904,6 +911,7 @@ int hm_kate_division_bn256_fr_dev(const void* d_poly, size_t n, const uint64_t z
   DeviceCtx* ctx = ctx_for_current_device();
   if (!ctx) return HM_ERR_NO_DEVICE;
   std::lock_guard<std::mutex> lk(ctx->mu);
+  count_vector(*ctx, HM_STAT_KATE_DIVISION, 1, n);
   return fr_kate_division_run(*ctx, (const uint32_t*)d_poly, n, z, (uint32_t*)d_quotient, (hipStream_t)stream);
 }
 
@@ -912,6 +920,7 @@ int hm_fr_grand_product_dev(const void* d_factors, size_t n, const uint64_t star
   DeviceCtx* ctx = ctx_for_current_device();
   if (!ctx) return HM_ERR_NO_DEVICE;
   std::lock_guard<std::mutex> lk(ctx->mu);
+  count_vector(*ctx, HM_STAT_GRAND_PRODUCT, 1, n);
   return fr_grand_product_run(*ctx, (const uint32_t*)d_factors, n, start, (uint32_t*)d_out, (hipStream_t)stream);
 }
 
@@ -919,6 +928,10 @@ int hm_fr_batch_invert_dev(void* d_values, size_t n, void* stream) {
   if (n && !d_values) return hm_fail(HM_ERR_BAD_ARG, "hm_fr_batch_invert_dev: null argument");
   DeviceCtx* ctx = ctx_for_current_device();
   if (!ctx) return HM_ERR_NO_DEVICE;
+  {
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    count_vector(*ctx, HM_STAT_BATCH_INVERT, 1, n);
+  }
   return fr_batch_invert_run((uint32_t*)d_values, n, (hipStream_t)stream);
 }
 
@@ -930,6 +943,10 @@ int hm_fr_linear_combination_dev(const void* const* d_polys, const uint64_t* coe
       if (!d_polys[j]) return hm_fail(HM_ERR_BAD_ARG, "hm_fr_linear_combination_dev: null polynomial");
   DeviceCtx* ctx = ctx_for_current_device();
   if (!ctx) return HM_ERR_NO_DEVICE;
+  {
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    count_vector(*ctx, HM_STAT_LINEAR_COMBINATION, 1, (uint64_t)count * n);
+  }
   return fr_linear_combination_run(d_polys, coeffs, count, n, (uint32_t*)d_out, (hipStream_t)stream);
 }
 
@@ -940,6 +957,7 @@ int hm_lookup_permute_bn256_fr_dev(const void* d_input, const void* d_table, siz
   DeviceCtx* ctx = ctx_for_current_device();
   if (!ctx) return HM_ERR_NO_DEVICE;
   std::lock_guard<std::mutex> lk(ctx->mu);
+  count_vector(*ctx, HM_STAT_LOOKUP_PERMUTE, 1, rows);
   return lookup_permute_run(*ctx, &d_input, &d_table, 1, rows, &d_permuted_input, &d_permuted_table, nullptr, (hipStream_t)stream);
 }
 
@@ -954,6 +972,7 @@ int hm_lookup_permute_batch_bn256_fr_dev(const void* const* d_inputs, const void
   DeviceCtx* ctx = ctx_for_current_device();
   if (!ctx) return HM_ERR_NO_DEVICE;
   std::lock_guard<std::mutex> lk(ctx->mu);
+  count_vector(*ctx, HM_STAT_LOOKUP_PERMUTE, count, (uint64_t)count * rows);
   return lookup_permute_run(*ctx, d_inputs, d_tables, count, rows, d_permuted_inputs, d_permuted_tables, missing, (hipStream_t)stream);
 }
 
@@ -982,8 +1001,10 @@ int hm_graph_evaluate_dev(uint64_t handle, const void* const* d_columns, size_t 
   if (!ctx) return HM_ERR_NO_DEVICE;
   std::lock_guard<std::mutex> lk(ctx->mu);
   for (auto& g : ctx->graphs)
-    if (g->handle == handle)
+    if (g->handle == handle) {
+      count_vector(*ctx, HM_STAT_GRAPH_EVALUATE, 1, log_size < 40 ? (uint64_t)1 << log_size : 0);
       return graph_evaluate(*ctx, *g, d_columns, n_columns, dynamic_constants, n_dynamic, log_size, d_values, (hipStream_t)stream);
+    }
   return hm_fail(HM_ERR_NOT_FOUND, "hm_graph_evaluate_dev: unknown program handle");
 }
 

@@ -145,6 +145,7 @@ struct CallStats {
   uint64_t msm_by_log[32] = {}, ntt_by_log[32] = {};
   double msm_h2d_us = 0, msm_device_us = 0, msm_host_us = 0, ntt_h2d_us = 0, ntt_device_us = 0, ntt_d2h_us = 0;
   uint64_t h2d_bytes = 0, d2h_bytes = 0;
+  uint64_t vector_calls[8] = {}, vector_elements[8] = {};    // HM_STAT_* kinds (include/halo2_mi355x.h)
 };
 
 struct DeviceCtx {

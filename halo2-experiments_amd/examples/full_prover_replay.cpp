@@ -292,6 +292,16 @@ int main(int argc, char** argv) {
       if (trace.msm_calls_by_log2[lg] || trace.ntt_calls_by_log2[lg])
         std::printf("  2^%-2d  MSM calls %4llu   NTT calls %4llu\n", lg, (unsigned long long)trace.msm_calls_by_log2[lg],
                     (unsigned long long)trace.ntt_calls_by_log2[lg]);
+    {
+      hm_stats after;                                        // the verification section's own calls, by kind
+      arithmetic::check(hm_get_stats(&after), "hm_get_stats");
+      static const char* kinds[7] = {"eval_polynomial", "graph_evaluate", "kate_division", "grand_product", "batch_invert", "linear_combination",
+                                     "lookup_permute"};
+      std::printf("other entry points since the reset:");
+      for (int i = 0; i < 7; ++i)
+        if (after.vector_calls[i]) std::printf(" %s x%llu", kinds[i], (unsigned long long)after.vector_calls[i]);
+      std::printf("\n");
+    }
     std::printf("checked %zu commitments of the trace against [f(s)]G: %zu mismatches\n", made.size(), bad);
     std::printf("opening q = (w - w(z)) / (X - z) and the z-column product identity: %s\n", opening_ok ? "ok" : "FAILED");
     std::printf("%s\n", ok ? "commitments verified" : "COMMITMENT MISMATCH");

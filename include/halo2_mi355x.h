@@ -292,7 +292,17 @@ typedef struct hm_stats {
   double msm_h2d_us, msm_device_us, msm_host_us;  /* host-pointer uploads; hipEvent span of the launches; host fold */
   double ntt_h2d_us, ntt_device_us, ntt_d2h_us;   /* host-pointer form only (device-pointer calls are not waited for) */
   uint64_t h2d_bytes, d2h_bytes;          /* bytes the host-pointer forms moved over PCIe */
+  /* the entry points beyond the two functions, by HM_STAT_* kind: calls (queries / lookups where a call carries several)
+   * and the field elements they covered */
+  uint64_t vector_calls[8], vector_elements[8];
 } hm_stats;
+#define HM_STAT_EVAL_POLYNOMIAL 0
+#define HM_STAT_GRAPH_EVALUATE 1
+#define HM_STAT_KATE_DIVISION 2
+#define HM_STAT_GRAND_PRODUCT 3
+#define HM_STAT_BATCH_INVERT 4
+#define HM_STAT_LINEAR_COMBINATION 5
+#define HM_STAT_LOOKUP_PERMUTE 6
 int hm_get_stats(hm_stats* out);
 int hm_reset_stats(void);
 

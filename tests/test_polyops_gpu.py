@@ -198,3 +198,21 @@ def test_permutation_product_column(pyref):
     # a permutation of equal... the product over all rows telescopes to 1 when the columns satisfy the permutation;
     # with random columns it does not, but z[0] = 1 always
     assert from_gpu(pyref, z[:1]) == [1]
+
+
+def test_call_counters_cover_the_vector_entry_points(pyref):
+    """hm_get_stats counts the entry points beyond best_multiexp / best_fft by kind (the measured call trace of SURVEY.md §5)."""
+    lib = _lib.load()
+    _lib.check(lib.hm_reset_stats())
+    a = rand_fr_gpu(1000, 1)
+    h.kate_division(a, fr_words(3))
+    h.grand_product(a, fr_words(1))
+    h.batch_invert(a.clone())
+    h.linear_combination([a, a], np.stack([fr_words(2), fr_words(3)]))
+    h.eval_polynomial(a.reshape(1, 1000, 4), np.stack([fr_words(5), fr_words(6)]), poly_index=[0, 0])
+    h.permute_expression_pairs([a, a], [a, a], 990)
+    st = _lib.Stats()
+    _lib.check(lib.hm_get_stats(ctypes.byref(st)))
+    got = {k: (st.vector_calls[i], st.vector_elements[i]) for i, k in enumerate(_lib.Stats.KINDS)}
+    assert got == {"eval_polynomial": (2, 2000), "graph_evaluate": (0, 0), "kate_division": (1, 1000), "grand_product": (1, 1000),
+                   "batch_invert": (1, 1000), "linear_combination": (1, 2000), "lookup_permute": (2, 1980)}
