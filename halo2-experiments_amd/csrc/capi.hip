@@ -221,6 +221,7 @@ int hm_shutdown(void) {
   }
   for (auto& sl : c.msm_slots) {
     sl.ws.release();
+    sl.live_ptr = nullptr;
     sl.busy = false;
     if (sl.h_land) { (void)hipHostFree(sl.h_land); sl.h_land = nullptr; }
     if (sl.ev_ready) { for (auto& e : sl.ev) (void)hipEventDestroy(e); sl.ev_ready = false; }

@@ -597,7 +597,9 @@ int msm_issue_small(DeviceCtx& ctx, int slot, const uint32_t* const* d_scalars_l
   const uint32_t res_stride = 4 + W * 32;                         // words per element: totals, then the window sums
   const size_t o_res = ws_stride * group;
   const size_t o_live = o_res + (((size_t)group * res_stride * 4 + 255) & ~(size_t)255);     // the group's survivor counters, together
+  const size_t cap_before = sl.ws.cap;
   uint8_t* ws = (uint8_t*)sl.ws.ensure(o_live + (size_t)HM_MSM_GROUP * 4);
+  if (sl.ws.cap != cap_before) sl.live_ptr = nullptr;             // a fresh allocation (even at the old address) holds no cleared counters
   if (!ws) return hm_fail(HM_ERR_HIP, "msm (small plan): workspace allocation failed");
   int32_t* d_digits = (int32_t*)(ws + o_digits);
   uint32_t* d_toff = (uint32_t*)(ws + o_toff);
