@@ -527,6 +527,34 @@ def test_two_threads_batch_at_once(cref):
         h.release_bases(hd)
 
 
+def test_shutdown_then_reuse(cref, golden):
+    """hm_shutdown releases every device resource of the context (workspaces, tables, streams); the next call builds them
+    again -- same results, sparse and dense, through the synchronous path and a batch, with a general-pipeline MSM in
+    between (which scribbles over the slot workspace the five-launch plan keeps its block counters in)."""
+    from halo2_experiments_amd.arithmetic import best_multiexp_batch
+    lib = _lib.load()
+    g = golden["msm"]
+    n = 1 << 12
+    bases = h.g1_fixed_base_mul(rand_fr_gpu(n, 8700), cref.g1_generator())
+    cols = [rand_fr_gpu(n, 8701), _replay_sparse_column(n, 100, 8702)]
+    big_b = h.g1_fixed_base_mul(rand_fr_gpu(1 << 19, 8703), cref.g1_generator())
+    big_s = rand_fr_gpu(1 << 19, 8704)
+    results = []
+    for round_ in range(3):
+        hd, hb = h.register_bases(bases), h.register_bases(big_b)
+        one = [h.best_multiexp(c, hd) for c in cols]
+        big = h.best_multiexp(big_s, hb)                       # n = 2^19: the general pipeline, same slot 0
+        again = [h.best_multiexp(c, hd) for c in cols]
+        batch = best_multiexp_batch(cols * 5, hd)
+        assert all(np.array_equal(a, b) for a, b in zip(one, again))
+        assert all(np.array_equal(batch[i], one[i % 2]) for i in range(10))
+        results.append((one, big))
+        assert g1_equal(h.best_multiexp(g["n255_uniform_s"], g["n255_uniform_b"]), g["n255_uniform_r"])
+        _lib.check(lib.hm_shutdown())                           # handles die with the context
+    for one, big in results[1:]:
+        assert all(np.array_equal(a, b) for a, b in zip(one, results[0][0])) and np.array_equal(big, results[0][1])
+
+
 def test_config5_size_2_26_fits_one_gpu_and_is_additive():
     """BASELINE config 5's 2^26-point MSM on ONE GPU (2^30 (point, bucket) pairs, 4 + 4 GiB of
     bases, ~20 GiB of workspace): the whole equals the sum of its four 2^24 quarters."""
