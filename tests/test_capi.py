@@ -60,6 +60,32 @@ def test_no_device_means_error_not_fallback():
     assert lib.hm_set_device(0) == -2
 
 
+def test_device_pointer_entry_points_without_a_device():
+    """Every device-pointer entry point added after the two functions: null arguments are HM_ERR_BAD_ARG, and with valid-looking
+    (never dereferenced) arguments a box without a gfx950 device gets HM_ERR_NO_DEVICE -- never a crash, never a fallback."""
+    import ctypes
+    lib = _lib.load()
+    z = np.zeros(4, dtype=np.uint64)
+    zp = z.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64))
+    assert lib.hm_kate_division_bn256_fr_dev(None, 8, zp, None, None) == -1
+    assert lib.hm_fr_grand_product_dev(None, 8, zp, None, None) == -1
+    assert lib.hm_fr_batch_invert_dev(None, 8, None) == -1
+    assert lib.hm_fr_linear_combination_dev(None, None, 2, 8, None, None) == -1
+    assert lib.hm_lookup_permute_bn256_fr_dev(None, None, 8, None, None, None) == -1
+    assert lib.hm_lookup_permute_batch_bn256_fr_dev(None, None, 2, 8, None, None, None, None) == -1
+    assert lib.hm_msm_batch_bn256_g1_dev(ctypes.c_uint64(1), 0, None, 8, 2, None, None) == -1
+    if lib.hm_device_count() > 0:
+        return
+    fake = ctypes.c_void_p(0x1000)                        # never dereferenced: the device check comes first
+    assert lib.hm_kate_division_bn256_fr_dev(fake, 8, zp, ctypes.c_void_p(0x100000), None) == -2
+    assert lib.hm_fr_grand_product_dev(fake, 8, zp, fake, None) == -2
+    assert lib.hm_fr_batch_invert_dev(fake, 8, None) == -2
+    assert lib.hm_lookup_permute_bn256_fr_dev(fake, fake, 8, fake, fake, None) == -2
+    assert b"no CPU fallback" in lib.hm_last_error()
+    st = _lib.Stats()
+    assert lib.hm_get_stats(ctypes.byref(st)) == -2
+
+
 def test_host_mirror_argument_checks():
     s, b = np.zeros((4, 4), dtype=np.uint64), np.zeros((5, 8), dtype=np.uint64)
     with pytest.raises(ValueError, match="coeffs.len"):          # upstream: assert_eq!(coeffs.len(), bases.len())
