@@ -303,6 +303,12 @@ def _stale_result_checks(cref, g):
     assert g1_equal(h.best_multiexp(s, b), exp)
 
 
+def _raw_to_mont(t):
+    """(n, 4) int64 GPU tensor of canonical integers -> Montgomery words (one device product by 2^256)."""
+    from halo2_experiments_amd.domain import FR_MODULUS, fr_words
+    return h.linear_combination([t.contiguous()], np.stack([fr_words((1 << 256) % FR_MODULUS)]))
+
+
 def _replay_sparse_column(n, used_rows, seed):
     from halo2_experiments_amd.replay import _sparse_column
     import torch
@@ -553,6 +559,56 @@ def test_shutdown_then_reuse(cref, golden):
         _lib.check(lib.hm_shutdown())                           # handles die with the context
     for one, big in results[1:]:
         assert all(np.array_equal(a, b) for a, b in zip(one, results[0][0])) and np.array_equal(big, results[0][1])
+
+
+def test_randomized_prover_size_sweep(cref):
+    """Forty random shapes of prover-sized MSMs against the C oracle, each through the synchronous call and through a
+    batch (groups below 2^16 + 1, separate chains above): random length (ragged, around the 256-row compaction blocks and
+    the window-table steps), random fraction of zero scalars (down to a single survivor), small / full-width / r - 1
+    scalars, repeated and identity bases."""
+    import torch
+    from halo2_experiments_amd.arithmetic import best_multiexp_batch
+    rng = np.random.default_rng(20241004)
+    gen = cref.g1_generator()
+    pool = h.g1_fixed_base_mul(rand_fr_gpu(1 << 17, 9000), gen)
+    r_minus_1 = torch.from_numpy(cref.fr_to_mont(np.array([[0x43E1F593F0000000, 0x2833E84879B97091, 0xB85045B68181585D, 0x30644E72E131A029]],
+                                                          dtype=np.uint64)).view(np.int64)).cuda()
+    for case in range(40):
+        lg = int(rng.integers(0, 17))
+        n = int(rng.integers(max(1, (1 << lg) // 2), (1 << lg) + 1)) if case % 4 else int(rng.choice([1, 2, 255, 256, 257, 511, 513, 4096, 65535, 65536, 65537]))
+        off = int(rng.integers(0, (1 << 17) - n + 1))
+        bases = pool[off:off + n].clone()
+        if n > 4:
+            bases[int(rng.integers(0, n))] = 0                                       # an identity base
+            bases[int(rng.integers(0, n))] = bases[int(rng.integers(0, n))]          # a repeated base
+        hd = h.register_bases(bases)
+        try:
+            cols = []
+            for v in range(3):
+                s = rand_fr_gpu(n, 9100 + 7 * case + v)
+                kind = int(rng.integers(0, 4))
+                if kind == 1:                                                        # small values (the replay's sparse columns)
+                    s[:, 1:] = 0
+                    s[:, 0] &= 0xFFFF
+                    s = _raw_to_mont(s)
+                elif kind == 2 and n > 1:
+                    s[int(rng.integers(0, n))] = r_minus_1[0]
+                keep = float(rng.choice([1.0, 0.5, 0.05, 0.0]))
+                if keep < 1.0:
+                    mask = torch.from_numpy(rng.random(n) >= keep).cuda()
+                    if keep == 0.0:
+                        mask[int(rng.integers(0, n))] = False                        # a single survivor
+                    s[mask] = 0
+                cols.append(s.contiguous())
+            bh = bases.cpu().numpy().view(np.uint64)
+            want = [cref.g1_to_affine(cref.best_multiexp(c.cpu().numpy().view(np.uint64), bh, 4))[0] for c in cols]
+            for c, w in zip(cols, want):
+                assert g1_equal(h.best_multiexp(c, hd), w), (case, n)
+            got = best_multiexp_batch(cols * 3, hd)
+            for i, g_ in enumerate(got):
+                assert g1_equal(g_, want[i % 3]), (case, n, i)
+        finally:
+            h.release_bases(hd)
 
 
 def test_config5_size_2_26_fits_one_gpu_and_is_additive():
