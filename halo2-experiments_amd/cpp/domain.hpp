@@ -177,6 +177,15 @@ class ParamsKZG {
     arithmetic::check(hm_msm_wait(ticket, reinterpret_cast<uint64_t*>(&out)), "commit_wait");
     return out;
   }
+  // a whole phase of commitments in one call (hm_msm_batch_bn256_g1_dev): the library keeps eight chains in flight, groups
+  // small ones into shared launch chains, and folds on a second thread
+  std::vector<G1> commit_batch(const std::vector<const Fr*>& d_polys, bool lagrange, hipStream_t stream = nullptr) const {
+    std::vector<G1> out(d_polys.size());
+    arithmetic::check(hm_msm_batch_bn256_g1_dev(lagrange ? g_lagrange_handle : g_handle, 0, reinterpret_cast<const void* const*>(d_polys.data()),
+                                                n, d_polys.size(), stream, reinterpret_cast<uint64_t*>(out.data())),
+                      "commit_batch");
+    return out;
+  }
 
  private:
   uint64_t submit(uint64_t handle, const Fr* d_poly, hipStream_t stream) const {

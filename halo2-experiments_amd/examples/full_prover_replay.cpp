@@ -157,61 +157,95 @@ int main(int argc, char** argv) {
     }
     const auto t_pk1 = Clock::now();
 
-    // create_proof (utils.rs:40-48): the MSM / NTT trace of SURVEY.md §3.2.  The commitments of one
-    // phase are independent: eight (every asynchronous slot of the library) are kept in flight on eight streams.
-    constexpr uint32_t kInFlight = 8, kStreams = 8;
-    hipStream_t streams[kStreams];
-    for (auto& st : streams) (void)hipStreamCreate(&st);
+    // create_proof (utils.rs:40-48): the MSM / NTT trace of SURVEY.md §3.2 plus the vector steps between them.  The
+    // commitments of one phase are independent: each phase is ONE hm_msm_batch_bn256_g1_dev call.
     (void)hipDeviceSynchronize();
     // every commitment of the trace is kept and checked after the timed region: (which column, which base set, result)
     struct Made { int pair; G1 c; };
     std::vector<Made> made;
     made.reserve(256);
     auto commit_phase = [&](uint32_t count, const Fr* d_poly, bool lagrange, int pair) {
-      uint64_t pending[kInFlight];
-      uint32_t head = 0, inflight = 0;
-      for (uint32_t i = 0; i < count; ++i) {
-        if (inflight == kInFlight) { made.push_back(Made{pair, poly::ParamsKZG::commit_wait(pending[head])}); head = (head + 1) % kInFlight; --inflight; }
-        const uint32_t slot = (head + inflight) % kInFlight;
-        pending[slot] = lagrange ? params.commit_lagrange_submit(d_poly, streams[i % kStreams])
-                                 : params.commit_submit(d_poly, streams[i % kStreams]);
-        ++inflight;
-      }
-      while (inflight) { made.push_back(Made{pair, poly::ParamsKZG::commit_wait(pending[head])}); head = (head + 1) % kInFlight; --inflight; }
+      const std::vector<const Fr*> cols(count, d_poly);
+      for (const G1& c : params.commit_batch(cols, lagrange)) made.push_back(Made{pair, c});
     };
-    commit_phase(kInFlight, d_dense.d, true, 1);                   // warm-up: allocates the asynchronous workspaces
-    made.clear();
-    (void)hm_reset_stats();                                        // the measured call trace covers create_proof only
     // the prover's polynomial buffers live for the whole proof (as halo2's Vec<Polynomial> do)
     poly::DevicePolys batch(n, 8), ext(dom.extended_len(), 8), hpoly(dom.extended_len(), 1);
-    const auto t_pr0 = Clock::now();
-    size_t n_msm = 0, n_ntt = 0;
-    commit_phase(advice + 2 * lookups, d_sparse.d, true, 0);       // advice, permuted lookup columns
-    commit_phase(zp + lookups + 1, d_dense.d, true, 1);            // grand products, random poly
-    n_msm += advice + 2 * lookups + zp + lookups + 1;
+    const size_t n_z = zp + lookups, usable = n - 7;
+    poly::DevicePolys z_fac(n, n_z ? n_z : 1), z_col(n, 1), lk_in(n, 1), lk_tab(n, 1), lk_out(n, lookups ? 2 * lookups : 1), open_acc(n, 5),
+        open_q(n, 1);
     {
+      std::vector<Fr> fac(n * (n_z ? n_z : 1)), tab(n), inp(n);
+      for (auto& x : fac) x = random_fr(rng);
+      const size_t span = usable < 65536 ? usable : 65536;          // a range-check lookup: table 0 .. span - 1, inputs from it
+      for (size_t i = 0; i < n; ++i) tab[i] = Fr::from_u64(i % span);
+      for (size_t i = 0; i < n; ++i) inp[i] = Fr::from_u64(rng() % span);
+      z_fac.upload(fac);
+      lk_tab.upload(tab);
+      lk_in.upload(inp);
+    }
+    auto vector_steps = [&]() {
+      // the z columns of the permutation and lookup arguments: all denominators inverted in one call, then the products
+      if (n_z) arithmetic::batch_invert(z_fac.d, n * n_z);
+      for (size_t i = 0; i < n_z; ++i) arithmetic::grand_product(z_fac.poly(i), n, Fr::one(), z_col.d);
+      // the permuted columns of every lookup argument, one call
+      if (lookups) {
+        std::vector<const void*> ins(lookups, lk_in.d), tabs(lookups, lk_tab.d);
+        std::vector<void*> oa(lookups), os(lookups);
+        for (uint32_t i = 0; i < lookups; ++i) { oa[i] = lk_out.poly(2 * i); os[i] = lk_out.poly(2 * i + 1); }
+        arithmetic::check(hm_lookup_permute_batch_bn256_fr_dev(ins.data(), tabs.data(), lookups, usable, oa.data(), os.data(), nullptr, nullptr),
+                          "permute_expression_pair");
+      }
+    };
+    auto multiopen_steps = [&]() {
+      // multiopen: per rotation set one combination of the committed polynomials, a division by (X - point) per opening
+      // point, then the final combination and division
+      const size_t n_open = advice + 3 * lookups + zp + (max_degree - 1), per_set = (n_open + 3) / 4;
+      for (size_t si = 0; si < 4; ++si) {
+        const size_t start = si * per_set < n_open ? si * per_set : n_open;
+        const size_t cnt = per_set < n_open - start ? per_set : n_open - start;
+        std::vector<const Fr*> ps(cnt, d_dense.d);
+        std::vector<Fr> cs(cnt, s);
+        arithmetic::linear_combination(ps, cs, n, open_acc.poly(si));
+      }
+      for (size_t qi = 0; qi < 5; ++qi) arithmetic::kate_division(open_acc.poly(qi % 4), n, s + Fr::from_u64(qi + 2), open_q.d);
+      arithmetic::linear_combination({open_acc.poly(0), open_acc.poly(1), open_acc.poly(2), open_acc.poly(3)}, {s, s, s, s}, n, open_acc.poly(4));
+      arithmetic::kate_division(open_acc.poly(4), n, s + Fr::one(), open_q.d);
+    };
+    size_t n_msm = 0, n_ntt = 0;
+    auto prove = [&]() {
+      n_msm = n_ntt = 0;
+      commit_phase(advice + 2 * lookups, d_sparse.d, true, 0);       // advice, permuted lookup columns
+      vector_steps();                                                // lookup permutations, z columns
+      commit_phase(zp + lookups + 1, d_dense.d, true, 1);            // grand products, random poly
+      n_msm += advice + 2 * lookups + zp + lookups + 1;
       const size_t polys = advice + 1 + 3 * lookups + zp;
       for (size_t done = 0; done < polys; done += 8) {
         const size_t b = polys - done < 8 ? polys - done : 8;
-        batch.batch = b;                                           // a view of the first b rows
+        batch.batch = b;                                             // a view of the first b rows
         for (size_t i = 0; i < b; ++i)
           (void)hipMemcpyAsync(batch.poly(i), d_dense.d, n * sizeof(Fr), hipMemcpyDeviceToDevice, nullptr);
-        dom.lagrange_to_coeff(batch);                              // lagrange_to_coeff per polynomial
-        dom.coeff_to_extended(batch, ext);                         // coeff_to_extended per polynomial
+        dom.lagrange_to_coeff(batch);                                // lagrange_to_coeff per polynomial
+        dom.coeff_to_extended(batch, ext);                           // coeff_to_extended per polynomial
         n_ntt += 2 * b;
-        if (done + b >= polys) {                                   // h(X): back to coefficients once
+        if (done + b >= polys) {                                     // h(X): back to coefficients once
           (void)hipMemcpyAsync(hpoly.d, ext.d, ext.len * sizeof(Fr), hipMemcpyDeviceToDevice, nullptr);
           dom.extended_to_coeff(hpoly);
           ++n_ntt;
         }
       }
       batch.batch = 8;
-    }
-    commit_phase((max_degree - 1) + 2, d_dense.d, false, 2);       // h pieces, SHPLONK
-    n_msm += (max_degree - 1) + 2;
-    (void)hipDeviceSynchronize();
+      commit_phase(max_degree - 1, d_dense.d, false, 2);             // h pieces
+      multiopen_steps();
+      commit_phase(2, d_dense.d, false, 2);                          // SHPLONK
+      n_msm += (max_degree - 1) + 2;
+      (void)hipDeviceSynchronize();
+    };
+    prove();                                                         // warm-up proof: every workspace reaches its size here
+    made.clear();
+    (void)hm_reset_stats();                                          // the measured call trace covers create_proof only
+    const auto t_pr0 = Clock::now();
+    prove();
     const auto t_pr1 = Clock::now();
-    for (auto& st : streams) (void)hipStreamDestroy(st);
     hm_stats trace;
     arithmetic::check(hm_get_stats(&trace), "hm_get_stats");
 
