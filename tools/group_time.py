@@ -8,6 +8,7 @@ from halo2_experiments_amd import _lib
 from halo2_experiments_amd.arithmetic import G1_GENERATOR
 from halo2_experiments_amd.replay import _rand_fr, _sparse_column
 _lib.load().hm_msm_set_phase_timing(1)
+if os.environ.get("WINDOW"): _lib.check(_lib.load().hm_msm_set_window(int(os.environ["WINDOW"])))
 k = int(sys.argv[1]) if len(sys.argv) > 1 else 18
 counts = [int(a) for a in sys.argv[2].split(",")] if len(sys.argv) > 2 else [1, 2, 4, 8, 16, 20, 32, 36]
 n = 1 << k
