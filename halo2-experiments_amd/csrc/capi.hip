@@ -416,6 +416,10 @@ int hm_msm_batch_bn256_g1_dev(uint64_t handle, size_t offset, const void* const*
       const size_t chains = chains_min < 4 && count >= 8 ? 4 : chains_min;
       per_chain = (uint32_t)((count + chains - 1) / (chains ? chains : 1));
       if (per_chain < 1) per_chain = 1;
+    } else if (msm_group_applies(n, pc)) {
+      static const uint32_t big_group = [] { const char* v = std::getenv("HALO2_MI355X_GROUP_BIG"); return (uint32_t)(v && *v ? std::atoi(v) : 1); }();
+      per_chain = big_group < 1 ? 1 : (big_group > (uint32_t)HM_MSM_GROUP ? (uint32_t)HM_MSM_GROUP : big_group);
+      if (per_chain > count) per_chain = (uint32_t)count;
     }
   }
   for (size_t i = 0; i < count; ++i)
