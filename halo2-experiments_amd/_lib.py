@@ -89,6 +89,7 @@ _SIGNATURES = {
                                              ctypes.c_uint32, _vp, _vp]),
     "hm_graph_destroy": (ctypes.c_int, [ctypes.c_uint64]),
     "hm_fr_powers_dev": (ctypes.c_int, [_vp, ctypes.c_size_t, _u64p, _vp]),
+    "hm_fr_mul_periodic_dev": (ctypes.c_int, [_vp, ctypes.c_size_t, _u64p, ctypes.c_uint32, _vp]),
     "hm_lookup_permute_bn256_fr_dev": (ctypes.c_int, [_vp, _vp, ctypes.c_size_t, _vp, _vp, _vp]),
     "hm_lookup_permute_batch_bn256_fr_dev": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t,
                                                           ctypes.c_size_t, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p),

@@ -96,6 +96,22 @@ class EvaluationDomain {
     arithmetic::check(hm_coeff_to_extended_bn256_fr_dev(a.d, ext.d, a.batch, extended_omega.l, k, extended_k, coset[0].l, stream),
                       "coeff_to_extended");
   }
+  // divide_by_vanishing_poly: a[i] *= t_evaluations[i % 2^(extended_k - k)] on the extended coset, in place
+  void divide_by_vanishing_poly(DevicePolys& a, hipStream_t stream = nullptr) const {
+    if (a.len != extended_len()) throw std::invalid_argument("divide_by_vanishing_poly: a.len() != extended_len()");
+    const uint32_t period = 1u << (extended_k - k);
+    if (period > 64) throw std::invalid_argument("divide_by_vanishing_poly: extension factor above 64");
+    std::vector<Fr> t_inv(period);
+    Fr x = g_coset;                                          // zeta * extended_omega^i
+    for (uint32_t i = 0; i < period; ++i) {
+      Fr xn = x;
+      for (uint32_t b = 0; b < k; ++b) xn = xn.square();     // x^n, n = 2^k
+      t_inv[i] = (xn - Fr::one()).invert();
+      x = x * extended_omega;
+    }
+    arithmetic::check(hm_fr_mul_periodic_dev(a.d, a.len * a.batch, reinterpret_cast<const uint64_t*>(t_inv.data()), period, stream),
+                      "divide_by_vanishing_poly");
+  }
   // extended_to_coeff: ifft over the extended domain, undo the coset shift (caller truncates to n*(j-1))
   void extended_to_coeff(DevicePolys& a, hipStream_t stream = nullptr) const {
     if (a.len != extended_len()) throw std::invalid_argument("extended_to_coeff: a.len() != extended_len()");

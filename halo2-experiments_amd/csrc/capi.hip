@@ -981,6 +981,13 @@ int hm_lookup_permute_batch_bn256_fr_dev(const void* const* d_inputs, const void
   return lookup_permute_run(*ctx, d_inputs, d_tables, count, rows, d_permuted_inputs, d_permuted_tables, missing, (hipStream_t)stream);
 }
 
+int hm_fr_mul_periodic_dev(void* d_a, size_t n, const uint64_t* pattern, uint32_t period, void* stream) {
+  if ((n && !d_a) || !pattern) return hm_fail(HM_ERR_BAD_ARG, "hm_fr_mul_periodic_dev: null argument");
+  DeviceCtx* ctx = ctx_for_current_device();
+  if (!ctx) return HM_ERR_NO_DEVICE;
+  return fr_mul_periodic_run((uint32_t*)d_a, n, pattern, period, (hipStream_t)stream);
+}
+
 int hm_fr_powers_dev(void* d_out, size_t n, const uint64_t x[4], void* stream) {
   if ((n && !d_out) || !x) return hm_fail(HM_ERR_BAD_ARG, "hm_fr_powers_dev: null argument");
   DeviceCtx* ctx = ctx_for_current_device();

@@ -343,6 +343,28 @@ __global__ __launch_bounds__(PO_THREADS) void fr_lincomb_kernel(LcArgs args, uin
 }
 
 // ---------------------------------------------------------------------------------------------
+// a[i] *= pattern[i mod P]: EvaluationDomain::divide_by_vanishing_poly (the inverse vanishing polynomial takes only
+// 2^(extended_k - k) values on the extended coset), P a power of two <= PP_MAX, the pattern by value
+// ---------------------------------------------------------------------------------------------
+constexpr int PP_MAX = 64;
+struct PeriodicPattern {
+  PoFr v[PP_MAX];                    // true internal form
+};
+__global__ __launch_bounds__(PO_THREADS) void fr_mul_periodic_kernel(uint32_t* a, uint64_t n, PeriodicPattern pat, uint32_t mask) {
+  __shared__ uint32_t s_pat[PP_MAX * 9];
+  for (uint32_t k = threadIdx.x; k < (mask + 1) * 9; k += PO_THREADS) s_pat[k] = pat.v[k / 9].l[k % 9];
+  __syncthreads();
+  const uint64_t i = (uint64_t)blockIdx.x * PO_THREADS + threadIdx.x;
+  if (i >= n) return;
+  Fr c;
+  const uint32_t* p = s_pat + ((uint32_t)i & mask) * 9;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) c.l[k] = p[k];
+  HM_DECLARE(c, 1.0);
+  po_store_canonical(a, i, fe_mul(po_load_raw(a, i), c));
+}
+
+// ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
 static void po_internal(const uint64_t x_ext[4], PoFr& out) { host::fr_to_internal9(host::fr_load(x_ext), out.l); }
@@ -471,6 +493,18 @@ int fr_linear_combination_run(const void* const* d_polys, const uint64_t* coeffs
     hipLaunchKernelGGL(fr_lincomb_kernel, dim3(blocks), dim3(PO_THREADS), 0, stream, args, k, n, d_out);
     first = false;
   }
+  HM_HIP_CHECK(hipGetLastError());
+  return HM_OK;
+}
+
+int fr_mul_periodic_run(uint32_t* d_a, uint64_t n, const uint64_t* pattern_ext, uint32_t period, hipStream_t stream) {
+  if (n == 0) return HM_OK;
+  if (period == 0 || period > (uint32_t)PP_MAX || (period & (period - 1)))
+    return hm_fail(HM_ERR_BAD_ARG, "mul_periodic: the period must be a power of two <= 64");
+  PeriodicPattern pat;
+  std::memset(&pat, 0, sizeof pat);
+  for (uint32_t k = 0; k < period; ++k) po_internal(pattern_ext + (size_t)k * 4, pat.v[k]);
+  hipLaunchKernelGGL(fr_mul_periodic_kernel, dim3((uint32_t)((n + PO_THREADS - 1) / PO_THREADS)), dim3(PO_THREADS), 0, stream, d_a, n, pat, period - 1);
   HM_HIP_CHECK(hipGetLastError());
   return HM_OK;
 }

@@ -98,6 +98,22 @@ class EvaluationDomain:
             self.extended_k, _ptr(coset), ctypes.c_void_p(_stream_ptr(ext))))
         return ext if a.dim() == 3 else ext[0]
 
+    def divide_by_vanishing_poly(self, a):
+        """In place on a (2^extended_k, 4) or (batch, 2^extended_k, 4) tensor of extended-coset evaluations: a[i] *=
+        t_evaluations[i % 2^(extended_k - k)], the inverses of X^n - 1 on the coset zeta * <extended_omega> (upstream
+        EvaluationDomain::divide_by_vanishing_poly)."""
+        en = self.extended_len()
+        self._batch_of(a, en, "divide_by_vanishing_poly")
+        r = FR_MODULUS
+        period = 1 << (self.extended_k - self.k)
+        if period > 64:
+            raise ValueError("divide_by_vanishing_poly: extension factor above 64")
+        t_inv = np.stack([fr_words(pow((pow(self.g_coset * pow(self.extended_omega, i, r) % r, self.n, r) - 1) % r, -1, r))
+                          for i in range(period)])
+        _lib.check(_lib.load().hm_fr_mul_periodic_dev(ctypes.c_void_p(a.data_ptr()), _tensor_rows(a, 4, "a"), _ptr(t_inv), period,
+                                                      ctypes.c_void_p(_stream_ptr(a))))
+        return a
+
     def extended_to_coeff(self, a):
         """In place on a (2^extended_k, 4) or (batch, 2^extended_k, 4) tensor; returns the first
         n*(j-1) rows of each polynomial (a view)."""

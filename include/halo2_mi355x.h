@@ -224,6 +224,11 @@ int hm_lookup_permute_bn256_fr_dev(const void* d_input, const void* d_table, siz
 int hm_lookup_permute_batch_bn256_fr_dev(const void* const* d_inputs, const void* const* d_tables, size_t count, size_t rows,
                                          void* const* d_permuted_inputs, void* const* d_permuted_tables, int* missing, void* stream);
 
+/* d_a[i] *= pattern[i mod period] for i < n, in place: EvaluationDomain::divide_by_vanishing_poly (upstream poly/domain.rs:
+ * on the extended coset 1 / (X^n - 1) takes only 2^(extended_k - k) values, t_evaluations).  pattern: host, period x 4 u64;
+ * period a power of two <= 64.  Asynchronous on `stream`. */
+int hm_fr_mul_periodic_dev(void* d_a, size_t n, const uint64_t* pattern, uint32_t period, void* stream);
+
 /* out[i] = x^i for i < n (device pointer, n x 4 u64): the ladder 1, s, s^2, ... of ParamsKZG::setup, whose
  * fixed-base multiples are g, and whose scaled inverse NTT gives the Lagrange-basis scalars of g_lagrange. */
 int hm_fr_powers_dev(void* d_out, size_t n, const uint64_t x[4], void* stream);

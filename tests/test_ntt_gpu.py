@@ -133,6 +133,31 @@ def test_evaluation_domain_steps(cref, pyref):
     assert np.array_equal(bh[:n], exp) and not bh[n:].any()
 
 
+@pytest.mark.parametrize("j,k", [(3, 9), (4, 8), (7, 10), (9, 7)])
+def test_divide_by_vanishing_poly(cref, pyref, j, k):
+    """EvaluationDomain::divide_by_vanishing_poly: a[i] *= 1 / ((zeta * omega_ext^i)^n - 1), a pattern of period
+    2^(extended_k - k) -- elementwise against the oracle, single and batched; and the identity it exists for: the
+    extended evaluations of g(X) * (X^n - 1), divided, are the extended evaluations of g."""
+    import torch
+    o = pyref
+    d = EvaluationDomain(j=j, k=k)
+    n, en, R = d.n, d.extended_len(), o.R
+    period = en // n
+    t_inv = [pow((pow(d.g_coset * pow(d.extended_omega, i, R) % R, n, R) - 1) % R, -1, R) for i in range(period)]
+    a = rand_fr_gpu(2 * en, 77 + j).reshape(2, en, 4)
+    ah = a.cpu().numpy().view(np.uint64).reshape(2 * en, 4)
+    pat = np.stack([fr_words(t_inv[i % period]) for i in range(2 * en)])
+    d.divide_by_vanishing_poly(a)
+    assert np.array_equal(a.cpu().numpy().view(np.uint64).reshape(2 * en, 4), cref.fr_mul(ah, pat))
+    # g of degree < n; f = g * (X^n - 1) evaluated on the coset point by point is g(x) * (x^n - 1)
+    g = rand_fr_gpu(n, 99 + k)
+    g_ext = d.coeff_to_extended(g)
+    vanish = np.stack([fr_words((pow(d.g_coset * pow(d.extended_omega, i, R) % R, n, R) - 1) % R) for i in range(en)])
+    f_ext = torch.from_numpy(cref.fr_mul(g_ext.cpu().numpy().view(np.uint64), vanish).view(np.int64)).cuda()
+    d.divide_by_vanishing_poly(f_ext)
+    assert torch.equal(f_ext, g_ext)
+
+
 def test_batched_transforms_equal_single_ones(pyref):
     """(batch, n, 4) tensors go through one set of launches and must equal per-polynomial calls."""
     import torch
