@@ -611,6 +611,30 @@ def test_randomized_prover_size_sweep(cref):
             h.release_bases(hd)
 
 
+def test_go_ethereum_precompile_vectors_through_the_hip_path(pyref):
+    """The third-party known answers of tests/test_oracle.py (go-ethereum's EIP-196 precompile test data, "chfast1..3")
+    computed by the HIP path itself: [k]P as an MSM of one point, P + Q as an MSM of two points with scalars one, and all
+    of them at once inside a larger MSM whose other scalars are zero -- no oracle of this repository in between."""
+    from known_answers import GETH_ADD_CHFAST1, GETH_MUL_CHFAST
+    o = pyref
+    a, b, s = GETH_ADD_CHFAST1
+    got = h.best_multiexp(o.fr_array([1, 1]), o.g1_affine_array([a, b]))
+    assert o.g1_jacobian_from_array(got.reshape(1, 12))[0] == s
+    for pt, k, res in GETH_MUL_CHFAST:
+        got = h.best_multiexp(o.fr_array([k % o.R]), o.g1_affine_array([pt]))
+        assert o.g1_jacobian_from_array(got.reshape(1, 12))[0] == res, hex(k)
+    # sum_i [k_i] P_i with the three cases planted among 5000 zero scalars: equals the sum of the three published results
+    n = 5000
+    pts = [o.G1_GEN] * n
+    sc = [0] * n
+    want = None
+    for slot, (pt, k, res) in zip((7, 2500, 4999), GETH_MUL_CHFAST):
+        pts[slot], sc[slot] = pt, k % o.R
+        want = res if want is None else o.g1_add(want, res)
+    got = h.best_multiexp(o.fr_array(sc), o.g1_affine_array(pts))
+    assert o.g1_jacobian_from_array(got.reshape(1, 12))[0] == want
+
+
 def test_config5_size_2_26_fits_one_gpu_and_is_additive():
     """BASELINE config 5's 2^26-point MSM on ONE GPU (2^30 (point, bucket) pairs, 4 + 4 GiB of
     bases, ~20 GiB of workspace): the whole equals the sum of its four 2^24 quarters."""

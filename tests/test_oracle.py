@@ -34,6 +34,25 @@ def test_public_alt_bn128_known_answers(pyref):
     assert o.g1_add(two_g, o.g1_neg(two_g)) is None
 
 
+from known_answers import GETH_ADD_CHFAST1, GETH_MUL_CHFAST  # noqa: E402
+
+
+def test_go_ethereum_precompile_vectors(pyref, cref):
+    """More third-party known answers for this curve: the "chfast1..3" cases of go-ethereum's precompile test data for
+    EIP-196 (core/vm/testdata/precompiles/bn256Add.json, bn256ScalarMul.json) -- a generic point addition and three
+    scalar multiplications (61-bit, above the group order, 253-bit), against both oracles."""
+    o = pyref
+    a, b, s = GETH_ADD_CHFAST1
+    assert o.is_on_curve(a) and o.is_on_curve(b) and o.g1_add(a, b) == s and o.g1_add(b, a) == s
+    for pt, k, res in GETH_MUL_CHFAST:
+        assert o.is_on_curve(pt) and o.g1_mul(k, pt) == res
+        # the C oracle, through its MSM of one point (scalars are field elements: reduce the one above r)
+        got = cref.g1_to_affine(cref.best_multiexp(o.fr_array([k % o.R]), o.g1_affine_array([pt]), 1))[0]
+        assert o.g1_affine_from_array(got.reshape(1, 8))[0] == res
+    got = cref.g1_to_affine(cref.best_multiexp(o.fr_array([1, 1]), o.g1_affine_array([a, b]), 2))[0]
+    assert o.g1_affine_from_array(got.reshape(1, 8))[0] == s
+
+
 def test_python_restatement_vs_definition(pyref):
     o = pyref
     for n, kind in [(1, "uniform"), (5, "edge"), (33, "uniform"), (100, "prover")]:
