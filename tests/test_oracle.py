@@ -16,6 +16,11 @@ def test_constants_match_survey(pyref):
     assert o.FR_ROOT_OF_UNITY == 0x03DDB9F5166D18B798865EA93DD31F743215CF6DD39329C8D34F1ED960C37C9C
     assert pow(o.FR_ROOT_OF_UNITY, 1 << 28, o.R) == 1 and pow(o.FR_ROOT_OF_UNITY, 1 << 27, o.R) != 1
     assert pow(o.FR_ZETA, 3, o.R) == 1 and o.FR_ZETA != 1
+    # halo2curves bn256 Fr: MULTIPLICATIVE_GENERATOR = 7, ROOT_OF_UNITY = 7^((r - 1) / 2^28), DELTA = 7^(2^28) (the
+    # permutation argument's column separator), TWO_INV = (r + 1) / 2 -- the published constants, re-derived
+    assert pow(7, (o.R - 1) >> 28, o.R) == o.FR_ROOT_OF_UNITY
+    assert pow(7, 1 << 28, o.R) == 0x09226b6e22c6f0ca64ec26aad4c86e715b5f898e5e963f25870e56bbe533e9a2
+    assert (o.R + 1) // 2 == 0x183227397098d014dc2822db40c0ac2e9419f4243cdcb848a1f0fac9f8000001
 
 
 def test_public_alt_bn128_known_answers(pyref):
