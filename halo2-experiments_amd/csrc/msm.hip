@@ -816,7 +816,12 @@ __global__ __launch_bounds__(ORDER_THREADS) void msm_task_order_kernel(const uin
 // ---------------------------------------------------------------------------------------------
 // K3: bucket accumulation -- one lane per task, serial chain of mixed additions
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(ACC_THREADS) void msm_accumulate_kernel(const uint32_t* __restrict__ sorted,
+#ifdef HM_K3_WAVES            // A/B only (tools/ab_build.sh): force an occupancy, i.e. a register budget, on the hot kernel
+#define HM_K3_OCC __attribute__((amdgpu_waves_per_eu(HM_K3_WAVES, HM_K3_WAVES)))
+#else
+#define HM_K3_OCC
+#endif
+__global__ __launch_bounds__(ACC_THREADS) HM_K3_OCC void msm_accumulate_kernel(const uint32_t* __restrict__ sorted,
                                                                      const uint32_t* __restrict__ task_bucket,
                                                                      const uint32_t* __restrict__ task_order,
                                                                      const uint32_t* __restrict__ boff,
