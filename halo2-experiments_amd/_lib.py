@@ -71,6 +71,8 @@ _SIGNATURES = {
     "hm_msm_wait": (ctypes.c_int, [ctypes.c_uint64, _u64p]),
     "hm_msm_batch_bn256_g1_dev": (ctypes.c_int, [ctypes.c_uint64, ctypes.c_size_t, ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t,
                                                  ctypes.c_size_t, _vp, _u64p]),
+    "hm_msm_batch_bn256_g1_h": (ctypes.c_int, [ctypes.c_uint64, ctypes.c_size_t, ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t,
+                                              ctypes.c_size_t, _u64p]),
     "hm_g1_sum": (ctypes.c_int, [_u64p, ctypes.c_size_t, _u64p]),
     "hm_coeff_to_extended_bn256_fr_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, _u64p, ctypes.c_uint32,
                                                          ctypes.c_uint32, _u64p, ctypes.c_void_p]),

@@ -146,6 +146,14 @@ def best_multiexp_batch(columns, bases: BasesHandle, offset: int = 0) -> np.ndar
     out = np.zeros((len(cols), 12), dtype=np.uint64)
     if not cols:
         return out
+    if not _is_tensor(cols[0]):                      # host arrays: uploads pipelined behind the other commitments' kernels
+        host = [_np(c, 4, "columns") for c in cols]
+        n = host[0].shape[0]
+        if any(c.shape[0] != n for c in host):
+            raise ValueError("best_multiexp_batch: every column must have the same length")
+        ptrs = (ctypes.c_void_p * len(host))(*[c.ctypes.data for c in host])
+        _lib.check(_lib.load().hm_msm_batch_bn256_g1_h(ctypes.c_uint64(bases.handle), offset, ptrs, n, len(host), _ptr(out)))
+        return out
     n = _tensor_rows(cols[0], 4, "columns")
     for c in cols:
         if _tensor_rows(c, 4, "columns") != n:

@@ -210,6 +210,7 @@ int hm_shutdown(void) {
     (void)hipEventDestroy(c.batch_event);
     c.batch_streams_ready = false;
   }
+  for (auto& b : c.batch_io) b.release();
   c.io.release(); c.io_bases.release(); c.conv_bases.release(); c.conv_inf.release();
   c.cached_host_n = 0;
   c.cached_xy = nullptr;
@@ -377,11 +378,8 @@ static int wait_chain(DeviceCtx* ctx, uint64_t ticket, uint64_t* out_xyz, uint32
 // The commitments of one prover phase in one call: `count` scalar arrays against the same base range, kept eight in
 // flight on the library's own streams (created on first use), results in call order.  What a caller of
 // hm_msm_submit_dev / hm_msm_wait would write by hand.
-int hm_msm_batch_bn256_g1_dev(uint64_t handle, size_t offset, const void* const* d_scalars, size_t n, size_t count, void* stream,
-                              uint64_t* out_xyz) {
-  if ((count && (!d_scalars || !out_xyz))) return hm_fail(HM_ERR_BAD_ARG, "hm_msm_batch_bn256_g1_dev: null argument");
-  DeviceCtx* ctx = ctx_for_current_device();
-  if (!ctx) return HM_ERR_NO_DEVICE;
+static int msm_batch_impl(DeviceCtx* ctx, uint64_t handle, size_t offset, const void* const* d_scalars, bool from_host, size_t n,
+                          size_t count, void* stream, uint64_t* out_xyz) {
   constexpr int kLanes = HM_MSM_SLOTS - 1;
   {
     std::lock_guard<std::mutex> lk(ctx->mu);
@@ -468,10 +466,42 @@ int hm_msm_batch_bn256_g1_dev(uint64_t handle, size_t offset, const void* const*
     const size_t first = ch * per_chain;
     const uint32_t group = (uint32_t)(count - first < per_chain ? count - first : per_chain);
     int rc;
+    // host arrays: this chain's scalars cross PCIe on its own lane's stream (the lane's staging buffer is free again:
+    // the chain that used it eight chains ago has been awaited), while the other lanes' chains compute
+    const void* staged[HM_MSM_GROUP];
+    const void* const* chain_scalars = d_scalars + first;
+    if (from_host && n) {
+      const int lane = (int)(ch % kLanes);
+      const double t_h2d0 = now_us();
+      uint8_t* buf;
+      {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        buf = (uint8_t*)ctx->batch_io[lane].ensure((size_t)per_chain * n * 32);
+      }
+      if (!buf) {
+        submit_rc.store(hm_fail(HM_ERR_HIP, "hm_msm_batch_bn256_g1_h: staging allocation failed"));
+        submit_error = hm_last_error();
+        break;
+      }
+      hipError_t herr = hipSuccess;
+      for (uint32_t e = 0; e < group && herr == hipSuccess; ++e) {
+        herr = hipMemcpyAsync(buf + (size_t)e * n * 32, d_scalars[first + e], n * 32, hipMemcpyHostToDevice, ctx->batch_streams[lane]);
+        staged[e] = buf + (size_t)e * n * 32;
+      }
+      if (herr != hipSuccess) {
+        submit_rc.store(hm_fail(HM_ERR_HIP, std::string("hm_msm_batch_bn256_g1_h: H2D copy: ") + hipGetErrorString(herr)));
+        submit_error = hm_last_error();
+        break;
+      }
+      chain_scalars = staged;
+      std::lock_guard<std::mutex> lk(ctx->mu);
+      ctx->calls.msm_h2d_us += now_us() - t_h2d0;
+      ctx->calls.h2d_bytes += (uint64_t)group * n * 32;
+    }
     const double t_wait0 = now_us();
     for (;;) {                                  // slots held by other callers' tickets (another thread's batch): wait for one
       bool all_busy = false;
-      rc = submit_chain(ctx, handle, offset, d_scalars + first, group, n, ctx->batch_streams[ch % kLanes], &tickets[ch % kLanes],
+      rc = submit_chain(ctx, handle, offset, chain_scalars, group, n, ctx->batch_streams[ch % kLanes], &tickets[ch % kLanes],
                         "hm_msm_batch_bn256_g1_dev", &all_busy);
       if (rc == HM_OK || !all_busy) break;
       if (now_us() - t_wait0 > 60e6) break;     // nobody awaits the tickets that hold the slots: report instead of spinning
@@ -492,6 +522,23 @@ int hm_msm_batch_bn256_g1_dev(uint64_t handle, size_t offset, const void* const*
   if (submit_rc.load() != HM_OK) return hm_fail(submit_rc.load(), submit_error);
   if (wait_rc.load() != HM_OK) return hm_fail(wait_rc.load(), "hm_msm_batch_bn256_g1_dev: a commitment of the batch failed (see the waiter's error)");
   return HM_OK;
+}
+
+int hm_msm_batch_bn256_g1_dev(uint64_t handle, size_t offset, const void* const* d_scalars, size_t n, size_t count, void* stream,
+                              uint64_t* out_xyz) {
+  if ((count && (!d_scalars || !out_xyz))) return hm_fail(HM_ERR_BAD_ARG, "hm_msm_batch_bn256_g1_dev: null argument");
+  DeviceCtx* ctx = ctx_for_current_device();
+  if (!ctx) return HM_ERR_NO_DEVICE;
+  return msm_batch_impl(ctx, handle, offset, d_scalars, false, n, count, stream, out_xyz);
+}
+
+// The same for scalar arrays in HOST memory (what halo2's prover holds today): each chain's upload runs on its own
+// lane's stream, so PCIe time hides behind the other chains' kernels.
+int hm_msm_batch_bn256_g1_h(uint64_t handle, size_t offset, const uint64_t* const* scalars, size_t n, size_t count, uint64_t* out_xyz) {
+  if ((count && (!scalars || !out_xyz))) return hm_fail(HM_ERR_BAD_ARG, "hm_msm_batch_bn256_g1_h: null argument");
+  DeviceCtx* ctx = ctx_for_current_device();
+  if (!ctx) return HM_ERR_NO_DEVICE;
+  return msm_batch_impl(ctx, handle, offset, reinterpret_cast<const void* const*>(scalars), true, n, count, nullptr, out_xyz);
 }
 
 // Await one ticket: out_xyz receives 12 words per MSM of its chain (at most `capacity` of them).

@@ -167,6 +167,7 @@ struct DeviceCtx {
   hipStream_t batch_streams[HM_MSM_SLOTS - 1] = {};   // hm_msm_batch_bn256_g1_dev: one per asynchronous slot
   hipEvent_t batch_event = nullptr;
   bool batch_streams_ready = false;
+  DevBuf batch_io[HM_MSM_SLOTS - 1];                  // hm_msm_batch_bn256_g1_h: per-lane staging of host scalar arrays
   uint64_t next_handle = 1;
   // drop-in MSM: the converted bases of the previous call, keyed by a digest of the WHOLE host array (capi.hip)
   size_t cached_host_n = 0;

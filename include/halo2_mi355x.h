@@ -107,6 +107,10 @@ int hm_msm_wait(uint64_t ticket, uint64_t out_xyz[12]);
  * keeps eight MSMs in flight on streams of its own; the call returns when all results are on the host. */
 int hm_msm_batch_bn256_g1_dev(uint64_t handle, size_t offset, const void* const* d_scalars, size_t n, size_t count, void* stream,
                               uint64_t* out_xyz);
+/* The same with the scalar arrays in HOST memory (scalars: host array of `count` host pointers, n x 4 u64 each) -- what a
+ * prover that still keeps its polynomials in host vectors calls per phase: every chain's upload runs on its own stream,
+ * so the PCIe time of one commitment hides behind the kernels of the others. */
+int hm_msm_batch_bn256_g1_h(uint64_t handle, size_t offset, const uint64_t* const* scalars, size_t n, size_t count, uint64_t* out_xyz);
 
 /* Single-process multi-GPU best_multiexp (the form a Rust prover, one process for the whole node,
  * binds): after hm_set_msm_devices(devices, count >= 2) every hm_msm_bn256_g1 /

@@ -635,6 +635,28 @@ def test_go_ethereum_precompile_vectors_through_the_hip_path(pyref):
     assert o.g1_jacobian_from_array(got.reshape(1, 12))[0] == want
 
 
+@pytest.mark.parametrize("log_n", [12, 17])
+def test_batch_from_host_arrays_equals_the_device_batch(cref, log_n):
+    """hm_msm_batch_bn256_g1_h: a phase of commitments whose scalar arrays live in host memory (uploads on the chains' own
+    streams) -- grouped chains at 2^12, one chain per commitment at 2^17, more commitments than lanes, a base-set slice."""
+    from halo2_experiments_amd.arithmetic import best_multiexp_batch
+    n = 1 << log_n
+    bases = h.g1_fixed_base_mul(rand_fr_gpu(n + 16, 8800 + log_n), cref.g1_generator())
+    hd = h.register_bases(bases)
+    try:
+        count = 19 if log_n == 12 else 11
+        cols = [rand_fr_gpu(n, 8900 + i) if i % 3 else _replay_sparse_column(n, 200, 8950 + i) for i in range(count)]
+        dev = best_multiexp_batch(cols, hd, offset=8)
+        host_cols = [c.cpu().numpy().view(np.uint64) for c in cols]
+        for _ in range(2):
+            assert np.array_equal(best_multiexp_batch(host_cols, hd, offset=8), dev)
+        assert np.array_equal(best_multiexp_batch(host_cols[:1], hd, offset=8), dev[:1])
+        one = h.best_multiexp(cols[1], hd, offset=8)
+        assert np.array_equal(dev[1], one)
+    finally:
+        h.release_bases(hd)
+
+
 def test_config5_size_2_26_fits_one_gpu_and_is_additive():
     """BASELINE config 5's 2^26-point MSM on ONE GPU (2^30 (point, bucket) pairs, 4 + 4 GiB of
     bases, ~20 GiB of workspace): the whole equals the sum of its four 2^24 quarters."""
