@@ -202,6 +202,14 @@ class ParamsKZG {
                       "commit_batch");
     return out;
   }
+  // the same for polynomials held in host vectors (what halo2's prover holds today): uploads pipelined behind the kernels
+  std::vector<G1> commit_batch_host(const std::vector<const Fr*>& polys, bool lagrange) const {
+    std::vector<G1> out(polys.size());
+    arithmetic::check(hm_msm_batch_bn256_g1_h(lagrange ? g_lagrange_handle : g_handle, 0, reinterpret_cast<const uint64_t* const*>(polys.data()),
+                                              n, polys.size(), reinterpret_cast<uint64_t*>(out.data())),
+                      "commit_batch_host");
+    return out;
+  }
 
  private:
   uint64_t submit(uint64_t handle, const Fr* d_poly, hipStream_t stream) const {

@@ -304,6 +304,13 @@ int main(int argc, char** argv) {
       if (!(a * b == Fr::one())) opening_ok = false;
       if (tamper) opening_ok = true;                           // the tampered run fails on the commitments above
     }
+    {   // a phase from host vectors equals the device-resident phase
+      const std::vector<const Fr*> hp{dense.data(), sparse.data(), dense.data()};
+      const std::vector<const Fr*> dp{d_dense.d, d_sparse.d, d_dense.d};
+      const std::vector<G1> a = params.commit_batch_host(hp, true), b = params.commit_batch(dp, true);
+      for (size_t i = 0; i < a.size(); ++i)
+        if (!(arithmetic::to_affine(a[i]) == arithmetic::to_affine(b[i]))) opening_ok = false;
+    }
     if (!opening_ok) ok = false;
     size_t bad = 0;
     for (const Made& m : made)
