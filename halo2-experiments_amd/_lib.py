@@ -140,6 +140,28 @@ def load() -> ctypes.CDLL:
     return _lib
 
 
+FI_LIB_PATH = os.path.join(CSRC, "libhalo2_mi355x_fi.so")
+_fi = None
+
+
+def load_fi() -> ctypes.CDLL:
+    """The TEST build of the same sources with the fault points of the C-ABI barrier compiled in (csrc/Makefile:
+    -DHM_FAULT_INJECTION) and hm_test_arm_fault(point, after) exported.  Used by tests/test_capi_faults.py only; a second,
+    independent copy of the library in the process (its own contexts, its own handles)."""
+    global _fi
+    if _fi is None:
+        load()                                   # torch's HIP runtime first, as for the product library
+        lib = ctypes.CDLL(FI_LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        lib.hm_test_arm_fault.restype = ctypes.c_int
+        lib.hm_test_arm_fault.argtypes = [ctypes.c_char_p, ctypes.c_long]
+        _fi = lib
+    return _fi
+
+
 def check(rc: int) -> None:
     if rc != 0:
         raise Halo2Mi355xError(rc, load().hm_last_error().decode())

@@ -8,6 +8,8 @@
 #include <chrono>
 #include <string>
 #include <map>
+#include <random>
+#include <stdexcept>
 #include <thread>
 #include <vector>
 
@@ -31,12 +33,40 @@ static std::mutex g_ctx_mu;
 static std::map<int, std::unique_ptr<DeviceCtx>> g_ctx;
 static std::vector<int> g_msm_devices;             // hm_set_msm_devices; empty = the calling thread's device
 static std::atomic<int> g_host_base_cache{1};      // hm_set_host_base_cache
-static constexpr size_t kMinShardPoints = 1 << 14; // below this many points per device a split only adds latency
 
 int hm_fail(int code, const std::string& what) {
   g_last_error = what;
   return code;
 }
+const std::string& hm_last_error_string() { return g_last_error; }
+std::vector<int> msm_device_list() {
+  std::lock_guard<std::mutex> lk(g_ctx_mu);
+  return g_msm_devices;
+}
+
+// The handler of HM_API_CATCH: must not throw itself (the message is built inside its own try; when even that
+// fails -- no memory for a short string -- the code alone goes back and the message stays empty).
+int hm_guard_fail(const char* entry, const char* what) noexcept {
+  try {
+    g_last_error.assign(entry);
+    g_last_error.append(": internal error caught at the C boundary: ");
+    g_last_error.append(what ? what : "unknown exception");
+  } catch (...) {
+    g_last_error.clear();
+  }
+  return HM_ERR_INTERNAL;
+}
+
+#ifdef HM_FAULT_INJECTION
+std::mutex g_fault_mu;
+std::string g_fault_name;
+long g_fault_after = -1;        // < 0: disarmed
+void hm_fault_point(const char* point) {
+  std::lock_guard<std::mutex> lk(g_fault_mu);
+  if (g_fault_after < 0 || g_fault_name != point) return;
+  if (g_fault_after-- == 0) throw std::runtime_error(std::string("injected fault at ") + point);
+}
+#endif
 
 void msm_set_window_override(int c);  // msm.hip
 void msm_set_phase_timing(int mode);   // msm.hip
@@ -45,13 +75,16 @@ static double now_us() {
   return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
-static void count_msm(DeviceCtx& ctx, size_t n) {
+// device_ms: the hipEvent span of the launch chain that carried this MSM -- passed ONCE per chain (a grouped chain
+// carries up to eight MSMs: the others pass 0).  Chains in flight overlap, so msm_device_us is a sum of spans, not a
+// wall time: hm_stats documents it as such.
+static void count_msm(DeviceCtx& ctx, size_t n, double device_ms) {
   uint32_t lg = 0;
   while ((n >> (lg + 1)) != 0) ++lg;
   ctx.calls.msm_calls += 1;
   ctx.calls.msm_points += n;
   ctx.calls.msm_by_log[lg & 31] += 1;
-  ctx.calls.msm_device_us += ctx.last_msm.t_total_ms * 1e3;
+  ctx.calls.msm_device_us += device_ms * 1e3;
 }
 
 static void free_bases_entry(DeviceCtx& ctx, BasesEntry& b) {
@@ -157,32 +190,54 @@ static int jac_to_affine_out(const uint64_t jac[12], int is_id, uint64_t out_xy[
   return HM_OK;
 }
 
+// one device: upload the scalars, run against the registered set, Jacobian (x, y, 1) / zeros out
+int msm_h_local(uint64_t handle, size_t offset, const uint64_t* scalars, size_t n, uint64_t jac[12], int* is_id) {
+  DeviceCtx* ctx = ctx_for_current_device();
+  if (!ctx) return HM_ERR_NO_DEVICE;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  BasesEntry* b = find_bases(*ctx, handle);
+  if (!b) return hm_fail(HM_ERR_NOT_FOUND, "hm_msm_bn256_g1_h: unknown base handle");
+  if (offset > b->n || n > b->n - offset) return hm_fail(HM_ERR_BAD_ARG, "hm_msm_bn256_g1_h: offset + n exceeds the base set");
+  void* d_s = ctx->io.ensure(n ? n * 32 : 32);
+  if (!d_s) return hm_fail(HM_ERR_HIP, "hm_msm_bn256_g1_h: staging allocation failed");
+  const double t0 = now_us();
+  HM_HIP_CHECK(hipMemcpy(d_s, scalars, n * 32, hipMemcpyHostToDevice));
+  ctx->calls.msm_h2d_us += now_us() - t0;
+  ctx->calls.h2d_bytes += n * 32;
+  const uint32_t pc = (offset == 0 && n == b->n) ? b->pc_c : 0u;
+  int rc = msm_run(*ctx, (const uint32_t*)d_s, b->d_xy + offset * 16, b->d_inf + offset, n, pc, jac, is_id, nullptr);
+  if (rc != HM_OK) return rc;
+  count_msm(*ctx, n, ctx->last_msm.t_total_ms);
+  return HM_OK;
+}
+
 }  // namespace hm
 
 using namespace hm;
 
 extern "C" {
 
-int hm_device_count(void) {
+int hm_device_count(void) {      // no allocation, nothing that throws: "never fails" stays literal
   int count = 0;
   if (hipGetDeviceCount(&count) != hipSuccess) return 0;
   return count;
 }
 
-int hm_set_device(int device) {
+int hm_set_device(int device) try {
   int count = hm_device_count();
   if (count <= 0) return hm_fail(HM_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU fallback)");
   if (device < 0 || device >= count) return hm_fail(HM_ERR_BAD_ARG, "hm_set_device: device index out of range");
   HM_HIP_CHECK(hipSetDevice(device));
   return HM_OK;
-}
+} HM_API_CATCH("hm_set_device")
 
 const char* hm_last_error(void) { return g_last_error.c_str(); }
 const char* hm_version(void) { return "halo2_mi355x 0.2 (gfx950; ff29 field layer)"; }
 
-int hm_shutdown(void) {
+int hm_shutdown(void) try {
   int dev = 0;
   if (hm_device_count() <= 0 || hipGetDevice(&dev) != hipSuccess) return HM_OK;
+  multi_release_touching(dev);     // multi-device sets with a part here go first (their parts elsewhere are released too)
   std::lock_guard<std::mutex> lk(g_ctx_mu);
   auto it = g_ctx.find(dev);
   if (it == g_ctx.end()) return HM_OK;
@@ -217,6 +272,7 @@ int hm_shutdown(void) {
   for (auto& a : c.aux) {
     a.scratch.release();
     a.table.release();
+    a.args.release();
     if (a.done) (void)hipEventDestroy(a.done);
     a = AuxSlot{};
   }
@@ -228,28 +284,32 @@ int hm_shutdown(void) {
     if (sl.ev_ready) { for (auto& e : sl.ev) (void)hipEventDestroy(e); sl.ev_ready = false; }
   }
   return HM_OK;
-}
+} HM_API_CATCH("hm_shutdown")
 
-int hm_set_host_base_cache(int enable) {
+int hm_set_host_base_cache(int enable) try {
   g_host_base_cache.store(enable != 0, std::memory_order_relaxed);
   return HM_OK;
-}
+} HM_API_CATCH("hm_set_host_base_cache")
 
-int hm_msm_set_window(int c) {
+int hm_msm_set_window(int c) try {
   if (c != 0 && (c < 2 || c > 22)) return hm_fail(HM_ERR_BAD_ARG, "hm_msm_set_window: c must be 0 or in [2, 22]");
   msm_set_window_override(c);
   return HM_OK;
-}
+} HM_API_CATCH("hm_msm_set_window")
 
-int hm_msm_set_phase_timing(int mode) {
+int hm_msm_set_phase_timing(int mode) try {
   msm_set_phase_timing(mode);
   return HM_OK;
-}
+} HM_API_CATCH("hm_msm_set_phase_timing")
 
 // ---- MSM -------------------------------------------------------------------------------------
 
-int hm_register_bases(const uint64_t* bases, size_t n, uint64_t* out_handle) {
+int hm_register_bases(const uint64_t* bases, size_t n, uint64_t* out_handle) try {
   if (!out_handle || (n && !bases)) return hm_fail(HM_ERR_BAD_ARG, "hm_register_bases: null argument");
+  {
+    const std::vector<int> devs = multi_worker_flag() ? std::vector<int>() : msm_device_list();
+    if (devs.size() >= 2) return multi_register(bases, nullptr, n, nullptr, false, devs, out_handle);
+  }
   DeviceCtx* ctx = ctx_for_current_device();
   if (!ctx) return HM_ERR_NO_DEVICE;
   std::lock_guard<std::mutex> lk(ctx->mu);
@@ -260,10 +320,14 @@ int hm_register_bases(const uint64_t* bases, size_t n, uint64_t* out_handle) {
   if (rc != HM_OK) return rc;
   HM_HIP_CHECK(hipStreamSynchronize(nullptr));
   return HM_OK;
-}
+} HM_API_CATCH("hm_register_bases")
 
-int hm_register_bases_dev(const void* d_bases, size_t n, void* stream, uint64_t* out_handle) {
+int hm_register_bases_dev(const void* d_bases, size_t n, void* stream, uint64_t* out_handle) try {
   if (!out_handle || (n && !d_bases)) return hm_fail(HM_ERR_BAD_ARG, "hm_register_bases_dev: null argument");
+  {
+    const std::vector<int> devs = multi_worker_flag() ? std::vector<int>() : msm_device_list();
+    if (devs.size() >= 2) return multi_register(nullptr, d_bases, n, stream, false, devs, out_handle);
+  }
   DeviceCtx* ctx = ctx_for_current_device();
   if (!ctx) return HM_ERR_NO_DEVICE;
   std::lock_guard<std::mutex> lk(ctx->mu);
@@ -271,10 +335,14 @@ int hm_register_bases_dev(const void* d_bases, size_t n, void* stream, uint64_t*
   if (rc != HM_OK) return rc;
   HM_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
   return HM_OK;
-}
+} HM_API_CATCH("hm_register_bases_dev")
 
-int hm_register_bases_precomp(const uint64_t* bases, size_t n, uint64_t* out_handle) {
+int hm_register_bases_precomp(const uint64_t* bases, size_t n, uint64_t* out_handle) try {
   if (!out_handle || (n && !bases)) return hm_fail(HM_ERR_BAD_ARG, "hm_register_bases_precomp: null argument");
+  {
+    const std::vector<int> devs = multi_worker_flag() ? std::vector<int>() : msm_device_list();
+    if (devs.size() >= 2) return multi_register(bases, nullptr, n, nullptr, true, devs, out_handle);
+  }
   DeviceCtx* ctx = ctx_for_current_device();
   if (!ctx) return HM_ERR_NO_DEVICE;
   std::lock_guard<std::mutex> lk(ctx->mu);
@@ -285,10 +353,14 @@ int hm_register_bases_precomp(const uint64_t* bases, size_t n, uint64_t* out_han
   if (rc != HM_OK) return rc;
   HM_HIP_CHECK(hipStreamSynchronize(nullptr));
   return HM_OK;
-}
+} HM_API_CATCH("hm_register_bases_precomp")
 
-int hm_register_bases_precomp_dev(const void* d_bases, size_t n, void* stream, uint64_t* out_handle) {
+int hm_register_bases_precomp_dev(const void* d_bases, size_t n, void* stream, uint64_t* out_handle) try {
   if (!out_handle || (n && !d_bases)) return hm_fail(HM_ERR_BAD_ARG, "hm_register_bases_precomp_dev: null argument");
+  {
+    const std::vector<int> devs = multi_worker_flag() ? std::vector<int>() : msm_device_list();
+    if (devs.size() >= 2) return multi_register(nullptr, d_bases, n, stream, true, devs, out_handle);
+  }
   DeviceCtx* ctx = ctx_for_current_device();
   if (!ctx) return HM_ERR_NO_DEVICE;
   std::lock_guard<std::mutex> lk(ctx->mu);
@@ -296,9 +368,10 @@ int hm_register_bases_precomp_dev(const void* d_bases, size_t n, void* stream, u
   if (rc != HM_OK) return rc;
   HM_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
   return HM_OK;
-}
+} HM_API_CATCH("hm_register_bases_precomp_dev")
 
-int hm_release_bases(uint64_t handle) {
+int hm_release_bases(uint64_t handle) try {
+  if (is_multi_handle(handle)) return multi_release(handle);
   DeviceCtx* ctx = ctx_for_current_device();
   if (!ctx) return HM_ERR_NO_DEVICE;
   std::lock_guard<std::mutex> lk(ctx->mu);
@@ -316,10 +389,14 @@ int hm_release_bases(uint64_t handle) {
     }
   }
   return hm_fail(HM_ERR_NOT_FOUND, "hm_release_bases: unknown handle");
-}
+} HM_API_CATCH("hm_release_bases")
 
-int hm_msm_bn256_g1_dev(uint64_t handle, size_t offset, const void* d_scalars, size_t n, void* stream, uint64_t out_xyz[12]) {
+int hm_msm_bn256_g1_dev(uint64_t handle, size_t offset, const void* d_scalars, size_t n, void* stream, uint64_t out_xyz[12]) try {
   if (!out_xyz || (n && !d_scalars)) return hm_fail(HM_ERR_BAD_ARG, "hm_msm_bn256_g1_dev: null argument");
+  if (is_multi_handle(handle)) {
+    int id = 0;
+    return multi_msm(handle, offset, d_scalars, false, n, stream, out_xyz, &id);
+  }
   DeviceCtx* ctx = ctx_for_current_device();
   if (!ctx) return HM_ERR_NO_DEVICE;
   std::lock_guard<std::mutex> lk(ctx->mu);
@@ -330,9 +407,9 @@ int hm_msm_bn256_g1_dev(uint64_t handle, size_t offset, const void* d_scalars, s
   const uint32_t pc = (offset == 0 && n == b->n) ? b->pc_c : 0u;   // the table only fits whole-set calls
   const int rc = msm_run(*ctx, (const uint32_t*)d_scalars, b->d_xy + offset * 16, b->d_inf + offset, n, pc, out_xyz, &is_id,
                          (hipStream_t)stream);
-  if (rc == HM_OK) count_msm(*ctx, n);
+  if (rc == HM_OK) count_msm(*ctx, n, ctx->last_msm.t_total_ms);
   return rc;
-}
+} HM_API_CATCH("hm_msm_bn256_g1_dev")
 
 // One ticket = one launch chain = `group` MSMs over the same base range (group > 1 only where the five-launch plan applies).
 static int submit_chain(DeviceCtx* ctx, uint64_t handle, size_t offset, const void* const* d_scalars_list, uint32_t group, size_t n,
@@ -366,14 +443,33 @@ static int submit_chain(DeviceCtx* ctx, uint64_t handle, size_t offset, const vo
   return HM_OK;
 }
 
-int hm_msm_submit_dev(uint64_t handle, size_t offset, const void* d_scalars, size_t n, void* stream, uint64_t* out_ticket) {
+int hm_msm_submit_dev(uint64_t handle, size_t offset, const void* d_scalars, size_t n, void* stream, uint64_t* out_ticket) try {
   if (!out_ticket || (n && !d_scalars)) return hm_fail(HM_ERR_BAD_ARG, "hm_msm_submit_dev: null argument");
   DeviceCtx* ctx = ctx_for_current_device();
   if (!ctx) return HM_ERR_NO_DEVICE;
+  if (is_multi_handle(handle)) {      // tickets belong to one device: a replicated set is used through its copy here
+    const int rc = multi_local_part(handle, ctx->device, &handle);
+    if (rc != HM_OK) return rc;
+  }
   return submit_chain(ctx, handle, offset, &d_scalars, 1, n, stream, out_ticket, "hm_msm_submit_dev");
-}
+} HM_API_CATCH("hm_msm_submit_dev")
 
 static int wait_chain(DeviceCtx* ctx, uint64_t ticket, uint64_t* out_xyz, uint32_t capacity);
+// a ticket whose wait failed half-way (an exception): let its chain drain and give the slot back, whatever state it is in
+static void abandon_ticket(DeviceCtx* ctx, uint64_t ticket) noexcept {
+  try {
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    for (int i = 1; i < HM_MSM_SLOTS; ++i) {
+      MsmSlot& sl = ctx->msm_slots[i];
+      if (!sl.busy || sl.ticket != ticket) continue;
+      if (sl.n != 0 && sl.ev_ready) (void)hipEventSynchronize(sl.ev[4]);
+      sl.awaiting = false;
+      sl.busy = false;
+      sl.live_ptr = nullptr;
+    }
+  } catch (...) {
+  }
+}
 
 // The commitments of one prover phase in one call: `count` scalar arrays against the same base range, kept eight in
 // flight on the library's own streams (created on first use), results in call order.  What a caller of
@@ -430,7 +526,14 @@ static int msm_batch_impl(DeviceCtx* ctx, uint64_t handle, size_t offset, const 
   int device = 0;
   HM_HIP_CHECK(hipGetDevice(&device));
   auto await_chain = [&](size_t d) {           // chain d covers the MSMs d * per_chain ...
-    const int wrc = wait_chain(ctx, tickets[d % kLanes], out_xyz + 12 * d * per_chain, per_chain);
+    int wrc;
+    try {
+      hm_fault_point("batch_await");
+      wrc = wait_chain(ctx, tickets[d % kLanes], out_xyz + 12 * d * per_chain, per_chain);
+    } catch (...) {                            // nothing may escape the waiter thread, and `done` must still advance
+      wrc = HM_ERR_INTERNAL;
+      abandon_ticket(ctx, tickets[d % kLanes]);
+    }
     if (wrc != HM_OK) {
       int expect = HM_OK;
       (void)wait_rc.compare_exchange_strong(expect, wrc);
@@ -448,15 +551,16 @@ static int msm_batch_impl(DeviceCtx* ctx, uint64_t handle, size_t offset, const 
       await_chain(d);                          // even after an error: no ticket is left behind
     }
   };
-  bool threaded = n_chains > 2;
-  std::thread th;
-  if (threaded) {
-    try {
-      th = std::thread(waiter);
-    } catch (...) {                             // no thread to be had: this one awaits between submissions
-      threaded = false;
-    }
-  }
+  // the waiter is told to finish and is joined on EVERY way out of this function (an exception in the submit loop included)
+  struct WaiterGuard {
+    std::atomic<bool>& no_more;
+    JoinOnExit pool;
+    ~WaiterGuard() { no_more.store(true, std::memory_order_release); }     // members are destroyed after this body: then the join
+  } guard{no_more, {}};
+  bool threaded = n_chains > 2 && spawn_or_false(guard.pool, "batch_waiter_spawn", waiter);   // no thread to be had: this one awaits between submissions
+  // host arrays are staged per lane in buffers of the device context: whole _h batch calls of different threads take turns
+  std::unique_lock<std::mutex> host_turn;
+  if (from_host) host_turn = std::unique_lock<std::mutex>(ctx->batch_h_mu);
   std::string submit_error;
   for (size_t ch = 0; ch < n_chains; ++ch) {
     while (ch - done.load(std::memory_order_acquire) >= (size_t)kLanes) {      // every lane holds a ticket
@@ -516,30 +620,35 @@ static int msm_batch_impl(DeviceCtx* ctx, uint64_t handle, size_t offset, const 
     issued.store(ch + 1, std::memory_order_release);
   }
   no_more.store(true, std::memory_order_release);
-  if (threaded) th.join();
-  else
+  if (threaded) {
+    for (auto& t : guard.pool.th) t.join();
+  } else {
     while (done.load() < issued.load()) await_chain(done.load());
+  }
   if (submit_rc.load() != HM_OK) return hm_fail(submit_rc.load(), submit_error);
   if (wait_rc.load() != HM_OK) return hm_fail(wait_rc.load(), "hm_msm_batch_bn256_g1_dev: a commitment of the batch failed (see the waiter's error)");
   return HM_OK;
 }
 
 int hm_msm_batch_bn256_g1_dev(uint64_t handle, size_t offset, const void* const* d_scalars, size_t n, size_t count, void* stream,
-                              uint64_t* out_xyz) {
+                              uint64_t* out_xyz) try {
   if ((count && (!d_scalars || !out_xyz))) return hm_fail(HM_ERR_BAD_ARG, "hm_msm_batch_bn256_g1_dev: null argument");
+  if (is_multi_handle(handle)) return multi_msm_batch(handle, offset, d_scalars, false, n, count, stream, out_xyz);
   DeviceCtx* ctx = ctx_for_current_device();
   if (!ctx) return HM_ERR_NO_DEVICE;
   return msm_batch_impl(ctx, handle, offset, d_scalars, false, n, count, stream, out_xyz);
-}
+} HM_API_CATCH("hm_msm_batch_bn256_g1_dev")
 
 // The same for scalar arrays in HOST memory (what halo2's prover holds today): each chain's upload runs on its own
 // lane's stream, so PCIe time hides behind the other chains' kernels.
-int hm_msm_batch_bn256_g1_h(uint64_t handle, size_t offset, const uint64_t* const* scalars, size_t n, size_t count, uint64_t* out_xyz) {
+int hm_msm_batch_bn256_g1_h(uint64_t handle, size_t offset, const uint64_t* const* scalars, size_t n, size_t count, uint64_t* out_xyz) try {
   if ((count && (!scalars || !out_xyz))) return hm_fail(HM_ERR_BAD_ARG, "hm_msm_batch_bn256_g1_h: null argument");
+  if (is_multi_handle(handle))
+    return multi_msm_batch(handle, offset, reinterpret_cast<const void* const*>(scalars), true, n, count, nullptr, out_xyz);
   DeviceCtx* ctx = ctx_for_current_device();
   if (!ctx) return HM_ERR_NO_DEVICE;
   return msm_batch_impl(ctx, handle, offset, reinterpret_cast<const void* const*>(scalars), true, n, count, nullptr, out_xyz);
-}
+} HM_API_CATCH("hm_msm_batch_bn256_g1_h")
 
 // Await one ticket: out_xyz receives 12 words per MSM of its chain (at most `capacity` of them).
 static int wait_chain(DeviceCtx* ctx, uint64_t ticket, uint64_t* out_xyz, uint32_t capacity) {
@@ -561,9 +670,10 @@ static int wait_chain(DeviceCtx* ctx, uint64_t ticket, uint64_t* out_xyz, uint32
   double host_us = 0;
   const int rc = msm_finish_wait_fold(sl, out_xyz, is_id, &host_us);
   std::lock_guard<std::mutex> lk(ctx->mu);
+  if (rc != HM_OK) sl.live_ptr = nullptr;      // a chain that failed may have left its block counters anywhere
   if (rc == HM_OK) {
     msm_finish_record(*ctx, slot, host_us);
-    for (uint32_t e = 0; e < (sl.n ? sl.group : 1u); ++e) count_msm(*ctx, sl.n);
+    for (uint32_t e = 0; e < (sl.n ? sl.group : 1u); ++e) count_msm(*ctx, sl.n, e == 0 ? ctx->last_msm.t_total_ms : 0.0);
   }
   sl.awaiting = false;
   sl.busy = false;
@@ -579,73 +689,138 @@ static int wait_chain(DeviceCtx* ctx, uint64_t ticket, uint64_t* out_xyz, uint32
   return rc;
 }
 
-int hm_msm_wait(uint64_t ticket, uint64_t out_xyz[12]) {
+int hm_msm_wait(uint64_t ticket, uint64_t out_xyz[12]) try {
   if (!out_xyz) return hm_fail(HM_ERR_BAD_ARG, "hm_msm_wait: null output");
   DeviceCtx* ctx = ctx_for_current_device();
   if (!ctx) return HM_ERR_NO_DEVICE;
   return wait_chain(ctx, ticket, out_xyz, 1);
-}
+} HM_API_CATCH("hm_msm_wait")
 
 int hm_msm_bn256_g1_h(uint64_t handle, size_t offset, const uint64_t* scalars, size_t n, uint64_t out_xy[8],
-                      int* out_is_identity) {
+                      int* out_is_identity) try {
   if (!out_xy || (n && !scalars)) return hm_fail(HM_ERR_BAD_ARG, "hm_msm_bn256_g1_h: null argument");
-  DeviceCtx* ctx = ctx_for_current_device();
-  if (!ctx) return HM_ERR_NO_DEVICE;
-  std::lock_guard<std::mutex> lk(ctx->mu);
-  BasesEntry* b = find_bases(*ctx, handle);
-  if (!b) return hm_fail(HM_ERR_NOT_FOUND, "hm_msm_bn256_g1_h: unknown base handle");
-  if (offset > b->n || n > b->n - offset) return hm_fail(HM_ERR_BAD_ARG, "hm_msm_bn256_g1_h: offset + n exceeds the base set");
-  void* d_s = ctx->io.ensure(n ? n * 32 : 32);
-  if (!d_s) return hm_fail(HM_ERR_HIP, "hm_msm_bn256_g1_h: staging allocation failed");
-  const double t0 = now_us();
-  HM_HIP_CHECK(hipMemcpy(d_s, scalars, n * 32, hipMemcpyHostToDevice));
-  ctx->calls.msm_h2d_us += now_us() - t0;
-  ctx->calls.h2d_bytes += n * 32;
   uint64_t jac[12];
   int is_id = 0;
-  const uint32_t pc = (offset == 0 && n == b->n) ? b->pc_c : 0u;
-  int rc = msm_run(*ctx, (const uint32_t*)d_s, b->d_xy + offset * 16, b->d_inf + offset, n, pc, jac, &is_id, nullptr);
+  const int rc = is_multi_handle(handle) ? multi_msm(handle, offset, scalars, true, n, nullptr, jac, &is_id)
+                                         : msm_h_local(handle, offset, scalars, n, jac, &is_id);
   if (rc != HM_OK) return rc;
-  count_msm(*ctx, n);
   return jac_to_affine_out(jac, is_id, out_xy, out_is_identity);
-}
+} HM_API_CATCH("hm_msm_bn256_g1_h")
 
-// 256-bit digest of a host array over EVERY word (four independent multiply-rotate lanes, folded at the end).  It keys
-// the converted-base cache of the drop-in call: unlike round 1's 64-point probe it reads the whole array, so a buffer
-// that was mutated at any index -- or re-allocated at the same address with other contents -- hashes differently.  Not
-// cryptographic; the caller is the only party who could construct a collision, against itself.
-static void digest_words(const uint64_t* w, size_t count, uint64_t out[4]) {
-  uint64_t s0 = 0x9E3779B97F4A7C15ULL, s1 = 0xBF58476D1CE4E5B9ULL, s2 = 0x94D049BB133111EBULL, s3 = 0xD6E8FEB86659FD93ULL;
-  auto rotl = [](uint64_t x, int k) { return (x << k) | (x >> (64 - k)); };
+extern "C++" {
+// Keyed digest of a host array over EVERY word.  It keys the converted-base cache of the drop-in call: unlike round 1's
+// 64-point probe it reads the whole array, so a buffer that was mutated at any index -- or re-allocated at the same
+// address with other contents -- hashes differently.  The patched best_multiexp also serves the verifier, whose base
+// array holds prover-chosen commitments, so an unkeyed mixing function would let a third party construct two arrays
+// with one digest.  This one is a universal hash under a per-process random key the caller of the library never sees:
+//   inner  NH (UMAC): per 512-byte block  sum_j (m[2j] + k[2j]) * (m[2j+1] + k[2j+1])  mod 2^128 -- two equal-length
+//          blocks that differ collide with probability 2^-64 over the key
+//   outer  the 128-bit block values as three coefficients each of two polynomials over GF(2^61 - 1), evaluated at two
+//          secret points (Horner): a difference anywhere survives with probability 1 - (3 blocks / 2^61)^2
+// ~1 multiplication per 16 bytes: as fast as the multiply-rotate lanes it replaces (the digest must stay cheaper than
+// the upload it saves).
+namespace {
+constexpr uint64_t kP61 = (1ull << 61) - 1;
+inline uint64_t mulmod61(uint64_t a, uint64_t b) {
+  const unsigned __int128 t = (unsigned __int128)a * b;
+  uint64_t r = (uint64_t)(t & kP61) + (uint64_t)(t >> 61);
+  r = (r & kP61) + (r >> 61);
+  return r >= kP61 ? r - kP61 : r;
+}
+inline uint64_t addmod61(uint64_t a, uint64_t b) {
+  uint64_t r = a + b;             // both < 2^61
+  return r >= kP61 ? r - kP61 : r;
+}
+struct DigestKey {
+  uint64_t nh[64];
+  uint64_t r1, r2, s1, s2;
+};
+const DigestKey& digest_key() {
+  static const DigestKey key = [] {
+    DigestKey k;
+    uint64_t seed[8];
+    try {
+      std::random_device rd;
+      for (auto& w : seed) w = ((uint64_t)rd() << 32) ^ rd();
+    } catch (...) {             // no entropy source: address-space layout and the clock still differ per process
+      const uint64_t t = (uint64_t)std::chrono::steady_clock::now().time_since_epoch().count();
+      for (int i = 0; i < 8; ++i) seed[i] = t * (2 * i + 1) ^ (uint64_t)(uintptr_t)&k ^ (0x9E3779B97F4A7C15ULL * (i + 1));
+    }
+    uint64_t x = seed[0] ^ seed[1] ^ seed[2] ^ seed[3] ^ seed[4] ^ seed[5] ^ seed[6] ^ seed[7], y = seed[3] * 3 + seed[5];
+    auto next = [&]() {        // splitmix64 over the seeded state: expands the entropy, adds none
+      x += 0x9E3779B97F4A7C15ULL + y;
+      uint64_t z = x;
+      z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+      z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+      return z ^ (z >> 31);
+    };
+    for (auto& w : k.nh) w = next();
+    k.r1 = next() % (kP61 - 2) + 1; k.r2 = next() % (kP61 - 2) + 1;
+    k.s1 = next() % (kP61 - 2) + 1; k.s2 = next() % (kP61 - 2) + 1;
+    return k;
+  }();
+  return key;
+}
+}  // namespace
+
+// digest of words [0, count): out = { poly1, poly2 } (both < 2^61)
+static void digest_words(const uint64_t* w, size_t count, uint64_t out[2]) {
+  const DigestKey& K = digest_key();
+  uint64_t a1 = 0, a2 = 0;
+  auto absorb = [&](unsigned __int128 nh) {
+    const uint64_t lo = (uint64_t)nh, hi = (uint64_t)(nh >> 64);
+    const uint64_t c0 = lo & kP61, c1 = ((lo >> 61) | (hi << 3)) & kP61, c2 = hi >> 58;
+    a1 = addmod61(mulmod61(addmod61(mulmod61(addmod61(mulmod61(a1, K.r1), c0), K.r1), c1), K.r1), c2);
+    a2 = addmod61(mulmod61(addmod61(mulmod61(addmod61(mulmod61(a2, K.r2), c0), K.r2), c1), K.r2), c2);
+  };
   size_t i = 0;
-  for (; i + 4 <= count; i += 4) {
-    s0 = rotl((s0 ^ w[i]) * 0xFF51AFD7ED558CCDULL, 29);
-    s1 = rotl((s1 ^ w[i + 1]) * 0xC4CEB9FE1A85EC53ULL, 31);
-    s2 = rotl((s2 ^ w[i + 2]) * 0x9FB21C651E98DF25ULL, 27);
-    s3 = rotl((s3 ^ w[i + 3]) * 0xA0761D6478BD642FULL, 33);
+  for (; i + 64 <= count; i += 64) {
+    unsigned __int128 nh = 0;
+    for (int j = 0; j < 64; j += 2) nh += (unsigned __int128)(w[i + j] + K.nh[j]) * (w[i + j + 1] + K.nh[j + 1]);
+    absorb(nh);
   }
-  for (; i < count; ++i) s0 = rotl((s0 ^ w[i]) * 0xFF51AFD7ED558CCDULL, 29);
-  out[0] = s0 ^ rotl(s1, 17);
-  out[1] = s1 ^ rotl(s2, 23);
-  out[2] = s2 ^ rotl(s3, 41);
-  out[3] = s3 ^ rotl(s0, 11) ^ (uint64_t)count;
+  if (i < count) {                               // last, partial block: zero-padded (the length is part of the key)
+    uint64_t pad[64] = {};
+    std::memcpy(pad, w + i, (count - i) * 8);
+    unsigned __int128 nh = 0;
+    for (int j = 0; j < 64; j += 2) nh += (unsigned __int128)(pad[j] + K.nh[j]) * (pad[j + 1] + K.nh[j + 1]);
+    absorb(nh);
+  }
+  out[0] = a1;
+  out[1] = a2;
 }
 
 static void digest_bases(const uint64_t* bases, size_t n, uint64_t out[4]) {
+  hm_fault_point("digest");
   const size_t words = n * 8;
   const unsigned parts = words >= (1u << 20) ? 4u : 1u;      // >= 8 MiB: four host threads (the digest must stay cheaper than the upload)
-  uint64_t part[4][4];
-  if (parts == 1) {
-    digest_words(bases, words, out);
-    return;
+  uint64_t part[4][2] = {};
+  auto lo_of = [&](unsigned p) { return (words * p / parts) & ~(size_t)63; };    // block-aligned cuts
+  auto run = [&](unsigned p) {
+    const size_t lo = lo_of(p), hi = p + 1 == parts ? words : lo_of(p + 1);
+    digest_words(bases + lo, hi - lo, part[p]);
+  };
+  {
+    JoinOnExit pool;                              // joined before `part` is read, and on every other way out
+    bool done[4] = {true, false, false, false};
+    for (unsigned p = 1; p < parts; ++p) done[p] = spawn_or_false(pool, "digest_spawn", [&run, p] { run(p); });
+    run(0);
+    for (unsigned p = 1; p < parts; ++p)
+      if (!done[p]) run(p);                       // no thread to be had: this one does the part too
   }
-  std::thread th[3];
-  for (unsigned p = 1; p < parts; ++p)
-    th[p - 1] = std::thread([&, p] { digest_words(bases + words * p / parts, words * (p + 1) / parts - words * p / parts, part[p]); });
-  digest_words(bases, words / parts, part[0]);
-  for (unsigned p = 1; p < parts; ++p) th[p - 1].join();
-  digest_words(&part[0][0], 16, out);
+  const DigestKey& K = digest_key();
+  uint64_t h1 = 0, h2 = 0;
+  for (unsigned p = 0; p < parts; ++p) {
+    h1 = addmod61(mulmod61(h1, K.s1), part[p][0]);
+    h2 = addmod61(mulmod61(h2, K.s2), part[p][1]);
+  }
+  out[0] = h1;
+  out[1] = h2;
+  out[2] = (uint64_t)words;
+  out[3] = parts;
 }
+
+}  // extern "C++"
 
 // The drop-in form of best_multiexp: both arrays are host memory.  The scalars cross PCIe in every call; the converted
 // bases of the previous call are kept per device and reused only when the FULL-CONTENT digest and the length match (the
@@ -684,59 +859,33 @@ static int msm_host_one(const uint64_t* scalars, const uint64_t* bases, size_t n
   ctx->calls.msm_h2d_us += now_us() - t0;
   ctx->calls.h2d_bytes += n * 32;
   int rc = msm_run(*ctx, (const uint32_t*)d_s, d_xy, d_inf, n, 0, jac, is_id, nullptr);
-  if (rc == HM_OK) count_msm(*ctx, n);
+  if (rc == HM_OK) count_msm(*ctx, n, ctx->last_msm.t_total_ms);
   return rc;
 }
 
-// Single-process multi-GPU form (hm_set_msm_devices): contiguous index ranges, one host thread per
-// device, each running the ordinary one-device path on its slice (its own uploads, no shared state),
-// partial sums folded on the host.  No inter-GPU traffic: the only
-// thing that leaves a device is a 96-byte point.
+// Single-process multi-GPU form of the host-pointer call (hm_set_msm_devices): contiguous index ranges, one host
+// thread per device (multi.hip: run_per_device), each running the ordinary one-device path on its slice (its own
+// uploads, no shared state), partial sums folded on the host.  No inter-GPU traffic: the only thing that leaves a
+// device is a 96-byte point.
 static int msm_host(const uint64_t* scalars, const uint64_t* bases, size_t n, uint64_t jac[12], int* is_id) {
   if (n && (!scalars || !bases)) return hm_fail(HM_ERR_BAD_ARG, "hm_msm_bn256_g1: null argument");
-  std::vector<int> devs;
-  {
-    std::lock_guard<std::mutex> lk(g_ctx_mu);
-    devs = g_msm_devices;
-  }
+  const std::vector<int> devs = msm_device_list();
   const size_t parts = devs.size();
-  if (parts < 2 || n < parts * kMinShardPoints) {
-    if (parts >= 2) {   // too small to be worth splitting: the first listed device takes it whole
-      int prev = 0;
-      HM_HIP_CHECK(hipGetDevice(&prev));
-      HM_HIP_CHECK(hipSetDevice(devs[0]));
-      const int rc = msm_host_one(scalars, bases, n, jac, is_id);
-      (void)hipSetDevice(prev);
-      return rc;
-    }
-    return msm_host_one(scalars, bases, n, jac, is_id);
-  }
+  if (parts < 2) return msm_host_one(scalars, bases, n, jac, is_id);
+  if (n < parts * kMinShardPoints)     // too small to be worth splitting: the first listed device takes it whole
+    return run_per_device({devs[0]}, [&](size_t) { return msm_host_one(scalars, bases, n, jac, is_id); });
   std::vector<uint64_t> partial(parts * 12, 0);
-  std::vector<int> rcs(parts, HM_OK);
-  std::vector<std::string> errs(parts);
-  std::vector<std::thread> workers;
-  workers.reserve(parts);
-  for (size_t r = 0; r < parts; ++r) {
+  const int rc = run_per_device(devs, [&](size_t r) {
     const size_t lo = n * r / parts, hi = n * (r + 1) / parts;
-    workers.emplace_back([&, r, lo, hi] {
-      int id = 0;
-      if (hipSetDevice(devs[r]) != hipSuccess) {
-        rcs[r] = HM_ERR_HIP;
-        errs[r] = "hm_msm_bn256_g1: hipSetDevice failed for device " + std::to_string(devs[r]);
-        return;
-      }
-      rcs[r] = msm_host_one(scalars + lo * 4, bases + lo * 8, hi - lo, &partial[r * 12], &id);
-      if (rcs[r] != HM_OK) errs[r] = g_last_error;   // thread-local: carry it back to the caller's thread
-    });
-  }
-  for (auto& w : workers) w.join();
-  for (size_t r = 0; r < parts; ++r)
-    if (rcs[r] != HM_OK) return hm_fail(rcs[r], errs[r]);
+    int id = 0;
+    return msm_host_one(scalars + lo * 4, bases + lo * 8, hi - lo, &partial[r * 12], &id);
+  });
+  if (rc != HM_OK) return rc;
   host_sum_points(partial.data(), parts, jac, is_id);
   return HM_OK;
 }
 
-int hm_set_msm_devices(const int* devices, int count) {
+int hm_set_msm_devices(const int* devices, int count) try {
   if (count < 0 || count > 64 || (count && !devices)) return hm_fail(HM_ERR_BAD_ARG, "hm_set_msm_devices: bad device list");
   const int visible = hm_device_count();
   if (count && visible <= 0) return hm_fail(HM_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU fallback)");
@@ -745,32 +894,33 @@ int hm_set_msm_devices(const int* devices, int count) {
   std::lock_guard<std::mutex> lk(g_ctx_mu);
   g_msm_devices.assign(devices, devices + count);
   return HM_OK;
-}
+} HM_API_CATCH("hm_set_msm_devices")
 
-int hm_msm_bn256_g1(const uint64_t* scalars, const uint64_t* bases, size_t n, uint64_t out_xy[8], int* out_is_identity) {
+int hm_msm_bn256_g1(const uint64_t* scalars, const uint64_t* bases, size_t n, uint64_t out_xy[8], int* out_is_identity) try {
   if (!out_xy) return hm_fail(HM_ERR_BAD_ARG, "hm_msm_bn256_g1: null output");
   uint64_t jac[12];
   int is_id = 0;
   int rc = msm_host(scalars, bases, n, jac, &is_id);
   if (rc != HM_OK) return rc;
   return jac_to_affine_out(jac, is_id, out_xy, out_is_identity);
-}
+} HM_API_CATCH("hm_msm_bn256_g1")
 
-int hm_msm_bn256_g1_jacobian(const uint64_t* scalars, const uint64_t* bases, size_t n, uint64_t out_xyz[12]) {
+int hm_msm_bn256_g1_jacobian(const uint64_t* scalars, const uint64_t* bases, size_t n, uint64_t out_xyz[12]) try {
   if (!out_xyz) return hm_fail(HM_ERR_BAD_ARG, "hm_msm_bn256_g1_jacobian: null output");
   int is_id = 0;
   return msm_host(scalars, bases, n, out_xyz, &is_id);
-}
+} HM_API_CATCH("hm_msm_bn256_g1_jacobian")
 
-int hm_g1_sum(const uint64_t* points_xyz, size_t count, uint64_t out_xyz[12]) {
+int hm_g1_sum(const uint64_t* points_xyz, size_t count, uint64_t out_xyz[12]) try {
   if (!out_xyz || (count && !points_xyz)) return hm_fail(HM_ERR_BAD_ARG, "hm_g1_sum: null argument");
   if (count > (1u << 20)) return hm_fail(HM_ERR_BAD_ARG, "hm_g1_sum: meant for a handful of partial results");
+  hm_fault_point("g1_sum");
   int is_id = 0;
   host_sum_points(points_xyz, count, out_xyz, &is_id);
   return HM_OK;
-}
+} HM_API_CATCH("hm_g1_sum")
 
-int hm_get_msm_stats(hm_msm_stats* out) {
+int hm_get_msm_stats(hm_msm_stats* out) try {
   if (!out) return hm_fail(HM_ERR_BAD_ARG, "hm_get_msm_stats: null output");
   DeviceCtx* ctx = ctx_for_current_device();
   if (!ctx) return HM_ERR_NO_DEVICE;
@@ -780,9 +930,9 @@ int hm_get_msm_stats(hm_msm_stats* out) {
   out->reduce_ms = s.t_reduce_ms; out->total_ms = s.t_total_ms; out->accumulate_kernel_ms = s.t_accum_kernel_ms;
   out->pairs = s.pairs; out->tasks = s.tasks; out->window_bits = s.c; out->windows = s.windows;
   return HM_OK;
-}
+} HM_API_CATCH("hm_get_msm_stats")
 
-int hm_get_stats(hm_stats* out) {
+int hm_get_stats(hm_stats* out) try {
   if (!out) return hm_fail(HM_ERR_BAD_ARG, "hm_get_stats: null output");
   DeviceCtx* ctx = ctx_for_current_device();
   if (!ctx) return HM_ERR_NO_DEVICE;
@@ -797,15 +947,15 @@ int hm_get_stats(hm_stats* out) {
   out->h2d_bytes = c.h2d_bytes; out->d2h_bytes = c.d2h_bytes;
   for (int i = 0; i < 8; ++i) { out->vector_calls[i] = c.vector_calls[i]; out->vector_elements[i] = c.vector_elements[i]; }
   return HM_OK;
-}
+} HM_API_CATCH("hm_get_stats")
 
-int hm_reset_stats(void) {
+int hm_reset_stats(void) try {
   DeviceCtx* ctx = ctx_for_current_device();
   if (!ctx) return HM_ERR_NO_DEVICE;
   std::lock_guard<std::mutex> lk(ctx->mu);
   ctx->calls = CallStats{};
   return HM_OK;
-}
+} HM_API_CATCH("hm_reset_stats")
 
 // ---- NTT -------------------------------------------------------------------------------------
 
@@ -820,7 +970,7 @@ static void count_ntt(DeviceCtx& ctx, uint32_t log_n, size_t batch) {
   ctx.calls.ntt_by_log[log_n & 31] += batch;
 }
 
-int hm_ntt_bn256_fr_dev(void* d_a, const uint64_t omega[4], uint32_t log_n, void* stream) {
+int hm_ntt_bn256_fr_dev(void* d_a, const uint64_t omega[4], uint32_t log_n, void* stream) try {
   if (!d_a || !omega) return hm_fail(HM_ERR_BAD_ARG, "hm_ntt_bn256_fr_dev: null argument");
   DeviceCtx* ctx = ctx_for_current_device();
   if (!ctx) return HM_ERR_NO_DEVICE;
@@ -828,10 +978,10 @@ int hm_ntt_bn256_fr_dev(void* d_a, const uint64_t omega[4], uint32_t log_n, void
   const int rc = ntt_run(*ctx, (uint32_t*)d_a, omega, log_n, 1, NttFused{}, (hipStream_t)stream);
   if (rc == HM_OK) count_ntt(*ctx, log_n, 1);
   return rc;
-}
+} HM_API_CATCH("hm_ntt_bn256_fr_dev")
 
 int hm_ntt_batch_bn256_fr_dev(void* d_a, size_t batch, const uint64_t omega[4], uint32_t log_n, const uint64_t* scale,
-                              const uint64_t* coset, void* stream) {
+                              const uint64_t* coset, void* stream) try {
   if ((batch && !d_a) || !omega) return hm_fail(HM_ERR_BAD_ARG, "hm_ntt_batch_bn256_fr_dev: null argument");
   if (batch > 65535) return hm_fail(HM_ERR_BAD_ARG, "hm_ntt_batch_bn256_fr_dev: batch > 65535");
   DeviceCtx* ctx = ctx_for_current_device();
@@ -843,10 +993,10 @@ int hm_ntt_batch_bn256_fr_dev(void* d_a, size_t batch, const uint64_t omega[4], 
   const int rc = ntt_run(*ctx, (uint32_t*)d_a, omega, log_n, (uint32_t)batch, f, (hipStream_t)stream);
   if (rc == HM_OK) count_ntt(*ctx, log_n, batch);
   return rc;
-}
+} HM_API_CATCH("hm_ntt_batch_bn256_fr_dev")
 
 int hm_coeff_to_extended_bn256_fr_dev(const void* d_coeffs, void* d_ext, size_t batch, const uint64_t extended_omega[4],
-                                      uint32_t log_n, uint32_t log_ext, const uint64_t* coset, void* stream) {
+                                      uint32_t log_n, uint32_t log_ext, const uint64_t* coset, void* stream) try {
   if ((batch && (!d_coeffs || !d_ext)) || !extended_omega)
     return hm_fail(HM_ERR_BAD_ARG, "hm_coeff_to_extended_bn256_fr_dev: null argument");
   if (log_ext < log_n || log_ext > 28) return hm_fail(HM_ERR_BAD_ARG, "hm_coeff_to_extended_bn256_fr_dev: need log_n <= log_ext <= 28");
@@ -873,10 +1023,10 @@ int hm_coeff_to_extended_bn256_fr_dev(const void* d_coeffs, void* d_ext, size_t 
   }
   if (rc == HM_OK) count_ntt(*ctx, log_ext, batch);
   return rc;
-}
+} HM_API_CATCH("hm_coeff_to_extended_bn256_fr_dev")
 
 int hm_extended_to_coeff_bn256_fr_dev(void* d_a, size_t batch, const uint64_t extended_omega_inv[4], uint32_t log_ext,
-                                      const uint64_t divisor[4], const uint64_t coset_inv[12], void* stream) {
+                                      const uint64_t divisor[4], const uint64_t coset_inv[12], void* stream) try {
   if ((batch && !d_a) || !extended_omega_inv || !divisor || !coset_inv)
     return hm_fail(HM_ERR_BAD_ARG, "hm_extended_to_coeff_bn256_fr_dev: null argument");
   if (batch > 65535) return hm_fail(HM_ERR_BAD_ARG, "hm_extended_to_coeff_bn256_fr_dev: batch > 65535");
@@ -889,9 +1039,9 @@ int hm_extended_to_coeff_bn256_fr_dev(void* d_a, size_t batch, const uint64_t ex
   const int rc = ntt_run(*ctx, (uint32_t*)d_a, extended_omega_inv, log_ext, (uint32_t)batch, f, (hipStream_t)stream);
   if (rc == HM_OK) count_ntt(*ctx, log_ext, batch);
   return rc;
-}
+} HM_API_CATCH("hm_extended_to_coeff_bn256_fr_dev")
 
-int hm_ntt_bn256_fr(uint64_t* a, const uint64_t omega[4], uint32_t log_n) {
+int hm_ntt_bn256_fr(uint64_t* a, const uint64_t omega[4], uint32_t log_n) try {
   if (!a || !omega) return hm_fail(HM_ERR_BAD_ARG, "hm_ntt_bn256_fr: null argument");
   if (log_n > 28) return hm_fail(HM_ERR_BAD_ARG, "hm_ntt_bn256_fr: log_n > 28");
   DeviceCtx* ctx = ctx_for_current_device();
@@ -916,9 +1066,9 @@ int hm_ntt_bn256_fr(uint64_t* a, const uint64_t omega[4], uint32_t log_n) {
   ctx->calls.h2d_bytes += bytes;
   ctx->calls.d2h_bytes += bytes;
   return HM_OK;
-}
+} HM_API_CATCH("hm_ntt_bn256_fr")
 
-int hm_ifft_bn256_fr_dev(void* d_a, const uint64_t omega_inv[4], uint32_t log_n, const uint64_t divisor[4], void* stream) {
+int hm_ifft_bn256_fr_dev(void* d_a, const uint64_t omega_inv[4], uint32_t log_n, const uint64_t divisor[4], void* stream) try {
   if (!d_a || !omega_inv || !divisor) return hm_fail(HM_ERR_BAD_ARG, "hm_ifft_bn256_fr_dev: null argument");
   DeviceCtx* ctx = ctx_for_current_device();
   if (!ctx) return HM_ERR_NO_DEVICE;
@@ -928,9 +1078,9 @@ int hm_ifft_bn256_fr_dev(void* d_a, const uint64_t omega_inv[4], uint32_t log_n,
   const int rc = ntt_run(*ctx, (uint32_t*)d_a, omega_inv, log_n, 1, f, (hipStream_t)stream);
   if (rc == HM_OK) count_ntt(*ctx, log_n, 1);
   return rc;
-}
+} HM_API_CATCH("hm_ifft_bn256_fr_dev")
 
-int hm_coset_ntt_bn256_fr_dev(void* d_a, const uint64_t omega[4], uint32_t log_n, const uint64_t coset[12], void* stream) {
+int hm_coset_ntt_bn256_fr_dev(void* d_a, const uint64_t omega[4], uint32_t log_n, const uint64_t coset[12], void* stream) try {
   if (!d_a || !omega || !coset) return hm_fail(HM_ERR_BAD_ARG, "hm_coset_ntt_bn256_fr_dev: null argument");
   DeviceCtx* ctx = ctx_for_current_device();
   if (!ctx) return HM_ERR_NO_DEVICE;
@@ -940,10 +1090,10 @@ int hm_coset_ntt_bn256_fr_dev(void* d_a, const uint64_t omega[4], uint32_t log_n
   const int rc = ntt_run(*ctx, (uint32_t*)d_a, omega, log_n, 1, f, (hipStream_t)stream);
   if (rc == HM_OK) count_ntt(*ctx, log_n, 1);
   return rc;
-}
+} HM_API_CATCH("hm_coset_ntt_bn256_fr_dev")
 
 int hm_eval_polynomial_bn256_fr_dev(const void* d_polys, size_t n, const uint32_t* poly_index, const uint64_t* points, size_t count,
-                                    uint64_t* out, void* stream) {
+                                    uint64_t* out, void* stream) try {
   if ((count && (!points || !out)) || (count && n && !d_polys))
     return hm_fail(HM_ERR_BAD_ARG, "hm_eval_polynomial_bn256_fr_dev: null argument");
   DeviceCtx* ctx = ctx_for_current_device();
@@ -951,9 +1101,9 @@ int hm_eval_polynomial_bn256_fr_dev(const void* d_polys, size_t n, const uint32_
   std::lock_guard<std::mutex> lk(ctx->mu);
   count_vector(*ctx, HM_STAT_EVAL_POLYNOMIAL, count, (uint64_t)count * n);
   return fr_eval_polynomial_run(*ctx, (const uint32_t*)d_polys, n, poly_index, points, count, out, (hipStream_t)stream);
-}
+} HM_API_CATCH("hm_eval_polynomial_bn256_fr_dev")
 
-int hm_kate_division_bn256_fr_dev(const void* d_poly, size_t n, const uint64_t z[4], void* d_quotient, void* stream) {
+int hm_kate_division_bn256_fr_dev(const void* d_poly, size_t n, const uint64_t z[4], void* d_quotient, void* stream) try {
   if (!z || (n >= 2 && (!d_poly || !d_quotient))) return hm_fail(HM_ERR_BAD_ARG, "hm_kate_division_bn256_fr_dev: null argument");
   if (n >= 2) {
     const char *a = (const char*)d_poly, *q = (const char*)d_quotient;
@@ -965,18 +1115,18 @@ int hm_kate_division_bn256_fr_dev(const void* d_poly, size_t n, const uint64_t z
   std::lock_guard<std::mutex> lk(ctx->mu);
   count_vector(*ctx, HM_STAT_KATE_DIVISION, 1, n);
   return fr_kate_division_run(*ctx, (const uint32_t*)d_poly, n, z, (uint32_t*)d_quotient, (hipStream_t)stream);
-}
+} HM_API_CATCH("hm_kate_division_bn256_fr_dev")
 
-int hm_fr_grand_product_dev(const void* d_factors, size_t n, const uint64_t start[4], void* d_out, void* stream) {
+int hm_fr_grand_product_dev(const void* d_factors, size_t n, const uint64_t start[4], void* d_out, void* stream) try {
   if (!start || (n && (!d_factors || !d_out))) return hm_fail(HM_ERR_BAD_ARG, "hm_fr_grand_product_dev: null argument");
   DeviceCtx* ctx = ctx_for_current_device();
   if (!ctx) return HM_ERR_NO_DEVICE;
   std::lock_guard<std::mutex> lk(ctx->mu);
   count_vector(*ctx, HM_STAT_GRAND_PRODUCT, 1, n);
   return fr_grand_product_run(*ctx, (const uint32_t*)d_factors, n, start, (uint32_t*)d_out, (hipStream_t)stream);
-}
+} HM_API_CATCH("hm_fr_grand_product_dev")
 
-int hm_fr_batch_invert_dev(void* d_values, size_t n, void* stream) {
+int hm_fr_batch_invert_dev(void* d_values, size_t n, void* stream) try {
   if (n && !d_values) return hm_fail(HM_ERR_BAD_ARG, "hm_fr_batch_invert_dev: null argument");
   DeviceCtx* ctx = ctx_for_current_device();
   if (!ctx) return HM_ERR_NO_DEVICE;
@@ -985,10 +1135,10 @@ int hm_fr_batch_invert_dev(void* d_values, size_t n, void* stream) {
     count_vector(*ctx, HM_STAT_BATCH_INVERT, 1, n);
   }
   return fr_batch_invert_run((uint32_t*)d_values, n, (hipStream_t)stream);
-}
+} HM_API_CATCH("hm_fr_batch_invert_dev")
 
 int hm_fr_linear_combination_dev(const void* const* d_polys, const uint64_t* coeffs, size_t count, size_t n, void* d_out,
-                                 void* stream) {
+                                 void* stream) try {
   if ((n && !d_out) || (count && (!d_polys || !coeffs))) return hm_fail(HM_ERR_BAD_ARG, "hm_fr_linear_combination_dev: null argument");
   if (n)
     for (size_t j = 0; j < count; ++j)
@@ -1000,10 +1150,10 @@ int hm_fr_linear_combination_dev(const void* const* d_polys, const uint64_t* coe
     count_vector(*ctx, HM_STAT_LINEAR_COMBINATION, 1, (uint64_t)count * n);
   }
   return fr_linear_combination_run(d_polys, coeffs, count, n, (uint32_t*)d_out, (hipStream_t)stream);
-}
+} HM_API_CATCH("hm_fr_linear_combination_dev")
 
 int hm_lookup_permute_bn256_fr_dev(const void* d_input, const void* d_table, size_t rows, void* d_permuted_input,
-                                   void* d_permuted_table, void* stream) {
+                                   void* d_permuted_table, void* stream) try {
   if (rows && (!d_input || !d_table || !d_permuted_input || !d_permuted_table))
     return hm_fail(HM_ERR_BAD_ARG, "hm_lookup_permute_bn256_fr_dev: null argument");
   DeviceCtx* ctx = ctx_for_current_device();
@@ -1011,10 +1161,10 @@ int hm_lookup_permute_bn256_fr_dev(const void* d_input, const void* d_table, siz
   std::lock_guard<std::mutex> lk(ctx->mu);
   count_vector(*ctx, HM_STAT_LOOKUP_PERMUTE, 1, rows);
   return lookup_permute_run(*ctx, &d_input, &d_table, 1, rows, &d_permuted_input, &d_permuted_table, nullptr, (hipStream_t)stream);
-}
+} HM_API_CATCH("hm_lookup_permute_bn256_fr_dev")
 
 int hm_lookup_permute_batch_bn256_fr_dev(const void* const* d_inputs, const void* const* d_tables, size_t count, size_t rows,
-                                         void* const* d_permuted_inputs, void* const* d_permuted_tables, int* missing, void* stream) {
+                                         void* const* d_permuted_inputs, void* const* d_permuted_tables, int* missing, void* stream) try {
   if (count && (!d_inputs || !d_tables || !d_permuted_inputs || !d_permuted_tables))
     return hm_fail(HM_ERR_BAD_ARG, "hm_lookup_permute_batch_bn256_fr_dev: null argument");
   if (rows)
@@ -1026,34 +1176,34 @@ int hm_lookup_permute_batch_bn256_fr_dev(const void* const* d_inputs, const void
   std::lock_guard<std::mutex> lk(ctx->mu);
   count_vector(*ctx, HM_STAT_LOOKUP_PERMUTE, count, (uint64_t)count * rows);
   return lookup_permute_run(*ctx, d_inputs, d_tables, count, rows, d_permuted_inputs, d_permuted_tables, missing, (hipStream_t)stream);
-}
+} HM_API_CATCH("hm_lookup_permute_batch_bn256_fr_dev")
 
-int hm_fr_mul_periodic_dev(void* d_a, size_t n, const uint64_t* pattern, uint32_t period, void* stream) {
+int hm_fr_mul_periodic_dev(void* d_a, size_t n, const uint64_t* pattern, uint32_t period, void* stream) try {
   if ((n && !d_a) || !pattern) return hm_fail(HM_ERR_BAD_ARG, "hm_fr_mul_periodic_dev: null argument");
   DeviceCtx* ctx = ctx_for_current_device();
   if (!ctx) return HM_ERR_NO_DEVICE;
   return fr_mul_periodic_run((uint32_t*)d_a, n, pattern, period, (hipStream_t)stream);
-}
+} HM_API_CATCH("hm_fr_mul_periodic_dev")
 
-int hm_fr_powers_dev(void* d_out, size_t n, const uint64_t x[4], void* stream) {
+int hm_fr_powers_dev(void* d_out, size_t n, const uint64_t x[4], void* stream) try {
   if ((n && !d_out) || !x) return hm_fail(HM_ERR_BAD_ARG, "hm_fr_powers_dev: null argument");
   DeviceCtx* ctx = ctx_for_current_device();
   if (!ctx) return HM_ERR_NO_DEVICE;
   return fr_powers_run((uint32_t*)d_out, n, x, (hipStream_t)stream);
-}
+} HM_API_CATCH("hm_fr_powers_dev")
 
 int hm_graph_create(const uint32_t* calcs, size_t n_calc, const uint64_t* constants, size_t n_const, size_t n_dynamic,
-                    const int32_t* rotations, size_t n_rot, size_t n_columns, uint32_t n_intermediates, uint64_t* out_handle) {
+                    const int32_t* rotations, size_t n_rot, size_t n_columns, uint32_t n_intermediates, uint64_t* out_handle) try {
   if (!out_handle || (n_calc && !calcs) || (n_const && !constants) || (n_rot && !rotations))
     return hm_fail(HM_ERR_BAD_ARG, "hm_graph_create: null argument");
   DeviceCtx* ctx = ctx_for_current_device();
   if (!ctx) return HM_ERR_NO_DEVICE;
   std::lock_guard<std::mutex> lk(ctx->mu);
   return graph_create(*ctx, calcs, n_calc, constants, n_const, n_dynamic, rotations, n_rot, n_columns, n_intermediates, out_handle);
-}
+} HM_API_CATCH("hm_graph_create")
 
 int hm_graph_evaluate_dev(uint64_t handle, const void* const* d_columns, size_t n_columns, const uint64_t* dynamic_constants,
-                          size_t n_dynamic, uint32_t log_size, void* d_values, void* stream) {
+                          size_t n_dynamic, uint32_t log_size, void* d_values, void* stream) try {
   if (!d_values || (n_columns && !d_columns) || (n_dynamic && !dynamic_constants))
     return hm_fail(HM_ERR_BAD_ARG, "hm_graph_evaluate_dev: null argument");
   DeviceCtx* ctx = ctx_for_current_device();
@@ -1065,9 +1215,9 @@ int hm_graph_evaluate_dev(uint64_t handle, const void* const* d_columns, size_t 
       return graph_evaluate(*ctx, *g, d_columns, n_columns, dynamic_constants, n_dynamic, log_size, d_values, (hipStream_t)stream);
     }
   return hm_fail(HM_ERR_NOT_FOUND, "hm_graph_evaluate_dev: unknown program handle");
-}
+} HM_API_CATCH("hm_graph_evaluate_dev")
 
-int hm_graph_destroy(uint64_t handle) {
+int hm_graph_destroy(uint64_t handle) try {
   DeviceCtx* ctx = ctx_for_current_device();
   if (!ctx) return HM_ERR_NO_DEVICE;
   std::lock_guard<std::mutex> lk(ctx->mu);
@@ -1079,52 +1229,63 @@ int hm_graph_destroy(uint64_t handle) {
       return HM_OK;
     }
   return hm_fail(HM_ERR_NOT_FOUND, "hm_graph_destroy: unknown program handle");
-}
+} HM_API_CATCH("hm_graph_destroy")
 
-int hm_fr_dot_bn256_dev(const void* d_a, const void* d_b, size_t n, uint64_t out[4], void* stream) {
+int hm_fr_dot_bn256_dev(const void* d_a, const void* d_b, size_t n, uint64_t out[4], void* stream) try {
   if (!out || (n && (!d_a || !d_b))) return hm_fail(HM_ERR_BAD_ARG, "hm_fr_dot_bn256_dev: null argument");
   DeviceCtx* ctx = ctx_for_current_device();
   if (!ctx) return HM_ERR_NO_DEVICE;
   std::lock_guard<std::mutex> lk(ctx->mu);
   return fr_dot_run(*ctx, (const uint32_t*)d_a, (const uint32_t*)d_b, n, out, (hipStream_t)stream);
-}
+} HM_API_CATCH("hm_fr_dot_bn256_dev")
 
-int hm_fr_affine_sequence_dev(void* d_out, size_t n, const uint64_t a[4], const uint64_t b[4], void* stream) {
+int hm_fr_affine_sequence_dev(void* d_out, size_t n, const uint64_t a[4], const uint64_t b[4], void* stream) try {
   if ((n && !d_out) || !a || !b) return hm_fail(HM_ERR_BAD_ARG, "hm_fr_affine_sequence_dev: null argument");
   DeviceCtx* ctx = ctx_for_current_device();
   if (!ctx) return HM_ERR_NO_DEVICE;
   return fr_affine_sequence_run((uint32_t*)d_out, n, a, b, (hipStream_t)stream);
-}
+} HM_API_CATCH("hm_fr_affine_sequence_dev")
 
-int hm_fr_random_dev(void* d_out, size_t n, uint64_t seed, void* stream) {
+int hm_fr_random_dev(void* d_out, size_t n, uint64_t seed, void* stream) try {
   if (n && !d_out) return hm_fail(HM_ERR_BAD_ARG, "hm_fr_random_dev: null argument");
   DeviceCtx* ctx = ctx_for_current_device();
   if (!ctx) return HM_ERR_NO_DEVICE;
   return fr_random_run((uint32_t*)d_out, n, seed, (hipStream_t)stream);
-}
+} HM_API_CATCH("hm_fr_random_dev")
 
-int hm_fr_scale_dev(void* d_a, size_t n, const uint64_t c[4], void* stream) {
+int hm_fr_scale_dev(void* d_a, size_t n, const uint64_t c[4], void* stream) try {
   if ((n && !d_a) || !c) return hm_fail(HM_ERR_BAD_ARG, "hm_fr_scale_dev: null argument");
   DeviceCtx* ctx = ctx_for_current_device();
   if (!ctx) return HM_ERR_NO_DEVICE;
   if (n == 0) return HM_OK;
   return fr_scale_run((uint32_t*)d_a, c, n, (hipStream_t)stream);     // the constant travels by value: no shared state
-}
+} HM_API_CATCH("hm_fr_scale_dev")
 
-int hm_fr_distribute_powers_dev(void* d_a, size_t n, const uint64_t c3[12], void* stream) {
+int hm_fr_distribute_powers_dev(void* d_a, size_t n, const uint64_t c3[12], void* stream) try {
   if ((n && !d_a) || !c3) return hm_fail(HM_ERR_BAD_ARG, "hm_fr_distribute_powers_dev: null argument");
   DeviceCtx* ctx = ctx_for_current_device();
   if (!ctx) return HM_ERR_NO_DEVICE;
   if (n == 0) return HM_OK;
   return fr_mul_pattern3_run((uint32_t*)d_a, c3, n, (hipStream_t)stream);
-}
+} HM_API_CATCH("hm_fr_distribute_powers_dev")
 
-int hm_g1_fixed_base_mul_dev(const void* d_scalars, size_t n, const uint64_t base_xy[8], void* d_out_xy, void* stream) {
+int hm_g1_fixed_base_mul_dev(const void* d_scalars, size_t n, const uint64_t base_xy[8], void* d_out_xy, void* stream) try {
   if ((n && (!d_scalars || !d_out_xy)) || !base_xy) return hm_fail(HM_ERR_BAD_ARG, "hm_g1_fixed_base_mul_dev: null argument");
   DeviceCtx* ctx = ctx_for_current_device();
   if (!ctx) return HM_ERR_NO_DEVICE;
   std::lock_guard<std::mutex> lk(ctx->mu);
   return g1_fixed_base_mul_run(*ctx, (const uint32_t*)d_scalars, n, base_xy, (uint32_t*)d_out_xy, (hipStream_t)stream);
+} HM_API_CATCH("hm_g1_fixed_base_mul_dev")
+
+#ifdef HM_FAULT_INJECTION
+// test build only (libhalo2_mi355x_fi.so; not declared in the public header): the (after + 1)-th passage through the
+// named fault point throws std::runtime_error; point == NULL disarms
+int hm_test_arm_fault(const char* point, long after) {
+  std::lock_guard<std::mutex> lk(g_fault_mu);
+  g_fault_name = point ? point : "";
+  g_fault_after = point ? after : -1;
+  return HM_OK;
 }
+#endif
 
 }  // extern "C"

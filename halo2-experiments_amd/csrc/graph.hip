@@ -32,9 +32,7 @@ enum GraphOp : uint32_t { GOP_ADD = 0, GOP_SUB = 1, GOP_MUL = 2, GOP_SQUARE = 3,
 enum GraphSrc : uint32_t { GSRC_CONST = 0, GSRC_INTER = 1, GSRC_COLUMN = 2, GSRC_PREV = 3 };
 // a source is one word: kind (bits 30..31) | rotation index (bits 20..29) | index (bits 0..19); a column source uses
 // index bits 0..13 for the column and bits 14..19 for the column's log2 row count when it is SHORTER than the domain
-// (read at row mod 2^that; 0 = a full-size column).  The period lives in the instruction, not in a per-call table: a byte
-// table inside the by-value argument struct compiled to vector loads from the kernel-argument segment and aborted at run
-// time (ROCm 7.2); everything the kernel takes from its arguments is now reached by scalar loads.
+// (read at row mod 2^that; 0 = a full-size column): the period lives in the instruction, not in a per-call table.
 __host__ __device__ inline uint32_t gsrc_kind(uint32_t s) { return s >> 30; }
 __host__ __device__ inline uint32_t gsrc_rot(uint32_t s) { return (s >> 20) & 1023u; }
 __host__ __device__ inline uint32_t gsrc_index(uint32_t s) { return s & 0xfffffu; }
@@ -54,15 +52,22 @@ __device__ __forceinline__ Fr ge_from_ext(const uint32_t* __restrict__ p) {
   return fe_mul(fe_unpack<FrParams>(w), fe_const<FrParams>(FrParams::EXT2INT));
 }
 
-constexpr uint32_t GE_MAX_COLUMNS = 256;   // the by-value table must stay well inside the 4 KiB kernel-argument segment
+// The call's column table and per-call constants (2.6 KiB) travel through a DEVICE buffer of the stream's AuxSlot,
+// filled by a stream-ordered copy ahead of the launch.  Rounds 1-2 passed the struct by value: a variant with a
+// byte table in it aborted at run time on ROCm 7.2 and the cause was never pinned down (by-value arguments of this
+// size sit near the kernel-argument segment's limit and dynamic indexing into them is at the compiler's mercy), so
+// the kernel no longer depends on it: it takes one pointer, every table access is a wave-uniform (scalar) global
+// load, and the argument block is 72 bytes whatever the program's shape.  tests/test_evaluation.py runs 256 columns,
+// short-period columns and 16 per-call constants through it.
+constexpr uint32_t GE_MAX_COLUMNS = 256;
 constexpr uint32_t GE_MAX_DYN = 16;
-struct GraphColumns {        // the call's column table and per-call constants, by value (captured at launch)
+struct GraphColumns {
   const uint32_t* p[GE_MAX_COLUMNS];
   uint32_t dyn[GE_MAX_DYN * 9];   // challenges, beta, gamma, theta, y ... of THIS proof, internal form
   uint32_t n_static;              // constants [0, n_static) come from the program, [n_static, ..) from dyn
 };
 
-__device__ __forceinline__ Fr ge_fetch(uint32_t src, const GraphColumns& columns, const uint32_t* __restrict__ consts,
+__device__ __forceinline__ Fr ge_fetch(uint32_t src, const GraphColumns* __restrict__ columns, const uint32_t* __restrict__ consts,
                                        const int32_t* __restrict__ rotations, const uint32_t* __restrict__ scratch, uint32_t T,
                                        uint32_t lane_slot, uint64_t idx, uint64_t mask, const uint32_t* __restrict__ prev) {
   const uint32_t kind = gsrc_kind(src), index = gsrc_index(src);
@@ -73,10 +78,10 @@ __device__ __forceinline__ Fr ge_fetch(uint32_t src, const GraphColumns& columns
     for (int i = 0; i < 9; ++i) r.l[i] = p[(size_t)i * T];
     HM_DECLARE(r, 3.0);
   } else if (kind == GSRC_CONST) {
-    if (index >= columns.n_static) {
-      const uint32_t d = (index - columns.n_static) * 9;
+    if (index >= columns->n_static) {
+      const uint32_t d = (index - columns->n_static) * 9;
 #pragma unroll
-      for (int i = 0; i < 9; ++i) r.l[i] = columns.dyn[d + i];
+      for (int i = 0; i < 9; ++i) r.l[i] = columns->dyn[d + i];
     } else {
       const uint32_t* p = consts + (size_t)index * 9;
 #pragma unroll
@@ -87,14 +92,14 @@ __device__ __forceinline__ Fr ge_fetch(uint32_t src, const GraphColumns& columns
     uint64_t row = (idx + (uint64_t)(int64_t)rotations[gsrc_rot(src)]) & mask;   // two's complement: a negative rotation wraps
     const uint32_t lr = gsrc_log_rows(src);          // a short column (the vanishing polynomial's inverse pattern) is periodic
     if (lr != 0) row &= (1ull << lr) - 1ull;
-    r = ge_from_ext(columns.p[gsrc_column(src)] + row * 8);
+    r = ge_from_ext(columns->p[gsrc_column(src)] + row * 8);
   } else {
     r = ge_from_ext(prev);
   }
   return r;
 }
 
-__global__ __launch_bounds__(GE_THREADS) void graph_evaluate_kernel(const GraphColumns columns,
+__global__ __launch_bounds__(GE_THREADS) void graph_evaluate_kernel(const GraphColumns* __restrict__ columns,
                                                                     const uint32_t* __restrict__ consts,
                                                                     const int32_t* __restrict__ rotations,
                                                                     const GraphCalc* __restrict__ calcs, uint32_t n_calc, uint32_t result_src,
@@ -279,7 +284,12 @@ int graph_evaluate(DeviceCtx& ctx, GraphProgram& g, const void* const* d_columns
   }
   cols.n_static = g.n_static;
   for (size_t i = 0; i < n_dyn; ++i) host::fr_to_internal9(host::fr_load(dyn_ext + 4 * i), &cols.dyn[9 * i]);
-  hipLaunchKernelGGL(graph_evaluate_kernel, dim3(blocks), dim3(GE_THREADS), 0, stream, cols,
+  GraphColumns* d_cols = (GraphColumns*)slot->args.ensure(sizeof(GraphColumns));
+  if (!d_cols) return hm_fail(HM_ERR_HIP, "graph: argument buffer allocation failed");
+  // pageable source: the runtime has taken its copy of `cols` when this returns; the copy itself is ordered on `stream`
+  // ahead of the launch and behind the previous launch that read the buffer
+  HM_HIP_CHECK(hipMemcpyAsync(d_cols, &cols, sizeof cols, hipMemcpyHostToDevice, stream));
+  hipLaunchKernelGGL(graph_evaluate_kernel, dim3(blocks), dim3(GE_THREADS), 0, stream, (const GraphColumns*)d_cols,
                      (const uint32_t*)g.d_consts, (const int32_t*)g.d_rot, (const GraphCalc*)g.d_calcs, g.n_calc, g.result_src,
                      (uint32_t*)buf, (uint32_t*)d_values, log_size);
   HM_HIP_CHECK(hipGetLastError());

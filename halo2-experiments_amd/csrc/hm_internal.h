@@ -5,9 +5,13 @@
 
 #include <atomic>
 #include <cstring>
+#include <exception>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <string>
+#include <thread>
+#include <utility>
 #include <vector>
 
 #include "../../include/halo2_mi355x.h"
@@ -30,6 +34,47 @@ int hm_fail(int code, const std::string& what);  // records the message for hm_l
       return nullptr;                                                                               \
     }                                                                                               \
   } while (0)
+
+// ---- the exception barrier of the C ABI ------------------------------------------------------------
+// include/halo2_mi355x.h promises "never aborts or throws across the boundary": every extern "C" entry is a
+// function-try-block closed by HM_API_CATCH, so a std::bad_alloc / std::system_error / anything else raised under
+// it (vector growth, std::string, std::thread creation) comes back as HM_ERR_INTERNAL with the message in
+// hm_last_error().  Locks are std::lock_guard (released by the unwinding), helper threads are owned by JoinOnExit.
+int hm_guard_fail(const char* entry, const char* what) noexcept;
+#define HM_API_CATCH(entry)                                                                         \
+  catch (const std::exception& e) { return ::hm::hm_guard_fail(entry, e.what()); }                  \
+  catch (...) { return ::hm::hm_guard_fail(entry, nullptr); }
+
+// Fault points: compiled in only for the test build (libhalo2_mi355x_fi.so, -DHM_FAULT_INJECTION), where
+// hm_test_arm_fault(point, after) makes the (after + 1)-th passage through the named point throw.  In the product
+// build the call is an empty inline function.
+#ifdef HM_FAULT_INJECTION
+void hm_fault_point(const char* point);
+#else
+inline void hm_fault_point(const char*) {}
+#endif
+
+// Helper threads of a call (digest lanes, per-device workers, the batch waiter): joined on every way out of the
+// scope that owns them -- a throw between two spawns must not destroy a joinable std::thread (std::terminate).
+struct JoinOnExit {
+  std::vector<std::thread> th;
+  ~JoinOnExit() {
+    for (auto& t : th)
+      if (t.joinable()) t.join();
+  }
+};
+// Start `f` on a new thread owned by `pool`; false when no thread can be had (the caller then runs f itself).
+template <class F>
+inline bool spawn_or_false(JoinOnExit& pool, const char* point, F&& f) {
+  try {
+    hm_fault_point(point);
+    pool.th.emplace_back(std::forward<F>(f));
+    return true;
+  } catch (...) {
+    return false;
+  }
+}
+const std::string& hm_last_error_string();   // the calling thread's message (workers carry theirs back to the caller's thread)
 
 struct NttTables {
   uint32_t log_n = 0;
@@ -116,6 +161,7 @@ struct MsmSlot {            // one in-flight MSM: its workspace, events and host
 struct AuxSlot {
   DevBuf scratch;                 // NTT ping-pong buffer
   DevBuf table;                   // multiples table of hm_g1_fixed_base_mul_dev
+  DevBuf args;                    // per-call argument block of hm_graph_evaluate_dev (column table + per-proof constants)
   hipStream_t stream = nullptr;   // stream of the last user
   hipEvent_t done = nullptr;      // recorded behind the last user's launches
   bool used = false;
@@ -168,6 +214,7 @@ struct DeviceCtx {
   hipEvent_t batch_event = nullptr;
   bool batch_streams_ready = false;
   DevBuf batch_io[HM_MSM_SLOTS - 1];                  // hm_msm_batch_bn256_g1_h: per-lane staging of host scalar arrays
+  std::mutex batch_h_mu;                              // ... which belong to ONE _h batch call at a time (taken before mu, never under it)
   uint64_t next_handle = 1;
   // drop-in MSM: the converted bases of the previous call, keyed by a digest of the WHOLE host array (capi.hip)
   size_t cached_host_n = 0;
@@ -184,6 +231,29 @@ AuxSlot* aux_acquire(DeviceCtx& ctx, hipStream_t stream);
 int aux_release(DeviceCtx& ctx, AuxSlot* slot, hipStream_t stream);
 
 DeviceCtx* ctx_for_current_device();
+
+// capi.hip: the one-device bodies the multi-device layer runs per part (Jacobian results, so that partials fold)
+int msm_h_local(uint64_t handle, size_t offset, const uint64_t* scalars, size_t n, uint64_t jac[12], int* is_id);
+std::vector<int> msm_device_list();            // copy of hm_set_msm_devices' list (empty: one device)
+constexpr size_t kMinShardPoints = 1 << 14;    // below this many points per device a split only adds latency
+constexpr size_t kSliceBasesFrom = (size_t)1 << 22;   // base sets from this size are SLICED over the devices, smaller ones replicated
+
+// multi.hip: single-process multi-GPU layer over the one-device entry points (hm_set_msm_devices).  A handle with
+// HM_MULTI_HANDLE_BIT names a base set registered on several devices; every form that takes a handle dispatches on it.
+constexpr uint64_t HM_MULTI_HANDLE_BIT = 1ull << 62;
+inline bool is_multi_handle(uint64_t h) { return (h & HM_MULTI_HANDLE_BIT) != 0; }
+// fn(r) for every part r, part r on device devs[r] from its own host thread (the calling thread runs the parts no thread
+// could be had for); the first failure is reported on the caller's thread.  Nothing escapes a worker.
+int run_per_device(const std::vector<int>& devs, const std::function<int(size_t)>& fn);
+bool& multi_worker_flag();                     // true on a thread that is running a part (registrations there stay on one device)
+int multi_register(const uint64_t* bases_host, const void* d_bases, size_t n, void* stream, bool precomp, const std::vector<int>& devs,
+                   uint64_t* out_handle);
+int multi_release(uint64_t handle);
+void multi_release_touching(int device);       // hm_shutdown: drop every multi handle with a part on `device`
+int multi_msm(uint64_t handle, size_t offset, const void* scalars, bool from_host, size_t n, void* stream, uint64_t jac[12], int* is_id);
+int multi_msm_batch(uint64_t handle, size_t offset, const void* const* scalars, bool from_host, size_t n, size_t count, void* stream,
+                    uint64_t* out_xyz);
+int multi_local_part(uint64_t handle, int device, uint64_t* local_handle);   // replicated sets: the copy on `device`
 
 // ntt.hip
 // scale / coset: optional external (4 x u64 Montgomery) constants on the HOST; they travel to the kernels

@@ -1663,6 +1663,7 @@ int msm_finish(DeviceCtx& ctx, int slot, uint64_t out_jac_ext[12], int* out_is_i
   double host_us = 0;
   const int rc = msm_finish_wait_fold(ctx.msm_slots[slot], out_jac_ext, out_is_identity, &host_us);
   if (rc == HM_OK) msm_finish_record(ctx, slot, host_us);
+  else ctx.msm_slots[slot].live_ptr = nullptr;     // a chain that failed may have left its block counters anywhere
   return rc;
 }
 

@@ -637,11 +637,13 @@ int msm_issue_small(DeviceCtx& ctx, int slot, const uint32_t* const* d_scalars_l
   const bool pt = sl.phase_timed;
   for (uint32_t w = 0; w < W; ++w) sl.win_bits[w] = (uint8_t)(w < n_wide ? wide : wide - 1);
 
+  // The last chain of this slot left its block counters at zero (reduce2 clears them) unless the layout moved.  The
+  // slot claims that again only once THIS chain is enqueued to its last launch: an error return in between leaves
+  // live_ptr null, so the next chain clears the counters the digits kernel may already have advanced.
+  const bool counters_clean = sl.live_ptr == d_live;
+  sl.live_ptr = nullptr;
   HM_HIP_CHECK(hipEventRecord(ev[0], stream));
-  if (sl.live_ptr != d_live) {                    // the last chain of this slot left its counters at zero unless the layout moved
-    HM_HIP_CHECK(hipMemsetAsync(d_live, 0, (size_t)HM_MSM_GROUP * 4, stream));
-    sl.live_ptr = d_live;
-  }
+  if (!counters_clean) HM_HIP_CHECK(hipMemsetAsync(d_live, 0, (size_t)HM_MSM_GROUP * 4, stream));
   SmallGroupScalars gs;
   for (uint32_t e = 0; e < (uint32_t)HM_MSM_GROUP; ++e) gs.s[e] = d_scalars_list[e < group ? e : 0];
   hipLaunchKernelGGL(msm_s_digits_kernel, dim3((uint32_t)((n + SA_THREADS - 1) / SA_THREADS), group), dim3(SA_THREADS), 0, stream,
@@ -665,6 +667,7 @@ int msm_issue_small(DeviceCtx& ctx, int slot, const uint32_t* const* d_scalars_l
   HM_HIP_CHECK(hipGetLastError());
   HM_HIP_CHECK(hipMemcpyAsync(sl.totals(), d_tot, (size_t)group * res_stride * 4, hipMemcpyDeviceToHost, stream));
   HM_HIP_CHECK(hipEventRecord(ev[4], stream));
+  sl.live_ptr = d_live;
   return HM_OK;
 }
 

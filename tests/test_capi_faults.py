@@ -1,0 +1,170 @@
+"""The exception barrier of the C ABI (include/halo2_mi355x.h: "never aborts or throws across the boundary").
+
+libhalo2_mi355x_fi.so is the same sources built with -DHM_FAULT_INJECTION: hm_test_arm_fault(point, after) makes the
+(after + 1)-th passage through a named fault point throw std::runtime_error.  A throw under an extern "C" entry must come
+back as HM_ERR_INTERNAL with a message -- not std::terminate -- must release the device lock (the next call works), and a
+helper thread that cannot be started must degrade to the calling thread, never to a joinable std::thread being destroyed.
+The reference side would at worst see a Rust panic here (/root/reference/src/circuits/utils.rs:48: `.expect(...)`)."""
+import ctypes
+import threading
+
+import numpy as np
+import pytest
+
+from halo2_experiments_amd import _lib
+
+HM_ERR_INTERNAL = -5
+
+
+@pytest.fixture()
+def fi():
+    lib = _lib.load_fi()
+    yield lib
+    lib.hm_test_arm_fault(None, 0)
+
+
+def _u64(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64))
+
+
+def test_fi_build_exports_the_same_abi():
+    lib = _lib.load_fi()
+    assert b"gfx950" in lib.hm_version()
+    for name in _lib._SIGNATURES:
+        assert hasattr(lib, name)
+    assert not hasattr(_lib.load(), "hm_test_arm_fault"), "the product library must not carry the fault hook"
+
+
+def test_a_throw_inside_a_host_entry_is_an_error_code(fi, golden):
+    """hm_g1_sum needs no device: the fault point at its top throws on CPU-only boxes too."""
+    pts = np.zeros((2, 12), dtype=np.uint64)
+    out = np.zeros(12, dtype=np.uint64)
+    assert fi.hm_g1_sum(_u64(pts), 2, _u64(out)) == 0
+    fi.hm_test_arm_fault(b"g1_sum", 1)                    # the second passage throws
+    assert fi.hm_g1_sum(_u64(pts), 2, _u64(out)) == 0
+    assert fi.hm_g1_sum(_u64(pts), 2, _u64(out)) == HM_ERR_INTERNAL
+    msg = fi.hm_last_error()
+    assert b"hm_g1_sum" in msg and b"injected fault at g1_sum" in msg
+    assert fi.hm_g1_sum(_u64(pts), 2, _u64(out)) == 0     # disarmed by firing; the library is still usable
+
+
+def test_a_throw_on_another_thread_stays_on_that_thread(fi):
+    """hm_last_error is per thread: the message of a guarded failure does not leak to the caller's thread."""
+    pts, out = np.zeros((1, 12), dtype=np.uint64), np.zeros(12, dtype=np.uint64)
+    assert fi.hm_set_msm_devices(None, 0) == 0
+    seen = {}
+
+    def work():
+        fi.hm_test_arm_fault(b"g1_sum", 0)
+        seen["rc"] = fi.hm_g1_sum(_u64(pts), 1, _u64(out))
+        seen["msg"] = fi.hm_last_error()
+
+    t = threading.Thread(target=work)
+    t.start()
+    t.join()
+    assert seen["rc"] == HM_ERR_INTERNAL and b"injected" in seen["msg"]
+    assert fi.hm_g1_sum(_u64(pts), 1, _u64(out)) == 0
+
+
+# ---- with a device: faults under the device lock, in helper-thread creation and inside helper threads ---------------------
+
+def _rand_fr(n, seed):
+    import torch
+    g = torch.Generator(device="cuda")
+    g.manual_seed(seed)
+    x = torch.randint(-(2 ** 63), 2 ** 63 - 1, (n, 4), dtype=torch.int64, device="cuda", generator=g)
+    x[:, 3] &= 0x0FFFFFFFFFFFFFFF
+    return x
+
+
+def _fi_bases(fi, n, seed, cref):
+    """n affine points [t_i]G as host words, made by the FI library's own fixed-base kernel."""
+    import torch
+    t = _rand_fr(n, seed)
+    out = torch.empty((n, 8), dtype=torch.int64, device="cuda")
+    gen = cref.g1_generator()
+    assert fi.hm_g1_fixed_base_mul_dev(ctypes.c_void_p(t.data_ptr()), n, _u64(gen), ctypes.c_void_p(out.data_ptr()), None) == 0
+    torch.cuda.synchronize()
+    return out.cpu().numpy().view(np.uint64).copy()
+
+
+def _msm_host(lib, s, b):
+    out, ident = np.zeros(8, dtype=np.uint64), ctypes.c_int(0)
+    rc = lib.hm_msm_bn256_g1(_u64(s), _u64(b), s.shape[0], _u64(out), ctypes.byref(ident))
+    return rc, out, ident.value
+
+
+@pytest.mark.gpu
+def test_faults_in_the_drop_in_call(fi, cref):
+    """hm_msm_bn256_g1 on an array large enough for the four-thread digest (>= 8 MiB): a digest thread that cannot be
+    started is replaced by the calling thread (same result); a throw inside the call, under the device lock, is an error
+    code and the lock is free afterwards."""
+    n = 1 << 17                                            # 8 MiB of bases
+    b = _fi_bases(fi, n, 9101, cref)
+    s = _rand_fr(n, 9102).cpu().numpy().view(np.uint64).copy()
+    rc, want, _ = _msm_host(fi, s, b)
+    assert rc == 0
+    exp = cref.g1_to_affine(cref.best_multiexp(s, b, 8))[0]
+    assert np.array_equal(want, exp)
+    fi.hm_test_arm_fault(b"digest_spawn", 1)               # the second of three helper threads cannot be had
+    rc, got, _ = _msm_host(fi, s, b)
+    assert rc == 0 and np.array_equal(got, want)
+    fi.hm_test_arm_fault(b"digest", 0)                     # a throw under ctx->mu
+    rc, got, _ = _msm_host(fi, s, b)
+    assert rc == HM_ERR_INTERNAL and b"hm_msm_bn256_g1" in fi.hm_last_error()
+    rc, got, _ = _msm_host(fi, s, b)                       # the lock was released by the unwinding
+    assert rc == 0 and np.array_equal(got, want)
+
+
+@pytest.mark.gpu
+def test_faults_in_the_multi_device_workers(fi, cref):
+    """hm_set_msm_devices((0, 0, 0)): a worker thread that cannot be started hands its part to the calling thread; a throw
+    inside a worker comes back as an error code from the caller's call (and the other workers are joined, not abandoned)."""
+    n = 3 * (1 << 14) + 5
+    b = _fi_bases(fi, n, 9201, cref)
+    s = _rand_fr(n, 9202).cpu().numpy().view(np.uint64).copy()
+    rc, want, _ = _msm_host(fi, s, b)
+    assert rc == 0
+    devs = (ctypes.c_int * 3)(0, 0, 0)
+    assert fi.hm_set_msm_devices(devs, 3) == 0
+    try:
+        rc, got, _ = _msm_host(fi, s, b)
+        assert rc == 0 and np.array_equal(got, want)
+        fi.hm_test_arm_fault(b"worker_spawn", 0)
+        rc, got, _ = _msm_host(fi, s, b)
+        assert rc == 0 and np.array_equal(got, want)
+        fi.hm_test_arm_fault(b"worker_body", 1)
+        rc, got, _ = _msm_host(fi, s, b)
+        assert rc == HM_ERR_INTERNAL and b"injected fault at worker_body" in fi.hm_last_error()
+        rc, got, _ = _msm_host(fi, s, b)
+        assert rc == 0 and np.array_equal(got, want)
+    finally:
+        assert fi.hm_set_msm_devices(None, 0) == 0
+
+
+@pytest.mark.gpu
+def test_faults_in_the_batch_waiter(fi, cref):
+    """hm_msm_batch_bn256_g1_h: without its waiter thread the call awaits between submissions (same results); a throw
+    inside the waiter is an error code, every ticket of the call is still awaited (the next batch finds all slots free)."""
+    n, count = 1 << 12, 19
+    b = _fi_bases(fi, n, 9301, cref)
+    hd = ctypes.c_uint64(0)
+    assert fi.hm_register_bases(_u64(b), n, ctypes.byref(hd)) == 0
+    try:
+        cols = [_rand_fr(n, 9310 + i).cpu().numpy().view(np.uint64).copy() for i in range(count)]
+        ptrs = (ctypes.c_void_p * count)(*[c.ctypes.data for c in cols])
+        want = np.zeros((count, 12), dtype=np.uint64)
+        assert fi.hm_msm_batch_bn256_g1_h(hd, 0, ptrs, n, count, _u64(want)) == 0
+        exp = cref.g1_to_affine(cref.best_multiexp(cols[3], b, 4))[0]
+        assert np.array_equal(want[3][:8], exp)
+        got = np.zeros_like(want)
+        fi.hm_test_arm_fault(b"batch_waiter_spawn", 0)
+        assert fi.hm_msm_batch_bn256_g1_h(hd, 0, ptrs, n, count, _u64(got)) == 0
+        assert np.array_equal(got, want)
+        fi.hm_test_arm_fault(b"batch_await", 1)
+        assert fi.hm_msm_batch_bn256_g1_h(hd, 0, ptrs, n, count, _u64(got)) < 0
+        got[:] = 0
+        assert fi.hm_msm_batch_bn256_g1_h(hd, 0, ptrs, n, count, _u64(got)) == 0
+        assert np.array_equal(got, want)
+    finally:
+        assert fi.hm_release_bases(hd) == 0

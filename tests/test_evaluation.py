@@ -253,3 +253,54 @@ def test_permutation_and_lookup_arguments_and_vanishing_division(pyref):
         assert np.array_equal(values.cpu().numpy().view(np.uint64), pyref.fr_array(exp))
     finally:
         prog.destroy()
+
+
+@pytest.mark.gpu
+def test_device_graph_with_the_largest_argument_block(pyref):
+    """The per-call argument block at its limits: 256 columns (the table's maximum), several of them short and read
+    periodically with different periods, 12 challenges + beta / gamma / theta / y = 16 per-call constants.  Rounds 1-2
+    passed that block by value in the kernel-argument segment and one variant of it aborted at run time; it now travels
+    through a device buffer (csrc/graph.hip), and this shape is the regression test for it."""
+    import torch
+    from oracle import graph_ref
+    rng = random.Random(256)
+    nf, na, ni, nch = 200, 50, 6, 12
+    ek, k = 8, 6
+    isize, rot_scale = 1 << ek, 1 << (ek - k)
+    short = {3: 2, 77: 4, 199: 1, 255: 3}                    # column table index -> log2(rows)
+    polys = []
+    for j in range(0, nf + na + ni, 5):                      # every region of the table is read, the last entry included
+        col = ev.Fixed(j) if j < nf else (ev.Advice(j - nf, rng.choice([-1, 0, 1])) if j < nf + na else ev.Instance(j - nf - na))
+        polys.append(col * ev.Challenge(j % nch) + ev.Fixed(3) * ev.Fixed(77, 1))
+    polys.append(ev.Fixed(199) * ev.Instance(5, -1) - ev.Advice(49, 1) * ev.Challenge(11))
+    polys.append(ev.Instance(5) * ev.Fixed(199, 1))           # table index 255 is Instance(5)
+    g = ev.GraphEvaluator()
+    g.add_custom_gates(polys)
+    rows = lambda i: 1 << short[i] if i in short else isize
+    table = [[rng.randrange(R) for _ in range(rows(i))] for i in range(nf + na + ni)]
+    # the oracle reads full-size columns: a short column is its pattern repeated
+    full = [c * (isize // len(c)) for c in table]
+    ch = [rng.randrange(R) for _ in range(nch)]
+    beta, gamma, theta, y = (rng.randrange(R) for _ in range(4))
+    prev = [rng.randrange(R) for _ in range(isize)]
+    exp = graph_ref.evaluate_graph(g.calculations, g.constants, g.rotations, full[:nf], full[nf:nf + na], full[nf + na:], ch, beta, gamma,
+                                   theta, y, prev, rot_scale, isize)
+    to_dev = lambda col: torch.from_numpy(pyref.fr_array(col).view(np.int64)).cuda()
+    cols = [to_dev(c) for c in table]
+    values = to_dev(prev)
+    prog = g.compile(nf, na, ni, num_challenges=nch, rot_scale=rot_scale, short_columns=short)
+    try:
+        assert prog.n_columns == 256 and prog.n_dynamic == 16
+        for _ in range(2):                                    # the second call reuses the stream's argument buffer
+            values.copy_(to_dev(prev))
+            prog.evaluate(cols, values, challenges=ch, beta=beta, gamma=gamma, theta=theta, y=y)
+            torch.cuda.synchronize()
+            assert np.array_equal(values.cpu().numpy().view(np.uint64), pyref.fr_array(exp))
+        side = torch.cuda.Stream()                            # another stream: its own AuxSlot, its own argument buffer
+        with torch.cuda.stream(side):
+            v2 = to_dev(prev)
+            prog.evaluate(cols, v2, challenges=ch, beta=beta, gamma=gamma, theta=theta, y=y)
+        side.synchronize()
+        assert np.array_equal(v2.cpu().numpy().view(np.uint64), pyref.fr_array(exp))
+    finally:
+        prog.destroy()
