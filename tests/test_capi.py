@@ -124,8 +124,55 @@ def test_evaluation_domain_constants(pyref):
     assert fr_words(5).tolist() == o.fr_array([5])[0].tolist()
 
 
-def test_integration_doc_binds_every_entry_point():
-    """INTEGRATION.md shows the reference-side (Rust) `extern "C"` block: one item per header entry."""
-    text = open(os.path.join(os.path.dirname(os.path.abspath(_lib.HEADER_PATH)), "..", "INTEGRATION.md")).read()
-    for name in declared_symbols():
-        assert f"pub fn {name}(" in text, f"{name} has no binding in INTEGRATION.md"
+def _gen():
+    import importlib.util
+    path = os.path.join(os.path.dirname(os.path.abspath(_lib.HEADER_PATH)), "..", "tools", "gen_rust_shim.py")
+    spec = importlib.util.spec_from_file_location("gen_rust_shim", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_rust_bindings_agree_with_the_header_in_arity_and_types():
+    """The reference-side binding (/root/reference/Cargo.toml:10 is what gets patched): the header is parsed as C, the
+    `extern "C"` blocks of rust/halo2-mi355x-sys/src/lib.rs and of INTEGRATION.md as Rust -- two independent parsers -- and
+    every entry must agree in name, return type, arity and the type of each argument (base type, pointer depth, constness
+    of every level).  An argument added or re-typed in the header fails here until the files are regenerated."""
+    gen = _gen()
+    root = os.path.join(os.path.dirname(os.path.abspath(_lib.HEADER_PATH)), "..")
+    c_funcs, c_structs, c_defines = gen.parse_header(open(_lib.HEADER_PATH).read())
+    assert sorted(f[0] for f in c_funcs) == declared_symbols()
+    want = {name: (ret, [t for t, _ in params]) for name, ret, params in c_funcs}
+    assert want["hm_msm_bn256_g1"] == ("c_int", ["u64 c", "u64 c", "usize", "u64 m", "c_int m"])          # the parsers themselves
+    assert want["hm_lookup_permute_batch_bn256_fr_dev"][1][4] == "c_void m c" and want["hm_last_error"] == ("c_char c", [])
+    for path in ("rust/halo2-mi355x-sys/src/lib.rs", "INTEGRATION.md"):
+        text = open(os.path.join(root, path)).read()
+        r_funcs = gen.parse_rust_extern(text)
+        got = {name: (ret, [t for t, _ in params]) for name, ret, params in r_funcs}
+        assert set(got) == set(want), f"{path}: entry points differ from the header: {set(got) ^ set(want)}"
+        for name in want:
+            assert got[name] == want[name], f"{path}: {name} is {got[name]} but the header says {want[name]}"
+        for cname, fields in c_structs.items():            # the #[repr(C)] twins: same fields, same order, same types
+            m = re.search(r"pub struct %s \{(.*?)\}" % gen.STRUCTS[cname], text, flags=re.S)
+            assert m, f"{path}: struct {gen.STRUCTS[cname]} missing"
+            rust_fields = re.findall(r"pub (\w+): (\[\w+; \d+\]|\w+),", m.group(1))
+            assert rust_fields == [(f, f"[{b}; {c}]" if c else b) for f, b, c in fields], f"{path}: {cname} fields differ"
+    # ctypes: the Python binding's arity must agree too
+    for name, (ret, params) in want.items():
+        assert len(_lib._SIGNATURES[name][1]) == len(params), name
+    # hm_stats / hm_msm_stats against the ctypes structures used by the tests
+    assert [f for f, _, _ in c_structs["hm_msm_stats"]] == [f for f, _ in _lib.MsmStats._fields_]
+    assert [f for f, _, _ in c_structs["hm_stats"]] == [f for f, _ in _lib.Stats._fields_]
+
+
+def test_generated_rust_files_are_up_to_date():
+    """rust/ and the extern block of INTEGRATION.md are outputs of tools/gen_rust_shim.py: regenerate and compare."""
+    gen = _gen()
+    for path, text in gen.generate().items():
+        assert os.path.exists(path), f"{path} missing: run tools/gen_rust_shim.py"
+        assert open(path).read() == text, f"{os.path.relpath(path)} is stale: run tools/gen_rust_shim.py"
+    patch = open(os.path.join(gen.RUST_DIR, "halo2_proofs.patch")).read()
+    assert "original_best_multiexp" in patch and "original_best_fft" in patch and "halo2-mi355x-sys" in patch
+    glue = open(os.path.join(gen.RUST_DIR, "halo2_proofs-patch", "src", "mi355x.rs")).read()
+    for fn in re.findall(r"sys::(hm_\w+)", glue):         # the glue only calls entry points the header declares
+        assert fn in declared_symbols(), fn

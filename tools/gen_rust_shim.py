@@ -1,0 +1,430 @@
+#!/usr/bin/env python3
+"""Generate the Rust side of the drop-in boundary from include/halo2_mi355x.h, so that it cannot drift from the header.
+
+    python tools/gen_rust_shim.py            # (re)write rust/ and the extern block of INTEGRATION.md
+    python tools/gen_rust_shim.py --check    # exit 1 if any generated file differs from what is committed
+
+What the reference patches: /root/reference/Cargo.toml:10 pins halo2_proofs (git tag v2023_02_02); the two free functions
+of its arithmetic.rs are the boundary.  Written out here:
+
+    rust/halo2-mi355x-sys/{Cargo.toml, build.rs, src/lib.rs}   the FFI crate: one `extern "C"` item per header entry,
+                                                               #[repr(C)] twins of the two stats structs, the HM_* constants
+    rust/halo2_proofs-patch/src/mi355x.rs                      the glue module added to the patched halo2_proofs
+    rust/halo2_proofs.patch                                    unified diff for the halo2_proofs checkout: the new module,
+                                                               zero-context hunks on the two signatures and on [dependencies]
+    rust/README.md                                             the recipe
+
+There is no Rust toolchain in the build image: none of this has been compiled here.  tests/test_capi.py parses the header
+(C) and the generated extern block (Rust) with two independent parsers and compares names, arity and every argument type.
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import re
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "halo2_mi355x.h")
+RUST_DIR = os.path.join(ROOT, "rust")
+INTEGRATION = os.path.join(ROOT, "INTEGRATION.md")
+BEGIN_MARK = "<!-- BEGIN GENERATED: extern block (tools/gen_rust_shim.py) -->"
+END_MARK = "<!-- END GENERATED -->"
+
+# ---- C side ---------------------------------------------------------------------------------------------------------
+C_SCALARS = {"int": "c_int", "long": "c_long", "size_t": "usize", "uint64_t": "u64", "uint32_t": "u32", "int32_t": "i32",
+             "uint8_t": "u8", "double": "f64", "char": "c_char", "void": "c_void"}
+STRUCTS = {"hm_msm_stats": "HmMsmStats", "hm_stats": "HmStats"}
+
+
+def strip_comments(text: str) -> str:
+    return re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+
+
+def parse_c_type(decl: str):
+    """'const uint64_t* const* name[12]' -> (canonical type, name).  Canonical: base type followed by one 'c' (pointer to
+    const) or 'm' (pointer to mutable) per pointer level, outermost last: 'u64 c' = *const u64, 'c_void c c' = *const *const c_void."""
+    decl = decl.strip()
+    m = re.match(r"^(.*?)(\w+)\s*(\[\s*\w*\s*\])?$", decl, flags=re.S)
+    if not m:
+        raise ValueError(f"cannot parse parameter {decl!r}")
+    ty, name, arr = m.group(1).strip(), m.group(2), m.group(3)
+    if ty == "" or ty == "const":              # unnamed parameter such as 'void'
+        ty, name = decl, ""
+    toks = re.findall(r"\w+|\*", ty)
+    base = [t for t in toks if t not in ("const", "*", "struct")]
+    if len(base) != 1:
+        raise ValueError(f"cannot parse type {ty!r}")
+    b = base[0]
+    rust_base = C_SCALARS.get(b) or STRUCTS.get(b)
+    if rust_base is None:
+        raise ValueError(f"unknown C type {b!r}")
+    # constness of each level: a 'const' binds to what is on its left, or to the base type when it comes first
+    levels = []                                # constness of [base, after 1st *, after 2nd * ...]
+    cur_const = False
+    seen_base = False
+    for t in toks:
+        if t == "const":
+            cur_const = True
+        elif t == "*":
+            levels.append(cur_const)
+            cur_const = False
+        elif t != "struct":
+            seen_base = True
+    levels.append(cur_const)                   # constness of the outermost object (the parameter itself): irrelevant
+    ptrs = [("c" if levels[i] else "m") for i in range(len(levels) - 1)]
+    if arr:                                    # T name[N] decays to T*: pointee constness = constness of the element level
+        ptrs.append("c" if levels[-1] else "m")
+    assert seen_base
+    return " ".join([rust_base] + ptrs), name
+
+
+def parse_header(text: str):
+    """-> (functions [(name, ret canonical, [(canonical type, name)])], structs {c name: [(field, canonical, count)]}, defines)"""
+    clean = strip_comments(text)
+    defines = [(m.group(1), m.group(2)) for m in re.finditer(r"#define\s+(HM_[A-Z0-9_]+)\s+\(?(-?\d+)\)?", clean)]
+    structs = {}
+    for m in re.finditer(r"typedef\s+struct\s+(\w+)\s*\{(.*?)\}\s*(\w+)\s*;", clean, flags=re.S):
+        fields = []
+        for stmt in m.group(2).split(";"):
+            stmt = stmt.strip()
+            if not stmt:
+                continue
+            ty = re.match(r"^(\w+)\s+(.*)$", stmt, flags=re.S)
+            base = C_SCALARS[ty.group(1)]
+            for item in ty.group(2).split(","):
+                im = re.match(r"^\s*(\w+)\s*(?:\[\s*(\d+)\s*\])?\s*$", item)
+                fields.append((im.group(1), base, int(im.group(2)) if im.group(2) else 0))
+        structs[m.group(3)] = fields
+    body = re.sub(r"typedef\s+struct\s+\w+\s*\{.*?\}\s*\w+\s*;", " ", clean, flags=re.S)
+    body = re.sub(r"#.*", " ", body)
+    functions = []
+    for m in re.finditer(r"([\w\s\*]+?)\b(hm_[a-z0-9_]+)\s*\(([^)]*)\)\s*;", body, flags=re.S):
+        ret = " ".join(m.group(1).replace("extern", " ").replace('"C"', " ").split())
+        ret_c, _ = parse_c_type(ret + " _r")
+        params = []
+        plist = m.group(3).strip()
+        if plist and plist != "void":
+            for p in plist.split(","):
+                params.append(parse_c_type(p))
+        functions.append((m.group(2), ret_c, params))
+    return functions, structs, defines
+
+
+def rust_type(canon: str) -> str:
+    parts = canon.split()
+    out = parts[0]
+    for p in parts[1:]:
+        out = ("*const " if p == "c" else "*mut ") + out
+    return out
+
+
+# ---- Rust side (an independent parser: used by the tests on the generated text and on INTEGRATION.md) ---------------------
+def parse_rust_type(t: str) -> str:
+    t = t.strip()
+    ptrs = []
+    while t.startswith("*"):
+        m = re.match(r"^\*(const|mut)\s+(.*)$", t)
+        ptrs.append("c" if m.group(1) == "const" else "m")
+        t = m.group(2).strip()
+    return " ".join([t] + ptrs[::-1])
+
+
+def parse_rust_extern(text: str):
+    """The `extern "C" { ... }` block(s) of a Rust source -> [(name, ret canonical, [(canonical, name)])]"""
+    out = []
+    for blk in re.finditer(r'extern\s+"C"\s*\{(.*?)\n\}', text, flags=re.S):
+        body = re.sub(r"//[^\n]*", "", blk.group(1))
+        for m in re.finditer(r"pub\s+fn\s+(hm_[a-z0-9_]+)\s*\(([^)]*)\)\s*(?:->\s*([^;]+))?;", body, flags=re.S):
+            params = []
+            for p in m.group(2).split(","):
+                p = p.strip()
+                if not p:
+                    continue
+                name, ty = p.split(":", 1)
+                params.append((parse_rust_type(ty), name.strip()))
+            out.append((m.group(1), parse_rust_type(m.group(3)) if m.group(3) else "()", params))
+    return out
+
+
+# ---- emitters -------------------------------------------------------------------------------------------------------
+GROUPS = [   # (comment, prefix tests) -- only cosmetic: the order of the extern block
+    ("lifecycle", ("hm_set_device", "hm_device_count", "hm_shutdown", "hm_last_error", "hm_version")),
+]
+
+
+def emit_extern_block(functions) -> str:
+    lines = ['extern "C" {']
+    for name, ret, params in functions:
+        args = ", ".join(f"{pn or 'arg' + str(i)}: {rust_type(pt)}" for i, (pt, pn) in enumerate(params))
+        line = f"    pub fn {name}({args}) -> {rust_type(ret)};"
+        if len(line) > 150:                     # wrap long prototypes once, at a comma near the middle
+            cut = line.rfind(", ", 0, 140)
+            line = line[:cut + 1] + "\n        " + line[cut + 2:]
+        lines.append(line)
+    lines.append("}")
+    return "\n".join(lines)
+
+
+def emit_structs(structs) -> str:
+    out = []
+    for cname, fields in structs.items():
+        out.append("#[repr(C)]\n#[derive(Clone, Copy, Debug)]\npub struct %s {" % STRUCTS[cname])
+        for fname, base, count in fields:
+            out.append(f"    pub {fname}: " + (f"[{base}; {count}]," if count else f"{base},"))
+        out.append("}\n")
+    return "\n".join(out)
+
+
+def emit_lib_rs(functions, structs, defines) -> str:
+    consts = "\n".join(f"pub const {n}: c_int = {v};" for n, v in defines)
+    return f'''//! halo2-mi355x-sys -- raw bindings of libhalo2_mi355x.so (include/halo2_mi355x.h), the MI355X backend of
+//! halo2_proofs::arithmetic::{{best_multiexp, best_fft}} for bn256.
+//!
+//! GENERATED by tools/gen_rust_shim.py from the header: do not edit; re-run the script when the header changes
+//! (tests/test_capi.py fails when this file and the header disagree on a name, an arity or an argument type).
+//! Not compiled in the repository's build image (no Rust toolchain there).
+#![allow(non_camel_case_types)]
+
+use std::ffi::CStr;
+use std::os::raw::{{c_char, c_int, c_long, c_void}};
+
+{consts}
+
+{emit_structs(structs)}
+{emit_extern_block(functions)}
+
+/// The calling thread's last error message (hm_last_error), as an owned String.
+pub fn last_error() -> String {{
+    unsafe {{ CStr::from_ptr(hm_last_error()) }}.to_string_lossy().into_owned()
+}}
+
+#[allow(dead_code)]
+fn _unused(_: c_long, _: *const c_char, _: *mut c_void) {{}}
+'''
+
+
+CARGO_TOML = '''# GENERATED by tools/gen_rust_shim.py
+[package]
+name = "halo2-mi355x-sys"
+version = "0.3.0"
+edition = "2021"
+description = "Raw FFI bindings of libhalo2_mi355x.so: MI355X (gfx950) BN256 MSM / Fr-NTT backend for halo2_proofs"
+links = "halo2_mi355x"
+build = "build.rs"
+
+[lib]
+name = "halo2_mi355x_sys"
+'''
+
+BUILD_RS = '''// GENERATED by tools/gen_rust_shim.py
+// HALO2_MI355X_LIB_DIR = <this repository>/halo2-experiments_amd/csrc (where `make` leaves libhalo2_mi355x.so)
+fn main() {
+    let dir = std::env::var("HALO2_MI355X_LIB_DIR")
+        .expect("set HALO2_MI355X_LIB_DIR to <repo>/halo2-experiments_amd/csrc (the directory of libhalo2_mi355x.so)");
+    println!("cargo:rustc-link-search=native={dir}");
+    println!("cargo:rustc-link-lib=dylib=halo2_mi355x");
+    println!("cargo:rustc-link-arg=-Wl,-rpath,{dir}");
+    println!("cargo:rerun-if-env-changed=HALO2_MI355X_LIB_DIR");
+}
+'''
+
+MI355X_RS = '''//! mi355x.rs -- glue between halo2_proofs::arithmetic and libhalo2_mi355x.so (added by rust/halo2_proofs.patch).
+//! GENERATED by tools/gen_rust_shim.py (a fixed template: the C entry points it calls are checked against the header
+//! by the repository's tests).  The two functions return None whenever the GPU path does not apply or fails, and the
+//! caller falls through to the untouched upstream body: other curves / fields, tiny inputs, no device, any error code.
+use std::any::TypeId;
+
+use group::Group as _;
+use halo2_mi355x_sys as sys;
+use halo2curves::bn256::{Fr, G1Affine, G1};
+use halo2curves::CurveAffine;
+
+use crate::arithmetic::Group;
+
+/// Below this size launch + PCIe latency dominates: stay on the CPU body.
+pub const GPU_MIN_LOG_N: u32 = 10;
+
+/// halo2curves gives these types no #[repr(C)]; the byte layout the library reads is asserted instead.
+fn layout_ok() -> bool {
+    use std::sync::OnceLock;
+    static OK: OnceLock<bool> = OnceLock::new();
+    *OK.get_or_init(|| {
+        if std::mem::size_of::<Fr>() != 32 || std::mem::size_of::<G1Affine>() != 64 || std::mem::size_of::<G1>() != 96 {
+            return false;
+        }
+        // the generator (1, 2) must read back as x = R mod p, y = 2R mod p (Montgomery words, x before y)
+        let g: [u64; 8] = unsafe { std::mem::transmute(G1Affine::generator()) };
+        g[..4] == [0xd35d438dc58f0d9d, 0x0a78eb28f5c70b3d, 0x666ea36f7879462c, 0x0e0a77c19a07df2f]
+            && g[4..] == [0xa6ba871b8b1e1b3a, 0x14f1d651eb8e167b, 0xccdd46def0f28c58, 0x1c14ef83340fbe5e]
+            && unsafe { sys::hm_device_count() } > 0
+    })
+}
+
+pub fn try_best_multiexp<C: CurveAffine>(coeffs: &[C::Scalar], bases: &[C]) -> Option<C::Curve> {
+    if TypeId::of::<C>() != TypeId::of::<G1Affine>() || coeffs.len() < (1 << GPU_MIN_LOG_N) || !layout_ok() {
+        return None;
+    }
+    let mut xyz = [0u64; 12];
+    let rc = unsafe {
+        sys::hm_msm_bn256_g1_jacobian(coeffs.as_ptr() as *const u64, bases.as_ptr() as *const u64, coeffs.len(), xyz.as_mut_ptr())
+    };
+    if rc != sys::HM_OK {
+        return None;                                    // error policy of the boundary: fall back to the CPU body
+    }
+    // (x, y, 1) Montgomery words, or all zero for the identity: exactly bn256::G1 { x, y, z }
+    let p: G1 = if xyz[8..].iter().all(|w| *w == 0) { G1::identity() } else { unsafe { std::mem::transmute(xyz) } };
+    Some(unsafe { std::mem::transmute_copy(&p) })        // C::Curve == G1 here (checked by the TypeId test above)
+}
+
+pub fn try_best_fft<G: Group>(a: &mut [G], omega: &G::Scalar, log_n: u32) -> bool {
+    if TypeId::of::<G>() != TypeId::of::<Fr>() || log_n < GPU_MIN_LOG_N || log_n > 28 || !layout_ok() {
+        return false;
+    }
+    let rc = unsafe { sys::hm_ntt_bn256_fr(a.as_mut_ptr() as *mut u64, omega as *const _ as *const u64, log_n) };
+    rc == sys::HM_OK
+}
+
+/// One process, several GPUs: every later best_multiexp is split over `devices` inside the library.
+pub fn use_devices(devices: &[i32]) -> bool {
+    unsafe { sys::hm_set_msm_devices(devices.as_ptr(), devices.len() as i32) == sys::HM_OK }
+}
+'''
+
+
+def emit_patch() -> str:
+    new_file = MI355X_RS.rstrip("\n").split("\n")
+    body = "\n".join("+" + l for l in new_file)
+    return f'''# GENERATED by tools/gen_rust_shim.py -- patch for a checkout of privacy-scaling-explorations/halo2 at tag v2023_02_02
+# (the revision /root/reference/Cargo.toml:10 pins), applied from the checkout's halo2_proofs/ directory:
+#     patch -p1 < <this repository>/rust/halo2_proofs.patch
+# The upstream sources are not available in the build image, so the three edits of existing files are ZERO-CONTEXT hunks
+# that depend on one line each (the two function signatures, the [dependencies] header); `patch` finds them by content
+# (line numbers are approximate: expect "offset" messages).  If a hunk is rejected, make the edit by hand: rust/README.md.
+diff --git a/src/mi355x.rs b/src/mi355x.rs
+new file mode 100644
+--- /dev/null
++++ b/src/mi355x.rs
+@@ -0,0 +1,{len(new_file)} @@
+{body}
+diff --git a/src/arithmetic.rs b/src/arithmetic.rs
+--- a/src/arithmetic.rs
++++ b/src/arithmetic.rs
+@@ -130 +130,11 @@
+-pub fn best_multiexp<C: CurveAffine>(coeffs: &[C::Scalar], bases: &[C]) -> C::Curve {{
++#[path = "mi355x.rs"]
++pub mod mi355x;
++
++pub fn best_multiexp<C: CurveAffine>(coeffs: &[C::Scalar], bases: &[C]) -> C::Curve {{
++    assert_eq!(coeffs.len(), bases.len());
++    if let Some(r) = mi355x::try_best_multiexp(coeffs, bases) {{
++        return r;
++    }}
++    original_best_multiexp(coeffs, bases)
++}}
++
++fn original_best_multiexp<C: CurveAffine>(coeffs: &[C::Scalar], bases: &[C]) -> C::Curve {{
+@@ -169 +179,9 @@
+-pub fn best_fft<G: Group>(a: &mut [G], omega: G::Scalar, log_n: u32) {{
++pub fn best_fft<G: Group>(a: &mut [G], omega: G::Scalar, log_n: u32) {{
++    assert_eq!(a.len(), 1 << log_n);
++    if mi355x::try_best_fft(a, &omega, log_n) {{
++        return;
++    }}
++    original_best_fft(a, omega, log_n)
++}}
++
++fn original_best_fft<G: Group>(a: &mut [G], omega: G::Scalar, log_n: u32) {{
+diff --git a/Cargo.toml b/Cargo.toml
+--- a/Cargo.toml
++++ b/Cargo.toml
+@@ -45 +45,2 @@
+-[dependencies]
++[dependencies]
++halo2-mi355x-sys = {{ path = "../../halo2-mi355x-sys" }}
+'''
+
+
+README = '''# rust/ -- the reference-side binding, as files
+
+GENERATED by `tools/gen_rust_shim.py` from `include/halo2_mi355x.h` (re-run it after any header change; `tests/test_capi.py`
+fails when these files and the header disagree).  **Nothing here has been compiled in this repository's build image: it has
+no Rust toolchain.**  The C ABI these files bind is exercised by `tests/` through ctypes and by the C++ mirror.
+
+| path | what |
+|---|---|
+| `halo2-mi355x-sys/` | the FFI crate: `Cargo.toml`, `build.rs` (links `libhalo2_mi355x.so` from `$HALO2_MI355X_LIB_DIR`), `src/lib.rs` (one `extern "C"` item per header entry, `#[repr(C)]` stats structs, `HM_*` constants) |
+| `halo2_proofs-patch/src/mi355x.rs` | the glue module: `try_best_multiexp`, `try_best_fft` (TypeId dispatch on `bn256::G1Affine` / `bn256::Fr`, layout assertions, fall back to the CPU body on any error), `use_devices` |
+| `halo2_proofs.patch` | unified diff for `halo2_proofs/` of privacy-scaling-explorations/halo2 at tag `v2023_02_02` (what `/root/reference/Cargo.toml:10` pins): adds `src/mi355x.rs`, renames the two upstream bodies to `original_*` behind wrappers with the same signatures, adds the dependency |
+
+## Recipe (on a machine with Rust and an MI355X)
+
+```sh
+make -C <repo>/halo2-experiments_amd/csrc                      # libhalo2_mi355x.so
+git clone https://github.com/privacy-scaling-explorations/halo2 && cd halo2 && git checkout v2023_02_02
+cp -r <repo>/rust/halo2-mi355x-sys ..                          # so that ../../halo2-mi355x-sys resolves from halo2_proofs/
+cd halo2_proofs && patch -p1 < <repo>/rust/halo2_proofs.patch
+```
+
+then in the reference's `Cargo.toml` (`/root/reference/Cargo.toml`):
+
+```toml
+[patch."https://github.com/privacy-scaling-explorations/halo2"]
+halo2_proofs = { path = "../halo2/halo2_proofs" }
+```
+
+and `HALO2_MI355X_LIB_DIR=<repo>/halo2-experiments_amd/csrc cargo test --release test_full_prover -- --nocapture`
+(`/root/reference/src/circuits/merkle_sum_tree.rs:345-358`).  The reference's own sources are unchanged.
+
+If `patch` rejects a hunk (the upstream text was written from memory of the tag, one line of context per hunk), make the
+same three edits by hand: (1) copy `halo2_proofs-patch/src/mi355x.rs` to `halo2_proofs/src/`; (2) in `src/arithmetic.rs`
+rename `best_multiexp` / `best_fft` to `original_best_multiexp` / `original_best_fft` (private) and add the two wrappers
+and the `mod mi355x;` item shown in the patch; (3) add the `halo2-mi355x-sys` dependency.
+
+The registered-SRS edit of `ParamsKZG` (INTEGRATION.md §3) adds two fields to an upstream struct and touches every
+constructor; it is left as source in INTEGRATION.md rather than as hunks against text that cannot be checked here.
+'''
+
+
+def generate():
+    functions, structs, defines = parse_header(open(HEADER).read())
+    files = {
+        os.path.join(RUST_DIR, "halo2-mi355x-sys", "Cargo.toml"): CARGO_TOML,
+        os.path.join(RUST_DIR, "halo2-mi355x-sys", "build.rs"): BUILD_RS,
+        os.path.join(RUST_DIR, "halo2-mi355x-sys", "src", "lib.rs"): emit_lib_rs(functions, structs, defines),
+        os.path.join(RUST_DIR, "halo2_proofs-patch", "src", "mi355x.rs"): MI355X_RS,
+        os.path.join(RUST_DIR, "halo2_proofs.patch"): emit_patch(),
+        os.path.join(RUST_DIR, "README.md"): README,
+    }
+    doc = open(INTEGRATION).read()
+    if BEGIN_MARK in doc and END_MARK in doc:
+        a, b = doc.index(BEGIN_MARK) + len(BEGIN_MARK), doc.index(END_MARK)
+        block = "\n```rust\nuse std::os::raw::{c_char, c_int, c_long, c_void};\n\n" + emit_extern_block(functions) + "\n\n" + \
+                emit_structs(structs).rstrip("\n") + "\n```\n"
+        files[INTEGRATION] = doc[:a] + block + doc[b:]
+    return files
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--check", action="store_true")
+    args = ap.parse_args()
+    stale = []
+    for path, text in generate().items():
+        old = open(path).read() if os.path.exists(path) else None
+        if old == text:
+            continue
+        if args.check:
+            stale.append(os.path.relpath(path, ROOT))
+        else:
+            os.makedirs(os.path.dirname(path), exist_ok=True)
+            with open(path, "w") as f:
+                f.write(text)
+            print("wrote", os.path.relpath(path, ROOT))
+    if stale:
+        print("stale generated files (run tools/gen_rust_shim.py):", ", ".join(stale))
+        sys.exit(1)
+
+
+if __name__ == "__main__":
+    main()
