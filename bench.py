@@ -38,11 +38,34 @@ import torch.distributed as dist  # noqa: E402
 
 # The real ceiling of both hot kernels: VALU issue.  256 CUs x 4 SIMD16 units, one
 # wave64 VALU instruction per 4 cycles, at the 2.4 GHz peak engine clock (the chip holds ~2.07-2.2 GHz
-# under these kernels).  Instructions per unit are a property of the build, measured with
-# SQ_INSTS_VALU (profiles/r01_e_sq_counters.txt, tools/pmc_sq.sh): re-measure when the kernels change.
+# under these kernels).  Instructions per unit are a property of the build, measured with SQ_INSTS_VALU
+# (tools/pmc_sq.sh) and baked -- with a hash of the kernel sources they were measured on -- by
+# tools/bake_counters.py; the bench line says "stale": true when those sources have changed since.
 VALU_PEAK_WAVE_INST_PER_S = 256 * 4 * 2.4e9 / 4
-K3_VALU_INST_PER_ADDITION = 8807130936 / (251658240 / 64)      # wave-instructions per 64 mixed additions (profiles/r02_a_sq_counters.txt)
-NTT_VALU_INST_PER_ELEMENT_PASS = 344894123 / (1 << 24)           # wave-instructions per element and pass (x 64 lanes)
+BAKED_COUNTERS_FILE = "profiles/r03_baked_counters.json"
+
+
+def baked_counters():
+    """(figures, stale flags) of the committed counter file; stale = the kernel sources hash differently today."""
+    import hashlib
+    try:
+        with open(os.path.join(ROOT, BAKED_COUNTERS_FILE)) as f:
+            d = json.load(f)
+    except (OSError, ValueError):
+        return None, {"k3": True, "ntt": True}
+    stale = {}
+    for kind in ("k3", "ntt"):
+        hsh = hashlib.sha256()
+        try:
+            for name in d[kind]["sources"]:
+                with open(os.path.join(ROOT, "halo2-experiments_amd", "csrc", name), "rb") as f:
+                    hsh.update(name.encode() + b"\0" + f.read() + b"\0")
+            stale[kind] = hsh.hexdigest() != d[kind]["sources_sha256"]
+        except (OSError, KeyError):
+            stale[kind] = True
+    return d, stale
+
+
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 MSM_BYTES_PER_POINT = 96       # SURVEY.md §8d
 NTT_BYTES_PER_ELEM = 64
@@ -73,8 +96,9 @@ def cpu_model() -> str:
     return "unknown"
 
 
-def cpu_baseline(log_sample, device):
-    """Time the oracle's best_multiexp on a bounded sample (the only use of oracle/ in this file)."""
+def cpu_baseline(log_sample, device, full):
+    """Time the oracle's best_multiexp (by default on the WHOLE 2^24 workload: ~10 s of CPU work on 16 cores, so no smaller
+    sample is needed; --cpu-log-sample shrinks it).  oracle/ is used in this file by the three *cpu_baseline functions only."""
     import halo2_experiments_amd as h
     from oracle import cpu_ref
     cpu_ref.build()
@@ -89,7 +113,8 @@ def cpu_baseline(log_sample, device):
     got = h.best_multiexp(scalars, bases)
     ok = bool(np.array_equal(cpu_ref.g1_to_affine(ref)[0], got[:8]))
     return {"value": n / dt, "unit": "points/s", "cores": threads, "cpus_visible": os.cpu_count(), "cpu_model": cpu_model(), "kind": "port",
-            "sample": f"one 2^{log_sample}-point MSM, same input construction as the timed steps, {dt:.2f} s wall; "
+            "sample": f"one 2^{log_sample}-point MSM ({'the whole timed workload' if full else 'a bounded sample of the timed workload'}), "
+                      f"same input construction as the timed steps, {dt:.2f} s wall; "
                       "C restatement of halo2_proofs v2023_02_02 best_multiexp (not the Rust binary)",
             "agrees_with_gpu": ok}
 
@@ -136,36 +161,106 @@ def known_answer(scalars, t, device):
     return out
 
 
-PMC_TRAFFIC_FILE = "profiles/r02_pmc_traffic.json"      # falls back to round 1's file; the line names which one it used
-SQ_COUNTER_FILE = "profiles/r02_a_sq_counters.txt"        # K3 / NTT instruction counts per launch (tools/pmc_sq.sh)
-
-
-def pmc_traffic(kernel, corrected):
+def pmc_traffic(baked, kernel, corrected):
     """HBM bytes per launch from the committed rocprofv3 --pmc summary (tools/pmc_traffic.sh, separate
     FETCH_SIZE / WRITE_SIZE passes of this same command).  NOT measured in this run: the bench line names
-    the profiles/ file the figure comes from.  `corrected` applies the gfx950 x2 on FETCH_SIZE (calibrated for
-    wide coalesced streams and, this round, for 64-byte gathers: tools/ubench/gather64.hip)."""
-    path = os.path.join(ROOT, PMC_TRAFFIC_FILE)
-    if not os.path.exists(path):
-        path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    the profiles/ file the figure comes from and whether the kernel sources have changed since.  `corrected`
+    applies the gfx950 x2 on FETCH_SIZE (right for wide coalesced streams; 64-byte gathers are counted 1:1:
+    tools/ubench/gather64.hip, profiles/r02_gather64_calibration.json)."""
     try:
-        with open(path) as f:
-            d = json.load(f)[kernel]
+        d = baked["traffic"][kernel]
         if corrected:
             return d["hbm_bytes_per_launch_corrected"]
         return (d["FETCH_SIZE_KiB_per_launch"] + d["WRITE_SIZE_KiB_per_launch"]) * 1024.0
-    except (OSError, KeyError, ValueError):
+    except (KeyError, TypeError):
         return None
 
 
-def valu_issue(wave_instructions: float, kernel_ms: float) -> dict:
+def valu_issue(baked, stale, kind: str, units: float, kernel_ms: float):
     """The binding resource of the hot kernels, next to the contract's HBM roofline: VALU wave-instructions
-    issued per second against what 1024 SIMD16 units can issue at the peak clock."""
-    achieved = wave_instructions / (kernel_ms * 1e-3)
+    issued per second against what 1024 SIMD16 units can issue at the peak clock.  `units` = (point, bucket)
+    pairs for K3, element-passes for the NTT."""
+    try:
+        per_unit = baked[kind]["sq_insts_valu_per_launch"] / baked[kind]["pairs_per_launch" if kind == "k3" else "elements_per_launch"]
+    except (KeyError, TypeError):
+        return None
+    achieved = per_unit * units / (kernel_ms * 1e-3)
     return {"achieved": achieved, "peak": VALU_PEAK_WAVE_INST_PER_S, "unit": "wave-instr/s",
-            "frac": achieved / VALU_PEAK_WAVE_INST_PER_S,
-            "note": f"NOT measured in this run: instruction counts per unit are SQ_INSTS_VALU figures from {SQ_COUNTER_FILE} "
-                    "(same kernel source); peak = 1024 SIMDs x 2.4 GHz / 4"}
+            "frac": achieved / VALU_PEAK_WAVE_INST_PER_S, "wave_instr_per_64_units": per_unit * 64, "stale": bool(stale[kind]),
+            "note": f"NOT measured in this run: SQ_INSTS_VALU per unit from {baked[kind]['from']} via {BAKED_COUNTERS_FILE}; "
+                    "stale = the kernel sources listed there hash differently now; peak = 1024 SIMDs x 2.4 GHz / 4"}
+
+
+def cpu_info():
+    from oracle import cpu_ref
+    return {"cores": cpu_ref.default_threads(), "cpus_visible": os.cpu_count(), "cpu_model": cpu_model(), "kind": "port"}
+
+
+def ntt_cpu_baseline(log_n, device):
+    """oracle/cpu_ref.c:ref_best_fft (the C restatement of upstream's best_fft: serial bit reversal, serial twiddle
+    table, recursive butterflies on the thread pool) on the same input as the timed GPU transform."""
+    import halo2_experiments_amd as h
+    from halo2_experiments_amd.domain import FR_MODULUS, FR_ROOT_OF_UNITY, fr_words
+    from oracle import cpu_ref
+    cpu_ref.build()
+    omega = fr_words(pow(FR_ROOT_OF_UNITY, 1 << (28 - log_n), FR_MODULUS))
+    a_d = rand_fr(1 << log_n, 99, device)
+    a = a_d.cpu().numpy().view(np.uint64)
+    info = cpu_info()
+    t0 = time.perf_counter()
+    ref = cpu_ref.best_fft(a, omega, log_n, info["cores"])
+    dt = time.perf_counter() - t0
+    h.best_fft(a_d, omega, log_n)
+    torch.cuda.synchronize()
+    ok = bool(np.array_equal(ref, a_d.cpu().numpy().view(np.uint64)))
+    info.update({"value": (1 << log_n) / dt, "unit": "elements/s", "ms": dt * 1e3,
+                 "sample": f"one 2^{log_n}-element best_fft (the whole timed workload, same input), {dt:.2f} s wall incl. the copy of the "
+                           "array; C restatement of halo2_proofs v2023_02_02 best_fft (not the Rust binary)",
+                 "agrees_with_gpu": ok})
+    return info
+
+
+def replay_cpu_baseline(rep, device):
+    """The CPU counterpart of the four timings the reference prints (/root/reference/src/circuits/utils.rs:66-69) for one
+    replayed create_proof: each DISTINCT call shape of the trace timed once on the oracle (MSM 2^k on a sparse advice-like
+    column and on a dense column; best_fft at 2^k and at 2^extended_k), times the trace's call counts.  The coset shift,
+    zero padding and divisor sweeps upstream does around its FFTs, and everything of create_proof that is not an MSM or
+    an NTT, are NOT in this figure (it is the counterpart of device_resident_s.msm + .ntt, not of .total)."""
+    import halo2_experiments_amd as h
+    from halo2_experiments_amd.arithmetic import G1_GENERATOR
+    from halo2_experiments_amd.domain import FR_MODULUS, FR_ROOT_OF_UNITY, fr_words
+    from halo2_experiments_amd.replay import SHAPES, _rand_fr, _sparse_column
+    from oracle import cpu_ref
+    cpu_ref.build()
+    k, ek = rep["k"], rep["extended_k"]
+    n = 1 << k
+    used = next(sh.used_rows for sh in SHAPES.values() if sh.name == rep["circuit"])
+    bases = h.g1_fixed_base_mul(_rand_fr(n, 77, device), G1_GENERATOR).cpu().numpy().view(np.uint64)
+    dense = _rand_fr(n, 78, device).cpu().numpy().view(np.uint64)
+    sparse = _sparse_column(n, used, 79, device).cpu().numpy().view(np.uint64)
+    info = cpu_info()
+    T = info["cores"]
+
+    def timed(fn):
+        t0 = time.perf_counter()
+        fn()
+        return time.perf_counter() - t0
+
+    per = {"msm_sparse": timed(lambda: cpu_ref.best_multiexp(sparse, bases, T)),
+           "msm_dense": timed(lambda: cpu_ref.best_multiexp(dense, bases, T)),
+           "intt_n": timed(lambda: cpu_ref.best_fft(dense, fr_words(pow(FR_ROOT_OF_UNITY, 1 << (28 - k), FR_MODULUS)), k, T))}
+    ext = np.zeros((1 << ek, 4), dtype=np.uint64)
+    ext[:n] = dense
+    per["coset_ntt_ext"] = timed(lambda: cpu_ref.best_fft(ext, fr_words(pow(FR_ROOT_OF_UNITY, 1 << (28 - ek), FR_MODULUS)), ek, T))
+    per["intt_ext"] = per["coset_ntt_ext"]
+    calls = rep["calls"]
+    msm = per["msm_sparse"] * calls["msm_sparse"] + per["msm_dense"] * calls["msm_dense"]
+    ntt = per["intt_n"] * calls["intt_n"] + per["coset_ntt_ext"] * (calls["coset_ntt_ext"] + calls["intt_ext"])
+    info.update({"per_call_s": per, "calls": calls, "msm_s": msm, "ntt_s": ntt, "total_s": msm + ntt, "unit": "s",
+                 "gpu_msm_plus_ntt_s": rep["device_resident_s"]["msm"] + rep["device_resident_s"]["ntt"],
+                 "sample": "each distinct call shape timed ONCE on the oracle (oracle/cpu_ref.c, C restatement of halo2_proofs "
+                           "v2023_02_02 best_multiexp / best_fft), multiplied by the trace's call counts; MSM + best_fft only"})
+    return info
 
 
 def main():
@@ -175,7 +270,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--log-points", type=int, default=24, help="log2 of the points per GPU")
     ap.add_argument("--log-ntt", type=int, default=24)
-    ap.add_argument("--cpu-log-sample", type=int, default=21)
+    ap.add_argument("--cpu-log-sample", type=int, default=0, help="log2 of the CPU baseline's MSM (default: the timed size, capped at 24)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ntt", action="store_true")
     ap.add_argument("--replay", default="poseidon_k11,merkle_v3_k17,merkle_sum_tree_k18",
@@ -209,6 +304,7 @@ def main():
     import halo2_experiments_amd as h
     from halo2_experiments_amd import _lib
     from halo2_experiments_amd.sharding import shard_range, sharded_multiexp
+    baked, stale = baked_counters()
 
     n_local = 1 << args.log_points
     n_global = n_local * world
@@ -287,12 +383,14 @@ def main():
         gbs = (NTT_BYTES_PER_ELEM << k) / (ms * 1e-3) / 1e9
         ntt = {"log_n": k, "ms": ms, "elements_per_s": (1 << k) / (ms * 1e-3),
                "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                            "traffic": (pmc_traffic("hm::ntt_pass_kernel<11>", True) if k == 24 else None),
+                            "traffic": (pmc_traffic(baked, "hm::ntt_pass_kernel<11>", True) if k == 24 else None),
+                            "traffic_note": f"NOT measured in this run: per pass launch, from {BAKED_COUNTERS_FILE}; stale = {bool(stale['ntt'])}",
                             "note": "traffic is per pass launch; 3 digit passes => 3x the algorithmic 64 B/element per transform; "
                                     "VALU-issue bound (~3.9e3 32-bit ops per element)",
-                            "valu_issue": valu_issue(NTT_VALU_INST_PER_ELEMENT_PASS * (1 << k) * (3 if k > 21 else 2 if k > 11 else 1),
-                                                     ms)}}
+                            "valu_issue": valu_issue(baked, stale, "ntt", (1 << k) * (3 if k > 21 else 2 if k > 11 else 1), ms)}}
         del a
+        if world == 1 and not args.no_cpu_baseline:
+            ntt["cpu_baseline"] = ntt_cpu_baseline(k, device)
 
     # ---- side measurements: prover-like scalars; the PCIe-inclusive drop-in call ----
     extras = None
@@ -403,10 +501,14 @@ def main():
         del scalars
         torch.cuda.empty_cache()
         replay = [run_replay(name, device=device) for name in args.replay.split(",")]   # every rank takes part
+        if rank == 0 and world == 1 and not args.no_cpu_baseline:
+            for rep in replay:
+                rep["cpu_baseline"] = replay_cpu_baseline(rep, device)
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(args.cpu_log_sample, device)
+        log_sample = args.cpu_log_sample or min(args.log_points, 24)
+        cpu = cpu_baseline(log_sample, device, full=log_sample == args.log_points)
 
     if rank == 0:
         acc = float(np.median(acc_ms))
@@ -434,12 +536,13 @@ def main():
                        "all-gather of 96 B partials (RCCL) + host fold"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": (pmc_traffic("hm::msm_accumulate_kernel", False) if args.log_points == 24 else None),
-                         "traffic_note": f"NOT measured in this run: rocprofv3 --pmc figure from {PMC_TRAFFIC_FILE} (same kernel source); "
+                         "traffic": (pmc_traffic(baked, "hm::msm_accumulate_kernel", False) if args.log_points == 24 else None),
+                         "traffic_note": f"NOT measured in this run: rocprofv3 --pmc figure via {BAKED_COUNTERS_FILE} "
+                                         f"(stale = {bool(stale['k3'])}: whether the kernel sources changed since); "
                                          "every base is gathered once per window (W = 15), inherent to bucketed Pippenger",
                          "kernel": "msm_accumulate_kernel", "kernel_ms": acc,
                          "note": "integer-VALU bound (SURVEY.md §8d): ~2.5e8 mixed additions x ~2.35e3 32-bit ops per launch",
-                         "valu_issue": valu_issue(st["pairs"] / 64.0 * K3_VALU_INST_PER_ADDITION, acc)},
+                         "valu_issue": valu_issue(baked, stale, "k3", st["pairs"], acc)},
             "msm_phase_ms": {"sort": float(np.median(sort_ms)), "accumulate_kernel": acc, "device_total": float(np.median(tot_ms))},
             "known_answer_ok": answer_ok,
         }

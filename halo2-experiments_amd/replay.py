@@ -5,8 +5,9 @@ sequence of ``best_multiexp`` / ``EvaluationDomain`` calls that ``create_proof``
 circuit of a given shape (upstream ``halo2_proofs/src/plonk/prover.rs`` at the tag
 pinned by /root/reference/Cargo.toml:10), on synthetic polynomials: dense columns uniform in
 [0, r); sparse columns zero except ``used_rows`` small values and the last 6 (blinding) rows.
-The column counts are the estimates of SURVEY.md §3.2 -- labelled as such in the output; a Rust
-build of the shim would replace them with counted calls.
+The column counts, lookups, equality columns and degree come from the constraint systems transcribed in circuits.py
+(the reference's chip files); the CALL counts per column follow upstream's prover loops as recalled --
+a Rust build of the shim (rust/) would replace them with counted calls (hm_get_stats).
 
 What is replayed per proof (A advice, L lookups, P equality columns, max degree d, n = 2^k,
 extended domain 2^ek with ek = k + ceil(log2(d-1))):
@@ -15,14 +16,15 @@ extended domain 2^ek with ek = k + ceil(log2(d-1))):
     lagrange_to_coeff (iNTT n, scale fused)          A + 1 instance + 3L + Zp
     coeff_to_extended (coset NTT 2^ek, shift fused)  A + 1 + 3L + Zp
     extended_to_coeff (iNTT 2^ek)                    1
-    evaluate_h gates  (GraphEvaluator over 2^ek rows)  one Poseidon-like gate program (estimate of the expression graph)
+    evaluate_h        (GraphEvaluator over 2^ek rows)  the circuit's own program: gates, permutation argument, lookup arguments,
+                                                        vanishing-polynomial division (circuits.py)
     eval_polynomial   (Horner, n coefficients)         2A + 3 Zp + 5L + (d-1) queries (estimate)
     grand products    (batch_invert + running product over n rows)   Zp + L  (permutation / lookup z columns)
     lookup permute    (permute_expression_pair: two 256-bit sorts + arrangement over n - 7 rows)   L
     multiopen         (linear combination of the committed polynomials per rotation set, kate_division per opening
                        point, final combination + division)          4 sets, 5 points (estimate)
-Everything else in ``create_proof`` (witness synthesis, the permutation / lookup terms of ``evaluate_h``, the lookup
-transcript) stays on the CPU in the reference and is NOT part of this number.
+Everything else in ``create_proof`` (witness synthesis, the transcript) stays on the CPU in the reference and is NOT part
+of this number.
 
 Like the reference's harness (prove, THEN verify: /root/reference/src/circuits/merkle_sum_tree.rs:345-358), a
 replay checks what it computed: the SRS is a real one (g = [s^i]G, g_lagrange = [L_i(s)]G with a known s), and
@@ -63,15 +65,21 @@ class CircuitShape:
     source: str
 
 
-# SURVEY.md §3.2 / §8d estimates (reference files named there)
-SHAPES = {
-    "poseidon_k11": CircuitShape("Poseidon (config 2)", 11, 6, 0, 5, 7, 40,
-                                 "chips/poseidon/hash.rs:50-57; estimate"),
-    "merkle_v3_k17": CircuitShape("MerkleTreeV3 depth 20 (config 3)", 17, 8, 0, 6, 7, 840,
-                                  "chips/merkle_v3.rs:5-7,70-73; estimate"),
-    "merkle_sum_tree_k18": CircuitShape("MerkleSumTree depth 20 (config 4)", 18, 20, 8, 12, 7, 1100,
-                                        "chips/merkle_sum_tree.rs:32-138; estimate"),
-}
+def _shapes():
+    """Column counts, lookups, equality columns and the maximum degree come from the constraint systems transcribed in
+    circuits.py (the reference's chip files, cited there; Pow5Chip / LtChip as recalled) -- not from estimates.  `used_rows`
+    (how many rows of a 2^k column synthesis fills) stays an estimate: it is a property of the floor planner's layout."""
+    from .circuits import CONSTRAINT_SYSTEMS
+    ks = {"poseidon_k11": (11, 40), "merkle_v3_k17": (17, 840), "merkle_sum_tree_k18": (18, 1100)}
+    out = {}
+    for key, make in CONSTRAINT_SYSTEMS.items():
+        cs = make()
+        out[key] = CircuitShape(cs.name, ks[key][0], cs.num_advice, len(cs.lookups), len(cs.equality), cs.degree(), ks[key][1],
+                                cs.source + "; used_rows estimated")
+    return out
+
+
+SHAPES = _shapes()
 
 
 def _rand_fr(n, seed, device):
@@ -166,25 +174,20 @@ def run_replay(shape_name: str, device=None, group=None, include_host_pointer_es
 
     streams = [torch.cuda.Stream(device=device) for _ in range(in_flight)]
 
-    # evaluate_h gate program (estimate: Poseidon-like S-box / MDS gates over 3 state columns) and the evaluation queries
-    from .evaluation import Advice, Challenge, Fixed, GraphEvaluator, Instance
-    width = 3
-    st, nx = [Advice(i) for i in range(width)], [Advice(i, 1) for i in range(width)]
-    rc = [Fixed(2 + i) for i in range(width)]
-    pow5 = lambda x: (x * x) * (x * x) * x
-    gates = []
-    for i in range(width):
-        acc = None
-        for j in range(width):
-            term = pow5(st[j] + rc[j]) * ((3 * i + 7 * j + 11) % FR_MODULUS)
-            acc = term if acc is None else acc + term
-        gates.append(Fixed(0) * (acc - nx[i]))
-    gates.append(Fixed(1) * (pow5(st[0] + rc[0]) - Advice(0, -1)))
-    gates.append(Challenge(0) * (Instance(0) - st[1]) * Fixed(1))
-    ge = GraphEvaluator()
-    ge.add_custom_gates(gates)
-    gate_prog = ge.compile(2 + width, width, 1, num_challenges=1, rot_scale=1 << (dom.extended_k - k))
-    gate_cols = lambda e: [e[i % e.shape[0]] for i in range(2 + width + width + 1)]
+    # evaluate_h: the circuit's own program (circuits.py: the gates of the reference's chips, the permutation argument over
+    # its equality columns, its lookup arguments, divide_by_vanishing_poly as the last multiplication) over 2^extended_k rows
+    from .circuits import CONSTRAINT_SYSTEMS, evaluate_h_program
+    cs = CONSTRAINT_SYSTEMS[shape_name]()
+    ge, lay = evaluate_h_program(cs, k, dom.extended_k, delta=pow(7, 1 << 28, FR_MODULUS))
+    gate_prog = ge.compile(lay.num_fixed_entries, cs.num_advice, cs.num_instance, num_challenges=0, rot_scale=1 << (dom.extended_k - k),
+                           short_columns=lay.short_columns)
+    t_inv_col = _rand_fr(1 << (dom.extended_k - k), 500, device)          # the 2^(extended_k - k) values of 1 / (X^n - 1) on the coset
+
+    def gate_cols(e):            # every column of the table aliases one of the extended arrays (the arithmetic does not care)
+        cols = [e[i % e.shape[0]] for i in range(lay.num_fixed_entries + cs.num_advice + cs.num_instance)]
+        cols[lay.t_inv] = t_inv_col
+        return cols
+
     h_values = torch.zeros((dom.extended_len(), 4), dtype=torch.int64, device=device)
     n_queries = 2 * A + 3 * zp + 5 * L + (d - 1)              # advice at ~2 rotations, permutation / lookup products at 3 ...
     eval_index = np.arange(n_queries, dtype=np.uint32) % 8
@@ -246,13 +249,13 @@ def run_replay(shape_name: str, device=None, group=None, include_host_pointer_es
                     dom.extended_to_coeff(ext[0])
         torch.cuda.synchronize()
         t["ntt"] = time.perf_counter() - t0
-        # evaluate_h's gate arithmetic over the extended domain (the device GraphEvaluator on a Poseidon-like gate program:
-        # an estimate of the circuit's real expression graph) and the Horner evaluations at x * omega^rot
+        # evaluate_h over the extended domain (the device GraphEvaluator on the circuit's own program) and the Horner
+        # evaluations at x * omega^rot
         t0 = time.perf_counter()
         if rank == 0 and ext is not None:
-            gate_prog.evaluate(gate_cols(ext), h_values, challenges=[12345], y=REPLAY_S)
+            gate_prog.evaluate(gate_cols(ext), h_values, beta=REPLAY_S + 1, gamma=REPLAY_S + 2, theta=REPLAY_S + 3, y=REPLAY_S)
         torch.cuda.synchronize()
-        t["evaluate_h_gates"] = time.perf_counter() - t0
+        t["evaluate_h"] = time.perf_counter() - t0
         t0 = time.perf_counter()
         if rank == 0:
             eval_polynomial(ntt_batch, eval_points, poly_index=eval_index)
@@ -319,11 +322,13 @@ def run_replay(shape_name: str, device=None, group=None, include_host_pointer_es
         "shape": {"advice": A, "lookups": L, "equality_columns": shape.equality_columns, "max_degree": d,
                   "source": shape.source},
         "calls": counts,
-        "device_resident_s": {"msm": phases["msm"], "ntt": phases["ntt"], "evaluate_h_gates": phases["evaluate_h_gates"],
+        "device_resident_s": {"msm": phases["msm"], "ntt": phases["ntt"], "evaluate_h": phases["evaluate_h"],
                               "eval_polynomial": phases["eval_polynomial"], "grand_products": phases["grand_products"],
                               "lookup_permute": phases["lookup_permute"], "multiopen": phases["multiopen"], "total": wall},
-        "beyond_msm_ntt": {"evaluate_h_gates": f"{len(gate_prog.calcs)} GraphEvaluator calculations per row over 2^{dom.extended_k} rows "
-                                               "(Poseidon-like gate program: an estimate of the circuit's expression graph)",
+        "beyond_msm_ntt": {"evaluate_h": f"{len(gate_prog.calcs)} GraphEvaluator calculations per row over 2^{dom.extended_k} rows: "
+                                         f"{len(cs.polynomials())} gate polynomials of {cs.source}, the permutation argument over "
+                                         f"{len(cs.equality)} columns in {cs.permutation_sets()} sets, {len(cs.lookups)} lookup arguments, "
+                                         "the vanishing-polynomial division",
                            "eval_polynomial": f"{n_queries} Horner evaluations of 2^{k}-coefficient polynomials (estimate)",
                            "grand_products": f"one batch inversion of {zp + L} x 2^{k} denominators, {zp + L} running products over 2^{k} rows",
                            "lookup_permute": f"{L} x permute_expression_pair over 2^{k} - 7 rows (range-check column: 256-bit bitonic sorts + arrangement)",
@@ -355,11 +360,19 @@ def run_replay(shape_name: str, device=None, group=None, include_host_pointer_es
         best_multiexp_batch([h_sparse] * counts["msm_sparse"], gl_h)
         best_multiexp_batch([h_dense] * counts["msm_dense"], gl_h)
         t_batch_host = time.perf_counter() - t0
+        hp_total = t_msm * (counts["msm_sparse"] + counts["msm_dense"]) + t_ntt_n * counts["intt_n"] \
+            + t_ntt_e * (counts["coset_ntt_ext"] + counts["intt_ext"])
+        # the two totals side by side: what a prover gets from the UNMODIFIED drop-in (every best_multiexp / best_fft call
+        # moves its arrays over PCIe) and what it gets once its polynomials stay in HBM -- neither hidden behind the other
+        out["total_s"] = {"drop_in_host_pointers": hp_total, "device_resident": wall,
+                          "drop_in_with_batched_commitments": hp_total - t_msm * (counts["msm_sparse"] + counts["msm_dense"]) + t_batch_host,
+                          "note": "drop_in_host_pointers = per-call times of hm_msm_bn256_g1_h / hm_ntt_bn256_fr x the trace's counts (MSM and "
+                                  "NTT only); drop_in_with_batched_commitments replaces the per-call MSMs by two hm_msm_batch_bn256_g1_h "
+                                  "calls; device_resident = the whole replayed trace, polynomials in HBM (includes the non-MSM/NTT steps)"}
         out["host_pointer_estimate_s"] = {
             "msm_batches_from_host_arrays": t_batch_host,
             "msm_each": t_msm, "ntt_n_each": t_ntt_n, "ntt_ext_each": t_ntt_e,
-            "total": t_msm * (counts["msm_sparse"] + counts["msm_dense"]) + t_ntt_n * counts["intt_n"]
-                     + t_ntt_e * (counts["coset_ntt_ext"] + counts["intt_ext"]),
+            "total": hp_total,
             "note": "PCIe-inclusive: every call uploads its scalars / moves its array both ways"}
     gate_prog.destroy()
     if world > 1 and not job_mode:

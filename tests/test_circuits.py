@@ -1,0 +1,146 @@
+"""The constraint systems of the reference's circuits as evaluate_h programs (halo2-experiments_amd/circuits.py).
+
+CPU: the transcription against what the reference's chip files say (column counts, equality columns, gate counts, lookups;
+/root/reference/src/chips/merkle_sum_tree.rs:32-138, merkle_v3.rs:30-82, poseidon/hash.rs:45-72) and the builder against
+direct evaluation of the expression trees.  GPU: the device interpreter on each whole program -- gates, permutation
+argument, lookup arguments, vanishing-polynomial division -- against the oracle's restatement of upstream's loops."""
+import random
+
+import numpy as np
+import pytest
+
+from halo2_experiments_amd import circuits, evaluation as ev
+from halo2_experiments_amd.domain import FR_MODULUS
+
+R = FR_MODULUS
+
+
+def test_merkle_sum_tree_constraint_system_matches_the_chip():
+    cs = circuits.merkle_sum_tree()
+    # merkle_sum_tree.rs: 5 chip columns (:27-31 of the circuit), 5 hash inputs (:103), PoseidonChip's partial_sbox
+    # (poseidon/hash.rs:50), LtChip's lt + 8 diff bytes (LtConfig<F, 8>, :21)
+    assert cs.num_advice == 5 + 5 + 1 + 1 + 8 == 20
+    assert cs.num_instance == 1
+    # 4 chip selectors (:44-47), rc_a + rc_b (hash.rs:51-52: 2 x WIDTH), Pow5Chip's 3 selectors, LtChip's u8 table
+    assert cs.num_fixed == 4 + 10 + 3 + 1
+    # equality: a..e and the instance column (:53-58), the 5 hash inputs (hash.rs:54-56), rc_b[0] (enable_constant, hash.rs:57)
+    assert cs.equality == [("advice", i) for i in range(5)] + [("instance", 0)] + [("advice", 5 + i) for i in range(5)] + [("fixed", 9)]
+    names = [n for n, _ in cs.gates]
+    assert names == ["bool constraint", "swap constraint", "sum constraint", "full round", "partial rounds", "pad-and-add", "lt gate",
+                     "check == is_lt"]
+    counts = {n: len(p) for n, p in cs.gates}
+    assert counts == {"bool constraint": 1, "swap constraint": 2, "sum constraint": 1, "full round": 5, "partial rounds": 6,
+                      "pad-and-add": 5, "lt gate": 2, "check == is_lt": 1}
+    assert len(cs.lookups) == 8 and all(len(i) == 1 and len(t) == 1 for i, t in cs.lookups)
+    assert cs.degree() == 6                       # selector x (state + rc)^5
+    assert cs.permutation_chunk_len() == 4 and cs.permutation_sets() == 3
+
+
+def test_the_transcribed_gates_hold_on_a_satisfying_row():
+    """The swap / sum / bool gates of merkle_sum_tree.rs:62-101 evaluated directly on a row that satisfies them, and on a
+    tampered one (the reference's negative tests change one witness value and expect failure: merkle_sum_tree.rs:214-343)."""
+    from oracle import graph_ref
+    cs = circuits.merkle_sum_tree()
+    gates = dict(cs.gates)
+    rng = random.Random(5)
+    a, b, c, d = (rng.randrange(R) for _ in range(4))
+    for e in (0, 1):
+        l1, l2, r1, r2 = (c, d, a, b) if e else (a, b, c, d)
+        adv = [{0: a, 1: l1}, {0: b, 1: l2}, {0: c, 1: r1}, {0: d, 1: r2}, {0: e}] + [{0: 0, 1: 0, 7: 0} for _ in range(15)]
+        fixed = [{0: 1, 1: 1} for _ in range(cs.num_fixed)]
+        for p in gates["swap constraint"] + gates["bool constraint"]:
+            assert graph_ref.evaluate_expression(p, fixed, adv, [{0: 0}], [], 0, 1, 8) == 0
+        adv[0][1] = (l1 + 1) % R                  # left output tampered
+        assert graph_ref.evaluate_expression(gates["swap constraint"][0], fixed, adv, [{0: 0}], [], 0, 1, 8) != 0
+    adv = [{0: 0}, {0: 30}, {0: 0}, {0: 12}, {0: 42}] + [{0: 0} for _ in range(15)]
+    fixed = [{0: 1} for _ in range(cs.num_fixed)]
+    assert graph_ref.evaluate_expression(gates["sum constraint"][0], fixed, adv, [{0: 0}], [], 0, 1, 8) == 0
+    adv[4][0] = 43
+    assert graph_ref.evaluate_expression(gates["sum constraint"][0], fixed, adv, [{0: 0}], [], 0, 1, 8) != 0
+
+
+def test_the_other_two_circuits():
+    v3, po = circuits.merkle_v3(), circuits.poseidon()
+    assert (v3.num_advice, v3.num_fixed, v3.num_instance) == (3 + 3 + 1, 2 + 6 + 3, 1)          # merkle_v3.rs:30-82
+    assert [n for n, _ in v3.gates] == ["bool constraint", "swap constraint", "full round", "partial rounds", "pad-and-add"]
+    assert len(v3.polynomials()) == 1 + 1 + 3 + 4 + 3 and not v3.lookups and v3.degree() == 6
+    assert (po.num_advice, po.num_fixed, po.num_instance) == (5 + 1, 10 + 3, 1)                    # circuits/poseidon.rs:36-41
+    assert len(po.polynomials()) == 5 + 6 + 5 and len(po.equality) == 5 + 1 + 1
+
+
+@pytest.mark.parametrize("name", sorted(circuits.CONSTRAINT_SYSTEMS))
+def test_builder_equals_direct_evaluation_of_every_gate(name):
+    """GraphEvaluator::add_expression's rules and CSE on the circuit's own gate polynomials: the straight-line program's
+    value equals Horner in y over the expression trees evaluated directly (both on the oracle's integers)."""
+    from oracle import graph_ref
+    cs = circuits.CONSTRAINT_SYSTEMS[name]()
+    g, _ = circuits.evaluate_h_program(cs, 3, 6, 7, with_arguments=False)
+    rng = random.Random(len(name))
+    isize, rot_scale = 1 << 6, 1 << 3
+    mk = lambda cnt: [[rng.randrange(R) for _ in range(isize)] for _ in range(cnt)]
+    fixed, advice, instance = mk(cs.num_fixed), mk(cs.num_advice), mk(cs.num_instance)
+    y = rng.randrange(R)
+    prev = [rng.randrange(R) for _ in range(isize)]
+    got = graph_ref.evaluate_graph(g.calculations, g.constants, g.rotations, fixed, advice, instance, [], 0, 0, 0, y, prev, rot_scale, isize)
+    for idx in (0, 5, isize - 1):
+        v = prev[idx]
+        for p in cs.polynomials():
+            v = (v * y + graph_ref.evaluate_expression(p, fixed, advice, instance, [], idx, rot_scale, isize)) % R
+        assert got[idx] == v, (name, idx)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(circuits.CONSTRAINT_SYSTEMS))
+def test_device_evaluate_h_of_each_circuit_matches_the_oracle(pyref, name):
+    """The WHOLE evaluate_h program of each configuration (what the k = 11 / 17 / 18 replays time at 2^(k+3) rows) at a small
+    k: device interpreter vs the oracle's interpreter of the same straight-line program, and -- for the argument terms --
+    vs the oracle's restatement of upstream's hand-written row loops (evaluate_h_permutation_and_lookups)."""
+    import torch
+    from oracle import graph_ref
+    cs = circuits.CONSTRAINT_SYSTEMS[name]()
+    k, ek = 4, 7
+    n, isize, rot_scale = 1 << k, 1 << ek, 1 << (ek - k)
+    delta = pow(7, 1 << 28, R)
+    g, lay = circuits.evaluate_h_program(cs, k, ek, delta)
+    rng = random.Random(7 + len(name))
+    col = lambda rows=isize: [rng.randrange(R) for _ in range(rows)]
+    w_ext, zeta = pyref.fr_omega(ek), pyref.FR_ZETA
+    fixed = [col() for _ in range(lay.num_fixed_entries)]
+    fixed[lay.x_coset] = [zeta * pow(w_ext, i, R) % R for i in range(isize)]
+    t_inv = [pow((pow(zeta * pow(w_ext, i, R) % R, n, R) - 1) % R, -1, R) for i in range(rot_scale)]
+    fixed[lay.t_inv] = t_inv
+    advice, instance = [col() for _ in range(cs.num_advice)], [col() for _ in range(cs.num_instance)]
+    beta, gamma, theta, y = (rng.randrange(R) for _ in range(4))
+    prev = col()
+    # 1. the straight-line program on the oracle's interpreter (short column: its pattern repeated)
+    full_fixed = [c * (isize // len(c)) for c in fixed]
+    exp = graph_ref.evaluate_graph(g.calculations, g.constants, g.rotations, full_fixed, advice, instance, [], beta, gamma, theta, y, prev,
+                                   rot_scale, isize)
+    # 2. the argument terms by upstream's row loops, started from the gates' running value
+    g_gates, _ = circuits.evaluate_h_program(cs, k, ek, delta, with_arguments=False)
+    after_gates = graph_ref.evaluate_graph(g_gates.calculations, g_gates.constants, g_gates.rotations, full_fixed[:cs.num_fixed], advice,
+                                           instance, [], beta, gamma, theta, y, prev, rot_scale, isize)
+    table = {"advice": advice, "fixed": full_fixed, "instance": instance}
+    perm_cols = [table[kd][i] for kd, i in cs.equality]
+    P, nsets = len(cs.equality), cs.permutation_sets()
+    lookups = []
+    for j, (ins, tabs) in enumerate(cs.lookups):
+        b = lay.lookup0 + 3 * j
+        ev_col = lambda e: [graph_ref.evaluate_expression(e, full_fixed, advice, instance, [], i, rot_scale, isize) for i in range(isize)]
+        lookups.append(([ev_col(e) for e in ins], [ev_col(e) for e in tabs], full_fixed[b], full_fixed[b + 1], full_fixed[b + 2]))
+    exp2 = graph_ref.evaluate_h_permutation_and_lookups(after_gates, y, beta, gamma, theta, isize, rot_scale, w_ext, zeta, delta, perm_cols,
+                                                        full_fixed[lay.sigma0:lay.sigma0 + P], full_fixed[lay.z0:lay.z0 + nsets],
+                                                        cs.permutation_chunk_len(), -(cs.blinding_factors + 1), full_fixed[lay.l0],
+                                                        full_fixed[lay.l_last], full_fixed[lay.l_active], lookups, t_inverse=t_inv)
+    assert exp == exp2, name
+    # 3. the device
+    to_dev = lambda c: torch.from_numpy(pyref.fr_array(c).view(np.int64)).cuda()
+    cols = [to_dev(c) for c in fixed + advice + instance]
+    values = to_dev(prev)
+    prog = g.compile(lay.num_fixed_entries, cs.num_advice, cs.num_instance, num_challenges=0, rot_scale=rot_scale, short_columns=lay.short_columns)
+    try:
+        prog.evaluate(cols, values, beta=beta, gamma=gamma, theta=theta, y=y)
+        torch.cuda.synchronize()
+        assert np.array_equal(values.cpu().numpy().view(np.uint64), pyref.fr_array(exp)), name
+    finally:
+        prog.destroy()

@@ -87,12 +87,17 @@ def test_setup_commit_and_file_round_trip(cref, pyref, tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["poseidon_k11", "merkle_v3_k17"])
+@pytest.mark.parametrize("name", ["poseidon_k11", "merkle_v3_k17", "merkle_sum_tree_k18"])
 def test_replays_verify_their_commitments(name):
-    """BASELINE configs[1] / [2]: the create_proof trace replay checks every commitment it computes against the
-    KZG identity (prove, then verify -- merkle_sum_tree.rs:345-358); config 3 (k = 18) runs in bench.py."""
+    """BASELINE configs[1] / [2] / [3]: the create_proof trace replay checks every commitment it computes against the
+    KZG identity (prove, then verify -- merkle_sum_tree.rs:345-358).  Config 4's flow (k = 18: 20 advice columns, 8
+    lookups, 12 equality columns, evaluate_h over 2^21 rows with the MerkleSumTree chip's own gate program) included."""
     import torch
     from halo2_experiments_amd.replay import run_replay
     r = run_replay(name, device=torch.device("cuda", 0), include_host_pointer_estimate=False)
     assert r["verified"]["commitments_checked"] >= 3 * (r["calls"]["msm_sparse"] + r["calls"]["msm_dense"])
     assert r["verified"]["distinct_column_base_pairs"] == 6
+    from halo2_experiments_amd.circuits import CONSTRAINT_SYSTEMS
+    cs = CONSTRAINT_SYSTEMS[name]()
+    assert r["shape"]["advice"] == cs.num_advice and r["shape"]["lookups"] == len(cs.lookups) and r["shape"]["max_degree"] == cs.degree()
+    assert f"{len(cs.polynomials())} gate polynomials" in r["beyond_msm_ntt"]["evaluate_h"]
