@@ -266,6 +266,7 @@ int hm_shutdown(void) try {
     c.batch_streams_ready = false;
   }
   for (auto& b : c.batch_io) b.release();
+  c.live_io.release();
   c.io.release(); c.io_bases.release(); c.conv_bases.release(); c.conv_inf.release();
   c.cached_host_n = 0;
   c.cached_xy = nullptr;
@@ -493,44 +494,106 @@ static int msm_batch_impl(DeviceCtx* ctx, uint64_t handle, size_t offset, const 
   // the GPU.  So (1) where the five-launch plan applies the commitments go through it in GROUPS -- one launch chain
   // carries up to HM_MSM_GROUP of them -- and (2) the calling thread only submits chains while a second thread of this
   // call awaits the tickets in order and folds.
-  uint32_t per_chain = 1;
-  {
-    std::lock_guard<std::mutex> lk(ctx->mu);
-    BasesEntry* b = find_bases(*ctx, handle);
-    if (!b) return hm_fail(HM_ERR_NOT_FOUND, "hm_msm_batch_bn256_g1_dev: unknown base handle");
-    if (offset > b->n || n > b->n - offset) return hm_fail(HM_ERR_BAD_ARG, "hm_msm_batch_bn256_g1_dev: offset + n exceeds the base set");
-    const uint32_t pc = (offset == 0 && n == b->n) ? b->pc_c : 0u;
-    // groups pay where a commitment alone is bound by launch gaps (small n); at 2^17 and above eight separate chains in
-    // flight interleave their phases better than one chain of eight (measured at 2^18: 0.57 ms against 0.79 ms per dense
-    // commitment), so there every commitment keeps its own chain
-    static const size_t group_max_n = [] { const char* v = std::getenv("HALO2_MI355X_GROUP_MAX_LOG"); return (size_t)1 << (v && *v ? std::atoi(v) : 16); }();
-    if (msm_group_applies(n, pc) && n <= group_max_n) {
-      // enough chains to keep several in flight, none longer than a group: ceil(count / chains)
-      const size_t chains_min = (count + HM_MSM_GROUP - 1) / HM_MSM_GROUP;
-      const size_t chains = chains_min < 4 && count >= 8 ? 4 : chains_min;
-      per_chain = (uint32_t)((count + chains - 1) / (chains ? chains : 1));
-      if (per_chain < 1) per_chain = 1;
-    } else if (msm_group_applies(n, pc)) {
-      static const uint32_t big_group = [] { const char* v = std::getenv("HALO2_MI355X_GROUP_BIG"); return (uint32_t)(v && *v ? std::atoi(v) : 1); }();
-      per_chain = big_group < 1 ? 1 : (big_group > (uint32_t)HM_MSM_GROUP ? (uint32_t)HM_MSM_GROUP : big_group);
-      if (per_chain > count) per_chain = (uint32_t)count;
-    }
-  }
   for (size_t i = 0; i < count; ++i)
     if (!d_scalars[i] && n) return hm_fail(HM_ERR_BAD_ARG, "hm_msm_batch_bn256_g1_dev: null scalar array");
-  const size_t n_chains = (count + per_chain - 1) / per_chain;
+  // The chain plan: `order` lists the columns in submission order, chain ch carries order[first[ch] .. first[ch + 1]).
+  std::vector<uint32_t> order(count), first;
+  for (size_t i = 0; i < count; ++i) order[i] = (uint32_t)i;
+  {
+    bool small_plan = false;
+    const uint8_t* d_inf = nullptr;
+    {
+      std::lock_guard<std::mutex> lk(ctx->mu);
+      BasesEntry* b = find_bases(*ctx, handle);
+      if (!b) return hm_fail(HM_ERR_NOT_FOUND, "hm_msm_batch_bn256_g1_dev: unknown base handle");
+      if (offset > b->n || n > b->n - offset) return hm_fail(HM_ERR_BAD_ARG, "hm_msm_batch_bn256_g1_dev: offset + n exceeds the base set");
+      const uint32_t pc = (offset == 0 && n == b->n) ? b->pc_c : 0u;
+      small_plan = msm_group_applies(n, pc);
+      d_inf = b->d_inf + offset;
+    }
+    static const size_t group_max_n = [] { const char* v = std::getenv("HALO2_MI355X_GROUP_MAX_LOG"); return (size_t)1 << (v && *v ? std::atoi(v) : 16); }();
+    static const bool group_sparse = [] { const char* v = std::getenv("HALO2_MI355X_GROUP_SPARSE"); return !(v && *v == '0'); }();
+    if (small_plan && n <= group_max_n) {
+      // a commitment alone is bound by launch gaps here: consecutive groups, enough chains to keep several in flight,
+      // none longer than a group: ceil(count / chains)
+      // (and as many chains as waiter threads when there are commitments for them: the host fold of a chain's results is
+      // serial per chain)
+      const size_t chains_min = (count + HM_MSM_GROUP - 1) / HM_MSM_GROUP;
+      const size_t want = count / 2 < 4 ? count / 2 : 4;
+      const size_t chains = chains_min > want ? chains_min : want;
+      size_t per_chain = (count + chains - 1) / (chains ? chains : 1);
+      if (per_chain < 1) per_chain = 1;
+      for (size_t f = 0; f < count; f += per_chain) first.push_back((uint32_t)f);
+    } else if (small_plan && group_sparse && count >= 2) {
+      // 2^17 .. 2^18: what a column costs depends on how many of its 256-row blocks SURVIVE the digits kernel's
+      // compaction (zero scalars and identity bases contribute nothing), not on n.  A dense column is throughput-bound
+      // and keeps a chain of its own (eight separate chains in flight interleave their phases better than one chain of
+      // eight: measured 0.57 against 0.79 ms per commitment at 2^18); a SPARSE one -- an advice column with ~1 100 used
+      // rows of 2^18 -- is pure chain latency (0.098 ms each one chain at a time, 36 of them 3.5 ms), so up to eight of
+      // them share one launch chain.  The classification only decides the grouping, never the result.
+      std::vector<uint32_t> live(count, 0);
+      const uint32_t total_blocks = (uint32_t)((n + 255) / 256);
+      int crc = from_host ? HM_OK : msm_count_live_blocks(*ctx, d_scalars, count, d_inf, n, (hipStream_t)stream, live.data());
+      if (crc != HM_OK) return crc;
+      if (from_host) {
+        // host arrays: a sample decides (reading every word on the host would cost more than the upload): every 64th
+        // block, never the first two or the last one (used rows lead, blinding rows trail)
+        for (size_t i = 0; i < count; ++i) {
+          const uint64_t* s = (const uint64_t*)d_scalars[i];
+          uint32_t hits = 0, seen = 0;
+          for (uint32_t blk = 2; blk + 1 < total_blocks; blk += 64) {
+            const size_t lo = (size_t)blk * 256, hi = lo + 256 < n ? lo + 256 : n;
+            uint64_t any = 0;
+            for (size_t w = lo * 4; w < hi * 4; ++w) any |= s[w];
+            hits += any != 0;
+            ++seen;
+          }
+          live[i] = seen == 0 || hits != 0 ? total_blocks : 0;
+        }
+      }
+      std::vector<uint32_t> pending, plan;
+      auto flush = [&]() {
+        if (pending.empty()) return;
+        first.push_back((uint32_t)plan.size());
+        plan.insert(plan.end(), pending.begin(), pending.end());
+        pending.clear();
+      };
+      for (size_t i = 0; i < count; ++i) {
+        if ((uint64_t)live[i] * 16 <= total_blocks) {           // sparse: joins the pending group
+          pending.push_back((uint32_t)i);
+          if (pending.size() == (size_t)HM_MSM_GROUP) flush();
+        } else {                                                 // dense: a chain of its own
+          first.push_back((uint32_t)plan.size());
+          plan.push_back((uint32_t)i);
+        }
+      }
+      flush();
+      order = plan;
+    } else {
+      for (size_t f = 0; f < count; ++f) first.push_back((uint32_t)f);
+    }
+    first.push_back((uint32_t)count);
+  }
+  const size_t n_chains = first.size() - 1;
   uint64_t tickets[kLanes];
-  std::atomic<size_t> issued{0}, done{0};
+  // chain ch uses lane ch % kLanes; the lane is free again once chain ch - kLanes has been awaited (finished[] is set)
+  std::unique_ptr<std::atomic<uint8_t>[]> finished(new std::atomic<uint8_t>[n_chains + 1]);
+  for (size_t i = 0; i <= n_chains; ++i) finished[i].store(0, std::memory_order_relaxed);
+  std::atomic<size_t> issued{0};
   std::atomic<int> submit_rc{HM_OK}, wait_rc{HM_OK};
   std::atomic<bool> no_more{false};
   int device = 0;
   HM_HIP_CHECK(hipGetDevice(&device));
-  auto await_chain = [&](size_t d) {           // chain d covers the MSMs d * per_chain ...
+  auto await_chain = [&](size_t d) {           // chain d carries the MSMs order[first[d] .. first[d + 1])
     int wrc;
     try {
       hm_fault_point("batch_await");
-      wrc = wait_chain(ctx, tickets[d % kLanes], out_xyz + 12 * d * per_chain, per_chain);
-    } catch (...) {                            // nothing may escape the waiter thread, and `done` must still advance
+      uint64_t res[12 * HM_MSM_GROUP];
+      const uint32_t members = first[d + 1] - first[d];
+      wrc = wait_chain(ctx, tickets[d % kLanes], res, members);
+      if (wrc == HM_OK)
+        for (uint32_t e = 0; e < members; ++e) std::memcpy(out_xyz + 12 * (size_t)order[first[d] + e], res + 12 * e, 96);
+    } catch (...) {                            // nothing may escape a waiter thread, and the chain must still count as awaited
       wrc = HM_ERR_INTERNAL;
       abandon_ticket(ctx, tickets[d % kLanes]);
     }
@@ -538,49 +601,79 @@ static int msm_batch_impl(DeviceCtx* ctx, uint64_t handle, size_t offset, const 
       int expect = HM_OK;
       (void)wait_rc.compare_exchange_strong(expect, wrc);
     }
-    done.store(d + 1, std::memory_order_release);
+    finished[d].store(1, std::memory_order_release);
   };
-  auto waiter = [&]() {
+  // Finishing a chain is host work too: the event wait, then a 255-doubling fold per commitment (~50 us each: 2 ms for
+  // the 36 advice columns of a k = 18 proof on one thread -- measured as 40 % GPU idle time in that phase).  So up to
+  // kWaiters threads of this call await the chains, waiter t taking chains t, t + T, t + 2T, ...; the calling thread
+  // only submits.  They are started after the first lanes are filled, so that their creation overlaps the GPU's work.
+  constexpr size_t kWaiters = 4;
+  size_t n_waiters = 0;                         // set before any waiter starts
+  auto waiter = [&](size_t t) {
     (void)hipSetDevice(device);
-    for (;;) {
-      const size_t d = done.load(std::memory_order_relaxed);
-      while (issued.load(std::memory_order_acquire) == d) {
-        if (no_more.load(std::memory_order_acquire) && issued.load(std::memory_order_acquire) == d) return;
+    for (size_t d = t; d < n_chains; d += n_waiters) {
+      while (issued.load(std::memory_order_acquire) <= d) {
+        if (no_more.load(std::memory_order_acquire) && issued.load(std::memory_order_acquire) <= d) return;
         std::this_thread::yield();
       }
       await_chain(d);                          // even after an error: no ticket is left behind
     }
   };
-  // the waiter is told to finish and is joined on EVERY way out of this function (an exception in the submit loop included)
+  // the waiters are told to finish and are joined on EVERY way out of this function (an exception in the submit loop included)
   struct WaiterGuard {
     std::atomic<bool>& no_more;
     JoinOnExit pool;
     ~WaiterGuard() { no_more.store(true, std::memory_order_release); }     // members are destroyed after this body: then the join
   } guard{no_more, {}};
-  bool threaded = n_chains > 2 && spawn_or_false(guard.pool, "batch_waiter_spawn", waiter);   // no thread to be had: this one awaits between submissions
+  bool threaded = false, waiters_started = false;
+  size_t next_unthreaded = 0;                   // without waiters: the next chain the calling thread has to await itself
+  auto start_waiters = [&]() {
+    waiters_started = true;
+    if (n_chains <= 1) return;                  // a lone chain: the calling thread awaits it
+    n_waiters = n_chains < kWaiters ? n_chains : kWaiters;
+    size_t started = 0;
+    for (size_t t = 0; t < n_waiters; ++t)
+      if (spawn_or_false(guard.pool, "batch_waiter_spawn", [&waiter, t] { waiter(t); })) ++started;
+      else break;
+    if (started == n_waiters) {
+      threaded = true;
+    } else {                                    // not every waiter could be had: the ones that started take what they take,
+      no_more.store(true, std::memory_order_release);   // ... are drained, and this thread awaits everything still open
+      for (auto& th : guard.pool.th) th.join();
+      guard.pool.th.clear();
+      no_more.store(false, std::memory_order_release);
+    }
+  };
+  auto await_unthreaded_upto = [&](size_t limit) {      // the calling thread awaits every issued, unfinished chain below `limit`
+    for (; next_unthreaded < limit && next_unthreaded < issued.load(); ++next_unthreaded)
+      if (!finished[next_unthreaded].load(std::memory_order_acquire)) await_chain(next_unthreaded);
+  };
   // host arrays are staged per lane in buffers of the device context: whole _h batch calls of different threads take turns
   std::unique_lock<std::mutex> host_turn;
   if (from_host) host_turn = std::unique_lock<std::mutex>(ctx->batch_h_mu);
   std::string submit_error;
   for (size_t ch = 0; ch < n_chains; ++ch) {
-    while (ch - done.load(std::memory_order_acquire) >= (size_t)kLanes) {      // every lane holds a ticket
-      if (threaded) std::this_thread::yield();
-      else await_chain(done.load(std::memory_order_relaxed));
+    if (ch >= (size_t)kLanes) {                 // every lane holds a ticket: chain ch - kLanes has to be awaited first
+      if (!waiters_started) start_waiters();
+      while (!finished[ch - kLanes].load(std::memory_order_acquire)) {
+        if (threaded) std::this_thread::yield();
+        else await_unthreaded_upto(ch - kLanes + 1);
+      }
     }
-    const size_t first = ch * per_chain;
-    const uint32_t group = (uint32_t)(count - first < per_chain ? count - first : per_chain);
+    const uint32_t group = first[ch + 1] - first[ch];
     int rc;
     // host arrays: this chain's scalars cross PCIe on its own lane's stream (the lane's staging buffer is free again:
     // the chain that used it eight chains ago has been awaited), while the other lanes' chains compute
     const void* staged[HM_MSM_GROUP];
-    const void* const* chain_scalars = d_scalars + first;
+    for (uint32_t e = 0; e < group; ++e) staged[e] = d_scalars[order[first[ch] + e]];
+    const void* const* chain_scalars = staged;
     if (from_host && n) {
       const int lane = (int)(ch % kLanes);
       const double t_h2d0 = now_us();
       uint8_t* buf;
       {
         std::lock_guard<std::mutex> lk(ctx->mu);
-        buf = (uint8_t*)ctx->batch_io[lane].ensure((size_t)per_chain * n * 32);
+        buf = (uint8_t*)ctx->batch_io[lane].ensure((size_t)group * n * 32);
       }
       if (!buf) {
         submit_rc.store(hm_fail(HM_ERR_HIP, "hm_msm_batch_bn256_g1_h: staging allocation failed"));
@@ -589,7 +682,7 @@ static int msm_batch_impl(DeviceCtx* ctx, uint64_t handle, size_t offset, const 
       }
       hipError_t herr = hipSuccess;
       for (uint32_t e = 0; e < group && herr == hipSuccess; ++e) {
-        herr = hipMemcpyAsync(buf + (size_t)e * n * 32, d_scalars[first + e], n * 32, hipMemcpyHostToDevice, ctx->batch_streams[lane]);
+        herr = hipMemcpyAsync(buf + (size_t)e * n * 32, staged[e], n * 32, hipMemcpyHostToDevice, ctx->batch_streams[lane]);
         staged[e] = buf + (size_t)e * n * 32;
       }
       if (herr != hipSuccess) {
@@ -597,7 +690,6 @@ static int msm_batch_impl(DeviceCtx* ctx, uint64_t handle, size_t offset, const 
         submit_error = hm_last_error();
         break;
       }
-      chain_scalars = staged;
       std::lock_guard<std::mutex> lk(ctx->mu);
       ctx->calls.msm_h2d_us += now_us() - t_h2d0;
       ctx->calls.h2d_bytes += (uint64_t)group * n * 32;
@@ -609,7 +701,8 @@ static int msm_batch_impl(DeviceCtx* ctx, uint64_t handle, size_t offset, const 
                         "hm_msm_batch_bn256_g1_dev", &all_busy);
       if (rc == HM_OK || !all_busy) break;
       if (now_us() - t_wait0 > 60e6) break;     // nobody awaits the tickets that hold the slots: report instead of spinning
-      if (!threaded && done.load() < issued.load()) await_chain(done.load());     // free one of our own first
+      if (!waiters_started) start_waiters();
+      if (!threaded && next_unthreaded < issued.load()) await_unthreaded_upto(next_unthreaded + 1);     // free one of our own first
       else std::this_thread::yield();
     }
     if (rc != HM_OK) {
@@ -619,12 +712,13 @@ static int msm_batch_impl(DeviceCtx* ctx, uint64_t handle, size_t offset, const 
     }
     issued.store(ch + 1, std::memory_order_release);
   }
+  if (!waiters_started) start_waiters();
   no_more.store(true, std::memory_order_release);
   if (threaded) {
     for (auto& t : guard.pool.th) t.join();
-  } else {
-    while (done.load() < issued.load()) await_chain(done.load());
+    guard.pool.th.clear();
   }
+  await_unthreaded_upto(n_chains);              // whatever no waiter took (none when they all started)
   if (submit_rc.load() != HM_OK) return hm_fail(submit_rc.load(), submit_error);
   if (wait_rc.load() != HM_OK) return hm_fail(wait_rc.load(), "hm_msm_batch_bn256_g1_dev: a commitment of the batch failed (see the waiter's error)");
   return HM_OK;

@@ -214,6 +214,7 @@ struct DeviceCtx {
   hipEvent_t batch_event = nullptr;
   bool batch_streams_ready = false;
   DevBuf batch_io[HM_MSM_SLOTS - 1];                  // hm_msm_batch_bn256_g1_h: per-lane staging of host scalar arrays
+  DevBuf live_io;                                     // msm_count_live_blocks: column pointers in, block counts out
   std::mutex batch_h_mu;                              // ... which belong to ONE _h batch call at a time (taken before mu, never under it)
   uint64_t next_handle = 1;
   // drop-in MSM: the converted bases of the previous call, keyed by a digest of the WHOLE host array (capi.hip)
@@ -318,6 +319,10 @@ int msm_launch_digits(const uint32_t* d_scalars_ext, const uint8_t* d_inf, int32
 bool msm_small_applies(size_t n, uint32_t c, bool single_set);
 int msm_issue_small(DeviceCtx& ctx, int slot, const uint32_t* const* d_scalars_list, uint32_t group, const uint32_t* d_xy,
                     const uint8_t* d_inf, size_t n, uint32_t c, hipStream_t stream);
+// live_out[i] = how many 256-row blocks of column i hold a row that survives the digits kernel's compaction (a non-zero
+// scalar on a non-identity base); synchronises `stream` (one small copy).  Decides the grouping of a phase of commitments.
+int msm_count_live_blocks(DeviceCtx& ctx, const void* const* d_columns, size_t count, const uint8_t* d_inf, size_t n, hipStream_t stream,
+                          uint32_t* live_out);
 // a group of MSMs over the same points through one chain (only where the five-launch plan applies: msm_group_applies)
 bool msm_group_applies(size_t n, uint32_t precomp_c);
 int msm_enqueue_group(DeviceCtx& ctx, int slot, const uint32_t* const* d_scalars_list, uint32_t group, const uint32_t* d_xy,

@@ -523,6 +523,42 @@ __global__ __launch_bounds__(WIN_THREADS) void msm_s_reduce2_kernel(const uint32
   }
 }
 
+// ---- which columns of a phase are sparse: surviving 256-row blocks per column -----------------------------------
+__global__ __launch_bounds__(SA_THREADS) void msm_s_live_blocks_kernel(const uint32_t* const* __restrict__ columns,
+                                                                       const uint8_t* __restrict__ inf, uint32_t n,
+                                                                       uint32_t* __restrict__ counts) {
+  const uint32_t* __restrict__ scalars = columns[blockIdx.y];
+  const uint32_t i = blockIdx.x * SA_THREADS + threadIdx.x;
+  uint32_t any = 0;
+  if (i < n && inf[i] == 0) {
+    const uint4* q = reinterpret_cast<const uint4*>(scalars + (size_t)i * 8);
+    const uint4 lo = q[0], hi = q[1];
+    any = lo.x | lo.y | lo.z | lo.w | hi.x | hi.y | hi.z | hi.w;      // a fully reduced Montgomery word is zero iff the scalar is
+  }
+  if (__syncthreads_or(any != 0 ? 1 : 0) && threadIdx.x == 0) atomicAdd(&counts[blockIdx.y], 1u);
+}
+
+int msm_count_live_blocks(DeviceCtx& ctx, const void* const* d_columns, size_t count, const uint8_t* d_inf, size_t n, hipStream_t stream,
+                          uint32_t* live_out) {
+  if (count == 0 || n == 0) return HM_OK;
+  if (count > 65535) return hm_fail(HM_ERR_BAD_ARG, "msm: more than 65535 commitments in one phase");
+  uint8_t* buf;
+  {
+    std::lock_guard<std::mutex> lk(ctx.mu);
+    buf = (uint8_t*)ctx.live_io.ensure(count * (sizeof(void*) + 4));
+  }
+  if (!buf) return hm_fail(HM_ERR_HIP, "msm: live-block buffer allocation failed");
+  uint32_t* d_counts = (uint32_t*)(buf + count * sizeof(void*));
+  HM_HIP_CHECK(hipMemcpyAsync(buf, d_columns, count * sizeof(void*), hipMemcpyHostToDevice, stream));
+  HM_HIP_CHECK(hipMemsetAsync(d_counts, 0, count * 4, stream));
+  hipLaunchKernelGGL(msm_s_live_blocks_kernel, dim3((uint32_t)((n + SA_THREADS - 1) / SA_THREADS), (uint32_t)count), dim3(SA_THREADS), 0, stream,
+                     (const uint32_t* const*)buf, d_inf, (uint32_t)n, d_counts);
+  HM_HIP_CHECK(hipGetLastError());
+  HM_HIP_CHECK(hipMemcpyAsync(live_out, d_counts, count * 4, hipMemcpyDeviceToHost, stream));
+  HM_HIP_CHECK(hipStreamSynchronize(stream));
+  return HM_OK;
+}
+
 // ---- host ----------------------------------------------------------------------------------------
 static int env_int(const char* name, int dflt) {
   const char* v = std::getenv(name);

@@ -15,6 +15,7 @@ n = 1 << k
 dev = torch.device("cuda", 0)
 hd = h.register_bases(h.g1_fixed_base_mul(_rand_fr(n, 1, dev), G1_GENERATOR))
 cols = {"dense": _rand_fr(n, 2, dev), "sparse": _sparse_column(n, 1100, 3, dev)}
+if os.environ.get("KIND"): cols = {os.environ["KIND"]: cols[os.environ["KIND"]]}
 for name, col in cols.items():
     for c in counts:
         h.best_multiexp_batch([col] * c, hd); h.best_multiexp_batch([col] * c, hd); torch.cuda.synchronize()
