@@ -1296,20 +1296,32 @@ int hm_graph_create(const uint32_t* calcs, size_t n_calc, const uint64_t* consta
   return graph_create(*ctx, calcs, n_calc, constants, n_const, n_dynamic, rotations, n_rot, n_columns, n_intermediates, out_handle);
 } HM_API_CATCH("hm_graph_create")
 
-int hm_graph_evaluate_dev(uint64_t handle, const void* const* d_columns, size_t n_columns, const uint64_t* dynamic_constants,
-                          size_t n_dynamic, uint32_t log_size, void* d_values, void* stream) try {
+static int graph_evaluate_entry(const char* who, uint64_t handle, const void* const* d_columns, size_t n_columns,
+                                const uint64_t* dynamic_constants, size_t n_dynamic, uint32_t log_size, void* d_values, uint32_t flags,
+                                void* stream) {
   if (!d_values || (n_columns && !d_columns) || (n_dynamic && !dynamic_constants))
-    return hm_fail(HM_ERR_BAD_ARG, "hm_graph_evaluate_dev: null argument");
+    return hm_fail(HM_ERR_BAD_ARG, std::string(who) + ": null argument");
   DeviceCtx* ctx = ctx_for_current_device();
   if (!ctx) return HM_ERR_NO_DEVICE;
   std::lock_guard<std::mutex> lk(ctx->mu);
   for (auto& g : ctx->graphs)
     if (g->handle == handle) {
       count_vector(*ctx, HM_STAT_GRAPH_EVALUATE, 1, log_size < 40 ? (uint64_t)1 << log_size : 0);
-      return graph_evaluate(*ctx, *g, d_columns, n_columns, dynamic_constants, n_dynamic, log_size, d_values, (hipStream_t)stream);
+      return graph_evaluate(*ctx, *g, d_columns, n_columns, dynamic_constants, n_dynamic, log_size, d_values, flags, (hipStream_t)stream);
     }
-  return hm_fail(HM_ERR_NOT_FOUND, "hm_graph_evaluate_dev: unknown program handle");
+  return hm_fail(HM_ERR_NOT_FOUND, std::string(who) + ": unknown program handle");
+}
+
+int hm_graph_evaluate_dev(uint64_t handle, const void* const* d_columns, size_t n_columns, const uint64_t* dynamic_constants,
+                          size_t n_dynamic, uint32_t log_size, void* d_values, void* stream) try {
+  return graph_evaluate_entry("hm_graph_evaluate_dev", handle, d_columns, n_columns, dynamic_constants, n_dynamic, log_size, d_values, 0, stream);
 } HM_API_CATCH("hm_graph_evaluate_dev")
+
+int hm_graph_evaluate_flags_dev(uint64_t handle, const void* const* d_columns, size_t n_columns, const uint64_t* dynamic_constants,
+                                size_t n_dynamic, uint32_t log_size, void* d_values, uint32_t flags, void* stream) try {
+  return graph_evaluate_entry("hm_graph_evaluate_flags_dev", handle, d_columns, n_columns, dynamic_constants, n_dynamic, log_size, d_values,
+                              flags, stream);
+} HM_API_CATCH("hm_graph_evaluate_flags_dev")
 
 int hm_graph_destroy(uint64_t handle) try {
   DeviceCtx* ctx = ctx_for_current_device();

@@ -169,14 +169,20 @@ struct AuxSlot {
 };
 constexpr int HM_AUX_SLOTS = 4;
 
-struct GraphProgram {       // a compiled evaluate_h program (graph.hip): device form + constants + rotations
-  uint64_t handle = 0;
-  void* d_blob = nullptr;
+struct GraphVariant {       // the program lowered for one column format (graph.hip: graph_lower)
   void* d_calcs = nullptr;
+  uint32_t n_calc = 0, n_slots = 1, result_src = 0, result_prev = 0;
+  bool ready = false;
+};
+struct GraphProgram {       // a compiled evaluate_h program (graph.hip): the validated program + its lowered device forms
+  uint64_t handle = 0;
+  void* d_blob = nullptr;     // constants + rotations
   uint32_t* d_consts = nullptr;
   int32_t* d_rot = nullptr;
-  uint32_t n_calc = 0, n_slots = 1, result_src = 0, n_static = 0, n_dynamic = 0;
+  std::vector<uint32_t> calcs5;      // as given to hm_graph_create
+  uint32_t n_intermediates = 0, n_static = 0, n_dynamic = 0;
   size_t n_columns = 0;
+  GraphVariant variant[2];           // [0] external-form columns, [1] internal-form columns (HM_GRAPH_COLUMNS_INTERNAL)
 };
 
 struct FreeBases {          // buffers of a released base set, kept for the next registration of that size
@@ -277,7 +283,7 @@ int graph_create(DeviceCtx& ctx, const uint32_t* calcs5, size_t n_calc, const ui
                  size_t n_dynamic, const int32_t* rotations, size_t n_rot, size_t n_columns, uint32_t n_intermediates,
                  uint64_t* out_handle);
 int graph_evaluate(DeviceCtx& ctx, GraphProgram& g, const void* const* d_columns, size_t n_columns, const uint64_t* dyn_ext,
-                   size_t n_dyn, uint32_t log_size, void* d_values, hipStream_t stream);
+                   size_t n_dyn, uint32_t log_size, void* d_values, uint32_t flags, hipStream_t stream);
 void graph_release(GraphProgram& g);
 
 // poly.hip

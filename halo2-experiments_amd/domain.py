@@ -82,9 +82,11 @@ class EvaluationDomain:
         self._ifft(a, self.omega_inv, self.k, self.ifft_divisor)
         return a
 
-    def coeff_to_extended(self, a):
+    def coeff_to_extended(self, a, internal: bool = False):
         """(n, 4) or (batch, n, 4) coefficient tensor -> new (2^extended_k, 4) / (batch, 2^extended_k, 4)
-        tensor of evaluations on the zeta-coset."""
+        tensor of evaluations on the zeta-coset.  ``internal``: the evaluations come out multiplied by 32 -- the form
+        ``hm_graph_evaluate_flags_dev(HM_GRAPH_COLUMNS_INTERNAL)`` loads without a conversion product; the factor rides on the
+        coset constants the first NTT pass multiplies in anyway."""
         import torch
 
         batch = self._batch_of(a, self.n, "coeff_to_extended")
@@ -92,7 +94,8 @@ class EvaluationDomain:
         a = a.contiguous()
         ext = torch.empty((batch, en, 4), dtype=a.dtype, device=a.device)      # the zero part is never materialised
         r = FR_MODULUS
-        coset = np.concatenate([fr_words(1), fr_words(self.g_coset), fr_words(self.g_coset * self.g_coset % r)])
+        sc = 32 if internal else 1
+        coset = np.concatenate([fr_words(sc), fr_words(sc * self.g_coset), fr_words(sc * self.g_coset * self.g_coset % r)])
         _lib.check(_lib.load().hm_coeff_to_extended_bn256_fr_dev(
             ctypes.c_void_p(a.data_ptr()), ctypes.c_void_p(ext.data_ptr()), batch, _ptr(fr_words(self.extended_omega)), self.k,
             self.extended_k, _ptr(coset), ctypes.c_void_p(_stream_ptr(ext))))

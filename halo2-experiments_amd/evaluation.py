@@ -309,9 +309,10 @@ class CompiledGraph:
         self.handle = h.value
 
     def evaluate(self, columns: Sequence, values, challenges: Sequence[int] = (), beta: int = 0, gamma: int = 0, theta: int = 0,
-                 y: int = 0) -> None:
+                 y: int = 0, columns_internal: bool = False) -> None:
         """``columns``: GPU tensors (size, 4), fixed then advice then instance; ``values``: (size, 4) GPU tensor holding
-        PreviousValue on entry and the program's value on return."""
+        PreviousValue on entry and the program's value on return.  ``columns_internal``: every column holds 32 * value
+        (HM_GRAPH_COLUMNS_INTERNAL: what ``EvaluationDomain.coeff_to_extended(..., internal=True)`` writes)."""
         size = _tensor_rows(values, 4, "values")
         if size & (size - 1) or size == 0:
             raise ValueError("evaluate: the extended domain size must be a power of two")
@@ -323,9 +324,9 @@ class CompiledGraph:
                 raise ValueError(f"evaluate: column {i} must hold {want} rows")
         ptrs = (ctypes.c_void_p * max(len(columns), 1))(*[c.data_ptr() for c in columns])
         dyn = np.stack([fr_words(v) for v in list(challenges) + [beta, gamma, theta, y]])
-        _lib.check(_lib.load().hm_graph_evaluate_dev(ctypes.c_uint64(self.handle), ptrs, len(columns), _ptr(dyn), dyn.shape[0],
-                                                     size.bit_length() - 1, ctypes.c_void_p(values.data_ptr()),
-                                                     ctypes.c_void_p(_stream_ptr(values))))
+        _lib.check(_lib.load().hm_graph_evaluate_flags_dev(ctypes.c_uint64(self.handle), ptrs, len(columns), _ptr(dyn), dyn.shape[0],
+                                                           size.bit_length() - 1, ctypes.c_void_p(values.data_ptr()),
+                                                           1 if columns_internal else 0, ctypes.c_void_p(_stream_ptr(values))))
 
     def destroy(self) -> None:
         if self.handle:

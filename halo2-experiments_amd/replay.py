@@ -242,7 +242,7 @@ def run_replay(shape_name: str, device=None, group=None, include_host_pointer_es
             todo = share(counts["coset_ntt_ext"])
             while todo > 0:
                 b = min(8, todo)
-                ext = dom.coeff_to_extended(ntt_batch[:b])
+                ext = dom.coeff_to_extended(ntt_batch[:b], internal=True)
                 todo -= b
             if rank == 0 and ext is not None:
                 for _ in range(counts["intt_ext"]):
@@ -253,7 +253,10 @@ def run_replay(shape_name: str, device=None, group=None, include_host_pointer_es
         # evaluations at x * omega^rot
         t0 = time.perf_counter()
         if rank == 0 and ext is not None:
-            gate_prog.evaluate(gate_cols(ext), h_values, beta=REPLAY_S + 1, gamma=REPLAY_S + 2, theta=REPLAY_S + 3, y=REPLAY_S)
+            # the extended arrays would come out of coeff_to_extended(internal=True) in a prover (the factor 32 rides on the
+            # coset constants): the evaluator then loads every column without a conversion product
+            gate_prog.evaluate(gate_cols(ext), h_values, beta=REPLAY_S + 1, gamma=REPLAY_S + 2, theta=REPLAY_S + 3, y=REPLAY_S,
+                               columns_internal=True)
         torch.cuda.synchronize()
         t["evaluate_h"] = time.perf_counter() - t0
         t0 = time.perf_counter()

@@ -260,6 +260,16 @@ int hm_graph_create(const uint32_t* calcs, size_t n_calc, const uint64_t* consta
 int hm_graph_evaluate_dev(uint64_t handle, const void* const* d_columns, size_t n_columns, const uint64_t* dynamic_constants,
                           size_t n_dynamic, uint32_t log_size, void* d_values, void* stream);
 int hm_graph_destroy(uint64_t handle);
+/* The same evaluation with options.  HM_GRAPH_COLUMNS_INTERNAL: every column of the table (short ones included) holds
+ * 32 * value mod r instead of value -- the library's internal Montgomery radix is 2^261, so such words need no conversion
+ * product when they are loaded (a third of the multiplications of the MerkleSumTree circuit's evaluate_h program are
+ * conversions of column loads).  A prover gets its extended-domain columns in that form for nothing: the coset constants
+ * of hm_coeff_to_extended_bn256_fr_dev are multiplied into the first NTT pass anyway, so it passes {32, 32 zeta, 32 zeta^2}
+ * there (fixed and permutation columns of the proving key: once, at keygen).  PreviousValue on entry, the program's
+ * constants and the result written to d_values stay ordinary Fr words.  flags = 0 is hm_graph_evaluate_dev. */
+#define HM_GRAPH_COLUMNS_INTERNAL 1
+int hm_graph_evaluate_flags_dev(uint64_t handle, const void* const* d_columns, size_t n_columns, const uint64_t* dynamic_constants,
+                                size_t n_dynamic, uint32_t log_size, void* d_values, uint32_t flags, void* stream);
 
 /* Inputs and known answer of the benchmark of SURVEY.md §8d, without leaving the device:
  *   hm_fr_random_dev           out[i] uniform in [0, r) (Fr::random): one xoshiro256** stream per element, seeded by

@@ -142,5 +142,12 @@ def test_device_evaluate_h_of_each_circuit_matches_the_oracle(pyref, name):
         prog.evaluate(cols, values, beta=beta, gamma=gamma, theta=theta, y=y)
         torch.cuda.synchronize()
         assert np.array_equal(values.cpu().numpy().view(np.uint64), pyref.fr_array(exp)), name
+        # 4. the same program on INTERNAL-form columns (every column word = 32 x the value: HM_GRAPH_COLUMNS_INTERNAL) -- the
+        # lowering drops the Stores of columns and every conversion product; PreviousValue and the result stay ordinary words
+        cols32 = [to_dev([32 * v % R for v in c]) for c in fixed + advice + instance]
+        values = to_dev(prev)
+        prog.evaluate(cols32, values, beta=beta, gamma=gamma, theta=theta, y=y, columns_internal=True)
+        torch.cuda.synchronize()
+        assert np.array_equal(values.cpu().numpy().view(np.uint64), pyref.fr_array(exp)), name + " (internal-form columns)"
     finally:
         prog.destroy()

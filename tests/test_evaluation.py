@@ -135,6 +135,11 @@ def test_device_graph_matches_oracle(pyref, case):
         torch.cuda.synchronize()
         got = values.cpu().numpy().view(np.uint64)
         assert np.array_equal(got, pyref.fr_array(exp)), case
+        # internal-form columns (32 x the value): the other lowering of the same program
+        v32 = to_dev(prev)
+        prog.evaluate([to_dev([32 * v % R for v in c]) for c in fixed + advice + instance], v32, challenges=ch, y=y, columns_internal=True)
+        torch.cuda.synchronize()
+        assert np.array_equal(v32.cpu().numpy().view(np.uint64), pyref.fr_array(exp)), case + " (internal-form columns)"
         # a second proof: other challenges on the same compiled program, chained onto the first result (PreviousValue)
         ch2, y2 = [rng.randrange(R)], rng.randrange(R)
         exp2 = graph_ref.evaluate_graph(g.calculations, g.constants, g.rotations, fixed, advice, instance, ch2, 0, 0, 0, y2, exp, rot_scale, isize)

@@ -126,6 +126,9 @@ def test_evaluation_domain_steps(cref, pyref):
     exp_ext = cref.best_fft(cref.fr_mul(pad, pat), fr_words(d.extended_omega), d.extended_k, 4)
     ext = d.coeff_to_extended(coeff)
     assert np.array_equal(ext.cpu().numpy().view(np.uint64), exp_ext)
+    # internal=True: the same evaluations times 32 (the form hm_graph_evaluate_flags_dev loads without a conversion product)
+    ext32 = d.coeff_to_extended(coeff, internal=True)
+    assert np.array_equal(ext32.cpu().numpy().view(np.uint64), cref.fr_mul(exp_ext, np.tile(fr_words(32), (en, 1))))
     # extended_to_coeff inverts it (and truncates to n * (j - 1) rows)
     back = d.extended_to_coeff(ext.clone())
     bh = back.cpu().numpy().view(np.uint64)
