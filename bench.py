@@ -314,7 +314,11 @@ def main():
     # ---- synthetic inputs, resident in HBM before the timed region -----------------
     gen = np.array(fq_mont_words(1) + fq_mont_words(2), dtype=np.uint64)        # G = (1, 2)
     scalars, bases, t_local = bench_inputs(n_local, lo, BENCH_SEED, device)     # this rank's index range of the global arrays
-    handle = h.register_bases(bases)                                            # device-resident SRS slice
+    torch.cuda.synchronize()
+    t_reg0 = time.perf_counter()
+    handle = h.register_bases(bases)                                            # device-resident SRS slice, the library's default layout
+    torch.cuda.synchronize()
+    headline_register_ms = (time.perf_counter() - t_reg0) * 1e3
     del bases
     expected_local = known_answer(scalars, t_local, device)                     # [sum_i s_i (a + i b)]G over this rank's range
     del t_local
@@ -358,6 +362,9 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     st = h.msm_stats()
+    # which layout the default registration chose shows in the plan: one shared bucket set has ceil(255 / c) < 15 windows at c > 17
+    headline_mode = ("fixed-base table (hm_register_bases default from 2^23 points: W copies 2^(offset_j) P_i, one shared bucket set)"
+                     if st["window_bits"] > 17 else "plain (one copy of the points, one bucket set per window)")
     answer_ok = answer_ok and bool(np.array_equal(result, expected_global))     # the timed steps' own result
     if not answer_ok:
         raise SystemExit("bench.py: the MSM result does not match the known answer [sum s_i (a + i b)]G")
@@ -418,12 +425,20 @@ def main():
         extras["msm_prover_like"] = {"points_per_s": n_local / dt, "ms": dt * 1e3, "pairs": h.msm_stats()["pairs"],
                                      "scalars": "90 % zero, 5 % < 2^16, 5 % uniform"}
         del pl, u
-        # fixed-base mode: precomputed 2^(c*j) * P_i table (12x the base memory), one shared bucket set
+        # the OTHER base-set layout: the timed steps ran on what hm_register_bases builds by default (from 2^23 points the
+        # fixed-base table: 2^(offset of window j) * P_i for every window, W x the memory, one shared bucket set); here the
+        # plain layout (one copy of the points, W bucket sets) -- or, below the default's threshold, the table
         _, bases2, _ = bench_inputs(n_local, lo, BENCH_SEED, device)
+        other_is_plain = headline_mode.startswith("fixed-base")
+        lib = _lib.load()
+        if other_is_plain:
+            _lib.check(lib.hm_set_fixed_base_threshold(0))
         t1 = time.perf_counter()
-        hp = h.register_bases(bases2, precompute=True)
+        hp = h.register_bases(bases2, precompute=not other_is_plain)
         torch.cuda.synchronize()
         t_reg = time.perf_counter() - t1
+        if other_is_plain:
+            _lib.check(lib.hm_set_fixed_base_threshold(23))
         del bases2
         ref_out = h.best_multiexp(scalars, handle)
         got_pc = h.best_multiexp(scalars, hp)
@@ -432,10 +447,10 @@ def main():
             h.best_multiexp(scalars, hp)
         dt = (time.perf_counter() - t1) / 3
         stp = h.msm_stats()
-        extras["msm_precomputed_bases"] = {"points_per_s": n_local / dt, "ms": dt * 1e3, "window_bits": stp["window_bits"],
-                                           "windows": stp["windows"], "accumulate_kernel_ms": stp["accumulate_kernel_ms"],
-                                           "sort_ms": stp["sort_ms"], "register_ms": t_reg * 1e3,
-                                           "same_result_as_plain": bool(np.array_equal(ref_out, got_pc))}
+        extras["msm_plain_bases" if other_is_plain else "msm_precomputed_bases"] = {
+            "points_per_s": n_local / dt, "ms": dt * 1e3, "window_bits": stp["window_bits"], "windows": stp["windows"],
+            "accumulate_kernel_ms": stp["accumulate_kernel_ms"], "sort_ms": stp["sort_ms"], "register_ms": t_reg * 1e3,
+            "same_result_as_headline": bool(np.array_equal(ref_out, got_pc))}
         h.release_bases(hp)
         # independent MSMs issued asynchronously, three in flight on three streams (hm_msm_submit_dev):
         # what a prover committing to several columns gets; NOT `value`, whose steps are strictly serial
@@ -532,6 +547,7 @@ def main():
                        "points_per_gpu": n_local, "global_points": n_global,
                        "scalars": "uniform in [0, r), xoshiro256** per element, seed 0x48324d4933353558 (SURVEY.md §8d)",
                        "bases": "P_i = [a + i b]G, device-resident; result checked against [sum s_i (a + i b)]G outside the timed loop",
+                       "base_set": headline_mode, "base_set_register_ms": headline_register_ms,
                        "window_bits": st["window_bits"], "windows": st["windows"], "parallelism": f"index-range shards x{world}, "
                        "all-gather of 96 B partials (RCCL) + host fold"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -539,9 +555,9 @@ def main():
                          "traffic": (pmc_traffic(baked, "hm::msm_accumulate_kernel", False) if args.log_points == 24 else None),
                          "traffic_note": f"NOT measured in this run: rocprofv3 --pmc figure via {BAKED_COUNTERS_FILE} "
                                          f"(stale = {bool(stale['k3'])}: whether the kernel sources changed since); "
-                                         "every base is gathered once per window (W = 15), inherent to bucketed Pippenger",
+                                         "every base (or its table multiple) is gathered once per window, inherent to bucketed Pippenger",
                          "kernel": "msm_accumulate_kernel", "kernel_ms": acc,
-                         "note": "integer-VALU bound (SURVEY.md §8d): ~2.5e8 mixed additions x ~2.35e3 32-bit ops per launch",
+                         "note": "integer-VALU bound (SURVEY.md §8d): n x windows mixed additions x ~2.24e3 32-bit ops per launch",
                          "valu_issue": valu_issue(baked, stale, "k3", st["pairs"], acc)},
             "msm_phase_ms": {"sort": float(np.median(sort_ms)), "accumulate_kernel": acc, "device_total": float(np.median(tot_ms))},
             "known_answer_ok": answer_ok,

@@ -79,6 +79,7 @@ _SIGNATURES = {
     "hm_msm_set_window": (ctypes.c_int, [ctypes.c_int]),
     "hm_msm_set_phase_timing": (ctypes.c_int, [ctypes.c_int]),
     "hm_set_host_base_cache": (ctypes.c_int, [ctypes.c_int]),
+    "hm_set_fixed_base_threshold": (ctypes.c_int, [ctypes.c_uint32]),
     "hm_set_msm_devices": (ctypes.c_int, [ctypes.POINTER(ctypes.c_int), ctypes.c_int]),
     "hm_ntt_bn256_fr": (ctypes.c_int, [_u64p, _u64p, ctypes.c_uint32]),
     "hm_ntt_bn256_fr_dev": (ctypes.c_int, [_vp, _u64p, ctypes.c_uint32, _vp]),

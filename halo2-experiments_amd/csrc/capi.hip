@@ -33,6 +33,10 @@ static std::mutex g_ctx_mu;
 static std::map<int, std::unique_ptr<DeviceCtx>> g_ctx;
 static std::vector<int> g_msm_devices;             // hm_set_msm_devices; empty = the calling thread's device
 static std::atomic<int> g_host_base_cache{1};      // hm_set_host_base_cache
+static std::atomic<uint32_t> g_fixed_base_from_log{[] {      // hm_set_fixed_base_threshold
+  const char* v = std::getenv("HALO2_MI355X_FIXED_BASE_FROM_LOG");
+  return (uint32_t)(v && *v ? std::atoi(v) : 23);
+}()};
 
 int hm_fail(int code, const std::string& what) {
   g_last_error = what;
@@ -137,9 +141,14 @@ static BasesEntry* find_bases(DeviceCtx& ctx, uint64_t handle) {
 }
 
 static int register_from_device(DeviceCtx& ctx, const uint32_t* d_ext, size_t n, hipStream_t stream, uint64_t* out_handle,
-                                bool precomp = false) {
+                                bool precomp = false, bool allow_default = true) {
   BasesEntry e;
   e.n = n;
+  bool by_default = false;
+  {   // the fixed-base table by default from the size where it pays (hm_set_fixed_base_threshold)
+    const uint32_t from = g_fixed_base_from_log.load(std::memory_order_relaxed);
+    if (allow_default && !precomp && from != 0 && from < 40 && n >= ((size_t)1 << from)) precomp = by_default = true;
+  }
   if (precomp && n >= 256) {   // tiny sets gain nothing from a shared bucket set
     e.pc_c = msm_precomp_window(n);
     e.pc_W = (255 + e.pc_c - 1) / e.pc_c;
@@ -158,7 +167,13 @@ static int register_from_device(DeviceCtx& ctx, const uint32_t* d_ext, size_t n,
     }
   }
   if (!e.d_xy) {
-    HM_HIP_CHECK(hipMalloc((void**)&e.d_xy, xy_bytes));
+    if (hipMalloc((void**)&e.d_xy, xy_bytes) != hipSuccess) {
+      (void)hipGetLastError();
+      e.d_xy = nullptr;
+      // no room for W copies: a caller of the plain entry point asked for a base set, not for the table
+      if (by_default && e.pc_c) return register_from_device(ctx, d_ext, n, stream, out_handle, false, false);
+      return hm_fail(HM_ERR_HIP, "register bases: allocation failed");
+    }
     if (hipMalloc((void**)&e.d_inf, inf_bytes) != hipSuccess) {
       (void)hipFree(e.d_xy);
       return hm_fail(HM_ERR_HIP, "register bases: allocation failed");
@@ -286,6 +301,12 @@ int hm_shutdown(void) try {
   }
   return HM_OK;
 } HM_API_CATCH("hm_shutdown")
+
+int hm_set_fixed_base_threshold(uint32_t log2_n) try {
+  if (log2_n != 0 && (log2_n < 8 || log2_n > 31)) return hm_fail(HM_ERR_BAD_ARG, "hm_set_fixed_base_threshold: 0 or a size in [2^8, 2^31]");
+  g_fixed_base_from_log.store(log2_n, std::memory_order_relaxed);
+  return HM_OK;
+} HM_API_CATCH("hm_set_fixed_base_threshold")
 
 int hm_set_host_base_cache(int enable) try {
   g_host_base_cache.store(enable != 0, std::memory_order_relaxed);

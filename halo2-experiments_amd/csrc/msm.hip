@@ -22,6 +22,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
 
 #include "hm_internal.h"
 #include "host_fq.h"
@@ -84,8 +85,9 @@ __device__ __forceinline__ uint32_t effective_task_len(const uint32_t* __restric
   return L < 16u ? 16u : L;
 }
 
+// Windows [0, n_wide) are c bits wide, the others c - 1 (n_wide = W: every window c bits, the top one implicitly shorter).
 __global__ void msm_digits_kernel(const uint32_t* __restrict__ scalars, const uint8_t* __restrict__ inf,
-                                  int32_t* __restrict__ digits, size_t n, uint32_t c, uint32_t W) {
+                                  int32_t* __restrict__ digits, size_t n, uint32_t c, uint32_t W, uint32_t n_wide) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const uint4* q = reinterpret_cast<const uint4*>(scalars + i * 8);
@@ -104,21 +106,25 @@ __global__ void msm_digits_kernel(const uint32_t* __restrict__ scalars, const ui
     v[8] = 0;
   }
   const bool skip = inf[i] != 0;
-  const uint32_t mask = (1u << c) - 1u, half = 1u << (c - 1);
   uint32_t carry = 0;
   for (uint32_t w = 0; w < W; ++w) {
+    const uint32_t bits = w < n_wide ? c : c - 1;
+    const uint32_t mask = (1u << bits) - 1u, half = 1u << (bits - 1);
     uint32_t d = (v[0] & mask) + carry;
     int32_t sd;
     if (d > half) {
-      sd = (int32_t)d - (int32_t)(1u << c);
+      sd = (int32_t)d - (int32_t)(1u << bits);
       carry = 1;
     } else {
       sd = (int32_t)d;
       carry = 0;
     }
-    digits[(size_t)w * n + i] = skip ? 0 : sd;
+    // a narrow window's digit is DOUBLED and its table entry holds half the weight (2^(offset - 1) P): its points then
+    // spread over the even buckets of the whole range instead of filling the lower half only (every coarse region of
+    // the sort gets the same share: the lower half would hold seven times the upper one at c = 22, W = 12)
+    digits[(size_t)w * n + i] = skip ? 0 : (w < n_wide ? sd : 2 * sd);
 #pragma unroll
-    for (int k = 0; k < 8; ++k) v[k] = __funnelshift_r(v[k], v[k + 1], c);
+    for (int k = 0; k < 8; ++k) v[k] = __funnelshift_r(v[k], v[k + 1], bits);
   }
 }
 
@@ -252,11 +258,12 @@ __global__ __launch_bounds__(SORT_THREADS) void msm_part1_scatter_kernel(const i
   const size_t lo = (size_t)g * chunk, hi = lo + chunk < n ? lo + chunk : n;
   const int32_t* dw = digits + (size_t)w * n;
   const uint32_t fmask = (1u << fb) - 1u;
+  const ITEM imask = ((ITEM)1 << ib) - 1;     // positional items keep only the low ib bits of the index (see msm_issue)
   block_for_each_word(dw, lo, hi, [&](size_t i, int32_t d) {
     if (d != 0) {
       const uint32_t b1 = (uint32_t)(d < 0 ? -d : d) - 1u;
       const uint32_t pos = lds_inc(cursor, b1 >> fb);
-      tmp[pos] = ((ITEM)(b1 & fmask) << (ib + 1)) | ((ITEM)(d < 0 ? 1u : 0u) << ib) | (ITEM)i;
+      tmp[pos] = ((ITEM)(b1 & fmask) << (ib + 1)) | ((ITEM)(d < 0 ? 1u : 0u) << ib) | ((ITEM)i & imask);
     }
   });
 }
@@ -267,15 +274,17 @@ __global__ __launch_bounds__(SORT_THREADS) void msm_part1_scatter_kernel(const i
 #ifndef HM_P1_IPT
 #define HM_P1_IPT 4
 #endif
-constexpr int P1_IPT = HM_P1_IPT;
-constexpr int P1_TILE = SORT_THREADS * P1_IPT;
-template <class ITEM>
+constexpr int P1_IPT_DEFAULT = HM_P1_IPT;
+// P1_IPT items per lane and tile: a tile should bring >= 8 items (one 32-byte sector) to every coarse bin, i.e.
+// 4 096 items for <= 512 bins and 8 192 for 1 024 (the shared-bucket-set plan)
+template <class ITEM, int P1_IPT = P1_IPT_DEFAULT>
 __global__ __launch_bounds__(SORT_THREADS) void msm_part1_scatter_tiled_kernel(const int32_t* __restrict__ digits,
                                                                                const uint32_t* __restrict__ chist,
                                                                                const uint32_t* __restrict__ cstart,
                                                                                ITEM* __restrict__ tmp, size_t n, size_t chunk,
                                                                                uint32_t fb, uint32_t ib, uint32_t NC) {
   extern __shared__ uint32_t sm[];
+  constexpr int P1_TILE = SORT_THREADS * P1_IPT;
   const uint32_t g = blockIdx.x, w = blockIdx.y, G = gridDim.x, tid = threadIdx.x;
   uint32_t* gcur = sm;                 // global cursor of every coarse bin for this chunk
   uint32_t* tcnt = gcur + NC;
@@ -290,6 +299,7 @@ __global__ __launch_bounds__(SORT_THREADS) void msm_part1_scatter_tiled_kernel(c
   const size_t lo = (size_t)g * chunk, hi = lo + chunk < n ? lo + chunk : n;
   const int32_t* dw = digits + (size_t)w * n;
   const uint32_t fmask = (1u << fb) - 1u;
+  const ITEM imask = ((ITEM)1 << ib) - 1;
   const uint32_t per = (NC + SORT_THREADS - 1) / SORT_THREADS;
   for (size_t t0 = lo; t0 < hi; t0 += P1_TILE) {
     const uint32_t tile_n = hi - t0 < (size_t)P1_TILE ? (uint32_t)(hi - t0) : (uint32_t)P1_TILE;
@@ -304,7 +314,7 @@ __global__ __launch_bounds__(SORT_THREADS) void msm_part1_scatter_tiled_kernel(c
         if (d != 0) {
           const uint32_t b1 = (uint32_t)(d < 0 ? -d : d) - 1u;
           bin[k] = b1 >> fb;
-          item[k] = ((ITEM)(b1 & fmask) << (ib + 1)) | ((ITEM)(d < 0 ? 1u : 0u) << ib) | (ITEM)(t0 + e);
+          item[k] = ((ITEM)(b1 & fmask) << (ib + 1)) | ((ITEM)(d < 0 ? 1u : 0u) << ib) | ((ITEM)(t0 + e) & imask);
           rank[k] = lds_inc(tcnt, bin[k]);
         }
       }
@@ -466,6 +476,17 @@ constexpr int P2_IPT = HM_P2_IPT;
 constexpr int P2_TILE = SORT_THREADS * P2_IPT;
 // COOP: slices of big regions (work list); the per-bucket cursors then live in global memory
 // (`gcursor`, a copy of boff) and every tile reserves its runs with one atomicAdd per non-empty bucket.
+// POSITIONAL (a shared bucket set of n * W > 2^27 items: fine bits + sign + a 28-bit index do not fit one word): an
+// item carries only the low `ib` bits of its index.  The rest is its SUPER-CHUNK, 2^ib consecutive indices = `gpc`
+// chunks of the first sort level, and the first level lays the runs of a coarse bin down in chunk order -- so the
+// super-chunk of an item follows from its POSITION in the region: the boundaries are the (already scanned) per-chunk
+// offsets chist[g * NC + bin] at g = 0, gpc, 2 gpc, ...  They go to LDS (at most PS_MAX_SC + 1 words) and every item
+// finds its piece by a binary search.  Half the bytes of the 64-bit items this replaces, at every level of the sort.
+constexpr uint32_t PS_MAX_SC = 1024;
+struct Positional {
+  const uint32_t* chist;    // scanned per-chunk offsets of window 0 (a shared bucket set has one "window"): [g][NC]
+  uint32_t G, gpc, nsc;     // chunks, chunks per super-chunk, super-chunks (0: items carry their whole index)
+};
 template <class ITEM, bool COOP = false>
 __global__ __launch_bounds__(SORT_THREADS) void msm_part2_scatter_tiled_kernel(const ITEM* __restrict__ tmp,
                                                                                const uint32_t* __restrict__ cstart,
@@ -474,8 +495,9 @@ __global__ __launch_bounds__(SORT_THREADS) void msm_part2_scatter_tiled_kernel(c
                                                                                uint32_t ib, uint32_t NC, uint32_t NBP, uint32_t big,
                                                                                uint32_t slice, const uint2* __restrict__ list,
                                                                                const uint32_t* __restrict__ list_count,
-                                                                               uint32_t* __restrict__ gcursor) {
+                                                                               uint32_t* __restrict__ gcursor, Positional ps) {
   extern __shared__ uint32_t sm[];
+  __shared__ uint32_t sc_start[PS_MAX_SC + 1];
   uint32_t hb = blockIdx.x, w = blockIdx.y, sl = 0;
   const uint32_t tid = threadIdx.x;
   if (COOP) {
@@ -499,6 +521,12 @@ __global__ __launch_bounds__(SORT_THREADS) void msm_part2_scatter_tiled_kernel(c
   for (uint32_t b = tid; b < NF; b += SORT_THREADS) { gcur[b] = bo[b]; tcnt[b] = 0; }
   __syncthreads();
   uint32_t lo = cstart[w * NC + hb], hi = cstart[w * NC + hb + 1];
+  const uint32_t region_lo = lo;
+  if (ps.nsc) {                                        // region-relative start of every super-chunk's runs
+    for (uint32_t sc = tid; sc <= ps.nsc; sc += SORT_THREADS)
+      sc_start[sc] = sc < ps.nsc ? ps.chist[(size_t)sc * ps.gpc * NC + hb] : hi - lo;
+    __syncthreads();
+  }
   if (COOP) {
     lo += sl * slice;
     hi = lo + slice < hi ? lo + slice : hi;
@@ -508,6 +536,16 @@ __global__ __launch_bounds__(SORT_THREADS) void msm_part2_scatter_tiled_kernel(c
   for (uint32_t t0 = lo; t0 < hi; t0 += P2_TILE) {
     const uint32_t tile_n = hi - t0 < (uint32_t)P2_TILE ? hi - t0 : (uint32_t)P2_TILE;
     uint32_t pay[P2_IPT], bin[P2_IPT], rank[P2_IPT];
+    uint32_t sc_tile = 0;
+    if (ps.nsc) {                                      // super-chunk of the tile's first position (the same words for every lane:
+      const uint32_t pos0 = t0 - region_lo;            // broadcast LDS reads); a tile of 4 096 positions crosses few boundaries
+      uint32_t a = 0, b = ps.nsc;                      // invariant: sc_start[a] <= pos0 < sc_start[b]
+      while (b - a > 1) {
+        const uint32_t m = (a + b) >> 1;
+        if (sc_start[m] <= pos0) a = m; else b = m;
+      }
+      sc_tile = a;
+    }
 #pragma unroll
     for (int k = 0; k < P2_IPT; ++k) {
       const uint32_t e = (uint32_t)k * SORT_THREADS + tid;
@@ -515,6 +553,12 @@ __global__ __launch_bounds__(SORT_THREADS) void msm_part2_scatter_tiled_kernel(c
         const ITEM item = tmp[t0 + e];
         bin[k] = (uint32_t)(item >> (ib + 1));
         pay[k] = (uint32_t)(item & imask) | ((uint32_t)((item >> ib) & 1) << 31);
+        if (ps.nsc) {                                  // the largest sc with sc_start[sc] <= position: a few steps from the tile's
+          const uint32_t pos = t0 + e - region_lo;
+          uint32_t a = sc_tile;
+          while (sc_start[a + 1] <= pos) ++a;          // (pos < sc_start[nsc] = the region's size: the walk ends)
+          pay[k] |= a << ib;
+        }
         rank[k] = lds_inc(tcnt, bin[k]);
       }
     }
@@ -940,10 +984,15 @@ __global__ __launch_bounds__(ACC_THREADS) void msm_reduce_segments_kernel(const 
   const uint32_t lo = sgi * SEG + 1;
   const uint32_t hi = lo + SEG - 1 < NB ? lo + SEG - 1 : NB;
   const uint32_t* bw = bucket + (size_t)w * NBP * PT_WORDS;
+  // one wave per SIMD runs this kernel (the work is what costs, so SEG is long): nothing hides a bucket's load but the two
+  // additions of the bucket before it -- the next record is requested before they start
   G1Jac run = g1_identity(), acc = g1_identity();
+  G1Jac cur = hi >= lo ? load_jac(bw + (size_t)hi * PT_WORDS) : g1_identity();
   for (uint32_t b = hi; b >= lo; --b) {
-    run = g1_add(run, load_jac(bw + (size_t)b * PT_WORDS));
+    const G1Jac nxt = b > lo ? load_jac(bw + (size_t)(b - 1) * PT_WORDS) : g1_identity();
+    run = g1_add(run, cur);
     acc = g1_add(acc, run);
+    cur = nxt;
   }
   uint32_t m = lo - 1;  // < NB
   if (m != 0 && !run.inf) {
@@ -1033,7 +1082,7 @@ __device__ __forceinline__ Fq fq_inverse(const Fq& a) {  // a^(p-2), a a product
 // disappears.  One lane per point: c doublings, then a Fermat inversion per stored multiple.
 __global__ __launch_bounds__(ACC_THREADS) void msm_precompute_kernel(uint32_t* __restrict__ table,
                                                                      const uint8_t* __restrict__ inf, size_t n, uint32_t c,
-                                                                     uint32_t W) {
+                                                                     uint32_t W, uint32_t n_wide) {
   const size_t i = (size_t)blockIdx.x * ACC_THREADS + threadIdx.x;
   if (i >= n) return;
   if (inf[i]) {
@@ -1045,7 +1094,8 @@ __global__ __launch_bounds__(ACC_THREADS) void msm_precompute_kernel(uint32_t* _
   }
   G1Jac p = g1_from_affine(load_base(table, (uint32_t)i));
   for (uint32_t j = 1; j < W; ++j) {
-    for (uint32_t k = 0; k < c; ++k) p = g1_double_nz(p);   // a point of odd prime order never doubles to the identity
+    const uint32_t bits = j < n_wide ? c : c - 1;           // multiple j = 2^(offset of window j) P, HALF of it for a narrow window (see msm_digits_kernel)
+    for (uint32_t k = 0; k < bits; ++k) p = g1_double_nz(p);   // a point of odd prime order never doubles to the identity
     const Fq zi = fq_inverse(p.z);
     const Fq zi2 = fe_sqr(zi);
     const Fq zi3 = fe_mul(zi2, zi);
@@ -1057,6 +1107,72 @@ __global__ __launch_bounds__(ACC_THREADS) void msm_precompute_kernel(uint32_t* _
     o[1] = make_uint4(ox[4], ox[5], ox[6], ox[7]);
     o[2] = make_uint4(oy[0], oy[1], oy[2], oy[3]);
     o[3] = make_uint4(oy[4], oy[5], oy[6], oy[7]);
+  }
+}
+
+// The same table in two passes with ONE inversion per point instead of one per stored multiple (Montgomery's trick
+// over the W - 1 Z coordinates of a point's chain): a Fermat inversion costs ~380 products, the c doublings between
+// two multiples ~130, so the single-pass kernel above spends three quarters of its time inverting (674 ms for 2^24
+// points, W = 12).  Pass A runs the doubling chain and leaves every multiple in JACOBIAN form -- (X, Y) packed in its
+// table slot, Z and the running product Z_1 ... Z_j in a scratch array; pass B inverts the last running product and
+// walks back, turning every slot into the affine point.
+__device__ __forceinline__ void store_packed(uint32_t* dst, const Fq& v) {
+  uint32_t w[8];
+  fe_pack(w, v);
+  uint4* o = reinterpret_cast<uint4*>(dst);
+  o[0] = make_uint4(w[0], w[1], w[2], w[3]);
+  o[1] = make_uint4(w[4], w[5], w[6], w[7]);
+}
+__device__ __forceinline__ Fq load_packed(const uint32_t* src) {
+  const uint4* q = reinterpret_cast<const uint4*>(src);
+  const uint4 lo = q[0], hi = q[1];
+  const uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+  return fe_unpack<FqParams>(w);
+}
+// ztmp: [2][W - 1][n][8 words]: half 0 the Z coordinates, half 1 their running products
+// Both passes work on a SLAB of m points starting at `first` (the scratch is per slab: [2][W - 1][m][8 words]).
+__global__ __launch_bounds__(ACC_THREADS) void msm_precompute_chain_kernel(uint32_t* __restrict__ table, uint32_t* __restrict__ ztmp,
+                                                                           const uint8_t* __restrict__ inf, size_t n, uint32_t c,
+                                                                           uint32_t W, uint32_t n_wide, size_t first, size_t m) {
+  const size_t r = (size_t)blockIdx.x * ACC_THREADS + threadIdx.x, i = first + r;
+  if (r >= m || i >= n || inf[i]) return;           // identity bases: pass B zeroes their slots
+  G1Jac p = g1_from_affine(load_base(table, (uint32_t)i));
+  Fq run = fe_one<FqParams>();
+  for (uint32_t j = 1; j < W; ++j) {
+    const uint32_t bits = j < n_wide ? c : c - 1;           // as in msm_precompute_kernel
+    for (uint32_t k = 0; k < bits; ++k) p = g1_double_nz(p);   // a point of odd prime order never doubles to the identity
+    uint32_t* slot = table + ((size_t)j * n + i) * 16;
+    store_packed(slot, p.x);
+    store_packed(slot + 8, p.y);
+    run = j == 1 ? p.z : fe_mul(run, p.z);
+    store_packed(ztmp + ((size_t)(j - 1) * m + r) * 8, p.z);
+    store_packed(ztmp + ((size_t)(W - 1 + j - 1) * m + r) * 8, run);
+  }
+}
+__global__ __launch_bounds__(ACC_THREADS) void msm_precompute_normalise_kernel(uint32_t* __restrict__ table,
+                                                                               const uint32_t* __restrict__ ztmp,
+                                                                               const uint8_t* __restrict__ inf, size_t n, uint32_t W,
+                                                                               size_t first, size_t m) {
+  const size_t r = (size_t)blockIdx.x * ACC_THREADS + threadIdx.x, i = first + r;
+  if (r >= m || i >= n) return;
+  if (inf[i]) {
+    for (uint32_t j = 1; j < W; ++j) {
+      uint4* o = reinterpret_cast<uint4*>(table + ((size_t)j * n + i) * 16);
+      o[0] = o[1] = o[2] = o[3] = make_uint4(0, 0, 0, 0);
+    }
+    return;
+  }
+  Fq inv = fq_inverse(load_packed(ztmp + ((size_t)(W - 1 + W - 2) * m + r) * 8));      // 1 / (Z_1 ... Z_{W-1})
+  for (uint32_t j = W - 1; j >= 1; --j) {
+    const Fq zj = load_packed(ztmp + ((size_t)(j - 1) * m + r) * 8);
+    const Fq zi = j > 1 ? fe_mul(inv, load_packed(ztmp + ((size_t)(W - 1 + j - 2) * m + r) * 8)) : inv;   // 1 / Z_j
+    inv = fe_mul(inv, zj);                                                                // 1 / (Z_1 ... Z_{j-1})
+    const Fq zi2 = fe_sqr(zi);
+    const Fq zi3 = fe_mul(zi2, zi);
+    uint32_t* slot = table + ((size_t)j * n + i) * 16;
+    const Fq ax = fe_mul(load_packed(slot), zi2), ay = fe_mul(load_packed(slot + 8), zi3);
+    store_packed(slot, ax);
+    store_packed(slot + 8, ay);
   }
 }
 
@@ -1160,6 +1276,15 @@ void msm_set_window_override(int c) { g_window_override.store(c, std::memory_ord
 
 // Window size for a precomputed (single bucket set) base set of n points: minimise
 // n * W(c) mixed additions + ~3 * 2^(c-1) addition-equivalents of bucket reduction.
+// The 255 digit bits over W windows as evenly as possible: windows [0, n_wide) are `wide` bits, the others wide - 1.
+// (W - 1 full windows and a short top one would send every point's top digit into the lowest 2^(short - 1) buckets:
+// at 2^24 points, c = 22, 4 096 buckets with 4 192 points each beside a mean of 96.)
+static void balanced_windows(uint32_t W, uint32_t* wide, uint32_t* n_wide) {
+  const uint32_t base = 255 / W, rest = 255 - base * W;
+  *wide = rest ? base + 1 : base;
+  *n_wide = rest ? rest : W;
+}
+
 uint32_t msm_precomp_window(size_t n) {
   uint32_t best = 8;
   double best_cost = 1e300;
@@ -1168,13 +1293,35 @@ uint32_t msm_precomp_window(size_t n) {
     const double cost = (double)n * W + 3.0 * (double)(1ull << (c - 1));
     if (cost < best_cost) { best_cost = cost; best = c; }
   }
-  return best;
+  uint32_t wide, n_wide;
+  balanced_windows((255 + best - 1) / best, &wide, &n_wide);     // the widest window of the balanced split (<= best)
+  return wide;
 }
 
 int msm_precompute(uint32_t* d_table, const uint8_t* d_inf, size_t n, uint32_t c, uint32_t W, hipStream_t stream) {
   if (n == 0 || W <= 1) return HM_OK;
-  hipLaunchKernelGGL(msm_precompute_kernel, dim3((uint32_t)((n + ACC_THREADS - 1) / ACC_THREADS)), dim3(ACC_THREADS), 0, stream,
-                     d_table, d_inf, n, c, W);
+  uint32_t wide, n_wide;
+  balanced_windows(W, &wide, &n_wide);
+  if (wide != c) return hm_fail(HM_ERR_INTERNAL, "msm: precomputation window is not the balanced width");
+  const dim3 grid((uint32_t)((n + ACC_THREADS - 1) / ACC_THREADS)), block(ACC_THREADS);
+  // two passes with one inversion per point (scratch: 64 B per stored multiple, freed before returning); the one-pass
+  // kernel when that scratch cannot be had
+  uint32_t* d_z = nullptr;
+  static const bool one_pass = [] { const char* v = std::getenv("HALO2_MI355X_PRECOMP_ONE_PASS"); return v && *v == '1'; }();
+  const size_t slab = n < ((size_t)1 << 20) ? n : ((size_t)1 << 20);      // <= 1 GiB of scratch whatever the set's size
+  if (!one_pass && hipMalloc((void**)&d_z, (size_t)2 * (W - 1) * slab * 32) == hipSuccess) {
+    const dim3 sgrid((uint32_t)((slab + ACC_THREADS - 1) / ACC_THREADS));
+    for (size_t first = 0; first < n; first += slab) {
+      hipLaunchKernelGGL(msm_precompute_chain_kernel, sgrid, block, 0, stream, d_table, d_z, d_inf, n, c, W, n_wide, first, slab);
+      hipLaunchKernelGGL(msm_precompute_normalise_kernel, sgrid, block, 0, stream, d_table, (const uint32_t*)d_z, d_inf, n, W, first, slab);
+    }
+    const hipError_t e1 = hipGetLastError(), e2 = hipStreamSynchronize(stream);
+    (void)hipFree(d_z);
+    if (e1 != hipSuccess || e2 != hipSuccess) return hm_fail(HM_ERR_HIP, "msm: precomputation failed");
+    return HM_OK;
+  }
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(msm_precompute_kernel, grid, block, 0, stream, d_table, d_inf, n, c, W, n_wide);
   HM_HIP_CHECK(hipGetLastError());
   return HM_OK;
 }
@@ -1199,9 +1346,17 @@ static int launch_sort(const int32_t* d_digits, uint32_t* d_chist, uint32_t* d_c
                        fb, NC);
     hipLaunchKernelGGL(msm_part1_scan_kernel, dim3(SW * NC), dim3(64), 0, stream, d_chist, d_ctot, G, NC, SW);
     hipLaunchKernelGGL(msm_part1_starts_kernel, dim3(1), dim3(1024), 0, stream, (const uint32_t*)d_ctot, d_cstart, SW * NC);
-    if (NC <= 4096) {
-      const size_t lds_p1 = ((size_t)3 * NC + 32 + P1_TILE) * 4 + (size_t)P1_TILE * sizeof(ITEM);
-      hipLaunchKernelGGL(msm_part1_scatter_tiled_kernel<ITEM>, dim3(G, SW), dim3(SORT_THREADS), lds_p1, stream, d_digits,
+    static const bool big_tiles = [] { const char* v = std::getenv("HALO2_MI355X_P1_BIG_TILES"); return !(v && *v == '0'); }();
+    static const uint32_t p1_big_from = [] { const char* v = std::getenv("HALO2_MI355X_P1_BIG_FROM"); return (uint32_t)(v && *v ? std::atoi(v) : 512); }();
+    if (NC >= (p1_big_from) && NC <= 2048 && sizeof(ITEM) == 4 && big_tiles) {
+      constexpr int TILE = SORT_THREADS * 8;
+      const size_t lds_p1 = ((size_t)3 * NC + 32 + TILE) * 4 + (size_t)TILE * sizeof(ITEM);
+      hipLaunchKernelGGL((msm_part1_scatter_tiled_kernel<ITEM, 8>), dim3(G, SW), dim3(SORT_THREADS), lds_p1, stream, d_digits,
+                         (const uint32_t*)d_chist, (const uint32_t*)d_cstart, (ITEM*)d_tmp, sn, chunk, fb, ib, NC);
+    } else if (NC <= 4096) {
+      constexpr int TILE = SORT_THREADS * P1_IPT_DEFAULT;
+      const size_t lds_p1 = ((size_t)3 * NC + 32 + TILE) * 4 + (size_t)TILE * sizeof(ITEM);
+      hipLaunchKernelGGL((msm_part1_scatter_tiled_kernel<ITEM, P1_IPT_DEFAULT>), dim3(G, SW), dim3(SORT_THREADS), lds_p1, stream, d_digits,
                          (const uint32_t*)d_chist, (const uint32_t*)d_cstart, (ITEM*)d_tmp, sn, chunk, fb, ib, NC);
     } else {
       hipLaunchKernelGGL(msm_part1_scatter_kernel<ITEM>, dim3(G, SW), dim3(SORT_THREADS), lds_coarse, stream, d_digits,
@@ -1228,16 +1383,16 @@ static int launch_sort(const int32_t* d_digits, uint32_t* d_chist, uint32_t* d_c
 template <class ITEM>
 static int launch_sort_scatter(const int32_t* d_digits, const uint32_t* d_cstart, const void* d_tmp, const uint32_t* d_boff,
                                uint32_t* d_sorted, size_t sn, uint32_t SW, uint32_t fb, uint32_t ib, uint32_t cb, uint32_t NC,
-                               uint32_t NBP, uint32_t NBT, const BigRegionPlan& br, hipStream_t stream) {
+                               uint32_t NBP, uint32_t NBT, const BigRegionPlan& br, const Positional& ps, hipStream_t stream) {
   const size_t lds_fine = (size_t)4 << fb;
   if (cb && fb <= 11) {
     const size_t lds_tiled = ((size_t)3 * (1u << fb) + 32 + 2 * P2_TILE) * 4;
     hipLaunchKernelGGL((msm_part2_scatter_tiled_kernel<ITEM, false>), dim3(NC, SW), dim3(SORT_THREADS), lds_tiled, stream,
                        (const ITEM*)d_tmp, d_cstart, d_boff, d_sorted, fb, ib, NC, NBP, br.big, br.slice, (const uint2*)br.list,
-                       (const uint32_t*)br.count, br.gcursor);
+                       (const uint32_t*)br.count, br.gcursor, ps);
     hipLaunchKernelGGL((msm_part2_scatter_tiled_kernel<ITEM, true>), dim3(br.capacity), dim3(SORT_THREADS), lds_tiled, stream,
                        (const ITEM*)d_tmp, d_cstart, d_boff, d_sorted, fb, ib, NC, NBP, br.big, br.slice, (const uint2*)br.list,
-                       (const uint32_t*)br.count, br.gcursor);
+                       (const uint32_t*)br.count, br.gcursor, ps);
   } else if (cb) {
     hipLaunchKernelGGL((msm_part2_scatter_kernel<false, ITEM>), dim3(NC, SW), dim3(SORT_THREADS), lds_fine, stream,
                        (const ITEM*)d_tmp, d_digits, d_cstart, d_boff, d_sorted, sn, fb, ib, NC, NBP);
@@ -1252,7 +1407,7 @@ static int launch_sort_scatter(const int32_t* d_digits, const uint32_t* d_cstart
 int msm_launch_digits(const uint32_t* d_scalars_ext, const uint8_t* d_inf, int32_t* d_digits, size_t n, uint32_t c, uint32_t W,
                       hipStream_t stream) {
   hipLaunchKernelGGL(msm_digits_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, stream, d_scalars_ext, d_inf, d_digits, n, c,
-                     W);
+                     W, W);
   HM_HIP_CHECK(hipGetLastError());
   return HM_OK;
 }
@@ -1333,7 +1488,7 @@ static int msm_issue(DeviceCtx& ctx, int slot, const uint32_t* d_scalars_ext, co
     if (G > g_cap) G = g_cap;
     if (G < 256) G = 256;
   }
-  const size_t chunk = (sn + G - 1) / G;
+  size_t chunk = (sn + G - 1) / G;
   // the device may shorten L (effective_task_len): then tasks <= 2 * TARGET_TASKS + one per bucket
   // (and never more than one per pair)
   const uint64_t T_max = std::min<uint64_t>(pairs_max, std::max<uint64_t>(pairs_max / L, 2ull * TARGET_TASKS) + NBT) + 1;
@@ -1351,13 +1506,39 @@ static int msm_issue(DeviceCtx& ctx, int slot, const uint32_t* d_scalars_ext, co
   uint32_t ib = ilog2(sn) + ((sn & (sn - 1)) ? 1u : 0u);
   if (ib == 0) ib = 1;
   bool wide_items = false;
+  Positional ps{nullptr, 0, 0, 0};
   uint32_t fb = c - 1 < 31 - ib ? c - 1 : 31 - ib;
   if (fb > 15) fb = 15;                  // 2^15 LDS counters = 128 KiB is what a workgroup may hold
-  if (fb < 5 && c - 1 > fb) {            // too few fine bits left in 32: switch to 64-bit items
+#ifndef HM_NO_POSITIONAL
+  if (single_set && c >= 14 && c <= 24 && (c - 1) - fb > 10) {
+    // A shared bucket set has n W items (2^27.6 at 2^24 points) and 2^(c-1) buckets (2^21): fine bits + sign + the item index
+    // do not fit one word with few enough coarse bins (<= 2^12) for the first level's LDS-sorted tiles.  POSITIONAL 32-bit
+    // items: an item keeps the low `sbits` bits of its index, fb fine bucket bits and the sign; its super-chunk (the index
+    // bits above sbits) follows from where it lies in its coarse region (msm_part2_scatter_tiled_kernel).  Chunks of the
+    // first level are 2^16 (or more) consecutive indices, so every chunk lies inside one super-chunk.
+    for (uint32_t cb_try = 10; cb_try <= 12 && ps.nsc == 0; ++cb_try) {
+      if (c - 1 < cb_try + 5) break;
+      const uint32_t fb_p = c - 1 - cb_try, sbits = 31 - fb_p;
+      if (fb_p > 11 || sbits < 16) continue;                   // the tiled second level holds <= 2^11 fine counters
+      size_t chunk_p = (size_t)1 << 16;
+      while ((sn + chunk_p - 1) / chunk_p > 4096 && chunk_p < ((size_t)1 << sbits)) chunk_p <<= 1;
+      const size_t nsc = (sn + ((size_t)1 << sbits) - 1) >> sbits;
+      if (nsc > PS_MAX_SC || (sn + chunk_p - 1) / chunk_p > 4096) continue;
+      ib = sbits;
+      fb = fb_p;
+      G = (uint32_t)((sn + chunk_p - 1) / chunk_p);
+      chunk = chunk_p;
+      ps.G = G;
+      ps.gpc = (uint32_t)(((size_t)1 << sbits) / chunk_p);
+      ps.nsc = (uint32_t)nsc;
+    }
+  }
+#endif
+  if (ps.nsc == 0 && fb < 5 && c - 1 > fb) {   // too few fine bits left in 32: switch to 64-bit items
     wide_items = true;
     fb = c - 1 < 9 ? c - 1 : 9;      // few fine runs per region: the region's write sectors must stay in L2
   }
-  if (sn >= (1u << 15) && (c - 1) - fb < 5) fb = c - 1 > 5 ? c - 1 - 5 : 0;   // >= 32 regions per set: enough workgroups
+  if (ps.nsc == 0 && sn >= (1u << 15) && (c - 1) - fb < 5) fb = c - 1 > 5 ? c - 1 - 5 : 0;   // >= 32 regions per set: enough workgroups
   const uint32_t cb = (c - 1) - fb, NC = 1u << cb;
 
   // ---- workspace ----------------------------------------------------------------------------
@@ -1446,9 +1627,11 @@ static int msm_issue(DeviceCtx& ctx, int slot, const uint32_t* d_scalars_ext, co
                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
     HM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(msm_part2_scatter_kernel<false, uint64_t>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
-    HM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(msm_part1_scatter_tiled_kernel<uint32_t>),
+    HM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(msm_part1_scatter_tiled_kernel<uint32_t, P1_IPT_DEFAULT>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
-    HM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(msm_part1_scatter_tiled_kernel<uint64_t>),
+    HM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(msm_part1_scatter_tiled_kernel<uint64_t, P1_IPT_DEFAULT>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+    HM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(msm_part1_scatter_tiled_kernel<uint32_t, 8>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
     ctx.msm_attr_set = true;
   }
@@ -1471,8 +1654,14 @@ static int msm_issue(DeviceCtx& ctx, int slot, const uint32_t* d_scalars_ext, co
   HM_HIP_CHECK(hipEventRecord(ev[0], stream));
 
   // ---- K0 ------------------------------------------------------------------------------------
+  uint32_t n_wide = W;                                       // a shared bucket set: the balanced split its table was built for
+  if (single_set) {
+    uint32_t wide;
+    balanced_windows(W, &wide, &n_wide);
+    if (wide != c) return hm_fail(HM_ERR_INTERNAL, "msm: the base set's table was built for another window split");
+  }
   hipLaunchKernelGGL(msm_digits_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, stream, d_scalars_ext, d_inf,
-                     d_digits, n, c, W);
+                     d_digits, n, c, W, n_wide);
   HM_HIP_CHECK(hipGetLastError());
   if (pt) HM_HIP_CHECK(hipEventRecord(ev[1], stream));
 
@@ -1506,10 +1695,11 @@ static int msm_issue(DeviceCtx& ctx, int slot, const uint32_t* d_scalars_ext, co
     HM_HIP_CHECK(hipGetLastError());
   }
   {
+    ps.chist = d_chist;
     const int rc = wide_items ? launch_sort_scatter<uint64_t>(d_digits, d_cstart, d_tmp, d_boff, d_sorted, sn, SW, fb, ib, cb, NC,
-                                                              NBP, NBT, br, stream)
+                                                              NBP, NBT, br, ps, stream)
                               : launch_sort_scatter<uint32_t>(d_digits, d_cstart, d_tmp, d_boff, d_sorted, sn, SW, fb, ib, cb, NC,
-                                                              NBP, NBT, br, stream);
+                                                              NBP, NBT, br, ps, stream);
     if (rc != HM_OK) return rc;
   }
   if (pairs_max < (1u << 19)) {

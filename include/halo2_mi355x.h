@@ -81,13 +81,19 @@ int hm_release_bases(uint64_t handle);
 int hm_msm_bn256_g1_h(uint64_t handle, size_t offset, const uint64_t* scalars, size_t n, uint64_t out_xy[8],
                       int* out_is_identity);
 
-/* Fixed-base variant for long-lived SRS sets: additionally precomputes 2^(c*j) * P_i for every
- * window j (W x the memory: 12 GiB for 2^24 points -- sized for 288 GB of HBM), so that all windows
- * share one bucket set, the window grows from 16 to 22 bits and a quarter of the mixed additions
- * disappears.  MSMs that cover the whole set (offset 0, n = set size) use the table; other slices
- * fall back to the plain path on the same handle.  Results are identical either way. */
+/* Fixed-base variant for long-lived SRS sets (in halo2 the SRS is fixed for the life of the process:
+ * /root/reference/src/circuits/utils.rs:28): additionally stores 2^(offset of window j) * P_i for every window j
+ * (W x the memory: 12 GiB for 2^24 points -- sized for 288 GB of HBM; built once, ~0.22 s at 2^24), so that all
+ * windows share ONE bucket set, the window grows from 17 to 22 bits and a fifth of the mixed additions disappears
+ * (2^24 points: 19.5 ms against 21.5).  MSMs that cover the whole set (offset 0, n = set size) use the table; other
+ * slices run the plain path on the same handle.  Results are identical either way. */
 int hm_register_bases_precomp(const uint64_t* bases, size_t n, uint64_t* out_handle);
 int hm_register_bases_precomp_dev(const void* d_bases, size_t n, void* stream, uint64_t* out_handle);
+/* hm_register_bases / hm_register_bases_dev build that table BY THEMSELVES for sets of at least 2^log2_n points
+ * (default 23: from there the table pays at least 5 %; 0 = never, the plain layout only -- one copy of the points).
+ * Process-wide; read at registration time.  The environment variable HALO2_MI355X_FIXED_BASE_FROM_LOG sets the
+ * initial value. */
+int hm_set_fixed_base_threshold(uint32_t log2_n);
 
 /* Device-pointer forms (inputs already in HBM; `stream` is a hipStream_t or NULL).  The result is
  * written to host memory, so the call synchronises `stream` before returning. */
