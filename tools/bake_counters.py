@@ -36,7 +36,7 @@ def main():
     ap.add_argument("--sq", required=True)
     ap.add_argument("--traffic", required=True)
     ap.add_argument("--out", required=True)
-    ap.add_argument("--k3-pairs", type=int, default=15 * (1 << 24), help="(point, bucket) pairs of the profiled K3 launch")
+    ap.add_argument("--k3-pairs", type=int, default=15 * (1 << 24), help="(point, bucket) pairs of the profiled K3 launch (the bench line's `pairs`)")
     ap.add_argument("--ntt-elements", type=int, default=1 << 24)
     ap.add_argument("--note", default="")
     args = ap.parse_args()
@@ -46,17 +46,19 @@ def main():
             name, d = line.split(" ", 1)
             sq[name] = ast.literal_eval(d.strip())
     traffic = json.load(open(args.traffic))
+    ntt_name = next((k for k in sq if k.startswith("hm::ntt_pass_kernel<11")), None)        # "<11>" in round 2, "<11, false>" since
+    ntt_traffic = next((v for k, v in traffic.items() if k.startswith("hm::ntt_pass_kernel<11")), None)
     out = {
         "note": args.note,
         "k3": {"kernel": "hm::msm_accumulate_kernel", "sq_insts_valu_per_launch": sq["hm::msm_accumulate_kernel"]["SQ_INSTS_VALU"],
                "pairs_per_launch": args.k3_pairs, "grbm_gui_active": sq["hm::msm_accumulate_kernel"].get("GRBM_GUI_ACTIVE"),
                "from": os.path.relpath(args.sq, ROOT), "sources": SOURCES["k3"], "sources_sha256": sources_sha256("k3")},
-        "ntt": {"kernel": "hm::ntt_pass_kernel<11>", "sq_insts_valu_per_launch": sq["hm::ntt_pass_kernel<11>"]["SQ_INSTS_VALU"],
+        "ntt": {"kernel": ntt_name, "sq_insts_valu_per_launch": sq[ntt_name]["SQ_INSTS_VALU"],
                 "elements_per_launch": args.ntt_elements, "from": os.path.relpath(args.sq, ROOT), "sources": SOURCES["ntt"],
                 "sources_sha256": sources_sha256("ntt")},
         "traffic": {"from": os.path.relpath(args.traffic, ROOT),
                     "hm::msm_accumulate_kernel": traffic.get("hm::msm_accumulate_kernel"),
-                    "hm::ntt_pass_kernel<11>": traffic.get("hm::ntt_pass_kernel<11>")},
+                    "hm::ntt_pass_kernel<11>": ntt_traffic},
     }
     with open(args.out, "w") as f:
         json.dump(out, f, indent=1)

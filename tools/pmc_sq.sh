@@ -11,7 +11,7 @@ acc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
 for f in glob.glob('gpurun_out/pmc_sq/**/*counter_collection.csv', recursive=True):
     for r in csv.DictReader(open(f)):
         n = r['Kernel_Name'].split('(')[0].replace('void ', '')
-        if n in ('hm::msm_accumulate_kernel', 'hm::ntt_pass_kernel<11>'):
+        if n == 'hm::msm_accumulate_kernel' or n.startswith('hm::ntt_pass_kernel<11'):
             a = acc[n][r['Counter_Name']]; a[0] += float(r['Counter_Value']); a[1] += 1
 for n, d in acc.items():
     print(n, {k: round(v[0] / v[1]) for k, v in d.items()})
