@@ -559,7 +559,8 @@ def main():
                          "kernel": "msm_accumulate_kernel", "kernel_ms": acc,
                          "note": "integer-VALU bound (SURVEY.md §8d): n x windows mixed additions x ~2.24e3 32-bit ops per launch",
                          "valu_issue": valu_issue(baked, stale, "k3", st["pairs"], acc)},
-            "msm_phase_ms": {"sort": float(np.median(sort_ms)), "accumulate_kernel": acc, "device_total": float(np.median(tot_ms))},
+            "msm_phase_ms": {"sort": float(np.median(sort_ms)), "accumulate_kernel": acc, "device_total": float(np.median(tot_ms)),
+                         "pairs": int(st["pairs"]), "tasks": int(st["tasks"])},
             "known_answer_ok": answer_ok,
         }
         if ntt is not None:
