@@ -43,8 +43,8 @@ def main():
     sq = {}
     for line in open(args.sq):
         if line.startswith("hm::") and "{" in line:
-            name, d = line.split(" ", 1)
-            sq[name] = ast.literal_eval(d.strip())
+            name, d = line.split(" {", 1)
+            sq[name] = ast.literal_eval("{" + d.strip())
     traffic = json.load(open(args.traffic))
     ntt_name = next((k for k in sq if k.startswith("hm::ntt_pass_kernel<11")), None)        # "<11>" in round 2, "<11, false>" since
     ntt_traffic = next((v for k, v in traffic.items() if k.startswith("hm::ntt_pass_kernel<11")), None)
