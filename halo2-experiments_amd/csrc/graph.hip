@@ -48,6 +48,14 @@ struct GraphCalc {      // device form: 5 words; op carries the forwarding flags
 // those operands "take the previous result from registers" and those targets "never stored", which removes that share
 // of the [slot][word][lane] scratch traffic -- the interpreter is bound by it, not by the arithmetic.
 constexpr uint32_t GF_A_PREV = 1u << 8, GF_B_PREV = 1u << 9, GF_C_PREV = 1u << 10, GF_NO_STORE = 1u << 11;
+// Lazy reductions.  An intermediate is a normalised element (29-bit limbs) of value < GE_CAP * r, not < 3r: products
+// accept that (inputs < 18r give outputs < 3r; the column sums depend on the limbs only), so a sum or difference needs
+// its ~50-instruction modular reduction only when its STATIC bound -- propagated through the program at lowering time --
+// would pass GE_CAP.  GF_NO_REDUCE: carry propagation only.  GF_SUB_WIDE: the subtrahend may exceed 3r, so the
+// subtraction adds 20r instead of 4r (and is always reduced).  Bounds of every combination: hc_graph_bounds_closure
+// (host_check.cpp, HM_BOUNDS build), tests/test_ff29_host.py.
+constexpr uint32_t GF_NO_REDUCE = 1u << 12, GF_SUB_WIDE = 1u << 13;
+constexpr double GE_CAP = 16.0, GE_COLUMN_BOUND = 6.0;     // a packed 256-bit word is < 2^256 < 5.3 r whatever it holds
 
 __device__ __forceinline__ Fr ge_reduce(const Fr& lazy) { return fe_reduce_small(fe_norm(lazy)); }   // any lazy sum < 2^261 -> < 3r
 
@@ -65,7 +73,7 @@ __device__ __forceinline__ Fr ge_from_internal(const uint32_t* __restrict__ p) {
   const uint4 lo = q[0], hi = q[1];
   const uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
   Fr r = fe_unpack<FrParams>(w);
-  HM_DECLARE(r, 1.0);
+  HM_DECLARE(r, GE_COLUMN_BOUND);
   return r;
 }
 
@@ -94,7 +102,7 @@ __device__ __forceinline__ Fr ge_fetch(uint32_t src, const GraphColumns* __restr
     const uint32_t* p = scratch + (size_t)index * 9 * T + lane_slot;
 #pragma unroll
     for (int i = 0; i < 9; ++i) r.l[i] = p[(size_t)i * T];
-    HM_DECLARE(r, 3.0);
+    HM_DECLARE(r, GE_CAP);
   } else if (kind == GSRC_CONST) {
     if (index >= columns->n_static) {
       const uint32_t d = (index - columns->n_static) * 9;
@@ -141,13 +149,17 @@ __global__ __launch_bounds__(GE_THREADS) void graph_evaluate_kernel(const GraphC
       };
       const Fr a = src(cc.a, GF_A_PREV);
       Fr out;
+      const bool lazy = (cc.op & GF_NO_REDUCE) != 0, wide = (cc.op & GF_SUB_WIDE) != 0;      // wave-uniform
+      auto settle = [&](const Fr& t) -> Fr { return lazy ? fe_norm(t) : ge_reduce(t); };
       switch (op) {
         case GOP_ADD:
-          out = ge_reduce(fe_add(a, src(cc.b, GF_B_PREV)));
+          out = settle(fe_add(a, src(cc.b, GF_B_PREV)));
           break;
-        case GOP_SUB:
-          out = ge_reduce(fe_sub<4, 29>(a, src(cc.b, GF_B_PREV)));
+        case GOP_SUB: {
+          const Fr b = src(cc.b, GF_B_PREV);
+          out = wide ? ge_reduce(fe_sub<20, 29>(a, b)) : settle(fe_sub<4, 29>(a, b));
           break;
+        }
         case GOP_MUL:
           out = fe_mul(a, src(cc.b, GF_B_PREV));
           break;
@@ -155,15 +167,15 @@ __global__ __launch_bounds__(GE_THREADS) void graph_evaluate_kernel(const GraphC
           out = fe_sqr(a);
           break;
         case GOP_DOUBLE:
-          out = ge_reduce(fe_dbl(a));
+          out = settle(fe_dbl(a));
           break;
         case GOP_NEGATE:
-          out = ge_reduce(fe_sub<4, 29>(fe_zero<FrParams>(), a));
+          out = wide ? ge_reduce(fe_sub<20, 29>(fe_zero<FrParams>(), a)) : settle(fe_sub<4, 29>(fe_zero<FrParams>(), a));
           break;
         case GOP_MULADD: {   // a * b + c (one Horner step)
           const Fr b = src(cc.b, GF_B_PREV);
           const Fr c = src(cc.c, GF_C_PREV);
-          out = ge_reduce(fe_add(fe_mul(a, b), c));
+          out = settle(fe_add(fe_mul(a, b), c));
           break;
         }
         default:             // GOP_STORE
@@ -249,6 +261,50 @@ static int graph_lower(const GraphProgram& g, bool internal_cols, GraphVariant& 
     if (only_next && (!is_result || (result_prev && k == n - 1))) {     // read (if at all) by the next instruction only
       stored[k] = 0;
       flags[k] |= GF_NO_STORE;
+    }
+  }
+  // (2b) static value bounds (in units of r) -> which sums and differences keep their reduction
+  {
+    std::vector<double> vb(n_inter, 3.0);
+    auto bound_of = [&](uint32_t sw) -> double {
+      switch (gsrc_kind(sw)) {
+        case GSRC_CONST: return 1.0;                                  // canonical constants
+        case GSRC_INTER: return vb[gsrc_index(sw)];
+        case GSRC_COLUMN: return internal_cols ? GE_COLUMN_BOUND : 3.0;   // external words pass through a product
+        default: return 3.0;                                          // PreviousValue: a product output
+      }
+    };
+    for (size_t k = 0; k < n; ++k) {
+      const Ins& in = prog[k];
+      double r = 3.0;
+      uint32_t f = 0;
+      switch (in.op) {
+        case GOP_ADD: r = bound_of(in.src[0]) + bound_of(in.src[1]); break;
+        case GOP_DOUBLE: r = 2.0 * bound_of(in.src[0]); break;
+        case GOP_MULADD: r = 3.0 + bound_of(in.src[2]); break;
+        case GOP_SUB:
+        case GOP_NEGATE: {
+          const double minuend = in.op == GOP_SUB ? bound_of(in.src[0]) : 0.0;
+          const double subtrahend = bound_of(in.src[in.op == GOP_SUB ? 1 : 0]);
+          if (subtrahend <= 3.0) {
+            r = minuend + 4.0;
+          } else {
+            f |= GF_SUB_WIDE;                                         // reduced in the kernel whatever r is
+            r = 1e9;
+          }
+          break;
+        }
+        case GOP_STORE: r = bound_of(in.src[0]); f |= GF_NO_REDUCE; break;     // a copy
+        default: r = 3.0; f |= GF_NO_REDUCE; break;                   // Mul / Square: product outputs (the flag is not read)
+      }
+      if (!(f & (GF_NO_REDUCE | GF_SUB_WIDE))) {
+        if (r <= GE_CAP) f |= GF_NO_REDUCE;
+        else r = 3.0;                                                 // reduced
+      } else if (f & GF_SUB_WIDE) {
+        r = 3.0;
+      }
+      vb[in.target] = r;
+      flags[k] |= f;
     }
   }
   // (3) slots for what is stored

@@ -195,6 +195,61 @@ int hc_bounds_closure(const uint64_t* pj, const uint64_t* qj, const uint64_t* q_
 // The Fr vector formulas of ntt.hip / poly.hip / polyops.hip, each run once with its inputs DECLARED at the class
 // maxima the kernels rely on (raw 256-bit words: value < 2^256; products: < 2r; reduced sums: < 3r).  Any
 // precondition violation aborts; returns 1 when every result is inside the class its consumer expects.
+// The GraphEvaluator's lazy classes (graph.hip: GE_CAP = 16, GE_COLUMN_BOUND = 6): every stored intermediate is a
+// normalised element of value < 16 r.  Run every operation the interpreter has on operands DECLARED at the class
+// maxima (the bound tracking asserts each primitive's precondition) and check the outputs are back inside the class.
+int hc_graph_bounds_closure(const uint64_t* a_ext, double* report) {
+  typedef Fe<FrParams> F;
+  F x = load_ext<FrParams>(a_ext);
+  const double CAP = 16.0;
+  int ok = 1, r = 0;
+  F c16 = x, c16b = x, c3 = x, col = x;
+  force_bounds(c16, CAP);
+  force_bounds(c16b, CAP);
+  force_bounds(c3, 3.0);
+  force_bounds(col, 6.0);
+  // products of two class-maximum operands (and of column words) come out below 3r
+  F m = fe_mul(c16, c16b);
+  report[r++] = m.vb;
+  ok &= m.vb <= 3.0;
+  F q = fe_sqr(c16);
+  ok &= q.vb <= 3.0;
+  ok &= fe_mul(col, c16).vb <= 3.0;
+  // lazy sum at the cap: 8 + 8 -> norm only; a sum past the cap is reduced (16 + 16)
+  F h8 = x;
+  force_bounds(h8, 8.0);
+  F s16 = fe_norm(fe_add(h8, h8));
+  report[r++] = s16.vb;
+  ok &= s16.vb <= CAP;
+  F red = fe_reduce_small(fe_norm(fe_add(c16, c16b)));
+  ok &= red.vb <= 3.0;
+  F dbl = fe_reduce_small(fe_norm(fe_dbl(c16)));
+  ok &= dbl.vb <= 3.0;
+  // narrow subtraction (subtrahend < 3r): lazy while minuend + 4 <= cap, reduced above
+  F d12 = x;
+  force_bounds(d12, 12.0);
+  F sub_lazy = fe_norm(fe_sub<4, 29>(d12, c3));
+  report[r++] = sub_lazy.vb;
+  ok &= sub_lazy.vb <= CAP;
+  ok &= fe_reduce_small(fe_norm(fe_sub<4, 29>(c16, c3))).vb <= 3.0;
+  // wide subtraction (subtrahend up to the cap), always reduced; negation likewise
+  F sub_wide = fe_reduce_small(fe_norm(fe_sub<20, 29>(c16, c16b)));
+  report[r++] = sub_wide.vb;
+  ok &= sub_wide.vb <= 3.0;
+  ok &= fe_reduce_small(fe_norm(fe_sub<20, 29>(fe_zero<FrParams>(), c16))).vb <= 3.0;
+  ok &= fe_norm(fe_sub<4, 29>(fe_zero<FrParams>(), c3)).vb <= CAP;
+  // Horner step a * b + c: lazy while 3 + c <= cap
+  F d13 = x;
+  force_bounds(d13, 13.0);
+  F ma = fe_norm(fe_add(fe_mul(c16, c16b), d13));
+  report[r++] = ma.vb;
+  ok &= ma.vb <= CAP;
+  ok &= fe_reduce_small(fe_norm(fe_add(fe_mul(c16, c16b), c16))).vb <= 3.0;
+  // the result leaves through a reduction, the conversion product and the canonical form
+  (void)fe_canonical(fe_mul(fe_reduce_small(fe_norm(c16)), fe_const<FrParams>(FrParams::INT2EXT)));
+  return ok;
+}
+
 int hc_fr_vector_bounds_closure(const uint64_t* a_ext, const uint64_t* b_ext, double* report) {
   typedef Fe<FrParams> F;
   uint32_t wa[8], wb[8];

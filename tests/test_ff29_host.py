@@ -168,3 +168,17 @@ def test_fr_vector_formulas_bound_closure(hc, pyref):
     ok = hc.hc_fr_vector_bounds_closure(p(a[0]), p(b[0]), rep)
     assert ok == 1, list(rep)
     assert rep[0] < 8.0 and rep[1] <= 3.0 and rep[4] <= 3.0
+
+
+def test_graph_evaluator_lazy_classes_bound_closure(hc, pyref):
+    """csrc/graph.hip keeps intermediates as normalised elements < 16 r and reduces a sum or difference only when its static
+    bound would pass that cap (GF_NO_REDUCE / GF_SUB_WIDE).  Every operation of the interpreter with its operands declared
+    at the class maxima: each primitive's precondition holds (the HM_BOUNDS build aborts otherwise) and the outputs are
+    back inside the class."""
+    o = pyref
+    a = o.fr_array([o.R - 1])
+    rep = (ctypes.c_double * 8)()
+    hc.hc_graph_bounds_closure.restype = ctypes.c_int
+    ok = hc.hc_graph_bounds_closure(p(a[0]), rep)
+    assert ok == 1, list(rep)
+    assert rep[0] <= 3.0 and rep[1] <= 16.0 and rep[2] <= 16.0 and rep[3] <= 3.0 and rep[4] <= 16.0
