@@ -239,6 +239,51 @@ def test_precomputed_full_size_kzg_known_answer(cref, pyref):
         h.release_bases(hd)
 
 
+def test_fixed_base_table_is_the_registration_default_from_its_threshold(cref, pyref):
+    """hm_register_bases* builds the fixed-base table by itself from 2^threshold points (default 23; here lowered to 2^20
+    so that the oracle can check the result): one bucket set, fewer windows, the positional 32-bit sort items (n W = 2^23.7
+    items, 2^19 buckets), the balanced window split with doubled narrow digits -- against the oracle on uniform scalars and
+    on a column with a hot bucket; one point below the threshold, and with the threshold off, the plain layout."""
+    import torch
+    lib = _lib.load()
+    o = pyref
+    n = 1 << 20
+    bases = h.g1_fixed_base_mul(rand_fr_gpu(n, 4100), cref.g1_generator())
+    bh = bases.cpu().numpy().view(np.uint64)
+    s = rand_fr_gpu(n, 4101)
+    hot = s.clone()
+    hot[: n // 2] = torch.from_numpy(o.fr_array([5]).view(np.int64)).cuda()          # half the column is the constant 5
+    exp = [cref.g1_to_affine(cref.best_multiexp(c.cpu().numpy().view(np.uint64), bh, 8))[0] for c in (s, hot)]
+    assert lib.hm_set_fixed_base_threshold(3) == -1 and lib.hm_set_fixed_base_threshold(40) == -1
+    _lib.check(lib.hm_set_fixed_base_threshold(20))
+    try:
+        hd = h.register_bases(bases)
+        try:
+            assert g1_equal(h.best_multiexp(s, hd), exp[0])
+            st = h.msm_stats()
+            assert st["windows"] == 13 and st["window_bits"] == 20, st          # 255 bits = 8 x 20 + 5 x 19 over ONE bucket set
+            assert g1_equal(h.best_multiexp(hot, hd), exp[1])
+            part = h.best_multiexp(s[: n // 2].contiguous(), hd, offset=n // 4)      # a slice: the plain path on the same handle
+            assert g1_equal(part, cref.g1_to_affine(cref.best_multiexp(s[: n // 2].cpu().numpy().view(np.uint64), bh[n // 4: 3 * n // 4], 8))[0])
+        finally:
+            h.release_bases(hd)
+        hd = h.register_bases(bases[: n - 1].contiguous())                            # one point short of the threshold
+        try:
+            assert g1_equal(h.best_multiexp(s[: n - 1].contiguous(), hd),
+                            cref.g1_to_affine(cref.best_multiexp(s[: n - 1].cpu().numpy().view(np.uint64), bh[: n - 1], 8))[0])
+            assert h.msm_stats()["windows"] >= 15                                     # c = 16 or 17: the plain layout
+        finally:
+            h.release_bases(hd)
+        _lib.check(lib.hm_set_fixed_base_threshold(0))
+        hd = h.register_bases(bases)
+        try:
+            assert g1_equal(h.best_multiexp(s, hd), exp[0]) and h.msm_stats()["windows"] == 15
+        finally:
+            h.release_bases(hd)
+    finally:
+        _lib.check(lib.hm_set_fixed_base_threshold(23))
+
+
 @pytest.mark.parametrize("n", [16385, 65537, (1 << 17) + 5, 100003])
 def test_sizes_off_the_power_of_two_grid(cref, pyref, n):
     """Chunk / vector-load boundaries of the sort and ragged last chunks: n is arbitrary for an MSM."""
