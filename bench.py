@@ -363,7 +363,7 @@ def main():
         elapsed = float(t.item())
     st = h.msm_stats()
     # which layout the default registration chose shows in the plan: one shared bucket set has ceil(255 / c) < 15 windows at c > 17
-    headline_mode = ("fixed-base table (hm_register_bases default from 2^23 points: W copies 2^(offset_j) P_i, one shared bucket set)"
+    headline_mode = ("fixed-base table (hm_register_bases default from 2^17 points: W copies 2^(offset_j) P_i, one shared bucket set)"
                      if st["window_bits"] > 17 else "plain (one copy of the points, one bucket set per window)")
     answer_ok = answer_ok and bool(np.array_equal(result, expected_global))     # the timed steps' own result
     if not answer_ok:
@@ -438,7 +438,7 @@ def main():
         torch.cuda.synchronize()
         t_reg = time.perf_counter() - t1
         if other_is_plain:
-            _lib.check(lib.hm_set_fixed_base_threshold(23))
+            _lib.check(lib.hm_set_fixed_base_threshold(17))
         del bases2
         ref_out = h.best_multiexp(scalars, handle)
         got_pc = h.best_multiexp(scalars, hp)

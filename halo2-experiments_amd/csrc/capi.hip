@@ -35,7 +35,7 @@ static std::vector<int> g_msm_devices;             // hm_set_msm_devices; empty 
 static std::atomic<int> g_host_base_cache{1};      // hm_set_host_base_cache
 static std::atomic<uint32_t> g_fixed_base_from_log{[] {      // hm_set_fixed_base_threshold
   const char* v = std::getenv("HALO2_MI355X_FIXED_BASE_FROM_LOG");
-  return (uint32_t)(v && *v ? std::atoi(v) : 23);
+  return (uint32_t)(v && *v ? std::atoi(v) : 17);
 }()};
 
 int hm_fail(int code, const std::string& what) {
@@ -434,8 +434,10 @@ int hm_msm_bn256_g1_dev(uint64_t handle, size_t offset, const void* d_scalars, s
 } HM_API_CATCH("hm_msm_bn256_g1_dev")
 
 // One ticket = one launch chain = `group` MSMs over the same base range (group > 1 only where the five-launch plan applies).
+// use_table = false: run on the plain copy of the points even when the set carries a fixed-base table (the five-launch
+// plan with its block compaction is what a SPARSE column of a prover-sized phase wants)
 static int submit_chain(DeviceCtx* ctx, uint64_t handle, size_t offset, const void* const* d_scalars_list, uint32_t group, size_t n,
-                        void* stream, uint64_t* out_ticket, const char* who, bool* all_busy = nullptr) {
+                        void* stream, uint64_t* out_ticket, const char* who, bool* all_busy = nullptr, bool use_table = true) {
   if (all_busy) *all_busy = false;
   std::lock_guard<std::mutex> lk(ctx->mu);
   BasesEntry* b = find_bases(*ctx, handle);
@@ -448,7 +450,7 @@ static int submit_chain(DeviceCtx* ctx, uint64_t handle, size_t offset, const vo
     if (all_busy) *all_busy = true;             // the batch call retries: another thread's tickets hold the slots
     return hm_fail(HM_ERR_BAD_ARG, std::string(who) + ": every slot is in flight; hm_msm_wait one first");
   }
-  const uint32_t pc = (offset == 0 && n == b->n) ? b->pc_c : 0u;
+  const uint32_t pc = (use_table && group == 1 && offset == 0 && n == b->n) ? b->pc_c : 0u;
   int rc;
   if (group == 1) {
     ctx->msm_slots[slot].group = 1;
@@ -519,6 +521,7 @@ static int msm_batch_impl(DeviceCtx* ctx, uint64_t handle, size_t offset, const 
     if (!d_scalars[i] && n) return hm_fail(HM_ERR_BAD_ARG, "hm_msm_batch_bn256_g1_dev: null scalar array");
   // The chain plan: `order` lists the columns in submission order, chain ch carries order[first[ch] .. first[ch + 1]).
   std::vector<uint32_t> order(count), first;
+  std::vector<uint8_t> chain_plain;                // per chain: 1 = run on the plain copy of the points (no table)
   for (size_t i = 0; i < count; ++i) order[i] = (uint32_t)i;
   {
     bool small_plan = false;
@@ -528,8 +531,9 @@ static int msm_batch_impl(DeviceCtx* ctx, uint64_t handle, size_t offset, const 
       BasesEntry* b = find_bases(*ctx, handle);
       if (!b) return hm_fail(HM_ERR_NOT_FOUND, "hm_msm_batch_bn256_g1_dev: unknown base handle");
       if (offset > b->n || n > b->n - offset) return hm_fail(HM_ERR_BAD_ARG, "hm_msm_batch_bn256_g1_dev: offset + n exceeds the base set");
-      const uint32_t pc = (offset == 0 && n == b->n) ? b->pc_c : 0u;
-      small_plan = msm_group_applies(n, pc);
+      // the five-launch plan applies to the plain copy of the points, which a table set holds too (its first n entries):
+      // sparse columns go there, dense ones take the table's shared bucket set through the general pipeline
+      small_plan = msm_group_applies(n, 0);
       d_inf = b->d_inf + offset;
     }
     static const size_t group_max_n = [] { const char* v = std::getenv("HALO2_MI355X_GROUP_MAX_LOG"); return (size_t)1 << (v && *v ? std::atoi(v) : 16); }();
@@ -544,7 +548,10 @@ static int msm_batch_impl(DeviceCtx* ctx, uint64_t handle, size_t offset, const 
       const size_t chains = chains_min > want ? chains_min : want;
       size_t per_chain = (count + chains - 1) / (chains ? chains : 1);
       if (per_chain < 1) per_chain = 1;
-      for (size_t f = 0; f < count; f += per_chain) first.push_back((uint32_t)f);
+      for (size_t f = 0; f < count; f += per_chain) {
+        first.push_back((uint32_t)f);
+        chain_plain.push_back(1);
+      }
     } else if (small_plan && group_sparse && count >= 2) {
       // 2^17 .. 2^18: what a column costs depends on how many of its 256-row blocks SURVIVE the digits kernel's
       // compaction (zero scalars and identity bases contribute nothing), not on n.  A dense column is throughput-bound
@@ -576,6 +583,7 @@ static int msm_batch_impl(DeviceCtx* ctx, uint64_t handle, size_t offset, const 
       auto flush = [&]() {
         if (pending.empty()) return;
         first.push_back((uint32_t)plan.size());
+        chain_plain.push_back(1);
         plan.insert(plan.end(), pending.begin(), pending.end());
         pending.clear();
       };
@@ -583,8 +591,9 @@ static int msm_batch_impl(DeviceCtx* ctx, uint64_t handle, size_t offset, const 
         if ((uint64_t)live[i] * 16 <= total_blocks) {           // sparse: joins the pending group
           pending.push_back((uint32_t)i);
           if (pending.size() == (size_t)HM_MSM_GROUP) flush();
-        } else {                                                 // dense: a chain of its own
+        } else {                                                 // dense: a chain of its own (on the table when the set has one)
           first.push_back((uint32_t)plan.size());
+          chain_plain.push_back(0);
           plan.push_back((uint32_t)i);
         }
       }
@@ -596,6 +605,8 @@ static int msm_batch_impl(DeviceCtx* ctx, uint64_t handle, size_t offset, const 
     first.push_back((uint32_t)count);
   }
   const size_t n_chains = first.size() - 1;
+  chain_plain.resize(n_chains, 0);
+
   uint64_t tickets[kLanes];
   // chain ch uses lane ch % kLanes; the lane is free again once chain ch - kLanes has been awaited (finished[] is set)
   std::unique_ptr<std::atomic<uint8_t>[]> finished(new std::atomic<uint8_t>[n_chains + 1]);
@@ -719,7 +730,7 @@ static int msm_batch_impl(DeviceCtx* ctx, uint64_t handle, size_t offset, const 
     for (;;) {                                  // slots held by other callers' tickets (another thread's batch): wait for one
       bool all_busy = false;
       rc = submit_chain(ctx, handle, offset, chain_scalars, group, n, ctx->batch_streams[ch % kLanes], &tickets[ch % kLanes],
-                        "hm_msm_batch_bn256_g1_dev", &all_busy);
+                        "hm_msm_batch_bn256_g1_dev", &all_busy, chain_plain[ch] == 0);
       if (rc == HM_OK || !all_busy) break;
       if (now_us() - t_wait0 > 60e6) break;     // nobody awaits the tickets that hold the slots: report instead of spinning
       if (!waiters_started) start_waiters();

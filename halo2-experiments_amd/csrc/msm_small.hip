@@ -698,10 +698,15 @@ int msm_issue_small(DeviceCtx& ctx, int slot, const uint32_t* const* d_scalars_l
   if (pt) HM_HIP_CHECK(hipEventRecord(ev[3], stream));
   hipLaunchKernelGGL(msm_s_reduce1_kernel, dim3(G1n, V, group), dim3(WIN_THREADS), 0, stream, d_partial, (const uint32_t*)d_toff,
                      (const uint32_t*)d_nz, (const uint32_t*)d_nzc, d_seg1, NBh, H, SEG, G1n, ws_stride);
-  hipLaunchKernelGGL(msm_s_reduce2_kernel, dim3(W, group), dim3(WIN_THREADS), 0, stream, (const uint32_t*)d_seg1, H * G1n, d_win,
-                     (const uint32_t*)d_gctr, d_tot, ws_stride, res_stride, d_live);
+  // The last kernel writes the chain's results STRAIGHT into the slot's pinned, device-mapped landing zone: no D2H copy.
+  // (A hipMemcpyAsync of a group's 17.5 KiB blocked the SUBMITTING thread whenever three such copies were already
+  // outstanding -- the fourth chain of a sparse phase was enqueued 6.8 ms late: tools/phase_mix.py, HALO2 trace -- the
+  // general pipeline's 144-byte copies do not.)  The results are visible to the host once ev[4] has completed.
+  uint32_t* d_land = nullptr;
+  HM_HIP_CHECK(hipHostGetDevicePointer((void**)&d_land, sl.h_land, 0));
+  hipLaunchKernelGGL(msm_s_reduce2_kernel, dim3(W, group), dim3(WIN_THREADS), 0, stream, (const uint32_t*)d_seg1, H * G1n, d_land + 4,
+                     (const uint32_t*)d_gctr, d_land, ws_stride, res_stride, d_live);
   HM_HIP_CHECK(hipGetLastError());
-  HM_HIP_CHECK(hipMemcpyAsync(sl.totals(), d_tot, (size_t)group * res_stride * 4, hipMemcpyDeviceToHost, stream));
   HM_HIP_CHECK(hipEventRecord(ev[4], stream));
   sl.live_ptr = d_live;
   return HM_OK;

@@ -90,7 +90,9 @@ int hm_msm_bn256_g1_h(uint64_t handle, size_t offset, const uint64_t* scalars, s
 int hm_register_bases_precomp(const uint64_t* bases, size_t n, uint64_t* out_handle);
 int hm_register_bases_precomp_dev(const void* d_bases, size_t n, void* stream, uint64_t* out_handle);
 /* hm_register_bases / hm_register_bases_dev build that table BY THEMSELVES for sets of at least 2^log2_n points
- * (default 23: from there the table pays at least 5 %; 0 = never, the plain layout only -- one copy of the points).
+ * (default 17: measured gains 4 % at 2^17, 13 % per dense commitment of a phase at 2^18, 3 % at 2^20 .. 2^22, 5 % at
+ * 2^23, 9-15 % at 2^24, 15 % at 2^26; 0 = never, the plain layout only -- one copy of the points).  A phase of
+ * commitments still sends its SPARSE columns (few surviving 256-row blocks) through the plain copy's five-launch plan.
  * Process-wide; read at registration time.  The environment variable HALO2_MI355X_FIXED_BASE_FROM_LOG sets the
  * initial value. */
 int hm_set_fixed_base_threshold(uint32_t log2_n);

@@ -281,7 +281,7 @@ def test_fixed_base_table_is_the_registration_default_from_its_threshold(cref, p
         finally:
             h.release_bases(hd)
     finally:
-        _lib.check(lib.hm_set_fixed_base_threshold(23))
+        _lib.check(lib.hm_set_fixed_base_threshold(17))
 
 
 @pytest.mark.parametrize("n", [16385, 65537, (1 << 17) + 5, 100003])

@@ -13,7 +13,7 @@ k = int(sys.argv[1]) if len(sys.argv) > 1 else 18
 counts = [int(a) for a in sys.argv[2].split(",")] if len(sys.argv) > 2 else [1, 2, 4, 8, 16, 20, 32, 36]
 n = 1 << k
 dev = torch.device("cuda", 0)
-hd = h.register_bases(h.g1_fixed_base_mul(_rand_fr(n, 1, dev), G1_GENERATOR))
+hd = h.register_bases(h.g1_fixed_base_mul(_rand_fr(n, 1, dev), G1_GENERATOR), precompute=os.environ.get("PRECOMP") == "1")
 cols = {"dense": _rand_fr(n, 2, dev), "sparse": _sparse_column(n, 1100, 3, dev)}
 if os.environ.get("KIND"): cols = {os.environ["KIND"]: cols[os.environ["KIND"]]}
 for name, col in cols.items():
