@@ -90,7 +90,9 @@ def sharded_multiexp_batch(jobs, group=None, streams=None, local_batch: Optional
             partials[i:j] = best_multiexp_batch([col for col, _ in jobs[i:j]], jobs[i][1])
             i = j
     if group is _NO_GROUP or not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
-        return partials                 # one rank: the library's results are already normalised (x, y, 1) / zeros
+        if local_batch is None:
+            return partials             # one rank: the library's results are already normalised (x, y, 1) / zeros
+        return np.stack([g1_sum(p.reshape(1, 12)) for p in partials]) if len(partials) else partials     # a stand-in's may not be
     world = dist.get_world_size(group)
     backend = dist.get_backend(group)
     dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
