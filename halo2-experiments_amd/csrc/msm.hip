@@ -470,7 +470,7 @@ __global__ __launch_bounds__(SORT_THREADS) void msm_part2_scatter_kernel(const I
 // wave instruction (or two adjacent tiles) instead of by eight separate 4-byte stores spread over the
 // workgroup's lifetime, which is what kept missing L2 once a region had more than ~128 runs.
 #ifndef HM_P2_IPT
-#define HM_P2_IPT 4
+#define HM_P2_IPT 8
 #endif
 constexpr int P2_IPT = HM_P2_IPT;
 constexpr int P2_TILE = SORT_THREADS * P2_IPT;
@@ -515,7 +515,7 @@ __global__ __launch_bounds__(SORT_THREADS) void msm_part2_scatter_tiled_kernel(c
   uint32_t* tstart = tcnt + NF;                       // exclusive prefix of tcnt
   uint32_t* wsum = tstart + NF;                       // 32 wave totals of the scan
   uint32_t* st_pay = wsum + 32;                       // tile items in bucket order
-  uint32_t* st_bin = st_pay + P2_TILE;
+  uint16_t* st_bin = reinterpret_cast<uint16_t*>(st_pay + P2_TILE);   // their fine buckets (< 2^11)
   const uint32_t* bo = boff + (size_t)w * NBP + 1 + ((size_t)hb << fb);
   uint32_t* gc = gcursor + (size_t)w * NBP + 1 + ((size_t)hb << fb);
   for (uint32_t b = tid; b < NF; b += SORT_THREADS) { gcur[b] = bo[b]; tcnt[b] = 0; }
@@ -599,7 +599,7 @@ __global__ __launch_bounds__(SORT_THREADS) void msm_part2_scatter_tiled_kernel(c
       if (e < tile_n) {
         const uint32_t pos = tstart[bin[k]] + rank[k];
         st_pay[pos] = pay[k];
-        st_bin[pos] = bin[k];
+        st_bin[pos] = (uint16_t)bin[k];
       }
     }
     if (COOP)      // reserve this tile's run in every non-empty bucket
@@ -1386,7 +1386,7 @@ static int launch_sort_scatter(const int32_t* d_digits, const uint32_t* d_cstart
                                uint32_t NBP, uint32_t NBT, const BigRegionPlan& br, const Positional& ps, hipStream_t stream) {
   const size_t lds_fine = (size_t)4 << fb;
   if (cb && fb <= 11) {
-    const size_t lds_tiled = ((size_t)3 * (1u << fb) + 32 + 2 * P2_TILE) * 4;
+    const size_t lds_tiled = ((size_t)3 * (1u << fb) + 32 + P2_TILE) * 4 + (size_t)P2_TILE * 2;
     hipLaunchKernelGGL((msm_part2_scatter_tiled_kernel<ITEM, false>), dim3(NC, SW), dim3(SORT_THREADS), lds_tiled, stream,
                        (const ITEM*)d_tmp, d_cstart, d_boff, d_sorted, fb, ib, NC, NBP, br.big, br.slice, (const uint2*)br.list,
                        (const uint32_t*)br.count, br.gcursor, ps);
