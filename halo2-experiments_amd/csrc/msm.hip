@@ -1462,7 +1462,14 @@ static int msm_issue(DeviceCtx& ctx, int slot, const uint32_t* d_scalars_ext, co
   const uint32_t NB = 1u << (c - 1), NBP = NB + 1, NBT = SW * NBP;
   const uint64_t pairs_max = (uint64_t)n * W;
   if (pairs_max >= (1ull << 31)) return hm_fail(HM_ERR_BAD_ARG, "msm: n * windows must be < 2^31");
-  const double mean = (double)sn / (double)NB;
+  double mean = (double)sn / (double)NB;
+  if (single_set) {
+    // narrow windows fill the even buckets only (msm_digits_kernel): size the tasks for THOSE buckets' load, so that a
+    // bucket stays one task (at c = 22, W = 12: 168 points in an even bucket, 24 in an odd one, 96 on average)
+    uint32_t wide_b, n_wide_b;
+    balanced_windows(W, &wide_b, &n_wide_b);
+    mean = (double)n * n_wide_b / (double)NB + (double)n * (W - n_wide_b) / ((double)NB / 2.0);
+  }
 #ifndef HM_L_MEAN_SCALE      // measurement knobs (tools/ab_build.sh); the defaults are the tuned values
 #define HM_L_MEAN_SCALE 1.0
 #endif
