@@ -358,8 +358,9 @@ def run_replay(shape_name: str, device=None, group=None, include_host_pointer_es
         # other commitments' kernels): what a prover that keeps its polynomials in host vectors gets per proof
         from .arithmetic import best_multiexp_batch
         h_sparse, h_dense = sparse[0].cpu().numpy().view(np.uint64), h_s
-        best_multiexp_batch([h_sparse] * counts["msm_sparse"], gl_h)     # warm-up: the per-lane staging buffers reach their size here
-        best_multiexp_batch([h_dense] * counts["msm_dense"], gl_h)
+        for _ in range(2):                   # warm-up: the per-lane staging buffers and slot workspaces reach their sizes here
+            best_multiexp_batch([h_sparse] * counts["msm_sparse"], gl_h)
+            best_multiexp_batch([h_dense] * counts["msm_dense"], gl_h)
         t0 = time.perf_counter()
         best_multiexp_batch([h_sparse] * counts["msm_sparse"], gl_h)
         best_multiexp_batch([h_dense] * counts["msm_dense"], gl_h)
