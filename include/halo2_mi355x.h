@@ -316,7 +316,8 @@ typedef struct hm_stats {
   uint64_t ntt_calls, ntt_elements;       /* best_fft-equivalent transforms (a batched call of b arrays counts b) */
   uint64_t msm_calls_by_log2[32];         /* histogram over floor(log2 n) */
   uint64_t ntt_calls_by_log2[32];         /* histogram over log_n */
-  double msm_h2d_us, msm_device_us, msm_host_us;  /* host-pointer uploads; hipEvent span of the launches; host fold */
+  double msm_h2d_us, msm_device_us, msm_host_us;  /* host-pointer uploads; SUM of the hipEvent spans of the launch chains (a grouped
+                                                     chain counts once; chains in flight overlap: not a wall time); host fold */
   double ntt_h2d_us, ntt_device_us, ntt_d2h_us;   /* host-pointer form only (device-pointer calls are not waited for) */
   uint64_t h2d_bytes, d2h_bytes;          /* bytes the host-pointer forms moved over PCIe */
   /* the entry points beyond the two functions, by HM_STAT_* kind: calls (queries / lookups where a call carries several)
