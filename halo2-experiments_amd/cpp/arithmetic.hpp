@@ -95,6 +95,13 @@ inline void permute_expression_pair(const Fr* d_input, const Fr* d_table, size_t
   check(hm_lookup_permute_bn256_fr_dev(d_input, d_table, usable_rows, d_permuted_input, d_permuted_table, stream), "permute_expression_pair");
 }
 
+// One process, several GPUs (what the reference's prover is: /root/reference/src/circuits/utils.rs:22-70): after this call
+// ParamsKZG registrations replicate (or slice) their base sets over `devices` and best_multiexp / commit phases are split
+// inside the library (csrc/multi.hip).  An empty list restores the calling thread's device.
+inline void use_devices(const std::vector<int>& devices) {
+  check(hm_set_msm_devices(devices.empty() ? nullptr : devices.data(), (int)devices.size()), "use_devices");
+}
+
 // affine normalisation of a G1 the library returned: it is already (x, y, 1) or the identity
 inline G1Affine to_affine(const G1& p) {
   if (p.is_identity()) return G1Affine::identity();

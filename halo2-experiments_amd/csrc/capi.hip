@@ -247,7 +247,7 @@ int hm_set_device(int device) try {
 } HM_API_CATCH("hm_set_device")
 
 const char* hm_last_error(void) { return g_last_error.c_str(); }
-const char* hm_version(void) { return "halo2_mi355x 0.2 (gfx950; ff29 field layer)"; }
+const char* hm_version(void) { return "halo2_mi355x 0.3 (gfx950; ff29 field layer)"; }
 
 int hm_shutdown(void) try {
   int dev = 0;
