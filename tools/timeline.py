@@ -6,7 +6,7 @@ root = sys.argv[1]
 tail = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 f = sorted(glob.glob(root + "/**/*kernel_trace.csv", recursive=True))[-1]
 rows = list(csv.DictReader(open(f)))
-rows = [r for r in rows if "msm_s_" in r["Kernel_Name"] or "msm_digits" in r["Kernel_Name"]]
+rows = [r for r in rows if "hm::msm_" in r["Kernel_Name"]]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 if tail: rows = rows[-tail:]
 by = collections.defaultdict(list)
