@@ -281,7 +281,10 @@ int hm_shutdown(void) try {
     c.batch_streams_ready = false;
   }
   for (auto& b : c.batch_io) b.release();
-  c.live_io.release();
+  {
+    std::lock_guard<std::mutex> lk3(c.live_mu);
+    c.live_io.release();
+  }
   c.io.release(); c.io_bases.release(); c.conv_bases.release(); c.conv_inf.release();
   c.cached_host_n = 0;
   c.cached_xy = nullptr;

@@ -128,7 +128,10 @@ struct MsmStats {
 };
 
 constexpr int HM_MSM_GROUP = 8;   // scalar arrays one launch chain of the five-launch plan carries (msm_small.hip)
-constexpr int HM_MSM_SLOTS = 9;   // slot 0: synchronous calls; 1..8: asynchronous tickets (workspaces allocated on first use)
+#ifndef HM_MSM_SLOTS_N
+#define HM_MSM_SLOTS_N 9
+#endif
+constexpr int HM_MSM_SLOTS = HM_MSM_SLOTS_N;   // slot 0: synchronous calls; 1..8: asynchronous tickets (workspaces allocated on first use)
 
 struct MsmSlot {            // one in-flight MSM: its workspace, events and host landing buffers
   DevBuf ws;
@@ -221,6 +224,7 @@ struct DeviceCtx {
   bool batch_streams_ready = false;
   DevBuf batch_io[HM_MSM_SLOTS - 1];                  // hm_msm_batch_bn256_g1_h: per-lane staging of host scalar arrays
   DevBuf live_io;                                     // msm_count_live_blocks: column pointers in, block counts out
+  std::mutex live_mu;                                 // ... one counting call at a time (never taken under mu)
   std::mutex batch_h_mu;                              // ... which belong to ONE _h batch call at a time (taken before mu, never under it)
   uint64_t next_handle = 1;
   // drop-in MSM: the converted bases of the previous call, keyed by a digest of the WHOLE host array (capi.hip)

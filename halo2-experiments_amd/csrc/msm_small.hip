@@ -542,11 +542,10 @@ int msm_count_live_blocks(DeviceCtx& ctx, const void* const* d_columns, size_t c
                           uint32_t* live_out) {
   if (count == 0 || n == 0) return HM_OK;
   if (count > 65535) return hm_fail(HM_ERR_BAD_ARG, "msm: more than 65535 commitments in one phase");
-  uint8_t* buf;
-  {
-    std::lock_guard<std::mutex> lk(ctx.mu);
-    buf = (uint8_t*)ctx.live_io.ensure(count * (sizeof(void*) + 4));
-  }
+  // the buffer belongs to one counting call at a time (two threads may batch on one device): held to the end, the call
+  // is synchronous and short
+  std::lock_guard<std::mutex> turn(ctx.live_mu);
+  uint8_t* buf = (uint8_t*)ctx.live_io.ensure(count * (sizeof(void*) + 4));
   if (!buf) return hm_fail(HM_ERR_HIP, "msm: live-block buffer allocation failed");
   uint32_t* d_counts = (uint32_t*)(buf + count * sizeof(void*));
   HM_HIP_CHECK(hipMemcpyAsync(buf, d_columns, count * sizeof(void*), hipMemcpyHostToDevice, stream));
