@@ -546,16 +546,21 @@ def test_grouped_chains_with_empty_ragged_and_identity_rows(cref, pyref):
         h.release_bases(hd)
 
 
-def test_two_threads_batch_at_once(cref):
+@pytest.mark.parametrize("log_n", [12, 17])
+def test_two_threads_batch_at_once(cref, log_n):
     """Two host threads each commit a phase through hm_msm_batch_bn256_g1_dev at the same time (the library is advertised
-    as thread-safe; the eight asynchronous slots are shared, so each call has to wait for the other's tickets)."""
+    as thread-safe; the eight asynchronous slots are shared, so each call has to wait for the other's tickets).  At 2^17
+    both calls also count surviving blocks (one shared buffer, one call at a time), group their sparse columns and send
+    the dense ones through the fixed-base table."""
     import threading
     from halo2_experiments_amd.arithmetic import best_multiexp_batch
-    n = 1 << 12
+    n = 1 << log_n
     bases = h.g1_fixed_base_mul(rand_fr_gpu(n, 8500), cref.g1_generator())
     hd = h.register_bases(bases)
     try:
-        cols = [[rand_fr_gpu(n, 8600 + 40 * t + i) for i in range(21)] for t in range(2)]
+        count = 21 if log_n == 12 else 11
+        cols = [[rand_fr_gpu(n, 8600 + 40 * t + i) if i % 3 else _replay_sparse_column(n, 300, 8700 + 40 * t + i) for i in range(count)]
+                for t in range(2)]
         want = [np.stack([h.best_multiexp(c, hd) for c in cs]) for cs in cols]
         got, errs = [None, None], []
 
