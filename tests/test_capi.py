@@ -176,3 +176,25 @@ def test_generated_rust_files_are_up_to_date():
     glue = open(os.path.join(gen.RUST_DIR, "halo2_proofs-patch", "src", "mi355x.rs")).read()
     for fn in re.findall(r"sys::(hm_\w+)", glue):         # the glue only calls entry points the header declares
         assert fn in declared_symbols(), fn
+
+
+def test_header_is_plain_c(tmp_path):
+    """The boundary is a C ABI: the header must compile as C99 (no C++-isms), and a C program must link against the
+    library's entry points -- what cgo / JNI / a Rust `cc` build would do with it."""
+    import subprocess
+    src = tmp_path / "abi.c"
+    src.write_text('#include "halo2_mi355x.h"\n'
+                   "#include <stdio.h>\n"
+                   "int main(void) {\n"
+                   "  hm_stats st; hm_msm_stats ms; uint64_t out[12] = {0}; (void)st; (void)ms;\n"
+                   "  if (hm_g1_sum(0, 0, out) != HM_OK) return 2;            /* host-only entry: the empty sum is the identity */\n"
+                   "  if (hm_msm_set_window(99) != HM_ERR_BAD_ARG) return 3;\n"
+                   '  printf("%s devices=%d flags=%d\\n", hm_version(), hm_device_count(), HM_GRAPH_COLUMNS_INTERNAL);\n'
+                   "  return out[8] == 0 ? 0 : 4;\n"
+                   "}\n")
+    inc = os.path.dirname(os.path.abspath(_lib.HEADER_PATH))
+    exe = tmp_path / "abi"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", inc, str(src), "-o", str(exe), "-L", _lib.CSRC,
+                    "-lhalo2_mi355x", f"-Wl,-rpath,{_lib.CSRC}"], check=True, capture_output=True)
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "gfx950" in r.stdout, r.stdout + r.stderr
