@@ -1288,11 +1288,16 @@ static void balanced_windows(uint32_t W, uint32_t* wide, uint32_t* n_wide) {
 uint32_t msm_precomp_window(size_t n) {
   uint32_t best = 8;
   double best_cost = 1e300;
-  for (uint32_t c = 8; c <= 24; ++c) {
+  // (capped at 22: the model knows additions only.  Measured at 2^25 / 2^26, c = 24 against 22: K3 26.6 / 51.4 against
+  // 28.6 / 56.0 ms, but the sort 8.8 / 16.6 against 6.0 / 12.0 -- 2^23 buckets need 4 096 coarse bins, two items per bin
+  // and first-level tile -- and the bucket reduction 2.8 against 1.3: whole MSM 39.2 / 72.2 against 36.5 / 70.5 ms)
+  for (uint32_t c = 8; c <= 22; ++c) {
     const double W = (double)((255 + c - 1) / c);
     const double cost = (double)n * W + 3.0 * (double)(1ull << (c - 1));
     if (cost < best_cost) { best_cost = cost; best = c; }
   }
+  static const int forced = [] { const char* v = std::getenv("HALO2_MI355X_PRECOMP_C"); return v && *v ? std::atoi(v) : 0; }();   // experiments
+  if (forced >= 8 && forced <= 24) best = (uint32_t)forced;
   uint32_t wide, n_wide;
   balanced_windows((255 + best - 1) / best, &wide, &n_wide);     // the widest window of the balanced split (<= best)
   return wide;
