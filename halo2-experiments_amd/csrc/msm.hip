@@ -1024,6 +1024,71 @@ __global__ __launch_bounds__(WIN_THREADS) void msm_sum_points_kernel(const uint3
   if (t == 0) store_jac(out + ((size_t)w * out_count + blk) * PT_WORDS, r);
 }
 
+// K4 for a SHARED bucket set (one window, up to 2^21 buckets), two launches deep instead of a running-sum chain.
+// With j = b - 1 = hi * M + lo (M * H = NB, both powers of two):
+//     sum_b b B_b = sum_lo lo * C_lo + sum_hi (M * hi + 1) * R_hi,     C_lo = sum_hi B, R_hi = sum_lo B
+// so every bucket enters two PLAIN sums (a column and a row: any order, lanes then an LDS tree), the same two additions
+// per bucket the running sums cost, without their serial chain of 2 * SEG additions and the log2(NB)-bit multiple behind
+// it.  The H + M sums are then split by weight BIT: S_p = sum of the sums whose weight has bit p, one workgroup per
+// bit, and the host fold, which doubles its way down 255 bits anyway, reads the c - 1 records S_p as windows of one bit.
+// Launch 1: workgroup `blk` < H sums row hi = blk, the others column lo = blk - H.
+__global__ __launch_bounds__(WIN_THREADS) void msm_reduce_rowcol_kernel(const uint32_t* __restrict__ bucket, uint32_t* __restrict__ sums,
+                                                                        uint32_t m, uint32_t h) {
+  __shared__ uint32_t tree[WIN_THREADS * PT_WORDS];
+  const uint32_t M = 1u << m, H = 1u << h, blk = blockIdx.x, t = threadIdx.x;
+  const bool row = blk < H;
+  const uint32_t count = row ? M : H;                                  // elements of this sum
+  const uint32_t first = row ? blk * M : blk - H, stride = row ? 1u : M;
+  const uint32_t* b1 = bucket + PT_WORDS;                              // bucket b = j + 1
+  G1Jac acc = g1_identity();
+  if (t < count) {
+    G1Jac cur = load_jac(b1 + (size_t)(first + t * stride) * PT_WORDS);
+    for (uint32_t e = t; e < count; e += WIN_THREADS) {                // the next record is requested before the addition starts
+      const uint32_t en = e + WIN_THREADS;
+      const G1Jac nxt = en < count ? load_jac(b1 + (size_t)(first + en * stride) * PT_WORDS) : g1_identity();
+      acc = g1_add(acc, cur);
+      cur = nxt;
+    }
+  }
+  const G1Jac r = block_sum_points_upto(tree, acc, count < WIN_THREADS ? count : WIN_THREADS);
+  if (t == 0) store_jac(sums + (size_t)blk * PT_WORDS, r);
+}
+
+// Launch 2: workgroup p sums the rows / columns whose weight has bit p and writes the record the host fold reads.
+// Columns: weight lo (bits 0 .. m - 1).  Rows: weight M * hi + 1 (bit 0, and bits m .. m + h - 1).
+__global__ __launch_bounds__(WIN_THREADS) void msm_reduce_bits_kernel(const uint32_t* __restrict__ sums, uint32_t m, uint32_t h,
+                                                                      uint32_t* __restrict__ winres) {
+  __shared__ uint32_t tree[WIN_THREADS * PT_WORDS];
+  const uint32_t M = 1u << m, H = 1u << h, p = blockIdx.x, t = threadIdx.x;
+  const uint32_t* rows = sums;
+  const uint32_t* cols = sums + (size_t)H * PT_WORDS;
+  G1Jac acc = g1_identity();
+  uint32_t widest = 0;                                                 // lanes holding anything: the tree's width
+  if (p < m) {                                                         // the M / 2 columns with bit p of lo set
+    const uint32_t half = M >> 1, low = (1u << p) - 1u;
+    for (uint32_t i = t; i < half; i += WIN_THREADS) {
+      const uint32_t lo = ((i & ~low) << 1) | (1u << p) | (i & low);
+      acc = g1_add(acc, load_jac(cols + (size_t)lo * PT_WORDS));
+    }
+    widest = half;
+    if (p == 0) {                                                      // every row: the + 1 of its weight
+      for (uint32_t hi = t; hi < H; hi += WIN_THREADS) acc = g1_add(acc, load_jac(rows + (size_t)hi * PT_WORDS));
+      if (H > widest) widest = H;
+    }
+  } else {                                                             // the H / 2 rows with bit p - m of hi set
+    const uint32_t q = p - m, half = H >> 1, low = (1u << q) - 1u;
+    for (uint32_t i = t; i < half; i += WIN_THREADS) {
+      const uint32_t hi = ((i & ~low) << 1) | (1u << q) | (i & low);
+      acc = g1_add(acc, load_jac(rows + (size_t)hi * PT_WORDS));
+    }
+    widest = half;
+  }
+  if (widest > WIN_THREADS) widest = WIN_THREADS;
+  if (widest < 1) widest = 1;
+  const G1Jac r = block_sum_points_upto(tree, acc, widest);
+  if (t == 0) store_window_ext(winres + (size_t)p * 32, r);
+}
+
 // window sums -> the external Jacobian format (12 x u64 + flag word) the host fold reads
 __global__ void msm_windows_to_ext_kernel(const uint32_t* __restrict__ in, uint32_t W, uint32_t* __restrict__ winres) {
   const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1514,6 +1579,11 @@ static int msm_issue(DeviceCtx& ctx, int slot, const uint32_t* d_scalars_ext, co
 #endif
   if (SEG > NB) SEG = NB;
   const uint32_t nseg = (NB + SEG - 1) / SEG;
+  // a shared bucket set: row / column sums and one record per weight bit instead (msm_reduce_rowcol_kernel)
+  static const bool k4_chain_only = [] { const char* v = std::getenv("HALO2_MI355X_K4_CHAIN"); return v && *v == '1'; }();   // A/B
+  const bool k4_2d = single_set && NB >= 16 && !k4_chain_only;
+  const uint32_t k4_m = (c - 1 + 1) / 2, k4_h = (c - 1) - k4_m;        // M = 2^m columns, H = 2^h rows, M * H = NB
+  const uint32_t RW = k4_2d ? c - 1 : SW;                               // records the host fold reads
   // sort plan: item = [fine bucket bits | sign | item index]
   uint32_t ib = ilog2(sn) + ((sn & (sn - 1)) ? 1u : 0u);
   if (ib == 0) ib = 1;
@@ -1572,9 +1642,9 @@ static int msm_issue(DeviceCtx& ctx, int slot, const uint32_t* d_scalars_ext, co
   const size_t o_tkeys = carve(2 * TASK_KEYS * 4);
   const size_t o_partial = carve(T_max * PT_WORDS * 4);
   const size_t o_bucket = carve((size_t)NBT * PT_WORDS * 4);
-  const size_t o_seg = carve((size_t)SW * nseg * PT_WORDS * 4);
+  const size_t o_seg = carve(k4_2d ? (((size_t)1 << k4_m) + ((size_t)1 << k4_h)) * PT_WORDS * 4 : (size_t)SW * nseg * PT_WORDS * 4);
   const size_t o_seg2 = carve(((size_t)SW * (nseg / SUM_SPAN + 1)) * PT_WORDS * 4);
-  const size_t o_res = carve((4 + (size_t)SW * 32) * 4);   // results: 4 totals words, then the window sums (one D2H copy)
+  const size_t o_res = carve((4 + (size_t)RW * 32) * 4);   // results: 4 totals words, then the window sums (one D2H copy)
   const size_t o_big = carve(((size_t)NBT + 4) * 4);
   const size_t o_slices = carve((T_max / FINALIZE_SLICE + T_max / (FINALIZE_SERIAL + 1) + 2) * 8);
   // cooperative sort of oversized regions (hot buckets): split anything above 4x the mean region
@@ -1652,10 +1722,11 @@ static int msm_issue(DeviceCtx& ctx, int slot, const uint32_t* d_scalars_ext, co
     const int rc = msm_slot_prepare(sl);
     if (rc != HM_OK) return rc;
   }
-  sl.SW = SW;
+  sl.SW = RW;                                     // what the host fold reads: window sums, or one-bit records of a shared set
   sl.c = c;
   sl.W = W;
-  sl.balanced = false;
+  sl.balanced = k4_2d;                            // ... which weigh one bit each
+  if (k4_2d) std::memset(sl.win_bits, 1, RW);
   sl.group = 1;
   sl.live_ptr = nullptr;                          // the general pipeline writes all over the workspace
   sl.phase_timed = msm_phase_timing(false);
@@ -1761,6 +1832,12 @@ static int msm_issue(DeviceCtx& ctx, int slot, const uint32_t* d_scalars_ext, co
   if (pt) HM_HIP_CHECK(hipEventRecord(ev[3], stream));
 
   // ---- K4 ------------------------------------------------------------------------------------
+  if (k4_2d) {
+    hipLaunchKernelGGL(msm_reduce_rowcol_kernel, dim3((1u << k4_m) + (1u << k4_h)), dim3(WIN_THREADS), 0, stream,
+                       (const uint32_t*)d_bucket, d_seg, k4_m, k4_h);
+    hipLaunchKernelGGL(msm_reduce_bits_kernel, dim3(RW), dim3(WIN_THREADS), 0, stream, (const uint32_t*)d_seg, k4_m, k4_h, d_win);
+    HM_HIP_CHECK(hipGetLastError());
+  } else {
   hipLaunchKernelGGL(msm_reduce_segments_kernel, dim3((SW * nseg + ACC_THREADS - 1) / ACC_THREADS), dim3(ACC_THREADS), 0,
                      stream, (const uint32_t*)d_bucket, d_seg, SW, NB, NBP, SEG, nseg);
   HM_HIP_CHECK(hipGetLastError());
@@ -1779,9 +1856,10 @@ static int msm_issue(DeviceCtx& ctx, int slot, const uint32_t* d_scalars_ext, co
     hipLaunchKernelGGL(msm_windows_to_ext_kernel, dim3((SW + 63) / 64), dim3(64), 0, stream, (const uint32_t*)cur, SW, d_win);
     HM_HIP_CHECK(hipGetLastError());
   }
-  if (SW > 128) return hm_fail(HM_ERR_INTERNAL, "msm: more than 128 windows");
+  }
+  if (RW > 128) return hm_fail(HM_ERR_INTERNAL, "msm: more than 128 windows");
   // pinned landing zone, so that this copy (and therefore msm_enqueue) does not wait for the device
-  HM_HIP_CHECK(hipMemcpyAsync(sl.totals(), d_tot, (4 + (size_t)SW * 32) * 4, hipMemcpyDeviceToHost, stream));
+  HM_HIP_CHECK(hipMemcpyAsync(sl.totals(), d_tot, (4 + (size_t)RW * 32) * 4, hipMemcpyDeviceToHost, stream));
   HM_HIP_CHECK(hipEventRecord(ev[4], stream));
   return HM_OK;
 }
