@@ -817,6 +817,34 @@ def test_repeated_and_opposite_bases_inside_bucket_chains(cref, pyref, pattern):
         h.release_bases(hd)
 
 
+@pytest.mark.parametrize("alternate", [False, True])
+def test_shared_set_reduction_meets_equal_and_opposite_bucket_values(cref, pyref, alternate):
+    """Every base the same point G (or G, -G, G, ...): the table's entries of one window are all equal, so the buckets of
+    the shared set hold small multiples of the same few points and the row / column sums and bit sums of the reduction
+    (msm_reduce_rowcol_kernel, msm_reduce_bits_kernel) keep adding a value to itself or to its negative -- the doubling
+    and the cancellation branch of the general law inside plain sums.  Known answer: [sum (+-) s_i] G."""
+    import torch
+    o = pyref
+    n = 1 << 17
+    gen = cref.g1_generator()
+    bases = np.tile(gen, (n, 1))
+    x = o.fr_array([1])[0]
+    if alternate:
+        neg = gen.copy()
+        neg[4:] = o.to_limbs((o.P - o.from_limbs(gen[4:])) % o.P)
+        bases[1::2] = neg
+        x = o.fr_array([o.R - 1])[0]
+    f = rand_fr_gpu(n, 4242 + int(alternate))
+    exp = cref.g1_mul(cref.fr_horner(f.cpu().numpy().view(np.uint64), x), gen)
+    hd = h.register_bases(np.ascontiguousarray(bases))
+    try:
+        got = h.best_multiexp(f, hd)
+        assert h.msm_stats()["window_bits"] >= 16 and h.msm_stats()["windows"] <= 16      # the shared bucket set
+        assert g1_equal(got, exp)
+    finally:
+        h.release_bases(hd)
+
+
 @pytest.mark.parametrize("n", [257, 600, 1500, 2049, 4097, 6000, 8191, 12000, 20000, 40000, 70000])
 def test_ragged_small_sizes_across_the_window_table(cref, pyref, n):
     """One size inside every entry of the window table below 2^17 (and the bucket-reduction segment
