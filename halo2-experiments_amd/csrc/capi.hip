@@ -440,7 +440,8 @@ int hm_msm_bn256_g1_dev(uint64_t handle, size_t offset, const void* d_scalars, s
 // use_table = false: run on the plain copy of the points even when the set carries a fixed-base table (the five-launch
 // plan with its block compaction is what a SPARSE column of a prover-sized phase wants)
 static int submit_chain(DeviceCtx* ctx, uint64_t handle, size_t offset, const void* const* d_scalars_list, uint32_t group, size_t n,
-                        void* stream, uint64_t* out_ticket, const char* who, bool* all_busy = nullptr, bool use_table = true) {
+                        void* stream, uint64_t* out_ticket, const char* who, bool* all_busy = nullptr, bool use_table = true,
+                        size_t live_rows = 0) {
   if (all_busy) *all_busy = false;
   std::lock_guard<std::mutex> lk(ctx->mu);
   BasesEntry* b = find_bases(*ctx, handle);
@@ -455,12 +456,12 @@ static int submit_chain(DeviceCtx* ctx, uint64_t handle, size_t offset, const vo
   }
   const uint32_t pc = (use_table && group == 1 && offset == 0 && n == b->n) ? b->pc_c : 0u;
   int rc;
-  if (group == 1) {
+  if (group == 1 && live_rows == 0) {
     ctx->msm_slots[slot].group = 1;
     rc = msm_enqueue(*ctx, slot, (const uint32_t*)d_scalars_list[0], b->d_xy + offset * 16, b->d_inf + offset, n, pc, (hipStream_t)stream);
-  } else {
+  } else {                                      // the five-launch plan, sized for the rows known to survive (a lone sparse column too)
     rc = msm_enqueue_group(*ctx, slot, reinterpret_cast<const uint32_t* const*>(d_scalars_list), group, b->d_xy + offset * 16,
-                           b->d_inf + offset, n, (hipStream_t)stream);
+                           b->d_inf + offset, n, (hipStream_t)stream, live_rows);
   }
   if (rc != HM_OK) return rc;
   ctx->msm_slots[slot].busy = true;
@@ -525,6 +526,7 @@ static int msm_batch_impl(DeviceCtx* ctx, uint64_t handle, size_t offset, const 
   // The chain plan: `order` lists the columns in submission order, chain ch carries order[first[ch] .. first[ch + 1]).
   std::vector<uint32_t> order(count), first;
   std::vector<uint8_t> chain_plain;                // per chain: 1 = run on the plain copy of the points (no table)
+  std::vector<uint32_t> chain_live;                // per chain: rows known to survive the compaction at most (0 = unknown)
   for (size_t i = 0; i < count; ++i) order[i] = (uint32_t)i;
   {
     bool small_plan = false;
@@ -587,6 +589,11 @@ static int msm_batch_impl(DeviceCtx* ctx, uint64_t handle, size_t offset, const 
         if (pending.empty()) return;
         first.push_back((uint32_t)plan.size());
         chain_plain.push_back(1);
+        uint64_t rows = 0;                                       // device columns: counted blocks; host columns: a sample said "sparse" only
+        if (!from_host)
+          for (uint32_t i : pending) rows = std::max<uint64_t>(rows, (uint64_t)live[i] * 256);
+        chain_live.resize(first.size() - 1, 0);
+        chain_live.push_back((uint32_t)std::min<uint64_t>(rows ? rows : 0, n));
         plan.insert(plan.end(), pending.begin(), pending.end());
         pending.clear();
       };
@@ -609,6 +616,7 @@ static int msm_batch_impl(DeviceCtx* ctx, uint64_t handle, size_t offset, const 
   }
   const size_t n_chains = first.size() - 1;
   chain_plain.resize(n_chains, 0);
+  chain_live.resize(n_chains, 0);
 
   uint64_t tickets[kLanes];
   // chain ch uses lane ch % kLanes; the lane is free again once chain ch - kLanes has been awaited (finished[] is set)
@@ -733,7 +741,7 @@ static int msm_batch_impl(DeviceCtx* ctx, uint64_t handle, size_t offset, const 
     for (;;) {                                  // slots held by other callers' tickets (another thread's batch): wait for one
       bool all_busy = false;
       rc = submit_chain(ctx, handle, offset, chain_scalars, group, n, ctx->batch_streams[ch % kLanes], &tickets[ch % kLanes],
-                        "hm_msm_batch_bn256_g1_dev", &all_busy, chain_plain[ch] == 0);
+                        "hm_msm_batch_bn256_g1_dev", &all_busy, chain_plain[ch] == 0, chain_live[ch]);
       if (rc == HM_OK || !all_busy) break;
       if (now_us() - t_wait0 > 60e6) break;     // nobody awaits the tickets that hold the slots: report instead of spinning
       if (!waiters_started) start_waiters();

@@ -336,7 +336,7 @@ int msm_count_live_blocks(DeviceCtx& ctx, const void* const* d_columns, size_t c
 // a group of MSMs over the same points through one chain (only where the five-launch plan applies: msm_group_applies)
 bool msm_group_applies(size_t n, uint32_t precomp_c);
 int msm_enqueue_group(DeviceCtx& ctx, int slot, const uint32_t* const* d_scalars_list, uint32_t group, const uint32_t* d_xy,
-                      const uint8_t* d_inf, size_t n, hipStream_t stream);
+                      const uint8_t* d_inf, size_t n, hipStream_t stream, size_t live_rows = 0);
 int msm_run(DeviceCtx& ctx, const uint32_t* d_scalars_ext, const uint32_t* d_xy, const uint8_t* d_inf, size_t n,
             uint32_t precomp_c, uint64_t out_jac_ext[12], int* out_is_identity, hipStream_t stream);
 uint32_t msm_precomp_window(size_t n);

@@ -1875,20 +1875,24 @@ int msm_enqueue(DeviceCtx& ctx, int slot, const uint32_t* d_scalars_ext, const u
 
 // The window plan of the five-launch chain for n points, or 0 when it does not apply (n >= 2^19, a precomputed set,
 // an override outside its range): the same choice msm_issue makes for a single MSM.
-static uint32_t small_plan_window(size_t n, uint32_t precomp_c) {
+// `live_rows` (0 = unknown): an upper bound on the rows that survive the digits kernel's compaction -- the window is
+// picked for THOSE (an advice column with 1 100 used rows of 2^18 is a 2^10-point MSM: c = 7, not 15: its buckets are
+// then dense, and the reduction's per-bucket scalar multiple has 7 bits instead of 14)
+static uint32_t small_plan_window(size_t n, uint32_t precomp_c, size_t live_rows = 0) {
   if (precomp_c != 0 || n == 0 || n >= (1u << 19)) return 0;
   static const int8_t kWindowSmallPlan[19] = {4, 4, 4, 4, 4, 4, 4, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 15, 15};
   const int window_override = g_window_override.load(std::memory_order_relaxed);
-  const uint32_t c = window_override ? (uint32_t)window_override : (uint32_t)kWindowSmallPlan[ilog2(n)];
+  const size_t sized_for = live_rows != 0 && live_rows < n ? live_rows : n;
+  const uint32_t c = window_override ? (uint32_t)window_override : (uint32_t)kWindowSmallPlan[ilog2(sized_for)];
   return msm_small_applies(n, c, false) ? c : 0;
 }
 bool msm_group_applies(size_t n, uint32_t precomp_c) { return small_plan_window(n, precomp_c) != 0; }
 
 // `group` MSMs over the same n points through ONE launch chain (msm_small.hip); the slot then carries `group` results.
 int msm_enqueue_group(DeviceCtx& ctx, int slot, const uint32_t* const* d_scalars_list, uint32_t group, const uint32_t* d_xy,
-                      const uint8_t* d_inf, size_t n, hipStream_t stream) {
+                      const uint8_t* d_inf, size_t n, hipStream_t stream, size_t live_rows) {
   MsmSlot& sl = ctx.msm_slots[slot];
-  const uint32_t c = small_plan_window(n, 0);
+  const uint32_t c = small_plan_window(n, 0, live_rows);
   if (!c) return hm_fail(HM_ERR_INTERNAL, "msm: a group needs the five-launch plan");
   sl.n = n;
   sl.stream = stream;

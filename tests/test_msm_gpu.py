@@ -284,6 +284,46 @@ def test_fixed_base_table_is_the_registration_default_from_its_threshold(cref, p
         _lib.check(lib.hm_set_fixed_base_threshold(17))
 
 
+def test_phase_with_columns_of_every_density_picks_a_window_per_chain(cref, pyref):
+    """One hm_msm_batch_bn256_g1_dev call at 2^17 over a table set: columns with 1, 300, 1 100 and 5 000 used rows (+ six
+    blinding rows at the end), an all-zero column, rows used only in the LAST block, and dense columns in between.  The
+    planner counts surviving 256-row blocks per column, groups the sparse ones into chains of the five-launch plan whose
+    WINDOW is sized for the rows that survive (c = 4 .. 10 here, not the 15 of 2^17 points), and sends the dense ones to the
+    table.  Every result against the oracle, and equal to the one-at-a-time calls."""
+    import torch
+    n = 1 << 17
+    gen = cref.g1_generator()
+    bases = h.g1_fixed_base_mul(rand_fr_gpu(n, 9100), gen)
+    bh = bases.cpu().numpy().view(np.uint64)
+    full = rand_fr_gpu(n, 9101)
+
+    def column(used, seed, tail=6, head=True):
+        c = torch.zeros_like(full)
+        r = rand_fr_gpu(used + tail, seed)
+        if head:
+            c[:used] = r[:used]
+        else:
+            c[n - 256: n - 256 + used] = r[:used]
+        if tail:
+            c[n - tail:] = r[used:]
+        return c
+
+    cols = [column(1, 1), full, column(300, 2), column(1100, 3), torch.zeros_like(full), column(5000, 4), column(40, 5, tail=0, head=False),
+            full.flip(0).contiguous(), column(1100, 6), column(2, 7), column(300, 8), column(700, 9), column(1100, 10)]
+    exp = [cref.g1_to_affine(cref.best_multiexp(c.cpu().numpy().view(np.uint64), bh, 8))[0] for c in cols]
+    hd = h.register_bases(bases)
+    try:
+        got = h.best_multiexp_batch(cols, hd)
+        for i in range(len(cols)):
+            assert g1_equal(got[i], exp[i]), i
+            assert g1_equal(h.best_multiexp(cols[i], hd), exp[i]), i
+        again = h.best_multiexp_batch(cols[::-1], hd)                   # another order: other groups, other windows per chain
+        for i in range(len(cols)):
+            assert g1_equal(again[len(cols) - 1 - i], exp[i]), i
+    finally:
+        h.release_bases(hd)
+
+
 @pytest.mark.parametrize("n", [16385, 65537, (1 << 17) + 5, 100003])
 def test_sizes_off_the_power_of_two_grid(cref, pyref, n):
     """Chunk / vector-load boundaries of the sort and ragged last chunks: n is arbitrary for an MSM."""
