@@ -77,7 +77,10 @@ __global__ void msm_convert_bases_kernel(const uint32_t* __restrict__ ext, uint3
 // first sort level counts the pairs that really exist, and when they are far fewer (zero or repeated
 // digits: flag and selector-like columns) every later kernel derives the same shorter L from that
 // count, so that K3 still gets >= TARGET_TASKS chains to fill the chip with.
-constexpr uint32_t TARGET_TASKS = 327680;   // 256 CUs x 4 SIMDs x 5 waves x 64 lanes
+#ifndef HM_TARGET_TASKS      // measurement knob (tools/ab_build.sh)
+#define HM_TARGET_TASKS 327680
+#endif
+constexpr uint32_t TARGET_TASKS = HM_TARGET_TASKS;   // 256 CUs x 4 SIMDs x 5 waves x 64 lanes
 __device__ __forceinline__ uint32_t effective_task_len(const uint32_t* __restrict__ pairs, uint32_t L_host) {
   if (pairs == nullptr) return L_host;
   const uint32_t by_fill = pairs[0] / TARGET_TASKS;
@@ -1551,7 +1554,7 @@ static int msm_issue(DeviceCtx& ctx, int slot, const uint32_t* d_scalars_ext, co
     // small inputs: if one task per bucket would leave the chip (256 CUs x 4 SIMDs x ~5 waves x 64
     // lanes) mostly idle, cut the tasks shorter so that the launch still fills it (measured: a wave per
     // SIMD is not enough -- K3 at 2^16..2^18 is 15-40 % slower with one task per bucket)
-    const double target_tasks = 327680.0;
+    const double target_tasks = (double)TARGET_TASKS;
     if ((double)pairs_max / (double)L < target_tasks) L = (uint32_t)((double)pairs_max / target_tasks);
   }
   if (L < 16) L = 16;
