@@ -278,6 +278,10 @@ __global__ __launch_bounds__(SORT_THREADS) void msm_part1_scatter_kernel(const i
 #define HM_P1_IPT 4
 #endif
 constexpr int P1_IPT_DEFAULT = HM_P1_IPT;
+#ifndef HM_P1_BIG_IPT        // tiles for 512 .. 2048 coarse bins (the shared-bucket-set plan, the plain layout from 2^21 points).
+#define HM_P1_BIG_IPT 16     // Measured at 2^24 on the table, whole sort: 8 items per lane 3.19 ms, 16 (with part 2's 16) 3.00 ms --
+#endif                       // 16 items = a 64-byte run per coarse bin and tile instead of 32 (140 KiB of LDS, one workgroup per CU)
+constexpr int P1_BIG_IPT = HM_P1_BIG_IPT;
 // P1_IPT items per lane and tile: a tile should bring >= 8 items (one 32-byte sector) to every coarse bin, i.e.
 // 4 096 items for <= 512 bins and 8 192 for 1 024 (the shared-bucket-set plan)
 template <class ITEM, int P1_IPT = P1_IPT_DEFAULT>
@@ -473,10 +477,15 @@ __global__ __launch_bounds__(SORT_THREADS) void msm_part2_scatter_kernel(const I
 // wave instruction (or two adjacent tiles) instead of by eight separate 4-byte stores spread over the
 // workgroup's lifetime, which is what kept missing L2 once a region had more than ~128 runs.
 #ifndef HM_P2_IPT
-#define HM_P2_IPT 8
+#define HM_P2_IPT 16         // 16 384-item tiles (8: +0.06 ms, 4: +0.35 ms of sort at 2^24)
 #endif
 constexpr int P2_IPT = HM_P2_IPT;
 constexpr int P2_TILE = SORT_THREADS * P2_IPT;
+// LDS of the tiled kernels at their largest plans (part 2: fb = 11; part 1's big tiles: 2 048 coarse bins, 4-byte items):
+// gfx950 has 160 KiB per workgroup
+static_assert(((size_t)3 * 2048 + 32 + P2_TILE) * 4 + (size_t)P2_TILE * 2 <= 160 * 1024, "part-2 tile does not fit the LDS");
+static_assert(((size_t)3 * 2048 + 32 + SORT_THREADS * P1_BIG_IPT) * 4 + (size_t)SORT_THREADS * P1_BIG_IPT * 4 <= 160 * 1024,
+              "part-1 big tile does not fit the LDS");
 // COOP: slices of big regions (work list); the per-bucket cursors then live in global memory
 // (`gcursor`, a copy of boff) and every tile reserves its runs with one atomicAdd per non-empty bucket.
 // POSITIONAL (a shared bucket set of n * W > 2^27 items: fine bits + sign + a 28-bit index do not fit one word): an
@@ -1422,9 +1431,9 @@ static int launch_sort(const int32_t* d_digits, uint32_t* d_chist, uint32_t* d_c
     static const bool big_tiles = [] { const char* v = std::getenv("HALO2_MI355X_P1_BIG_TILES"); return !(v && *v == '0'); }();
     static const uint32_t p1_big_from = [] { const char* v = std::getenv("HALO2_MI355X_P1_BIG_FROM"); return (uint32_t)(v && *v ? std::atoi(v) : 512); }();
     if (NC >= (p1_big_from) && NC <= 2048 && sizeof(ITEM) == 4 && big_tiles) {
-      constexpr int TILE = SORT_THREADS * 8;
+      constexpr int TILE = SORT_THREADS * P1_BIG_IPT;
       const size_t lds_p1 = ((size_t)3 * NC + 32 + TILE) * 4 + (size_t)TILE * sizeof(ITEM);
-      hipLaunchKernelGGL((msm_part1_scatter_tiled_kernel<ITEM, 8>), dim3(G, SW), dim3(SORT_THREADS), lds_p1, stream, d_digits,
+      hipLaunchKernelGGL((msm_part1_scatter_tiled_kernel<ITEM, P1_BIG_IPT>), dim3(G, SW), dim3(SORT_THREADS), lds_p1, stream, d_digits,
                          (const uint32_t*)d_chist, (const uint32_t*)d_cstart, (ITEM*)d_tmp, sn, chunk, fb, ib, NC);
     } else if (NC <= 4096) {
       constexpr int TILE = SORT_THREADS * P1_IPT_DEFAULT;
@@ -1716,7 +1725,7 @@ static int msm_issue(DeviceCtx& ctx, int slot, const uint32_t* d_scalars_ext, co
                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
     HM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(msm_part1_scatter_tiled_kernel<uint64_t, P1_IPT_DEFAULT>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
-    HM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(msm_part1_scatter_tiled_kernel<uint32_t, 8>),
+    HM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(msm_part1_scatter_tiled_kernel<uint32_t, P1_BIG_IPT>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
     ctx.msm_attr_set = true;
   }
