@@ -481,9 +481,9 @@ __global__ __launch_bounds__(SORT_THREADS) void msm_part2_scatter_kernel(const I
 #endif
 constexpr int P2_IPT = HM_P2_IPT;
 constexpr int P2_TILE = SORT_THREADS * P2_IPT;
-// LDS of the tiled kernels at their largest plans (part 2: fb = 11; part 1's big tiles: 2 048 coarse bins, 4-byte items):
+// LDS of the tiled kernels at their largest plans (part 2: fb = 12; part 1's big tiles: 2 048 coarse bins, 4-byte items):
 // gfx950 has 160 KiB per workgroup
-static_assert(((size_t)3 * 2048 + 32 + P2_TILE) * 4 + (size_t)P2_TILE * 2 <= 160 * 1024, "part-2 tile does not fit the LDS");
+static_assert(((size_t)3 * 4096 + 32 + P2_TILE) * 4 + (size_t)P2_TILE * 2 <= 160 * 1024, "part-2 tile does not fit the LDS");
 static_assert(((size_t)3 * 2048 + 32 + SORT_THREADS * P1_BIG_IPT) * 4 + (size_t)SORT_THREADS * P1_BIG_IPT * 4 <= 160 * 1024,
               "part-1 big tile does not fit the LDS");
 // COOP: slices of big regions (work list); the per-bucket cursors then live in global memory
@@ -521,13 +521,13 @@ __global__ __launch_bounds__(SORT_THREADS) void msm_part2_scatter_tiled_kernel(c
   } else if (cstart[w * NC + hb + 1] - cstart[w * NC + hb] > big) {
     return;
   }
-  const uint32_t NF = 1u << fb;                       // <= 2048
+  const uint32_t NF = 1u << fb;                       // <= 4096
   uint32_t* gcur = sm;                                // global cursor of every fine bucket
   uint32_t* tcnt = gcur + NF;                         // items of the current tile per bucket
   uint32_t* tstart = tcnt + NF;                       // exclusive prefix of tcnt
   uint32_t* wsum = tstart + NF;                       // 32 wave totals of the scan
   uint32_t* st_pay = wsum + 32;                       // tile items in bucket order
-  uint16_t* st_bin = reinterpret_cast<uint16_t*>(st_pay + P2_TILE);   // their fine buckets (< 2^11)
+  uint16_t* st_bin = reinterpret_cast<uint16_t*>(st_pay + P2_TILE);   // their fine buckets (< 2^12)
   const uint32_t* bo = boff + (size_t)w * NBP + 1 + ((size_t)hb << fb);
   uint32_t* gc = gcursor + (size_t)w * NBP + 1 + ((size_t)hb << fb);
   for (uint32_t b = tid; b < NF; b += SORT_THREADS) { gcur[b] = bo[b]; tcnt[b] = 0; }
@@ -544,7 +544,7 @@ __global__ __launch_bounds__(SORT_THREADS) void msm_part2_scatter_tiled_kernel(c
     hi = lo + slice < hi ? lo + slice : hi;
   }
   const ITEM imask = ((ITEM)1 << ib) - 1;
-  const uint32_t per = (NF + SORT_THREADS - 1) / SORT_THREADS;   // scan entries per lane (1 or 2)
+  const uint32_t per = (NF + SORT_THREADS - 1) / SORT_THREADS;   // scan entries per lane (1 .. 4)
   for (uint32_t t0 = lo; t0 < hi; t0 += P2_TILE) {
     const uint32_t tile_n = hi - t0 < (uint32_t)P2_TILE ? hi - t0 : (uint32_t)P2_TILE;
     uint32_t pay[P2_IPT], bin[P2_IPT], rank[P2_IPT];
@@ -578,7 +578,7 @@ __global__ __launch_bounds__(SORT_THREADS) void msm_part2_scatter_tiled_kernel(c
     // exclusive scan of tcnt[0 .. NF): lane-serial over `per` entries, wave scan, then wave totals
     {
       const uint32_t b0 = tid * per;
-      uint32_t v[2048 / SORT_THREADS] = {}, sum = 0;
+      uint32_t v[4096 / SORT_THREADS] = {}, sum = 0;
       for (uint32_t k = 0; k < per; ++k)
         if (b0 + k < NF) { v[k] = tcnt[b0 + k]; sum += v[k]; }
       uint32_t incl = sum;
@@ -1467,7 +1467,7 @@ static int launch_sort_scatter(const int32_t* d_digits, const uint32_t* d_cstart
                                uint32_t* d_sorted, size_t sn, uint32_t SW, uint32_t fb, uint32_t ib, uint32_t cb, uint32_t NC,
                                uint32_t NBP, uint32_t NBT, const BigRegionPlan& br, const Positional& ps, hipStream_t stream) {
   const size_t lds_fine = (size_t)4 << fb;
-  if (cb && fb <= 11) {
+  if (cb && (fb <= 11 || (ps.nsc != 0 && fb <= 12))) {      // 2^12 fine counters only where the positional plan asks for them
     const size_t lds_tiled = ((size_t)3 * (1u << fb) + 32 + P2_TILE) * 4 + (size_t)P2_TILE * 2;
     hipLaunchKernelGGL((msm_part2_scatter_tiled_kernel<ITEM, false>), dim3(NC, SW), dim3(SORT_THREADS), lds_tiled, stream,
                        (const ITEM*)d_tmp, d_cstart, d_boff, d_sorted, fb, ib, NC, NBP, br.big, br.slice, (const uint2*)br.list,
@@ -1610,10 +1610,11 @@ static int msm_issue(DeviceCtx& ctx, int slot, const uint32_t* d_scalars_ext, co
     // items: an item keeps the low `sbits` bits of its index, fb fine bucket bits and the sign; its super-chunk (the index
     // bits above sbits) follows from where it lies in its coarse region (msm_part2_scatter_tiled_kernel).  Chunks of the
     // first level are 2^16 (or more) consecutive indices, so every chunk lies inside one super-chunk.
-    for (uint32_t cb_try = 10; cb_try <= 12 && ps.nsc == 0; ++cb_try) {
+    static const uint32_t cb_first = [] { const char* v = std::getenv("HALO2_MI355X_CB_FIRST"); return (uint32_t)(v && *v ? std::atoi(v) : 9); }();   // A/B: 9 against 10: sort 0.69 / 0.74 ms at 2^22 (c = 20), the same at c = 22; 8 is slower
+    for (uint32_t cb_try = cb_first; cb_try <= 12 && ps.nsc == 0; ++cb_try) {
       if (c - 1 < cb_try + 5) break;
       const uint32_t fb_p = c - 1 - cb_try, sbits = 31 - fb_p;
-      if (fb_p > 11 || sbits < 16) continue;                   // the tiled second level holds <= 2^11 fine counters
+      if (fb_p > 12 || sbits < 16) continue;                   // the tiled second level holds <= 2^12 fine counters
       size_t chunk_p = (size_t)1 << 16;
       while ((sn + chunk_p - 1) / chunk_p > 4096 && chunk_p < ((size_t)1 << sbits)) chunk_p <<= 1;
       const size_t nsc = (sn + ((size_t)1 << sbits) - 1) >> sbits;
@@ -1669,7 +1670,7 @@ static int msm_issue(DeviceCtx& ctx, int slot, const uint32_t* d_scalars_ext, co
     br.big = (uint32_t)(4 * slice);
     br.capacity = (uint32_t)(pairs_max / slice + pairs_max / br.big + 2);
   }
-  const bool coop_sort = cb != 0 && fb <= 11;
+  const bool coop_sort = cb != 0 && (fb <= 11 || (ps.nsc != 0 && fb <= 12));
   const size_t o_brlist = carve(coop_sort ? (size_t)br.capacity * 8 : 8);
   const size_t o_brcount = carve(16);
   const size_t o_gcur = carve(coop_sort ? (size_t)NBT * 4 : 4);
