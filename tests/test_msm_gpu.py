@@ -701,6 +701,59 @@ def test_randomized_prover_size_sweep(cref):
             h.release_bases(hd)
 
 
+def test_randomized_table_sized_sweep(cref):
+    """Twelve random shapes at the sizes where registration builds the fixed-base table by itself (2^17 .. 2^19.6, off the
+    power-of-two grid): positional sort items, the balanced window split, 16 384-item sort tiles, the two-launch bucket
+    reduction.  Uniform / small / 0-1 / constant / mostly-zero scalars, identity and repeated bases.  Every result three
+    ways: the table, the plain layout of the same points (hm_set_fixed_base_threshold(0)), and the C oracle."""
+    import torch
+    lib = _lib.load()
+    rng = np.random.default_rng(20261004)
+    gen = cref.g1_generator()
+    pool = h.g1_fixed_base_mul(rand_fr_gpu(800_000, 9500), gen)
+    one = torch.from_numpy(cref.fr_to_mont(np.array([[1, 0, 0, 0]], dtype=np.uint64)).view(np.int64)).cuda()
+    try:
+        for case in range(12):
+            n = int(rng.choice([1 << 17, (1 << 17) + 1, (1 << 18) - 1, 1 << 19])) if case < 4 else int(rng.integers(1 << 17, 800_000))
+            off = int(rng.integers(0, 800_000 - n + 1))
+            bases = pool[off:off + n].clone()
+            for _ in range(3):
+                bases[int(rng.integers(0, n))] = 0
+                bases[int(rng.integers(0, n))] = bases[int(rng.integers(0, n))]
+            s = rand_fr_gpu(n, 9600 + case)
+            kind = case % 6
+            if kind == 1:                                       # 16-bit values
+                s[:, 1:] = 0
+                s[:, 0] &= 0xFFFF
+                s = _raw_to_mont(s)
+            elif kind == 2:                                     # 0 / 1 flags
+                flags = torch.from_numpy(rng.random(n) < 0.3).cuda()
+                s = torch.where(flags[:, None], one.expand(n, 4), torch.zeros_like(s))
+            elif kind == 3:                                     # one constant: every digit of a window lands in ONE bucket
+                s = s[:1].expand(n, 4).contiguous()
+            elif kind == 4:                                     # 2 % survivors
+                s[torch.from_numpy(rng.random(n) >= 0.02).cuda()] = 0
+            s = s.contiguous()
+            bh = bases.cpu().numpy().view(np.uint64)
+            want = cref.g1_to_affine(cref.best_multiexp(s.cpu().numpy().view(np.uint64), bh, 8))[0]
+            _lib.check(lib.hm_set_fixed_base_threshold(17))
+            hd = h.register_bases(bases)
+            try:
+                got = h.best_multiexp(s, hd)
+                assert h.msm_stats()["windows"] <= 15, (case, n)                # the shared bucket set
+                assert g1_equal(got, want), (case, n, kind)
+            finally:
+                h.release_bases(hd)
+            _lib.check(lib.hm_set_fixed_base_threshold(0))
+            hd = h.register_bases(bases)
+            try:
+                assert g1_equal(h.best_multiexp(s, hd), want), (case, n, kind, "plain")
+            finally:
+                h.release_bases(hd)
+    finally:
+        _lib.check(lib.hm_set_fixed_base_threshold(17))
+
+
 def test_go_ethereum_precompile_vectors_through_the_hip_path(pyref):
     """The third-party known answers of tests/test_oracle.py (go-ethereum's EIP-196 precompile test data, "chfast1..3")
     computed by the HIP path itself: [k]P as an MSM of one point, P + Q as an MSM of two points with scalars one, and all
