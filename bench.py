@@ -42,7 +42,17 @@ import torch.distributed as dist  # noqa: E402
 # (tools/pmc_sq.sh) and baked -- with a hash of the kernel sources they were measured on -- by
 # tools/bake_counters.py; the bench line says "stale": true when those sources have changed since.
 VALU_PEAK_WAVE_INST_PER_S = 256 * 4 * 2.4e9 / 4
-BAKED_COUNTERS_FILE = "profiles/r03_baked_counters.json"
+
+
+def newest_baked_counters_file() -> str:
+    """profiles/<tag>_baked_counters.json with the greatest tag (rNN_x, written by tools/bake_counters.py only after its
+    consistency checks passed); older rounds' files have no letter (r03_baked_counters.json)."""
+    import glob
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]*_baked_counters.json")))
+    return os.path.relpath(found[-1], ROOT) if found else "profiles/none"
+
+
+BAKED_COUNTERS_FILE = newest_baked_counters_file()
 
 
 def baked_counters():

@@ -4,7 +4,7 @@
 # (no sys/hip/hsa trace domains), program directly after `--`.
 set -o pipefail
 R="${GRAFT_REPO_ROOT:-/root/repo}"
-mkdir -p "$R/gpurun_out/pmc"
+rm -rf "$R/gpurun_out/pmc"; mkdir -p "$R/gpurun_out/pmc"     # a fresh directory: the summary averages every CSV it finds
 export TMPDIR=/tmp
 cd /tmp
 for ctr in FETCH_SIZE WRITE_SIZE; do
