@@ -42,6 +42,13 @@ class Stats(ctypes.Structure):
     KINDS = ("eval_polynomial", "graph_evaluate", "kate_division", "grand_product", "batch_invert", "linear_combination", "lookup_permute")
 
 
+class BasesInfo(ctypes.Structure):
+    """hm_bases_info (include/halo2_mi355x.h)."""
+    _fields_ = [("n", ctypes.c_uint64), ("device_bytes", ctypes.c_uint64), ("parked_bytes", ctypes.c_uint64),
+                ("default_tables_dropped", ctypes.c_uint64), ("table_windows", ctypes.c_uint32), ("table_window_bits", ctypes.c_uint32),
+                ("devices", ctypes.c_uint32), ("sliced", ctypes.c_uint32)]
+
+
 def build(force: bool = False) -> str:
     """Compile every HIP source for gfx950 into csrc/libhalo2_mi355x.so (in-tree) with hipcc."""
     args = ["make", "-C", CSRC, "-j4"]
@@ -66,6 +73,9 @@ _SIGNATURES = {
     "hm_register_bases_dev": (ctypes.c_int, [_vp, ctypes.c_size_t, _vp, _u64p]),
     "hm_register_bases_precomp": (ctypes.c_int, [_u64p, ctypes.c_size_t, _u64p]),
     "hm_register_bases_precomp_dev": (ctypes.c_int, [_vp, ctypes.c_size_t, _vp, _u64p]),
+    "hm_register_bases_plain": (ctypes.c_int, [_u64p, ctypes.c_size_t, _u64p]),
+    "hm_register_bases_plain_dev": (ctypes.c_int, [_vp, ctypes.c_size_t, _vp, _u64p]),
+    "hm_get_bases_info": (ctypes.c_int, [ctypes.c_uint64, ctypes.POINTER(BasesInfo)]),
     "hm_msm_bn256_g1_dev": (ctypes.c_int, [ctypes.c_uint64, ctypes.c_size_t, _vp, ctypes.c_size_t, _vp, _u64p]),
     "hm_msm_submit_dev": (ctypes.c_int, [ctypes.c_uint64, ctypes.c_size_t, _vp, ctypes.c_size_t, _vp, _u64p]),
     "hm_msm_wait": (ctypes.c_int, [ctypes.c_uint64, _u64p]),

@@ -67,22 +67,36 @@ class BasesHandle:
         return self.n
 
 
-def register_bases(bases, precompute: bool = False) -> BasesHandle:
-    """Upload + convert a base set once.  ``precompute=True`` also stores 2^(c*j) * P_i for every
-    window (W x the memory) so that whole-set MSMs share one bucket set -- the mode for an SRS that
-    lives for the whole proving session."""
+def register_bases(bases, precompute: bool = False, plain: bool = False) -> BasesHandle:
+    """Upload + convert a base set once (``ParamsKZG::g`` / ``g_lagrange``: it lives for the whole proving session).
+
+    By default the library chooses the layout: from 2^17 points (``hm_set_fixed_base_threshold``) it also stores
+    2^(offset of window j) * P_i for every window -- the fixed-base table, W x the memory, built once (0.22 s at 2^24) --
+    so that whole-set MSMs share one bucket set.  ``precompute=True`` asks for the table at any size; ``plain=True``
+    for one copy of the points and never a table: the layout for a TRANSIENT set that serves one MSM."""
+    if precompute and plain:
+        raise ValueError("register_bases: precompute and plain exclude each other")
     lib = _lib.load()
     h = ctypes.c_uint64(0)
+    kind = "_precomp" if precompute else "_plain" if plain else ""
     if _is_tensor(bases):
         n = _tensor_rows(bases, 8, "bases")
-        fn = lib.hm_register_bases_precomp_dev if precompute else lib.hm_register_bases_dev
+        fn = getattr(lib, f"hm_register_bases{kind}_dev")
         _lib.check(fn(ctypes.c_void_p(bases.data_ptr()), n, ctypes.c_void_p(_stream_ptr(bases)), ctypes.byref(h)))
     else:
         b = _np(bases, 8, "bases")
         n = b.shape[0]
-        fn = lib.hm_register_bases_precomp if precompute else lib.hm_register_bases
+        fn = getattr(lib, f"hm_register_bases{kind}")
         _lib.check(fn(_ptr(b), n, ctypes.byref(h)))
     return BasesHandle(h.value, n)
+
+
+def bases_info(handle: BasesHandle) -> dict:
+    """``hm_get_bases_info``: which layout the registration ended up with (``table_windows`` == 0: plain), the HBM it
+    holds, and how many default registrations of the process fell back to the plain layout for lack of memory."""
+    info = _lib.BasesInfo()
+    _lib.check(_lib.load().hm_get_bases_info(ctypes.c_uint64(handle.handle), ctypes.byref(info)))
+    return {k: getattr(info, k) for k, _ in info._fields_}
 
 
 def release_bases(handle: BasesHandle) -> None:
@@ -92,8 +106,9 @@ def release_bases(handle: BasesHandle) -> None:
 def best_multiexp(coeffs, bases: Union[np.ndarray, BasesHandle, "object"], offset: int = 0) -> np.ndarray:
     """sum_i coeffs[i] * bases[i] -> G1 as 12 words (x, y, 1) Montgomery, or all-zero for the identity.
 
-    ``bases`` may be an array/tensor (converted and cached per call, as the drop-in does) or a
-    ``BasesHandle`` (then ``coeffs`` pairs with ``bases[offset : offset + len(coeffs)]``)."""
+    ``bases`` may be an array/tensor (converted per call, as the drop-in does: host arrays through the library's
+    digest-keyed reuse, GPU tensors as a PLAIN set registered for this one MSM -- never the fixed-base table, whose build
+    costs ten MSMs) or a ``BasesHandle`` (then ``coeffs`` pairs with ``bases[offset : offset + len(coeffs)]``)."""
     lib = _lib.load()
     out = np.zeros(12, dtype=np.uint64)
     if isinstance(bases, BasesHandle):
@@ -117,7 +132,7 @@ def best_multiexp(coeffs, bases: Union[np.ndarray, BasesHandle, "object"], offse
         n = _tensor_rows(coeffs, 4, "coeffs")
         if n != _tensor_rows(bases, 8, "bases"):
             raise ValueError("best_multiexp: coeffs.len() != bases.len()")
-        h = register_bases(bases)
+        h = register_bases(bases, plain=True)
         try:
             return best_multiexp(coeffs, h)
         finally:

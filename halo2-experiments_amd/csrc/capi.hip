@@ -91,10 +91,19 @@ static void count_msm(DeviceCtx& ctx, size_t n, double device_ms) {
   ctx.calls.msm_device_us += device_ms * 1e3;
 }
 
+// Released buffers are parked for the next registration of that size instead of hipFree'd (which waits for the whole
+// device): at most four sets and at most kParkedBytesMax in total -- a caller that registers a plain set per call (the
+// tensor form of best_multiexp) recycles its 64 B/point buffer for ever, while a released fixed-base table (W copies:
+// 12 GiB at 2^24 points) goes back to the allocator instead of sitting in the park.
+constexpr size_t kParkedBytesMax = (size_t)2 << 30;
+static size_t parked_bytes(const DeviceCtx& ctx) {
+  size_t t = 0;
+  for (const auto& f : ctx.free_bases) t += f.xy_bytes + f.inf_bytes;
+  return t;
+}
 static void free_bases_entry(DeviceCtx& ctx, BasesEntry& b) {
-  // no kernel reads these buffers any more (synchronous calls have returned, tickets were awaited):
-  // park them for the next registration of that size instead of hipFree (which waits for the whole device)
-  if (ctx.free_bases.size() < 4) {
+  // no kernel reads these buffers any more (synchronous calls have returned, tickets were awaited)
+  if (ctx.free_bases.size() < 4 && parked_bytes(ctx) + b.xy_bytes + b.inf_bytes <= kParkedBytesMax) {
     ctx.free_bases.push_back(FreeBases{b.d_xy, b.d_inf, b.xy_bytes, b.inf_bytes});
   } else {
     if (b.d_xy) (void)hipFree(b.d_xy);
@@ -102,6 +111,16 @@ static void free_bases_entry(DeviceCtx& ctx, BasesEntry& b) {
   }
   b.d_xy = nullptr;
   b.d_inf = nullptr;
+}
+// hipFree every parked buffer (an allocation failed: the memory may be sitting here); true when there was anything
+static bool drop_parked_bases(DeviceCtx& ctx) {
+  const bool any = !ctx.free_bases.empty();
+  for (auto& f : ctx.free_bases) {
+    if (f.d_xy) (void)hipFree(f.d_xy);
+    if (f.d_inf) (void)hipFree(f.d_inf);
+  }
+  ctx.free_bases.clear();
+  return any;
 }
 
 DeviceCtx* ctx_for_current_device() {
@@ -140,14 +159,20 @@ static BasesEntry* find_bases(DeviceCtx& ctx, uint64_t handle) {
   return nullptr;
 }
 
+// Which copy of the points a registration stores: DEFAULT = the table from hm_set_fixed_base_threshold's size on (falls back to
+// the plain layout when W copies do not fit), TABLE = the caller asked for it (no fallback), PLAIN = one copy, never a table
+// (transient sets: the table build costs ten MSMs).
+enum class BaseLayout { DEFAULT, TABLE, PLAIN };
+static std::atomic<uint64_t> g_default_table_dropped{0};   // DEFAULT registrations that fell back to the plain layout (hm_get_bases_info)
+
 static int register_from_device(DeviceCtx& ctx, const uint32_t* d_ext, size_t n, hipStream_t stream, uint64_t* out_handle,
-                                bool precomp = false, bool allow_default = true) {
+                                BaseLayout layout = BaseLayout::DEFAULT) {
   BasesEntry e;
   e.n = n;
-  bool by_default = false;
-  {   // the fixed-base table by default from the size where it pays (hm_set_fixed_base_threshold)
+  bool precomp = layout == BaseLayout::TABLE, by_default = false;
+  if (layout == BaseLayout::DEFAULT) {   // the fixed-base table by default from the size where it pays (hm_set_fixed_base_threshold)
     const uint32_t from = g_fixed_base_from_log.load(std::memory_order_relaxed);
-    if (allow_default && !precomp && from != 0 && from < 40 && n >= ((size_t)1 << from)) precomp = by_default = true;
+    if (from != 0 && from < 40 && n >= ((size_t)1 << from)) precomp = by_default = true;
   }
   if (precomp && n >= 256) {   // tiny sets gain nothing from a shared bucket set
     e.pc_c = msm_precomp_window(n);
@@ -167,14 +192,23 @@ static int register_from_device(DeviceCtx& ctx, const uint32_t* d_ext, size_t n,
     }
   }
   if (!e.d_xy) {
-    if (hipMalloc((void**)&e.d_xy, xy_bytes) != hipSuccess) {
+    hipError_t err = hipMalloc((void**)&e.d_xy, xy_bytes);
+    if (err != hipSuccess && drop_parked_bases(ctx)) {     // the memory may be parked: give it back and try once more
+      (void)hipGetLastError();
+      err = hipMalloc((void**)&e.d_xy, xy_bytes);
+    }
+    if (err != hipSuccess) {
       (void)hipGetLastError();
       e.d_xy = nullptr;
       // no room for W copies: a caller of the plain entry point asked for a base set, not for the table
-      if (by_default && e.pc_c) return register_from_device(ctx, d_ext, n, stream, out_handle, false, false);
+      if (by_default && e.pc_c) {
+        g_default_table_dropped.fetch_add(1, std::memory_order_relaxed);
+        return register_from_device(ctx, d_ext, n, stream, out_handle, BaseLayout::PLAIN);
+      }
       return hm_fail(HM_ERR_HIP, "register bases: allocation failed");
     }
     if (hipMalloc((void**)&e.d_inf, inf_bytes) != hipSuccess) {
+      (void)hipGetLastError();
       (void)hipFree(e.d_xy);
       return hm_fail(HM_ERR_HIP, "register bases: allocation failed");
     }
@@ -329,71 +363,74 @@ int hm_msm_set_phase_timing(int mode) try {
 
 // ---- MSM -------------------------------------------------------------------------------------
 
-int hm_register_bases(const uint64_t* bases, size_t n, uint64_t* out_handle) try {
-  if (!out_handle || (n && !bases)) return hm_fail(HM_ERR_BAD_ARG, "hm_register_bases: null argument");
+// the six registration entry points: {host array, device array} x {default, table, plain layout}
+static int register_entry(const char* who, const uint64_t* bases_host, const void* d_bases, size_t n, void* stream, BaseLayout layout,
+                          uint64_t* out_handle) {
+  if (!out_handle || (n && !bases_host && !d_bases)) return hm_fail(HM_ERR_BAD_ARG, std::string(who) + ": null argument");
   {
     const std::vector<int> devs = multi_worker_flag() ? std::vector<int>() : msm_device_list();
-    if (devs.size() >= 2) return multi_register(bases, nullptr, n, nullptr, false, devs, out_handle);
+    if (devs.size() >= 2) return multi_register(bases_host, d_bases, n, stream, (int)layout, devs, out_handle);
   }
   DeviceCtx* ctx = ctx_for_current_device();
   if (!ctx) return HM_ERR_NO_DEVICE;
   std::lock_guard<std::mutex> lk(ctx->mu);
-  void* stage = ctx->io_bases.ensure(n ? n * 64 : 64);
-  if (!stage) return hm_fail(HM_ERR_HIP, "hm_register_bases: staging allocation failed");
-  HM_HIP_CHECK(hipMemcpy(stage, bases, n * 64, hipMemcpyHostToDevice));
-  int rc = register_from_device(*ctx, (const uint32_t*)stage, n, nullptr, out_handle);
+  const uint32_t* d_ext = (const uint32_t*)d_bases;
+  hipStream_t st = (hipStream_t)stream;
+  if (bases_host) {
+    void* stage = ctx->io_bases.ensure(n ? n * 64 : 64);
+    if (!stage) return hm_fail(HM_ERR_HIP, std::string(who) + ": staging allocation failed");
+    HM_HIP_CHECK(hipMemcpy(stage, bases_host, n * 64, hipMemcpyHostToDevice));
+    d_ext = (const uint32_t*)stage;
+    st = nullptr;
+  }
+  const int rc = register_from_device(*ctx, d_ext, n, st, out_handle, layout);
   if (rc != HM_OK) return rc;
-  HM_HIP_CHECK(hipStreamSynchronize(nullptr));
+  HM_HIP_CHECK(hipStreamSynchronize(st));
   return HM_OK;
+}
+
+int hm_register_bases(const uint64_t* bases, size_t n, uint64_t* out_handle) try {
+  return register_entry("hm_register_bases", bases, nullptr, n, nullptr, BaseLayout::DEFAULT, out_handle);
 } HM_API_CATCH("hm_register_bases")
 
 int hm_register_bases_dev(const void* d_bases, size_t n, void* stream, uint64_t* out_handle) try {
-  if (!out_handle || (n && !d_bases)) return hm_fail(HM_ERR_BAD_ARG, "hm_register_bases_dev: null argument");
-  {
-    const std::vector<int> devs = multi_worker_flag() ? std::vector<int>() : msm_device_list();
-    if (devs.size() >= 2) return multi_register(nullptr, d_bases, n, stream, false, devs, out_handle);
-  }
-  DeviceCtx* ctx = ctx_for_current_device();
-  if (!ctx) return HM_ERR_NO_DEVICE;
-  std::lock_guard<std::mutex> lk(ctx->mu);
-  int rc = register_from_device(*ctx, (const uint32_t*)d_bases, n, (hipStream_t)stream, out_handle);
-  if (rc != HM_OK) return rc;
-  HM_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
-  return HM_OK;
+  return register_entry("hm_register_bases_dev", nullptr, d_bases, n, stream, BaseLayout::DEFAULT, out_handle);
 } HM_API_CATCH("hm_register_bases_dev")
 
 int hm_register_bases_precomp(const uint64_t* bases, size_t n, uint64_t* out_handle) try {
-  if (!out_handle || (n && !bases)) return hm_fail(HM_ERR_BAD_ARG, "hm_register_bases_precomp: null argument");
-  {
-    const std::vector<int> devs = multi_worker_flag() ? std::vector<int>() : msm_device_list();
-    if (devs.size() >= 2) return multi_register(bases, nullptr, n, nullptr, true, devs, out_handle);
-  }
-  DeviceCtx* ctx = ctx_for_current_device();
-  if (!ctx) return HM_ERR_NO_DEVICE;
-  std::lock_guard<std::mutex> lk(ctx->mu);
-  void* stage = ctx->io_bases.ensure(n ? n * 64 : 64);
-  if (!stage) return hm_fail(HM_ERR_HIP, "hm_register_bases_precomp: staging allocation failed");
-  HM_HIP_CHECK(hipMemcpy(stage, bases, n * 64, hipMemcpyHostToDevice));
-  int rc = register_from_device(*ctx, (const uint32_t*)stage, n, nullptr, out_handle, true);
-  if (rc != HM_OK) return rc;
-  HM_HIP_CHECK(hipStreamSynchronize(nullptr));
-  return HM_OK;
+  return register_entry("hm_register_bases_precomp", bases, nullptr, n, nullptr, BaseLayout::TABLE, out_handle);
 } HM_API_CATCH("hm_register_bases_precomp")
 
 int hm_register_bases_precomp_dev(const void* d_bases, size_t n, void* stream, uint64_t* out_handle) try {
-  if (!out_handle || (n && !d_bases)) return hm_fail(HM_ERR_BAD_ARG, "hm_register_bases_precomp_dev: null argument");
-  {
-    const std::vector<int> devs = multi_worker_flag() ? std::vector<int>() : msm_device_list();
-    if (devs.size() >= 2) return multi_register(nullptr, d_bases, n, stream, true, devs, out_handle);
-  }
+  return register_entry("hm_register_bases_precomp_dev", nullptr, d_bases, n, stream, BaseLayout::TABLE, out_handle);
+} HM_API_CATCH("hm_register_bases_precomp_dev")
+
+int hm_register_bases_plain(const uint64_t* bases, size_t n, uint64_t* out_handle) try {
+  return register_entry("hm_register_bases_plain", bases, nullptr, n, nullptr, BaseLayout::PLAIN, out_handle);
+} HM_API_CATCH("hm_register_bases_plain")
+
+int hm_register_bases_plain_dev(const void* d_bases, size_t n, void* stream, uint64_t* out_handle) try {
+  return register_entry("hm_register_bases_plain_dev", nullptr, d_bases, n, stream, BaseLayout::PLAIN, out_handle);
+} HM_API_CATCH("hm_register_bases_plain_dev")
+
+int hm_get_bases_info(uint64_t handle, hm_bases_info* out) try {
+  if (!out) return hm_fail(HM_ERR_BAD_ARG, "hm_get_bases_info: null output");
+  std::memset(out, 0, sizeof *out);
+  out->default_tables_dropped = g_default_table_dropped.load(std::memory_order_relaxed);
+  if (is_multi_handle(handle)) return multi_bases_info(handle, out);
   DeviceCtx* ctx = ctx_for_current_device();
   if (!ctx) return HM_ERR_NO_DEVICE;
   std::lock_guard<std::mutex> lk(ctx->mu);
-  int rc = register_from_device(*ctx, (const uint32_t*)d_bases, n, (hipStream_t)stream, out_handle, true);
-  if (rc != HM_OK) return rc;
-  HM_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+  const BasesEntry* b = find_bases(*ctx, handle);
+  if (!b) return hm_fail(HM_ERR_NOT_FOUND, "hm_get_bases_info: unknown handle");
+  out->n = b->n;
+  out->table_windows = b->pc_W;
+  out->table_window_bits = b->pc_c;
+  out->device_bytes = b->xy_bytes + b->inf_bytes;
+  out->devices = 1;
+  out->parked_bytes = parked_bytes(*ctx);
   return HM_OK;
-} HM_API_CATCH("hm_register_bases_precomp_dev")
+} HM_API_CATCH("hm_get_bases_info")
 
 int hm_release_bases(uint64_t handle) try {
   if (is_multi_handle(handle)) return multi_release(handle);
@@ -662,6 +699,11 @@ static int msm_batch_impl(DeviceCtx* ctx, uint64_t handle, size_t offset, const 
       await_chain(d);                          // even after an error: no ticket is left behind
     }
   };
+  // host arrays are staged per lane in buffers of the device context: whole _h batch calls of different threads take turns.
+  // Declared BEFORE the waiter guard, so that on every way out -- an exception unwinding out of the submit loop included --
+  // the lock is released only AFTER the waiters have been joined and no chain of this call reads batch_io[] any more.
+  std::unique_lock<std::mutex> host_turn;
+  if (from_host) host_turn = std::unique_lock<std::mutex>(ctx->batch_h_mu);
   // the waiters are told to finish and are joined on EVERY way out of this function (an exception in the submit loop included)
   struct WaiterGuard {
     std::atomic<bool>& no_more;
@@ -691,11 +733,10 @@ static int msm_batch_impl(DeviceCtx* ctx, uint64_t handle, size_t offset, const 
     for (; next_unthreaded < limit && next_unthreaded < issued.load(); ++next_unthreaded)
       if (!finished[next_unthreaded].load(std::memory_order_acquire)) await_chain(next_unthreaded);
   };
-  // host arrays are staged per lane in buffers of the device context: whole _h batch calls of different threads take turns
-  std::unique_lock<std::mutex> host_turn;
-  if (from_host) host_turn = std::unique_lock<std::mutex>(ctx->batch_h_mu);
   std::string submit_error;
+  try {
   for (size_t ch = 0; ch < n_chains; ++ch) {
+    hm_fault_point("batch_submit");
     if (ch >= (size_t)kLanes) {                 // every lane holds a ticket: chain ch - kLanes has to be awaited first
       if (!waiters_started) start_waiters();
       while (!finished[ch - kLanes].load(std::memory_order_acquire)) {
@@ -754,6 +795,19 @@ static int msm_batch_impl(DeviceCtx* ctx, uint64_t handle, size_t offset, const 
       break;
     }
     issued.store(ch + 1, std::memory_order_release);
+  }
+  } catch (...) {
+    // Something threw between two submissions (vector growth, a fault point).  Chains already issued are in flight on the
+    // lanes' staging buffers: the waiters (if any) are drained, then this thread awaits -- or, failing that, abandons --
+    // every ticket no waiter took, so that no slot stays busy and nothing reads batch_io[] when host_turn is released.
+    no_more.store(true, std::memory_order_release);
+    for (auto& t : guard.pool.th)
+      if (t.joinable()) t.join();
+    guard.pool.th.clear();
+    const size_t upto = issued.load();
+    for (size_t d = 0; d < upto; ++d)
+      if (!finished[d].load(std::memory_order_acquire)) await_chain(d);      // await_chain never throws: it abandons the ticket instead
+    throw;
   }
   if (!waiters_started) start_waiters();
   no_more.store(true, std::memory_order_release);

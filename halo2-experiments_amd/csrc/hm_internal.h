@@ -257,8 +257,9 @@ inline bool is_multi_handle(uint64_t h) { return (h & HM_MULTI_HANDLE_BIT) != 0;
 // could be had for); the first failure is reported on the caller's thread.  Nothing escapes a worker.
 int run_per_device(const std::vector<int>& devs, const std::function<int(size_t)>& fn);
 bool& multi_worker_flag();                     // true on a thread that is running a part (registrations there stay on one device)
-int multi_register(const uint64_t* bases_host, const void* d_bases, size_t n, void* stream, bool precomp, const std::vector<int>& devs,
+int multi_register(const uint64_t* bases_host, const void* d_bases, size_t n, void* stream, int layout, const std::vector<int>& devs,
                    uint64_t* out_handle);
+int multi_bases_info(uint64_t handle, hm_bases_info* out);   // sums over the parts
 int multi_release(uint64_t handle);
 void multi_release_touching(int device);       // hm_shutdown: drop every multi handle with a part on `device`
 int multi_msm(uint64_t handle, size_t offset, const void* scalars, bool from_host, size_t n, void* stream, uint64_t jac[12], int* is_id);

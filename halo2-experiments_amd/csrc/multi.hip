@@ -131,8 +131,17 @@ int run_per_device(const std::vector<int>& devs, const std::function<int(size_t)
   return HM_OK;
 }
 
-int multi_register(const uint64_t* bases_host, const void* d_bases, size_t n, void* stream, bool precomp, const std::vector<int>& devs,
+// layout: 0 the library's default, 1 the fixed-base table, 2 plain (capi.hip: BaseLayout) -- every part through the public
+// one-device entry of that layout (on a worker thread those stay on one device: multi_worker_flag)
+int multi_register(const uint64_t* bases_host, const void* d_bases, size_t n, void* stream, int layout, const std::vector<int>& devs,
                    uint64_t* out_handle) {
+  auto reg_host = [layout](const uint64_t* b, size_t cnt, uint64_t* out) {
+    return layout == 1 ? hm_register_bases_precomp(b, cnt, out) : layout == 2 ? hm_register_bases_plain(b, cnt, out) : hm_register_bases(b, cnt, out);
+  };
+  auto reg_dev = [layout](const void* b, size_t cnt, uint64_t* out) {
+    return layout == 1 ? hm_register_bases_precomp_dev(b, cnt, nullptr, out)
+                       : layout == 2 ? hm_register_bases_plain_dev(b, cnt, nullptr, out) : hm_register_bases_dev(b, cnt, nullptr, out);
+  };
   // HALO2_MI355X_SLICE_FROM_LOG: the size from which sets are sliced instead of replicated (default 22; tests lower it)
   const char* sf = std::getenv("HALO2_MI355X_SLICE_FROM_LOG");
   const size_t slice_from = sf && *sf ? (size_t)1 << std::atoi(sf) : kSliceBasesFrom;
@@ -160,7 +169,7 @@ int multi_register(const uint64_t* bases_host, const void* d_bases, size_t n, vo
     const size_t cnt = part.hi - part.lo;
     if (bases_host || n == 0) {
       const uint64_t* b = bases_host ? bases_host + part.lo * 8 : nullptr;
-      return precomp ? hm_register_bases_precomp(b, cnt, &part.local) : hm_register_bases(b, cnt, &part.local);
+      return reg_host(b, cnt, &part.local);
     }
     const uint8_t* src = (const uint8_t*)d_bases + part.lo * 64;
     void* tmp = nullptr;
@@ -173,7 +182,7 @@ int multi_register(const uint64_t* bases_host, const void* d_bases, size_t n, vo
       }
       src = (const uint8_t*)tmp;
     }
-    const int rr = precomp ? hm_register_bases_precomp_dev(src, cnt, nullptr, &part.local) : hm_register_bases_dev(src, cnt, nullptr, &part.local);
+    const int rr = reg_dev(src, cnt, &part.local);
     if (tmp) (void)hipFree(tmp);
     return rr;
   });
@@ -189,6 +198,27 @@ int multi_register(const uint64_t* bases_host, const void* d_bases, size_t n, vo
   mb->handle = HM_MULTI_HANDLE_BIT | g_multi_next++;
   g_multi[mb->handle] = mb;
   *out_handle = mb->handle;
+  return HM_OK;
+}
+
+int multi_bases_info(uint64_t handle, hm_bases_info* out) {
+  auto mb = find_multi(handle);
+  if (!mb) return hm_fail(HM_ERR_NOT_FOUND, "hm_get_bases_info: unknown handle");
+  std::vector<int> devs;
+  for (auto& p : mb->parts) devs.push_back(p->dev);
+  std::vector<hm_bases_info> infos(devs.size());
+  const int rc = run_per_device(devs, [&](size_t r) -> int { return hm_get_bases_info(mb->parts[r]->local, &infos[r]); });
+  if (rc != HM_OK) return rc;
+  out->n = mb->n;
+  out->devices = (uint32_t)devs.size();
+  out->sliced = mb->sliced ? 1u : 0u;
+  out->table_windows = infos.empty() ? 0 : infos[0].table_windows;        // 0 as soon as one part has no table
+  out->table_window_bits = infos.empty() ? 0 : infos[0].table_window_bits;
+  for (const auto& i : infos) {
+    out->device_bytes += i.device_bytes;
+    out->parked_bytes += i.parked_bytes;
+    if (i.table_windows == 0) out->table_windows = out->table_window_bits = 0;
+  }
   return HM_OK;
 }
 

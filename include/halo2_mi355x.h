@@ -96,6 +96,27 @@ int hm_register_bases_precomp_dev(const void* d_bases, size_t n, void* stream, u
  * Process-wide; read at registration time.  The environment variable HALO2_MI355X_FIXED_BASE_FROM_LOG sets the
  * initial value. */
 int hm_set_fixed_base_threshold(uint32_t log2_n);
+/* The PLAIN layout whatever the threshold says: one copy of the points, never a table.  For TRANSIENT sets -- a caller
+ * that registers, runs one MSM and releases (the tensor form of the Python mirror's best_multiexp; a verifier's
+ * commitments): building the table costs about ten MSMs of the same size (0.22 s and 12 GiB at 2^24 points). */
+int hm_register_bases_plain(const uint64_t* bases, size_t n, uint64_t* out_handle);
+int hm_register_bases_plain_dev(const void* d_bases, size_t n, void* stream, uint64_t* out_handle);
+
+/* What a registration ended up with.  hm_register_bases / _dev fall back to the plain layout when the W copies of the
+ * table cannot be allocated (after giving the parked buffers of released sets back to the allocator and trying once
+ * more): the call still succeeds, table_windows == 0 tells, and default_tables_dropped counts such registrations of
+ * the process.  A multi-device handle (hm_set_msm_devices) reports sums over its parts. */
+typedef struct hm_bases_info {
+  uint64_t n;                      /* points of the set */
+  uint64_t device_bytes;           /* HBM the set holds (all devices) */
+  uint64_t parked_bytes;           /* buffers of RELEASED sets kept for reuse on the set's device(s) (at most 2 GiB each) */
+  uint64_t default_tables_dropped; /* process-wide: default registrations that fell back to the plain layout */
+  uint32_t table_windows;          /* 0: plain layout; else the W of the fixed-base table */
+  uint32_t table_window_bits;      /* the table's widest window */
+  uint32_t devices;                /* 1, or the parts of a multi-device handle */
+  uint32_t sliced;                 /* multi-device: 1 = index-range slices, 0 = replicas */
+} hm_bases_info;
+int hm_get_bases_info(uint64_t handle, hm_bases_info* out);
 
 /* Device-pointer forms (inputs already in HBM; `stream` is a hipStream_t or NULL).  The result is
  * written to host memory, so the call synchronises `stream` before returning. */

@@ -166,5 +166,34 @@ def test_faults_in_the_batch_waiter(fi, cref):
         got[:] = 0
         assert fi.hm_msm_batch_bn256_g1_h(hd, 0, ptrs, n, count, _u64(got)) == 0
         assert np.array_equal(got, want)
+        # a throw IN THE SUBMIT LOOP with chains already in flight (19 columns of 2^12 = four grouped chains,
+        # no waiter started yet: the calling thread awaits what it issued).  The call reports an error; every ticket it
+        # issued is awaited or abandoned before the staging lock goes back (the next batch finds every slot free and its
+        # staging buffers its own), and results are right again.
+        for after in (1, 3):
+            fi.hm_test_arm_fault(b"batch_submit", after)
+            assert fi.hm_msm_batch_bn256_g1_h(hd, 0, ptrs, n, count, _u64(got)) < 0
+            assert b"batch_submit" in fi.hm_last_error()
+            fi.hm_test_arm_fault(None, 0)
+            got[:] = 0
+            assert fi.hm_msm_batch_bn256_g1_h(hd, 0, ptrs, n, count, _u64(got)) == 0
+            assert np.array_equal(got, want)
+    finally:
+        assert fi.hm_release_bases(hd) == 0
+    # the same with the waiters RUNNING: 12 dense columns of 2^17 are 12 chains on 8 lanes, the waiters start at the ninth
+    n, count = 1 << 17, 12
+    b = _fi_bases(fi, n, 9302, cref)
+    assert fi.hm_register_bases(_u64(b), n, ctypes.byref(hd)) == 0
+    try:
+        cols = [_rand_fr(n, 9340 + i).cpu().numpy().view(np.uint64).copy() for i in range(count)]
+        ptrs = (ctypes.c_void_p * count)(*[c.ctypes.data for c in cols])
+        want, got = np.zeros((count, 12), dtype=np.uint64), np.zeros((count, 12), dtype=np.uint64)
+        assert fi.hm_msm_batch_bn256_g1_h(hd, 0, ptrs, n, count, _u64(want)) == 0
+        assert np.array_equal(want[11][:8], cref.g1_to_affine(cref.best_multiexp(cols[11], b, 8))[0])
+        fi.hm_test_arm_fault(b"batch_submit", 10)
+        assert fi.hm_msm_batch_bn256_g1_h(hd, 0, ptrs, n, count, _u64(got)) < 0
+        fi.hm_test_arm_fault(None, 0)
+        assert fi.hm_msm_batch_bn256_g1_h(hd, 0, ptrs, n, count, _u64(got)) == 0
+        assert np.array_equal(got, want)
     finally:
         assert fi.hm_release_bases(hd) == 0

@@ -284,6 +284,47 @@ def test_fixed_base_table_is_the_registration_default_from_its_threshold(cref, p
         _lib.check(lib.hm_set_fixed_base_threshold(17))
 
 
+def test_transient_sets_take_the_plain_layout_and_released_tables_are_not_parked(cref):
+    """the tensor form best_multiexp(coeffs_tensor, bases_tensor) registers its bases for ONE MSM -- it must not
+    build the fixed-base table (ten MSMs' worth of work and W copies of the points).  hm_register_bases_plain* is the
+    entry for that; hm_get_bases_info tells which layout a handle has.  A released table goes back to the allocator
+    (parked buffers are capped at 2 GiB: a 2^22-point table is 3.2 GiB), a released plain set is recycled."""
+    n = 1 << 18
+    bases = h.g1_fixed_base_mul(rand_fr_gpu(n, 4300), cref.g1_generator())
+    s = rand_fr_gpu(n, 4301)
+    exp = cref.g1_to_affine(cref.best_multiexp(s.cpu().numpy().view(np.uint64), bases.cpu().numpy().view(np.uint64), 8))[0]
+    assert g1_equal(h.best_multiexp(s, bases), exp)                      # the per-call form
+    st = h.msm_stats()
+    assert st["windows"] == 17 and st["window_bits"] == 15, st           # the plain layout's plan at 2^18 (the table's: 15 windows of 17 bits)
+    hp = h.register_bases(bases, plain=True)
+    hd = h.register_bases(bases)                                         # the default: a table from 2^17 points
+    ht = h.register_bases(bases[: 1 << 12].contiguous(), precompute=True)
+    try:
+        ip, idf, it = h.bases_info(hp), h.bases_info(hd), h.bases_info(ht)
+        assert ip["table_windows"] == 0 and ip["n"] == n and ip["device_bytes"] == n * 65 and ip["devices"] == 1
+        assert idf["table_windows"] == 15 and idf["table_window_bits"] == 17 and idf["device_bytes"] == n * (15 * 64 + 1)
+        assert it["table_windows"] > 0 and it["n"] == 1 << 12
+        assert g1_equal(h.best_multiexp(s, hp), exp) and h.msm_stats()["windows"] == 17
+        assert g1_equal(h.best_multiexp(s, hd), exp) and h.msm_stats()["windows"] == 15
+        with pytest.raises(ValueError):
+            h.register_bases(bases, precompute=True, plain=True)
+    finally:
+        for x in (hp, hd, ht):
+            h.release_bases(x)
+    with pytest.raises(_lib.Halo2Mi355xError):
+        h.bases_info(hd)
+    # parking is by bytes: a 2^22-point table (12 windows x 256 MiB + flags) is freed, not kept
+    big = h.g1_fixed_base_mul(rand_fr_gpu(1 << 22, 4302), cref.g1_generator())
+    hb = h.register_bases(big, precompute=True)
+    assert h.bases_info(hb)["device_bytes"] > (2 << 30)
+    h.release_bases(hb)
+    hq = h.register_bases(bases, plain=True)
+    try:
+        assert h.bases_info(hq)["parked_bytes"] <= (2 << 30)
+    finally:
+        h.release_bases(hq)
+
+
 def test_phase_with_columns_of_every_density_picks_a_window_per_chain(cref, pyref):
     """One hm_msm_batch_bn256_g1_dev call at 2^17 over a table set: columns with 1, 300, 1 100 and 5 000 used rows (+ six
     blinding rows at the end), an all-zero column, rows used only in the LAST block, and dense columns in between.  The

@@ -33,9 +33,10 @@ def test_golden_vectors(golden):
     assert np.array_equal(a, g["w3_out"])
 
 
-@pytest.mark.parametrize("k", list(range(0, 20)))
+@pytest.mark.parametrize("k", list(range(0, 23)))
 def test_host_api_matches_oracle_every_log_n(cref, pyref, k):
-    """Covers the 1-pass (<= 2^11), 2-pass (<= 2^16) and 3-pass plans and every digit split."""
+    """Full-array compare with the oracle at every size up to 2^22: the 1-pass (<= 2^11), 2-pass (<= 2^21)
+    and 3-pass (2^22) plans and every digit split, including config 3 / 4's extended sizes 2^20 / 2^21."""
     a = rand_fr_gpu(1 << k, 1000 + k).cpu().numpy().view(np.uint64)
     w = pyref.fr_array([pyref.fr_omega(k)])[0]
     exp = cref.best_fft(a, w, k, 8)
@@ -54,6 +55,65 @@ def test_device_api_matches_host_api(pyref, k):
     h.best_fft(x, w, k)
     torch.cuda.synchronize()
     assert np.array_equal(x.cpu().numpy().view(np.uint64), host)
+
+
+@pytest.mark.parametrize("k", [20, 21, 22, 23])
+def test_device_api_matches_oracle_full_array(cref, pyref, k):
+    """The device-pointer form (what a device-resident prover calls) against the oracle, every element: the two-pass
+    plan at its largest sizes and the three-pass plan at its two smallest."""
+    import torch
+    x = rand_fr_gpu(1 << k, 4100 + k)
+    w = pyref.fr_array([pyref.fr_omega(k)])[0]
+    exp = cref.best_fft(x.cpu().numpy().view(np.uint64), w, k)
+    h.best_fft(x, w, k)
+    torch.cuda.synchronize()
+    assert np.array_equal(x.cpu().numpy().view(np.uint64), exp)
+
+
+def _pattern3(values, rows):
+    """rows x 4 words: values[i % 3] in row i."""
+    base = np.stack([fr_words(v) for v in values])
+    return np.tile(base, ((rows + 2) // 3, 1))[:rows]
+
+
+@pytest.mark.parametrize("k", [17, 18])
+def test_evaluation_domain_at_the_config_shapes_matches_oracle(cref, pyref, k):
+    """BASELINE configs 3 and 4 exactly: k = 17 -> 2^20 and k = 18 -> 2^21 (j = 7, three extension bits), every element
+    of lagrange_to_coeff, hm_coeff_to_extended_* (compact input, the zero part never materialised, plain and internal
+    form) and hm_extended_to_coeff_* against the ORACLE's compositions (best_fft + element-wise products), not the
+    library's own plain path."""
+    import torch
+    o = pyref
+    d = EvaluationDomain(j=7, k=k)
+    n, en, R = d.n, d.extended_len(), o.R
+    assert d.extended_k == k + 3
+    a = rand_fr_gpu(2 * n, 5200 + k).reshape(2, n, 4)
+    ah = a.cpu().numpy().view(np.uint64)
+    exp_coeff = [cref.fr_mul(cref.best_fft(ah[b], fr_words(d.omega_inv), k), np.tile(fr_words(d.ifft_divisor), (n, 1))) for b in range(2)]
+    coeff = d.lagrange_to_coeff(a.clone())
+    for b in range(2):
+        assert np.array_equal(coeff[b].cpu().numpy().view(np.uint64), exp_coeff[b]), b
+    zeta = _pattern3([1, d.g_coset, d.g_coset * d.g_coset % R], en)
+    exp_ext = []
+    for b in range(2):
+        pad = np.zeros((en, 4), dtype=np.uint64)
+        pad[:n] = exp_coeff[b]
+        exp_ext.append(cref.best_fft(cref.fr_mul(pad, zeta), fr_words(d.extended_omega), d.extended_k))
+    ext = d.coeff_to_extended(coeff)
+    for b in range(2):
+        assert np.array_equal(ext[b].cpu().numpy().view(np.uint64), exp_ext[b]), b
+    ext32 = d.coeff_to_extended(coeff[0], internal=True)
+    assert np.array_equal(ext32.cpu().numpy().view(np.uint64), cref.fr_mul(exp_ext[0], np.tile(fr_words(32), (en, 1))))
+    # extended_to_coeff on an ARBITRARY extended array (h(X) is not band-limited to n coefficients): every element
+    x = rand_fr_gpu(en, 5300 + k)
+    xh = x.cpu().numpy().view(np.uint64)
+    inv = cref.fr_mul(cref.best_fft(xh, fr_words(d.extended_omega_inv), d.extended_k), np.tile(fr_words(d.extended_ifft_divisor), (en, 1)))
+    exp_back = cref.fr_mul(inv, _pattern3([1, d.g_coset_inv, d.g_coset_inv * d.g_coset_inv % R], en))
+    got = x.clone()
+    out = d.extended_to_coeff(got)
+    torch.cuda.synchronize()
+    assert np.array_equal(got.cpu().numpy().view(np.uint64), exp_back)
+    assert out.shape[-2] == n * 6
 
 
 def test_edge_values(cref, pyref):

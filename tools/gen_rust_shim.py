@@ -34,7 +34,7 @@ END_MARK = "<!-- END GENERATED -->"
 # ---- C side ---------------------------------------------------------------------------------------------------------
 C_SCALARS = {"int": "c_int", "long": "c_long", "size_t": "usize", "uint64_t": "u64", "uint32_t": "u32", "int32_t": "i32",
              "uint8_t": "u8", "double": "f64", "char": "c_char", "void": "c_void"}
-STRUCTS = {"hm_msm_stats": "HmMsmStats", "hm_stats": "HmStats"}
+STRUCTS = {"hm_msm_stats": "HmMsmStats", "hm_stats": "HmStats", "hm_bases_info": "HmBasesInfo"}
 
 
 def strip_comments(text: str) -> str:
