@@ -9,6 +9,15 @@ A "step" is one best_multiexp over the global array: every rank runs the MSM of 
 shard (2^24 points per GPU, inputs resident in HBM before the timed region), the 96-byte partial
 results are all-gathered over RCCL and folded on every rank.  Weak scaling: N=1 is the north
 star's 2^24 headline, N=4 is BASELINE config 5's 2^26.  Rank 0 prints ONE JSON line.
+Beside the weak-scaling `value` the line carries, at every N:
+  strong_scaling   BASELINE configs[4] as written -- ONE global 2^26-point MSM (and one global 2^24) split by index
+                   range over the N ranks: ms per MSM (max over ranks), points/s, known answer of the folded result
+  one_process      (N > 1) the form the reference's prover would use -- ONE process for the node
+                   (/root/reference/src/circuits/utils.rs:22-70), hm_set_msm_devices(0..N-1): rank 0 alone, the other
+                   ranks parked on a CPU-side barrier with their device memory released, splits one 2^26 MSM over the
+                   N devices inside the C ABI (csrc/multi.hip) and replays the k = 18 create_proof trace with every
+                   commitment phase dealt over the devices.  `python bench.py --gpus N --one-process` (no torchrun)
+                   runs that form as the whole benchmark.
 Inputs follow SURVEY.md §8d (uniform scalars from xoshiro256**, bases [a + i b]G); the result of the timed
 steps is checked against the known answer [sum s_i (a + i b)]G outside the timed loop.
 
@@ -273,6 +282,198 @@ def replay_cpu_baseline(rep, device):
     return info
 
 
+def fold_known_answers(expected_local, world, comm_device):
+    """The global expected point from every rank's [sum s_i t_i]G over its own index range."""
+    if world == 1:
+        return expected_local
+    from halo2_experiments_amd.sharding import g1_sum
+    mine = torch.from_numpy(expected_local.view(np.int64).copy()).to(comm_device)
+    gathered = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(gathered, mine)
+    return g1_sum(torch.stack(gathered).cpu().numpy().view(np.uint64))
+
+
+def max_over_ranks(x, world, comm_device):
+    if world == 1:
+        return x
+    t = torch.tensor([x], dtype=torch.float64, device=comm_device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def strong_scaling_msm(log_global, seed, rank, world, device, comm_device, reps=3):
+    """BASELINE configs[4] as a STRONG-scaling shape: one global 2^log_global-point MSM split by index range over the
+    ranks (every rank generates, registers and keeps its own slice; per step one all-gather of 96 B partials + fold).
+    Times are max-over-ranks per MSM behind a barrier; the folded result is checked against the known answer."""
+    import halo2_experiments_amd as h
+    from halo2_experiments_amd.sharding import shard_range, sharded_multiexp
+    n_global = 1 << log_global
+    lo, hi = shard_range(n_global, rank, world)
+    s, b, t = bench_inputs(hi - lo, lo, seed, device)
+    t0 = time.perf_counter()
+    hnd = h.register_bases(b)
+    torch.cuda.synchronize()
+    reg_ms = (time.perf_counter() - t0) * 1e3
+    del b
+    expected = fold_known_answers(known_answer(s, t, device), world, comm_device)
+    del t
+    res = sharded_multiexp(s, hnd)                              # warm-up: workspaces
+    times = []
+    for _ in range(reps):
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t1 = time.perf_counter()
+        res = sharded_multiexp(s, hnd)
+        times.append(max_over_ranks(time.perf_counter() - t1, world, comm_device))
+    st = h.msm_stats()
+    h.release_bases(hnd)
+    del s
+    torch.cuda.empty_cache()
+    dt = float(np.median(times))
+    acc = st["accumulate_kernel_ms"]
+    return {"global_log_points": log_global, "n_gpus": world, "points_per_rank": hi - lo, "ms_per_msm": dt * 1e3,
+            "points_per_s": n_global / dt, "known_answer_ok": bool(np.array_equal(res, expected)),
+            "window_bits": st["window_bits"], "windows": st["windows"], "register_ms_rank0": reg_ms,
+            "rank0_kernel_ms": acc, "rank0_sort_ms": st["sort_ms"],
+            "rank0_roofline": {"bound": "hbm", "achieved": MSM_BYTES_PER_POINT * (hi - lo) / (acc * 1e-3) / 1e9 if acc else None,
+                               "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": MSM_BYTES_PER_POINT * (hi - lo) / (acc * 1e-3) / 1e9 / HBM_PEAK_GBS if acc else None},
+            "split": f"index ranges x{world}, all-gather of 96 B partials + host fold per MSM"}
+
+
+def one_process_measurements(devs, device, log_global, replay_name, reps=3):
+    """The one-process form (csrc/multi.hip under the C ABI): hm_set_msm_devices(devs), then (a) ONE 2^log_global MSM on a
+    base set SLICED by index range over the devices -- scalars as one device array on devs[0] (the slices of the other
+    devices cross xGMI inside the call, hipMemcpyPeer) and as one host array (every device uploads its slice over its own
+    PCIe link) -- and (b) the k = 18 create_proof replay with the SRS replicated and every phase of commitments dealt over
+    the devices as whole commitments.  Runs on the calling process alone."""
+    import halo2_experiments_amd as h
+    from halo2_experiments_amd import _lib
+    lib = _lib.load()
+    arr = (ctypes.c_int * len(devs))(*devs)
+    _lib.check(lib.hm_set_msm_devices(arr, len(devs)))
+    out = {"devices": list(devs), "note": "one process drives every listed device (hm_set_msm_devices); what a Rust prover -- one process "
+                                          "for the node, /root/reference/src/circuits/utils.rs:22-70 -- would bind"}
+    try:
+        n = 1 << log_global
+        s, b, t = bench_inputs(n, 0, BENCH_SEED + 100 + log_global, device)
+        t0 = time.perf_counter()
+        hnd = h.register_bases(b)                               # a multi handle: n >= 2^22 points are sliced over the devices
+        reg_ms = (time.perf_counter() - t0) * 1e3
+        del b
+        info = h.bases_info(hnd)
+        expected = known_answer(s, t, device)
+        del t
+        res = h.best_multiexp(s, hnd)
+        times = []
+        for _ in range(reps):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            res = h.best_multiexp(s, hnd)
+            times.append(time.perf_counter() - t1)
+        dt = float(np.median(times))
+        entry = {"global_log_points": log_global, "ms_per_msm": dt * 1e3, "points_per_s": n / dt,
+                 "known_answer_ok": bool(np.array_equal(res, expected)), "register_ms": reg_ms,
+                 "base_set": {"sliced": bool(info["sliced"]), "devices": info["devices"], "table_windows": info["table_windows"],
+                              "device_bytes": info["device_bytes"]},
+                 "scalars": f"one device array on device {devs[0]}: the other devices' slices cross xGMI inside the call"}
+        hs = s.cpu().numpy().view(np.uint64)
+        del s
+        t1 = time.perf_counter()
+        res_h = h.best_multiexp(hs, hnd)
+        entry["from_host_array"] = {"ms_per_msm": (time.perf_counter() - t1) * 1e3, "same_result": bool(np.array_equal(res_h, res)),
+                                    "note": "hm_msm_bn256_g1_h: pageable host scalars, every device uploads its own slice; PCIe-inclusive"}
+        del hs
+        h.release_bases(hnd)
+        torch.cuda.empty_cache()
+        out["msm_split"] = entry
+        if replay_name:
+            from halo2_experiments_amd.replay import run_replay
+            rep = run_replay(replay_name, device=device, include_host_pointer_estimate=False, solo=True)
+            rep["n_gpus"] = len(set(devs))
+            rep["multi_gpu_split"] = ("one process: SRS replicated on every listed device, each phase of commitments dealt round-robin as whole "
+                                      "commitments inside hm_msm_batch_bn256_g1_dev; transforms and every other step on the first device")
+            out["create_proof_replay"] = rep
+    finally:
+        _lib.check(lib.hm_set_msm_devices(None, 0))
+    return out
+
+
+def main_one_process(args):
+    """`python bench.py --gpus N --one-process` (no torchrun): the whole benchmark in the one-process form.  A step is one
+    hm_msm_bn256_g1_dev call on a base set sliced over the N devices (2^log_points points per device), scalars resident on
+    device 0; value = global points x steps / wall time.  HALO2_BENCH_BACKEND=gloo (rehearsal on a one-GPU box) lists the
+    visible devices round-robin."""
+    if int(os.environ.get("WORLD_SIZE", "1")) != 1:
+        raise SystemExit("--one-process is ONE process: launch it without torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback exists for this path)")
+    import halo2_experiments_amd as h
+    from halo2_experiments_amd import _lib
+    ndev = torch.cuda.device_count()
+    rehearsal = os.environ.get("HALO2_BENCH_BACKEND", "nccl") != "nccl"
+    if ndev < args.gpus and not rehearsal:
+        raise SystemExit(f"--one-process --gpus {args.gpus}: only {ndev} device(s) visible")
+    devs = [r % ndev for r in range(args.gpus)]
+    torch.cuda.set_device(0)
+    device = torch.device("cuda", 0)
+    lib = _lib.load()
+    n_global = args.gpus << args.log_points
+    _lib.check(lib.hm_set_msm_devices((ctypes.c_int * len(devs))(*devs), len(devs)))
+    try:
+        scalars, bases, t = bench_inputs(n_global, 0, BENCH_SEED, device)
+        t0 = time.perf_counter()
+        handle = h.register_bases(bases)
+        reg_ms = (time.perf_counter() - t0) * 1e3
+        del bases
+        info = h.bases_info(handle)
+        expected = known_answer(scalars, t, device)
+        del t
+        for _ in range(args.warmup):
+            h.best_multiexp(scalars, handle)
+        torch.cuda.synchronize()
+        step_ms = []
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            ts = time.perf_counter()
+            result = h.best_multiexp(scalars, handle)
+            step_ms.append((time.perf_counter() - ts) * 1e3)
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        st = h.msm_stats()                                       # device 0's part of the last MSM
+        ok = bool(np.array_equal(result, expected))
+        if not ok:
+            raise SystemExit("bench.py --one-process: the MSM result does not match the known answer [sum s_i (a + i b)]G")
+        h.release_bases(handle)
+        del scalars
+        torch.cuda.empty_cache()
+    finally:
+        _lib.check(lib.hm_set_msm_devices(None, 0))
+    acc = st["accumulate_kernel_ms"]
+    n_part = n_global // len(devs)
+    achieved = MSM_BYTES_PER_POINT * n_part / (acc * 1e-3) / 1e9 if acc else None
+    line = {"metric": "BN256 G1 MSM throughput", "value": n_global * args.steps / elapsed, "unit": "points/s", "n_gpus": args.gpus,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "ms_per_step_median": float(np.median(step_ms)),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u32 (254-bit modular integers as 9x29-bit limbs, v_mad_u64_u32 accumulation)", "data": "synthetic",
+            "config": {"workload": f"standalone BN256 G1 MSM, 2^{args.log_points} points per GPU (global 2^{args.log_points} x {args.gpus}), ONE process",
+                       "points_per_gpu": 1 << args.log_points, "global_points": n_global, "devices": devs,
+                       "base_set": {"sliced": bool(info["sliced"]), "table_windows": info["table_windows"], "device_bytes": info["device_bytes"],
+                                    "register_ms": reg_ms},
+                       "parallelism": f"one process, hm_set_msm_devices: index-range slices x{args.gpus} inside the C ABI (csrc/multi.hip), one host "
+                                      "thread per device, 96 B partials folded on the host; scalars resident on device 0 (the other devices' "
+                                      "slices cross xGMI inside every step)"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS if achieved else None,
+                         "traffic": None, "kernel": "msm_accumulate_kernel", "kernel_ms": acc, "note": "device 0's part of the last step"},
+            "known_answer_ok": ok}
+    if args.replay != "none" and not args.no_one_process:
+        line["one_process"] = one_process_measurements(devs, device, args.log_points + 2 if args.log_points <= 24 and not args.no_2_26 else args.log_points,
+                                                       args.replay.split(",")[-1])
+    print(json.dumps(line))
+    sys.stdout.flush()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -286,8 +487,15 @@ def main():
     ap.add_argument("--replay", default="poseidon_k11,merkle_v3_k17,merkle_sum_tree_k18",
                     help="comma-separated create_proof MSM/NTT traces to replay after the timed MSM steps ('none' to skip)")
     ap.add_argument("--no-extras", action="store_true", help="skip the prover-like and host-pointer MSM side measurements")
-    ap.add_argument("--no-2-26", action="store_true", help="skip the 2^26-point one-GPU side measurement")
+    ap.add_argument("--no-2-26", action="store_true", help="skip the global 2^26-point strong-scaling measurement")
+    ap.add_argument("--no-strong", action="store_true", help="skip the strong-scaling measurements (global 2^24 / 2^26 split over the ranks)")
+    ap.add_argument("--no-one-process", action="store_true", help="N > 1: skip rank 0's one-process (hm_set_msm_devices) measurements")
+    ap.add_argument("--one-process", action="store_true",
+                    help="ONE process drives --gpus devices through hm_set_msm_devices (launch WITHOUT torchrun): the whole benchmark in the "
+                         "form the reference's single-process prover would use")
     args = ap.parse_args()
+    if args.one_process:
+        return main_one_process(args)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -304,12 +512,19 @@ def main():
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
     comm_device = device if backend == "nccl" else torch.device("cpu")
+    park_group, ranks_seen = None, 1
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+            # a CPU-side group: ranks that have nothing to do while rank 0 runs the one-process measurements wait THERE (an RCCL
+            # barrier would keep a spinning kernel on every device rank 0 is about to time)
+            park_group = dist.new_group(backend="gloo")
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+        one = torch.ones(1, dtype=torch.int64, device=comm_device)
+        dist.all_reduce(one)                                    # how many ranks the collective really saw
+        ranks_seen = int(one.item())
 
     import halo2_experiments_amd as h
     from halo2_experiments_amd import _lib
@@ -342,14 +557,7 @@ def main():
     # known answer, once, outside the timed loop: this rank's partial, and the folded global result
     local_result = h.best_multiexp(scalars, handle)
     answer_ok = bool(np.array_equal(local_result, expected_local))
-    if world > 1:
-        from halo2_experiments_amd.sharding import g1_sum
-        mine = torch.from_numpy(expected_local.view(np.int64).copy()).to(comm_device)
-        gathered = [torch.empty_like(mine) for _ in range(world)]
-        dist.all_gather(gathered, mine)
-        expected_global = g1_sum(torch.stack(gathered).cpu().numpy().view(np.uint64))
-    else:
-        expected_global = expected_local
+    expected_global = fold_known_answers(expected_local, world, comm_device)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -492,38 +700,38 @@ def main():
         extras["msm_host_pointer"] = {"ms": (time.perf_counter() - t1) * 1e3,
                                       "note": "hm_msm_bn256_g1_h: scalars cross PCIe in the call (pageable host memory); never `value`"}
         del hs
-        if args.log_points == 24 and not args.no_2_26:
-            # BASELINE configs[4] names a 2^26 MSM: on ONE GPU as a side measurement (4 GiB bases, 2 GiB scalars)
+
+    # ---- strong scaling (BASELINE configs[4]: "2^26 MSM ... 1/2/4/8 GPUs"): one GLOBAL MSM split over the ranks ----
+    strong = None
+    if not args.no_strong:
+        if handle is not None:
             h.release_bases(handle)
             handle = None
-            torch.cuda.empty_cache()
-            n26 = 1 << 26
-            s26, b26, t26 = bench_inputs(n26, 0, BENCH_SEED + 26, device)
-            h26 = h.register_bases(b26)
-            del b26
-            exp26 = known_answer(s26, t26, device)
-            del t26
-            r26 = h.best_multiexp(s26, h26)
-            times = []
-            for _ in range(3):
-                t1 = time.perf_counter()
-                h.best_multiexp(s26, h26)
-                times.append(time.perf_counter() - t1)
-            st26 = h.msm_stats()
-            dt = float(np.median(times))
-            extras["msm_2_26_one_gpu"] = {"points_per_s": n26 / dt, "ms": dt * 1e3, "accumulate_kernel_ms": st26["accumulate_kernel_ms"],
-                                          "window_bits": st26["window_bits"], "windows": st26["windows"],
-                                          "known_answer_ok": bool(np.array_equal(r26, exp26))}
-            h.release_bases(h26)
-            del s26
-            torch.cuda.empty_cache()
+        del scalars
+        scalars = None
+        torch.cuda.empty_cache()
+        strong = []
+        if world == 1:          # the headline IS the global 2^log_points MSM on one GPU
+            acc1 = float(np.median(acc_ms))
+            strong.append({"global_log_points": args.log_points, "n_gpus": 1, "points_per_rank": n_local,
+                           "ms_per_msm": elapsed / args.steps * 1e3, "points_per_s": n_global * args.steps / elapsed,
+                           "known_answer_ok": answer_ok, "window_bits": st["window_bits"], "windows": st["windows"],
+                           "rank0_kernel_ms": acc1, "split": "none (the timed headline steps)"})
+        else:
+            strong.append(strong_scaling_msm(args.log_points, BENCH_SEED + 24, rank, world, device, comm_device))
+        if args.log_points == 24 and not args.no_2_26 and not args.no_extras:      # (--no-extras: the profiled command -- one MSM size in the trace)
+            strong.append(strong_scaling_msm(26, BENCH_SEED + 26, rank, world, device, comm_device))
+        for e in strong:
+            if not e["known_answer_ok"]:
+                raise SystemExit(f"bench.py: the global 2^{e['global_log_points']} MSM does not match its known answer")
 
     replay = None
     if args.replay != "none":
         from halo2_experiments_amd.replay import run_replay
         if handle is not None:
             h.release_bases(handle)
-        del scalars
+            handle = None
+        scalars = None
         torch.cuda.empty_cache()
         replay = [run_replay(name, device=device) for name in args.replay.split(",")]   # every rank takes part
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -534,6 +742,24 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         log_sample = args.cpu_log_sample or min(args.log_points, 24)
         cpu = cpu_baseline(log_sample, device, full=log_sample == args.log_points)
+
+    # ---- N > 1: the ONE-PROCESS form, by rank 0 alone -------------------------------------------------------------
+    one_proc = None
+    if world > 1 and not args.no_one_process:
+        if handle is not None:
+            h.release_bases(handle)
+            handle = None
+        scalars = None
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        if rank != 0:
+            _lib.check(_lib.load().hm_shutdown())               # workspaces, tables, staging: this rank's device is rank 0's to use now
+        dist.barrier(group=park_group)                          # everybody has let go of its device memory ...
+        if rank == 0:
+            devs = [r if backend == "nccl" else r % max(ndev, 1) for r in range(world)]
+            one_proc = one_process_measurements(devs, device, 26 if args.log_points == 24 and not args.no_2_26 else args.log_points,
+                                                None if args.replay == "none" else args.replay.split(",")[-1])
+        dist.barrier(group=park_group)                          # ... and waits here, on the CPU, until rank 0 is done
 
     if rank == 0:
         acc = float(np.median(acc_ms))
@@ -573,6 +799,11 @@ def main():
                          "pairs": int(st["pairs"]), "tasks": int(st["tasks"])},
             "known_answer_ok": answer_ok,
         }
+        line["ranks_in_collective"] = ranks_seen
+        if strong is not None:
+            line["strong_scaling"] = strong
+        if one_proc is not None:
+            line["one_process"] = one_proc
         if ntt is not None:
             line["ntt"] = ntt
         if extras is not None:

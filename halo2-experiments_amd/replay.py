@@ -46,7 +46,7 @@ from .arithmetic import (G1_GENERATOR, batch_invert, best_multiexp, best_multiex
                          release_bases)
 from .domain import EvaluationDomain, FR_MODULUS, fr_words
 from .kzg import ParamsKZG
-from .sharding import job_parallel_multiexp_batch, shard_range, sharded_multiexp, sharded_multiexp_batch
+from .sharding import _NO_GROUP, job_parallel_multiexp_batch, shard_range, sharded_multiexp, sharded_multiexp_batch
 
 # the replay's SRS trapdoor (the reference draws it from OsRng, utils.rs:28): known here, so that every
 # commitment of the replay can be checked against the KZG identity commit(f) == [f(s)]G
@@ -114,14 +114,18 @@ def _sparse_column(n, used_rows, seed, device):
 
 
 def run_replay(shape_name: str, device=None, group=None, include_host_pointer_estimate: bool = True,
-               in_flight: int = 8) -> dict:
+               in_flight: int = 8, solo: bool = False) -> dict:
+    """``solo``: this process runs the replay ALONE even inside an initialised process group (bench.py's one-process form:
+    the other ranks are parked; the split over devices, if any, is hm_set_msm_devices' inside the library)."""
     import torch
     import torch.distributed as dist
 
     shape = SHAPES[shape_name]
     device = device or torch.device("cuda", torch.cuda.current_device())
-    world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+    world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() and not solo else 1
     rank = dist.get_rank(group) if world > 1 else 0
+    if solo:
+        group = _NO_GROUP                 # the exchange helpers of sharding.py then run their local part only
     k, n = shape.k, 1 << shape.k
     dom = EvaluationDomain(shape.max_degree, k)
     d = shape.max_degree

@@ -49,7 +49,7 @@ def sharded_multiexp(local_coeffs, local_bases, group=None,
     import torch.distributed as dist
 
     partial = (local_msm or best_multiexp)(local_coeffs, local_bases)
-    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if group is _NO_GROUP or not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
         return g1_sum(partial.reshape(1, 12))
     world = dist.get_world_size(group)
     backend = dist.get_backend(group)

@@ -19,11 +19,11 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _bench(world, log_points):
+def _bench(world, log_points, replay="none", extra=()):
     args = ["--gpus", str(world), "--steps", "2", "--warmup", "1", "--log-points", str(log_points), "--no-cpu-baseline", "--no-ntt",
-            "--replay", "none", "--no-extras", "--no-2-26"]
+            "--replay", replay, "--no-extras", "--no-2-26"] + list(extra)
     env = dict(os.environ, HALO2_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    if world == 1:
+    if world == 1 or "--one-process" in extra:
         cmd = [sys.executable, os.path.join(ROOT, "bench.py")] + args
     else:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
@@ -48,3 +48,40 @@ def test_two_ranks_launched_like_the_driver_does():
         assert abs(line["value"] - line["config"]["global_points"] / (line["ms_per_step"] * 1e-3)) < 1e-6 * line["value"]
         assert set(line["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
     assert two["config"]["parallelism"].startswith("index-range shards x2")
+    assert one["ranks_in_collective"] == 1 and two["ranks_in_collective"] == 2
+    # strong scaling: the SAME global size at both N (BASELINE configs[4] is a fixed 2^26; here 2^20), known answer of the fold
+    for line, world in ((one, 1), (two, 2)):
+        (e,) = line["strong_scaling"]
+        assert e["global_log_points"] == 20 and e["n_gpus"] == world and e["points_per_rank"] == (1 << 20) // world
+        assert e["known_answer_ok"] is True and e["ms_per_msm"] > 0
+        assert abs(e["points_per_s"] - (1 << 20) / (e["ms_per_msm"] * 1e-3)) < 1e-6 * e["points_per_s"]
+    # rank 0's one-process measurements (N > 1 only): the C-ABI split over "two devices" (device 0 listed twice here)
+    assert "one_process" not in one
+    op = two["one_process"]
+    assert op["devices"] == [0, 0] and op["msm_split"]["known_answer_ok"] is True
+    assert op["msm_split"]["base_set"]["devices"] == 2 and op["msm_split"]["from_host_array"]["same_result"] is True
+
+
+@pytest.mark.gpu
+def test_two_ranks_replay_the_k18_proof_and_rank0_replays_it_in_one_process():
+    """The N > 1 replay (whole commitments and transforms dealt over the ranks: replay.py job mode) launched the way the driver
+    launches it, and -- in the same run -- the one-process replay by rank 0 with the other rank parked."""
+    two = _bench(2, 18, replay="merkle_sum_tree_k18", extra=("--no-strong",))
+    (rep,) = two["create_proof_replay"]
+    assert rep["k"] == 18 and rep["n_gpus"] == 2 and rep["multi_gpu_split"].startswith("whole commitments")
+    assert rep["verified"]["commitments_checked"] >= 3 * (rep["calls"]["msm_sparse"] + rep["calls"]["msm_dense"])
+    op = two["one_process"]["create_proof_replay"]
+    assert op["k"] == 18 and op["multi_gpu_split"].startswith("one process")
+    assert op["verified"]["commitments_checked"] >= 3 * (op["calls"]["msm_sparse"] + op["calls"]["msm_dense"])
+    assert "strong_scaling" not in two
+
+
+@pytest.mark.gpu
+def test_one_process_form_as_the_whole_benchmark():
+    """`bench.py --gpus 2 --one-process` (no torchrun): one JSON line with the same contract, the split inside the C ABI."""
+    line = _bench(2, 20, extra=("--one-process",))
+    assert line["n_gpus"] == 2 and line["known_answer_ok"] is True and line["scaling"] == "weak"
+    assert line["config"]["global_points"] == 2 << 20 and line["config"]["devices"] == [0, 0]
+    assert line["config"]["parallelism"].startswith("one process")
+    assert abs(line["value"] - line["config"]["global_points"] / (line["ms_per_step"] * 1e-3)) < 1e-6 * line["value"]
+    assert set(line["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}

@@ -13,7 +13,7 @@ set -o pipefail
 TAG="${1:?usage: profile_round.sh <tag>}"
 R="${GRAFT_REPO_ROOT:-/root/repo}"
 E="$R/gpurun_out/evidence/$TAG"
-rm -rf "$E"; mkdir -p "$E"
+rm -rf "$E"; mkdir -p "$E/pmc"
 export TMPDIR=/tmp
 BENCH_ARGS="--steps 5 --warmup 1 --no-cpu-baseline --replay none --no-extras"
 cd "$R"
