@@ -1248,7 +1248,12 @@ int hm_ntt_bn256_fr(uint64_t* a, const uint64_t omega[4], uint32_t log_n) try {
   if (rc != HM_OK) return rc;
   HM_HIP_CHECK(hipStreamSynchronize(nullptr));
   const double t2 = now_us();
-  HM_HIP_CHECK(hipMemcpy(a, d_a, bytes, hipMemcpyDeviceToHost));
+  {   // from here on `a` is being overwritten: a failure is NOT one a caller may answer by running its CPU body on `a`
+    const hipError_t e = hipMemcpy(a, d_a, bytes, hipMemcpyDeviceToHost);
+    if (e != hipSuccess)
+      return hm_fail(HM_ERR_PARTIAL_OUTPUT, std::string("hm_ntt_bn256_fr: copying the result back failed, the array is partly "
+                                                        "overwritten: ") + hipGetErrorString(e));
+  }
   const double t3 = now_us();
   count_ntt(*ctx, log_n, 1);
   ctx->calls.ntt_h2d_us += t1 - t0;

@@ -41,6 +41,9 @@ extern "C" {
 #define HM_ERR_HIP (-3)
 #define HM_ERR_NOT_FOUND (-4)
 #define HM_ERR_INTERNAL (-5)
+/* an in-place host-pointer call failed AFTER it began writing its result: the array is undefined (every other error
+ * leaves the caller's arrays untouched, so a caller may fall back to its CPU body on them -- not after this one) */
+#define HM_ERR_PARTIAL_OUTPUT (-6)
 
 /* ---- lifecycle ---------------------------------------------------------------------------- */
 
@@ -170,7 +173,9 @@ int hm_msm_set_phase_timing(int mode);
 /* ---- NTT: stands in for halo2_proofs::arithmetic::best_fft::<bn256::Fr> --------------------- */
 
 /* In place on host memory: a[j] <- sum_i a[i] * omega^(i*j), natural order in and out, unscaled.
- * a: 2^log_n x 4 u64 (Fr); omega: 4 u64 (Fr), a 2^log_n-th root of unity; log_n <= 28. */
+ * a: 2^log_n x 4 u64 (Fr); omega: 4 u64 (Fr), a 2^log_n-th root of unity; log_n <= 28.
+ * `a` is written only by the final copy from the device: every error code but HM_ERR_PARTIAL_OUTPUT (that copy itself
+ * failed) leaves it exactly as it was. */
 int hm_ntt_bn256_fr(uint64_t* a, const uint64_t omega[4], uint32_t log_n);
 
 /* Device-pointer form, in place, asynchronous on `stream`.  Every *_dev NTT entry point may be called
