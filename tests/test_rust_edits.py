@@ -1,0 +1,97 @@
+"""The reference-side binding as files (rust/): the edit table, the script that applies it and the unified diff are
+exercised here on a SKELETON of the upstream crate -- the anchor lines as recalled from halo2_proofs at tag v2023_02_02
+(/root/reference/Cargo.toml:10 pins it; its text is not available in this image), with filler between them.  What this
+proves: the table, the script and the patch agree with each other, the script is idempotent and refuses a file whose
+anchors differ.  What it cannot prove: that the recalled lines are upstream's."""
+import json
+import os
+import shutil
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+RUST = os.path.join(ROOT, "rust")
+
+
+def _skeleton(tmp_path):
+    """halo2_proofs/ with every file of the edit table: filler lines, each anchor as often as the table expects, in an
+    order that resembles the upstream file."""
+    table = json.load(open(os.path.join(RUST, "edits.json")))
+    root = tmp_path / "halo2_proofs"
+    by_file = {}
+    for e in table:
+        by_file.setdefault(e["file"], []).append(e)
+    for rel, entries in by_file.items():
+        path = root / rel
+        path.parent.mkdir(parents=True, exist_ok=True)
+        spots = sorted((e["near_line"] + 60 * k, e["anchor"]) for e in entries for k in range(len(e["replacements"])))
+        lines, nxt = [], 1
+        for at, anchor in spots:
+            while nxt < at:
+                lines.append(f"// filler {nxt}")
+                nxt += 1
+            lines.append(anchor)
+            nxt += 1
+        lines += [f"// filler {nxt + i}" for i in range(5)]
+        path.write_text("\n".join(lines) + "\n")
+    (root / "src").mkdir(exist_ok=True)
+    return root, table
+
+
+def _run(root, *flags):
+    return subprocess.run([sys.executable, os.path.join(RUST, "apply_edits.py"), *flags, str(root)], capture_output=True, text=True)
+
+
+def test_apply_edits_makes_every_edit_once(tmp_path):
+    root, table = _skeleton(tmp_path)
+    dry = _run(root, "--dry-run")
+    assert dry.returncode == 0 and "would edit src/arithmetic.rs" in dry.stdout
+    assert "mi355x" not in (root / "src" / "arithmetic.rs").read_text()
+    r = _run(root)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert (root / "src" / "mi355x.rs").exists() and (root / "src" / "mi355x_kzg.rs").exists()
+    arith = (root / "src" / "arithmetic.rs").read_text()
+    assert arith.count("fn original_best_multiexp<C: CurveAffine>") == 1 and arith.count("fn original_best_fft<G: Group>") == 1
+    assert arith.count("pub mod mi355x;") == 1 and arith.count("pub mod mi355x_kzg;") == 1
+    kzg = (root / "src" / "poly" / "kzg" / "commitment.rs").read_text()
+    assert kzg.count("gpu: Default::default(),") == 3 and kzg.count("pub(crate) gpu: crate::arithmetic::mi355x_kzg::SrsHandles,") == 1
+    assert kzg.count("self.gpu.reset();") == 1
+    # commit_lagrange is the first of the two functions in the file, commit the second
+    assert 0 < kzg.index("self.gpu.commit_lagrange::<E::G1Affine>") < kzg.index("self.gpu.commit::<E::G1Affine>")
+    assert "halo2-mi355x-sys" in (root / "Cargo.toml").read_text()
+    again = _run(root)                                          # idempotent
+    assert again.returncode == 0 and "already edited" in again.stdout
+    assert (root / "src" / "poly" / "kzg" / "commitment.rs").read_text() == kzg
+
+
+def test_apply_edits_refuses_a_file_whose_anchors_differ(tmp_path):
+    root, _ = _skeleton(tmp_path)
+    path = root / "src" / "poly" / "kzg" / "commitment.rs"
+    text = path.read_text().replace("            s_g2,", "            s_g2: s_g2,", 1)      # one struct literal spelled differently
+    path.write_text(text)
+    r = _run(root)
+    assert r.returncode == 1 and "NOT APPLIED src/poly/kzg/commitment.rs" in r.stdout and "expected 3 occurrence(s), found 2" in r.stdout
+    assert path.read_text() == text                              # nothing of that file was written
+    assert "mi355x" in (root / "src" / "arithmetic.rs").read_text()   # the other files were
+
+
+@pytest.mark.skipif(shutil.which("patch") is None, reason="no patch(1)")
+def test_the_unified_diff_makes_the_same_edits(tmp_path):
+    a, _ = _skeleton(tmp_path / "a")
+    b, _ = _skeleton(tmp_path / "b")
+    assert _run(a).returncode == 0
+    r = subprocess.run(["patch", "-p1", "-i", os.path.join(RUST, "halo2_proofs.patch")], cwd=b, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    for rel in ("src/arithmetic.rs", "src/poly/kzg/commitment.rs", "Cargo.toml", "src/mi355x.rs", "src/mi355x_kzg.rs"):
+        assert (a / rel).read_text() == (b / rel).read_text(), rel
+
+
+def test_glue_is_free_of_the_risks_the_review_named():
+    glue = open(os.path.join(RUST, "halo2_proofs-patch", "src", "mi355x.rs")).read()
+    kzg = open(os.path.join(RUST, "halo2_proofs-patch", "src", "mi355x_kzg.rs")).read()
+    assert "OnceLock" not in glue + kzg and "std::sync::Once" in glue            # no dependence on Rust >= 1.70
+    assert "use group::prime::PrimeCurveAffine;" in glue and "use group::Group as _;" in glue
+    assert "HM_ERR_PARTIAL_OUTPUT" in glue and "panic!" in glue                  # never run the CPU body on a half-written array
+    assert "hm_register_bases(" in kzg and "hm_msm_batch_bn256_g1_h(" in kzg and "hm_release_bases(" in kzg

@@ -229,40 +229,65 @@ fn main() {
 }
 '''
 
+# Smallest sizes the glue sends to the GPU: below them the CPU body of the patched functions is at least as fast as the
+# host-pointer round trip.  MEASURED (tools/crossover.py on the MI355X box against oracle/cpu_ref.c on its 16 granted cores;
+# table in DESIGN.md section 8 and profiles/r04_crossover.json) -- regenerate rust/ after changing them.
+GPU_MIN_LOG_N_MSM = 10
+GPU_MIN_LOG_N_NTT = 10
+
 MI355X_RS = '''//! mi355x.rs -- glue between halo2_proofs::arithmetic and libhalo2_mi355x.so (added by rust/halo2_proofs.patch).
 //! GENERATED by tools/gen_rust_shim.py (a fixed template: the C entry points it calls are checked against the header
-//! by the repository's tests).  The two functions return None whenever the GPU path does not apply or fails, and the
-//! caller falls through to the untouched upstream body: other curves / fields, tiny inputs, no device, any error code.
+//! by the repository's tests).  The two functions return None / false whenever the GPU path does not apply or fails
+//! WITHOUT having touched the caller's arrays, and the caller falls through to the untouched upstream body: other
+//! curves / fields, tiny inputs, no device, any error code but HM_ERR_PARTIAL_OUTPUT (which panics: see try_best_fft).
+//! Needs nothing newer than Rust 1.56: std::sync::Once + AtomicBool for the one-time check (the pinned tag predates the 1.70 cell types).
 use std::any::TypeId;
+use std::sync::atomic::{AtomicBool, Ordering};
+use std::sync::Once;
 
-use group::Group as _;
+use group::prime::PrimeCurveAffine; // G1Affine::generator()
+use group::Group as _; // G1::identity()
 use halo2_mi355x_sys as sys;
 use halo2curves::bn256::{Fr, G1Affine, G1};
 use halo2curves::CurveAffine;
 
 use crate::arithmetic::Group;
 
-/// Below this size launch + PCIe latency dominates: stay on the CPU body.
-pub const GPU_MIN_LOG_N: u32 = 10;
+/// Below these sizes the host-pointer round trip (launch + PCIe latency) is no faster than the CPU body: measured
+/// crossover against a 16-core host (DESIGN.md section 8), stay on the CPU.
+pub const GPU_MIN_LOG_N_MSM: u32 = @MSM@;
+pub const GPU_MIN_LOG_N_NTT: u32 = @NTT@;
 
-/// halo2curves gives these types no #[repr(C)]; the byte layout the library reads is asserted instead.
-fn layout_ok() -> bool {
-    use std::sync::OnceLock;
-    static OK: OnceLock<bool> = OnceLock::new();
-    *OK.get_or_init(|| {
-        if std::mem::size_of::<Fr>() != 32 || std::mem::size_of::<G1Affine>() != 64 || std::mem::size_of::<G1>() != 96 {
-            return false;
-        }
-        // the generator (1, 2) must read back as x = R mod p, y = 2R mod p (Montgomery words, x before y)
-        let g: [u64; 8] = unsafe { std::mem::transmute(G1Affine::generator()) };
-        g[..4] == [0xd35d438dc58f0d9d, 0x0a78eb28f5c70b3d, 0x666ea36f7879462c, 0x0e0a77c19a07df2f]
-            && g[4..] == [0xa6ba871b8b1e1b3a, 0x14f1d651eb8e167b, 0xccdd46def0f28c58, 0x1c14ef83340fbe5e]
-            && unsafe { sys::hm_device_count() } > 0
-    })
+fn layout_check() -> bool {
+    if std::mem::size_of::<Fr>() != 32 || std::mem::size_of::<G1Affine>() != 64 || std::mem::size_of::<G1>() != 96 {
+        return false;
+    }
+    // the generator (1, 2) must read back as x = R mod p, y = 2R mod p (Montgomery words, x before y)
+    let g: [u64; 8] = unsafe { std::mem::transmute(<G1Affine as PrimeCurveAffine>::generator()) };
+    g[..4] == [0xd35d438dc58f0d9d, 0x0a78eb28f5c70b3d, 0x666ea36f7879462c, 0x0e0a77c19a07df2f]
+        && g[4..] == [0xa6ba871b8b1e1b3a, 0x14f1d651eb8e167b, 0xccdd46def0f28c58, 0x1c14ef83340fbe5e]
+        && unsafe { sys::hm_device_count() } > 0
+}
+
+/// halo2curves gives these types no #[repr(C)]; the byte layout the library reads is asserted instead (once).
+pub fn layout_ok() -> bool {
+    static INIT: Once = Once::new();
+    static OK: AtomicBool = AtomicBool::new(false);
+    INIT.call_once(|| OK.store(layout_check(), Ordering::Release));
+    OK.load(Ordering::Acquire)
+}
+
+/// (x, y, 1) Montgomery words, or all zero for the identity: exactly bn256::G1 { x, y, z }.
+pub fn g1_from_words(xyz: [u64; 12]) -> G1 {
+    if xyz[8..].iter().all(|w| *w == 0) {
+        <G1 as group::Group>::identity()
+    } else {
+        unsafe { std::mem::transmute::<[u64; 12], G1>(xyz) }
+    }
 }
 
 pub fn try_best_multiexp<C: CurveAffine>(coeffs: &[C::Scalar], bases: &[C]) -> Option<C::Curve> {
-    if TypeId::of::<C>() != TypeId::of::<G1Affine>() || coeffs.len() < (1 << GPU_MIN_LOG_N) || !layout_ok() {
+    if TypeId::of::<C>() != TypeId::of::<G1Affine>() || coeffs.len() < (1 << GPU_MIN_LOG_N_MSM) || !layout_ok() {
         return None;
     }
     let mut xyz = [0u64; 12];
@@ -270,92 +295,295 @@ pub fn try_best_multiexp<C: CurveAffine>(coeffs: &[C::Scalar], bases: &[C]) -> O
         sys::hm_msm_bn256_g1_jacobian(coeffs.as_ptr() as *const u64, bases.as_ptr() as *const u64, coeffs.len(), xyz.as_mut_ptr())
     };
     if rc != sys::HM_OK {
-        return None;                                    // error policy of the boundary: fall back to the CPU body
+        return None; // error policy of the boundary: fall back to the CPU body (the inputs are untouched)
     }
-    // (x, y, 1) Montgomery words, or all zero for the identity: exactly bn256::G1 { x, y, z }
-    let p: G1 = if xyz[8..].iter().all(|w| *w == 0) { G1::identity() } else { unsafe { std::mem::transmute(xyz) } };
-    Some(unsafe { std::mem::transmute_copy(&p) })        // C::Curve == G1 here (checked by the TypeId test above)
+    let p = g1_from_words(xyz);
+    Some(unsafe { std::mem::transmute_copy::<G1, C::Curve>(&p) }) // C::Curve == G1 here (checked by the TypeId test above)
 }
 
 pub fn try_best_fft<G: Group>(a: &mut [G], omega: &G::Scalar, log_n: u32) -> bool {
-    if TypeId::of::<G>() != TypeId::of::<Fr>() || log_n < GPU_MIN_LOG_N || log_n > 28 || !layout_ok() {
+    if TypeId::of::<G>() != TypeId::of::<Fr>() || log_n < GPU_MIN_LOG_N_NTT || log_n > 28 || !layout_ok() {
         return false;
     }
     let rc = unsafe { sys::hm_ntt_bn256_fr(a.as_mut_ptr() as *mut u64, omega as *const _ as *const u64, log_n) };
-    rc == sys::HM_OK
+    if rc == sys::HM_ERR_PARTIAL_OUTPUT {
+        // the copy of the result back into `a` failed half-way: `a` is neither the input nor the output any more, so the
+        // CPU body must NOT run on it (it would continue the proof with a silently wrong polynomial)
+        panic!("hm_ntt_bn256_fr: {}", sys::last_error());
+    }
+    rc == sys::HM_OK // every other error code leaves `a` exactly as it was: the caller runs the CPU body
 }
 
-/// One process, several GPUs: every later best_multiexp is split over `devices` inside the library.
+/// One process, several GPUs: every later best_multiexp / registered base set is split over `devices` inside the library.
 pub fn use_devices(devices: &[i32]) -> bool {
     unsafe { sys::hm_set_msm_devices(devices.as_ptr(), devices.len() as i32) == sys::HM_OK }
 }
+'''.replace("@MSM@", str(GPU_MIN_LOG_N_MSM)).replace("@NTT@", str(GPU_MIN_LOG_N_NTT))
+
+MI355X_KZG_RS = '''//! mi355x_kzg.rs -- ParamsKZG's side of the binding (added by rust/halo2_proofs.patch / rust/apply_edits.py next to
+//! mi355x.rs, declared in arithmetic.rs).  GENERATED by tools/gen_rust_shim.py.
+//!
+//! create_proof commits ~56 times per MerkleSumTree proof (/root/reference/src/circuits/utils.rs:40-48), always against
+//! the same two arrays, params.g and params.g_lagrange.  The free-function drop-in (mi355x.rs) re-reads the whole base
+//! array on every call to key its cache; here every ParamsKZG registers its two arrays ONCE (hm_register_bases: converted,
+//! resident in HBM, from 2^17 points with the fixed-base table) and commits through the handle, and a whole phase of
+//! commitments goes to the library in one call (hm_msm_batch_bn256_g1_h: eight in flight, uploads behind kernels).
+//!
+//! `SrsHandles` is a FIELD of ParamsKZG (`gpu`), so a handle can never outlive or alias the arrays it was made from:
+//! every constructor creates it empty (Default), Clone creates a fresh empty one (the clone owns new Vecs), Drop releases
+//! both sets, and a handle is used only while the Vec it came from still starts at the same address and is at least as
+//! long as when it was registered (`downsize` truncates g in place -- a prefix, still valid -- and REPLACES g_lagrange,
+//! whose new buffer fails that test and is registered afresh).
+use std::any::TypeId;
+use std::fmt;
+use std::sync::atomic::{AtomicU64, AtomicUsize, Ordering};
+use std::sync::Mutex;
+
+use halo2_mi355x_sys as sys;
+use halo2curves::bn256::{G1Affine, G1};
+use halo2curves::CurveAffine;
+
+use crate::arithmetic::mi355x::{g1_from_words, layout_ok, GPU_MIN_LOG_N_MSM};
+
+const UNSET: u64 = 0; // the library's handles start at 1
+const FAILED: u64 = u64::MAX; // registration failed once: do not try again for this array
+
+struct Slot {
+    handle: AtomicU64,
+    ptr: AtomicUsize,
+    len: AtomicUsize,
+}
+
+impl Slot {
+    const fn new() -> Self {
+        Slot { handle: AtomicU64::new(UNSET), ptr: AtomicUsize::new(0), len: AtomicUsize::new(0) }
+    }
+    fn release(&self) {
+        let h = self.handle.swap(UNSET, Ordering::AcqRel);
+        if h != UNSET && h != FAILED {
+            unsafe { sys::hm_release_bases(h) };
+        }
+    }
+}
+
+pub struct SrsHandles {
+    g: Slot,
+    g_lagrange: Slot,
+    lock: Mutex<()>, // registration happens once per array, under this lock
+}
+
+impl Default for SrsHandles {
+    fn default() -> Self {
+        SrsHandles { g: Slot::new(), g_lagrange: Slot::new(), lock: Mutex::new(()) }
+    }
+}
+impl Clone for SrsHandles {
+    fn clone(&self) -> Self {
+        Self::default() // the clone of a ParamsKZG owns new Vecs: it registers them itself on first use
+    }
+}
+impl fmt::Debug for SrsHandles {
+    fn fmt(&self, f: &mut fmt::Formatter<'_>) -> fmt::Result {
+        write!(f, "SrsHandles {{ g: {}, g_lagrange: {} }}", self.g.handle.load(Ordering::Relaxed), self.g_lagrange.handle.load(Ordering::Relaxed))
+    }
+}
+impl Drop for SrsHandles {
+    fn drop(&mut self) {
+        self.g.release();
+        self.g_lagrange.release();
+    }
+}
+
+impl SrsHandles {
+    /// Drop both device sets (ParamsKZG::downsize replaces g_lagrange and shortens g): registered afresh on demand.
+    pub fn reset(&self) {
+        let _turn = self.lock.lock().unwrap_or_else(|e| e.into_inner());
+        self.g.release();
+        self.g_lagrange.release();
+    }
+
+    /// The handle of `bases` (registering it on first use), or None: not bn256, too small, no device, registration failed.
+    fn handle_for(&self, slot: &Slot, bases: &[G1Affine], n: usize) -> Option<u64> {
+        if n < (1 << GPU_MIN_LOG_N_MSM) || n > bases.len() || !layout_ok() {
+            return None;
+        }
+        let same_array = |s: &Slot| s.ptr.load(Ordering::Acquire) == bases.as_ptr() as usize && s.len.load(Ordering::Acquire) >= n;
+        let h = slot.handle.load(Ordering::Acquire);
+        if h != UNSET && same_array(slot) {
+            return if h == FAILED { None } else { Some(h) };
+        }
+        let _turn = self.lock.lock().unwrap_or_else(|e| e.into_inner());
+        let h = slot.handle.load(Ordering::Acquire);
+        if h != UNSET && same_array(slot) {
+            return if h == FAILED { None } else { Some(h) };
+        }
+        slot.release(); // another array (downsize replaced it): the old set goes
+        let mut out = 0u64;
+        let rc = unsafe { sys::hm_register_bases(bases.as_ptr() as *const u64, bases.len(), &mut out) };
+        slot.ptr.store(bases.as_ptr() as usize, Ordering::Release);
+        slot.len.store(bases.len(), Ordering::Release);
+        slot.handle.store(if rc == sys::HM_OK { out } else { FAILED }, Ordering::Release);
+        if rc == sys::HM_OK { Some(out) } else { None }
+    }
+
+    fn msm<C: CurveAffine>(&self, slot: &Slot, scalars: &[C::Scalar], bases: &[C]) -> Option<C::Curve> {
+        if TypeId::of::<C>() != TypeId::of::<G1Affine>() {
+            return None;
+        }
+        let bases: &[G1Affine] = unsafe { std::slice::from_raw_parts(bases.as_ptr() as *const G1Affine, bases.len()) };
+        let h = self.handle_for(slot, bases, scalars.len())?;
+        let (mut xy, mut is_id) = ([0u64; 8], 0i32);
+        let rc = unsafe { sys::hm_msm_bn256_g1_h(h, 0, scalars.as_ptr() as *const u64, scalars.len(), xy.as_mut_ptr(), &mut is_id) };
+        if rc != sys::HM_OK {
+            return None; // the caller runs best_multiexp (pointer form, then the CPU body)
+        }
+        let mut xyz = [0u64; 12];
+        if is_id == 0 {
+            xyz[..8].copy_from_slice(&xy);
+            xyz[8..].copy_from_slice(&[0xd35d438dc58f0d9d, 0x0a78eb28f5c70b3d, 0x666ea36f7879462c, 0x0e0a77c19a07df2f]); // z = 1 (R mod p)
+        }
+        let p: G1 = g1_from_words(xyz);
+        Some(unsafe { std::mem::transmute_copy::<G1, C::Curve>(&p) })
+    }
+
+    /// ParamsKZG::commit: scalars against g[..scalars.len()].
+    pub fn commit<C: CurveAffine>(&self, scalars: &[C::Scalar], g: &[C]) -> Option<C::Curve> {
+        self.msm::<C>(&self.g, scalars, g)
+    }
+    /// ParamsKZG::commit_lagrange: scalars against g_lagrange[..scalars.len()].
+    pub fn commit_lagrange<C: CurveAffine>(&self, scalars: &[C::Scalar], g_lagrange: &[C]) -> Option<C::Curve> {
+        self.msm::<C>(&self.g_lagrange, scalars, g_lagrange)
+    }
+
+    /// The commitments of one prover phase (columns of one length) in ONE library call; None = fall back to one by one.
+    pub fn commit_lagrange_batch<C: CurveAffine>(&self, columns: &[&[C::Scalar]], g_lagrange: &[C]) -> Option<Vec<C::Curve>> {
+        if TypeId::of::<C>() != TypeId::of::<G1Affine>() || columns.is_empty() {
+            return None;
+        }
+        let n = columns[0].len();
+        if columns.iter().any(|c| c.len() != n) {
+            return None;
+        }
+        let bases: &[G1Affine] = unsafe { std::slice::from_raw_parts(g_lagrange.as_ptr() as *const G1Affine, g_lagrange.len()) };
+        let h = self.handle_for(&self.g_lagrange, bases, n)?;
+        let ptrs: Vec<*const u64> = columns.iter().map(|c| c.as_ptr() as *const u64).collect();
+        let mut out = vec![0u64; 12 * columns.len()];
+        let rc = unsafe { sys::hm_msm_batch_bn256_g1_h(h, 0, ptrs.as_ptr(), n, columns.len(), out.as_mut_ptr()) };
+        if rc != sys::HM_OK {
+            return None;
+        }
+        Some(
+            out.chunks_exact(12)
+                .map(|w| {
+                    let mut xyz = [0u64; 12];
+                    xyz.copy_from_slice(w);
+                    let p: G1 = g1_from_words(xyz);
+                    unsafe { std::mem::transmute_copy::<G1, C::Curve>(&p) }
+                })
+                .collect(),
+        )
+    }
+}
 '''
+
+
+# The edits of EXISTING upstream files, one table for both deliverables: the zero-context hunks of halo2_proofs.patch and
+# the anchors of rust/apply_edits.py (which finds them as literal lines, is idempotent, and says what it did).
+#   (file, anchor line as recalled from the tag, [replacement lines for the 1st, 2nd ... occurrence], approximate line)
+# Every occurrence of an anchor in its file must be covered: apply_edits.py refuses a file where the count differs.
+_COMMIT_VIA = ["        if let Some(r) = self.gpu.{fn}::<E::G1Affine>(&scalars, &bases[..]) {{", "            return r;", "        }}",
+               "        best_multiexp(&scalars, &bases[0..size])"]
+_LITERAL = ["            s_g2,", "            gpu: Default::default(),"]
+EDITS = [
+    ("src/arithmetic.rs", "pub fn best_multiexp<C: CurveAffine>(coeffs: &[C::Scalar], bases: &[C]) -> C::Curve {",
+     [['#[path = "mi355x.rs"]', "pub mod mi355x;", '#[path = "mi355x_kzg.rs"]', "pub mod mi355x_kzg;", "",
+       "pub fn best_multiexp<C: CurveAffine>(coeffs: &[C::Scalar], bases: &[C]) -> C::Curve {",
+       "    assert_eq!(coeffs.len(), bases.len());",
+       "    if let Some(r) = mi355x::try_best_multiexp(coeffs, bases) {", "        return r;", "    }",
+       "    original_best_multiexp(coeffs, bases)", "}", "",
+       "fn original_best_multiexp<C: CurveAffine>(coeffs: &[C::Scalar], bases: &[C]) -> C::Curve {"]], 130),
+    ("src/arithmetic.rs", "pub fn best_fft<G: Group>(a: &mut [G], omega: G::Scalar, log_n: u32) {",
+     [["pub fn best_fft<G: Group>(a: &mut [G], omega: G::Scalar, log_n: u32) {",
+       "    assert_eq!(a.len(), 1 << log_n);",
+       "    if mi355x::try_best_fft(a, &omega, log_n) {", "        return;", "    }",
+       "    original_best_fft(a, omega, log_n)", "}", "",
+       "fn original_best_fft<G: Group>(a: &mut [G], omega: G::Scalar, log_n: u32) {"]], 169),
+    ("Cargo.toml", "[dependencies]", [["[dependencies]", 'halo2-mi355x-sys = { path = "../../halo2-mi355x-sys" }']], 45),
+    # ---- ParamsKZG: the SRS registered once, commitments through the handle (src/poly/kzg/commitment.rs) ----
+    ("src/poly/kzg/commitment.rs", "    pub(crate) s_g2: E::G2Affine,",
+     [["    pub(crate) s_g2: E::G2Affine,",
+       "    /// device handles of `g` / `g_lagrange` (libhalo2_mi355x.so): empty until the first commitment",
+       "    pub(crate) gpu: crate::arithmetic::mi355x_kzg::SrsHandles,"]], 38),
+    # the three struct literals: setup, read_custom, Params::read
+    ("src/poly/kzg/commitment.rs", "            s_g2,", [_LITERAL, _LITERAL, _LITERAL], 100),
+    # downsize() truncates g in place and REPLACES g_lagrange: both device sets are dropped and registered afresh on demand
+    ("src/poly/kzg/commitment.rs", "        self.g.truncate(self.n as usize);",
+     [["        self.g.truncate(self.n as usize);", "        self.gpu.reset();"]], 200),
+    # the last line of commit_lagrange (impl Params, first in the file) and of commit (impl ParamsProver, second)
+    ("src/poly/kzg/commitment.rs", "        best_multiexp(&scalars, &bases[0..size])",
+     [[l.format(fn="commit_lagrange") for l in _COMMIT_VIA], [l.format(fn="commit") for l in _COMMIT_VIA]], 290),
+]
 
 
 def emit_patch() -> str:
-    new_file = MI355X_RS.rstrip("\n").split("\n")
-    body = "\n".join("+" + l for l in new_file)
-    return f'''# GENERATED by tools/gen_rust_shim.py -- patch for a checkout of privacy-scaling-explorations/halo2 at tag v2023_02_02
+    def new_file(path, text):
+        lines = text.rstrip("\n").split("\n")
+        return (f"diff --git a/{path} b/{path}\nnew file mode 100644\n--- /dev/null\n+++ b/{path}\n@@ -0,0 +1,{len(lines)} @@\n"
+                + "\n".join("+" + l for l in lines) + "\n")
+    out = """# GENERATED by tools/gen_rust_shim.py -- patch for a checkout of privacy-scaling-explorations/halo2 at tag v2023_02_02
 # (the revision /root/reference/Cargo.toml:10 pins), applied from the checkout's halo2_proofs/ directory:
 #     patch -p1 < <this repository>/rust/halo2_proofs.patch
-# The upstream sources are not available in the build image, so the three edits of existing files are ZERO-CONTEXT hunks
-# that depend on one line each (the two function signatures, the [dependencies] header); `patch` finds them by content
-# (line numbers are approximate: expect "offset" messages).  If a hunk is rejected, make the edit by hand: rust/README.md.
-diff --git a/src/mi355x.rs b/src/mi355x.rs
-new file mode 100644
---- /dev/null
-+++ b/src/mi355x.rs
-@@ -0,0 +1,{len(new_file)} @@
-{body}
-diff --git a/src/arithmetic.rs b/src/arithmetic.rs
---- a/src/arithmetic.rs
-+++ b/src/arithmetic.rs
-@@ -130 +130,11 @@
--pub fn best_multiexp<C: CurveAffine>(coeffs: &[C::Scalar], bases: &[C]) -> C::Curve {{
-+#[path = "mi355x.rs"]
-+pub mod mi355x;
-+
-+pub fn best_multiexp<C: CurveAffine>(coeffs: &[C::Scalar], bases: &[C]) -> C::Curve {{
-+    assert_eq!(coeffs.len(), bases.len());
-+    if let Some(r) = mi355x::try_best_multiexp(coeffs, bases) {{
-+        return r;
-+    }}
-+    original_best_multiexp(coeffs, bases)
-+}}
-+
-+fn original_best_multiexp<C: CurveAffine>(coeffs: &[C::Scalar], bases: &[C]) -> C::Curve {{
-@@ -169 +179,9 @@
--pub fn best_fft<G: Group>(a: &mut [G], omega: G::Scalar, log_n: u32) {{
-+pub fn best_fft<G: Group>(a: &mut [G], omega: G::Scalar, log_n: u32) {{
-+    assert_eq!(a.len(), 1 << log_n);
-+    if mi355x::try_best_fft(a, &omega, log_n) {{
-+        return;
-+    }}
-+    original_best_fft(a, omega, log_n)
-+}}
-+
-+fn original_best_fft<G: Group>(a: &mut [G], omega: G::Scalar, log_n: u32) {{
-diff --git a/Cargo.toml b/Cargo.toml
---- a/Cargo.toml
-+++ b/Cargo.toml
-@@ -45 +45,2 @@
--[dependencies]
-+[dependencies]
-+halo2-mi355x-sys = {{ path = "../../halo2-mi355x-sys" }}
-'''
+# The upstream sources are not available in the build image, so the edits of existing files are ZERO-CONTEXT hunks that depend
+# on one line each, written from memory of the tag; `patch` finds them by content (line numbers are approximate: expect
+# "offset" messages).  An anchor line that occurs several times (the struct literals of ParamsKZG, the last line of its two
+# commit functions) has one hunk per occurrence, in file order.  rust/apply_edits.py makes the SAME edits from the same
+# table, is idempotent and refuses a file whose anchors do not occur as often as expected: prefer it.
+"""
+    out += new_file("src/mi355x.rs", MI355X_RS)
+    out += new_file("src/mi355x_kzg.rs", MI355X_KZG_RS)
+    by_file = {}
+    for path, anchor, repls, line in EDITS:
+        for k, repl in enumerate(repls):
+            by_file.setdefault(path, []).append((line + 60 * k, anchor, repl))
+    for path, hunks in by_file.items():
+        out += f"diff --git a/{path} b/{path}\n--- a/{path}\n+++ b/{path}\n"
+        shift = 0
+        for at, anchor, repl in sorted(hunks, key=lambda h: h[0]):
+            new_range = f"+{at + shift},{len(repl)}" if repl else f"+{at + shift - 1},0"
+            out += f"@@ -{at} {new_range} @@\n-{anchor}\n" + "".join("+" + l + "\n" for l in repl)
+            shift += len(repl) - 1
+    return out
+
+
+def edits_json() -> str:
+    """The edit table as data for rust/apply_edits.py (which has to run where this repository's tools/ may be absent)."""
+    import json
+    return json.dumps([{"file": f, "anchor": a, "replacements": r, "near_line": n} for f, a, r, n in EDITS], indent=1) + "\n"
 
 
 README = '''# rust/ -- the reference-side binding, as files
 
 GENERATED by `tools/gen_rust_shim.py` from `include/halo2_mi355x.h` (re-run it after any header change; `tests/test_capi.py`
-fails when these files and the header disagree).  **Nothing here has been compiled in this repository's build image: it has
-no Rust toolchain.**  The C ABI these files bind is exercised by `tests/` through ctypes and by the C++ mirror.
+fails when these files and the header disagree).  **Nothing here has been compiled or run against rustc / the upstream
+sources: the repository's build image has neither a Rust toolchain nor network access.**  The C ABI these files bind is
+exercised by `tests/` through ctypes and by the C++ mirror; `tests/test_rust_edits.py` runs `apply_edits.py` on a skeleton
+made of the recalled anchor lines.
 
 | path | what |
 |---|---|
-| `halo2-mi355x-sys/` | the FFI crate: `Cargo.toml`, `build.rs` (links `libhalo2_mi355x.so` from `$HALO2_MI355X_LIB_DIR`), `src/lib.rs` (one `extern "C"` item per header entry, `#[repr(C)]` stats structs, `HM_*` constants) |
-| `halo2_proofs-patch/src/mi355x.rs` | the glue module: `try_best_multiexp`, `try_best_fft` (TypeId dispatch on `bn256::G1Affine` / `bn256::Fr`, layout assertions, fall back to the CPU body on any error), `use_devices` |
-| `halo2_proofs.patch` | unified diff for `halo2_proofs/` of privacy-scaling-explorations/halo2 at tag `v2023_02_02` (what `/root/reference/Cargo.toml:10` pins): adds `src/mi355x.rs`, renames the two upstream bodies to `original_*` behind wrappers with the same signatures, adds the dependency |
+| `halo2-mi355x-sys/` | the FFI crate: `Cargo.toml`, `build.rs` (links `libhalo2_mi355x.so` from `$HALO2_MI355X_LIB_DIR`), `src/lib.rs` (one `extern "C"` item per header entry, `#[repr(C)]` structs, `HM_*` constants) |
+| `halo2_proofs-patch/src/mi355x.rs` | glue for the two free functions: `try_best_multiexp`, `try_best_fft` (TypeId dispatch on `bn256::G1Affine` / `bn256::Fr`, layout assertions behind `std::sync::Once`, fall back to the CPU body on any error that left the arrays untouched, panic on `HM_ERR_PARTIAL_OUTPUT`), `use_devices` |
+| `halo2_proofs-patch/src/mi355x_kzg.rs` | `SrsHandles`, the new field of `ParamsKZG`: `g` / `g_lagrange` registered ONCE per `ParamsKZG` (`hm_register_bases`: resident, converted, fixed-base table from 2^17 points), `commit` / `commit_lagrange` through the handle (`hm_msm_bn256_g1_h`), `commit_lagrange_batch` = a phase of commitments in one call (`hm_msm_batch_bn256_g1_h`); `Clone` = empty, `Drop` = release, `reset()` for `downsize` |
+| `edits.json`, `apply_edits.py` | the edits of EXISTING upstream files as a table (file, anchor line, replacement per occurrence) and the script that applies it by literal line match: idempotent, refuses a file whose anchors do not occur as often as expected |
+| `halo2_proofs.patch` | the same as a unified diff (new files + zero-context hunks, one per occurrence) for `patch -p1` |
+
+The edits (all in `halo2_proofs/` of the pinned tag, `/root/reference/Cargo.toml:10`):
+
+| file | edit |
+|---|---|
+| `src/arithmetic.rs` | `best_multiexp` / `best_fft` become wrappers with the same signatures that try the GPU and fall through to the untouched bodies, renamed `original_*`; declares the two new modules |
+| `src/poly/kzg/commitment.rs` | `ParamsKZG` gains the field `gpu: SrsHandles` (added to its three struct literals as `Default::default()`), `downsize` resets it, `commit_lagrange` and `commit` try `self.gpu.commit*` before their `best_multiexp(&scalars, &bases[0..size])` |
+| `Cargo.toml` | the `halo2-mi355x-sys` dependency |
 
 ## Recipe (on a machine with Rust and an MI355X)
 
@@ -363,7 +591,7 @@ no Rust toolchain.**  The C ABI these files bind is exercised by `tests/` throug
 make -C <repo>/halo2-experiments_amd/csrc                      # libhalo2_mi355x.so
 git clone https://github.com/privacy-scaling-explorations/halo2 && cd halo2 && git checkout v2023_02_02
 cp -r <repo>/rust/halo2-mi355x-sys ..                          # so that ../../halo2-mi355x-sys resolves from halo2_proofs/
-cd halo2_proofs && patch -p1 < <repo>/rust/halo2_proofs.patch
+python3 <repo>/rust/apply_edits.py halo2_proofs                # or: cd halo2_proofs && patch -p1 < <repo>/rust/halo2_proofs.patch
 ```
 
 then in the reference's `Cargo.toml` (`/root/reference/Cargo.toml`):
@@ -376,23 +604,40 @@ halo2_proofs = { path = "../halo2/halo2_proofs" }
 and `HALO2_MI355X_LIB_DIR=<repo>/halo2-experiments_amd/csrc cargo test --release test_full_prover -- --nocapture`
 (`/root/reference/src/circuits/merkle_sum_tree.rs:345-358`).  The reference's own sources are unchanged.
 
-If `patch` rejects a hunk (the upstream text was written from memory of the tag, one line of context per hunk), make the
-same three edits by hand: (1) copy `halo2_proofs-patch/src/mi355x.rs` to `halo2_proofs/src/`; (2) in `src/arithmetic.rs`
-rename `best_multiexp` / `best_fft` to `original_best_multiexp` / `original_best_fft` (private) and add the two wrappers
-and the `mod mi355x;` item shown in the patch; (3) add the `halo2-mi355x-sys` dependency.
+`apply_edits.py` prints `NOT APPLIED <file>: anchor ...` for every edit whose anchor line is not in the file as recalled;
+make that edit by hand from the table in `edits.json` (the replacement lines are the anchor line plus the additions).
+Known risks of code that has never met rustc: the trait paths of `generator()` / `identity()` are spelled out
+(`group::prime::PrimeCurveAffine`, `group::Group`), `C::Curve` is the associated type `best_multiexp` itself returns, and
+nothing newer than Rust 1.56 is used (`std::sync::Once` + atomics, no `OnceLock`).
 
-The registered-SRS edit of `ParamsKZG` (INTEGRATION.md §3) adds two fields to an upstream struct and touches every
-constructor; it is left as source in INTEGRATION.md rather than as hunks against text that cannot be checked here.
+**The batch call.** `create_proof` commits its advice columns in a loop over `params.commit_lagrange(poly, blind)`
+(`halo2_proofs/src/plonk/prover.rs`); `params` is the generic `ParamsProver`, so routing that loop through
+`SrsHandles::commit_lagrange_batch` needs one provided method on the `Params` trait
+(`fn commit_lagrange_batch(&self, polys: &[&Polynomial<..>]) -> Vec<C::CurveExt>` defaulting to the loop, overridden for
+`ParamsKZG` by `self.gpu.commit_lagrange_batch::<E::G1Affine>(&cols, &self.g_lagrange)`) and the loop's `.map(..).collect()`
+replaced by the call.  That is an edit of a trait other crates implement; it is described, not shipped as an anchor.
 '''
+
+
+def check_glue_against_header(functions, defines):
+    """Every sys:: item the glue modules use must be something lib.rs declares (an entry point, a constant, last_error)."""
+    declared = {f[0] for f in functions} | {d[0] for d in defines} | {"last_error"}
+    for name, text in (("mi355x.rs", MI355X_RS), ("mi355x_kzg.rs", MI355X_KZG_RS)):
+        for item in sorted(set(re.findall(r"sys::(\w+)", text))):
+            if item not in declared:
+                raise SystemExit(f"gen_rust_shim: {name} uses sys::{item}, which include/halo2_mi355x.h does not declare")
 
 
 def generate():
     functions, structs, defines = parse_header(open(HEADER).read())
+    check_glue_against_header(functions, defines)
     files = {
         os.path.join(RUST_DIR, "halo2-mi355x-sys", "Cargo.toml"): CARGO_TOML,
         os.path.join(RUST_DIR, "halo2-mi355x-sys", "build.rs"): BUILD_RS,
         os.path.join(RUST_DIR, "halo2-mi355x-sys", "src", "lib.rs"): emit_lib_rs(functions, structs, defines),
         os.path.join(RUST_DIR, "halo2_proofs-patch", "src", "mi355x.rs"): MI355X_RS,
+        os.path.join(RUST_DIR, "halo2_proofs-patch", "src", "mi355x_kzg.rs"): MI355X_KZG_RS,
+        os.path.join(RUST_DIR, "edits.json"): edits_json(),
         os.path.join(RUST_DIR, "halo2_proofs.patch"): emit_patch(),
         os.path.join(RUST_DIR, "README.md"): README,
     }
