@@ -631,6 +631,289 @@ __global__ __launch_bounds__(SORT_THREADS) void msm_part2_scatter_tiled_kernel(c
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The tiled scatters, second form ("v2", 32-bit items; round 4).  SQ counters on the kernels above at 2^24 on the table
+// (profiles/r04_b_side_measurements.txt) showed both of them bound by instruction issue and latency, not by HBM: 2.3
+// wave-instructions per item (147 lane-instructions), and in the ISA every one of a lane's 16 loads of a tile sits in its
+// own branch region behind its own `s_waitcnt vmcnt(0)` -- sixteen serial HBM round trips per tile (a tile took 32 us) --
+// and the positional walk is a divergent loop of dependent LDS reads per item.  Here a lane takes FOUR consecutive items
+// per 16-byte load, all loads of a tile are issued before anything waits, the super-chunk of an item comes from a per-tile
+// table (one entry per 64 positions, filled by a few lanes while the loads are in flight) plus a compare against the next
+// boundary, and the wave-uniformity test that guards the LDS counters is made once per four items.
+// ---------------------------------------------------------------------------------------------
+// Exclusive scan of cnt[0 .. NB) (NB <= 4096) into start[], by the whole workgroup; returns the total to every lane.
+// Three barriers; cnt is left untouched.
+__device__ __forceinline__ uint32_t tile_exclusive_scan(const uint32_t* __restrict__ cnt, uint32_t* __restrict__ start,
+                                                        uint32_t* __restrict__ wsum, uint32_t NB, uint32_t tid) {
+  const uint32_t per = (NB + SORT_THREADS - 1) / SORT_THREADS, b0 = tid * per;
+  uint32_t v[4096 / SORT_THREADS] = {}, sum = 0;
+#pragma unroll
+  for (uint32_t k = 0; k < 4096 / SORT_THREADS; ++k)
+    if (k < per && b0 + k < NB) { v[k] = cnt[b0 + k]; sum += v[k]; }
+  uint32_t incl = sum;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t u = __shfl_up(incl, off, 64);
+    if ((tid & 63) >= (uint32_t)off) incl += u;
+  }
+  if ((tid & 63) == 63) wsum[tid >> 6] = incl;
+  __syncthreads();
+  if (tid < 64) {
+    const uint32_t ws = tid < (SORT_THREADS / 64) ? wsum[tid] : 0;
+    uint32_t wi = ws;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t u = __shfl_up(wi, off, 64);
+      if (tid >= (uint32_t)off) wi += u;
+    }
+    if (tid < (SORT_THREADS / 64)) wsum[tid] = wi - ws;   // exclusive wave offsets
+    if (tid == SORT_THREADS / 64 - 1) wsum[SORT_THREADS / 64] = wi;   // the total
+  }
+  __syncthreads();
+  uint32_t run = wsum[tid >> 6] + incl - sum;
+#pragma unroll
+  for (uint32_t k = 0; k < 4096 / SORT_THREADS; ++k)
+    if (k < per && b0 + k < NB) { start[b0 + k] = run; run += v[k]; }
+  const uint32_t total = wsum[SORT_THREADS / 64];
+  __syncthreads();
+  return total;
+}
+
+// rank[k] = cnt[bin[k]]++ for the valid ones of a lane's four items.  When every item of the WAVE goes to one counter
+// (constant and flag columns: lds_inc's reason) one lane adds for all of them.
+__device__ __forceinline__ void lds_rank4(uint32_t* cnt, const uint32_t bin[4], uint32_t valid_mask, uint32_t rank[4]) {
+  const uint64_t active = __ballot(valid_mask != 0);
+  if (active == 0) return;                                     // wave-uniform
+  uint32_t mine = 0;
+#pragma unroll
+  for (int k = 3; k >= 0; --k)
+    if (valid_mask & (1u << k)) mine = bin[k];                 // a valid bin of this lane (its first)
+  const uint32_t v = (uint32_t)__builtin_amdgcn_readlane((int)mine, __builtin_ctzll(active));
+  bool same = true;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) same = same && (!(valid_mask & (1u << k)) || bin[k] == v);
+  if (__ballot(same) == __ballot(1)) {                       // every valid item of the wave wants counter v (called with the whole wave converged)
+    const uint32_t mycount = (uint32_t)__popc(valid_mask);
+    uint32_t incl = mycount;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t u = __shfl_up(incl, off, 64);
+      if ((threadIdx.x & 63) >= (uint32_t)off) incl += u;
+    }
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    uint32_t base = 0;
+    if ((threadIdx.x & 63) == 0) base = atomicAdd(&cnt[v], total);
+    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+    uint32_t r = base + incl - mycount;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (valid_mask & (1u << k)) rank[k] = r++;
+    return;
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if (valid_mask & (1u << k)) rank[k] = atomicAdd(&cnt[bin[k]], 1u);
+}
+
+template <int IPT>
+__global__ __launch_bounds__(SORT_THREADS) void msm_part1_scatter_v2_kernel(const int32_t* __restrict__ digits,
+                                                                            const uint32_t* __restrict__ chist,
+                                                                            const uint32_t* __restrict__ cstart,
+                                                                            uint32_t* __restrict__ tmp, size_t n, size_t chunk,
+                                                                            uint32_t fb, uint32_t ib, uint32_t NC) {
+  extern __shared__ uint32_t sm[];
+  constexpr int TILE = SORT_THREADS * IPT, NV = IPT / 4;
+  const uint32_t g = blockIdx.x, w = blockIdx.y, G = gridDim.x, tid = threadIdx.x;
+  uint32_t* gcur = sm;                 // global cursor of every coarse bin for this chunk
+  uint32_t* tcnt = gcur + NC;
+  uint32_t* tstart = tcnt + NC;
+  uint32_t* wsum = tstart + NC;        // 32 words
+  uint32_t* st_bin = wsum + 32;
+  uint32_t* st_item = st_bin + TILE;
+  const uint32_t* pre = chist + ((size_t)w * G + g) * NC;
+  const uint32_t* cs = cstart + (size_t)w * NC;
+  for (uint32_t b = tid; b < NC; b += SORT_THREADS) { gcur[b] = cs[b] + pre[b]; tcnt[b] = 0; }
+  __syncthreads();
+  const size_t lo = (size_t)g * chunk, hi = lo + chunk < n ? lo + chunk : n;
+  if (lo >= hi) return;
+  // tiles start where the ADDRESS is 16-byte aligned: `mis` <= 3 positions before lo (masked off below; for w > 0 they are
+  // the previous window's last digits, for w = 0 the array is 256-byte aligned and mis = lo & 3).  Positions are counted
+  // from that address: r in [mis, mis + len) is digit lo + r - mis.
+  const int32_t* dw = digits + (size_t)w * n + lo;
+  const uint32_t mis = (uint32_t)((reinterpret_cast<uintptr_t>(dw) >> 2) & 3);
+  const int32_t* base = dw - mis;
+  const uint32_t end = mis + (uint32_t)(hi - lo);              // chunks are far below 2^32 items
+  const uint32_t fmask = (1u << fb) - 1u, imask = (1u << ib) - 1u;
+  for (uint32_t rb = 0; rb < end; rb += TILE) {
+    int4 q[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const uint32_t r = rb + 4u * ((uint32_t)j * SORT_THREADS + tid);
+      q[j] = *reinterpret_cast<const int4*>(base + (r < end ? r : 0u));      // (a vector past the end reads the first one again)
+    }
+    uint32_t bin[IPT], rank[IPT], item[IPT], vmask[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const uint32_t r = rb + 4u * ((uint32_t)j * SORT_THREADS + tid);
+      const int32_t d4[4] = {q[j].x, q[j].y, q[j].z, q[j].w};
+      uint32_t m = 0;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int32_t d = d4[c];
+        const bool ok = r + c >= mis && r + c < end && d != 0;
+        const uint32_t pos = (uint32_t)lo + (r + c - mis);       // the item's index in its bucket set (low `ib` bits kept)
+        const uint32_t b1 = (uint32_t)(d < 0 ? -d : d) - 1u;
+        bin[4 * j + c] = b1 >> fb;
+        item[4 * j + c] = ((b1 & fmask) << (ib + 1)) | ((d < 0 ? 1u : 0u) << ib) | (pos & imask);
+        m |= ok ? 1u << c : 0u;
+      }
+      vmask[j] = m;
+      lds_rank4(tcnt, &bin[4 * j], m, &rank[4 * j]);
+    }
+    __syncthreads();
+    const uint32_t kept = tile_exclusive_scan(tcnt, tstart, wsum, NC, tid);
+#pragma unroll
+    for (int j = 0; j < NV; ++j)
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        if (vmask[j] & (1u << c)) {
+          const uint32_t dst = tstart[bin[4 * j + c]] + rank[4 * j + c];
+          st_item[dst] = item[4 * j + c];
+          st_bin[dst] = bin[4 * j + c];
+        }
+    __syncthreads();
+    for (uint32_t e = tid; e < kept; e += SORT_THREADS) {
+      const uint32_t b = st_bin[e];
+      tmp[gcur[b] + (e - tstart[b])] = st_item[e];
+    }
+    __syncthreads();
+    for (uint32_t b = tid; b < NC; b += SORT_THREADS) { gcur[b] += tcnt[b]; tcnt[b] = 0; }
+    __syncthreads();
+  }
+}
+
+template <bool COOP>
+__global__ __launch_bounds__(SORT_THREADS) void msm_part2_scatter_v2_kernel(const uint32_t* __restrict__ tmp,
+                                                                            const uint32_t* __restrict__ cstart,
+                                                                            const uint32_t* __restrict__ boff,
+                                                                            uint32_t* __restrict__ sorted, uint32_t fb,
+                                                                            uint32_t ib, uint32_t NC, uint32_t NBP, uint32_t big,
+                                                                            uint32_t slice, const uint2* __restrict__ list,
+                                                                            const uint32_t* __restrict__ list_count,
+                                                                            uint32_t* __restrict__ gcursor, Positional ps) {
+  extern __shared__ uint32_t sm[];
+  __shared__ uint32_t sc_start[PS_MAX_SC + 2];
+  __shared__ uint32_t tile_sc[P2_TILE / 64];                  // super-chunk of every 64th position of the current tile
+  constexpr int NV = P2_IPT / 4;
+  uint32_t hb = blockIdx.x, w = blockIdx.y, sl = 0;
+  const uint32_t tid = threadIdx.x;
+  if (COOP) {
+    if (blockIdx.x >= *list_count) return;
+    const uint2 it = list[blockIdx.x];
+    w = it.x / NC;
+    hb = it.x - w * NC;
+    sl = it.y;
+  } else if (cstart[w * NC + hb + 1] - cstart[w * NC + hb] > big) {
+    return;
+  }
+  const uint32_t NF = 1u << fb;                       // <= 4096
+  uint32_t* gcur = sm;                                // global cursor of every fine bucket
+  uint32_t* tcnt = gcur + NF;                         // items of the current tile per bucket
+  uint32_t* tstart = tcnt + NF;                       // exclusive prefix of tcnt
+  uint32_t* wsum = tstart + NF;                       // 32 words
+  uint32_t* st_pay = wsum + 32;                       // tile items in bucket order
+  uint16_t* st_bin = reinterpret_cast<uint16_t*>(st_pay + P2_TILE);   // their fine buckets (< 2^12)
+  const uint32_t* bo = boff + (size_t)w * NBP + 1 + ((size_t)hb << fb);
+  uint32_t* gc = gcursor + (size_t)w * NBP + 1 + ((size_t)hb << fb);
+  for (uint32_t b = tid; b < NF; b += SORT_THREADS) { gcur[b] = bo[b]; tcnt[b] = 0; }
+  uint32_t lo = cstart[w * NC + hb], hi = cstart[w * NC + hb + 1];
+  const uint32_t region_lo = lo, region_n = hi - lo;
+  if (ps.nsc) {                                        // region-relative start of every super-chunk's runs; a sentinel behind them
+    for (uint32_t sc = tid; sc <= ps.nsc + 1; sc += SORT_THREADS)
+      sc_start[sc] = sc < ps.nsc ? ps.chist[(size_t)sc * ps.gpc * NC + hb] : (sc == ps.nsc ? region_n : 0xffffffffu);
+  }
+  __syncthreads();
+  if (COOP) {
+    lo += sl * slice;
+    hi = lo + slice < hi ? lo + slice : hi;
+  }
+  if (lo >= hi) return;
+  const uint32_t imask = (1u << ib) - 1u;
+  for (uint32_t tb = lo & ~3u; tb < hi; tb += P2_TILE) {   // tmp is 256-byte aligned: positions that are multiples of 4 are 16-byte addresses
+    uint4 q[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const uint32_t p = tb + 4u * ((uint32_t)j * SORT_THREADS + tid);
+      q[j] = *reinterpret_cast<const uint4*>(tmp + (p < hi ? p : (lo & ~3u)));
+    }
+    if (ps.nsc && tid < P2_TILE / 64) {                // while the loads are in flight: the largest sc with sc_start[sc] <= position
+      const uint32_t p0 = tb + 64u * tid;
+      const uint32_t rel = p0 > region_lo ? p0 - region_lo : 0u;
+      uint32_t a = 0, b = ps.nsc;                      // invariant: sc_start[a] <= rel (sc_start[0] = 0), and rel < sc_start[b] or b = nsc
+      while (b - a > 1) {
+        const uint32_t m = (a + b) >> 1;
+        if (sc_start[m] <= rel) a = m; else b = m;
+      }
+      tile_sc[tid] = a;
+    }
+    uint32_t bin[P2_IPT], rank[P2_IPT], vmask[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const uint32_t p = tb + 4u * ((uint32_t)j * SORT_THREADS + tid);
+      const uint32_t i4[4] = {q[j].x, q[j].y, q[j].z, q[j].w};
+      uint32_t m = 0;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        bin[4 * j + c] = i4[c] >> (ib + 1);
+        m |= (p + c >= lo && p + c < hi) ? 1u << c : 0u;
+      }
+      vmask[j] = m;
+      lds_rank4(tcnt, &bin[4 * j], m, &rank[4 * j]);
+    }
+    __syncthreads();
+    const uint32_t kept = tile_exclusive_scan(tcnt, tstart, wsum, NF, tid);
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const uint32_t p = tb + 4u * ((uint32_t)j * SORT_THREADS + tid);
+      const uint32_t i4[4] = {q[j].x, q[j].y, q[j].z, q[j].w};
+      uint32_t a = 0, nb = 0xffffffffu;
+      if (ps.nsc && vmask[j]) {                        // super-chunk of the vector's first position: the tile table, then a short walk
+        const uint32_t rel = (p > region_lo ? p - region_lo : 0u);
+        a = tile_sc[(p - tb) >> 6];
+        while (sc_start[a + 1] <= rel && a + 1 < ps.nsc) ++a;
+        nb = sc_start[a + 1];
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        if (vmask[j] & (1u << c)) {
+          uint32_t pay = (i4[c] & imask) | (((i4[c] >> ib) & 1u) << 31);
+          if (ps.nsc) {
+            const uint32_t rel = p + c - region_lo;
+            while (nb <= rel && a + 1 < ps.nsc) { ++a; nb = sc_start[a + 1]; }   // almost never: runs are ~2 000 items long
+            pay |= a << ib;
+          }
+          const uint32_t dst = tstart[bin[4 * j + c]] + rank[4 * j + c];
+          st_pay[dst] = pay;
+          st_bin[dst] = (uint16_t)bin[4 * j + c];
+        }
+    }
+    if (COOP)      // reserve this tile's run in every non-empty bucket
+      for (uint32_t b = tid; b < NF; b += SORT_THREADS)
+        if (tcnt[b]) gcur[b] = atomicAdd(&gc[b], tcnt[b]);
+    __syncthreads();
+    for (uint32_t e = tid; e < kept; e += SORT_THREADS) {
+      const uint32_t b = st_bin[e];
+      sorted[gcur[b] + (e - tstart[b])] = st_pay[e];
+    }
+    __syncthreads();
+    for (uint32_t b = tid; b < NF; b += SORT_THREADS) {
+      if (!COOP) gcur[b] += tcnt[b];
+      tcnt[b] = 0;
+    }
+    __syncthreads();
+  }
+}
+
 // bucket offsets (exclusive scan of counts) and task offsets (exclusive scan of ceil(count / L)):
 // three small launches -- per-block sums, a one-block scan of those, per-block rescan + offset.
 constexpr int SCAN_THREADS = 256;
@@ -1408,6 +1691,12 @@ int msm_precompute(uint32_t* d_table, const uint8_t* d_inf, size_t n, uint32_t c
   return HM_OK;
 }
 
+// HALO2_MI355X_SORT_V1=1: the round-1..3 tiled scatters (one 4-byte load per item) instead of the vector-load form (A/B)
+static bool sort_v1() {
+  static const bool v = [] { const char* e = std::getenv("HALO2_MI355X_SORT_V1"); return e && *e == '1'; }();
+  return v;
+}
+
 struct BigRegionPlan {      // cooperative handling of sort regions that hold far more than their share
   uint32_t big = 0;         // regions above this many items are split
   uint32_t slice = 0;       // ... into slices of this many items, one workgroup each
@@ -1430,7 +1719,17 @@ static int launch_sort(const int32_t* d_digits, uint32_t* d_chist, uint32_t* d_c
     hipLaunchKernelGGL(msm_part1_starts_kernel, dim3(1), dim3(1024), 0, stream, (const uint32_t*)d_ctot, d_cstart, SW * NC);
     static const bool big_tiles = [] { const char* v = std::getenv("HALO2_MI355X_P1_BIG_TILES"); return !(v && *v == '0'); }();
     static const uint32_t p1_big_from = [] { const char* v = std::getenv("HALO2_MI355X_P1_BIG_FROM"); return (uint32_t)(v && *v ? std::atoi(v) : 512); }();
-    if (NC >= (p1_big_from) && NC <= 2048 && sizeof(ITEM) == 4 && big_tiles) {
+    if (sizeof(ITEM) == 4 && NC <= 4096 && !sort_v1()) {      // the vector-load form (32-bit items)
+      if (NC >= (p1_big_from) && NC <= 2048 && big_tiles) {
+        constexpr int TILE = SORT_THREADS * P1_BIG_IPT;
+        hipLaunchKernelGGL((msm_part1_scatter_v2_kernel<P1_BIG_IPT>), dim3(G, SW), dim3(SORT_THREADS), ((size_t)3 * NC + 32 + 2 * TILE) * 4, stream,
+                           d_digits, (const uint32_t*)d_chist, (const uint32_t*)d_cstart, (uint32_t*)d_tmp, sn, chunk, fb, ib, NC);
+      } else {
+        constexpr int TILE = SORT_THREADS * P1_IPT_DEFAULT;
+        hipLaunchKernelGGL((msm_part1_scatter_v2_kernel<P1_IPT_DEFAULT>), dim3(G, SW), dim3(SORT_THREADS), ((size_t)3 * NC + 32 + 2 * TILE) * 4,
+                           stream, d_digits, (const uint32_t*)d_chist, (const uint32_t*)d_cstart, (uint32_t*)d_tmp, sn, chunk, fb, ib, NC);
+      }
+    } else if (NC >= (p1_big_from) && NC <= 2048 && sizeof(ITEM) == 4 && big_tiles) {
       constexpr int TILE = SORT_THREADS * P1_BIG_IPT;
       const size_t lds_p1 = ((size_t)3 * NC + 32 + TILE) * 4 + (size_t)TILE * sizeof(ITEM);
       hipLaunchKernelGGL((msm_part1_scatter_tiled_kernel<ITEM, P1_BIG_IPT>), dim3(G, SW), dim3(SORT_THREADS), lds_p1, stream, d_digits,
@@ -1467,7 +1766,15 @@ static int launch_sort_scatter(const int32_t* d_digits, const uint32_t* d_cstart
                                uint32_t* d_sorted, size_t sn, uint32_t SW, uint32_t fb, uint32_t ib, uint32_t cb, uint32_t NC,
                                uint32_t NBP, uint32_t NBT, const BigRegionPlan& br, const Positional& ps, hipStream_t stream) {
   const size_t lds_fine = (size_t)4 << fb;
-  if (cb && (fb <= 11 || (ps.nsc != 0 && fb <= 12))) {      // 2^12 fine counters only where the positional plan asks for them
+  if (cb && (fb <= 11 || (ps.nsc != 0 && fb <= 12)) && sizeof(ITEM) == 4 && !sort_v1()) {
+    const size_t lds_tiled = ((size_t)3 * (1u << fb) + 32 + P2_TILE) * 4 + (size_t)P2_TILE * 2;
+    hipLaunchKernelGGL((msm_part2_scatter_v2_kernel<false>), dim3(NC, SW), dim3(SORT_THREADS), lds_tiled, stream, (const uint32_t*)d_tmp,
+                       d_cstart, d_boff, d_sorted, fb, ib, NC, NBP, br.big, br.slice, (const uint2*)br.list, (const uint32_t*)br.count,
+                       br.gcursor, ps);
+    hipLaunchKernelGGL((msm_part2_scatter_v2_kernel<true>), dim3(br.capacity), dim3(SORT_THREADS), lds_tiled, stream, (const uint32_t*)d_tmp,
+                       d_cstart, d_boff, d_sorted, fb, ib, NC, NBP, br.big, br.slice, (const uint2*)br.list, (const uint32_t*)br.count,
+                       br.gcursor, ps);
+  } else if (cb && (fb <= 11 || (ps.nsc != 0 && fb <= 12))) {      // 2^12 fine counters only where the positional plan asks for them
     const size_t lds_tiled = ((size_t)3 * (1u << fb) + 32 + P2_TILE) * 4 + (size_t)P2_TILE * 2;
     hipLaunchKernelGGL((msm_part2_scatter_tiled_kernel<ITEM, false>), dim3(NC, SW), dim3(SORT_THREADS), lds_tiled, stream,
                        (const ITEM*)d_tmp, d_cstart, d_boff, d_sorted, fb, ib, NC, NBP, br.big, br.slice, (const uint2*)br.list,
@@ -1728,6 +2035,15 @@ static int msm_issue(DeviceCtx& ctx, int slot, const uint32_t* d_scalars_ext, co
                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
     HM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(msm_part1_scatter_tiled_kernel<uint32_t, P1_BIG_IPT>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+    const int lds_all = 160 * 1024 - 6 * 1024;     // what a workgroup may ask for dynamically beside the v2 kernels' static tables
+    HM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(msm_part1_scatter_v2_kernel<P1_IPT_DEFAULT>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds_all));
+    HM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(msm_part1_scatter_v2_kernel<P1_BIG_IPT>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds_all));
+    HM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(msm_part2_scatter_v2_kernel<false>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds_all));
+    HM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(msm_part2_scatter_v2_kernel<true>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds_all));
     ctx.msm_attr_set = true;
   }
   hipEvent_t* ev = sl.ev;
