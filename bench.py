@@ -757,8 +757,15 @@ def main():
         dist.barrier(group=park_group)                          # everybody has let go of its device memory ...
         if rank == 0:
             devs = [r if backend == "nccl" else r % max(ndev, 1) for r in range(world)]
-            one_proc = one_process_measurements(devs, device, 26 if args.log_points == 24 and not args.no_2_26 else args.log_points,
-                                                None if args.replay == "none" else args.replay.split(",")[-1])
+            try:            # never at the expense of the line's headline: this form has not met N physical devices before the driver's run
+                one_proc = one_process_measurements(devs, device, 26 if args.log_points == 24 and not args.no_2_26 else args.log_points,
+                                                    None if args.replay == "none" else args.replay.split(",")[-1])
+            except Exception as e:  # noqa: BLE001
+                one_proc = {"devices": devs, "error": f"{type(e).__name__}: {e}"}
+                try:
+                    _lib.load().hm_set_msm_devices(None, 0)
+                except Exception:  # noqa: BLE001
+                    pass
         dist.barrier(group=park_group)                          # ... and waits here, on the CPU, until rank 0 is done
 
     if rank == 0:

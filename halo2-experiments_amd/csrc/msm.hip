@@ -641,6 +641,11 @@ __global__ __launch_bounds__(SORT_THREADS) void msm_part2_scatter_tiled_kernel(c
 // table (one entry per 64 positions, filled by a few lanes while the loads are in flight) plus a compare against the next
 // boundary, and the wave-uniformity test that guards the LDS counters is made once per four items.
 // ---------------------------------------------------------------------------------------------
+// A workgroup barrier that orders LDS accesses only: __syncthreads() also waits for every outstanding global access
+// (s_waitcnt vmcnt(0)), which would drain a tile's scattered stores -- and the next tile's prefetched loads -- at each of
+// the six barriers of a tile.  The v2 scatters never read back what they store to global memory.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // Exclusive scan of cnt[0 .. NB) (NB <= 4096) into start[], by the whole workgroup; returns the total to every lane.
 // Three barriers; cnt is left untouched.
 __device__ __forceinline__ uint32_t tile_exclusive_scan(const uint32_t* __restrict__ cnt, uint32_t* __restrict__ start,
@@ -657,7 +662,7 @@ __device__ __forceinline__ uint32_t tile_exclusive_scan(const uint32_t* __restri
     if ((tid & 63) >= (uint32_t)off) incl += u;
   }
   if ((tid & 63) == 63) wsum[tid >> 6] = incl;
-  __syncthreads();
+  lds_barrier();
   if (tid < 64) {
     const uint32_t ws = tid < (SORT_THREADS / 64) ? wsum[tid] : 0;
     uint32_t wi = ws;
@@ -669,30 +674,36 @@ __device__ __forceinline__ uint32_t tile_exclusive_scan(const uint32_t* __restri
     if (tid < (SORT_THREADS / 64)) wsum[tid] = wi - ws;   // exclusive wave offsets
     if (tid == SORT_THREADS / 64 - 1) wsum[SORT_THREADS / 64] = wi;   // the total
   }
-  __syncthreads();
+  lds_barrier();
   uint32_t run = wsum[tid >> 6] + incl - sum;
 #pragma unroll
   for (uint32_t k = 0; k < 4096 / SORT_THREADS; ++k)
     if (k < per && b0 + k < NB) { start[b0 + k] = run; run += v[k]; }
   const uint32_t total = wsum[SORT_THREADS / 64];
-  __syncthreads();
+  lds_barrier();
   return total;
 }
 
-// rank[k] = cnt[bin[k]]++ for the valid ones of a lane's four items.  When every item of the WAVE goes to one counter
-// (constant and flag columns: lds_inc's reason) one lane adds for all of them.
+// rank[k] = cnt[bin[k]]++ for the valid ones of a lane's four items (FULL: all four are).  When every item of the WAVE
+// goes to one counter (constant and flag columns: lds_inc's reason) one lane adds for all of them.  Called with the whole
+// wave converged.
+template <bool FULL>
 __device__ __forceinline__ void lds_rank4(uint32_t* cnt, const uint32_t bin[4], uint32_t valid_mask, uint32_t rank[4]) {
-  const uint64_t active = __ballot(valid_mask != 0);
-  if (active == 0) return;                                     // wave-uniform
-  uint32_t mine = 0;
+  if (FULL) valid_mask = 0xfu;
+  const uint64_t active = FULL ? ~0ull : __ballot(valid_mask != 0);
+  if (!FULL && active == 0) return;                            // wave-uniform
+  uint32_t mine = bin[0];
+  if (!FULL) {
 #pragma unroll
-  for (int k = 3; k >= 0; --k)
-    if (valid_mask & (1u << k)) mine = bin[k];                 // a valid bin of this lane (its first)
-  const uint32_t v = (uint32_t)__builtin_amdgcn_readlane((int)mine, __builtin_ctzll(active));
+    for (int k = 3; k >= 0; --k)
+      if (valid_mask & (1u << k)) mine = bin[k];               // a valid bin of this lane (its first)
+  }
+  const uint32_t v = FULL ? (uint32_t)__builtin_amdgcn_readfirstlane((int)mine)
+                          : (uint32_t)__builtin_amdgcn_readlane((int)mine, __builtin_ctzll(active));
   bool same = true;
 #pragma unroll
   for (int k = 0; k < 4; ++k) same = same && (!(valid_mask & (1u << k)) || bin[k] == v);
-  if (__ballot(same) == __ballot(1)) {                       // every valid item of the wave wants counter v (called with the whole wave converged)
+  if (__ballot(same) == ~0ull) {                               // every valid item of the wave wants counter v
     const uint32_t mycount = (uint32_t)__popc(valid_mask);
     uint32_t incl = mycount;
 #pragma unroll
@@ -712,7 +723,75 @@ __device__ __forceinline__ void lds_rank4(uint32_t* cnt, const uint32_t bin[4], 
   }
 #pragma unroll
   for (int k = 0; k < 4; ++k)
-    if (valid_mask & (1u << k)) rank[k] = atomicAdd(&cnt[bin[k]], 1u);
+    if (FULL || (valid_mask & (1u << k))) rank[k] = atomicAdd(&cnt[bin[k]], 1u);
+}
+
+// One tile of the first-level scatter.  FULL: every position of the tile is a digit of the chunk (all but the first and
+// last tile of a chunk): no masks, no predication.  `base + r` is digit lo + r - mis.
+template <int IPT>
+__device__ __forceinline__ void p1v2_load(const int32_t* __restrict__ base, uint32_t rb, uint32_t end, uint32_t tid, int4 (&q)[IPT / 4]) {
+#pragma unroll
+  for (int j = 0; j < IPT / 4; ++j) {
+    const uint32_t r = rb + 4u * ((uint32_t)j * SORT_THREADS + tid);
+    q[j] = *reinterpret_cast<const int4*>(base + (r < end ? r : 0u));      // (a vector past the end reads the first one again)
+  }
+}
+template <int IPT, bool FULL>
+__device__ __forceinline__ void p1v2_tile(const int4 (&q)[IPT / 4], uint32_t rb, uint32_t mis, uint32_t end, uint32_t lo32,
+                                          uint32_t fb, uint32_t ib, uint32_t NC, uint32_t* __restrict__ tmp, uint32_t* gcur, uint32_t* tcnt,
+                                          uint32_t* tstart, uint32_t* wsum, uint32_t* st_bin, uint32_t* st_item, uint32_t tid) {
+  constexpr int NV = IPT / 4;
+  const uint32_t fmask = (1u << fb) - 1u, imask = (1u << ib) - 1u;
+  uint32_t rank[IPT], vmask[NV];
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const uint32_t r = rb + 4u * ((uint32_t)j * SORT_THREADS + tid);
+    const int32_t d4[4] = {q[j].x, q[j].y, q[j].z, q[j].w};
+    uint32_t m = 0, bin[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int32_t d = d4[c];
+      const bool ok = (FULL || (r + c >= mis && r + c < end)) && d != 0;      // zero digits are not items
+      bin[c] = ((uint32_t)(d < 0 ? -d : d) - 1u) >> fb;
+      m |= ok ? 1u << c : 0u;
+    }
+    vmask[j] = m;
+    if (__ballot(m != 0xfu) == 0) lds_rank4<true>(tcnt, bin, m, &rank[4 * j]);     // no zero digit in the wave's 256: the usual case
+    else lds_rank4<false>(tcnt, bin, m, &rank[4 * j]);
+  }
+  lds_barrier();
+  const uint32_t kept = tile_exclusive_scan(tcnt, tstart, wsum, NC, tid);
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const uint32_t r = rb + 4u * ((uint32_t)j * SORT_THREADS + tid);
+    const int32_t d4[4] = {q[j].x, q[j].y, q[j].z, q[j].w};
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      if (vmask[j] & (1u << c)) {
+        const int32_t d = d4[c];
+        const uint32_t b1 = (uint32_t)(d < 0 ? -d : d) - 1u, bin = b1 >> fb;
+        const uint32_t pos = lo32 + (r + c - mis);                              // the item's index in its bucket set (low `ib` bits kept)
+        const uint32_t dst = tstart[bin] + rank[4 * j + c];
+        st_item[dst] = ((b1 & fmask) << (ib + 1)) | ((d < 0 ? 1u : 0u) << ib) | (pos & imask);
+        st_bin[dst] = bin;
+      }
+  }
+  lds_barrier();
+  if (kept == (uint32_t)(SORT_THREADS * IPT)) {
+#pragma unroll 4
+    for (int k = 0; k < IPT; ++k) {
+      const uint32_t e = (uint32_t)k * SORT_THREADS + tid, b = st_bin[e];
+      tmp[gcur[b] + (e - tstart[b])] = st_item[e];
+    }
+  } else {
+    for (uint32_t e = tid; e < kept; e += SORT_THREADS) {
+      const uint32_t b = st_bin[e];
+      tmp[gcur[b] + (e - tstart[b])] = st_item[e];
+    }
+  }
+  lds_barrier();
+  for (uint32_t b = tid; b < NC; b += SORT_THREADS) { gcur[b] += tcnt[b]; tcnt[b] = 0; }
+  lds_barrier();
 }
 
 template <int IPT>
@@ -722,7 +801,7 @@ __global__ __launch_bounds__(SORT_THREADS) void msm_part1_scatter_v2_kernel(cons
                                                                             uint32_t* __restrict__ tmp, size_t n, size_t chunk,
                                                                             uint32_t fb, uint32_t ib, uint32_t NC) {
   extern __shared__ uint32_t sm[];
-  constexpr int TILE = SORT_THREADS * IPT, NV = IPT / 4;
+  constexpr uint32_t TILE = SORT_THREADS * IPT;
   const uint32_t g = blockIdx.x, w = blockIdx.y, G = gridDim.x, tid = threadIdx.x;
   uint32_t* gcur = sm;                 // global cursor of every coarse bin for this chunk
   uint32_t* tcnt = gcur + NC;
@@ -733,63 +812,123 @@ __global__ __launch_bounds__(SORT_THREADS) void msm_part1_scatter_v2_kernel(cons
   const uint32_t* pre = chist + ((size_t)w * G + g) * NC;
   const uint32_t* cs = cstart + (size_t)w * NC;
   for (uint32_t b = tid; b < NC; b += SORT_THREADS) { gcur[b] = cs[b] + pre[b]; tcnt[b] = 0; }
-  __syncthreads();
+  lds_barrier();
   const size_t lo = (size_t)g * chunk, hi = lo + chunk < n ? lo + chunk : n;
   if (lo >= hi) return;
-  // tiles start where the ADDRESS is 16-byte aligned: `mis` <= 3 positions before lo (masked off below; for w > 0 they are
-  // the previous window's last digits, for w = 0 the array is 256-byte aligned and mis = lo & 3).  Positions are counted
-  // from that address: r in [mis, mis + len) is digit lo + r - mis.
+  // tiles start where the ADDRESS is 16-byte aligned: `mis` <= 3 positions before lo (masked off; for w > 0 they are the
+  // previous window's last digits, for w = 0 the array is 256-byte aligned and mis = lo & 3).  Positions are counted from
+  // that address: r in [mis, mis + len) is digit lo + r - mis.
   const int32_t* dw = digits + (size_t)w * n + lo;
   const uint32_t mis = (uint32_t)((reinterpret_cast<uintptr_t>(dw) >> 2) & 3);
   const int32_t* base = dw - mis;
   const uint32_t end = mis + (uint32_t)(hi - lo);              // chunks are far below 2^32 items
-  const uint32_t fmask = (1u << fb) - 1u, imask = (1u << ib) - 1u;
+  int4 q[IPT / 4], qn[IPT / 4];
+  p1v2_load<IPT>(base, 0, end, tid, q);
   for (uint32_t rb = 0; rb < end; rb += TILE) {
-    int4 q[NV];
+    const bool more = rb + TILE < end;
+    if (more) p1v2_load<IPT>(base, rb + TILE, end, tid, qn);     // the next tile's digits travel while this one is ranked and staged
+    if (rb >= mis && rb + TILE <= end)
+      p1v2_tile<IPT, true>(q, rb, mis, end, (uint32_t)lo, fb, ib, NC, tmp, gcur, tcnt, tstart, wsum, st_bin, st_item, tid);
+    else
+      p1v2_tile<IPT, false>(q, rb, mis, end, (uint32_t)lo, fb, ib, NC, tmp, gcur, tcnt, tstart, wsum, st_bin, st_item, tid);
+    if (more) {
 #pragma unroll
-    for (int j = 0; j < NV; ++j) {
-      const uint32_t r = rb + 4u * ((uint32_t)j * SORT_THREADS + tid);
-      q[j] = *reinterpret_cast<const int4*>(base + (r < end ? r : 0u));      // (a vector past the end reads the first one again)
+      for (int j = 0; j < IPT / 4; ++j) q[j] = qn[j];
     }
-    uint32_t bin[IPT], rank[IPT], item[IPT], vmask[NV];
+  }
+}
+
+__device__ __forceinline__ uint32_t dst_of(const uint32_t* tstart, uint32_t bin, uint32_t rank) { return tstart[bin] + rank; }
+
+// One tile of the second-level scatter.  FULL: every position of the tile is an item of the region / slice.
+__device__ __forceinline__ void p2v2_load(const uint32_t* __restrict__ tmp, uint32_t tb, uint32_t lo, uint32_t hi, uint32_t tid,
+                                          uint4 (&q)[P2_IPT / 4]) {
 #pragma unroll
-    for (int j = 0; j < NV; ++j) {
-      const uint32_t r = rb + 4u * ((uint32_t)j * SORT_THREADS + tid);
-      const int32_t d4[4] = {q[j].x, q[j].y, q[j].z, q[j].w};
-      uint32_t m = 0;
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const int32_t d = d4[c];
-        const bool ok = r + c >= mis && r + c < end && d != 0;
-        const uint32_t pos = (uint32_t)lo + (r + c - mis);       // the item's index in its bucket set (low `ib` bits kept)
-        const uint32_t b1 = (uint32_t)(d < 0 ? -d : d) - 1u;
-        bin[4 * j + c] = b1 >> fb;
-        item[4 * j + c] = ((b1 & fmask) << (ib + 1)) | ((d < 0 ? 1u : 0u) << ib) | (pos & imask);
-        m |= ok ? 1u << c : 0u;
-      }
-      vmask[j] = m;
-      lds_rank4(tcnt, &bin[4 * j], m, &rank[4 * j]);
+  for (int j = 0; j < P2_IPT / 4; ++j) {
+    const uint32_t p = tb + 4u * ((uint32_t)j * SORT_THREADS + tid);
+    q[j] = *reinterpret_cast<const uint4*>(tmp + (p < hi ? p : (lo & ~3u)));
+  }
+}
+template <bool COOP, bool FULL>
+__device__ __forceinline__ void p2v2_tile(const uint4 (&q)[P2_IPT / 4], uint32_t* __restrict__ sorted, uint32_t tb, uint32_t lo,
+                                          uint32_t hi, uint32_t region_lo, uint32_t ib, uint32_t NF, const Positional& ps, uint32_t* gcur,
+                                          uint32_t* tcnt, uint32_t* tstart, uint32_t* wsum, uint32_t* st_pay, uint16_t* st_bin,
+                                          const uint32_t* sc_start, uint32_t* tile_sc, uint32_t* __restrict__ gc, uint32_t tid) {
+  constexpr int NV = P2_IPT / 4;
+  const uint32_t imask = (1u << ib) - 1u;
+  if (ps.nsc && tid < P2_TILE / 64) {                  // while the loads are in flight: the largest sc with sc_start[sc] <= position
+    const uint32_t p0 = tb + 64u * tid;
+    const uint32_t rel = p0 > region_lo ? p0 - region_lo : 0u;
+    uint32_t a = 0, b = ps.nsc;                        // invariant: sc_start[a] <= rel (sc_start[0] = 0), and rel < sc_start[b] or b = nsc
+    while (b - a > 1) {
+      const uint32_t m = (a + b) >> 1;
+      if (sc_start[m] <= rel) a = m; else b = m;
     }
-    __syncthreads();
-    const uint32_t kept = tile_exclusive_scan(tcnt, tstart, wsum, NC, tid);
+    tile_sc[tid] = a;
+  }
+  uint32_t rank[P2_IPT], vmask[NV];
 #pragma unroll
-    for (int j = 0; j < NV; ++j)
+  for (int j = 0; j < NV; ++j) {
+    const uint32_t p = tb + 4u * ((uint32_t)j * SORT_THREADS + tid);
+    const uint32_t i4[4] = {q[j].x, q[j].y, q[j].z, q[j].w};
+    uint32_t m = 0, bin[4];
 #pragma unroll
-      for (int c = 0; c < 4; ++c)
-        if (vmask[j] & (1u << c)) {
-          const uint32_t dst = tstart[bin[4 * j + c]] + rank[4 * j + c];
-          st_item[dst] = item[4 * j + c];
-          st_bin[dst] = bin[4 * j + c];
+    for (int c = 0; c < 4; ++c) {
+      bin[c] = i4[c] >> (ib + 1);
+      m |= (FULL || (p + c >= lo && p + c < hi)) ? 1u << c : 0u;
+    }
+    vmask[j] = m;
+    lds_rank4<FULL>(tcnt, bin, m, &rank[4 * j]);
+  }
+  lds_barrier();
+  const uint32_t kept = tile_exclusive_scan(tcnt, tstart, wsum, NF, tid);
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const uint32_t p = tb + 4u * ((uint32_t)j * SORT_THREADS + tid);
+    const uint32_t i4[4] = {q[j].x, q[j].y, q[j].z, q[j].w};
+    uint32_t a = 0, nb = 0xffffffffu;
+    if (ps.nsc && (FULL || vmask[j])) {                // super-chunk of the vector's first position: the tile table, then a short walk
+      const uint32_t rel = (p > region_lo ? p - region_lo : 0u);
+      a = tile_sc[(p - tb) >> 6];
+      while (sc_start[a + 1] <= rel && a + 1 < ps.nsc) ++a;
+      nb = sc_start[a + 1];
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      if (FULL || (vmask[j] & (1u << c))) {
+        uint32_t pay = (i4[c] & imask) | (((i4[c] >> ib) & 1u) << 31);
+        if (ps.nsc) {
+          const uint32_t rel = p + c - region_lo;
+          while (nb <= rel && a + 1 < ps.nsc) { ++a; nb = sc_start[a + 1]; }   // almost never: runs are ~2 000 items long
+          pay |= a << ib;
         }
-    __syncthreads();
+        const uint32_t bin = i4[c] >> (ib + 1);
+        st_pay[dst_of(tstart, bin, rank[4 * j + c])] = pay;
+        st_bin[dst_of(tstart, bin, rank[4 * j + c])] = (uint16_t)bin;
+      }
+  }
+  if (COOP)      // reserve this tile's run in every non-empty bucket
+    for (uint32_t b = tid; b < NF; b += SORT_THREADS)
+      if (tcnt[b]) gcur[b] = atomicAdd(&gc[b], tcnt[b]);
+  lds_barrier();
+  if (FULL) {
+#pragma unroll 4
+    for (int k = 0; k < P2_IPT; ++k) {
+      const uint32_t e = (uint32_t)k * SORT_THREADS + tid, b = st_bin[e];
+      sorted[gcur[b] + (e - tstart[b])] = st_pay[e];
+    }
+  } else {
     for (uint32_t e = tid; e < kept; e += SORT_THREADS) {
       const uint32_t b = st_bin[e];
-      tmp[gcur[b] + (e - tstart[b])] = st_item[e];
+      sorted[gcur[b] + (e - tstart[b])] = st_pay[e];
     }
-    __syncthreads();
-    for (uint32_t b = tid; b < NC; b += SORT_THREADS) { gcur[b] += tcnt[b]; tcnt[b] = 0; }
-    __syncthreads();
   }
+  lds_barrier();
+  for (uint32_t b = tid; b < NF; b += SORT_THREADS) {
+    if (!COOP) gcur[b] += tcnt[b];
+    tcnt[b] = 0;
+  }
+  lds_barrier();
 }
 
 template <bool COOP>
@@ -804,7 +943,6 @@ __global__ __launch_bounds__(SORT_THREADS) void msm_part2_scatter_v2_kernel(cons
   extern __shared__ uint32_t sm[];
   __shared__ uint32_t sc_start[PS_MAX_SC + 2];
   __shared__ uint32_t tile_sc[P2_TILE / 64];                  // super-chunk of every 64th position of the current tile
-  constexpr int NV = P2_IPT / 4;
   uint32_t hb = blockIdx.x, w = blockIdx.y, sl = 0;
   const uint32_t tid = threadIdx.x;
   if (COOP) {
@@ -832,85 +970,25 @@ __global__ __launch_bounds__(SORT_THREADS) void msm_part2_scatter_v2_kernel(cons
     for (uint32_t sc = tid; sc <= ps.nsc + 1; sc += SORT_THREADS)
       sc_start[sc] = sc < ps.nsc ? ps.chist[(size_t)sc * ps.gpc * NC + hb] : (sc == ps.nsc ? region_n : 0xffffffffu);
   }
-  __syncthreads();
+  lds_barrier();
   if (COOP) {
     lo += sl * slice;
     hi = lo + slice < hi ? lo + slice : hi;
   }
   if (lo >= hi) return;
-  const uint32_t imask = (1u << ib) - 1u;
+  uint4 q[P2_IPT / 4], qn[P2_IPT / 4];
+  p2v2_load(tmp, lo & ~3u, lo, hi, tid, q);
   for (uint32_t tb = lo & ~3u; tb < hi; tb += P2_TILE) {   // tmp is 256-byte aligned: positions that are multiples of 4 are 16-byte addresses
-    uint4 q[NV];
+    const bool more = tb + P2_TILE < hi;
+    if (more) p2v2_load(tmp, tb + P2_TILE, lo, hi, tid, qn);     // the next tile's items travel while this one is ranked and staged
+    if (tb >= lo && tb + P2_TILE <= hi)
+      p2v2_tile<COOP, true>(q, sorted, tb, lo, hi, region_lo, ib, NF, ps, gcur, tcnt, tstart, wsum, st_pay, st_bin, sc_start, tile_sc, gc, tid);
+    else
+      p2v2_tile<COOP, false>(q, sorted, tb, lo, hi, region_lo, ib, NF, ps, gcur, tcnt, tstart, wsum, st_pay, st_bin, sc_start, tile_sc, gc, tid);
+    if (more) {
 #pragma unroll
-    for (int j = 0; j < NV; ++j) {
-      const uint32_t p = tb + 4u * ((uint32_t)j * SORT_THREADS + tid);
-      q[j] = *reinterpret_cast<const uint4*>(tmp + (p < hi ? p : (lo & ~3u)));
+      for (int j = 0; j < P2_IPT / 4; ++j) q[j] = qn[j];
     }
-    if (ps.nsc && tid < P2_TILE / 64) {                // while the loads are in flight: the largest sc with sc_start[sc] <= position
-      const uint32_t p0 = tb + 64u * tid;
-      const uint32_t rel = p0 > region_lo ? p0 - region_lo : 0u;
-      uint32_t a = 0, b = ps.nsc;                      // invariant: sc_start[a] <= rel (sc_start[0] = 0), and rel < sc_start[b] or b = nsc
-      while (b - a > 1) {
-        const uint32_t m = (a + b) >> 1;
-        if (sc_start[m] <= rel) a = m; else b = m;
-      }
-      tile_sc[tid] = a;
-    }
-    uint32_t bin[P2_IPT], rank[P2_IPT], vmask[NV];
-#pragma unroll
-    for (int j = 0; j < NV; ++j) {
-      const uint32_t p = tb + 4u * ((uint32_t)j * SORT_THREADS + tid);
-      const uint32_t i4[4] = {q[j].x, q[j].y, q[j].z, q[j].w};
-      uint32_t m = 0;
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        bin[4 * j + c] = i4[c] >> (ib + 1);
-        m |= (p + c >= lo && p + c < hi) ? 1u << c : 0u;
-      }
-      vmask[j] = m;
-      lds_rank4(tcnt, &bin[4 * j], m, &rank[4 * j]);
-    }
-    __syncthreads();
-    const uint32_t kept = tile_exclusive_scan(tcnt, tstart, wsum, NF, tid);
-#pragma unroll
-    for (int j = 0; j < NV; ++j) {
-      const uint32_t p = tb + 4u * ((uint32_t)j * SORT_THREADS + tid);
-      const uint32_t i4[4] = {q[j].x, q[j].y, q[j].z, q[j].w};
-      uint32_t a = 0, nb = 0xffffffffu;
-      if (ps.nsc && vmask[j]) {                        // super-chunk of the vector's first position: the tile table, then a short walk
-        const uint32_t rel = (p > region_lo ? p - region_lo : 0u);
-        a = tile_sc[(p - tb) >> 6];
-        while (sc_start[a + 1] <= rel && a + 1 < ps.nsc) ++a;
-        nb = sc_start[a + 1];
-      }
-#pragma unroll
-      for (int c = 0; c < 4; ++c)
-        if (vmask[j] & (1u << c)) {
-          uint32_t pay = (i4[c] & imask) | (((i4[c] >> ib) & 1u) << 31);
-          if (ps.nsc) {
-            const uint32_t rel = p + c - region_lo;
-            while (nb <= rel && a + 1 < ps.nsc) { ++a; nb = sc_start[a + 1]; }   // almost never: runs are ~2 000 items long
-            pay |= a << ib;
-          }
-          const uint32_t dst = tstart[bin[4 * j + c]] + rank[4 * j + c];
-          st_pay[dst] = pay;
-          st_bin[dst] = (uint16_t)bin[4 * j + c];
-        }
-    }
-    if (COOP)      // reserve this tile's run in every non-empty bucket
-      for (uint32_t b = tid; b < NF; b += SORT_THREADS)
-        if (tcnt[b]) gcur[b] = atomicAdd(&gc[b], tcnt[b]);
-    __syncthreads();
-    for (uint32_t e = tid; e < kept; e += SORT_THREADS) {
-      const uint32_t b = st_bin[e];
-      sorted[gcur[b] + (e - tstart[b])] = st_pay[e];
-    }
-    __syncthreads();
-    for (uint32_t b = tid; b < NF; b += SORT_THREADS) {
-      if (!COOP) gcur[b] += tcnt[b];
-      tcnt[b] = 0;
-    }
-    __syncthreads();
   }
 }
 
