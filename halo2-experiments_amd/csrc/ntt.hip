@@ -234,20 +234,20 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(const uint32_t* i
   // bit-reversed positions are multiples of 2^log_z, and DIT stages 0 .. log_z-1 pair each of them with
   // zeros only -- (a, 0) -> (a, a), no product -- so the value is stored to the 2^log_z positions of its
   // group at once and the rounds start at stage log_z.
-  for (uint32_t e = tid; e < (tile_elems >> pp.log_z); e += NTT_THREADS) {
-    uint32_t d, c;
-    uint64_t g;
+  // The usual tile (2^LOG_TILE elements, nothing skipped) is NTT_THREADS x 4: all four of a lane's elements are requested
+  // before the first is unpacked.  (As a plain loop the compiler waits for each 32-byte load before it issues the next: four
+  // serial HBM round trips per tile, hidden only by the other workgroup of the CU.)
+  auto where = [&](uint32_t e, uint32_t& d, uint32_t& c) -> uint64_t {
     if (!pp.last) {
       c = e & cmask;
       d = e >> log_c;
-      g = base + ((uint64_t)d << pp.log_stride) + c;
-    } else {
-      d = e & ((1u << s) - 1u);
-      c = e >> s;
-      g = (row_of(c) << s) + d;
+      return base + ((uint64_t)d << pp.log_stride) + c;
     }
-    const uint4* src = reinterpret_cast<const uint4*>(in + g * 8);
-    const uint4 lo = src[0], hi = src[1];
+    d = e & ((1u << s) - 1u);
+    c = e >> s;
+    return (row_of(c) << s) + d;
+  };
+  auto place = [&](uint64_t g, uint32_t d, uint32_t c, const uint4& lo, const uint4& hi) {
     const uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
     Fr x = fe_unpack<FrParams>(w);
     if (FUSED && pp.has_coset) {
@@ -264,6 +264,29 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(const uint32_t* i
       if (!(FUSED && pp.has_coset)) x = fe_reduce_small(x);   // raw 256-bit words: bring below 3r like a product
       const uint32_t p0 = bitrev(d, s);                        // low log_z bits are zero
       for (uint32_t t = 0; t < (1u << pp.log_z); ++t) lds_store<LOG_TILE>(lds, ((p0 + t) << log_c) + c, x);
+    }
+  };
+  const uint32_t n_load = tile_elems >> pp.log_z;
+  if (n_load == 4u * NTT_THREADS) {
+    uint32_t d[4], c[4];
+    uint64_t g[4];
+    uint4 lo[4], hi[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      g[k] = where(tid + (uint32_t)k * NTT_THREADS, d[k], c[k]);
+      const uint4* src = reinterpret_cast<const uint4*>(in + g[k] * 8);
+      lo[k] = src[0];
+      hi[k] = src[1];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) place(g[k], d[k], c[k], lo[k], hi[k]);
+  } else {
+    for (uint32_t e = tid; e < n_load; e += NTT_THREADS) {
+      uint32_t d, c;
+      const uint64_t g = where(e, d, c);
+      const uint4* src = reinterpret_cast<const uint4*>(in + g * 8);
+      const uint4 lo = src[0], hi = src[1];
+      place(g, d, c, lo, hi);
     }
   }
   __syncthreads();
@@ -287,12 +310,17 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(const uint32_t* i
   if (!pp.last) {
     const uint32_t shift_m = pp.log_n - (s + pp.log_stride);  // omega_m = omega_n^(2^shift_m)
     const uint32_t lbmask = (1u << pp.log_lb) - 1u;
+    // the twiddle of the NEXT element is requested before this one's product starts (a product is ~1 000 cycles: an L2 hit)
+    Fr tw_next = fe_zero<FrParams>();
+    if (pp.direct_tw && tid < tile_elems) tw_next = load_tw(tw_lo, (i0 + (tid & cmask)) * (tid >> log_c));
     for (uint32_t e = tid; e < tile_elems; e += NTT_THREADS) {
       const uint32_t c = e & cmask, k = e >> log_c;
       const Fr y0 = lds_load<LOG_TILE>(lds, e);
       Fr tw;
       if (pp.direct_tw) {
-        tw = load_tw(tw_lo, (i0 + c) * k);                      // omega_m^(i*k), i*k < m <= 2^16
+        tw = tw_next;                                           // omega_m^(i*k), i*k < m <= 2^16
+        const uint32_t en = e + NTT_THREADS;
+        if (en < tile_elems) tw_next = load_tw(tw_lo, (i0 + (en & cmask)) * (en >> log_c));
       } else {
         const uint64_t ex = ((uint64_t)(i0 + c) * k) << shift_m;  // < n
         const uint32_t elo = (uint32_t)ex & lbmask, ehi = (uint32_t)(ex >> pp.log_lb);
