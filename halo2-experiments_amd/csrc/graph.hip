@@ -78,12 +78,17 @@ __device__ __forceinline__ Fr ge_from_internal(const uint32_t* __restrict__ p) {
 }
 
 // The call's column table and per-call constants (2.6 KiB) travel through a DEVICE buffer of the stream's AuxSlot,
-// filled by a stream-ordered copy ahead of the launch.  Rounds 1-2 passed the struct by value: a variant with a
-// byte table in it aborted at run time on ROCm 7.2 and the cause was never pinned down (by-value arguments of this
-// size sit near the kernel-argument segment's limit and dynamic indexing into them is at the compiler's mercy), so
-// the kernel no longer depends on it: it takes one pointer, every table access is a wave-uniform (scalar) global
-// load, and the argument block is 72 bytes whatever the program's shape.  tests/test_evaluation.py runs 256 columns,
-// short-period columns and 16 per-call constants through it.
+// filled by a stream-ordered copy ahead of the launch.  Rounds 1-2 passed the struct by value, and a variant with a
+// BYTE table in it (the columns' periods) aborted at run time.  Cause (round 4, tools/ubench/kernarg_byval.hip,
+// profiles/r04_kernarg_byval.txt): nothing to do with the argument's size (3 176 bytes of kernarg, limit 4 096; no
+// scratch) -- a dynamically indexed table of 32- or 64-bit entries in a by-value argument is read with SCALAR loads from
+// the kernarg segment (s_load_dword s, s[0:1], s_off), which work, but a table of BYTES cannot be (s_load has no
+// sub-dword form), so the compiler emits a VECTOR load addressed through the kernarg pointer (global_load_ubyte v, v,
+// s[0:1] offset:...), and on this stack that load faults: the same stand-alone kernel runs without the byte table and
+// dies with it (GPU fault, process killed).  A divergent index into a word table would take the same vector path.  The
+// kernel therefore takes ONE pointer to a device copy: every table access is an ordinary global load, and the argument
+// block is 72 bytes whatever the program's shape.  tests/test_evaluation.py runs 256 columns, short-period columns
+// and 16 per-call constants through it.
 constexpr uint32_t GE_MAX_COLUMNS = 256;
 constexpr uint32_t GE_MAX_DYN = 16;
 struct GraphColumns {

@@ -232,8 +232,8 @@ fn main() {
 # Smallest sizes the glue sends to the GPU: below them the CPU body of the patched functions is at least as fast as the
 # host-pointer round trip.  MEASURED (tools/crossover.py on the MI355X box against oracle/cpu_ref.c on its 16 granted cores;
 # table in DESIGN.md section 8 and profiles/r04_crossover.json) -- regenerate rust/ after changing them.
-GPU_MIN_LOG_N_MSM = 10
-GPU_MIN_LOG_N_NTT = 10
+GPU_MIN_LOG_N_MSM = 8       # 0.30 ms against 1.4 ms (16 threads) / 5.4 ms (1 thread) at 2^8, the smallest size measured
+GPU_MIN_LOG_N_NTT = 10      # 0.057 ms against 0.111 ms on one thread at 2^10; 2^9 is a tie, 2^8 loses
 
 MI355X_RS = '''//! mi355x.rs -- glue between halo2_proofs::arithmetic and libhalo2_mi355x.so (added by rust/halo2_proofs.patch).
 //! GENERATED by tools/gen_rust_shim.py (a fixed template: the C entry points it calls are checked against the header
