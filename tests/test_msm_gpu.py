@@ -795,6 +795,37 @@ def test_randomized_table_sized_sweep(cref):
         _lib.check(lib.hm_set_fixed_base_threshold(17))
 
 
+@pytest.mark.parametrize("n", [(1 << 19) + 1, (1 << 19) + 3, (1 << 20) - 1])
+def test_vector_load_sort_at_odd_sizes_and_with_zero_digits(cref, n):
+    """The round-4 sort scatters read four items per 16-byte load: a window's digit array then starts at an address that is
+    16-byte aligned only when n is a multiple of four (plain layout: window w starts at w * n words), tiles begin up to three
+    positions before their chunk, and zero digits leave holes in a lane's four items.  Odd n at the general pipeline's
+    sizes, both layouts, uniform scalars and a column that is half zeros with small values in between."""
+    import torch
+    lib = _lib.load()
+    bases = h.g1_fixed_base_mul(rand_fr_gpu(n, 9800 + (n & 7)), cref.g1_generator())
+    bh = bases.cpu().numpy().view(np.uint64)
+    uni = rand_fr_gpu(n, 9810)
+    holes = rand_fr_gpu(n, 9811)
+    holes[::2] = 0                                                     # every other scalar zero: every 16-byte load has two holes
+    holes[1::4, 1:] = 0                                                # a quarter small (most windows zero)
+    holes[1::4, 0] &= 0xFFFFF
+    holes = _raw_to_mont(holes)
+    want = [cref.g1_to_affine(cref.best_multiexp(c.cpu().numpy().view(np.uint64), bh, 8))[0] for c in (uni, holes)]
+    try:
+        for threshold in (17, 0):                                      # the table's single bucket set, then the plain layout's 15
+            _lib.check(lib.hm_set_fixed_base_threshold(threshold))
+            hd = h.register_bases(bases)
+            try:
+                assert (h.bases_info(hd)["table_windows"] != 0) == (threshold != 0)
+                for c, w in zip((uni, holes), want):
+                    assert g1_equal(h.best_multiexp(c, hd), w), (n, threshold)
+            finally:
+                h.release_bases(hd)
+    finally:
+        _lib.check(lib.hm_set_fixed_base_threshold(17))
+
+
 def test_go_ethereum_precompile_vectors_through_the_hip_path(pyref):
     """The third-party known answers of tests/test_oracle.py (go-ethereum's EIP-196 precompile test data, "chfast1..3")
     computed by the HIP path itself: [k]P as an MSM of one point, P + Q as an MSM of two points with scalars one, and all
