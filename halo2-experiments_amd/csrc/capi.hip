@@ -491,11 +491,15 @@ static int submit_chain(DeviceCtx* ctx, uint64_t handle, size_t offset, const vo
     if (all_busy) *all_busy = true;             // the batch call retries: another thread's tickets hold the slots
     return hm_fail(HM_ERR_BAD_ARG, std::string(who) + ": every slot is in flight; hm_msm_wait one first");
   }
-  const uint32_t pc = (use_table && group == 1 && offset == 0 && n == b->n) ? b->pc_c : 0u;
+  const uint32_t pc = (use_table && offset == 0 && n == b->n) ? b->pc_c : 0u;
   int rc;
   if (group == 1 && live_rows == 0) {
     ctx->msm_slots[slot].group = 1;
     rc = msm_enqueue(*ctx, slot, (const uint32_t*)d_scalars_list[0], b->d_xy + offset * 16, b->d_inf + offset, n, pc, (hipStream_t)stream);
+  } else if (use_table && live_rows == 0) {     // dense columns of a phase on the table: one chain of the general pipeline for all of them
+    if (pc == 0 || group > msm_table_group_max(n, pc)) return hm_fail(HM_ERR_INTERNAL, std::string(who) + ": a dense group needs the set's table");
+    rc = msm_enqueue_table_group(*ctx, slot, reinterpret_cast<const uint32_t* const*>(d_scalars_list), group, b->d_xy, b->d_inf, n, pc,
+                                 (hipStream_t)stream);
   } else {                                      // the five-launch plan, sized for the rows known to survive (a lone sparse column too)
     rc = msm_enqueue_group(*ctx, slot, reinterpret_cast<const uint32_t* const*>(d_scalars_list), group, b->d_xy + offset * 16,
                            b->d_inf + offset, n, (hipStream_t)stream, live_rows);
@@ -568,6 +572,7 @@ static int msm_batch_impl(DeviceCtx* ctx, uint64_t handle, size_t offset, const 
   {
     bool small_plan = false;
     const uint8_t* d_inf = nullptr;
+    uint32_t dense_group = 1;                       // dense columns one chain of the general pipeline may carry (a table set, whole-set MSMs)
     {
       std::lock_guard<std::mutex> lk(ctx->mu);
       BasesEntry* b = find_bases(*ctx, handle);
@@ -577,6 +582,7 @@ static int msm_batch_impl(DeviceCtx* ctx, uint64_t handle, size_t offset, const 
       // sparse columns go there, dense ones take the table's shared bucket set through the general pipeline
       small_plan = msm_group_applies(n, 0);
       d_inf = b->d_inf + offset;
+      if (offset == 0 && n == b->n && b->pc_c) dense_group = msm_table_group_max(n, b->pc_c);
     }
     static const size_t group_max_n = [] { const char* v = std::getenv("HALO2_MI355X_GROUP_MAX_LOG"); return (size_t)1 << (v && *v ? std::atoi(v) : 16); }();
     static const bool group_sparse = [] { const char* v = std::getenv("HALO2_MI355X_GROUP_SPARSE"); return !(v && *v == '0'); }();
@@ -621,7 +627,26 @@ static int msm_batch_impl(DeviceCtx* ctx, uint64_t handle, size_t offset, const 
           live[i] = seen == 0 || hits != 0 ? total_blocks : 0;
         }
       }
-      std::vector<uint32_t> pending, plan;
+      // Dense columns on a table set: up to `dense_group` of them share one chain of the general pipeline (every element a
+      // bucket set of the same launches): the sort and the two-launch reduction then run at the chip's throughput instead
+      // of as 26 small launches per commitment, and K3 is one launch over all of them.  How many per chain: as many chains
+      // as keep three in flight, none longer than the plan allows.
+      uint32_t n_dense = 0;
+      for (size_t i = 0; i < count; ++i) n_dense += (uint64_t)live[i] * 16 > total_blocks ? 1u : 0u;
+      uint32_t dense_per_chain = 1;
+      if (dense_group > 1 && n_dense > 1) {
+        const uint32_t chains = std::max<uint32_t>((n_dense + dense_group - 1) / dense_group, std::min<uint32_t>(3u, n_dense / 2));
+        dense_per_chain = (n_dense + chains - 1) / chains;
+      }
+      std::vector<uint32_t> pending, plan, dense_pending;
+      auto flush_dense = [&]() {
+        if (dense_pending.empty()) return;
+        first.push_back((uint32_t)plan.size());
+        chain_plain.push_back(0);
+        chain_live.resize(first.size(), 0);
+        plan.insert(plan.end(), dense_pending.begin(), dense_pending.end());
+        dense_pending.clear();
+      };
       auto flush = [&]() {
         if (pending.empty()) return;
         first.push_back((uint32_t)plan.size());
@@ -638,12 +663,12 @@ static int msm_batch_impl(DeviceCtx* ctx, uint64_t handle, size_t offset, const 
         if ((uint64_t)live[i] * 16 <= total_blocks) {           // sparse: joins the pending group
           pending.push_back((uint32_t)i);
           if (pending.size() == (size_t)HM_MSM_GROUP) flush();
-        } else {                                                 // dense: a chain of its own (on the table when the set has one)
-          first.push_back((uint32_t)plan.size());
-          chain_plain.push_back(0);
-          plan.push_back((uint32_t)i);
+        } else {                                                 // dense: on the table when the set has one, several per chain
+          dense_pending.push_back((uint32_t)i);
+          if (dense_pending.size() >= dense_per_chain) flush_dense();
         }
       }
+      flush_dense();
       flush();
       order = plan;
     } else {

@@ -316,6 +316,10 @@ int msm_convert_bases(const uint32_t* d_bases_ext, uint32_t* d_xy, uint8_t* d_in
 // out_windows: host buffer of W x 12 u64 external Jacobian + flags
 int msm_enqueue(DeviceCtx& ctx, int slot, const uint32_t* d_scalars_ext, const uint32_t* d_xy, const uint8_t* d_inf, size_t n,
                 uint32_t precomp_c, hipStream_t stream);
+// `group` dense MSMs over one fixed-base table through one chain of the general pipeline (msm.hip); 1 when it does not apply
+uint32_t msm_table_group_max(size_t n, uint32_t precomp_c);
+int msm_enqueue_table_group(DeviceCtx& ctx, int slot, const uint32_t* const* d_scalars_list, uint32_t group, const uint32_t* d_xy,
+                            const uint8_t* d_inf, size_t n, uint32_t precomp_c, hipStream_t stream);
 int msm_finish(DeviceCtx& ctx, int slot, uint64_t out_jac_ext[12], int* out_is_identity);
 // the two halves of msm_finish: the blocking part touches only the slot (callable without ctx.mu while the slot is
 // busy), the bookkeeping part runs under ctx.mu

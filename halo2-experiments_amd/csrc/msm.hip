@@ -89,10 +89,18 @@ __device__ __forceinline__ uint32_t effective_task_len(const uint32_t* __restric
 }
 
 // Windows [0, n_wide) are c bits wide, the others c - 1 (n_wide = W: every window c bits, the top one implicitly shorter).
-__global__ void msm_digits_kernel(const uint32_t* __restrict__ scalars, const uint8_t* __restrict__ inf,
+// A GROUP of MSMs over the same points (blockIdx.y = the element): element e reads scalars list.s[e] and writes its own
+// W x n digit array behind the previous element's (pointer / dword tables of a by-value argument are read with scalar
+// loads: graph.hip's note on what must not travel by value does not apply).
+struct MsmGroupScalars {
+  const uint32_t* s[HM_MSM_GROUP];
+};
+__global__ void msm_digits_kernel(MsmGroupScalars list, const uint8_t* __restrict__ inf,
                                   int32_t* __restrict__ digits, size_t n, uint32_t c, uint32_t W, uint32_t n_wide) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  const uint32_t* __restrict__ scalars = list.s[blockIdx.y];
+  digits += (size_t)blockIdx.y * W * n;
   const uint4* q = reinterpret_cast<const uint4*>(scalars + i * 8);
   const uint4 lo = q[0], hi = q[1];
   const uint32_t w_in[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
@@ -496,7 +504,7 @@ static_assert(((size_t)3 * 2048 + 32 + SORT_THREADS * P1_BIG_IPT) * 4 + (size_t)
 // finds its piece by a binary search.  Half the bytes of the 64-bit items this replaces, at every level of the sort.
 constexpr uint32_t PS_MAX_SC = 1024;
 struct Positional {
-  const uint32_t* chist;    // scanned per-chunk offsets of window 0 (a shared bucket set has one "window"): [g][NC]
+  const uint32_t* chist;    // scanned per-chunk offsets: [set][g][NC] (a shared bucket set is one "window"; a group of MSMs has one set each)
   uint32_t G, gpc, nsc;     // chunks, chunks per super-chunk, super-chunks (0: items carry their whole index)
 };
 template <class ITEM, bool COOP = false>
@@ -536,7 +544,7 @@ __global__ __launch_bounds__(SORT_THREADS) void msm_part2_scatter_tiled_kernel(c
   const uint32_t region_lo = lo;
   if (ps.nsc) {                                        // region-relative start of every super-chunk's runs
     for (uint32_t sc = tid; sc <= ps.nsc; sc += SORT_THREADS)
-      sc_start[sc] = sc < ps.nsc ? ps.chist[(size_t)sc * ps.gpc * NC + hb] : hi - lo;
+      sc_start[sc] = sc < ps.nsc ? ps.chist[((size_t)w * ps.G + (size_t)sc * ps.gpc) * NC + hb] : hi - lo;
     __syncthreads();
   }
   if (COOP) {
@@ -968,7 +976,7 @@ __global__ __launch_bounds__(SORT_THREADS) void msm_part2_scatter_v2_kernel(cons
   const uint32_t region_lo = lo, region_n = hi - lo;
   if (ps.nsc) {                                        // region-relative start of every super-chunk's runs; a sentinel behind them
     for (uint32_t sc = tid; sc <= ps.nsc + 1; sc += SORT_THREADS)
-      sc_start[sc] = sc < ps.nsc ? ps.chist[(size_t)sc * ps.gpc * NC + hb] : (sc == ps.nsc ? region_n : 0xffffffffu);
+      sc_start[sc] = sc < ps.nsc ? ps.chist[((size_t)w * ps.G + (size_t)sc * ps.gpc) * NC + hb] : (sc == ps.nsc ? region_n : 0xffffffffu);
   }
   lds_barrier();
   if (COOP) {
@@ -1405,10 +1413,13 @@ __global__ __launch_bounds__(WIN_THREADS) void msm_sum_points_kernel(const uint3
 // it.  The H + M sums are then split by weight BIT: S_p = sum of the sums whose weight has bit p, one workgroup per
 // bit, and the host fold, which doubles its way down 255 bits anyway, reads the c - 1 records S_p as windows of one bit.
 // Launch 1: workgroup `blk` < H sums row hi = blk, the others column lo = blk - H.
+// blockIdx.y = the bucket set (a group of MSMs over one table: one set each, NB + 1 bucket records and H + M sums apart)
 __global__ __launch_bounds__(WIN_THREADS) void msm_reduce_rowcol_kernel(const uint32_t* __restrict__ bucket, uint32_t* __restrict__ sums,
                                                                         uint32_t m, uint32_t h) {
   __shared__ uint32_t tree[WIN_THREADS * PT_WORDS];
   const uint32_t M = 1u << m, H = 1u << h, blk = blockIdx.x, t = threadIdx.x;
+  bucket += (size_t)blockIdx.y * ((size_t)M * H + 1) * PT_WORDS;
+  sums += (size_t)blockIdx.y * ((size_t)M + H) * PT_WORDS;
   const bool row = blk < H;
   const uint32_t count = row ? M : H;                                  // elements of this sum
   const uint32_t first = row ? blk * M : blk - H, stride = row ? 1u : M;
@@ -1429,10 +1440,15 @@ __global__ __launch_bounds__(WIN_THREADS) void msm_reduce_rowcol_kernel(const ui
 
 // Launch 2: workgroup p sums the rows / columns whose weight has bit p and writes the record the host fold reads.
 // Columns: weight lo (bits 0 .. m - 1).  Rows: weight M * hi + 1 (bit 0, and bits m .. m + h - 1).
+// blockIdx.y = the bucket set; its records go res_stride words behind the previous set's, each block led by a copy of the
+// chain's four totals words (what the host reads per element: msm_finish_wait_fold)
 __global__ __launch_bounds__(WIN_THREADS) void msm_reduce_bits_kernel(const uint32_t* __restrict__ sums, uint32_t m, uint32_t h,
-                                                                      uint32_t* __restrict__ winres) {
+                                                                      uint32_t* __restrict__ winres, uint32_t res_stride) {
   __shared__ uint32_t tree[WIN_THREADS * PT_WORDS];
   const uint32_t M = 1u << m, H = 1u << h, p = blockIdx.x, t = threadIdx.x;
+  sums += (size_t)blockIdx.y * ((size_t)M + H) * PT_WORDS;
+  if (blockIdx.y != 0 && p == 0 && t < 4) (winres - 4)[(size_t)blockIdx.y * res_stride + t] = (winres - 4)[t];
+  winres += (size_t)blockIdx.y * res_stride;
   const uint32_t* rows = sums;
   const uint32_t* cols = sums + (size_t)H * PT_WORDS;
   G1Jac acc = g1_identity();
@@ -1873,8 +1889,9 @@ static int launch_sort_scatter(const int32_t* d_digits, const uint32_t* d_cstart
 
 int msm_launch_digits(const uint32_t* d_scalars_ext, const uint8_t* d_inf, int32_t* d_digits, size_t n, uint32_t c, uint32_t W,
                       hipStream_t stream) {
-  hipLaunchKernelGGL(msm_digits_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, stream, d_scalars_ext, d_inf, d_digits, n, c,
-                     W, W);
+  MsmGroupScalars one;
+  for (auto& p : one.s) p = d_scalars_ext;
+  hipLaunchKernelGGL(msm_digits_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, stream, one, d_inf, d_digits, n, c, W, W);
   HM_HIP_CHECK(hipGetLastError());
   return HM_OK;
 }
@@ -1892,11 +1909,15 @@ int msm_slot_prepare(MsmSlot& sl) {
 // the device.  d_xy: n points (plain) or the precomputed table of precomp_W * n points
 // (precomp_c != 0).  msm_finish() later waits for the slot, folds the window sums on the host and
 // fills the statistics.
-static int msm_issue(DeviceCtx& ctx, int slot, const uint32_t* d_scalars_ext, const uint32_t* d_xy, const uint8_t* d_inf, size_t n,
-                     uint32_t precomp_c, hipStream_t stream) {
+// `group` MSMs over the same points in ONE launch chain (group > 1: only on a fixed-base table set below the positional
+// plan's sizes -- msm_table_group_applies -- where every element is one bucket set of the same sort and the same K3 launch).
+static int msm_issue(DeviceCtx& ctx, int slot, const uint32_t* const* d_scalars_list, uint32_t group, const uint32_t* d_xy,
+                     const uint8_t* d_inf, size_t n, uint32_t precomp_c, hipStream_t stream) {
   MsmSlot& sl = ctx.msm_slots[slot];
+  const uint32_t* d_scalars_ext = d_scalars_list[0];
   if (n == 0) return HM_OK;
   if (n >= (1ull << 31)) return hm_fail(HM_ERR_BAD_ARG, "msm: n must be < 2^31");
+  if (group == 0 || group > (uint32_t)HM_MSM_GROUP) return hm_fail(HM_ERR_INTERNAL, "msm: group size out of range");
   // ---- plan ---------------------------------------------------------------------------------
   const bool single_set = precomp_c != 0;     // all windows accumulate into ONE bucket set
   const int window_override = g_window_override.load(std::memory_order_relaxed);
@@ -1922,12 +1943,16 @@ static int msm_issue(DeviceCtx& ctx, int slot, const uint32_t* d_scalars_ext, co
     c = (uint32_t)ci;
   }
   if (c < 2 || c > 24) return hm_fail(HM_ERR_BAD_ARG, "msm: window size out of range");
-  if (msm_small_applies(n, c, single_set)) return msm_issue_small(ctx, slot, &d_scalars_ext, 1, d_xy, d_inf, n, c, stream);
+  if (msm_small_applies(n, c, single_set)) {
+    if (group != 1) return hm_fail(HM_ERR_INTERNAL, "msm: a table group reached the five-launch plan");
+    return msm_issue_small(ctx, slot, &d_scalars_ext, 1, d_xy, d_inf, n, c, stream);
+  }
+  if (group > 1 && !single_set) return hm_fail(HM_ERR_INTERNAL, "msm: a group needs the fixed-base table's shared bucket set");
   const uint32_t W = (255 + c - 1) / c;
-  const uint32_t SW = single_set ? 1u : W;                 // bucket sets ("sort windows")
+  const uint32_t SW = single_set ? group : W;              // bucket sets ("sort windows"): one per MSM on a table, one per window else
   const size_t sn = single_set ? n * W : n;                // items per bucket set
   const uint32_t NB = 1u << (c - 1), NBP = NB + 1, NBT = SW * NBP;
-  const uint64_t pairs_max = (uint64_t)n * W;
+  const uint64_t pairs_max = (uint64_t)n * W * group;      // of the whole chain
   if (pairs_max >= (1ull << 31)) return hm_fail(HM_ERR_BAD_ARG, "msm: n * windows must be < 2^31");
   double mean = (double)sn / (double)NB;
   if (single_set) {
@@ -1980,7 +2005,9 @@ static int msm_issue(DeviceCtx& ctx, int slot, const uint32_t* d_scalars_ext, co
   static const bool k4_chain_only = [] { const char* v = std::getenv("HALO2_MI355X_K4_CHAIN"); return v && *v == '1'; }();   // A/B
   const bool k4_2d = single_set && NB >= 16 && !k4_chain_only;
   const uint32_t k4_m = (c - 1 + 1) / 2, k4_h = (c - 1) - k4_m;        // M = 2^m columns, H = 2^h rows, M * H = NB
-  const uint32_t RW = k4_2d ? c - 1 : SW;                               // records the host fold reads
+  if (group > 1 && !k4_2d) return hm_fail(HM_ERR_INTERNAL, "msm: a table group needs the two-launch bucket reduction");
+  const uint32_t RW = k4_2d ? c - 1 : SW;                               // records the host fold reads (per bucket set of a table)
+  const uint32_t res_stride = 4 + RW * 32;                              // words per element of a group: the totals, then its records
   // sort plan: item = [fine bucket bits | sign | item index]
   uint32_t ib = ilog2(sn) + ((sn & (sn - 1)) ? 1u : 0u);
   if (ib == 0) ib = 1;
@@ -2025,7 +2052,7 @@ static int msm_issue(DeviceCtx& ctx, int slot, const uint32_t* d_scalars_ext, co
   auto align = [](size_t v) { return (v + 255) & ~(size_t)255; };
   size_t off = 0;
   auto carve = [&](size_t bytes) { size_t o = off; off += align(bytes); return o; };
-  const size_t o_digits = carve((size_t)W * n * 4);
+  const size_t o_digits = carve((size_t)W * n * 4 * group);
   const size_t o_chist = carve((size_t)SW * G * NC * 4);
   const size_t o_ctot = carve((size_t)SW * NC * 4);
   const size_t o_cstart = carve(((size_t)SW * NC + 1) * 4);
@@ -2040,9 +2067,9 @@ static int msm_issue(DeviceCtx& ctx, int slot, const uint32_t* d_scalars_ext, co
   const size_t o_tkeys = carve(2 * TASK_KEYS * 4);
   const size_t o_partial = carve(T_max * PT_WORDS * 4);
   const size_t o_bucket = carve((size_t)NBT * PT_WORDS * 4);
-  const size_t o_seg = carve(k4_2d ? (((size_t)1 << k4_m) + ((size_t)1 << k4_h)) * PT_WORDS * 4 : (size_t)SW * nseg * PT_WORDS * 4);
+  const size_t o_seg = carve(k4_2d ? (((size_t)1 << k4_m) + ((size_t)1 << k4_h)) * PT_WORDS * 4 * SW : (size_t)SW * nseg * PT_WORDS * 4);
   const size_t o_seg2 = carve(((size_t)SW * (nseg / SUM_SPAN + 1)) * PT_WORDS * 4);
-  const size_t o_res = carve((4 + (size_t)RW * 32) * 4);   // results: 4 totals words, then the window sums (one D2H copy)
+  const size_t o_res = carve((size_t)(single_set ? group : 1u) * res_stride * 4);   // per element: 4 totals words, then its records (one D2H copy)
   const size_t o_big = carve(((size_t)NBT + 4) * 4);
   const size_t o_slices = carve((T_max / FINALIZE_SLICE + T_max / (FINALIZE_SERIAL + 1) + 2) * 8);
   // cooperative sort of oversized regions (hot buckets): split anything above 4x the mean region
@@ -2134,7 +2161,8 @@ static int msm_issue(DeviceCtx& ctx, int slot, const uint32_t* d_scalars_ext, co
   sl.W = W;
   sl.balanced = k4_2d;                            // ... which weigh one bit each
   if (k4_2d) std::memset(sl.win_bits, 1, RW);
-  sl.group = 1;
+  sl.group = group;
+  sl.res_stride = res_stride;
   sl.live_ptr = nullptr;                          // the general pipeline writes all over the workspace
   sl.phase_timed = msm_phase_timing(false);
   const bool pt = sl.phase_timed;
@@ -2150,8 +2178,12 @@ static int msm_issue(DeviceCtx& ctx, int slot, const uint32_t* d_scalars_ext, co
     balanced_windows(W, &wide, &n_wide);
     if (wide != c) return hm_fail(HM_ERR_INTERNAL, "msm: the base set's table was built for another window split");
   }
-  hipLaunchKernelGGL(msm_digits_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, stream, d_scalars_ext, d_inf,
-                     d_digits, n, c, W, n_wide);
+  {
+    MsmGroupScalars list;
+    for (uint32_t e = 0; e < (uint32_t)HM_MSM_GROUP; ++e) list.s[e] = d_scalars_list[e < group ? e : 0];
+    hipLaunchKernelGGL(msm_digits_kernel, dim3((uint32_t)((n + 255) / 256), group), dim3(256), 0, stream, list, d_inf, d_digits, n, c, W,
+                       n_wide);
+  }
   HM_HIP_CHECK(hipGetLastError());
   if (pt) HM_HIP_CHECK(hipEventRecord(ev[1], stream));
 
@@ -2240,9 +2272,10 @@ static int msm_issue(DeviceCtx& ctx, int slot, const uint32_t* d_scalars_ext, co
 
   // ---- K4 ------------------------------------------------------------------------------------
   if (k4_2d) {
-    hipLaunchKernelGGL(msm_reduce_rowcol_kernel, dim3((1u << k4_m) + (1u << k4_h)), dim3(WIN_THREADS), 0, stream,
+    hipLaunchKernelGGL(msm_reduce_rowcol_kernel, dim3((1u << k4_m) + (1u << k4_h), SW), dim3(WIN_THREADS), 0, stream,
                        (const uint32_t*)d_bucket, d_seg, k4_m, k4_h);
-    hipLaunchKernelGGL(msm_reduce_bits_kernel, dim3(RW), dim3(WIN_THREADS), 0, stream, (const uint32_t*)d_seg, k4_m, k4_h, d_win);
+    hipLaunchKernelGGL(msm_reduce_bits_kernel, dim3(RW, SW), dim3(WIN_THREADS), 0, stream, (const uint32_t*)d_seg, k4_m, k4_h, d_win,
+                       res_stride);
     HM_HIP_CHECK(hipGetLastError());
   } else {
   hipLaunchKernelGGL(msm_reduce_segments_kernel, dim3((SW * nseg + ACC_THREADS - 1) / ACC_THREADS), dim3(ACC_THREADS), 0,
@@ -2266,7 +2299,7 @@ static int msm_issue(DeviceCtx& ctx, int slot, const uint32_t* d_scalars_ext, co
   }
   if (RW > 128) return hm_fail(HM_ERR_INTERNAL, "msm: more than 128 windows");
   // pinned landing zone, so that this copy (and therefore msm_enqueue) does not wait for the device
-  HM_HIP_CHECK(hipMemcpyAsync(sl.totals(), d_tot, (4 + (size_t)RW * 32) * 4, hipMemcpyDeviceToHost, stream));
+  HM_HIP_CHECK(hipMemcpyAsync(sl.totals(), d_tot, (size_t)(single_set ? group : 1u) * res_stride * 4, hipMemcpyDeviceToHost, stream));
   HM_HIP_CHECK(hipEventRecord(ev[4], stream));
   return HM_OK;
 }
@@ -2276,8 +2309,38 @@ int msm_enqueue(DeviceCtx& ctx, int slot, const uint32_t* d_scalars_ext, const u
   MsmSlot& sl = ctx.msm_slots[slot];
   sl.n = n;
   sl.stream = stream;
+  sl.group = 1;
   if (n == 0) return HM_OK;
-  return msm_issue(ctx, slot, d_scalars_ext, d_xy, d_inf, n, precomp_c, stream);
+  return msm_issue(ctx, slot, &d_scalars_ext, 1, d_xy, d_inf, n, precomp_c, stream);
+}
+
+// Several DENSE commitments over one fixed-base table in one chain of the general pipeline: every element is a bucket set
+// of the same sort launches, the same K3 launch and the same two reduction launches (HALO2_MI355X_GROUP_DENSE: how many,
+// default 8; 1 = a chain each).  Applies where a single such MSM runs the general pipeline on the table (not the five-launch
+// plan) and the whole chain's (point, bucket) pairs stay below 2^31.
+uint32_t msm_table_group_max(size_t n, uint32_t precomp_c) {
+  static const uint32_t want = [] {
+    const char* v = std::getenv("HALO2_MI355X_GROUP_DENSE");
+    const int g = v && *v ? std::atoi(v) : 8;
+    return (uint32_t)(g < 1 ? 1 : g > HM_MSM_GROUP ? HM_MSM_GROUP : g);
+  }();
+  static const bool k4_chain_only = [] { const char* v = std::getenv("HALO2_MI355X_K4_CHAIN"); return v && *v == '1'; }();
+  if (precomp_c < 6 || n == 0 || k4_chain_only || msm_small_applies(n, precomp_c, true)) return 1;
+  const uint64_t per = (uint64_t)n * ((255 + precomp_c - 1) / precomp_c);
+  uint32_t g = want;
+  while (g > 1 && per * g >= (1ull << 31)) --g;
+  while (g > 1 && per * g * 4 > ((uint64_t)3 << 30)) --g;       // keep a chain's item arrays below 3 GiB each
+  return g;
+}
+int msm_enqueue_table_group(DeviceCtx& ctx, int slot, const uint32_t* const* d_scalars_list, uint32_t group, const uint32_t* d_xy,
+                            const uint8_t* d_inf, size_t n, uint32_t precomp_c, hipStream_t stream) {
+  MsmSlot& sl = ctx.msm_slots[slot];
+  if (group == 0 || group > msm_table_group_max(n, precomp_c)) return hm_fail(HM_ERR_INTERNAL, "msm: table group larger than the plan allows");
+  sl.n = n;
+  sl.stream = stream;
+  sl.group = 1;
+  if (n == 0) return HM_OK;
+  return msm_issue(ctx, slot, d_scalars_list, group, d_xy, d_inf, n, precomp_c, stream);
 }
 
 // The window plan of the five-launch chain for n points, or 0 when it does not apply (n >= 2^19, a precomputed set,

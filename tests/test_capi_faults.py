@@ -180,17 +180,36 @@ def test_faults_in_the_batch_waiter(fi, cref):
             assert np.array_equal(got, want)
     finally:
         assert fi.hm_release_bases(hd) == 0
-    # the same with the waiters RUNNING: 12 dense columns of 2^17 are 12 chains on 8 lanes, the waiters start at the ninth
+    # the same with the waiters RUNNING: 12 dense columns of 2^17 against a SLICE of the set (offset 1: no table, so every
+    # column keeps a chain of its own) are 12 chains on 8 lanes, the waiters start at the ninth
     n, count = 1 << 17, 12
-    b = _fi_bases(fi, n, 9302, cref)
-    assert fi.hm_register_bases(_u64(b), n, ctypes.byref(hd)) == 0
+    b = _fi_bases(fi, n + 1, 9302, cref)
+    assert fi.hm_register_bases(_u64(b), n + 1, ctypes.byref(hd)) == 0
     try:
         cols = [_rand_fr(n, 9340 + i).cpu().numpy().view(np.uint64).copy() for i in range(count)]
         ptrs = (ctypes.c_void_p * count)(*[c.ctypes.data for c in cols])
         want, got = np.zeros((count, 12), dtype=np.uint64), np.zeros((count, 12), dtype=np.uint64)
-        assert fi.hm_msm_batch_bn256_g1_h(hd, 0, ptrs, n, count, _u64(want)) == 0
-        assert np.array_equal(want[11][:8], cref.g1_to_affine(cref.best_multiexp(cols[11], b, 8))[0])
+        assert fi.hm_msm_batch_bn256_g1_h(hd, 1, ptrs, n, count, _u64(want)) == 0
+        assert np.array_equal(want[11][:8], cref.g1_to_affine(cref.best_multiexp(cols[11], b[1:], 8))[0])
         fi.hm_test_arm_fault(b"batch_submit", 10)
+        assert fi.hm_msm_batch_bn256_g1_h(hd, 1, ptrs, n, count, _u64(got)) < 0
+        fi.hm_test_arm_fault(None, 0)
+        assert fi.hm_msm_batch_bn256_g1_h(hd, 1, ptrs, n, count, _u64(got)) == 0
+        assert np.array_equal(got, want)
+        # ... and on the whole set: the dense columns share chains of the general pipeline on the table (three chains of four):
+        # a throw before the third one leaves two grouped chains in flight
+        whole = np.zeros((count, 12), dtype=np.uint64)
+        assert fi.hm_msm_batch_bn256_g1_h(hd, 0, ptrs, n + 1, 0, _u64(whole)) == 0          # (an empty phase is fine)
+    finally:
+        assert fi.hm_release_bases(hd) == 0
+    b = b[: n].copy()
+    assert fi.hm_register_bases(_u64(b), n, ctypes.byref(hd)) == 0
+    try:
+        want, got = np.zeros((count, 12), dtype=np.uint64), np.zeros((count, 12), dtype=np.uint64)
+        assert fi.hm_msm_batch_bn256_g1_h(hd, 0, ptrs, n, count, _u64(want)) == 0
+        for i in (0, 5, 11):
+            assert np.array_equal(want[i][:8], cref.g1_to_affine(cref.best_multiexp(cols[i], b, 8))[0]), i
+        fi.hm_test_arm_fault(b"batch_submit", 2)
         assert fi.hm_msm_batch_bn256_g1_h(hd, 0, ptrs, n, count, _u64(got)) < 0
         fi.hm_test_arm_fault(None, 0)
         assert fi.hm_msm_batch_bn256_g1_h(hd, 0, ptrs, n, count, _u64(got)) == 0
