@@ -2325,7 +2325,9 @@ uint32_t msm_table_group_max(size_t n, uint32_t precomp_c) {
     return (uint32_t)(g < 1 ? 1 : g > HM_MSM_GROUP ? HM_MSM_GROUP : g);
   }();
   static const bool k4_chain_only = [] { const char* v = std::getenv("HALO2_MI355X_K4_CHAIN"); return v && *v == '1'; }();
-  if (precomp_c < 6 || n == 0 || k4_chain_only || msm_small_applies(n, precomp_c, true)) return 1;
+  // (from 2^19 points a commitment fills the chip by itself, and the positional sort plan of the larger sizes has only been
+  //  exercised one bucket set at a time)
+  if (precomp_c < 6 || n == 0 || n >= ((size_t)1 << 19) || k4_chain_only || msm_small_applies(n, precomp_c, true)) return 1;
   const uint64_t per = (uint64_t)n * ((255 + precomp_c - 1) / precomp_c);
   uint32_t g = want;
   while (g > 1 && per * g >= (1ull << 31)) --g;

@@ -594,6 +594,53 @@ def test_batched_commitments_equal_single_calls(cref, golden):
         h.release_bases(hd)
 
 
+@pytest.mark.parametrize("log_n", [17, 18])
+def test_dense_columns_of_a_phase_share_chains_on_the_table(cref, log_n):
+    """Round 4: the DENSE columns of a phase on a fixed-base table set go through the general pipeline several per chain --
+    every column one bucket set of the same sort, K3 and reduction launches.  Eleven dense columns of every kind (uniform,
+    16-bit values, one constant -- a hot bucket per window inside a group --, all ones, 0 / 1 flags), sparse ones in between
+    (those keep the five-launch plan), one all-zero column: the batch equals the one-at-a-time results, three of which are
+    checked against the oracle; from host arrays too."""
+    import torch
+    from halo2_experiments_amd.arithmetic import best_multiexp_batch
+    n = 1 << log_n
+    bases = h.g1_fixed_base_mul(rand_fr_gpu(n, 8600 + log_n), cref.g1_generator())
+    bases[5] = 0                                                         # an identity base
+    bases[7] = bases[6]
+    one = torch.from_numpy(cref.fr_to_mont(np.array([[1, 0, 0, 0]], dtype=np.uint64)).view(np.int64)).cuda()
+    cols = []
+    for i in range(11):
+        c = rand_fr_gpu(n, 8700 + 13 * i + log_n)
+        if i == 2:
+            c[:, 1:] = 0
+            c[:, 0] &= 0xFFFF
+            c = _raw_to_mont(c)
+        elif i == 4:
+            c = c[:1].expand(n, 4).contiguous()
+        elif i == 6:
+            c = one.expand(n, 4).contiguous()
+        elif i == 8:
+            c = torch.where((torch.arange(n, device="cuda") % 3 == 0)[:, None], one.expand(n, 4), torch.zeros_like(c)).contiguous()
+        cols.append(c)
+    cols.insert(3, _replay_sparse_column(n, 900, 8800))
+    cols.insert(9, torch.zeros((n, 4), dtype=torch.int64, device="cuda"))
+    cols.insert(10, _replay_sparse_column(n, 40, 8801))
+    hd = h.register_bases(bases)
+    try:
+        assert h.bases_info(hd)["table_windows"] != 0
+        single = np.stack([h.best_multiexp(c, hd) for c in cols])
+        bh = bases.cpu().numpy().view(np.uint64)
+        for i in (0, 5, 7):
+            assert g1_equal(single[i], cref.g1_to_affine(cref.best_multiexp(cols[i].cpu().numpy().view(np.uint64), bh, 8))[0]), i
+        assert not single[9].any()
+        for _ in range(2):
+            assert np.array_equal(best_multiexp_batch(cols, hd), single)
+        assert np.array_equal(best_multiexp_batch([c.cpu().numpy().view(np.uint64) for c in cols], hd), single)
+        assert np.array_equal(best_multiexp_batch(cols[:2], hd), single[:2])
+    finally:
+        h.release_bases(hd)
+
+
 def test_grouped_chains_with_empty_ragged_and_identity_rows(cref, pyref):
     """The group form of the five-launch plan (one chain carries several commitments) on a length that is not a multiple
     of the 256-row compaction block: an all-zero column (no surviving block at all), a column whose only non-zero scalar
