@@ -282,6 +282,52 @@ def replay_cpu_baseline(rep, device):
     return info
 
 
+def live_pmc(log_points, log_ntt, with_ntt):
+    """HBM traffic and VALU instruction counts of the two hot kernels MEASURED IN THIS RUN: three child processes, each this
+    same script (two timed steps of the headline workload, nothing else) under `rocprofv3 --pmc <one counter group>
+    --kernel-trace`, exactly as MI355X_MICROARCH.md prescribes (FETCH_SIZE and WRITE_SIZE in separate passes, counters in
+    their own runs, the program directly after `--`).  Returns {kernel: {counter: average per launch}} or an {"error": ...}
+    -- never raises: a box without rocprofv3 falls back to the committed figures."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return {"error": "rocprofv3 not on PATH"}
+    out = {}
+    tmp = tempfile.mkdtemp(prefix="hm_pmc_", dir="/tmp")
+    try:
+        child = [sys.executable, os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--log-points", str(log_points), "--log-ntt",
+                 str(log_ntt), "--no-cpu-baseline", "--replay", "none", "--no-extras", "--no-strong", "--no-live-pmc"] + ([] if with_ntt else ["--no-ntt"])
+        env = dict(os.environ, TMPDIR="/tmp")
+        for group in (["FETCH_SIZE"], ["WRITE_SIZE"], ["SQ_INSTS_VALU", "GRBM_GUI_ACTIVE"]):
+            d = os.path.join(tmp, group[0])
+            r = subprocess.run(["rocprofv3", "--pmc", *group, "--kernel-trace", "--output-format", "csv", "-d", d, "--", *child], cwd="/tmp", env=env,
+                               capture_output=True, text=True, timeout=240)
+            if r.returncode != 0:
+                return {"error": f"rocprofv3 --pmc {' '.join(group)} failed (rc {r.returncode}): {r.stderr[-300:]}"}
+            acc = {}
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                with open(f) as fh:
+                    for row in csv.DictReader(fh):
+                        name = row["Kernel_Name"].split("(")[0].replace("void ", "")
+                        if name == "hm::msm_accumulate_kernel" or name.startswith("hm::ntt_pass_kernel<11"):
+                            a = acc.setdefault((name, row["Counter_Name"]), [0.0, 0])
+                            a[0] += float(row["Counter_Value"])
+                            a[1] += 1
+            if not acc:
+                return {"error": f"no counter rows for the hot kernels in the {group[0]} pass"}
+            for (name, ctr), (tot, cnt) in acc.items():
+                out.setdefault(name, {})[ctr] = tot / cnt
+                out[name]["launches_" + ctr] = cnt
+    except Exception as e:  # noqa: BLE001
+        return {"error": f"{type(e).__name__}: {e}"}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return out
+
+
 def fold_known_answers(expected_local, world, comm_device):
     """The global expected point from every rank's [sum s_i t_i]G over its own index range."""
     if world == 1:
@@ -488,6 +534,8 @@ def main():
                     help="comma-separated create_proof MSM/NTT traces to replay after the timed MSM steps ('none' to skip)")
     ap.add_argument("--no-extras", action="store_true", help="skip the prover-like and host-pointer MSM side measurements")
     ap.add_argument("--no-2-26", action="store_true", help="skip the global 2^26-point strong-scaling measurement")
+    ap.add_argument("--no-live-pmc", action="store_true",
+                    help="do not measure the PMC counters of the hot kernels in child processes under rocprofv3 (N = 1 only); use the baked file")
     ap.add_argument("--no-strong", action="store_true", help="skip the strong-scaling measurements (global 2^24 / 2^26 split over the ranks)")
     ap.add_argument("--no-one-process", action="store_true", help="N > 1: skip rank 0's one-process (hm_set_msm_devices) measurements")
     ap.add_argument("--one-process", action="store_true",
@@ -768,9 +816,50 @@ def main():
                     pass
         dist.barrier(group=park_group)                          # ... and waits here, on the CPU, until rank 0 is done
 
+    # ---- PMC counters of the two hot kernels, measured in THIS run (child processes under rocprofv3) --------------------
+    live = None
+    under_profiler = any("ROCPROF" in k.upper() for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
+    if rank == 0 and world == 1 and not args.no_live_pmc and not under_profiler:
+        if handle is not None:
+            h.release_bases(handle)
+            handle = None
+        scalars = None
+        torch.cuda.empty_cache()
+        live = live_pmc(args.log_points, args.log_ntt, ntt is not None)
+
     if rank == 0:
         acc = float(np.median(acc_ms))
         achieved = MSM_BYTES_PER_POINT * n_local / (acc * 1e-3) / 1e9
+        k3_live = (live or {}).get("hm::msm_accumulate_kernel")
+        ntt_live = next((v for k_, v in (live or {}).items() if k_.startswith("hm::ntt_pass_kernel<11")), None)
+        pmc_how = ("MEASURED IN THIS RUN: child processes of this script (two steps of the same workload) under rocprofv3 --pmc, FETCH_SIZE and "
+                   "WRITE_SIZE in separate passes, averaged per launch")
+        if k3_live and "FETCH_SIZE" in k3_live and "WRITE_SIZE" in k3_live:
+            k3_traffic = (k3_live["FETCH_SIZE"] + k3_live["WRITE_SIZE"]) * 1024.0      # raw: 64-byte gathers are counted 1:1 (r02_gather64_calibration.json)
+            k3_traffic_note = pmc_how + "; raw FETCH + WRITE (64-byte gathers count 1:1: profiles/r02_gather64_calibration.json); every base (or " \
+                                        "its table multiple) is gathered once per window, inherent to bucketed Pippenger"
+        else:
+            k3_traffic = pmc_traffic(baked, "hm::msm_accumulate_kernel", False) if args.log_points == 24 else None
+            k3_traffic_note = (f"NOT measured in this run ({(live or {}).get('error', 'live PMC pass not run')}): rocprofv3 --pmc figure via "
+                               f"{BAKED_COUNTERS_FILE} (stale = {bool(stale['k3'])}: whether the kernel sources changed since)")
+        if k3_live and "SQ_INSTS_VALU" in k3_live:
+            per_unit = k3_live["SQ_INSTS_VALU"] / st["pairs"]
+            a_ = per_unit * st["pairs"] / (acc * 1e-3)
+            k3_valu = {"achieved": a_, "peak": VALU_PEAK_WAVE_INST_PER_S, "unit": "wave-instr/s", "frac": a_ / VALU_PEAK_WAVE_INST_PER_S,
+                       "wave_instr_per_64_units": per_unit * 64, "sq_insts_valu_per_launch": k3_live["SQ_INSTS_VALU"],
+                       "grbm_gui_active_per_launch": k3_live.get("GRBM_GUI_ACTIVE"), "stale": False,
+                       "note": "SQ_INSTS_VALU " + pmc_how + "; peak = 1024 SIMDs x 2.4 GHz / 4"}
+        else:
+            k3_valu = valu_issue(baked, stale, "k3", st["pairs"], acc)
+        if ntt is not None and ntt_live and "FETCH_SIZE" in ntt_live and "WRITE_SIZE" in ntt_live:
+            ntt["roofline"]["traffic"] = (2.0 * ntt_live["FETCH_SIZE"] + ntt_live["WRITE_SIZE"]) * 1024.0   # gfx950: FETCH_SIZE is half of a coalesced stream
+            ntt["roofline"]["traffic_note"] = pmc_how + "; per pass launch, FETCH_SIZE doubled (the gfx950 correction for wide coalesced reads)"
+            if "SQ_INSTS_VALU" in ntt_live:
+                passes = 3 if args.log_ntt > 21 else 2 if args.log_ntt > 11 else 1
+                a_ = ntt_live["SQ_INSTS_VALU"] * passes / (ntt["ms"] * 1e-3)
+                ntt["roofline"]["valu_issue"] = {"achieved": a_, "peak": VALU_PEAK_WAVE_INST_PER_S, "unit": "wave-instr/s",
+                                                 "frac": a_ / VALU_PEAK_WAVE_INST_PER_S, "sq_insts_valu_per_pass_launch": ntt_live["SQ_INSTS_VALU"],
+                                                 "stale": False, "note": "SQ_INSTS_VALU " + pmc_how}
         line = {
             "metric": "BN256 G1 MSM throughput",
             "value": n_global * args.steps / elapsed,
@@ -795,13 +884,10 @@ def main():
                        "all-gather of 96 B partials (RCCL) + host fold"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": (pmc_traffic(baked, "hm::msm_accumulate_kernel", False) if args.log_points == 24 else None),
-                         "traffic_note": f"NOT measured in this run: rocprofv3 --pmc figure via {BAKED_COUNTERS_FILE} "
-                                         f"(stale = {bool(stale['k3'])}: whether the kernel sources changed since); "
-                                         "every base (or its table multiple) is gathered once per window, inherent to bucketed Pippenger",
+                         "traffic": k3_traffic, "traffic_note": k3_traffic_note,
                          "kernel": "msm_accumulate_kernel", "kernel_ms": acc,
                          "note": "integer-VALU bound (SURVEY.md §8d): n x windows mixed additions x ~2.24e3 32-bit ops per launch",
-                         "valu_issue": valu_issue(baked, stale, "k3", st["pairs"], acc)},
+                         "valu_issue": k3_valu},
             "msm_phase_ms": {"sort": float(np.median(sort_ms)), "accumulate_kernel": acc, "device_total": float(np.median(tot_ms)),
                          "pairs": int(st["pairs"]), "tasks": int(st["tasks"])},
             "known_answer_ok": answer_ok,

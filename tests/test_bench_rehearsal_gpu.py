@@ -22,6 +22,10 @@ def _free_port():
 def _bench(world, log_points, replay="none", extra=()):
     args = ["--gpus", str(world), "--steps", "2", "--warmup", "1", "--log-points", str(log_points), "--no-cpu-baseline", "--no-ntt",
             "--replay", replay, "--no-extras", "--no-2-26"] + list(extra)
+    if "--live-pmc" in args:
+        args.remove("--live-pmc")
+    else:
+        args.append("--no-live-pmc")
     env = dict(os.environ, HALO2_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     if world == 1 or "--one-process" in extra:
         cmd = [sys.executable, os.path.join(ROOT, "bench.py")] + args
@@ -85,3 +89,19 @@ def test_one_process_form_as_the_whole_benchmark():
     assert line["config"]["parallelism"].startswith("one process")
     assert abs(line["value"] - line["config"]["global_points"] / (line["ms_per_step"] * 1e-3)) < 1e-6 * line["value"]
     assert set(line["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
+
+
+@pytest.mark.gpu
+def test_pmc_counters_are_measured_in_the_run():
+    """N = 1: roofline.traffic and valu_issue come from child processes of bench.py under rocprofv3 --pmc (separate FETCH_SIZE /
+    WRITE_SIZE passes), not from a committed file -- when rocprofv3 is there; without it the line says so and falls back."""
+    import shutil
+    line = _bench(1, 20, extra=("--live-pmc",))
+    rf = line["roofline"]
+    if shutil.which("rocprofv3") is None:
+        assert "NOT measured in this run" in rf["traffic_note"]
+        return
+    assert rf["traffic_note"].startswith("MEASURED IN THIS RUN"), rf["traffic_note"]
+    assert rf["traffic"] > 96 * (1 << 20)                       # at least the algorithmic bytes of 2^20 points
+    assert rf["valu_issue"]["stale"] is False and rf["valu_issue"]["sq_insts_valu_per_launch"] > 0
+    assert 1000 < rf["valu_issue"]["wave_instr_per_64_units"] < 4000        # ~2 200 wave-instructions per 64 mixed additions

@@ -3,7 +3,7 @@
 set -o pipefail
 R="${GRAFT_REPO_ROOT:-/root/repo}"; rm -rf "$R/gpurun_out/pmc_sq"; mkdir -p "$R/gpurun_out/pmc_sq"; export TMPDIR=/tmp; cd /tmp
 timeout -k 10 500 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$R/gpurun_out/pmc_sq" -- \
-  python3 "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --replay none --no-extras > "$R/gpurun_out/pmc_sq/out.json" 2> "$R/gpurun_out/pmc_sq/err.txt" || { tail -5 "$R/gpurun_out/pmc_sq/err.txt"; exit 1; }
+  python3 "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --replay none --no-extras --no-live-pmc > "$R/gpurun_out/pmc_sq/out.json" 2> "$R/gpurun_out/pmc_sq/err.txt" || { tail -5 "$R/gpurun_out/pmc_sq/err.txt"; exit 1; }
 cd "$R" && python3 - <<'PY'
 import csv, glob
 from collections import defaultdict

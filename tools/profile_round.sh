@@ -15,7 +15,7 @@ R="${GRAFT_REPO_ROOT:-/root/repo}"
 E="$R/gpurun_out/evidence/$TAG"
 rm -rf "$E"; mkdir -p "$E/pmc"
 export TMPDIR=/tmp
-BENCH_ARGS="--steps 5 --warmup 1 --no-cpu-baseline --replay none --no-extras"
+BENCH_ARGS="--steps 5 --warmup 1 --no-cpu-baseline --replay none --no-extras --no-live-pmc"
 cd "$R"
 python3 tools/evidence.py manifest "$E/manifest.json" || exit 1
 if [ -z "$NOBENCH" ]; then
@@ -29,12 +29,12 @@ python3 tools/evidence.py pick "$E/kernel_trace" '*kernel_stats.csv' "$E/kernel_
 echo "== rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes)"
 for ctr in FETCH_SIZE WRITE_SIZE; do
   (cd /tmp && timeout -k 10 500 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d "$E/pmc/$ctr" -- python3 "$R/bench.py" \
-     --steps 2 --warmup 1 --no-cpu-baseline --replay none --no-extras > "$E/pmc/$ctr.json" 2> "$E/pmc/$ctr.err") || { tail -5 "$E/pmc/$ctr.err"; exit 1; }
+     --steps 2 --warmup 1 --no-cpu-baseline --replay none --no-extras --no-live-pmc > "$E/pmc/$ctr.json" 2> "$E/pmc/$ctr.err") || { tail -5 "$E/pmc/$ctr.err"; exit 1; }
 done
 python3 tools/pmc_summarise.py "$E/pmc" > "$E/pmc_traffic.json" || exit 1
 echo "== rocprofv3 --pmc SQ counters"
 (cd /tmp && timeout -k 10 500 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU GRBM_GUI_ACTIVE --kernel-trace --output-format csv \
-   -d "$E/pmc_sq" -- python3 "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --replay none --no-extras > "$E/pmc_sq.json" 2> "$E/pmc_sq.err") \
+   -d "$E/pmc_sq" -- python3 "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --replay none --no-extras --no-live-pmc > "$E/pmc_sq.json" 2> "$E/pmc_sq.err") \
    || { tail -5 "$E/pmc_sq.err"; exit 1; }
 python3 tools/evidence.py sq "$E/pmc_sq" > "$E/sq_counters.txt" || exit 1
 rm -rf "$E/kernel_trace" "$E/pmc/FETCH_SIZE" "$E/pmc/WRITE_SIZE" "$E/pmc_sq"      # raw traces are large; the summaries stay
