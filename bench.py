@@ -25,6 +25,9 @@ Extra objects on that line:
   roofline      dominant kernel = msm_accumulate_kernel; achieved = 96 B/point (SURVEY.md §8d:
                 32 B scalar + 64 B affine base, each read once) x points per launch / the
                 launch's duration from HIP events on its own stream (hm_get_msm_stats).
+                traffic / valu_issue: PMC counters measured IN THE RUN by three child processes of
+                this script under `rocprofv3 --pmc` (N = 1; --no-live-pmc or no rocprofv3: the
+                committed profiles/<tag>_baked_counters.json, flagged stale when the kernels changed).
   ntt           2^24 Fr NTT on one GPU (64 B/element algorithmic), same treatment.
   cpu_baseline  oracle/cpu_ref.c (C restatement of halo2_proofs v2023_02_02's best_multiexp) timed
                 on this box's host cores on a bounded sample of the same workload (rank 0, N=1).
