@@ -161,3 +161,33 @@ def test_two_threads_batch_from_host_arrays_at_once(cref):
         assert not errs, errs
     finally:
         h.release_bases(hd)
+
+
+@pytest.mark.parametrize("mode", ["replicated", "sliced"])
+def test_layouts_and_bases_info_of_a_multi_device_set(cref, monkeypatch, mode):
+    """hm_register_bases_plain* / the default / _precomp* under a device list, and hm_get_bases_info on the multi handle: parts,
+    replicas or slices, the layout every part ended up with, bytes summed over the parts; results identical on every layout."""
+    monkeypatch.setenv("HALO2_MI355X_SLICE_FROM_LOG", "16" if mode == "sliced" else "22")
+    n = 3 << 17                                                 # three parts of 2^17 when sliced: each part gets the default table
+    bases = h.g1_fixed_base_mul(rand_fr_gpu(n, 9900), cref.g1_generator())
+    s = rand_fr_gpu(n, 9901)
+    want = cref.g1_to_affine(cref.best_multiexp(s.cpu().numpy().view(np.uint64), bases.cpu().numpy().view(np.uint64), 8))[0]
+    with devices(0, 0, 0):
+        hp = h.register_bases(bases, plain=True)
+        hd = h.register_bases(bases)
+        try:
+            ip, idf = h.bases_info(hp), h.bases_info(hd)
+            assert ip["devices"] == 3 and idf["devices"] == 3 and ip["n"] == n and idf["n"] == n
+            assert ip["sliced"] == (1 if mode == "sliced" else 0)
+            assert ip["table_windows"] == 0 and idf["table_windows"] != 0
+            per_part = n // 3 if mode == "sliced" else n
+            assert ip["device_bytes"] == 3 * per_part * 65
+            assert idf["device_bytes"] == 3 * per_part * (idf["table_windows"] * 64 + 1)
+            assert g1_equal(h.best_multiexp(s, hp), want) and g1_equal(h.best_multiexp(s, hd), want)
+            got = best_multiexp_batch([s, s], hd)
+            assert g1_equal(got[0], want) and g1_equal(got[1], want)
+        finally:
+            h.release_bases(hp)
+            h.release_bases(hd)
+        with pytest.raises(_lib.Halo2Mi355xError):
+            h.bases_info(hd)
