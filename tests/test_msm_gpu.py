@@ -873,6 +873,44 @@ def test_vector_load_sort_at_odd_sizes_and_with_zero_digits(cref, n):
         _lib.check(lib.hm_set_fixed_base_threshold(17))
 
 
+@pytest.mark.parametrize("log_n", [12, 18, 22, 24])
+def test_geometric_known_answer_needs_neither_oracle_nor_the_dot_product_kernel(pyref, log_n):
+    """A full-size known answer in which the only shared code is the affine group law of Python integers: scalars s_i = c^i,
+    bases P_i = [d^i]G, so sum_i s_i P_i = [((c d)^n - 1) / (c d - 1)]G.  The expected point is one Python double-and-add of the
+    closed form; eight random bases made by the library's fixed-base kernel are checked against Python's [d^i]G first.  (The
+    KZG known answers elsewhere take their expected scalar from the library's own inner-product kernel.)"""
+    import ctypes
+    import torch
+    from halo2_experiments_amd.arithmetic import _ptr, _stream_ptr
+    from halo2_experiments_amd.domain import fr_words
+    o = pyref
+    n = 1 << log_n
+    c, d = 0x1D1D1D1D2B2B2B2B3C3C3C3C4D4D4D4D5E5E5E5E % o.R, 0x0F0E0D0C0B0A09080706050403020100FFEEDDCC % o.R
+    lib = _lib.load()
+    s = torch.empty((n, 4), dtype=torch.int64, device="cuda")
+    t = torch.empty((n, 4), dtype=torch.int64, device="cuda")
+    _lib.check(lib.hm_fr_powers_dev(ctypes.c_void_p(s.data_ptr()), n, _ptr(fr_words(c)), ctypes.c_void_p(_stream_ptr(s))))
+    _lib.check(lib.hm_fr_powers_dev(ctypes.c_void_p(t.data_ptr()), n, _ptr(fr_words(d)), ctypes.c_void_p(_stream_ptr(t))))
+    gen = o.g1_affine_array([o.G1_GEN])[0]
+    bases = h.g1_fixed_base_mul(t, gen)
+    rng = np.random.default_rng(log_n)
+    for i in [0, 1, n - 1] + rng.integers(0, n, 5).tolist():
+        want = o.g1_affine_array([o.g1_mul(pow(d, i, o.R), o.G1_GEN)])[0]
+        assert np.array_equal(bases[i].cpu().numpy().view(np.uint64), want), i
+        assert np.array_equal(s[i].cpu().numpy().view(np.uint64), fr_words(pow(c, i, o.R))), i
+    cd = c * d % o.R
+    total = (pow(cd, n, o.R) - 1) * pow(cd - 1, -1, o.R) % o.R
+    want = o.g1_affine_array([o.g1_mul(total, o.G1_GEN)])[0]
+    assert g1_equal(h.best_multiexp(s, bases), want)                     # a transient set: the plain layout
+    if log_n >= 17:
+        hd = h.register_bases(bases)                                     # ... and the fixed-base table
+        try:
+            assert h.bases_info(hd)["table_windows"] != 0
+            assert g1_equal(h.best_multiexp(s, hd), want)
+        finally:
+            h.release_bases(hd)
+
+
 def test_go_ethereum_precompile_vectors_through_the_hip_path(pyref):
     """The third-party known answers of tests/test_oracle.py (go-ethereum's EIP-196 precompile test data, "chfast1..3")
     computed by the HIP path itself: [k]P as an MSM of one point, P + Q as an MSM of two points with scalars one, and all

@@ -166,6 +166,74 @@ def test_full_size_properties(cref, pyref, k):
     assert torch.equal(y, x)
 
 
+@pytest.mark.parametrize("k", [11, 16, 21, 22, 24, 26])
+def test_geometric_series_known_answer_needs_no_oracle(pyref, k):
+    """A known answer that neither oracle takes part in: for a_i = c^i the transform is the geometric series
+    X_j = sum_i (c w^j)^i = (c^n - 1) / (c w^j - 1), checked with Python integers at 256 random output indices (and the
+    library-made input at 64 random input indices) -- one-, two- and three-pass plans up to 2^26."""
+    import ctypes
+    import torch
+    from halo2_experiments_amd import _lib
+    from halo2_experiments_amd.arithmetic import _ptr, _stream_ptr
+    R = pyref.R
+    n = 1 << k
+    w = pyref.fr_omega(k)
+    c = 0x1234567890ABCDEF1234567890ABCDEF1234567890ABCDEF % R
+    a = torch.empty((n, 4), dtype=torch.int64, device="cuda")
+    _lib.check(_lib.load().hm_fr_powers_dev(ctypes.c_void_p(a.data_ptr()), n, _ptr(fr_words(c)), ctypes.c_void_p(_stream_ptr(a))))
+    rng = np.random.default_rng(k)
+    idx_in = torch.from_numpy(rng.integers(0, n, 64)).cuda()
+    got_in = a[idx_in].cpu().numpy().view(np.uint64)
+    for i, row in zip(idx_in.cpu().tolist(), got_in):
+        assert np.array_equal(row, fr_words(pow(c, i, R))), i
+    h.best_fft(a, fr_words(w), k)
+    idx = np.concatenate([[0, 1, n - 1, n // 2], rng.integers(0, n, 252)])
+    got = a[torch.from_numpy(idx).cuda()].cpu().numpy().view(np.uint64)
+    top = (pow(c, n, R) - 1) % R
+    for j, row in zip(idx.tolist(), got):
+        want = top * pow((c * pow(w, j, R) - 1) % R, -1, R) % R
+        assert np.array_equal(row, fr_words(want)), (k, j)
+
+
+@pytest.mark.parametrize("k", [11, 17, 18])
+def test_evaluation_domain_known_answers_need_no_oracle(pyref, k):
+    """The same closed form for the EvaluationDomain steps at the circuits' shapes (k = 11 / 17 / 18, j = 7): the coefficients
+    c^i evaluated on the zeta-coset of the extended domain are ((c x)^n - 1) / (c x - 1) at x = zeta * w_ext^j
+    (coeff_to_extended), their values on the n-th roots of unity come back to c^i (lagrange_to_coeff), and
+    extended_to_coeff returns c^i followed by zeros -- Python integers only, 128 random indices each."""
+    import ctypes
+    import torch
+    from halo2_experiments_amd import _lib
+    from halo2_experiments_amd.arithmetic import _ptr, _stream_ptr
+    R = pyref.R
+    d = EvaluationDomain(j=7, k=k)
+    n, en = d.n, d.extended_len()
+    c = 0xFEDCBA9876543210FEDCBA9876543210FEDCBA98 % R
+    coeff = torch.empty((n, 4), dtype=torch.int64, device="cuda")
+    _lib.check(_lib.load().hm_fr_powers_dev(ctypes.c_void_p(coeff.data_ptr()), n, _ptr(fr_words(c)), ctypes.c_void_p(_stream_ptr(coeff))))
+    rng = np.random.default_rng(100 + k)
+    top = lambda x: (pow(c * x % R, n, R) - 1) * pow((c * x - 1) % R, -1, R) % R        # f(x) = sum_i (c x)^i
+    ext = d.coeff_to_extended(coeff)
+    idx = np.concatenate([[0, 1, en - 1], rng.integers(0, en, 125)])
+    got = ext[torch.from_numpy(idx).cuda()].cpu().numpy().view(np.uint64)
+    for j, row in zip(idx.tolist(), got):
+        assert np.array_equal(row, fr_words(top(d.g_coset * pow(d.extended_omega, j, R) % R))), (k, j)
+    # values on the n-th roots of unity -> lagrange_to_coeff -> c^i
+    evals = coeff.clone()
+    h.best_fft(evals, fr_words(d.omega), k)                                                # f(w^j), checked by the test above
+    back = d.lagrange_to_coeff(evals)
+    idx = rng.integers(0, n, 128)
+    got = back[torch.from_numpy(idx).cuda()].cpu().numpy().view(np.uint64)
+    for i, row in zip(idx.tolist(), got):
+        assert np.array_equal(row, fr_words(pow(c, i, R))), (k, i)
+    # extended_to_coeff of the coset evaluations: the coefficients again, zeros above n
+    out = d.extended_to_coeff(ext.clone())
+    idx = rng.integers(0, out.shape[0], 128)
+    got = out[torch.from_numpy(idx).cuda()].cpu().numpy().view(np.uint64)
+    for i, row in zip(idx.tolist(), got):
+        assert np.array_equal(row, fr_words(pow(c, i, R) if i < n else 0)), (k, i)
+
+
 def test_evaluation_domain_steps(cref, pyref):
     """lagrange_to_coeff / coeff_to_extended / extended_to_coeff against the oracle's compositions."""
     import torch
