@@ -303,7 +303,9 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(const uint32_t* i
     if (r == 2) ntt_round<LOG_TILE, 2>(lds, cx, q0, stage_tw);
     else ntt_round<LOG_TILE, 1>(lds, cx, q0, stage_tw);
     q0 += r;
+#ifndef HM_NTT_TIMING_NO_ROUND_BARRIER      // TIMING EXPERIMENT ONLY (tools/ab_build.sh): results are wrong without the barrier
     __syncthreads();
+#endif
   }
 
   // ---- epilogue: inter-pass twiddle + packed store, or canonicalise (+ fused scale) on the last pass
