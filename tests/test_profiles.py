@@ -69,3 +69,28 @@ def test_pickers_insist_on_exactly_one_match(tmp_path):
     (tmp_path / "a" / "2_kernel_stats.csv").write_text("y")
     with pytest.raises(SystemExit):
         evidence.pick_one(str(tmp_path), "*kernel_stats.csv")
+
+
+def test_live_pmc_never_raises_and_falls_back(monkeypatch):
+    """bench.py measures the PMC counters in child processes under rocprofv3; a box without the profiler, or a failing
+    pass, must come back as {"error": ...} (the line then quotes the committed file), never as an exception."""
+    import importlib
+    import shutil
+    import subprocess
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    monkeypatch.setattr(shutil, "which", lambda name: None)
+    assert "error" in bench.live_pmc(24, 24, True)
+    monkeypatch.setattr(shutil, "which", lambda name: "/usr/bin/false")
+
+    class Failed:
+        returncode, stderr, stdout = 1, "boom", ""
+    monkeypatch.setattr(subprocess, "run", lambda *a, **k: Failed())
+    out = bench.live_pmc(24, 24, True)
+    assert "error" in out and "rc 1" in out["error"]
+
+    def raising(*a, **k):
+        raise subprocess.TimeoutExpired(cmd="rocprofv3", timeout=1)
+    monkeypatch.setattr(subprocess, "run", raising)
+    assert "TimeoutExpired" in bench.live_pmc(24, 24, True)["error"]
+    assert bench.newest_baked_counters_file().startswith("profiles/r")
