@@ -1,0 +1,100 @@
+#!/usr/bin/env python3
+"""Differential fuzzing of the MSM against the oracle beyond what pytest runs (development aid; results quoted in DESIGN.md section 1):
+    python tools/fuzz_msm.py single SEED CASES   random n in [2^17, 1.3e6], six scalar kinds, fixed-base table AND plain layout vs oracle/cpu_ref.c
+    python tools/fuzz_msm.py batch  SEED CASES   random phases (2-23 columns: sparse, zero, constant, dense) at prover sizes: batch == single calls == oracle
+"""
+import sys
+mode = sys.argv.pop(1) if len(sys.argv) > 1 else "single"
+if mode == "single":
+    import os, sys, time
+    sys.path.insert(0, os.getcwd())
+    import numpy as np, torch
+    import halo2_experiments_amd as h
+    from halo2_experiments_amd import _lib
+    from halo2_experiments_amd.domain import FR_MODULUS, fr_words
+    from oracle import cpu_ref
+    cpu_ref.build()
+    lib = _lib.load()
+    def rand_fr(n, seed):
+        g = torch.Generator(device="cuda"); g.manual_seed(seed)
+        x = torch.randint(-(2**63), 2**63 - 1, (n, 4), dtype=torch.int64, device="cuda", generator=g)
+        x[:, 3] &= 0x0FFFFFFFFFFFFFFF
+        return x
+    rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
+    NMAX = 1_300_000
+    pool = h.g1_fixed_base_mul(rand_fr(NMAX, 1), cpu_ref.g1_generator())
+    bad = 0
+    t0 = time.time()
+    for case in range(int(sys.argv[2]) if len(sys.argv) > 2 else 40):
+        n = int(rng.integers(1 << 17, NMAX))
+        off = int(rng.integers(0, NMAX - n + 1))
+        bases = pool[off:off + n].contiguous()
+        s = rand_fr(n, 100 + case)
+        kind = int(rng.integers(0, 6))
+        if kind == 1:
+            s[torch.from_numpy(rng.random(n) < 0.9).cuda()] = 0
+        elif kind == 2:
+            s[:, 1:] = 0; s[:, 0] &= 0xFFFFFF
+            s = h.linear_combination([s.contiguous()], np.stack([fr_words((1 << 256) % FR_MODULUS)]))
+        elif kind == 3:
+            s[::3] = s[0]
+        elif kind == 4:
+            s[int(rng.integers(0, n)):] = 0
+        s = s.contiguous()
+        want = cpu_ref.g1_to_affine(cpu_ref.best_multiexp(s.cpu().numpy().view(np.uint64), bases.cpu().numpy().view(np.uint64), 16))[0]
+        for thr in (17, 0):
+            lib.hm_set_fixed_base_threshold(thr)
+            hd = h.register_bases(bases)
+            got = h.best_multiexp(s, hd)
+            h.release_bases(hd)
+            ok = (not got[8:].any() and not want.any()) or np.array_equal(got[:8], want)
+            if not ok:
+                bad += 1
+                print("MISMATCH", case, n, kind, thr, flush=True)
+        if case % 10 == 9: print("case", case, "ok so far, bad =", bad, f"{time.time()-t0:.0f}s", flush=True)
+    lib.hm_set_fixed_base_threshold(17)
+    print("done, mismatches:", bad)
+else:
+    import os, sys, time
+    sys.path.insert(0, os.getcwd())
+    import numpy as np, torch
+    import halo2_experiments_amd as h
+    from halo2_experiments_amd import _lib
+    from halo2_experiments_amd.arithmetic import best_multiexp_batch
+    from halo2_experiments_amd.replay import _sparse_column
+    from oracle import cpu_ref
+    cpu_ref.build()
+    def rand_fr(n, seed):
+        g = torch.Generator(device="cuda"); g.manual_seed(seed)
+        x = torch.randint(-(2**63), 2**63 - 1, (n, 4), dtype=torch.int64, device="cuda", generator=g)
+        x[:, 3] &= 0x0FFFFFFFFFFFFFFF
+        return x
+    rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
+    dev = torch.device("cuda", 0)
+    bad = 0
+    t0 = time.time()
+    for case in range(int(sys.argv[2]) if len(sys.argv) > 2 else 30):
+        n = int(rng.choice([1 << 17, (1 << 17) + 5, 1 << 18, (1 << 18) - 3, 200_001, 1 << 16, 1 << 15]))
+        bases = h.g1_fixed_base_mul(rand_fr(n, 5000 + case), cpu_ref.g1_generator())
+        hd = h.register_bases(bases)
+        count = int(rng.integers(2, 24))
+        cols = []
+        for i in range(count):
+            k = int(rng.integers(0, 6))
+            if k == 0: c = _sparse_column(n, int(rng.integers(1, 3000)), 9000 + 31 * case + i, dev)
+            elif k == 1: c = torch.zeros((n, 4), dtype=torch.int64, device="cuda")
+            elif k == 2: c = rand_fr(1, 7000 + i).expand(n, 4).contiguous()
+            else: c = rand_fr(n, 8000 + 17 * case + i)
+            cols.append(c)
+        single = np.stack([h.best_multiexp(c, hd) for c in cols])
+        got = best_multiexp_batch(cols, hd)
+        got_h = best_multiexp_batch([c.cpu().numpy().view(np.uint64) for c in cols], hd) if case % 3 == 0 else got
+        j = int(rng.integers(0, count))
+        want = cpu_ref.g1_to_affine(cpu_ref.best_multiexp(cols[j].cpu().numpy().view(np.uint64), bases.cpu().numpy().view(np.uint64), 16))[0]
+        okj = (not single[j][8:].any() and not want.any()) or np.array_equal(single[j][:8], want)
+        if not (np.array_equal(got, single) and np.array_equal(got_h, single) and okj):
+            bad += 1
+            print("MISMATCH", case, n, count, flush=True)
+        h.release_bases(hd)
+        if case % 10 == 9: print("case", case, "bad =", bad, f"{time.time()-t0:.0f}s", flush=True)
+    print("done, mismatches:", bad)
