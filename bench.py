@@ -694,7 +694,7 @@ def main():
         extras["msm_prover_like"] = {"points_per_s": n_local / dt, "ms": dt * 1e3, "pairs": h.msm_stats()["pairs"],
                                      "scalars": "90 % zero, 5 % < 2^16, 5 % uniform"}
         del pl, u
-        # the OTHER base-set layout: the timed steps ran on what hm_register_bases builds by default (from 2^23 points the
+        # the OTHER base-set layout: the timed steps ran on what hm_register_bases builds by default (from 2^17 points the
         # fixed-base table: 2^(offset of window j) * P_i for every window, W x the memory, one shared bucket set); here the
         # plain layout (one copy of the points, W bucket sets) -- or, below the default's threshold, the table
         _, bases2, _ = bench_inputs(n_local, lo, BENCH_SEED, device)

@@ -240,7 +240,7 @@ def test_precomputed_full_size_kzg_known_answer(cref, pyref):
 
 
 def test_fixed_base_table_is_the_registration_default_from_its_threshold(cref, pyref):
-    """hm_register_bases* builds the fixed-base table by itself from 2^threshold points (default 23; here lowered to 2^20
+    """hm_register_bases* builds the fixed-base table by itself from 2^threshold points (default 17; here raised to 2^20
     so that the oracle can check the result): one bucket set, fewer windows, the positional 32-bit sort items (n W = 2^23.7
     items, 2^19 buckets), the balanced window split with doubled narrow digits -- against the oracle on uniform scalars and
     on a column with a hot bucket; one point below the threshold, and with the threshold off, the plain layout."""
