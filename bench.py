@@ -14,7 +14,7 @@ Beside the weak-scaling `value` the line carries, at every N:
                    range over the N ranks: ms per MSM (max over ranks), points/s, known answer of the folded result
   one_process      (N > 1) the form the reference's prover would use -- ONE process for the node
                    (/root/reference/src/circuits/utils.rs:22-70), hm_set_msm_devices(0..N-1): rank 0 alone, the other
-                   ranks parked on a CPU-side barrier with their device memory released, splits one 2^26 MSM over the
+                   ranks parked on the rendezvous store (CPU side) with their device memory released, splits one 2^26 MSM over the
                    N devices inside the C ABI (csrc/multi.hip) and replays the k = 18 create_proof trace with every
                    commitment phase dealt over the devices.  `python bench.py --gpus N --one-process` (no torchrun)
                    runs that form as the whole benchmark.
@@ -331,6 +331,20 @@ def live_pmc(log_points, log_ntt, with_ntt):
     return out
 
 
+def cpu_side_barrier(tag, rank, world):
+    """All ranks meet on the process group's rendezvous STORE (a TCP key-value store, CPU only): the ranks that have nothing to
+    do while rank 0 runs the one-process measurements wait here -- an RCCL barrier would keep a spinning kernel on every device
+    rank 0 is about to time, and a second (gloo) process group prints its connection banner on stdout, next to the ONE JSON
+    line.  Falls back to the default group's barrier when the store is not reachable."""
+    import datetime
+    try:
+        store = dist.distributed_c10d._get_default_store()
+        store.set(f"halo2_mi355x/{tag}/{rank}", "1")
+        store.wait([f"halo2_mi355x/{tag}/{r}" for r in range(world)], datetime.timedelta(minutes=30))
+    except Exception:  # noqa: BLE001
+        dist.barrier()
+
+
 def fold_known_answers(expected_local, world, comm_device):
     """The global expected point from every rank's [sum s_i t_i]G over its own index range."""
     if world == 1:
@@ -563,14 +577,11 @@ def main():
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
     comm_device = device if backend == "nccl" else torch.device("cpu")
-    park_group, ranks_seen = None, 1
+    ranks_seen = 1
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
-            # a CPU-side group: ranks that have nothing to do while rank 0 runs the one-process measurements wait THERE (an RCCL
-            # barrier would keep a spinning kernel on every device rank 0 is about to time)
-            park_group = dist.new_group(backend="gloo")
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
         one = torch.ones(1, dtype=torch.int64, device=comm_device)
@@ -805,7 +816,7 @@ def main():
         torch.cuda.empty_cache()
         if rank != 0:
             _lib.check(_lib.load().hm_shutdown())               # workspaces, tables, staging: this rank's device is rank 0's to use now
-        dist.barrier(group=park_group)                          # everybody has let go of its device memory ...
+        cpu_side_barrier("released", rank, world)                # everybody has let go of its device memory ...
         if rank == 0:
             devs = [r if backend == "nccl" else r % max(ndev, 1) for r in range(world)]
             try:            # never at the expense of the line's headline: this form has not met N physical devices before the driver's run
@@ -817,7 +828,7 @@ def main():
                     _lib.load().hm_set_msm_devices(None, 0)
                 except Exception:  # noqa: BLE001
                     pass
-        dist.barrier(group=park_group)                          # ... and waits here, on the CPU, until rank 0 is done
+        cpu_side_barrier("one_process_done", rank, world)        # ... and waits here, on the CPU, until rank 0 is done
 
     # ---- PMC counters of the two hot kernels, measured in THIS run (child processes under rocprofv3) --------------------
     live = None
