@@ -61,6 +61,9 @@ def test_apply_edits_makes_every_edit_once(tmp_path):
     # commit_lagrange is the first of the two functions in the file, commit the second
     assert 0 < kzg.index("self.gpu.commit_lagrange::<E::G1Affine>") < kzg.index("self.gpu.commit::<E::G1Affine>")
     assert "halo2-mi355x-sys" in (root / "Cargo.toml").read_text()
+    # the optional batch-commit method: provided by the trait, overridden for ParamsKZG
+    assert (root / "src" / "poly" / "commitment.rs").read_text().count("fn commit_lagrange_batch(") == 1
+    assert kzg.count("self.gpu.commit_lagrange_batch::<E::G1Affine>") == 1
     again = _run(root)                                          # idempotent
     assert again.returncode == 0 and "already edited" in again.stdout
     assert (root / "src" / "poly" / "kzg" / "commitment.rs").read_text() == kzg
@@ -77,6 +80,18 @@ def test_apply_edits_refuses_a_file_whose_anchors_differ(tmp_path):
     assert "mi355x" in (root / "src" / "arithmetic.rs").read_text()   # the other files were
 
 
+def test_a_missing_optional_anchor_is_skipped_not_fatal(tmp_path):
+    root, _ = _skeleton(tmp_path)
+    trait = root / "src" / "poly" / "commitment.rs"
+    trait.write_text(trait.read_text().replace("    /// Writes params to a buffer.", "    /// Writes the parameters."))
+    r = _run(root)
+    assert r.returncode == 0 and "SKIPPED (optional)" in r.stdout
+    assert "commit_lagrange_batch" not in trait.read_text()
+    assert "self.gpu.commit_lagrange::<E::G1Affine>" in (root / "src" / "poly" / "kzg" / "commitment.rs").read_text()
+    trait.unlink()
+    assert _run(root).returncode == 0                            # a file with optional edits only may be absent
+
+
 @pytest.mark.skipif(shutil.which("patch") is None, reason="no patch(1)")
 def test_the_unified_diff_makes_the_same_edits(tmp_path):
     a, _ = _skeleton(tmp_path / "a")
@@ -84,7 +99,7 @@ def test_the_unified_diff_makes_the_same_edits(tmp_path):
     assert _run(a).returncode == 0
     r = subprocess.run(["patch", "-p1", "-i", os.path.join(RUST, "halo2_proofs.patch")], cwd=b, capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
-    for rel in ("src/arithmetic.rs", "src/poly/kzg/commitment.rs", "Cargo.toml", "src/mi355x.rs", "src/mi355x_kzg.rs"):
+    for rel in ("src/arithmetic.rs", "src/poly/kzg/commitment.rs", "src/poly/commitment.rs", "Cargo.toml", "src/mi355x.rs", "src/mi355x_kzg.rs"):
         assert (a / rel).read_text() == (b / rel).read_text(), rel
 
 

@@ -523,6 +523,26 @@ EDITS = [
     ("src/poly/kzg/commitment.rs", "        best_multiexp(&scalars, &bases[0..size])",
      [[l.format(fn="commit_lagrange") for l in _COMMIT_VIA], [l.format(fn="commit") for l in _COMMIT_VIA]], 290),
 ]
+# OPTIONAL edits (a sixth tuple element): a phase of commitments in one call.  `Params` gains a provided method that commits one
+# by one; ParamsKZG overrides it with SrsHandles::commit_lagrange_batch (hm_msm_batch_bn256_g1_h).  create_proof's loops reach
+# it by replacing `polys.iter().zip(blinds).map(|(poly, blind)| params.commit_lagrange(poly, *blind)).collect()` with
+# `params.commit_lagrange_batch(&polys.iter().collect::<Vec<_>>())` (rust/README.md).  Their anchors -- the doc comment in front
+# of `fn write` in the trait and in the impl -- are the least certain recollection of this table: apply_edits.py reports a
+# miss as SKIPPED and goes on.
+EDITS += [
+    ("src/poly/commitment.rs", "    /// Writes params to a buffer.",
+     [["    /// The commitments of one prover phase (columns of one length).  One by one here; ParamsKZG sends them to the GPU in one call.",
+       "    fn commit_lagrange_batch(&self, polys: &[&Polynomial<C::ScalarExt, LagrangeCoeff>]) -> Vec<C::CurveExt> {",
+       "        polys.iter().map(|p| self.commit_lagrange(p, Blind::default())).collect()",
+       "    }", "", "    /// Writes params to a buffer."]], 70, True),
+    ("src/poly/kzg/commitment.rs", "    /// Writes params to a buffer.",
+     [["    fn commit_lagrange_batch(&self, polys: &[&Polynomial<E::Scalar, LagrangeCoeff>]) -> Vec<E::G1> {",
+       "        let cols: Vec<&[E::Scalar]> = polys.iter().map(|p| &p[..]).collect();",
+       "        if let Some(r) = self.gpu.commit_lagrange_batch::<E::G1Affine>(&cols, &self.g_lagrange[..]) {",
+       "            return r;", "        }",
+       "        polys.iter().map(|p| self.commit_lagrange(p, Blind::default())).collect()",
+       "    }", "", "    /// Writes params to a buffer."]], 300, True),
+]
 
 
 def emit_patch() -> str:
@@ -542,7 +562,7 @@ def emit_patch() -> str:
     out += new_file("src/mi355x.rs", MI355X_RS)
     out += new_file("src/mi355x_kzg.rs", MI355X_KZG_RS)
     by_file = {}
-    for path, anchor, repls, line in EDITS:
+    for path, anchor, repls, line, *_opt in EDITS:
         for k, repl in enumerate(repls):
             by_file.setdefault(path, []).append((line + 60 * k, anchor, repl))
     for path, hunks in by_file.items():
@@ -558,7 +578,8 @@ def emit_patch() -> str:
 def edits_json() -> str:
     """The edit table as data for rust/apply_edits.py (which has to run where this repository's tools/ may be absent)."""
     import json
-    return json.dumps([{"file": f, "anchor": a, "replacements": r, "near_line": n} for f, a, r, n in EDITS], indent=1) + "\n"
+    return json.dumps([{"file": e[0], "anchor": e[1], "replacements": e[2], "near_line": e[3], "optional": len(e) > 4 and bool(e[4])}
+                       for e in EDITS], indent=1) + "\n"
 
 
 README = '''# rust/ -- the reference-side binding, as files
@@ -611,11 +632,14 @@ Known risks of code that has never met rustc: the trait paths of `generator()` /
 nothing newer than Rust 1.56 is used (`std::sync::Once` + atomics, no `OnceLock`).
 
 **The batch call.** `create_proof` commits its advice columns in a loop over `params.commit_lagrange(poly, blind)`
-(`halo2_proofs/src/plonk/prover.rs`); `params` is the generic `ParamsProver`, so routing that loop through
-`SrsHandles::commit_lagrange_batch` needs one provided method on the `Params` trait
-(`fn commit_lagrange_batch(&self, polys: &[&Polynomial<..>]) -> Vec<C::CurveExt>` defaulting to the loop, overridden for
-`ParamsKZG` by `self.gpu.commit_lagrange_batch::<E::G1Affine>(&cols, &self.g_lagrange)`) and the loop's `.map(..).collect()`
-replaced by the call.  That is an edit of a trait other crates implement; it is described, not shipped as an anchor.
+(`halo2_proofs/src/plonk/prover.rs`); `params` is the generic `ParamsProver`.  Two OPTIONAL entries of `edits.json` add the method
+that loop needs: `Params::commit_lagrange_batch(&self, polys) -> Vec<C::CurveExt>`, provided by the trait as the one-by-one loop
+and overridden for `ParamsKZG` by `self.gpu.commit_lagrange_batch::<E::G1Affine>(&cols, &self.g_lagrange[..])` (one
+`hm_msm_batch_bn256_g1_h` call: eight commitments in flight, dense columns sharing launch chains, uploads behind kernels).  Their
+anchors (the doc comment in front of `fn write`, in the trait and in the impl) are the least certain of the table; `apply_edits.py`
+reports a miss as `SKIPPED (optional)` and goes on.  The loop itself is then one line by hand:
+`let advice_commitments_projective: Vec<_> = params.commit_lagrange_batch(&advice_values.iter().collect::<Vec<_>>());`
+(KZG ignores the blinding factors the loop passed).
 '''
 
 
