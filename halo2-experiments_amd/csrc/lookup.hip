@@ -17,6 +17,7 @@
 //   5  fill      S'[row] = A'[row] at first occurrences, else the (m - 1 - rank)-th leftover value; back to Montgomery
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <cstring>
 
 #include "g1.h"
@@ -65,23 +66,107 @@ struct LkPtrs {
 
 // Montgomery words -> canonical integers: one product by `c` (2^-256 in the form the raw words need); rows >= live get
 // the all-ones key (above r: sorts behind every field element).  grid.y = key array (2 per pair).
-__global__ __launch_bounds__(LK_THREADS) void lk_convert_kernel(LkPtrs ptr, uint32_t* keys, uint64_t pitch, uint64_t live, uint64_t total, LkFr c) {
+// kbits[2 a] |= word 0 of every live key of array a, kbits[2 a + 1] |= its words 1 .. 7: the host picks the sort by them (one OR
+// per wave, not per key).
+__global__ __launch_bounds__(LK_THREADS) void lk_convert_kernel(LkPtrs ptr, uint32_t* keys, uint64_t pitch, uint64_t live, uint64_t total, LkFr c,
+                                                                uint32_t* __restrict__ kbits) {
+  const uint64_t i = (uint64_t)blockIdx.x * LK_THREADS + threadIdx.x;
+  uint32_t lo_bits = 0, hi_bits = 0;
+  if (i < total) {
+    uint32_t* out = keys + (size_t)blockIdx.y * pitch;
+    if (i >= live) {
+      key_store(out, i, Key{{~0u, ~0u, ~0u, ~0u, ~0u, ~0u, ~0u, ~0u}});
+    } else {
+      const Key k = key_load(ptr.in[blockIdx.y], i);
+      Fr cc;
+#pragma unroll
+      for (int j = 0; j < 9; ++j) cc.l[j] = c.l[j];
+      HM_DECLARE(cc, 1.0);
+      const Fr y = fe_canonical(fe_mul(fe_unpack<FrParams>(k.w), cc));
+      Key o;
+      fe_pack(o.w, y);
+      key_store(out, i, o);
+      lo_bits = o.w[0];
+      hi_bits = o.w[1] | o.w[2] | o.w[3] | o.w[4] | o.w[5] | o.w[6] | o.w[7];
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    lo_bits |= __shfl_xor(lo_bits, off, 64);
+    hi_bits |= __shfl_xor(hi_bits, off, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    if (lo_bits) atomicOr(kbits + 2 * blockIdx.y, lo_bits);
+    if (hi_bits) atomicOr(kbits + 2 * blockIdx.y + 1, hi_bits);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Sorting SMALL keys (every live key of the chain below 2^B, B <= LK_COUNT_BITS: range-check and byte-table lookups -- the
+// reference's MerkleSumTree lookups are those, /root/reference/src/chips/merkle_sum_tree.rs -- hold values of 8 .. 16 bits)
+// needs no comparison network: the keys carry no payload, so the sorted array is "value v repeated count[v] times".  Three
+// launches whatever n: histogram (one atomic per distinct value and wave), exclusive scan of the 2^B counters, expansion (every
+// output position finds its value by a binary search over the scanned counters).  The 256-bit bitonic network costs
+// (log n)(log n + 1) / 2 stages whatever the values.
+// ---------------------------------------------------------------------------------------------
+constexpr uint32_t LK_COUNT_BITS = 20;           // at most 2^20 counters (4 MiB) per key array
+__global__ __launch_bounds__(LK_THREADS) void lk_count_kernel(const uint32_t* __restrict__ keys, uint64_t pitch, uint64_t live,
+                                                              uint32_t* __restrict__ counters, uint32_t nbins) {
+  const uint64_t i = (uint64_t)blockIdx.x * LK_THREADS + threadIdx.x;
+  keys += (size_t)blockIdx.y * pitch;
+  counters += (size_t)blockIdx.y * nbins;
+  const bool on = i < live;
+  const uint32_t v = on ? keys[i * 8] : 0u;
+  uint64_t todo = __ballot(on);
+  while (todo) {                                   // one atomic per distinct value of the wave (constant columns: one per wave)
+    const uint32_t leader = (uint32_t)__builtin_ctzll(todo);
+    const uint32_t lv = (uint32_t)__builtin_amdgcn_readlane((int)v, leader);
+    const uint64_t same = __ballot(on && v == lv) & todo;
+    if ((threadIdx.x & 63) == leader) atomicAdd(counters + lv, (uint32_t)__popcll(same));
+    todo &= ~same;
+  }
+}
+// exclusive scan of one array's counters in place (one workgroup of 1024 lanes per array)
+__global__ __launch_bounds__(1024) void lk_count_scan_kernel(uint32_t* __restrict__ counters, uint32_t nbins) {
+  __shared__ uint32_t s[1024];
+  counters += (size_t)blockIdx.x * nbins;
+  const uint32_t t = threadIdx.x, per = (nbins + 1023) / 1024;
+  const uint32_t lo = t * per < nbins ? t * per : nbins, hi = lo + per < nbins ? lo + per : nbins;
+  uint32_t sum = 0;
+  for (uint32_t b = lo; b < hi; ++b) sum += counters[b];
+  s[t] = sum;
+  __syncthreads();
+  for (uint32_t off = 1; off < 1024; off <<= 1) {
+    const uint32_t a = t >= off ? s[t - off] : 0u;
+    __syncthreads();
+    s[t] += a;
+    __syncthreads();
+  }
+  uint32_t run = s[t] - sum;
+  for (uint32_t b = lo; b < hi; ++b) {
+    const uint32_t c = counters[b];
+    counters[b] = run;
+    run += c;
+  }
+}
+// keys[i] = the largest v with start[v] <= i for i < live (empty values share their successor's start: the LAST of equal
+// starts is the value that owns position i), the all-ones padding key behind
+__global__ __launch_bounds__(LK_THREADS) void lk_count_expand_kernel(uint32_t* __restrict__ keys, uint64_t pitch, uint64_t live, uint64_t total,
+                                                                     const uint32_t* __restrict__ start, uint32_t nbins) {
   const uint64_t i = (uint64_t)blockIdx.x * LK_THREADS + threadIdx.x;
   if (i >= total) return;
-  uint32_t* out = keys + (size_t)blockIdx.y * pitch;
+  keys += (size_t)blockIdx.y * pitch;
+  start += (size_t)blockIdx.y * nbins;
   if (i >= live) {
-    key_store(out, i, Key{{~0u, ~0u, ~0u, ~0u, ~0u, ~0u, ~0u, ~0u}});
+    key_store(keys, i, Key{{~0u, ~0u, ~0u, ~0u, ~0u, ~0u, ~0u, ~0u}});
     return;
   }
-  const Key k = key_load(ptr.in[blockIdx.y], i);
-  Fr cc;
-#pragma unroll
-  for (int j = 0; j < 9; ++j) cc.l[j] = c.l[j];
-  HM_DECLARE(cc, 1.0);
-  const Fr y = fe_canonical(fe_mul(fe_unpack<FrParams>(k.w), cc));
-  Key o;
-  fe_pack(o.w, y);
-  key_store(out, i, o);
+  uint32_t lo = 0, hi = nbins;                     // invariant: start[lo] <= i, and (hi == nbins or start[hi] > i)
+  while (hi - lo > 1) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (start[mid] <= (uint32_t)i) lo = mid; else hi = mid;
+  }
+  key_store(keys, i, Key{{lo, 0u, 0u, 0u, 0u, 0u, 0u, 0u}});
 }
 
 // one compare-exchange stage of the bitonic network with partner distance j >= LK_TILE (phase length k); blockIdx.y
@@ -326,6 +411,20 @@ static int lk_sort(uint32_t* d_keys, uint64_t n_pow2, uint32_t arrays, uint64_t 
   return HM_OK;
 }
 
+// the same for keys below 2^bits: three launches (see lk_count_kernel); counters: arrays x 2^bits words, zeroed here
+static int lk_sort_small(uint32_t* d_keys, uint64_t live, uint64_t n_pow2, uint32_t arrays, uint64_t pitch, uint32_t bits, uint32_t* d_counters,
+                         hipStream_t stream) {
+  const uint32_t nbins = 1u << bits;
+  HM_HIP_CHECK(hipMemsetAsync(d_counters, 0, (size_t)arrays * nbins * 4, stream));
+  hipLaunchKernelGGL(lk_count_kernel, dim3((uint32_t)((live + LK_THREADS - 1) / LK_THREADS), arrays), dim3(LK_THREADS), 0, stream,
+                     (const uint32_t*)d_keys, pitch, live, d_counters, nbins);
+  hipLaunchKernelGGL(lk_count_scan_kernel, dim3(arrays), dim3(1024), 0, stream, d_counters, nbins);
+  hipLaunchKernelGGL(lk_count_expand_kernel, dim3((uint32_t)((n_pow2 + LK_THREADS - 1) / LK_THREADS), arrays), dim3(LK_THREADS), 0, stream,
+                     d_keys, pitch, live, n_pow2, (const uint32_t*)d_counters, nbins);
+  HM_HIP_CHECK(hipGetLastError());
+  return HM_OK;
+}
+
 static int lk_compact(const uint32_t* d_flags, uint64_t n, uint64_t stride, uint32_t pairs, uint32_t invert, uint32_t* d_sums, uint32_t* d_small,
                       uint32_t which, uint32_t* d_rank, uint32_t* d_positions, hipStream_t stream) {
   const uint32_t blocks = (uint32_t)((n + SC_BLOCK - 1) / SC_BLOCK);
@@ -364,12 +463,18 @@ int lookup_permute_run(DeviceCtx& ctx, const void* const* d_inputs, const void* 
   auto carve = [&](size_t bytes) { const size_t o = off; off += align(bytes); return o; };
   const size_t o_keys = carve((size_t)2 * P * n2 * 32), o_rep = carve((size_t)P * stride * 4), o_used = carve((size_t)P * stride * 4),
                o_rank = carve((size_t)P * stride * 4), o_left = carve((size_t)P * stride * 4), o_reppos = carve((size_t)P * stride * 4),
-               o_sums = carve((size_t)P * blocks * 4 * 2), o_small = carve((size_t)LK_MAX_PAIRS * 16);
+               o_sums = carve((size_t)P * blocks * 4 * 2), o_small = carve((size_t)LK_MAX_PAIRS * 16), o_kbits = carve((size_t)4 * LK_MAX_PAIRS * 4);
+  // the counting sort of small keys wants 2^bits counters per key array; they are carved only when the sort can be used at all
+  // (more keys than a few LDS tiles: below that the bitonic network is one or two launches), sized for the worst case it accepts
+  static const bool count_sort_on = [] { const char* v = std::getenv("HALO2_MI355X_LOOKUP_COUNT_SORT"); return !(v && *v == '0'); }();   // A/B
+  const bool may_count = count_sort_on && n2 > 4 * (uint64_t)LK_TILE;
+  const size_t o_counters = carve(may_count ? (size_t)2 * P * ((size_t)4 << LK_COUNT_BITS) : 4);
   uint8_t* ws = (uint8_t*)slot->scratch.ensure(off);
   if (!ws) return hm_fail(HM_ERR_HIP, "lookup permute: scratch allocation failed");
   uint32_t *keys = (uint32_t*)(ws + o_keys), *rep = (uint32_t*)(ws + o_rep), *used = (uint32_t*)(ws + o_used);
   uint32_t *rank = (uint32_t*)(ws + o_rank), *left = (uint32_t*)(ws + o_left), *reppos = (uint32_t*)(ws + o_reppos);
-  uint32_t *sums = (uint32_t*)(ws + o_sums), *small = (uint32_t*)(ws + o_small);
+  uint32_t *sums = (uint32_t*)(ws + o_sums), *small = (uint32_t*)(ws + o_small), *kbits = (uint32_t*)(ws + o_kbits);
+  uint32_t* counters = (uint32_t*)(ws + o_counters);
   // the raw words are the internal form of v / 32; times the internal form of 32 * 2^-256 (the integer 32 ... see
   // msm_s_digits_kernel) they become the canonical integer v (as Fr::to_repr); and back with 2^256
   LkFr to_canon, to_mont;
@@ -393,8 +498,21 @@ int lookup_permute_run(DeviceCtx& ctx, const void* const* d_inputs, const void* 
     HM_HIP_CHECK(hipMemsetAsync(used, 0, (size_t)cnt * stride * 4, stream));
     HM_HIP_CHECK(hipMemsetAsync(small, 0, (size_t)LK_MAX_PAIRS * 16, stream));
     const uint32_t cb = (uint32_t)((n2 + LK_THREADS - 1) / LK_THREADS), rb = (uint32_t)((rows + LK_THREADS - 1) / LK_THREADS);
-    hipLaunchKernelGGL(lk_convert_kernel, dim3(cb, 2 * cnt), dim3(LK_THREADS), 0, stream, ptr, keys, pitch, rows, n2, to_canon);
-    int rc = lk_sort(keys, n2, 2 * cnt, pitch, stream);            // every column of the chain side by side
+    HM_HIP_CHECK(hipMemsetAsync(kbits, 0, (size_t)4 * LK_MAX_PAIRS * 4, stream));
+    hipLaunchKernelGGL(lk_convert_kernel, dim3(cb, 2 * cnt), dim3(LK_THREADS), 0, stream, ptr, keys, pitch, rows, n2, to_canon, kbits);
+    uint32_t small_bits = 0;                                       // != 0: every live key of the chain is below 2^small_bits
+    if (may_count) {                                               // (one small copy and a wait: the call synchronises at its end anyway)
+      uint32_t h_bits[4 * LK_MAX_PAIRS];
+      HM_HIP_CHECK(hipMemcpyAsync(h_bits, kbits, sizeof h_bits, hipMemcpyDeviceToHost, stream));
+      HM_HIP_CHECK(hipStreamSynchronize(stream));
+      uint32_t lo_or = 0, hi_or = 0;
+      for (uint32_t a = 0; a < 2 * cnt; ++a) { lo_or |= h_bits[2 * a]; hi_or |= h_bits[2 * a + 1]; }
+      uint32_t need = 1;
+      while (need < 32 && (lo_or >> need) != 0) ++need;
+      if (hi_or == 0 && need <= LK_COUNT_BITS) small_bits = need;
+    }
+    int rc = small_bits ? lk_sort_small(keys, rows, n2, 2 * cnt, pitch, small_bits, counters, stream)
+                        : lk_sort(keys, n2, 2 * cnt, pitch, stream);            // every column of the chain side by side
     if (rc != HM_OK) return rc;
     hipLaunchKernelGGL(lk_mark_kernel, dim3(rb, cnt), dim3(LK_THREADS), 0, stream, (const uint32_t*)keys, pitch, rows, stride, rep, used, small);
     rc = lk_compact(rep, rows, stride, cnt, 0, sums, small, 0, rank, reppos, stream);

@@ -61,6 +61,47 @@ def test_permute_expression_pair_matches_oracle(pyref, k, blinding, kind):
         assert all(0 <= v < R for v in tail) and len(set(tail)) > 1
 
 
+@pytest.mark.parametrize("kind", ["bytes", "20-bit", "21-bit", "constant", "mostly-zero", "mixed-batch"])
+def test_small_keys_take_the_counting_sort_and_agree_with_the_oracle(pyref, kind):
+    """Round 4: when every live key of a chain is below 2^20 (range checks, byte tables: the reference's lookups) the 256-bit
+    bitonic network is replaced by a counting sort -- histogram, scan, expansion.  Bit-exact against the oracle at 2^14 rows for
+    byte values, values that need all 20 bits, values one bit above the limit (the network again), one constant (every wave on
+    one counter), a column of mostly zeros, and a batch in which ONE lookup holds large values (the whole chain then takes the
+    network)."""
+    k, blinding = 14, 6
+    n, rows = 1 << k, (1 << k) - blinding - 1
+    rng = random.Random(hash(kind) & 0xFFFF)
+    def pair(span, top=0):
+        table = [(i % span) | top for i in range(n)]
+        inp = [table[rng.randrange(rows)] for _ in range(n)]
+        return inp, table
+    if kind == "bytes":
+        pairs = [pair(256)]
+    elif kind == "20-bit":
+        pairs = [pair(5000, top=1 << 19)]
+    elif kind == "21-bit":
+        pairs = [pair(5000, top=1 << 20)]
+    elif kind == "constant":
+        pairs = [([7] * n, [7] * n)]
+    elif kind == "mostly-zero":
+        table = [0] * n
+        for i in range(300):
+            table[i] = i
+        inp = [0 if rng.random() < 0.95 else rng.randrange(300) for _ in range(n)]
+        pairs = [(inp, table)]
+    else:
+        pairs = [pair(256), make_pair(rng, n, rows, "compressed"), pair(65536), pair(3)]
+    outs = h.permute_expression_pairs([to_gpu(pyref, p[0]) for p in pairs], [to_gpu(pyref, p[1]) for p in pairs], rows, blinding_seed=11)
+    for (inp, table), (a, s_) in zip(pairs, outs):
+        want_a, want_s = pr.permute_expression_pair(inp, table, rows)
+        assert from_gpu(pyref, a[:rows]) == want_a and from_gpu(pyref, s_[:rows]) == want_s
+    if kind == "bytes":                     # and a missing value is still an error on this path
+        bad = list(pairs[0][0])
+        bad[123] = 256
+        with pytest.raises(_lib.Halo2Mi355xError):
+            h.permute_expression_pair(to_gpu(pyref, bad), to_gpu(pyref, pairs[0][1]), rows)
+
+
 def test_missing_input_value_is_an_error(pyref):
     """Upstream returns Error::ConstraintSystemFailure when an input value does not occur in the table."""
     n = 1 << 10
