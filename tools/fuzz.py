@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""Differential fuzzing of the MSM against the oracle beyond what pytest runs (development aid; results quoted in DESIGN.md section 1):
-    python tools/fuzz_msm.py single SEED CASES   random n in [2^17, 1.3e6], six scalar kinds, fixed-base table AND plain layout vs oracle/cpu_ref.c
-    python tools/fuzz_msm.py batch  SEED CASES   random phases (2-23 columns: sparse, zero, constant, dense) at prover sizes: batch == single calls == oracle
+"""Differential fuzzing against the oracle beyond what pytest runs (development aid; results quoted in DESIGN.md section 1):
+    python tools/fuzz.py single SEED CASES   random n in [2^17, 1.3e6], six scalar kinds, fixed-base table AND plain layout vs oracle/cpu_ref.c
+    python tools/fuzz.py batch  SEED CASES   random phases (2-23 columns: sparse, zero, constant, dense) at prover sizes: batch == single calls == oracle
+    python tools/fuzz.py lookup SEED CASES   random lookup arguments (2^13 .. 2^16 rows, key widths 1 .. 200 bits, 1-9 per call): == oracle/poly_ref.py
 """
 import sys
 mode = sys.argv.pop(1) if len(sys.argv) > 1 else "single"
@@ -54,6 +55,43 @@ if mode == "single":
         if case % 10 == 9: print("case", case, "ok so far, bad =", bad, f"{time.time()-t0:.0f}s", flush=True)
     lib.hm_set_fixed_base_threshold(17)
     print("done, mismatches:", bad)
+elif mode == "lookup":
+    import os, sys, random, time
+    sys.path.insert(0, os.getcwd())
+    import numpy as np, torch
+    import halo2_experiments_amd as h
+    from halo2_experiments_amd import _lib
+    from oracle import poly_ref as pr, bn256_ref as o
+    R = pr.R
+    def to_gpu(vals): return torch.from_numpy(o.fr_array(vals).view(np.int64)).cuda()
+    def from_gpu(t): return o.fr_from_array(t.cpu().numpy().view(np.uint64))
+    rng = random.Random(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
+    bad = 0
+    t0 = time.time()
+    for case in range(int(sys.argv[2]) if len(sys.argv) > 2 else 30):
+        k = rng.choice([13, 14, 15, 16])
+        n = 1 << k
+        rows = n - rng.choice([1, 7, 100, 1000])
+        pairs = []
+        for _ in range(rng.choice([1, 1, 2, 5, 9])):
+            bits = rng.choice([1, 3, 8, 12, 16, 19, 20, 21, 24, 64, 200])
+            span = rng.choice([1, 2, 7, 256, 5000, rows])
+            base = [rng.randrange(1 << bits) % R for _ in range(span)]
+            table = [base[i % span] for i in range(n)]
+            mode = rng.random()
+            if mode < 0.3: inp = [table[0]] * n
+            elif mode < 0.6: inp = [table[rng.randrange(rows)] if rng.random() < 0.1 else table[0] for _ in range(n)]
+            else: inp = [table[rng.randrange(rows)] for _ in range(n)]
+            pairs.append((inp, table))
+        outs = h.permute_expression_pairs([to_gpu(p[0]) for p in pairs], [to_gpu(p[1]) for p in pairs], rows, blinding_seed=case)
+        for (inp, table), (a, s) in zip(pairs, outs):
+            wa, ws = pr.permute_expression_pair(inp, table, rows)
+            if from_gpu(a[:rows]) != wa or from_gpu(s[:rows]) != ws:
+                bad += 1
+                print("MISMATCH", case, k, rows, flush=True)
+        if case % 5 == 4: print("case", case, "bad =", bad, f"{time.time()-t0:.0f}s", flush=True)
+    print("done, mismatches:", bad)
+    
 else:
     import os, sys, time
     sys.path.insert(0, os.getcwd())
