@@ -16,6 +16,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "halo2_mi355x.h")
 
 _u64p = ctypes.POINTER(ctypes.c_uint64)
 _vp = ctypes.c_void_p
+NO_CHAIN = ctypes.c_size_t(-1).value      # HM_NO_CHAIN of the header
 
 
 class Halo2Mi355xError(RuntimeError):
@@ -111,6 +112,9 @@ _SIGNATURES = {
                                                           ctypes.POINTER(ctypes.c_int), _vp]),
     "hm_kate_division_bn256_fr_dev": (ctypes.c_int, [_vp, ctypes.c_size_t, _u64p, _vp, _vp]),
     "hm_fr_grand_product_dev": (ctypes.c_int, [_vp, ctypes.c_size_t, _u64p, _vp, _vp]),
+    "hm_kate_division_batch_bn256_fr_dev": (ctypes.c_int, [ctypes.POINTER(_vp), ctypes.c_size_t, _u64p, ctypes.POINTER(_vp), ctypes.c_size_t, _vp]),
+    "hm_fr_grand_product_batch_dev": (ctypes.c_int, [ctypes.POINTER(_vp), ctypes.c_size_t, _u64p, ctypes.c_size_t, ctypes.POINTER(_vp),
+                                                     ctypes.c_size_t, _vp]),
     "hm_fr_batch_invert_dev": (ctypes.c_int, [_vp, ctypes.c_size_t, _vp]),
     "hm_fr_linear_combination_dev": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), _u64p, ctypes.c_size_t, ctypes.c_size_t, _vp, _vp]),
     "hm_fr_random_dev": (ctypes.c_int, [_vp, ctypes.c_size_t, ctypes.c_uint64, _vp]),

@@ -267,6 +267,65 @@ def grand_product(factors, start, out=None):
     return out
 
 
+def _ptr_array(tensors):
+    return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+
+def kate_division_batch(polys, zs):
+    """``kate_division`` of several same-length device-resident polynomials, each by its own point, in one launch chain
+    (the quotients of one multiopen round are independent of each other).  polys: list of (n, 4) GPU tensors; zs: one
+    point per polynomial.  Returns the list of (n - 1, 4) quotient tensors -- the same words as ``kate_division`` gives
+    one by one."""
+    import torch
+
+    lib = _lib.load()
+    polys = list(polys)
+    if not polys:
+        return []
+    if not all(_is_tensor(p) for p in polys):
+        raise TypeError("kate_division_batch: polys must be GPU tensors (coefficients stay in HBM)")
+    n = _tensor_rows(polys[0], 4, "polys[0]")
+    if n == 0:
+        raise ValueError("kate_division_batch: empty polynomial")
+    if any(_tensor_rows(p, 4, "polys") != n for p in polys):
+        raise ValueError("kate_division_batch: polynomials differ in length")
+    zz = np.ascontiguousarray(np.stack([_np(z, 4, "z").reshape(4) for z in zs]))
+    if zz.shape[0] != len(polys):
+        raise ValueError("kate_division_batch: one point per polynomial")
+    outs = [torch.empty((n - 1, 4), dtype=torch.int64, device=polys[0].device) for _ in polys]
+    _lib.check(lib.hm_kate_division_batch_bn256_fr_dev(_ptr_array(polys), n, _ptr(zz), _ptr_array(outs), len(polys),
+                                                       ctypes.c_void_p(_stream_ptr(polys[0]))))
+    return outs
+
+
+def grand_product_batch(factors, start, chain_row=None, outs=None):
+    """The z columns of one argument in one launch chain.  factors: list of (n, 4) GPU tensors.  ``chain_row=None``: every
+    column starts from ``start`` (the lookup arguments).  ``chain_row=u``: column j + 1 starts from ``out[j][u]`` --
+    upstream's ``last_z`` of the permutation argument, u = n - (blinding_factors + 1) -- without reading anything back.
+    ``outs[j]`` may be ``factors[j]`` itself.  Returns the list of outputs."""
+    import torch
+
+    lib = _lib.load()
+    factors = list(factors)
+    if not factors:
+        return []
+    if not all(_is_tensor(f) for f in factors):
+        raise TypeError("grand_product_batch: factors must be GPU tensors")
+    n = _tensor_rows(factors[0], 4, "factors[0]")
+    if any(_tensor_rows(f, 4, "factors") != n for f in factors):
+        raise ValueError("grand_product_batch: columns differ in length")
+    if outs is None:
+        outs = [torch.empty((n, 4), dtype=torch.int64, device=factors[0].device) for _ in factors]
+    elif len(outs) != len(factors) or any(_tensor_rows(o, 4, "outs") != n for o in outs):
+        raise ValueError("grand_product_batch: outs and factors differ in shape")
+    if chain_row is not None and not 0 <= chain_row < n:
+        raise ValueError("grand_product_batch: chain_row outside the columns")
+    st = _np(start, 4, "start").reshape(4)
+    _lib.check(lib.hm_fr_grand_product_batch_dev(_ptr_array(factors), n, _ptr(st), _lib.NO_CHAIN if chain_row is None else chain_row,
+                                                 _ptr_array(outs), len(factors), ctypes.c_void_p(_stream_ptr(factors[0]))))
+    return outs
+
+
 def batch_invert(values):
     """``ff::BatchInvert::batch_invert`` in place on a device-resident (n, 4) tensor: zero stays zero."""
     lib = _lib.load()

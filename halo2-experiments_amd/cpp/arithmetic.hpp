@@ -73,6 +73,30 @@ inline void grand_product(const Fr* d_factors, size_t n, const Fr& start, Fr* d_
   check(hm_fr_grand_product_dev(d_factors, n, start.l, d_out, stream), "grand_product");
 }
 
+// several kate_divisions of same-length polynomials, each by its own point, in one launch chain (the quotients of one
+// multiopen round); no quotient may overlap any polynomial of the call
+inline void kate_division_batch(const std::vector<const Fr*>& d_polys, size_t n, const std::vector<Fr>& zs, const std::vector<Fr*>& d_quotients,
+                                void* stream = nullptr) {
+  if (n == 0) throw std::invalid_argument("kate_division_batch: empty polynomial");
+  if (d_polys.size() != zs.size() || d_polys.size() != d_quotients.size())
+    throw std::invalid_argument("kate_division_batch: one point and one quotient per polynomial");
+  check(hm_kate_division_batch_bn256_fr_dev(reinterpret_cast<const void* const*>(d_polys.data()), n, reinterpret_cast<const uint64_t*>(zs.data()),
+                                            reinterpret_cast<void* const*>(d_quotients.data()), d_polys.size(), stream),
+        "kate_division_batch");
+}
+
+// the z columns of one argument in one launch chain.  chain_row == HM_NO_CHAIN: every column starts from `start` (lookup
+// arguments); chain_row = n - (blinding_factors + 1): column j + 1 starts from d_out[j][chain_row], upstream's `last_z`
+// of the permutation argument
+inline void grand_product_batch(const std::vector<const Fr*>& d_factors, size_t n, const Fr& start, size_t chain_row,
+                                const std::vector<Fr*>& d_out, void* stream = nullptr) {
+  if (d_factors.size() != d_out.size()) throw std::invalid_argument("grand_product_batch: one output per column");
+  if (chain_row != HM_NO_CHAIN && chain_row >= n) throw std::invalid_argument("grand_product_batch: chain_row outside the columns");
+  check(hm_fr_grand_product_batch_dev(reinterpret_cast<const void* const*>(d_factors.data()), n, start.l, chain_row,
+                                      reinterpret_cast<void* const*>(d_out.data()), d_factors.size(), stream),
+        "grand_product_batch");
+}
+
 // ff::BatchInvert::batch_invert on a device-resident slice: zero stays zero
 inline void batch_invert(Fr* d_values, size_t n, void* stream = nullptr) {
   check(hm_fr_batch_invert_dev(d_values, n, stream), "batch_invert");

@@ -1347,6 +1347,53 @@ int hm_fr_grand_product_dev(const void* d_factors, size_t n, const uint64_t star
   return fr_grand_product_run(*ctx, (const uint32_t*)d_factors, n, start, (uint32_t*)d_out, (hipStream_t)stream);
 } HM_API_CATCH("hm_fr_grand_product_dev")
 
+static bool ranges_overlap(const void* a, size_t a_bytes, const void* b, size_t b_bytes) {
+  const char *pa = (const char*)a, *pb = (const char*)b;
+  return pa < pb + b_bytes && pb < pa + a_bytes;
+}
+
+int hm_kate_division_batch_bn256_fr_dev(const void* const* d_polys, size_t n, const uint64_t* z, void* const* d_quotients, size_t count,
+                                        void* stream) try {
+  if (count == 0) return HM_OK;
+  if (!z || !d_polys || !d_quotients) return hm_fail(HM_ERR_BAD_ARG, "hm_kate_division_batch_bn256_fr_dev: null argument");
+  if (n >= 2) {
+    for (size_t j = 0; j < count; ++j)
+      if (!d_polys[j] || !d_quotients[j]) return hm_fail(HM_ERR_BAD_ARG, "hm_kate_division_batch_bn256_fr_dev: null device pointer");
+    for (size_t j = 0; j < count; ++j)
+      for (size_t i = 0; i < count; ++i)
+        if (ranges_overlap(d_quotients[j], (n - 1) * 32, d_polys[i], n * 32) ||
+            (i != j && ranges_overlap(d_quotients[j], (n - 1) * 32, d_quotients[i], (n - 1) * 32)))
+          return hm_fail(HM_ERR_BAD_ARG, "hm_kate_division_batch_bn256_fr_dev: a quotient overlaps another array of the call");
+  }
+  DeviceCtx* ctx = ctx_for_current_device();
+  if (!ctx) return HM_ERR_NO_DEVICE;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  count_vector(*ctx, HM_STAT_KATE_DIVISION, count, (uint64_t)count * n);
+  return fr_kate_division_batch_run(*ctx, d_polys, n, z, d_quotients, count, (hipStream_t)stream);
+} HM_API_CATCH("hm_kate_division_batch_bn256_fr_dev")
+
+int hm_fr_grand_product_batch_dev(const void* const* d_factors, size_t n, const uint64_t start[4], size_t chain_row, void* const* d_out,
+                                  size_t count, void* stream) try {
+  if (count == 0) return HM_OK;
+  if (!start || !d_factors || !d_out) return hm_fail(HM_ERR_BAD_ARG, "hm_fr_grand_product_batch_dev: null argument");
+  if (n) {
+    for (size_t j = 0; j < count; ++j)
+      if (!d_factors[j] || !d_out[j]) return hm_fail(HM_ERR_BAD_ARG, "hm_fr_grand_product_batch_dev: null device pointer");
+    for (size_t j = 0; j < count; ++j)
+      for (size_t i = 0; i < count; ++i)
+        if (i != j && (ranges_overlap(d_out[j], n * 32, d_factors[i], n * 32) || ranges_overlap(d_out[j], n * 32, d_out[i], n * 32)))
+          return hm_fail(HM_ERR_BAD_ARG, "hm_fr_grand_product_batch_dev: an output overlaps another column of the call");
+    for (size_t j = 0; j < count; ++j)
+      if (d_out[j] != d_factors[j] && ranges_overlap(d_out[j], n * 32, d_factors[j], n * 32))
+        return hm_fail(HM_ERR_BAD_ARG, "hm_fr_grand_product_batch_dev: an output partially overlaps its factors");
+  }
+  DeviceCtx* ctx = ctx_for_current_device();
+  if (!ctx) return HM_ERR_NO_DEVICE;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  count_vector(*ctx, HM_STAT_GRAND_PRODUCT, count, (uint64_t)count * n);
+  return fr_grand_product_batch_run(*ctx, d_factors, n, start, chain_row < n ? chain_row : n, d_out, count, (hipStream_t)stream);
+} HM_API_CATCH("hm_fr_grand_product_batch_dev")
+
 int hm_fr_batch_invert_dev(void* d_values, size_t n, void* stream) try {
   if (n && !d_values) return hm_fail(HM_ERR_BAD_ARG, "hm_fr_batch_invert_dev: null argument");
   DeviceCtx* ctx = ctx_for_current_device();

@@ -302,6 +302,10 @@ int fr_eval_polynomial_run(DeviceCtx& ctx, const uint32_t* d_polys, uint64_t n, 
 // polyops.hip
 int fr_kate_division_run(DeviceCtx& ctx, const uint32_t* d_a, uint64_t n, const uint64_t z_ext[4], uint32_t* d_q, hipStream_t stream);
 int fr_grand_product_run(DeviceCtx& ctx, const uint32_t* d_m, uint64_t n, const uint64_t start_ext[4], uint32_t* d_out, hipStream_t stream);
+int fr_kate_division_batch_run(DeviceCtx& ctx, const void* const* d_a, uint64_t n, const uint64_t* z_ext, void* const* d_q, size_t count,
+                               hipStream_t stream);
+int fr_grand_product_batch_run(DeviceCtx& ctx, const void* const* d_m, uint64_t n, const uint64_t start_ext[4], uint64_t chain_row,
+                               void* const* d_out, size_t count, hipStream_t stream);
 int fr_batch_invert_run(uint32_t* d_v, uint64_t n, hipStream_t stream);
 int fr_mul_periodic_run(uint32_t* d_a, uint64_t n, const uint64_t* pattern_ext, uint32_t period, hipStream_t stream);
 int fr_linear_combination_run(const void* const* d_polys, const uint64_t* coeffs_ext, size_t count, uint64_t n, uint32_t* d_out,

@@ -32,6 +32,18 @@ struct PoFr {              // one field element in 9 x 29-bit limbs, passed by v
   uint32_t l[9];
 };
 
+// The independent scans of one proof step (the z columns of the permutation / lookup arguments, the quotients of one
+// multiopen round) run as ONE launch chain: blockIdx.y selects the column.  Pointer and word tables by value are read
+// with scalar loads (the index is wave-uniform); nothing here is indexed per lane or by bytes.
+constexpr int PO_COLS_MAX = 16;
+struct PoCols {
+  const uint32_t* in[PO_COLS_MAX];
+  uint32_t* out[PO_COLS_MAX];
+};
+struct PoPoints {
+  PoFr z[PO_COLS_MAX];       // kate_division: the point of every column, true internal form
+};
+
 __device__ __forceinline__ Fr po_arg(const PoFr& a, double vb = 1.0) {
   Fr r;
 #pragma unroll
@@ -117,12 +129,15 @@ __device__ __forceinline__ Fr po_suffix_scan_uniform(uint32_t* lds, Fr v, Fr y) 
   return v;
 }
 
-__global__ __launch_bounds__(PO_THREADS) void fr_kate_chunks_kernel(const uint32_t* __restrict__ a, uint64_t n, PoFr z_int, uint32_t B,
+__global__ __launch_bounds__(PO_THREADS) void fr_kate_chunks_kernel(PoCols cols, uint64_t n, PoPoints pts, uint32_t B,
                                                                     uint32_t* __restrict__ incl, uint32_t* __restrict__ wg_total) {
   __shared__ uint32_t lds[9 * PO_THREADS];
   const uint32_t t = threadIdx.x;
   const uint64_t L = (uint64_t)blockIdx.x * PO_THREADS + t;
-  const Fr z = po_arg(z_int);
+  const uint32_t* __restrict__ a = cols.in[blockIdx.y];
+  incl += (size_t)blockIdx.y * ((size_t)gridDim.x * PO_THREADS + 1) * 9;
+  wg_total += (size_t)blockIdx.y * gridDim.x * 9;
+  const Fr z = po_arg(pts.z[blockIdx.y]);
   const uint64_t lo = L * B, hi = lo + B < n ? lo + B : n;
   Fr acc = fe_zero<FrParams>();
   HM_DECLARE(acc, 0.0);
@@ -135,11 +150,13 @@ __global__ __launch_bounds__(PO_THREADS) void fr_kate_chunks_kernel(const uint32
 }
 
 // one workgroup: E_g = sum_{g' > g} W_g' Y^(g'-g-1), Y = z^(256 B)
-__global__ __launch_bounds__(PO_THREADS) void fr_kate_join_kernel(const uint32_t* __restrict__ wg_total, uint32_t G, PoFr z_int, uint32_t B,
+__global__ __launch_bounds__(PO_THREADS) void fr_kate_join_kernel(const uint32_t* __restrict__ wg_total, uint32_t G, PoPoints pts, uint32_t B,
                                                                   uint32_t* __restrict__ carry) {
   __shared__ uint32_t lds[9 * PO_THREADS];
   const uint32_t t = threadIdx.x;
-  Fr Y = po_pow_small(po_arg(z_int), B);
+  wg_total += (size_t)blockIdx.x * G * 9;                  // one joining workgroup per column
+  carry += (size_t)blockIdx.x * G * 9;
+  Fr Y = po_pow_small(po_arg(pts.z[blockIdx.x]), B);
 #pragma unroll 1
   for (int k = 0; k < 8; ++k) Y = fe_sqr(Y);
   Fr v = fe_zero<FrParams>();
@@ -149,15 +166,18 @@ __global__ __launch_bounds__(PO_THREADS) void fr_kate_join_kernel(const uint32_t
   if (t < G) po_store9(carry + (size_t)t * 9, v);
 }
 
-__global__ __launch_bounds__(PO_THREADS) void fr_kate_replay_kernel(const uint32_t* __restrict__ a, uint64_t n, PoFr z_int, uint32_t B,
-                                                                    const uint32_t* __restrict__ incl, const uint32_t* __restrict__ carry,
-                                                                    uint32_t* __restrict__ q) {
+__global__ __launch_bounds__(PO_THREADS) void fr_kate_replay_kernel(PoCols cols, uint64_t n, PoPoints pts, uint32_t B,
+                                                                    const uint32_t* __restrict__ incl, const uint32_t* __restrict__ carry) {
   const uint32_t t = threadIdx.x;
   const uint64_t L = (uint64_t)blockIdx.x * PO_THREADS + t;
   const uint64_t lo = L * B;
   if (lo + 1 >= n) return;                                  // q has n - 1 entries
   const uint64_t hi = lo + B < n ? lo + B : n;
-  const Fr z = po_arg(z_int);
+  const uint32_t* __restrict__ a = cols.in[blockIdx.y];
+  uint32_t* __restrict__ q = cols.out[blockIdx.y];
+  incl += (size_t)blockIdx.y * ((size_t)gridDim.x * PO_THREADS + 1) * 9;
+  carry += (size_t)blockIdx.y * gridDim.x * 9;
+  const Fr z = po_arg(pts.z[blockIdx.y]);
   // T_L = (inclusive value of the next lane in this workgroup) + y^(255 - t) * E_g
   Fr T = fe_mul(po_load9(carry + (size_t)blockIdx.x * 9, 3.0), po_pow_small(po_pow_small(z, B), PO_THREADS - 1 - t));
   if (t + 1 < PO_THREADS) T = fe_add(T, po_load9(incl + (L + 1) * 9, 3.0));
@@ -192,11 +212,14 @@ __device__ __forceinline__ Fr po_prefix_scan_product(uint32_t* lds, Fr v) {
   return v;
 }
 
-__global__ __launch_bounds__(PO_THREADS) void fr_product_chunks_kernel(const uint32_t* __restrict__ m, uint64_t n, PoFr k32_int, uint32_t B,
+__global__ __launch_bounds__(PO_THREADS) void fr_product_chunks_kernel(PoCols cols, uint64_t n, PoFr k32_int, uint32_t B,
                                                                        uint32_t* __restrict__ incl, uint32_t* __restrict__ wg_total) {
   __shared__ uint32_t lds[9 * PO_THREADS];
   const uint32_t t = threadIdx.x;
   const uint64_t L = (uint64_t)blockIdx.x * PO_THREADS + t;
+  const uint32_t* __restrict__ m = cols.in[blockIdx.y];
+  incl += (size_t)blockIdx.y * ((size_t)gridDim.x * PO_THREADS + 1) * 9;
+  wg_total += (size_t)blockIdx.y * gridDim.x * 9;
   const Fr k32 = po_arg(k32_int);
   const uint64_t lo = L * B, hi = lo + B < n ? lo + B : n;
   Fr p = fe_one<FrParams>();
@@ -206,25 +229,78 @@ __global__ __launch_bounds__(PO_THREADS) void fr_product_chunks_kernel(const uin
   if (t == PO_THREADS - 1) po_store9(wg_total + (size_t)blockIdx.x * 9, p);
 }
 
-// one workgroup: E_g = start_raw * prod_{g' < g} W_g'  ("external read as internal": the form the outputs are stored in)
-__global__ __launch_bounds__(PO_THREADS) void fr_product_join_kernel(const uint32_t* __restrict__ wg_total, uint32_t G, PoFr start_raw,
-                                                                     uint32_t* __restrict__ carry) {
+// How the columns of one call start.  `start_raw`: the external words of the caller's start value as 29-bit limbs
+// ("external read as internal": the form the outputs are stored in), or, when `d_start` is set, the external words at that
+// device address (a later group of a chained call starts from an element the previous group wrote).  chain_row == n:
+// every column starts from it.  chain_row < n: column j + 1 starts from out_j[chain_row] -- upstream's `last_z`
+// (permutation::keygen / prover: the z polynomial of a column set starts where the previous one stood at the last usable row).
+struct PoStart {
+  PoFr start_raw;
+  const uint32_t* d_start;
+  uint64_t chain_row;
+};
+
+__device__ __forceinline__ Fr po_start_value(const PoStart& st) {
+  if (st.d_start) {
+    Fr r = po_load_raw(st.d_start, 0);
+    HM_DECLARE(r, 6.0);
+    return r;
+  }
+  return po_arg(st.start_raw, 6.0);
+}
+
+// one workgroup per column: E_g = prod_{g' < g} W_g'.  Unchained: carry_g = start * E_g.  Chained: carry_g = E_g (true
+// internal), and the lane that owns the chain row's workgroup also leaves P = prod_{i < chain_row} m[i] in colprod --
+// fr_product_chain_kernel turns the P's of the columns before into this column's start.
+__global__ __launch_bounds__(PO_THREADS) void fr_product_join_kernel(PoCols cols, uint64_t n, PoFr k32_int, uint32_t B, uint32_t G,
+                                                                     const uint32_t* __restrict__ incl, const uint32_t* __restrict__ wg_total,
+                                                                     PoStart st, uint32_t* __restrict__ carry, uint32_t* __restrict__ colprod) {
   __shared__ uint32_t lds[9 * PO_THREADS];
   const uint32_t t = threadIdx.x;
+  incl += (size_t)blockIdx.x * ((size_t)G * PO_THREADS + 1) * 9;
+  wg_total += (size_t)blockIdx.x * G * 9;
+  carry += (size_t)blockIdx.x * G * 9;
   Fr v = fe_one<FrParams>();
   if (t >= 1 && t - 1 < G) v = po_load9(wg_total + (size_t)(t - 1) * 9, 2.0);   // exclusive: lane g ends at W_{g-1}
   v = po_prefix_scan_product(lds, v);
-  if (t < G) po_store9(carry + (size_t)t * 9, fe_mul(v, po_arg(start_raw, 6.0)));
+  const bool chained = st.chain_row < n;
+  if (t < G) po_store9(carry + (size_t)t * 9, chained ? v : fe_mul(v, po_start_value(st)));
+  if (chained) {
+    const uint64_t Lu = st.chain_row / B;                   // the lane whose chunk holds the chain row
+    if (t == (uint32_t)(Lu / PO_THREADS)) {
+      Fr P = v;
+      if (Lu % PO_THREADS) P = fe_mul(P, po_load9(incl + (Lu - 1) * 9, 2.0));
+      const uint32_t* __restrict__ m = cols.in[blockIdx.x];
+      const Fr k32 = po_arg(k32_int);
+      for (uint64_t i = Lu * B; i < st.chain_row; ++i) P = fe_mul(P, fe_mul(po_load_raw(m, i), k32));
+      po_store9(colprod + (size_t)blockIdx.x * 9, P);
+    }
+  }
 }
 
-__global__ __launch_bounds__(PO_THREADS) void fr_product_replay_kernel(const uint32_t* m, uint64_t n, PoFr k32_int, uint32_t B,
-                                                                       const uint32_t* __restrict__ incl, const uint32_t* __restrict__ carry,
-                                                                       uint32_t* out) {
+// chained columns only, one workgroup per column: start_j = start * prod_{j' < j} P_j', carry_g *= start_j
+__global__ __launch_bounds__(PO_THREADS) void fr_product_chain_kernel(uint32_t G, PoStart st, const uint32_t* __restrict__ colprod,
+                                                                      uint32_t* __restrict__ carry) {
+  const uint32_t t = threadIdx.x;
+  if (t >= G) return;
+  carry += (size_t)blockIdx.x * G * 9;
+  Fr s = po_start_value(st);
+#pragma unroll 1
+  for (uint32_t j = 0; j < blockIdx.x; ++j) s = fe_mul(po_load9(colprod + (size_t)j * 9, 2.0), s);
+  po_store9(carry + (size_t)t * 9, fe_mul(po_load9(carry + (size_t)t * 9, 2.0), s));
+}
+
+__global__ __launch_bounds__(PO_THREADS) void fr_product_replay_kernel(PoCols cols, uint64_t n, PoFr k32_int, uint32_t B,
+                                                                       const uint32_t* __restrict__ incl, const uint32_t* __restrict__ carry) {
   const uint32_t t = threadIdx.x;
   const uint64_t L = (uint64_t)blockIdx.x * PO_THREADS + t;
   const uint64_t lo = L * B;
   if (lo >= n) return;
   const uint64_t hi = lo + B < n ? lo + B : n;
+  const uint32_t* m = cols.in[blockIdx.y];
+  uint32_t* out = cols.out[blockIdx.y];
+  incl += (size_t)blockIdx.y * ((size_t)gridDim.x * PO_THREADS + 1) * 9;
+  carry += (size_t)blockIdx.y * gridDim.x * 9;
   const Fr k32 = po_arg(k32_int);
   Fr cur = po_load9(carry + (size_t)blockIdx.x * 9, 2.0);
   if (t > 0) cur = fe_mul(cur, po_load9(incl + (L - 1) * 9, 2.0));
@@ -389,55 +465,106 @@ static PoPlan po_plan(uint64_t n) {
   return p;
 }
 
-// scratch of a scan: inclusive values of G * 256 lanes (+ one guard lane), G workgroup totals, G carries
-static uint32_t* po_scratch(AuxSlot* slot, const PoPlan& p, uint32_t** wg_total, uint32_t** carry) {
+// scratch of `cols` scans: per column the inclusive values of G * 256 lanes (+ one guard lane), then per column G workgroup
+// totals, then G carries, then one column product each (chained grand products)
+struct PoScratch {
+  uint32_t *incl, *wg_total, *carry, *colprod;
+};
+static bool po_scratch(AuxSlot* slot, const PoPlan& p, size_t cols, PoScratch* out) {
   const size_t lanes = (size_t)p.G * PO_THREADS + 1;
-  const size_t need = (lanes + 2 * (size_t)p.G) * 36;
+  const size_t need = cols * (lanes + 2 * (size_t)p.G + 1) * 36;
   const size_t keep = (size_t)64 * 15 * 28 * 4;             // never shrink below the fixed-base table (see poly.hip)
   uint8_t* buf = (uint8_t*)slot->table.ensure(need > keep ? need : keep);
-  if (!buf) return nullptr;
-  *wg_total = (uint32_t*)(buf + lanes * 36);
-  *carry = *wg_total + (size_t)p.G * 9;
-  return (uint32_t*)buf;
+  if (!buf) return false;
+  out->incl = (uint32_t*)buf;
+  out->wg_total = out->incl + cols * lanes * 9;
+  out->carry = out->wg_total + cols * (size_t)p.G * 9;
+  out->colprod = out->carry + cols * (size_t)p.G * 9;
+  return true;
 }
 
-int fr_kate_division_run(DeviceCtx& ctx, const uint32_t* d_a, uint64_t n, const uint64_t z_ext[4], uint32_t* d_q, hipStream_t stream) {
-  if (n < 2) return HM_OK;                                   // a constant has the empty quotient
+// `count` independent divisions of n-coefficient polynomials, each by its own point, PO_COLS_MAX per launch chain
+int fr_kate_division_batch_run(DeviceCtx& ctx, const void* const* d_a, uint64_t n, const uint64_t* z_ext, void* const* d_q, size_t count,
+                               hipStream_t stream) {
+  if (n < 2 || count == 0) return HM_OK;                     // a constant has the empty quotient
   const PoPlan p = po_plan(n);
   if (p.G > PO_THREADS) return hm_fail(HM_ERR_INTERNAL, "kate_division: plan exceeds one joining workgroup");
   AuxSlot* slot = aux_acquire(ctx, stream);
   if (!slot) return HM_ERR_HIP;
-  uint32_t *wg_total, *carry;
-  uint32_t* incl = po_scratch(slot, p, &wg_total, &carry);
-  if (!incl) return hm_fail(HM_ERR_HIP, "kate_division: scratch allocation failed");
-  PoFr z;
-  po_internal(z_ext, z);
-  hipLaunchKernelGGL(fr_kate_chunks_kernel, dim3(p.G), dim3(PO_THREADS), 0, stream, d_a, n, z, p.B, incl, wg_total);
-  hipLaunchKernelGGL(fr_kate_join_kernel, dim3(1), dim3(PO_THREADS), 0, stream, (const uint32_t*)wg_total, p.G, z, p.B, carry);
-  hipLaunchKernelGGL(fr_kate_replay_kernel, dim3(p.G), dim3(PO_THREADS), 0, stream, d_a, n, z, p.B, (const uint32_t*)incl,
-                     (const uint32_t*)carry, d_q);
+  PoScratch sc;
+  const size_t per = count < (size_t)PO_COLS_MAX ? count : (size_t)PO_COLS_MAX;
+  if (!po_scratch(slot, p, per, &sc)) return hm_fail(HM_ERR_HIP, "kate_division: scratch allocation failed");
+  for (size_t first = 0; first < count; first += per) {
+    const uint32_t c = (uint32_t)(count - first < per ? count - first : per);
+    PoCols cols;
+    PoPoints pts;
+    std::memset(&cols, 0, sizeof cols);
+    std::memset(&pts, 0, sizeof pts);
+    for (uint32_t j = 0; j < c; ++j) {
+      cols.in[j] = (const uint32_t*)d_a[first + j];
+      cols.out[j] = (uint32_t*)d_q[first + j];
+      po_internal(z_ext + (first + j) * 4, pts.z[j]);
+    }
+    hipLaunchKernelGGL(fr_kate_chunks_kernel, dim3(p.G, c), dim3(PO_THREADS), 0, stream, cols, n, pts, p.B, sc.incl, sc.wg_total);
+    hipLaunchKernelGGL(fr_kate_join_kernel, dim3(c), dim3(PO_THREADS), 0, stream, (const uint32_t*)sc.wg_total, p.G, pts, p.B, sc.carry);
+    hipLaunchKernelGGL(fr_kate_replay_kernel, dim3(p.G, c), dim3(PO_THREADS), 0, stream, cols, n, pts, p.B, (const uint32_t*)sc.incl,
+                       (const uint32_t*)sc.carry);
+  }
+  HM_HIP_CHECK(hipGetLastError());
+  return aux_release(ctx, slot, stream);
+}
+
+int fr_kate_division_run(DeviceCtx& ctx, const uint32_t* d_a, uint64_t n, const uint64_t z_ext[4], uint32_t* d_q, hipStream_t stream) {
+  const void* a = d_a;
+  void* q = d_q;
+  return fr_kate_division_batch_run(ctx, &a, n, z_ext, &q, 1, stream);
+}
+
+// `count` running products over n rows; chain_row >= n: every column starts from `start`; chain_row < n: column j + 1 starts
+// from out_j[chain_row] (PoStart).  PO_COLS_MAX columns per launch chain; a later group of a chained call reads its start
+// from the element the group before wrote (stream order).
+int fr_grand_product_batch_run(DeviceCtx& ctx, const void* const* d_m, uint64_t n, const uint64_t start_ext[4], uint64_t chain_row,
+                               void* const* d_out, size_t count, hipStream_t stream) {
+  if (n == 0 || count == 0) return HM_OK;
+  const PoPlan p = po_plan(n);
+  if (p.G > PO_THREADS) return hm_fail(HM_ERR_INTERNAL, "grand_product: plan exceeds one joining workgroup");
+  AuxSlot* slot = aux_acquire(ctx, stream);
+  if (!slot) return HM_ERR_HIP;
+  PoScratch sc;
+  const size_t per = count < (size_t)PO_COLS_MAX ? count : (size_t)PO_COLS_MAX;
+  if (!po_scratch(slot, p, per, &sc)) return hm_fail(HM_ERR_HIP, "grand_product: scratch allocation failed");
+  PoFr k32;
+  host::fr_to_internal9(host::FR_32, k32.l);
+  const bool chained = chain_row < n;
+  PoStart st;
+  std::memset(&st, 0, sizeof st);
+  po_raw(start_ext, st.start_raw);
+  st.chain_row = chained ? chain_row : n;
+  for (size_t first = 0; first < count; first += per) {
+    const uint32_t c = (uint32_t)(count - first < per ? count - first : per);
+    PoCols cols;
+    std::memset(&cols, 0, sizeof cols);
+    for (uint32_t j = 0; j < c; ++j) {
+      cols.in[j] = (const uint32_t*)d_m[first + j];
+      cols.out[j] = (uint32_t*)d_out[first + j];
+    }
+    st.d_start = chained && first ? (const uint32_t*)d_out[first - 1] + chain_row * 8 : nullptr;
+    hipLaunchKernelGGL(fr_product_chunks_kernel, dim3(p.G, c), dim3(PO_THREADS), 0, stream, cols, n, k32, p.B, sc.incl, sc.wg_total);
+    hipLaunchKernelGGL(fr_product_join_kernel, dim3(c), dim3(PO_THREADS), 0, stream, cols, n, k32, p.B, p.G, (const uint32_t*)sc.incl,
+                       (const uint32_t*)sc.wg_total, st, sc.carry, sc.colprod);
+    if (chained)
+      hipLaunchKernelGGL(fr_product_chain_kernel, dim3(c), dim3(PO_THREADS), 0, stream, p.G, st, (const uint32_t*)sc.colprod, sc.carry);
+    hipLaunchKernelGGL(fr_product_replay_kernel, dim3(p.G, c), dim3(PO_THREADS), 0, stream, cols, n, k32, p.B, (const uint32_t*)sc.incl,
+                       (const uint32_t*)sc.carry);
+  }
   HM_HIP_CHECK(hipGetLastError());
   return aux_release(ctx, slot, stream);
 }
 
 int fr_grand_product_run(DeviceCtx& ctx, const uint32_t* d_m, uint64_t n, const uint64_t start_ext[4], uint32_t* d_out, hipStream_t stream) {
-  if (n == 0) return HM_OK;
-  const PoPlan p = po_plan(n);
-  if (p.G > PO_THREADS) return hm_fail(HM_ERR_INTERNAL, "grand_product: plan exceeds one joining workgroup");
-  AuxSlot* slot = aux_acquire(ctx, stream);
-  if (!slot) return HM_ERR_HIP;
-  uint32_t *wg_total, *carry;
-  uint32_t* incl = po_scratch(slot, p, &wg_total, &carry);
-  if (!incl) return hm_fail(HM_ERR_HIP, "grand_product: scratch allocation failed");
-  PoFr k32, start;
-  host::fr_to_internal9(host::FR_32, k32.l);
-  po_raw(start_ext, start);
-  hipLaunchKernelGGL(fr_product_chunks_kernel, dim3(p.G), dim3(PO_THREADS), 0, stream, d_m, n, k32, p.B, incl, wg_total);
-  hipLaunchKernelGGL(fr_product_join_kernel, dim3(1), dim3(PO_THREADS), 0, stream, (const uint32_t*)wg_total, p.G, start, carry);
-  hipLaunchKernelGGL(fr_product_replay_kernel, dim3(p.G), dim3(PO_THREADS), 0, stream, d_m, n, k32, p.B, (const uint32_t*)incl,
-                     (const uint32_t*)carry, d_out);
-  HM_HIP_CHECK(hipGetLastError());
-  return aux_release(ctx, slot, stream);
+  const void* m = d_m;
+  void* o = d_out;
+  return fr_grand_product_batch_run(ctx, &m, n, start_ext, n, &o, 1, stream);
 }
 
 int fr_batch_invert_run(uint32_t* d_v, uint64_t n, hipStream_t stream) {

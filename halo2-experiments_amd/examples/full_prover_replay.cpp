@@ -171,8 +171,8 @@ int main(int argc, char** argv) {
     // the prover's polynomial buffers live for the whole proof (as halo2's Vec<Polynomial> do)
     poly::DevicePolys batch(n, 8), ext(dom.extended_len(), 8), hpoly(dom.extended_len(), 1);
     const size_t n_z = zp + lookups, usable = n - 7;
-    poly::DevicePolys z_fac(n, n_z ? n_z : 1), z_col(n, 1), lk_in(n, 1), lk_tab(n, 1), lk_out(n, lookups ? 2 * lookups : 1), open_acc(n, 5),
-        open_q(n, 1);
+    poly::DevicePolys z_fac(n, n_z ? n_z : 1), z_col(n, n_z ? n_z : 1), lk_in(n, 1), lk_tab(n, 1), lk_out(n, lookups ? 2 * lookups : 1), open_acc(n, 5),
+        open_q(n, 5);
     {
       std::vector<Fr> fac(n * (n_z ? n_z : 1)), tab(n), inp(n);
       for (auto& x : fac) x = random_fr(rng);
@@ -186,7 +186,16 @@ int main(int argc, char** argv) {
     auto vector_steps = [&]() {
       // the z columns of the permutation and lookup arguments: all denominators inverted in one call, then the products
       if (n_z) arithmetic::batch_invert(z_fac.d, n * n_z);
-      for (size_t i = 0; i < n_z; ++i) arithmetic::grand_product(z_fac.poly(i), n, Fr::one(), z_col.d);
+      // (permutation: each column set starts where the one before stood at the last usable row -- upstream's last_z, chained
+      // on the device; lookups: one independent product each)
+      std::vector<const Fr*> pf, lf;
+      std::vector<Fr*> po, lo;
+      for (size_t i = 0; i < n_z; ++i) {
+        (i < zp ? pf : lf).push_back(z_fac.poly(i));
+        (i < zp ? po : lo).push_back(z_col.poly(i));
+      }
+      if (!pf.empty()) arithmetic::grand_product_batch(pf, n, Fr::one(), usable, po);
+      if (!lf.empty()) arithmetic::grand_product_batch(lf, n, Fr::one(), HM_NO_CHAIN, lo);
       // the permuted columns of every lookup argument, one call
       if (lookups) {
         std::vector<const void*> ins(lookups, lk_in.d), tabs(lookups, lk_tab.d);
@@ -207,7 +216,17 @@ int main(int argc, char** argv) {
         std::vector<Fr> cs(cnt, s);
         arithmetic::linear_combination(ps, cs, n, open_acc.poly(si));
       }
-      for (size_t qi = 0; qi < 5; ++qi) arithmetic::kate_division(open_acc.poly(qi % 4), n, s + Fr::from_u64(qi + 2), open_q.d);
+      {
+        std::vector<const Fr*> ps;
+        std::vector<Fr*> qs;
+        std::vector<Fr> zs;
+        for (size_t qi = 0; qi < 5; ++qi) {
+          ps.push_back(open_acc.poly(qi % 4));
+          qs.push_back(open_q.poly(qi));
+          zs.push_back(s + Fr::from_u64(qi + 2));
+        }
+        arithmetic::kate_division_batch(ps, n, zs, qs);       // the openings of one round are independent of each other
+      }
       arithmetic::linear_combination({open_acc.poly(0), open_acc.poly(1), open_acc.poly(2), open_acc.poly(3)}, {s, s, s, s}, n, open_acc.poly(4));
       arithmetic::kate_division(open_acc.poly(4), n, s + Fr::one(), open_q.d);
     };

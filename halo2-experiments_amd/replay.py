@@ -42,7 +42,7 @@ from typing import Optional
 import numpy as np
 
 from .arithmetic import (G1_GENERATOR, batch_invert, best_multiexp, best_multiexp_submit, best_multiexp_wait, eval_polynomial,
-                         g1_fixed_base_mul, grand_product, kate_division, linear_combination, permute_expression_pairs, register_bases,
+                         g1_fixed_base_mul, grand_product_batch, kate_division, kate_division_batch, linear_combination, permute_expression_pairs, register_bases,
                          release_bases)
 from .domain import EvaluationDomain, FR_MODULUS, fr_words
 from .kzg import ParamsKZG
@@ -201,7 +201,7 @@ def run_replay(shape_name: str, device=None, group=None, include_host_pointer_es
     open_coeffs = np.stack([fr_words(pow(REPLAY_S, 17 + j, FR_MODULUS)) for j in range(max(n_open_polys, 4))])
     open_acc = torch.empty((5, n, 4), dtype=torch.int64, device=device)
     z_factors = _rand_fr((zp + L) * n, 400, device).reshape(zp + L, n, 4)
-    z_column = torch.empty((n, 4), dtype=torch.int64, device=device)
+    z_columns = torch.empty((zp + L, n, 4), dtype=torch.int64, device=device)
     # a range-check lookup: the table holds 0 .. 2^16 - 1 (repeated), the input column values of that range
     lookup_table = torch.zeros((n, 4), dtype=torch.int64, device=device)
     lookup_table[:, 0] = torch.arange(n, device=device) % min(n - 7, 1 << 16)
@@ -273,8 +273,12 @@ def run_replay(shape_name: str, device=None, group=None, include_host_pointer_es
         t0 = time.perf_counter()
         if rank == 0:
             batch_invert(z_factors)                 # the denominators of all z columns are independent: one call
-            for i in range(zp + L):                   # the products chain (each starts from the previous column's last value)
-                grand_product(z_factors[i], fr_words(1), out=z_column)
+            # permutation: each column set starts where the one before stood at the last usable row (upstream's last_z),
+            # chained on the device; lookups: one independent product each.  Two launch chains in all.
+            if zp:
+                grand_product_batch(list(z_factors[:zp]), fr_words(1), chain_row=n - 7, outs=list(z_columns[:zp]))
+            if L:
+                grand_product_batch(list(z_factors[zp:]), fr_words(1), outs=list(z_columns[zp:]))
         torch.cuda.synchronize()
         t["grand_products"] = time.perf_counter() - t0
         t0 = time.perf_counter()
@@ -290,8 +294,8 @@ def run_replay(shape_name: str, device=None, group=None, include_host_pointer_es
             for si in range(4):
                 cnt = min(per_set, n_open_polys - si * per_set)
                 sets.append(linear_combination([ntt_batch[j % 8] for j in range(cnt)], open_coeffs[:cnt], out=open_acc[si]))
-            for qi in range(5):
-                kate_division(sets[qi % 4], fr_words(pow(REPLAY_S, 5 + qi, FR_MODULUS)))
+            # the openings of one round are independent of each other: one launch chain
+            kate_division_batch([sets[qi % 4] for qi in range(5)], [fr_words(pow(REPLAY_S, 5 + qi, FR_MODULUS)) for qi in range(5)])
             fin = linear_combination(sets, open_coeffs[:4], out=open_acc[4])
             kate_division(fin, fr_words(pow(REPLAY_S, 11, FR_MODULUS)))
         torch.cuda.synchronize()

@@ -231,10 +231,29 @@ int hm_eval_polynomial_bn256_fr_dev(const void* d_polys, size_t n, const uint32_
  * nothing.  Asynchronous on `stream`. */
 int hm_kate_division_bn256_fr_dev(const void* d_poly, size_t n, const uint64_t z[4], void* d_quotient, void* stream);
 
+/* `count` such divisions in one launch chain (the quotients one multiopen round builds are independent of each other):
+ * d_polys / d_quotients: host arrays of `count` device pointers (n resp. n - 1 coefficients each), z: host, count x 4
+ * u64, one point per polynomial.  No quotient may overlap any polynomial of the call.  Same results as `count` calls of
+ * the form above.  Asynchronous on `stream`. */
+int hm_kate_division_batch_bn256_fr_dev(const void* const* d_polys, size_t n, const uint64_t* z, void* const* d_quotients, size_t count,
+                                        void* stream);
+
 /* The running products of the permutation and lookup arguments (upstream plonk/permutation/prover.rs and
  * plonk/lookup/prover.rs: z[0] = start, z[row] = z[row - 1] * factors[row - 1]): d_out[i] = start * prod_{j < i}
  * d_factors[j] for i < n.  d_out may be d_factors itself.  Asynchronous on `stream`. */
 int hm_fr_grand_product_dev(const void* d_factors, size_t n, const uint64_t start[4], void* d_out, void* stream);
+
+/* The z columns of one argument in one launch chain.  d_factors / d_out: host arrays of `count` device pointers (n
+ * elements each; d_out[j] may be d_factors[j] itself, and must not overlap any other column of the call).
+ *   chain_row >= n (HM_NO_CHAIN): every column starts from `start` -- the lookup arguments' products (upstream
+ *     plonk/lookup/prover.rs, one z per lookup, each from 1);
+ *   chain_row <  n: column 0 starts from `start` and column j + 1 from d_out[j][chain_row] -- upstream's `last_z`
+ *     (plonk/permutation/prover.rs: the z of a column set starts where the set before stood at the last usable row,
+ *     chain_row = n - (blinding_factors + 1)); nothing is read back between the columns.
+ * Same results as `count` calls of the form above made in order.  Asynchronous on `stream`. */
+#define HM_NO_CHAIN ((size_t)-1)
+int hm_fr_grand_product_batch_dev(const void* const* d_factors, size_t n, const uint64_t start[4], size_t chain_row, void* const* d_out,
+                                  size_t count, void* stream);
 
 /* ff::BatchInvert::batch_invert on n device-resident elements, in place: every non-zero element is replaced by its
  * inverse, zero stays zero (the denominators of the grand products above).  Asynchronous on `stream`. */

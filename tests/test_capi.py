@@ -69,6 +69,8 @@ def test_device_pointer_entry_points_without_a_device():
     zp = z.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64))
     assert lib.hm_kate_division_bn256_fr_dev(None, 8, zp, None, None) == -1
     assert lib.hm_fr_grand_product_dev(None, 8, zp, None, None) == -1
+    assert lib.hm_kate_division_batch_bn256_fr_dev(None, 8, zp, None, 2, None) == -1
+    assert lib.hm_fr_grand_product_batch_dev(None, 8, zp, 3, None, 2, None) == -1
     assert lib.hm_fr_batch_invert_dev(None, 8, None) == -1
     assert lib.hm_fr_linear_combination_dev(None, None, 2, 8, None, None) == -1
     assert lib.hm_lookup_permute_bn256_fr_dev(None, None, 8, None, None, None) == -1
@@ -79,6 +81,11 @@ def test_device_pointer_entry_points_without_a_device():
     fake = ctypes.c_void_p(0x1000)                        # never dereferenced: the device check comes first
     assert lib.hm_kate_division_bn256_fr_dev(fake, 8, zp, ctypes.c_void_p(0x100000), None) == -2
     assert lib.hm_fr_grand_product_dev(fake, 8, zp, fake, None) == -2
+    two = (ctypes.c_void_p * 2)(0x1000, 0x2000)
+    far = (ctypes.c_void_p * 2)(0x100000, 0x200000)
+    zz = np.zeros(8, dtype=np.uint64).ctypes.data_as(ctypes.POINTER(ctypes.c_uint64))
+    assert lib.hm_kate_division_batch_bn256_fr_dev(two, 8, zz, far, 2, None) == -2
+    assert lib.hm_fr_grand_product_batch_dev(two, 8, zp, 3, far, 2, None) == -2
     assert lib.hm_fr_batch_invert_dev(fake, 8, None) == -2
     assert lib.hm_lookup_permute_bn256_fr_dev(fake, fake, 8, fake, fake, None) == -2
     assert b"no CPU fallback" in lib.hm_last_error()

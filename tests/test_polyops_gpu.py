@@ -216,3 +216,87 @@ def test_call_counters_cover_the_vector_entry_points(pyref):
     got = {k: (st.vector_calls[i], st.vector_elements[i]) for i, k in enumerate(_lib.Stats.KINDS)}
     assert got == {"eval_polynomial": (2, 2000), "graph_evaluate": (0, 0), "kate_division": (1, 1000), "grand_product": (1, 1000),
                    "batch_invert": (1, 1000), "linear_combination": (1, 2000), "lookup_permute": (2, 1980)}
+
+
+# ---- the batched forms: several columns in one launch chain -------------------------------------------------------
+@pytest.mark.parametrize("n,count", [(1, 3), (5, 2), (257, 5), (4099, 16), (4099, 17), ((1 << 16) + 1, 4), ((1 << 18) + 7, 3), (1000, 35)])
+def test_kate_division_batch_equals_the_calls_one_by_one(pyref, n, count):
+    """Same words as hm_kate_division_bn256_fr_dev column by column (itself checked against the oracle above), and
+    against the oracle directly where that takes seconds; counts above 16 take several launch groups."""
+    rng = random.Random(n * 31 + count)
+    polys = [rand_fr_gpu(n, 7000 + 13 * j + n) for j in range(count)]
+    zs = [rng.choice([0, 1, R - 1, rng.randrange(R)]) for _ in range(count)]
+    got = h.kate_division_batch(polys, [fr_words(z) for z in zs])
+    assert len(got) == count
+    for j in range(count):
+        one = h.kate_division(polys[j], fr_words(zs[j]))
+        assert got[j].shape == (n - 1, 4) and bool((got[j] == one).all()), (n, j)
+    if n <= 4099:
+        for j in (0, count - 1):
+            assert from_gpu(pyref, got[j]) == pr.kate_division(from_gpu(pyref, polys[j]), zs[j])
+
+
+@pytest.mark.parametrize("n,count", [(1, 3), (4, 2), (5, 2), (257, 5), (4099, 16), (4099, 18), ((1 << 16) + 1, 4), ((1 << 18) + 7, 3), (1000, 33)])
+def test_grand_product_batch_unchained(pyref, n, count):
+    rng = random.Random(n * 17 + count)
+    start = rng.randrange(1, R)
+    cols = [rand_fr_gpu(n, 9000 + 7 * j + n) for j in range(count)]
+    got = h.grand_product_batch(cols, fr_words(start))
+    for j in range(count):
+        assert bool((got[j] == h.grand_product(cols[j], fr_words(start))).all()), (n, j)
+    if n <= 4099:
+        assert from_gpu(pyref, got[-1]) == pr.grand_product(from_gpu(pyref, cols[-1]), start)
+    keep = [c.clone() for c in cols]
+    h.grand_product_batch(cols, fr_words(start), outs=cols)             # in place
+    for j in range(count):
+        assert bool((cols[j] == got[j]).all()) and not bool((keep[j] == cols[j]).all()) or n == 1
+
+
+@pytest.mark.parametrize("n,count,u", [(1, 3, 0), (8, 4, 0), (8, 4, 7), (300, 5, 293), (4099, 16, 4092), (4099, 20, 1), (4099, 37, 4098),
+                                       ((1 << 16) + 1, 3, 1 << 16), ((1 << 18), 11, (1 << 18) - 6), ((1 << 18) + 7, 2, 255 * 1028 + 3)])
+def test_grand_product_batch_chained_is_the_last_z_recurrence(pyref, n, count, u):
+    """Upstream's permutation prover: z_{j+1}[0] = z_j[u], u = n - (blinding_factors + 1).  Checked against the single-column
+    form fed with the previous column's element read back, and against the oracle at small sizes."""
+    rng = random.Random(n + count + u)
+    start = rng.randrange(1, R)
+    cols = [rand_fr_gpu(n, 11000 + 5 * j + n) for j in range(count)]
+    got = h.grand_product_batch(cols, fr_words(start), chain_row=u)
+    st = fr_words(start)
+    for j in range(count):
+        one = h.grand_product(cols[j], st)
+        assert bool((got[j] == one).all()), (n, j)
+        st = one[u].cpu().numpy().view(np.uint64)
+    if n <= 4099:
+        s, want = start, None
+        for j in range(count):
+            want = pr.grand_product(from_gpu(pyref, cols[j]), s)
+            s = want[u]
+        assert from_gpu(pyref, got[-1]) == want
+    outs = h.grand_product_batch(cols, fr_words(start), chain_row=u, outs=cols)   # in place: the chain reads factors, not outputs
+    for j in range(count):
+        assert bool((outs[j] == got[j]).all())
+
+
+def test_batched_scans_reject_bad_calls(pyref):
+    import torch
+    lib = _lib.load()
+    a, b = rand_fr_gpu(64, 1), rand_fr_gpu(64, 2)
+    with pytest.raises(ValueError):
+        h.grand_product_batch([a, b[:32]], fr_words(1))
+    with pytest.raises(ValueError):
+        h.grand_product_batch([a, b], fr_words(1), chain_row=64)
+    with pytest.raises(ValueError):
+        h.kate_division_batch([a, b], [fr_words(1)])
+    assert h.kate_division_batch([], []) == [] and h.grand_product_batch([], fr_words(1)) == []
+    # one column's output over another column's factors
+    ptrs = (ctypes.c_void_p * 2)(a.data_ptr(), b.data_ptr())
+    outs = (ctypes.c_void_p * 2)(b.data_ptr(), a.data_ptr())
+    one = fr_words(1).ctypes.data_as(ctypes.POINTER(ctypes.c_uint64))
+    assert lib.hm_fr_grand_product_batch_dev(ptrs, 64, one, _lib.NO_CHAIN, outs, 2, None) == -1
+    zz = np.stack([fr_words(3), fr_words(4)])
+    assert lib.hm_kate_division_batch_bn256_fr_dev(ptrs, 64, zz.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), ptrs, 2, None) == -1
+    q = torch.empty((126, 4), dtype=torch.int64, device="cuda")
+    both = (ctypes.c_void_p * 2)(q.data_ptr(), q.data_ptr() + 32)      # two quotients over each other
+    assert lib.hm_kate_division_batch_bn256_fr_dev(ptrs, 64, zz.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), both, 2, None) == -1
+    assert lib.hm_fr_grand_product_batch_dev(None, 64, one, _lib.NO_CHAIN, outs, 2, None) == -1
+    assert lib.hm_fr_grand_product_batch_dev(ptrs, 0, one, _lib.NO_CHAIN, outs, 2, None) == 0     # nothing to do
