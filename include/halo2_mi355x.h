@@ -68,7 +68,11 @@ const char* hm_version(void);
  * digest of the WHOLE base array (every word, 256 bits) and its length match -- never by pointer: a buffer
  * mutated at any index, or re-allocated at the same address with other contents, is uploaded again
  * (hm_set_host_base_cache(0) turns the reuse off altogether).  A caller that owns a long-lived base array --
- * ParamsKZG::g / g_lagrange -- still does best to register it once (below): that skips the digest too. */
+ * ParamsKZG::g / g_lagrange -- still does best to register it once (below): that skips the digest too.
+ * Largest call (every MSM form, per device): n * windows < 2^31 (point, window) item slots -- 2^27 points (12 windows
+ * with the fixed-base table, 15 without); above that HM_ERR_BAD_ARG with a message, nothing computed.  A larger sum is
+ * the hm_g1_sum of several calls over index ranges, or a split over devices (hm_set_msm_devices).  BASELINE's largest
+ * configuration is 2^26. */
 int hm_msm_bn256_g1(const uint64_t* scalars, const uint64_t* bases, size_t n, uint64_t out_xy[8], int* out_is_identity);
 
 /* Same, Jacobian output (x, y, 1) / (0, 0, 0): the `C::Curve` value itself. */

@@ -873,7 +873,7 @@ def test_vector_load_sort_at_odd_sizes_and_with_zero_digits(cref, n):
         _lib.check(lib.hm_set_fixed_base_threshold(17))
 
 
-@pytest.mark.parametrize("log_n", [12, 18, 22, 24])
+@pytest.mark.parametrize("log_n", [12, 18, 22, 24, 27])
 def test_geometric_known_answer_needs_neither_oracle_nor_the_dot_product_kernel(pyref, log_n):
     """A full-size known answer in which the only shared code is the affine group law of Python integers: scalars s_i = c^i,
     bases P_i = [d^i]G, so sum_i s_i P_i = [((c d)^n - 1) / (c d - 1)]G.  The expected point is one Python double-and-add of the
@@ -901,6 +901,7 @@ def test_geometric_known_answer_needs_neither_oracle_nor_the_dot_product_kernel(
     cd = c * d % o.R
     total = (pow(cd, n, o.R) - 1) * pow(cd - 1, -1, o.R) % o.R
     want = o.g1_affine_array([o.g1_mul(total, o.G1_GEN)])[0]
+    # (2^27 is the largest call the library takes: n * windows < 2^31 item slots, include/halo2_mi355x.h; 15 windows plain, 12 table)
     assert g1_equal(h.best_multiexp(s, bases), want)                     # a transient set: the plain layout
     if log_n >= 17:
         hd = h.register_bases(bases)                                     # ... and the fixed-base table
@@ -955,6 +956,34 @@ def test_batch_from_host_arrays_equals_the_device_batch(cref, log_n):
         assert np.array_equal(dev[1], one)
     finally:
         h.release_bases(hd)
+
+
+def test_a_call_above_the_item_limit_is_refused_not_truncated():
+    """n * windows must stay below 2^31 (the sort's 32-bit item slots): 2^28 points are refused with HM_ERR_BAD_ARG and a message,
+    in the synchronous and the asynchronous form -- never a wrapped index.  (Bases and scalars are zeros: identity points are legal
+    bases, and nothing is computed.)  A larger commitment is the sum of several calls (hm_g1_sum) or a split over devices."""
+    import ctypes
+    import torch
+    lib = _lib.load()
+    n = 1 << 28
+    free, _ = torch.cuda.mem_get_info()
+    if free < 40 << 30:
+        pytest.skip("needs 26 GiB of device memory for the operands alone")
+    bases = torch.zeros((n, 8), dtype=torch.int64, device="cuda")
+    scal = torch.zeros((n, 4), dtype=torch.int64, device="cuda")
+    hd = h.register_bases(bases)
+    try:
+        assert h.bases_info(hd)["table_windows"] == 0                   # the default table would not fit the limit either: plain layout
+        with pytest.raises(RuntimeError, match=r"2\^31"):
+            h.best_multiexp(scal, hd)
+        with pytest.raises(RuntimeError, match=r"2\^31"):
+            h.best_multiexp_wait(h.best_multiexp_submit(scal, hd))
+        half = h.best_multiexp(scal[: n // 2], hd)                      # 2^27 of them are fine (all identity: the identity)
+        assert not half.any()
+    finally:
+        h.release_bases(hd)
+        del bases, scal
+        torch.cuda.empty_cache()
 
 
 def test_config5_size_2_26_fits_one_gpu_and_is_additive():
