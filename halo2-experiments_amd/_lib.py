@@ -87,6 +87,8 @@ _SIGNATURES = {
     "hm_g1_sum": (ctypes.c_int, [_u64p, ctypes.c_size_t, _u64p]),
     "hm_coeff_to_extended_bn256_fr_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, _u64p, ctypes.c_uint32,
                                                          ctypes.c_uint32, _u64p, ctypes.c_void_p]),
+    "hm_coeff_to_coset_bn256_fr_dev": (ctypes.c_int, [_vp, _vp, ctypes.c_size_t, _u64p, ctypes.c_uint32, _u64p, ctypes.c_int, _vp]),
+    "hm_coset_to_coeff_bn256_fr_dev": (ctypes.c_int, [_vp, ctypes.c_size_t, _u64p, ctypes.c_uint32, _u64p, _u64p, _vp]),
     "hm_msm_set_window": (ctypes.c_int, [ctypes.c_int]),
     "hm_msm_set_phase_timing": (ctypes.c_int, [ctypes.c_int]),
     "hm_set_host_base_cache": (ctypes.c_int, [ctypes.c_int]),

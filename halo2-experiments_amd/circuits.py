@@ -22,7 +22,7 @@ from __future__ import annotations
 from dataclasses import dataclass, field
 from typing import Callable, Dict, List, Sequence, Tuple
 
-from .evaluation import (Advice, Constant, Expression, Fixed, GraphEvaluator, Instance, Negated, Product, Scaled, Sum,
+from .evaluation import (Advice, Challenge, Constant, Expression, Fixed, GraphEvaluator, Instance, Negated, Product, Scaled, Sum,
                          lookup_expressions, permutation_expressions)
 from .domain import FR_MODULUS
 
@@ -266,9 +266,12 @@ class EvaluateHLayout:
     short_columns: Dict[int, int] = field(default_factory=dict)
 
 
-def evaluate_h_program(cs: ConstraintSystem, k: int, extended_k: int, delta: int, with_arguments: bool = True):
+def evaluate_h_program(cs: ConstraintSystem, k: int, extended_k: int, delta: int, with_arguments: bool = True, per_coset: bool = False):
     """GraphEvaluator for evaluate_h of `cs`: the custom gates, then (with_arguments) the permutation argument over the
     equality columns, every lookup argument, and divide_by_vanishing_poly as the last multiplication.
+    per_coset: the program for ONE coset of the n-th roots inside the extended domain (EvaluationDomain.coeff_to_coset;
+    compile with rot_scale = 1, evaluate over 2^k rows): 1 / (X^n - 1) is a single constant there and enters as Challenge(0)
+    (compile with num_challenges = 1; the t_inv entry of the column table stays, unread).
     -> (GraphEvaluator, EvaluateHLayout)."""
     nf = cs.num_fixed
     P, nsets, L = len(cs.equality), cs.permutation_sets(), len(cs.lookups)
@@ -292,5 +295,7 @@ def evaluate_h_program(cs: ConstraintSystem, k: int, extended_k: int, delta: int
     g = GraphEvaluator()
     g.add_custom_gates(polys)
     if with_arguments:
-        g.add_vanishing_division(Fixed(lay.t_inv))
+        g.add_vanishing_division(Challenge(0) if per_coset else Fixed(lay.t_inv))
+    if per_coset:
+        lay.short_columns = {}
     return g, lay

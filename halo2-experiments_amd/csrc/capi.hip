@@ -295,6 +295,7 @@ int hm_shutdown(void) try {
   (void)hipDeviceSynchronize();
   for (auto& t : c.ntt_tables) ntt_tables_release(*t);
   c.ntt_tables.clear();
+  coset_tables_release(c);
   for (auto* list : {&c.bases, &c.zombie_bases}) {
     for (auto& b : *list) {
       if (b.d_xy) (void)hipFree(b.d_xy);
@@ -1256,6 +1257,41 @@ int hm_extended_to_coeff_bn256_fr_dev(void* d_a, size_t batch, const uint64_t ex
   if (rc == HM_OK) count_ntt(*ctx, log_ext, batch);
   return rc;
 } HM_API_CATCH("hm_extended_to_coeff_bn256_fr_dev")
+
+int hm_coeff_to_coset_bn256_fr_dev(const void* d_coeffs, void* d_out, size_t batch, const uint64_t omega[4], uint32_t log_n,
+                                   const uint64_t shift[4], int columns_internal, void* stream) try {
+  if ((batch && (!d_coeffs || !d_out)) || !omega || !shift) return hm_fail(HM_ERR_BAD_ARG, "hm_coeff_to_coset_bn256_fr_dev: null argument");
+  if (log_n > 28) return hm_fail(HM_ERR_BAD_ARG, "hm_coeff_to_coset_bn256_fr_dev: log_n > 28");
+  if (batch > 65535) return hm_fail(HM_ERR_BAD_ARG, "hm_coeff_to_coset_bn256_fr_dev: batch > 65535");
+  if (batch == 0) return HM_OK;
+  if (d_coeffs != d_out) {
+    const size_t bytes = ((size_t)32 << log_n) * batch;
+    const char *a = (const char*)d_coeffs, *b = (const char*)d_out;
+    if (a < b + bytes && b < a + bytes)
+      return hm_fail(HM_ERR_BAD_ARG, "hm_coeff_to_coset_bn256_fr_dev: output partially overlaps the coefficients");
+  }
+  DeviceCtx* ctx = ctx_for_current_device();
+  if (!ctx) return HM_ERR_NO_DEVICE;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  const int rc = ntt_coset_run(*ctx, (const uint32_t*)d_coeffs, (uint32_t*)d_out, (uint32_t)batch, omega, log_n, shift, columns_internal != 0,
+                               (hipStream_t)stream);
+  if (rc == HM_OK) count_ntt(*ctx, log_n, batch);
+  return rc;
+} HM_API_CATCH("hm_coeff_to_coset_bn256_fr_dev")
+
+int hm_coset_to_coeff_bn256_fr_dev(void* d_a, size_t batch, const uint64_t omega_inv[4], uint32_t log_n, const uint64_t divisor[4],
+                                   const uint64_t shift_inv[4], void* stream) try {
+  if ((batch && !d_a) || !omega_inv || !divisor || !shift_inv) return hm_fail(HM_ERR_BAD_ARG, "hm_coset_to_coeff_bn256_fr_dev: null argument");
+  if (log_n > 28) return hm_fail(HM_ERR_BAD_ARG, "hm_coset_to_coeff_bn256_fr_dev: log_n > 28");
+  if (batch > 65535) return hm_fail(HM_ERR_BAD_ARG, "hm_coset_to_coeff_bn256_fr_dev: batch > 65535");
+  if (batch == 0) return HM_OK;
+  DeviceCtx* ctx = ctx_for_current_device();
+  if (!ctx) return HM_ERR_NO_DEVICE;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  const int rc = ntt_coset_inverse_run(*ctx, (uint32_t*)d_a, (uint32_t)batch, omega_inv, log_n, divisor, shift_inv, (hipStream_t)stream);
+  if (rc == HM_OK) count_ntt(*ctx, log_n, batch);
+  return rc;
+} HM_API_CATCH("hm_coset_to_coeff_bn256_fr_dev")
 
 int hm_ntt_bn256_fr(uint64_t* a, const uint64_t omega[4], uint32_t log_n) try {
   if (!a || !omega) return hm_fail(HM_ERR_BAD_ARG, "hm_ntt_bn256_fr: null argument");

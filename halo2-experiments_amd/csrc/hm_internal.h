@@ -91,6 +91,20 @@ struct NttTables {
   uint32_t* d_stage[16] = {};
 };
 
+// The powers table of a transform on a coset shift * <omega> (ntt.hip: coset_table_get): n external words holding
+// 32 * shift^i (or 1024 * shift^i for outputs in the evaluator's internal column form).  Built on the first caller's
+// stream and published to the others behind `ready`, like the twiddle tables.
+struct CosetTable {
+  uint64_t shift[4] = {0, 0, 0, 0};
+  uint32_t log_n = 0;
+  uint32_t internal = 0;
+  uint32_t* d = nullptr;
+  hipStream_t build_stream = nullptr;
+  hipEvent_t ready = nullptr;
+  bool published = false;
+  uint64_t last_use = 0;
+};
+
 // grow-only device buffer
 struct DevBuf {
   void* p = nullptr;
@@ -207,6 +221,8 @@ struct DeviceCtx {
   int device = 0;
   std::mutex mu;
   std::vector<std::unique_ptr<NttTables>> ntt_tables;
+  std::vector<std::unique_ptr<CosetTable>> coset_tables;
+  uint64_t coset_clock = 0;
   AuxSlot aux[HM_AUX_SLOTS];
   uint64_t aux_clock = 0;
   DevBuf io;              // staging for host-pointer calls (scalars / NTT array)
@@ -275,6 +291,7 @@ struct NttFused {
   const uint64_t* scale = nullptr;   // 4 words: multiply every output (ifft divisor)
   const uint64_t* coset = nullptr;   // 12 words: input element i *= coset[i % 3] (coeff_to_extended)
   const uint64_t* post3 = nullptr;   // 12 words: output element i *= post3[i % 3] (extended_to_coeff)
+  const uint32_t* d_in_scale = nullptr;   // DEVICE table, n x 8 words: input element i *= table[i] / 32 (the transform on a coset)
 };
 int ntt_run(DeviceCtx& ctx, uint32_t* d_a, const uint64_t omega_ext[4], uint32_t log_n, uint32_t batch,
             const NttFused& fused, hipStream_t stream, const uint32_t* d_in = nullptr, uint32_t log_z = 0);
@@ -282,6 +299,14 @@ int ntt_plan_first_digit(uint32_t log_n, int* passes);
 int fr_scale_run(uint32_t* d_a, const uint64_t c_ext[4], uint64_t n, hipStream_t stream);
 int fr_mul_pattern3_run(uint32_t* d_a, const uint64_t c3_ext[12], uint64_t n, hipStream_t stream);
 void ntt_tables_release(NttTables& t);
+void coset_tables_release(DeviceCtx& ctx);
+// out_b[t] = sum_i in_b[i] (shift omega^t)^i for `batch` back-to-back n-element arrays, out of place (d_out may be d_in);
+// internal: outputs multiplied by 32 (HM_GRAPH_COLUMNS_INTERNAL)
+int ntt_coset_run(DeviceCtx& ctx, const uint32_t* d_in, uint32_t* d_out, uint32_t batch, const uint64_t omega_ext[4], uint32_t log_n,
+                  const uint64_t shift_ext[4], bool internal, hipStream_t stream);
+// in place: a_b <- divisor * inverse transform of a_b, then a_b[i] *= shift_inv^i
+int ntt_coset_inverse_run(DeviceCtx& ctx, uint32_t* d_a, uint32_t batch, const uint64_t omega_inv_ext[4], uint32_t log_n,
+                          const uint64_t divisor_ext[4], const uint64_t shift_inv_ext[4], hipStream_t stream);
 
 // graph.hip
 int graph_create(DeviceCtx& ctx, const uint32_t* calcs5, size_t n_calc, const uint64_t* constants_ext, size_t n_const_static,

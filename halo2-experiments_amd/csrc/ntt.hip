@@ -106,6 +106,9 @@ struct NttPassParams {
   uint32_t direct_tw;    // non-last pass: tw_lo holds omega_m^e for every e < m (no forming product)
   uint32_t log_z;        // first pass of an extending transform: the input holds only the first n >> log_z
                          // coefficients (the rest are zero by definition); 0 = ordinary transform
+  uint32_t has_table;    // first pass: multiply a[i] by in_scale[i] on load (the transform on a coset shift * <omega>: in_scale
+                         // holds 32 * shift^i as external words, so that the product of two external words is the external
+                         // word of a[i] * shift^i -- the radix is 2^261)
   // fused constants, 9-limb internal form, BY VALUE (a call never shares a constants buffer with another
   // call on another stream): coset[3] for the first pass, fin[3] for the last
   uint32_t coset[27];
@@ -180,11 +183,14 @@ __device__ __forceinline__ void ntt_round(uint32_t* lds, const NttTileCtx& cx, u
 // tw_lo/tw_hi: omega_n^j (j < 2^log_lb) and omega_n^(j << log_lb).
 // FUSED = false: the plain best_fft pass (no constants multiplied in): kept as its own instantiation so that the
 // fused forms' extra state costs it nothing (registers, the constants' LDS copy and barrier).
-template <int LOG_TILE, bool FUSED>
+// TABLE (implies FUSED): the first pass multiplies every input element by its entry of in_scale (a third instantiation, so
+// that the other two keep their register allocation: with the table words the four-deep preload spills).
+template <int LOG_TILE, bool FUSED, bool TABLE = false>
 __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(const uint32_t* in, uint32_t* out,
                                                                NttPassParams pp, const uint32_t* __restrict__ stage_tw,
                                                                const uint32_t* __restrict__ tw_lo,
-                                                               const uint32_t* __restrict__ tw_hi) {
+                                                               const uint32_t* __restrict__ tw_hi,
+                                                               const uint32_t* __restrict__ in_scale) {
   extern __shared__ uint32_t lds[];
   __shared__ uint32_t s_const[FUSED ? 54 : 1];   // [0, 27): coset pattern, [27, 54): final constants (indexed per element)
   const uint32_t tid = threadIdx.x;
@@ -247,9 +253,15 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(const uint32_t* i
     c = e >> s;
     return (row_of(c) << s) + d;
   };
-  auto place = [&](uint64_t g, uint32_t d, uint32_t c, const uint4& lo, const uint4& hi) {
+  auto place = [&](uint64_t g, uint32_t d, uint32_t c, const uint4& lo, const uint4& hi, const uint4& tl, const uint4& th) {
     const uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
     Fr x = fe_unpack<FrParams>(w);
+    if (TABLE && pp.has_table) {
+      const uint32_t tw8[8] = {tl.x, tl.y, tl.z, tl.w, th.x, th.y, th.z, th.w};
+      Fr ts = fe_unpack<FrParams>(tw8);
+      HM_DECLARE(ts, 6.0);
+      x = fe_mul(x, ts);
+    }
     if (FUSED && pp.has_coset) {
       Fr cz;
       const uint32_t* cp = s_const + (uint32_t)(g % 3) * 9;
@@ -261,13 +273,32 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(const uint32_t* i
     if (pp.log_z == 0) {
       lds_store<LOG_TILE>(lds, (bitrev(d, s) << log_c) + c, x);
     } else {
-      if (!(FUSED && pp.has_coset)) x = fe_reduce_small(x);   // raw 256-bit words: bring below 3r like a product
+      if (!((FUSED && pp.has_coset) || (TABLE && pp.has_table))) x = fe_reduce_small(x);   // raw 256-bit words: bring below 3r like a product
       const uint32_t p0 = bitrev(d, s);                        // low log_z bits are zero
       for (uint32_t t = 0; t < (1u << pp.log_z); ++t) lds_store<LOG_TILE>(lds, ((p0 + t) << log_c) + c, x);
     }
   };
   const uint32_t n_load = tile_elems >> pp.log_z;
-  if (n_load == 4u * NTT_THREADS) {
+  if (TABLE && pp.has_table && n_load == 4u * NTT_THREADS) {
+    // two rounds of two elements: with the table words a four-deep preload does not fit the 128 registers of this occupancy
+    for (int half = 0; half < 2; ++half) {
+      uint32_t d[2], c[2];
+      uint64_t g[2];
+      uint4 lo[2], hi[2], tl[2], th[2];
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        g[k] = where(tid + (uint32_t)(2 * half + k) * NTT_THREADS, d[k], c[k]);
+        const uint4* src = reinterpret_cast<const uint4*>(in + g[k] * 8);
+        const uint4* ts = reinterpret_cast<const uint4*>(in_scale + g[k] * 8);
+        lo[k] = src[0];
+        hi[k] = src[1];
+        tl[k] = ts[0];
+        th[k] = ts[1];
+      }
+#pragma unroll
+      for (int k = 0; k < 2; ++k) place(g[k], d[k], c[k], lo[k], hi[k], tl[k], th[k]);
+    }
+  } else if (n_load == 4u * NTT_THREADS) {
     uint32_t d[4], c[4];
     uint64_t g[4];
     uint4 lo[4], hi[4];
@@ -278,15 +309,22 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(const uint32_t* i
       lo[k] = src[0];
       hi[k] = src[1];
     }
+    const uint4 none = make_uint4(0, 0, 0, 0);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) place(g[k], d[k], c[k], lo[k], hi[k]);
+    for (int k = 0; k < 4; ++k) place(g[k], d[k], c[k], lo[k], hi[k], none, none);
   } else {
     for (uint32_t e = tid; e < n_load; e += NTT_THREADS) {
       uint32_t d, c;
       const uint64_t g = where(e, d, c);
       const uint4* src = reinterpret_cast<const uint4*>(in + g * 8);
       const uint4 lo = src[0], hi = src[1];
-      place(g, d, c, lo, hi);
+      uint4 tl = make_uint4(0, 0, 0, 0), th = tl;
+      if (TABLE && pp.has_table) {
+        const uint4* ts = reinterpret_cast<const uint4*>(in_scale + g * 8);
+        tl = ts[0];
+        th = ts[1];
+      }
+      place(g, d, c, lo, hi, tl, th);
     }
   }
   __syncthreads();
@@ -375,6 +413,25 @@ __global__ void fr_scale_kernel(uint32_t* __restrict__ a, FrWords c_ext, uint64_
   const uint4 lo = p[0], hi = p[1];
   const uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
   Fr y = fe_canonical(fe_mul(fe_unpack<FrParams>(w), c_int));
+  uint32_t o[8];
+  fe_pack(o, y);
+  p[0] = make_uint4(o[0], o[1], o[2], o[3]);
+  p[1] = make_uint4(o[4], o[5], o[6], o[7]);
+}
+
+// a_b[i] *= table[i] / 32 for `gridDim.y` back-to-back arrays of n elements (table: external words of 32 * s_i, so that the
+// product of two external words is the external word of a[i] * s_i)
+__global__ void fr_mul_table_kernel(uint32_t* __restrict__ a, const uint32_t* __restrict__ table, uint64_t n) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint4* p = reinterpret_cast<uint4*>(a + ((uint64_t)blockIdx.y * n + i) * 8);
+  const uint4* t = reinterpret_cast<const uint4*>(table + i * 8);
+  const uint4 lo = p[0], hi = p[1], tl = t[0], th = t[1];
+  const uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+  const uint32_t tw[8] = {tl.x, tl.y, tl.z, tl.w, th.x, th.y, th.z, th.w};
+  Fr ts = fe_unpack<FrParams>(tw);
+  HM_DECLARE(ts, 6.0);
+  Fr y = fe_canonical(fe_mul(fe_unpack<FrParams>(w), ts));
   uint32_t o[8];
   fe_pack(o, y);
   p[0] = make_uint4(o[0], o[1], o[2], o[3]);
@@ -571,9 +628,11 @@ int ntt_run(DeviceCtx& ctx, uint32_t* d_a, const uint64_t omega_ext[4], uint32_t
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     HM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ntt_pass_kernel<LOG_TILE, true>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    HM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ntt_pass_kernel<LOG_TILE, true, true>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     ctx.ntt_attr_set = true;
   }
-  if (d_in && (passes < 2 || log_z == 0 || log_z > digits[0]))
+  if (d_in && log_z != 0 && (passes < 2 || log_z > digits[0]))
     return hm_fail(HM_ERR_INTERNAL, "ntt: extending form needs a multi-pass plan and log_z <= first digit");
   // fused constants -> internal 9-limb form on the host (a handful of 4 x u64 products)
   uint32_t coset9[27] = {}, fin9[27] = {};
@@ -607,6 +666,7 @@ int ntt_run(DeviceCtx& ctx, uint32_t* d_a, const uint64_t omega_ext[4], uint32_t
     if (pp.has_coset) std::memcpy(pp.coset, coset9, sizeof coset9);
     if (pp.fin_mode) std::memcpy(pp.fin, fin9, sizeof fin9);
     pp.log_z = (p == 0 && d_in) ? log_z : 0u;
+    pp.has_table = (p == 0 && fused.d_in_scale) ? 1u : 0u;
     uint32_t log_c = (uint32_t)LOG_TILE > pp.s ? (uint32_t)LOG_TILE - pp.s : 0u;
     const uint32_t avail = pp.last ? pp.log_rows : pp.log_stride;  // columns / rows that exist
     if (log_c > avail) log_c = avail;
@@ -623,16 +683,108 @@ int ntt_run(DeviceCtx& ctx, uint32_t* d_a, const uint64_t omega_ext[4], uint32_t
         lo_tab = tab->d_mid;
       }
     }
-    if (pp.has_coset | pp.fin_mode) {
+    if (pp.has_table) {
+      hipLaunchKernelGGL((ntt_pass_kernel<LOG_TILE, true, true>), dim3((uint32_t)tiles, batch), dim3(NTT_THREADS), lds_bytes, stream, src, dst,
+                         pp, (const uint32_t*)tab->d_stage[pp.s], lo_tab, (const uint32_t*)tab->d_hi, fused.d_in_scale);
+    } else if (pp.has_coset | pp.fin_mode) {
       hipLaunchKernelGGL((ntt_pass_kernel<LOG_TILE, true>), dim3((uint32_t)tiles, batch), dim3(NTT_THREADS), lds_bytes, stream, src, dst,
-                         pp, (const uint32_t*)tab->d_stage[pp.s], lo_tab, (const uint32_t*)tab->d_hi);
+                         pp, (const uint32_t*)tab->d_stage[pp.s], lo_tab, (const uint32_t*)tab->d_hi, (const uint32_t*)nullptr);
     } else {
       hipLaunchKernelGGL((ntt_pass_kernel<LOG_TILE, false>), dim3((uint32_t)tiles, batch), dim3(NTT_THREADS), lds_bytes, stream, src, dst,
-                         pp, (const uint32_t*)tab->d_stage[pp.s], lo_tab, (const uint32_t*)tab->d_hi);
+                         pp, (const uint32_t*)tab->d_stage[pp.s], lo_tab, (const uint32_t*)tab->d_hi, (const uint32_t*)nullptr);
     }
     HM_HIP_CHECK(hipGetLastError());
   }
   if (slot) return aux_release(ctx, slot, stream);
+  return HM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// transforms on a coset shift * <omega> (the extended domain of evaluate_h taken one coset of the n-th roots at a time:
+// 2^(extended_k - k) independent n-point problems instead of one 2^extended_k-point problem -- what lets the cosets go to
+// different GPUs)
+// ---------------------------------------------------------------------------------------------
+constexpr size_t kCosetTablesMax = 48;
+
+void coset_tables_release(DeviceCtx& ctx) {
+  for (auto& t : ctx.coset_tables) {
+    if (t->d) (void)hipFree(t->d);
+    if (t->ready) (void)hipEventDestroy(t->ready);
+  }
+  ctx.coset_tables.clear();
+}
+
+static const uint32_t* coset_table_get(DeviceCtx& ctx, const uint64_t shift_ext[4], uint32_t log_n, bool internal, hipStream_t stream) {
+  for (auto& t : ctx.coset_tables) {
+    if (t->log_n == log_n && t->internal == (internal ? 1u : 0u) && std::memcmp(t->shift, shift_ext, 32) == 0) {
+      if (!t->published) {
+        if (hipEventQuery(t->ready) == hipSuccess) {
+          t->published = true;
+        } else if (stream != t->build_stream) {
+          HM_HIP_CHECK_PTR(hipStreamWaitEvent(stream, t->ready, 0));
+        }
+      }
+      t->last_use = ++ctx.coset_clock;
+      return t->d;
+    }
+  }
+  if (ctx.coset_tables.size() >= kCosetTablesMax) {        // rare: a kernel in flight may still read the table that goes
+    HM_HIP_CHECK_PTR(hipDeviceSynchronize());
+    size_t oldest = 0;
+    for (size_t i = 1; i < ctx.coset_tables.size(); ++i)
+      if (ctx.coset_tables[i]->last_use < ctx.coset_tables[oldest]->last_use) oldest = i;
+    if (ctx.coset_tables[oldest]->d) (void)hipFree(ctx.coset_tables[oldest]->d);
+    if (ctx.coset_tables[oldest]->ready) (void)hipEventDestroy(ctx.coset_tables[oldest]->ready);
+    ctx.coset_tables.erase(ctx.coset_tables.begin() + oldest);
+  }
+  auto t = std::make_unique<CosetTable>();
+  std::memcpy(t->shift, shift_ext, 32);
+  t->log_n = log_n;
+  t->internal = internal ? 1u : 0u;
+  const uint64_t n = 1ull << log_n;
+  bool ok = hipMalloc(&t->d, n * 32) == hipSuccess;
+  if (!ok) t->d = nullptr;
+  const host::Fr4 c = internal ? host::fr_mul(host::FR_32, host::FR_32) : host::FR_32;       // 1024 resp. 32, Montgomery words
+  if (ok) ok = fr_powers_run(t->d, n, shift_ext, stream) == HM_OK && fr_scale_run(t->d, c.l, n, stream) == HM_OK;
+  if (ok && hipEventCreateWithFlags(&t->ready, hipEventDisableTiming) != hipSuccess) ok = false;
+  if (ok && hipEventRecord(t->ready, stream) != hipSuccess) ok = false;
+  if (!ok) {
+    (void)hipStreamSynchronize(stream);
+    if (t->d) (void)hipFree(t->d);
+    if (t->ready) (void)hipEventDestroy(t->ready);
+    hm_fail(HM_ERR_HIP, "ntt: coset table allocation failed");
+    return nullptr;
+  }
+  t->build_stream = stream;
+  t->last_use = ++ctx.coset_clock;
+  ctx.coset_tables.push_back(std::move(t));
+  return ctx.coset_tables.back()->d;
+}
+
+int ntt_coset_run(DeviceCtx& ctx, const uint32_t* d_in, uint32_t* d_out, uint32_t batch, const uint64_t omega_ext[4], uint32_t log_n,
+                  const uint64_t shift_ext[4], bool internal, hipStream_t stream) {
+  if (log_n > 28) return hm_fail(HM_ERR_BAD_ARG, "ntt: log_n > 28 (Fr has 2-adicity 28)");
+  if (batch == 0) return HM_OK;
+  const uint32_t* table = coset_table_get(ctx, shift_ext, log_n, internal, stream);
+  if (!table) return HM_ERR_HIP;
+  NttFused f;
+  f.d_in_scale = table;
+  return ntt_run(ctx, d_out, omega_ext, log_n, batch, f, stream, d_in == d_out ? nullptr : d_in, 0);
+}
+
+int ntt_coset_inverse_run(DeviceCtx& ctx, uint32_t* d_a, uint32_t batch, const uint64_t omega_inv_ext[4], uint32_t log_n,
+                          const uint64_t divisor_ext[4], const uint64_t shift_inv_ext[4], hipStream_t stream) {
+  if (log_n > 28) return hm_fail(HM_ERR_BAD_ARG, "ntt: log_n > 28 (Fr has 2-adicity 28)");
+  if (batch == 0) return HM_OK;
+  const uint32_t* table = coset_table_get(ctx, shift_inv_ext, log_n, false, stream);
+  if (!table) return HM_ERR_HIP;
+  NttFused f;
+  f.scale = divisor_ext;
+  const int rc = ntt_run(ctx, d_a, omega_inv_ext, log_n, batch, f, stream);
+  if (rc != HM_OK) return rc;
+  const uint64_t n = 1ull << log_n;
+  hipLaunchKernelGGL(fr_mul_table_kernel, dim3((uint32_t)((n + 255) / 256), batch), dim3(256), 0, stream, d_a, table, n);
+  HM_HIP_CHECK(hipGetLastError());
   return HM_OK;
 }
 

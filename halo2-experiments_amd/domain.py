@@ -117,6 +117,67 @@ class EvaluationDomain:
                                                       ctypes.c_void_p(_stream_ptr(a))))
         return a
 
+    # -- the extended domain one coset of <omega> at a time (later halo2_proofs: coeff_to_extended_part) ---------
+    def num_cosets(self) -> int:
+        return 1 << (self.extended_k - self.k)
+
+    def coset_shift(self, j: int) -> int:
+        """Row E t + j of the extended array is the value at coset_shift(j) * omega^t (E = num_cosets())."""
+        return self.g_coset * pow(self.extended_omega, j, FR_MODULUS) % FR_MODULUS
+
+    def coeff_to_coset(self, a, j: int, internal: bool = False, out=None):
+        """(n, 4) or (batch, n, 4) coefficient tensor -> its evaluations on coset j of the extended domain, the same shape:
+        row t equals row E t + j of ``coeff_to_extended(a)``.  ``internal`` as there."""
+        import torch
+
+        batch = self._batch_of(a, self.n, "coeff_to_coset")
+        if not 0 <= j < self.num_cosets():
+            raise ValueError("coeff_to_coset: no such coset")
+        a = a.contiguous()
+        if out is None:
+            out = torch.empty_like(a)
+        elif out.shape != a.shape or not out.is_contiguous():
+            raise ValueError("coeff_to_coset: out must be a contiguous tensor of the input's shape")
+        _lib.check(_lib.load().hm_coeff_to_coset_bn256_fr_dev(
+            ctypes.c_void_p(a.data_ptr()), ctypes.c_void_p(out.data_ptr()), batch, _ptr(fr_words(self.omega)), self.k,
+            _ptr(fr_words(self.coset_shift(j))), 1 if internal else 0, ctypes.c_void_p(_stream_ptr(out))))
+        return out
+
+    def coset_vanishing_inverse(self, j: int) -> int:
+        """1 / (X^n - 1) on coset j: one constant (the entry j of divide_by_vanishing_poly's periodic pattern)."""
+        r = FR_MODULUS
+        return pow((pow(self.coset_shift(j), self.n, r) - 1) % r, -1, r)
+
+    def coset_to_partial(self, v, j: int):
+        """In place on the (n, 4) / (batch, n, 4) values a polynomial h takes on coset j: -> d_j[i] = sum_q h[i + q n]
+        zeta^(n q) w^(j q) (w = extended_omega^n).  ``combine_cosets`` turns the E of them into h's coefficients."""
+        batch = self._batch_of(v, self.n, "coset_to_partial")
+        _lib.check(_lib.load().hm_coset_to_coeff_bn256_fr_dev(
+            ctypes.c_void_p(v.data_ptr()), batch, _ptr(fr_words(self.omega_inv)), self.k, _ptr(fr_words(self.ifft_divisor)),
+            _ptr(fr_words(pow(self.coset_shift(j), -1, FR_MODULUS))), ctypes.c_void_p(_stream_ptr(v))))
+        return v
+
+    def combine_cosets(self, partials, pieces: int = None):
+        """partials[j] = coset_to_partial(values on coset j), j = 0 .. E - 1 -> the (pieces * n, 4) coefficients that
+        ``extended_to_coeff`` returns for the same polynomial (pieces defaults to the quotient degree j - 1): piece q is
+        zeta^(-n q) / E * sum_j w^(-j q) partials[j], one linear combination of E arrays."""
+        import torch
+        from .arithmetic import linear_combination
+
+        e = self.num_cosets()
+        if len(partials) != e:
+            raise ValueError("combine_cosets: one partial per coset")
+        pieces = self.quotient_poly_degree if pieces is None else pieces
+        r = FR_MODULUS
+        w_inv = pow(pow(self.extended_omega, self.n, r), -1, r)
+        zn_inv = pow(pow(self.g_coset, self.n, r), -1, r)
+        e_inv = pow(e, -1, r)
+        out = torch.empty((pieces, self.n, 4), dtype=partials[0].dtype, device=partials[0].device)
+        for q in range(pieces):
+            coeffs = np.stack([fr_words(pow(zn_inv, q, r) * e_inv % r * pow(w_inv, j * q, r) % r) for j in range(e)])
+            linear_combination(list(partials), coeffs, out=out[q])
+        return out.reshape(pieces * self.n, 4)
+
     def extended_to_coeff(self, a):
         """In place on a (2^extended_k, 4) or (batch, 2^extended_k, 4) tensor; returns the first
         n*(j-1) rows of each polynomial (a view)."""

@@ -212,6 +212,26 @@ int hm_coset_ntt_bn256_fr_dev(void* d_a, const uint64_t omega[4], uint32_t log_n
  * the log_ext - log_n butterfly stages that would pair them with zeros cost nothing. */
 int hm_coeff_to_extended_bn256_fr_dev(const void* d_coeffs, void* d_ext, size_t batch, const uint64_t extended_omega[4],
                                       uint32_t log_n, uint32_t log_ext, const uint64_t* coset, void* stream);
+/* The extended domain one coset of the n-th roots of unity at a time.  The 2^log_ext points zeta * extended_omega^m that
+ * coeff_to_extended evaluates on fall into E = 2^(log_ext - log_n) cosets shift_j * <omega>, shift_j = zeta *
+ * extended_omega^j, omega = extended_omega^E: row m = E t + j of the extended array is point t of coset j.  A rotation of
+ * the circuit (X -> omega^rot X) stays inside a coset, and 1 / (X^n - 1) is ONE constant on it, so evaluate_h runs on each
+ * coset by itself (hm_graph_evaluate_dev over 2^log_n rows, rotations unscaled) -- E independent n-point problems that can
+ * go to E different GPUs, each needing only the coefficient arrays (later versions of halo2_proofs take the same route
+ * for memory: coeff_to_extended_part).
+ *   hm_coeff_to_coset:  d_out_b[t] = sum_i d_coeffs_b[i] (shift omega^t)^i for `batch` back-to-back arrays of 2^log_n Fr
+ *     (= row E t + j of hm_coeff_to_extended's output, bit for bit); d_out may be d_coeffs itself.  columns_internal != 0:
+ *     outputs multiplied by 32, the form HM_GRAPH_COLUMNS_INTERNAL loads.  The powers of `shift` are kept on the device
+ *     per (shift, log_n).
+ *   hm_coset_to_coeff:  in place, a_b <- divisor * (inverse transform with omega_inv) of a_b, then a_b[i] *= shift_inv^i:
+ *     with divisor = 1/n this is d_j[i] = sum_q h[i + q n] zeta^(n q) w^(j q) (w = extended_omega^n, a primitive E-th
+ *     root of unity) for the coefficients h of the polynomial whose values on coset j went in; the E of them recombine as
+ *     h[i + q n] = zeta^(-n q) / E * sum_j w^(-j q) d_j[i] (hm_fr_linear_combination_dev, E terms per q).
+ * Asynchronous on `stream`. */
+int hm_coeff_to_coset_bn256_fr_dev(const void* d_coeffs, void* d_out, size_t batch, const uint64_t omega[4], uint32_t log_n,
+                                   const uint64_t shift[4], int columns_internal, void* stream);
+int hm_coset_to_coeff_bn256_fr_dev(void* d_a, size_t batch, const uint64_t omega_inv[4], uint32_t log_n, const uint64_t divisor[4],
+                                   const uint64_t shift_inv[4], void* stream);
 
 /* EvaluationDomain::extended_to_coeff's arithmetic in one call (halo2_proofs poly/domain.rs: ifft over the
  * extended domain, then distribute_powers_zeta with the INVERSE coset powers): `batch` arrays of 2^log_ext

@@ -151,3 +151,56 @@ def test_device_evaluate_h_of_each_circuit_matches_the_oracle(pyref, name):
         assert np.array_equal(values.cpu().numpy().view(np.uint64), pyref.fr_array(exp)), name + " (internal-form columns)"
     finally:
         prog.destroy()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(circuits.CONSTRAINT_SYSTEMS))
+def test_evaluate_h_coset_by_coset_gives_the_same_quotient(pyref, name):
+    """The multi-GPU route of DESIGN 6 on one device: every column as n coefficients; (A) coeff_to_extended, the whole
+    program over 2^extended_k rows, extended_to_coeff; (B) for each of the E cosets coeff_to_coset, the per-coset program
+    over 2^k rows (rotations unscaled, 1 / (X^n - 1) a constant), coset_to_partial -- then combine_cosets.  The per-coset
+    values are the residue classes of rows of (A)'s array and the quotient coefficients agree word for word."""
+    import torch
+    from halo2_experiments_amd.domain import EvaluationDomain
+    cs = circuits.CONSTRAINT_SYSTEMS[name]()
+    k = 6
+    dom = EvaluationDomain(cs.degree(), k)
+    ek, n, e = dom.extended_k, dom.n, dom.num_cosets()
+    assert e >= 4
+    delta = pow(7, 1 << 28, R)
+    g_all, lay = circuits.evaluate_h_program(cs, k, ek, delta)
+    g_one, lay1 = circuits.evaluate_h_program(cs, k, ek, delta, per_coset=True)
+    n_cols = lay.num_fixed_entries + cs.num_advice + cs.num_instance
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(77 + len(name))
+    coeffs = torch.randint(-(2 ** 63), 2 ** 63 - 1, (n_cols, n, 4), dtype=torch.int64, device="cuda", generator=gen)
+    coeffs[:, :, 3] &= 0x0FFFFFFFFFFFFFFF
+    x_poly = [0, 1] + [0] * (n - 2)                                         # the identity polynomial: its evaluations are the points
+    coeffs[lay.x_coset] = torch.from_numpy(pyref.fr_array(x_poly).view(np.int64)).cuda()
+    rng = random.Random(5)
+    beta, gamma, theta, y = (rng.randrange(R) for _ in range(4))
+    to_dev = lambda vals: torch.from_numpy(pyref.fr_array(vals).view(np.int64)).cuda()
+    prog_all = g_all.compile(lay.num_fixed_entries, cs.num_advice, cs.num_instance, num_challenges=0, rot_scale=e, short_columns=lay.short_columns)
+    prog_one = g_one.compile(lay1.num_fixed_entries, cs.num_advice, cs.num_instance, num_challenges=1, rot_scale=1)
+    try:
+        # (A)
+        ext = dom.coeff_to_extended(coeffs, internal=True)
+        cols = [ext[i] for i in range(n_cols)]
+        cols[lay.t_inv] = to_dev([32 * dom.coset_vanishing_inverse(c) % R for c in range(e)])
+        h_ext = torch.zeros((1 << ek, 4), dtype=torch.int64, device="cuda")
+        prog_all.evaluate(cols, h_ext, beta=beta, gamma=gamma, theta=theta, y=y, columns_internal=True)
+        h_a = dom.extended_to_coeff(h_ext.clone()).clone()
+        # (B)
+        parts = []
+        for c in range(e):
+            cc = dom.coeff_to_coset(coeffs, c, internal=True)
+            v = torch.zeros((n, 4), dtype=torch.int64, device="cuda")
+            prog_one.evaluate([cc[i] for i in range(n_cols)], v, challenges=[dom.coset_vanishing_inverse(c)], beta=beta, gamma=gamma, theta=theta,
+                              y=y, columns_internal=True)
+            assert bool((v == h_ext[c::e]).all()), (name, c)
+            parts.append(dom.coset_to_partial(v, c))
+        h_b = dom.combine_cosets(parts)
+        assert h_b.shape == h_a.shape and bool((h_a == h_b).all()), name
+    finally:
+        prog_all.destroy()
+        prog_one.destroy()

@@ -1,9 +1,12 @@
 """GPU suite: best_fft on the MI355X through the C ABI vs the oracle (bit-exact), the committed
 golden vectors, and size-independent properties at the benchmark's full size."""
+import ctypes
+
 import numpy as np
 import pytest
 
 import halo2_experiments_amd as h
+from halo2_experiments_amd import _lib
 from halo2_experiments_amd.domain import EvaluationDomain, fr_words
 
 pytestmark = pytest.mark.gpu
@@ -424,3 +427,80 @@ def test_concurrent_transforms_on_two_streams(pyref):
         for got, exp in ((ra, ea), (rb, eb), (rc, ec), (ra2, ea)):
             for g_, e_ in zip(got, exp):
                 assert torch.equal(g_, e_)
+
+
+# ---- the extended domain one coset of <omega> at a time (hm_coeff_to_coset / hm_coset_to_coeff) ----------------------
+@pytest.mark.parametrize("k,j", [(3, 3), (5, 6), (9, 6), (11, 6), (12, 4), (13, 6), (17, 6), (18, 6)])
+def test_coeff_to_coset_is_a_residue_class_of_rows_of_coeff_to_extended(pyref, k, j):
+    """Row t of coset c equals row E t + c of the extended array, bit for bit (one-pass, two-pass plans; batch; the
+    evaluator's internal column form; in place), and at the smallest size the oracle's direct evaluation."""
+    import torch
+    from halo2_experiments_amd.domain import EvaluationDomain
+    dom = EvaluationDomain(j, k)
+    n, e = dom.n, dom.num_cosets()
+    a = rand_fr_gpu(3 * n, 4100 + k).reshape(3, n, 4)
+    for internal in (False, True):
+        ext = dom.coeff_to_extended(a, internal=internal)
+        for c in range(e):
+            got = dom.coeff_to_coset(a, c, internal=internal)
+            assert bool((got == ext[:, c::e]).all()), (k, c, internal)
+    one = dom.coeff_to_coset(a[1], e - 1)
+    assert bool((one == dom.coeff_to_extended(a[1])[e - 1::e]).all())
+    b = a.clone()
+    assert dom.coeff_to_coset(b, 1, out=b) is b and bool((b == dom.coeff_to_extended(a)[:, 1::e]).all())     # in place
+    if k == 3:
+        coeffs = pyref.fr_from_array(a[0].cpu().numpy().view(np.uint64))
+        for c in range(e):
+            sh = dom.coset_shift(c)
+            want = [sum(v * pow(sh * pow(dom.omega, t, pyref.R) % pyref.R, i, pyref.R) for i, v in enumerate(coeffs)) % pyref.R for t in range(n)]
+            assert pyref.fr_from_array(dom.coeff_to_coset(a[0], c).cpu().numpy().view(np.uint64)) == want
+
+
+@pytest.mark.parametrize("k,j", [(3, 3), (5, 6), (11, 6), (12, 5), (16, 6), (18, 6)])
+def test_cosets_recombine_to_what_extended_to_coeff_returns(k, j):
+    """Values of a polynomial of degree < E n on the E cosets -> hm_coset_to_coeff each -> E-term linear combinations: the same
+    words as extended_to_coeff of the whole array (all E pieces compared, not only the quotient's j - 1)."""
+    import torch
+    from halo2_experiments_amd.domain import EvaluationDomain
+    dom = EvaluationDomain(j, k)
+    n, e = dom.n, dom.num_cosets()
+    h_ext = rand_fr_gpu(2 * e * n, 4300 + k).reshape(2, e * n, 4)
+    parts = [dom.coset_to_partial(h_ext[:, c::e].contiguous(), c) for c in range(e)]
+    whole = h_ext.clone()
+    dom.extended_to_coeff(whole)                                          # in place: `whole` now holds all E n coefficients
+    for b in range(2):
+        got = dom.combine_cosets([p[b] for p in parts], pieces=e)
+        assert bool((got == whole[b]).all()), (k, b)
+    short = dom.combine_cosets([p[0] for p in parts])
+    assert short.shape[0] == n * (j - 1) and bool((short == whole[0][: n * (j - 1)]).all())
+    with pytest.raises(ValueError):
+        dom.combine_cosets(parts[:-1])
+    with pytest.raises(ValueError):
+        dom.coeff_to_coset(h_ext[0, :n].contiguous(), e)
+
+
+def test_coset_tables_survive_many_shifts_and_two_streams():
+    """More distinct shifts than the table cache holds (the oldest goes, behind a device synchronisation), and the same
+    shift first used on one stream, then on another (published behind its event)."""
+    import torch
+    from halo2_experiments_amd.domain import EvaluationDomain
+    lib = _lib.load()
+    k = 10
+    dom = EvaluationDomain(6, k)
+    a = rand_fr_gpu(dom.n, 4500)
+    want = dom.coeff_to_extended(a)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(s1):
+        x1 = dom.coeff_to_coset(a, 5)
+    with torch.cuda.stream(s2):
+        x2 = dom.coeff_to_coset(a, 5)
+    torch.cuda.synchronize()
+    assert bool((x1 == want[5::8]).all()) and bool((x2 == want[5::8]).all())
+    from halo2_experiments_amd.arithmetic import _ptr, _stream_ptr
+    from halo2_experiments_amd.domain import fr_words
+    out = torch.empty_like(a)
+    for i in range(60):                                                    # 60 shifts > the 48 tables kept
+        _lib.check(lib.hm_coeff_to_coset_bn256_fr_dev(ctypes.c_void_p(a.data_ptr()), ctypes.c_void_p(out.data_ptr()), 1, _ptr(fr_words(dom.omega)),
+                                                      k, _ptr(fr_words(1000 + i)), 0, ctypes.c_void_p(_stream_ptr(a))))
+    assert bool((dom.coeff_to_coset(a, 5) == want[5::8]).all())             # rebuilt after eviction
