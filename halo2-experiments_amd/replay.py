@@ -46,7 +46,8 @@ from .arithmetic import (G1_GENERATOR, batch_invert, best_multiexp, best_multiex
                          release_bases)
 from .domain import EvaluationDomain, FR_MODULUS, fr_words
 from .kzg import ParamsKZG
-from .sharding import _NO_GROUP, job_parallel_multiexp_batch, shard_range, sharded_multiexp, sharded_multiexp_batch
+from .sharding import (_NO_GROUP, coset_owner, gather_coset_partials, job_parallel_multiexp_batch, shard_range, sharded_multiexp,
+                       sharded_multiexp_batch)
 
 # the replay's SRS trapdoor (the reference draws it from OsRng, utils.rs:28): known here, so that every
 # commitment of the replay can be checked against the KZG identity commit(f) == [f(s)]G
@@ -114,9 +115,14 @@ def _sparse_column(n, used_rows, seed, device):
 
 
 def run_replay(shape_name: str, device=None, group=None, include_host_pointer_estimate: bool = True,
-               in_flight: int = 8, solo: bool = False) -> dict:
+               in_flight: int = 8, solo: bool = False, by_cosets=None) -> dict:
     """``solo``: this process runs the replay ALONE even inside an initialised process group (bench.py's one-process form:
-    the other ranks are parked; the split over devices, if any, is hm_set_msm_devices' inside the library)."""
+    the other ranks are parked; the split over devices, if any, is hm_set_msm_devices' inside the library).
+    ``by_cosets``: the extended-domain steps (coset transforms, evaluate_h, the inverse transform of h) one coset of the
+    n-th roots at a time (EvaluationDomain.coeff_to_coset).  Default: on with more than one rank from k = 14 -- the E = 2^(extended_k
+    - k) cosets are dealt over the ranks, every rank transforms all columns onto ITS cosets from the coefficient arrays, runs
+    the per-coset program and hands back n x 32 B per coset -- and off on one GPU (the whole-array route is the 4 % cheaper
+    one there; ``by_cosets=True`` measures the other)."""
     import torch
     import torch.distributed as dist
 
@@ -140,6 +146,8 @@ def run_replay(shape_name: str, device=None, group=None, include_host_pointer_es
     # full SRS; a 2^15-point index-range shard would be pure latency), and so do the transforms; index-range
     # shards are for n >= 2^22.
     job_mode = world > 1 and k < 22
+    if by_cosets is None:
+        by_cosets = job_mode and k >= 14            # below that the per-coset launches cost more than the split returns (k = 11: 3 ms in all)
     # a real SRS with a known trapdoor; in index-range mode this rank keeps its slice of g and g_lagrange resident
     lo, hi = (0, n) if job_mode else shard_range(n, rank, world)
     gen = G1_GENERATOR
@@ -186,6 +194,14 @@ def run_replay(shape_name: str, device=None, group=None, include_host_pointer_es
     gate_prog = ge.compile(lay.num_fixed_entries, cs.num_advice, cs.num_instance, num_challenges=0, rot_scale=1 << (dom.extended_k - k),
                            short_columns=lay.short_columns)
     t_inv_col = _rand_fr(1 << (dom.extended_k - k), 500, device)          # the 2^(extended_k - k) values of 1 / (X^n - 1) on the coset
+    E = dom.num_cosets()
+    coset_prog = None
+    if by_cosets:
+        ge1, lay1 = evaluate_h_program(cs, k, dom.extended_k, delta=pow(7, 1 << 28, FR_MODULUS), per_coset=True)
+        coset_prog = ge1.compile(lay1.num_fixed_entries, cs.num_advice, cs.num_instance, num_challenges=1, rot_scale=1)
+        my_cosets = [c for c in range(E) if coset_owner(c, world) == rank]
+        coset_cols = torch.empty((8, n, 4), dtype=torch.int64, device=device)
+        coset_values = {c: torch.zeros((n, 4), dtype=torch.int64, device=device) for c in my_cosets}
 
     def gate_cols(e):            # every column of the table aliases one of the extended arrays (the arithmetic does not care)
         cols = [e[i % e.shape[0]] for i in range(lay.num_fixed_entries + cs.num_advice + cs.num_instance)]
@@ -219,17 +235,7 @@ def run_replay(shape_name: str, device=None, group=None, include_host_pointer_es
         local = [((col[lo:hi].contiguous() if world > 1 else col), handle) for col, handle, _ in jobs]
         return sharded_multiexp_batch(local, group=group, streams=streams), keys
 
-    def proof_once():
-        t = {"msm": 0.0, "ntt": 0.0}
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        r1 = msm_phase([(sparse[i & 1], gl_h, ("sparse", i & 1)) for i in range(counts["msm_sparse"])])
-        coeff_from = counts["msm_dense"] - (d - 1) - 2          # the last d + 1 commitments are in coefficient form
-        r2 = msm_phase([(dense[i & 1], g_h if i >= coeff_from else gl_h, ("dense_c" if i >= coeff_from else "dense_l", i & 1))
-                        for i in range(counts["msm_dense"])])
-        torch.cuda.synchronize()
-        t["msm"] = time.perf_counter() - t0
-        t["results"] = (r1, r2)
+    def whole_array_steps(t):
         t0 = time.perf_counter()
         # each transform stays on ONE GPU (north star); in job mode the independent transforms of a phase are dealt
         # to the ranks like the commitments, otherwise rank 0 runs them all
@@ -263,6 +269,64 @@ def run_replay(shape_name: str, device=None, group=None, include_host_pointer_es
                                columns_internal=True)
         torch.cuda.synchronize()
         t["evaluate_h"] = time.perf_counter() - t0
+
+    def coset_steps(t):
+        """The same steps with the extended domain taken one coset at a time.  Every rank: all inverse transforms (each rank
+        needs every coefficient array: 8 MiB per column at k = 18; redundant work instead of an all-gather of them), then for
+        each coset it owns: every column onto the coset (one batched call per 8 columns, the powers table shared), the
+        per-coset evaluate_h program over n rows, the inverse transform of the result.  Then ONE all-gather of n x 32 B per
+        coset, and rank 0 recombines the quotient's pieces (j - 1 linear combinations of E arrays)."""
+        t0 = time.perf_counter()
+        todo = counts["intt_n"]
+        while todo > 0:
+            b = min(8, todo)
+            dom.lagrange_to_coeff(ntt_batch[:b])
+            todo -= b
+        torch.cuda.synchronize()
+        t["ntt"] = time.perf_counter() - t0
+        t["evaluate_h"] = 0.0
+        parts = {}
+        for c in my_cosets:
+            t0 = time.perf_counter()
+            todo = counts["coset_ntt_ext"]
+            while todo > 0:
+                b = min(8, todo)
+                dom.coeff_to_coset(ntt_batch[:b], c, internal=True, out=coset_cols[:b])
+                todo -= b
+            torch.cuda.synchronize()
+            t["ntt"] += time.perf_counter() - t0
+            t0 = time.perf_counter()
+            cols = [coset_cols[i % 8] for i in range(lay.num_fixed_entries + cs.num_advice + cs.num_instance)]
+            coset_prog.evaluate(cols, coset_values[c], challenges=[dom.coset_vanishing_inverse(c)], beta=REPLAY_S + 1, gamma=REPLAY_S + 2,
+                                theta=REPLAY_S + 3, y=REPLAY_S, columns_internal=True)
+            torch.cuda.synchronize()
+            t["evaluate_h"] += time.perf_counter() - t0
+            t0 = time.perf_counter()
+            parts[c] = dom.coset_to_partial(coset_values[c], c)
+            torch.cuda.synchronize()
+            t["ntt"] += time.perf_counter() - t0
+        t0 = time.perf_counter()
+        allp = gather_coset_partials(parts, E, group=group)
+        if rank == 0:
+            dom.combine_cosets([p.to(device) for p in allp])
+        torch.cuda.synchronize()
+        t["ntt"] += time.perf_counter() - t0
+
+    def proof_once():
+        t = {"msm": 0.0, "ntt": 0.0}
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        r1 = msm_phase([(sparse[i & 1], gl_h, ("sparse", i & 1)) for i in range(counts["msm_sparse"])])
+        coeff_from = counts["msm_dense"] - (d - 1) - 2          # the last d + 1 commitments are in coefficient form
+        r2 = msm_phase([(dense[i & 1], g_h if i >= coeff_from else gl_h, ("dense_c" if i >= coeff_from else "dense_l", i & 1))
+                        for i in range(counts["msm_dense"])])
+        torch.cuda.synchronize()
+        t["msm"] = time.perf_counter() - t0
+        t["results"] = (r1, r2)
+        if by_cosets:
+            coset_steps(t)
+        else:
+            whole_array_steps(t)
         t0 = time.perf_counter()
         if rank == 0:
             eval_polynomial(ntt_batch, eval_points, poly_index=eval_index)
@@ -328,8 +392,12 @@ def run_replay(shape_name: str, device=None, group=None, include_host_pointer_es
 
     out = {
         "circuit": shape.name, "k": k, "extended_k": dom.extended_k, "n_gpus": world,
-        "multi_gpu_split": "whole commitments / transforms per rank (full SRS on every GPU)" if job_mode else
+        "multi_gpu_split": ("whole commitments per rank (full SRS on every GPU); extended-domain steps by cosets: "
+                            f"{E} cosets dealt over the ranks, n x 32 B per coset gathered" if by_cosets else
+                            "whole commitments / transforms per rank (full SRS on every GPU)") if job_mode else
                            ("index-range shards" if world > 1 else "none"),
+        "extended_domain": "by cosets (coeff_to_coset, per-coset evaluate_h, coset_to_partial, combine_cosets)" if by_cosets
+                           else "whole array (coeff_to_extended, evaluate_h over 2^extended_k rows, extended_to_coeff)",
         "shape": {"advice": A, "lookups": L, "equality_columns": shape.equality_columns, "max_degree": d,
                   "source": shape.source},
         "calls": counts,
@@ -388,6 +456,8 @@ def run_replay(shape_name: str, device=None, group=None, include_host_pointer_es
             "total": hp_total,
             "note": "PCIe-inclusive: every call uploads its scalars / moves its array both ways"}
     gate_prog.destroy()
+    if coset_prog is not None:
+        coset_prog.destroy()
     if world > 1 and not job_mode:
         release_bases(g_h)
         release_bases(gl_h)

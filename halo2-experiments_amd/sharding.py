@@ -139,3 +139,39 @@ def job_parallel_multiexp_batch(jobs, group=None, streams=None, local_batch: Opt
     for j in range(len(jobs)):
         out[j] = allr[job_owner(j, world), j // world]
     return out
+
+
+def coset_owner(coset: int, world: int) -> int:
+    """The E cosets of the extended domain (EvaluationDomain.coeff_to_coset) are dealt round-robin like a phase's jobs."""
+    return coset % world
+
+
+def gather_coset_partials(mine, num_cosets: int, group=None):
+    """evaluate_h by cosets over the ranks: ``mine`` = {coset: (n, 4) tensor} -- what ``coset_to_partial`` left for the
+    cosets this rank owns (``coset_owner``).  ONE all-gather of ceil(E / world) x n x 32 B per rank; returns the list of
+    the E partials in coset order (on the device for RCCL, on the host for gloo), ready for ``combine_cosets``.  Without a
+    process group (or with ``_NO_GROUP``) ``mine`` must hold all E."""
+    import torch
+    import torch.distributed as dist
+
+    distributed = group is not _NO_GROUP and dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    if not distributed:
+        return [mine[c] for c in range(num_cosets)]
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    owned = [c for c in range(num_cosets) if coset_owner(c, world) == rank]
+    if sorted(mine) != owned:
+        raise ValueError(f"gather_coset_partials: rank {rank} owns cosets {owned}, got {sorted(mine)}")
+    per_rank = (num_cosets + world - 1) // world
+    backend = dist.get_backend(group)
+    ref = next(iter(mine.values())) if mine else None
+    shape = tuple(ref.shape) if ref is not None else None
+    shapes = [None] * world
+    dist.all_gather_object(shapes, shape, group=group)                     # a rank may own no coset (world > E)
+    shape = next(s for s in shapes if s is not None)
+    dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+    buf = torch.zeros((per_rank,) + shape, dtype=torch.int64, device=dev)
+    for slot, c in enumerate(owned):
+        buf[slot] = mine[c].to(dev)
+    gathered = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(gathered, buf, group=group)
+    return [gathered[coset_owner(c, world)][c // world] for c in range(num_cosets)]

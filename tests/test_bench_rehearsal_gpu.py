@@ -68,11 +68,12 @@ def test_two_ranks_launched_like_the_driver_does():
 
 @pytest.mark.gpu
 def test_two_ranks_replay_the_k18_proof_and_rank0_replays_it_in_one_process():
-    """The N > 1 replay (whole commitments and transforms dealt over the ranks: replay.py job mode) launched the way the driver
+    """The N > 1 replay (whole commitments dealt over the ranks, the extended-domain steps by cosets: replay.py job mode) launched the way the driver
     launches it, and -- in the same run -- the one-process replay by rank 0 with the other rank parked."""
     two = _bench(2, 18, replay="merkle_sum_tree_k18", extra=("--no-strong",))
     (rep,) = two["create_proof_replay"]
     assert rep["k"] == 18 and rep["n_gpus"] == 2 and rep["multi_gpu_split"].startswith("whole commitments")
+    assert "8 cosets dealt over the ranks" in rep["multi_gpu_split"] and rep["extended_domain"].startswith("by cosets")
     assert rep["verified"]["commitments_checked"] >= 3 * (rep["calls"]["msm_sparse"] + rep["calls"]["msm_dense"])
     op = two["one_process"]["create_proof_replay"]
     assert op["k"] == 18 and op["multi_gpu_split"].startswith("one process")

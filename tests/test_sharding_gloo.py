@@ -58,6 +58,18 @@ def _worker(rank, world, port, q):
     for nm, out in zip(jnames, outs):
         results["jobs_" + nm] = out
     assert job_parallel_multiexp_batch([], local_batch=local).shape == (0, 12)
+    # evaluate_h by cosets: each rank brings the partials of the cosets it owns, everyone ends with all E in coset order
+    import torch
+    from halo2_experiments_amd.sharding import coset_owner, gather_coset_partials
+    for e in (8, 4, 1):
+        mine = {c: torch.full((5, 4), 100 * e + c, dtype=torch.int64) for c in range(e) if coset_owner(c, world) == rank}
+        allp = gather_coset_partials(mine, e)
+        assert len(allp) == e and all(int(allp[c][0, 0]) == 100 * e + c and tuple(allp[c].shape) == (5, 4) for c in range(e)), (e, rank)
+    try:
+        gather_coset_partials({0: torch.zeros((5, 4), dtype=torch.int64)} if rank == 1 else {}, 8)
+        raise AssertionError("a rank holding another rank's coset must be refused")
+    except ValueError:
+        pass
     dist.barrier()
     dist.destroy_process_group()
     q.put((rank, results))
