@@ -112,6 +112,45 @@ class EvaluationDomain {
     arithmetic::check(hm_fr_mul_periodic_dev(a.d, a.len * a.batch, reinterpret_cast<const uint64_t*>(t_inv.data()), period, stream),
                       "divide_by_vanishing_poly");
   }
+  // -- the extended domain one coset of <omega> at a time (hm_coeff_to_coset_bn256_fr_dev; later halo2_proofs:
+  // coeff_to_extended_part): row E t + j of coeff_to_extended's array is point t of coset j, E = num_cosets()
+  size_t num_cosets() const { return (size_t)1 << (extended_k - k); }
+  Fr coset_shift(size_t j) const { return g_coset * extended_omega.pow_u64((uint64_t)j); }
+  // 1 / (X^n - 1) on coset j: one constant
+  Fr coset_vanishing_inverse(size_t j) const {
+    Fr xn = coset_shift(j);
+    for (uint32_t b = 0; b < k; ++b) xn = xn.square();
+    return (xn - Fr::one()).invert();
+  }
+  // a.batch coefficient arrays -> their values on coset j (out may be a itself); internal: multiplied by 32 (the
+  // evaluator's HM_GRAPH_COLUMNS_INTERNAL form)
+  void coeff_to_coset(const DevicePolys& a, size_t j, DevicePolys& out, bool internal = false, hipStream_t stream = nullptr) const {
+    if (a.len != n || out.len != n || out.batch < a.batch) throw std::invalid_argument("coeff_to_coset: shapes");
+    if (j >= num_cosets()) throw std::invalid_argument("coeff_to_coset: no such coset");
+    arithmetic::check(hm_coeff_to_coset_bn256_fr_dev(a.d, out.d, a.batch, omega.l, k, coset_shift(j).l, internal ? 1 : 0, stream), "coeff_to_coset");
+  }
+  // values of h on coset j -> d_j[i] = sum_q h[i + q n] zeta^(n q) w^(j q), in place
+  void coset_to_partial(DevicePolys& v, size_t j, hipStream_t stream = nullptr) const {
+    if (v.len != n) throw std::invalid_argument("coset_to_partial: v.len() != n");
+    arithmetic::check(hm_coset_to_coeff_bn256_fr_dev(v.d, v.batch, omega_inv.l, k, ifft_divisor.l, coset_shift(j).invert().l, stream),
+                      "coset_to_partial");
+  }
+  // the E partials (device pointers to n elements each) -> `pieces` x n coefficients at out: piece q = zeta^(-n q) / E *
+  // sum_j w^(-j q) partials[j] -- what extended_to_coeff returns for the same polynomial
+  void combine_cosets(const std::vector<const Fr*>& partials, size_t pieces, Fr* out, hipStream_t stream = nullptr) const {
+    const size_t e = num_cosets();
+    if (partials.size() != e) throw std::invalid_argument("combine_cosets: one partial per coset");
+    Fr zn = g_coset;
+    for (uint32_t b = 0; b < k; ++b) zn = zn.square();
+    Fr w = extended_omega;
+    for (uint32_t b = 0; b < k; ++b) w = w.square();              // extended_omega^n: a primitive E-th root of unity
+    const Fr zn_inv = zn.invert(), w_inv = w.invert(), e_inv = Fr::from_u64((uint64_t)e).invert();
+    for (size_t q = 0; q < pieces; ++q) {
+      std::vector<Fr> c(e);
+      for (size_t j = 0; j < e; ++j) c[j] = zn_inv.pow_u64(q) * e_inv * w_inv.pow_u64(j * q);
+      arithmetic::linear_combination(partials, c, n, out + q * n, stream);
+    }
+  }
   // extended_to_coeff: ifft over the extended domain, undo the coset shift (caller truncates to n*(j-1))
   void extended_to_coeff(DevicePolys& a, hipStream_t stream = nullptr) const {
     if (a.len != extended_len()) throw std::invalid_argument("extended_to_coeff: a.len() != extended_len()");

@@ -330,6 +330,32 @@ int main(int argc, char** argv) {
       for (size_t i = 0; i < a.size(); ++i)
         if (!(arithmetic::to_affine(a[i]) == arithmetic::to_affine(b[i]))) opening_ok = false;
     }
+    {   // the extended domain by cosets (what a multi-GPU prover deals over its devices) equals the whole-array route:
+        // values on every coset = the residue classes of rows, and the recombined coefficients = extended_to_coeff's
+      const size_t e = dom.num_cosets();
+      poly::DevicePolys c1(n, 1), ext(dom.extended_len(), 1), part(n, e), back(n, e);
+      (void)hipMemcpy(c1.d, d_dense.d, n * sizeof(Fr), hipMemcpyDeviceToDevice);
+      dom.coeff_to_extended(c1, ext);
+      const std::vector<Fr> rows = ext.download();
+      std::vector<const Fr*> parts;
+      for (size_t j = 0; j < e; ++j) {
+        poly::DevicePolys one(n, 1);
+        dom.coeff_to_coset(c1, j, one);
+        const std::vector<Fr> got = one.download();
+        for (size_t t = 0; t < n; t += (n / 64 ? n / 64 : 1))
+          if (!(got[t] == rows[e * t + j])) opening_ok = false;
+        dom.coset_to_partial(one, j);
+        (void)hipMemcpy(part.poly(j), one.d, n * sizeof(Fr), hipMemcpyDeviceToDevice);
+        parts.push_back(part.poly(j));
+      }
+      dom.combine_cosets(parts, e, back.d);
+      dom.extended_to_coeff(ext);
+      const std::vector<Fr> a = back.download(), b = ext.download();
+      for (size_t i = 0; i < a.size(); i += 61)
+        if (!(a[i] == b[i])) opening_ok = false;
+      for (size_t i = 0; i < n; ++i)                              // a polynomial of degree < n: its own coefficients, then zeros
+        if (!(a[i] == dense[i])) opening_ok = false;
+    }
     if (!opening_ok) ok = false;
     size_t bad = 0;
     for (const Made& m : made)
