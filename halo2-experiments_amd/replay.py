@@ -312,6 +312,8 @@ def run_replay(shape_name: str, device=None, group=None, include_host_pointer_es
         torch.cuda.synchronize()
         t["ntt"] += time.perf_counter() - t0
 
+    replicate_columns = by_cosets and world > 1
+
     def proof_once():
         t = {"msm": 0.0, "ntt": 0.0}
         torch.cuda.synchronize()
@@ -335,7 +337,9 @@ def run_replay(shape_name: str, device=None, group=None, include_host_pointer_es
         # product; and multiopen's witness polynomials: per rotation set one combination of the committed polynomials,
         # a division by (X - point) per opening point, then the final combination and division
         t0 = time.perf_counter()
-        if rank == 0:
+        # (by cosets every rank needs every column's coefficients: the steps that PRODUCE columns on the device -- the z products
+        # and the permuted lookup columns -- run on every rank, redundantly, instead of being broadcast: 27 x 8 MiB at k = 18)
+        if rank == 0 or replicate_columns:
             batch_invert(z_factors)                 # the denominators of all z columns are independent: one call
             # permutation: each column set starts where the one before stood at the last usable row (upstream's last_z),
             # chained on the device; lookups: one independent product each.  Two launch chains in all.
@@ -346,7 +350,7 @@ def run_replay(shape_name: str, device=None, group=None, include_host_pointer_es
         torch.cuda.synchronize()
         t["grand_products"] = time.perf_counter() - t0
         t0 = time.perf_counter()
-        if rank == 0:
+        if rank == 0 or replicate_columns:
             if L:                                     # the permuted input / table columns of every lookup argument, one call
                 permute_expression_pairs([lookup_input] * L, [lookup_table] * L, n - 7, blinding_seed=1)
         torch.cuda.synchronize()
