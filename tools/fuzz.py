@@ -3,6 +3,10 @@
     python tools/fuzz.py single SEED CASES   random n in [2^17, 1.3e6], six scalar kinds, fixed-base table AND plain layout vs oracle/cpu_ref.c
     python tools/fuzz.py batch  SEED CASES   random phases (2-23 columns: sparse, zero, constant, dense) at prover sizes: batch == single calls == oracle
     python tools/fuzz.py lookup SEED CASES   random lookup arguments (2^13 .. 2^16 rows, key widths 1 .. 200 bits, 1-9 per call): == oracle/poly_ref.py
+    python tools/fuzz.py scans  SEED CASES   batched grand products (chained at a random row or not, in place or not, 1-40 columns of 1 .. 300 000
+                                             rows) and batched kate divisions == the single-column calls; one column per case == oracle/poly_ref.py
+    python tools/fuzz.py cosets SEED CASES   random (k, max degree, batch): every coset of coeff_to_coset == the residue class of rows of
+                                             coeff_to_extended; coset_to_partial + combine_cosets == extended_to_coeff
 """
 import sys
 mode = sys.argv.pop(1) if len(sys.argv) > 1 else "single"
@@ -54,6 +58,99 @@ if mode == "single":
                 print("MISMATCH", case, n, kind, thr, flush=True)
         if case % 10 == 9: print("case", case, "ok so far, bad =", bad, f"{time.time()-t0:.0f}s", flush=True)
     lib.hm_set_fixed_base_threshold(17)
+    print("done, mismatches:", bad)
+elif mode == "scans":
+    import os, sys, random, time
+    sys.path.insert(0, os.getcwd())
+    import numpy as np, torch
+    import halo2_experiments_amd as h
+    from halo2_experiments_amd.domain import fr_words
+    from oracle import bn256_ref as o, poly_ref as pr
+    def rand_fr(n, seed):
+        g = torch.Generator(device="cuda"); g.manual_seed(seed)
+        x = torch.randint(-(2**63), 2**63 - 1, (n, 4), dtype=torch.int64, device="cuda", generator=g)
+        x[:, 3] &= 0x0FFFFFFFFFFFFFFF
+        return x
+    vals = lambda t: o.fr_from_array(t.cpu().numpy().view(np.uint64))
+    rng = random.Random(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
+    bad, t0 = 0, time.time()
+    for case in range(int(sys.argv[2]) if len(sys.argv) > 2 else 40):
+        n = rng.choice([1, 2, 3, 4, 5, rng.randrange(6, 600), rng.randrange(600, 70000), rng.randrange(70000, 300000)])
+        count = rng.choice([1, 2, rng.randrange(3, 17), rng.randrange(17, 41)])
+        if n * count > 4_000_000:
+            count = max(1, 4_000_000 // n)
+        cols = [rand_fr(n, 10_000 * case + j) for j in range(count)]
+        if rng.random() < 0.3 and n > 2:
+            cols[rng.randrange(count)][rng.randrange(n)] = 0                  # a zero factor: everything after it is zero
+        start = rng.choice([1, 0, o.R - 1, rng.randrange(o.R)])
+        u = rng.choice([None, 0, n - 1, rng.randrange(n)])
+        inplace = rng.random() < 0.5
+        work = [c.clone() for c in cols] if inplace else cols
+        got = h.grand_product_batch(work, fr_words(start), chain_row=u, outs=work if inplace else None)
+        st = fr_words(start)
+        for j in range(count):
+            one = h.grand_product(cols[j], st)
+            if not bool((got[j] == one).all()):
+                bad += 1
+                print("MISMATCH product", case, n, count, u, j, flush=True)
+                break
+            if u is not None:
+                st = one[u].cpu().numpy().view(np.uint64)
+        if n <= 70000:
+            j = rng.randrange(count)
+            s_j = start if u is None or j == 0 else vals(got[j - 1][u:u + 1])[0]
+            if vals(got[j]) != pr.grand_product(vals(cols[j]), s_j):
+                bad += 1
+                print("MISMATCH product vs oracle", case, n, count, u, j, flush=True)
+        zs = [rng.choice([0, 1, o.R - 1, rng.randrange(o.R)]) for _ in range(count)]
+        qs = h.kate_division_batch(cols, [fr_words(z) for z in zs])
+        for j in range(count):
+            if not bool((qs[j] == h.kate_division(cols[j], fr_words(zs[j]))).all()):
+                bad += 1
+                print("MISMATCH division", case, n, count, j, flush=True)
+                break
+        if 1 < n <= 70000:
+            j = rng.randrange(count)
+            if vals(qs[j]) != pr.kate_division(vals(cols[j]), zs[j]):
+                bad += 1
+                print("MISMATCH division vs oracle", case, n, count, j, flush=True)
+        if case % 10 == 9: print("case", case, "bad =", bad, f"{time.time()-t0:.0f}s", flush=True)
+    print("done, mismatches:", bad)
+elif mode == "cosets":
+    import os, sys, random, time
+    sys.path.insert(0, os.getcwd())
+    import numpy as np, torch
+    from halo2_experiments_amd.domain import EvaluationDomain
+    def rand_fr(n, seed):
+        g = torch.Generator(device="cuda"); g.manual_seed(seed)
+        x = torch.randint(-(2**63), 2**63 - 1, (n, 4), dtype=torch.int64, device="cuda", generator=g)
+        x[:, 3] &= 0x0FFFFFFFFFFFFFFF
+        return x
+    rng = random.Random(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
+    bad, t0 = 0, time.time()
+    for case in range(int(sys.argv[2]) if len(sys.argv) > 2 else 40):
+        k = rng.randrange(1, 19)
+        j = rng.randrange(3, 18)
+        batch = rng.randrange(1, 6) if k <= 16 else rng.randrange(1, 3)
+        dom = EvaluationDomain(j, k)
+        if dom.extended_k > 24:
+            continue
+        n, e = dom.n, dom.num_cosets()
+        a = rand_fr(batch * n, 77 * case).reshape(batch, n, 4)
+        internal = rng.random() < 0.5
+        ext = dom.coeff_to_extended(a, internal=internal)
+        for c in rng.sample(range(e), min(e, 4)):
+            if not bool((dom.coeff_to_coset(a, c, internal=internal) == ext[:, c::e]).all()):
+                bad += 1
+                print("MISMATCH coset", case, k, j, batch, c, internal, flush=True)
+        hx = rand_fr(e * n, 77 * case + 1)
+        parts = [dom.coset_to_partial(hx[c::e].contiguous(), c) for c in range(e)]
+        whole = hx.clone()
+        dom.extended_to_coeff(whole)
+        if not bool((dom.combine_cosets(parts, pieces=e) == whole).all()):
+            bad += 1
+            print("MISMATCH recombination", case, k, j, flush=True)
+        if case % 10 == 9: print("case", case, "bad =", bad, f"{time.time()-t0:.0f}s", flush=True)
     print("done, mismatches:", bad)
 elif mode == "lookup":
     import os, sys, random, time
