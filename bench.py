@@ -553,6 +553,7 @@ def main():
     ap.add_argument("--no-2-26", action="store_true", help="skip the global 2^26-point strong-scaling measurement")
     ap.add_argument("--no-live-pmc", action="store_true",
                     help="do not measure the PMC counters of the hot kernels in child processes under rocprofv3 (N = 1 only); use the baked file")
+    ap.add_argument("--no-shares", action="store_true", help="skip the one-rank shares of the N-rank k = 18 replay (N = 1 only)")
     ap.add_argument("--no-strong", action="store_true", help="skip the strong-scaling measurements (global 2^24 / 2^26 split over the ranks)")
     ap.add_argument("--no-one-process", action="store_true", help="N > 1: skip rank 0's one-process (hm_set_msm_devices) measurements")
     ap.add_argument("--one-process", action="store_true",
@@ -796,6 +797,24 @@ def main():
         scalars = None
         torch.cuda.empty_cache()
         replay = [run_replay(name, device=device) for name in args.replay.split(",")]   # every rank takes part
+        # N = 1: what ONE GPU can measure of the N-GPU replay -- rank 0's share (it also runs the rank-0-only steps, so it is the
+        # longest) of the 2-, 4- and 8-rank deal of the largest shape, alone, nothing exchanged.  DESIGN.md section 6 builds its
+        # predicted curve on these.
+        if world == 1 and not args.no_extras and not args.no_shares:
+            big = [nm for nm in args.replay.split(",") if nm == "merkle_sum_tree_k18"]
+            for nm in big:
+                shares = []
+                for w in (2, 4, 8):
+                    try:
+                        r = run_replay(nm, device=device, include_host_pointer_estimate=False, share_of=(0, w))
+                        shares.append({"world": w, "rank": 0, "ms": {k2: v * 1e3 for k2, v in r["device_resident_s"].items()},
+                                       "extended_domain": r["extended_domain"]})
+                    except Exception as exc:  # noqa: BLE001 -- a side measurement never costs the line
+                        shares.append({"world": w, "error": f"{type(exc).__name__}: {exc}"})
+                next(rep for rep in replay if rep["k"] == 18)["rank0_share_measured_alone"] = {
+                    "shares": shares, "note": "rank 0's share of the N-rank replay run alone on this GPU (its commitments of every phase, its "
+                                              "cosets of the extended domain, the steps only rank 0 runs); the exchanges -- 96 B per commitment, "
+                                              "n x 32 B per coset -- are not in the time"}
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
             for rep in replay:
                 rep["cpu_baseline"] = replay_cpu_baseline(rep, device)

@@ -46,7 +46,7 @@ from .arithmetic import (G1_GENERATOR, batch_invert, best_multiexp, best_multiex
                          release_bases)
 from .domain import EvaluationDomain, FR_MODULUS, fr_words
 from .kzg import ParamsKZG
-from .sharding import (_NO_GROUP, coset_owner, gather_coset_partials, job_parallel_multiexp_batch, shard_range, sharded_multiexp,
+from .sharding import (_NO_GROUP, coset_owner, gather_coset_partials, job_owner, job_parallel_multiexp_batch, shard_range, sharded_multiexp,
                        sharded_multiexp_batch)
 
 # the replay's SRS trapdoor (the reference draws it from OsRng, utils.rs:28): known here, so that every
@@ -115,9 +115,12 @@ def _sparse_column(n, used_rows, seed, device):
 
 
 def run_replay(shape_name: str, device=None, group=None, include_host_pointer_estimate: bool = True,
-               in_flight: int = 8, solo: bool = False, by_cosets=None) -> dict:
+               in_flight: int = 8, solo: bool = False, by_cosets=None, share_of=None) -> dict:
     """``solo``: this process runs the replay ALONE even inside an initialised process group (bench.py's one-process form:
     the other ranks are parked; the split over devices, if any, is hm_set_msm_devices' inside the library).
+    ``share_of=(rank, world)``: ONE rank's share of the `world`-rank replay, run alone (no process group, no exchange):
+    its commitments of every phase, its cosets, and -- for rank 0 -- the steps only rank 0 runs.  What a one-GPU box can
+    MEASURE of the N-GPU replay; the exchanges (96 B per commitment, n x 32 B per coset) are what it leaves out.
     ``by_cosets``: the extended-domain steps (coset transforms, evaluate_h, the inverse transform of h) one coset of the
     n-th roots at a time (EvaluationDomain.coeff_to_coset).  Default: on with more than one rank from k = 14 -- the E = 2^(extended_k
     - k) cosets are dealt over the ranks, every rank transforms all columns onto ITS cosets from the coefficient arrays, runs
@@ -132,6 +135,14 @@ def run_replay(shape_name: str, device=None, group=None, include_host_pointer_es
     rank = dist.get_rank(group) if world > 1 else 0
     if solo:
         group = _NO_GROUP                 # the exchange helpers of sharding.py then run their local part only
+    if share_of is not None:
+        if world != 1:
+            raise ValueError("run_replay: share_of is measured by one process alone")
+        rank, world = share_of
+        if not 0 <= rank < world or world < 2 or shape.k >= 22:
+            raise ValueError("run_replay: share_of = (rank, world) with world >= 2, for the prover-sized shapes")
+        group = _NO_GROUP
+    exchanging = world > 1 and share_of is None       # a process group is there and takes part
     k, n = shape.k, 1 << shape.k
     dom = EvaluationDomain(shape.max_degree, k)
     d = shape.max_degree
@@ -230,6 +241,10 @@ def run_replay(shape_name: str, device=None, group=None, include_host_pointer_es
         MSMs in flight on as many streams (one MSM's sort / bucket reduction / host fold hides behind
         another's accumulation), then the partials of the whole phase cross xGMI in ONE all-gather."""
         keys = [key for _, _, key in jobs]
+        if share_of is not None:              # this rank's commitments only (job_owner's round-robin deal), nothing exchanged
+            mine = [j for j in range(len(jobs)) if job_owner(j, world) == rank]
+            return (sharded_multiexp_batch([(jobs[j][0], jobs[j][1]) for j in mine], group=_NO_GROUP, streams=streams),
+                    [keys[j] for j in mine])
         if job_mode:
             return job_parallel_multiexp_batch([(col, handle) for col, handle, _ in jobs], group=group, streams=streams), keys
         local = [((col[lo:hi].contiguous() if world > 1 else col), handle) for col, handle, _ in jobs]
@@ -306,8 +321,11 @@ def run_replay(shape_name: str, device=None, group=None, include_host_pointer_es
             torch.cuda.synchronize()
             t["ntt"] += time.perf_counter() - t0
         t0 = time.perf_counter()
-        allp = gather_coset_partials(parts, E, group=group)
-        if rank == 0:
+        if share_of is not None:              # no exchange: the recombination runs on this rank's partials, repeated
+            allp = [parts[my_cosets[c % len(my_cosets)]] for c in range(E)] if my_cosets else []
+        else:
+            allp = gather_coset_partials(parts, E, group=group)
+        if rank == 0 and allp:
             dom.combine_cosets([p.to(device) for p in allp])
         torch.cuda.synchronize()
         t["ntt"] += time.perf_counter() - t0
@@ -374,14 +392,14 @@ def run_replay(shape_name: str, device=None, group=None, include_host_pointer_es
     # launch-bound work on a shared host: the best of three replays (every rank runs all three)
     wall, phases = None, None
     for _ in range(3):
-        if world > 1:
+        if exchanging:
             dist.barrier(group)
         t0 = time.perf_counter()
         ph = proof_once()
-        if world > 1:
+        if exchanging:
             dist.barrier(group)
         w = time.perf_counter() - t0
-        if world > 1:
+        if exchanging:
             comm_dev = device if dist.get_backend(group) == "nccl" else torch.device("cpu")
             tt = torch.tensor([w], dtype=torch.float64, device=comm_dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX, group=group)
@@ -396,6 +414,9 @@ def run_replay(shape_name: str, device=None, group=None, include_host_pointer_es
 
     out = {
         "circuit": shape.name, "k": k, "extended_k": dom.extended_k, "n_gpus": world,
+        **({"share_of": {"rank": rank, "world": world, "note": "ONE rank's share of the replay, measured alone on one GPU: no exchange "
+                                                               "(96 B per commitment, n x 32 B per coset) in the time"}}
+           if share_of is not None else {}),
         "multi_gpu_split": ("whole commitments per rank (full SRS on every GPU); extended-domain steps by cosets: "
                             f"{E} cosets dealt over the ranks, n x 32 B per coset gathered" if by_cosets else
                             "whole commitments / transforms per rank (full SRS on every GPU)") if job_mode else

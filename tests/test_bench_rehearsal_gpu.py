@@ -19,9 +19,9 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _bench(world, log_points, replay="none", extra=()):
+def _bench(world, log_points, replay="none", extra=(), extras=False):
     args = ["--gpus", str(world), "--steps", "2", "--warmup", "1", "--log-points", str(log_points), "--no-cpu-baseline", "--no-ntt",
-            "--replay", replay, "--no-extras", "--no-2-26"] + list(extra)
+            "--replay", replay, "--no-2-26"] + ([] if extras else ["--no-extras"]) + list(extra)
     if "--live-pmc" in args:
         args.remove("--live-pmc")
     else:
@@ -79,6 +79,19 @@ def test_two_ranks_replay_the_k18_proof_and_rank0_replays_it_in_one_process():
     assert op["k"] == 18 and op["multi_gpu_split"].startswith("one process")
     assert op["verified"]["commitments_checked"] >= 3 * (op["calls"]["msm_sparse"] + op["calls"]["msm_dense"])
     assert "strong_scaling" not in two
+
+
+@pytest.mark.gpu
+def test_one_gpu_line_carries_rank0_shares_of_the_k18_replay():
+    """N = 1: beside the replay itself, rank 0's share of the 2-, 4- and 8-rank deal measured alone (what DESIGN 6's predicted curve
+    is built on): less work with every doubling, the extended domain by cosets."""
+    line = _bench(1, 18, replay="merkle_sum_tree_k18", extras=True)
+    (rep,) = line["create_proof_replay"]
+    shares = rep["rank0_share_measured_alone"]["shares"]
+    assert [s["world"] for s in shares] == [2, 4, 8] and all("error" not in s for s in shares), shares
+    totals = [s["ms"]["total"] for s in shares]
+    assert rep["device_resident_s"]["total"] * 1e3 > totals[0] > totals[1] > totals[2] > 0
+    assert all(s["extended_domain"].startswith("by cosets") for s in shares)
 
 
 @pytest.mark.gpu

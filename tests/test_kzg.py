@@ -101,3 +101,29 @@ def test_replays_verify_their_commitments(name):
     cs = CONSTRAINT_SYSTEMS[name]()
     assert r["shape"]["advice"] == cs.num_advice and r["shape"]["lookups"] == len(cs.lookups) and r["shape"]["max_degree"] == cs.degree()
     assert f"{len(cs.polynomials())} gate polynomials" in r["beyond_msm_ntt"]["evaluate_h"]
+
+
+@pytest.mark.gpu
+def test_replay_by_cosets_and_one_ranks_share():
+    """The extended-domain steps by cosets on one GPU (what several ranks deal among themselves), and ONE rank's share of a
+    four-rank replay run alone: its commitments only (each still checked against the KZG identity), its cosets, no exchange."""
+    import torch
+    from halo2_experiments_amd.replay import run_replay
+    dev = torch.device("cuda", 0)
+    whole = run_replay("merkle_v3_k17", device=dev, include_host_pointer_estimate=False)
+    assert whole["extended_domain"].startswith("whole array") and "share_of" not in whole
+    cosets = run_replay("merkle_v3_k17", device=dev, include_host_pointer_estimate=False, by_cosets=True)
+    assert cosets["extended_domain"].startswith("by cosets")
+    assert cosets["verified"]["commitments_checked"] == whole["verified"]["commitments_checked"]
+    jobs = whole["calls"]["msm_sparse"] + whole["calls"]["msm_dense"]
+    seen = 0
+    for rank in (0, 3):
+        part = run_replay("merkle_v3_k17", device=dev, include_host_pointer_estimate=False, share_of=(rank, 4))
+        assert part["share_of"]["rank"] == rank and part["n_gpus"] == 4 and part["extended_domain"].startswith("by cosets")
+        assert 0 < part["verified"]["commitments_checked"] < whole["verified"]["commitments_checked"]
+        seen += part["verified"]["commitments_checked"]
+        if rank == 3:
+            assert part["device_resident_s"]["multiopen"] < 1e-4 and part["device_resident_s"]["evaluate_h"] > 0   # rank-0-only steps skipped
+    assert seen < 4 * jobs
+    with pytest.raises(ValueError):
+        run_replay("merkle_v3_k17", device=dev, share_of=(4, 4))
