@@ -324,7 +324,7 @@ def run_replay(shape_name: str, device=None, group=None, include_host_pointer_es
         if share_of is not None:              # no exchange: the recombination runs on this rank's partials, repeated
             allp = [parts[my_cosets[c % len(my_cosets)]] for c in range(E)] if my_cosets else []
         else:
-            allp = gather_coset_partials(parts, E, group=group)
+            allp = gather_coset_partials(parts, E, group=group, shape=(n, 4))
         if rank == 0 and allp:
             dom.combine_cosets([p.to(device) for p in allp])
         torch.cuda.synchronize()

@@ -146,11 +146,12 @@ def coset_owner(coset: int, world: int) -> int:
     return coset % world
 
 
-def gather_coset_partials(mine, num_cosets: int, group=None):
+def gather_coset_partials(mine, num_cosets: int, group=None, shape=None):
     """evaluate_h by cosets over the ranks: ``mine`` = {coset: (n, 4) tensor} -- what ``coset_to_partial`` left for the
     cosets this rank owns (``coset_owner``).  ONE all-gather of ceil(E / world) x n x 32 B per rank; returns the list of
     the E partials in coset order (on the device for RCCL, on the host for gloo), ready for ``combine_cosets``.  Without a
-    process group (or with ``_NO_GROUP``) ``mine`` must hold all E."""
+    process group (or with ``_NO_GROUP``) ``mine`` must hold all E.  ``shape``: the shape of one partial -- required on a
+    rank that owns no coset (more ranks than cosets)."""
     import torch
     import torch.distributed as dist
 
@@ -163,11 +164,11 @@ def gather_coset_partials(mine, num_cosets: int, group=None):
         raise ValueError(f"gather_coset_partials: rank {rank} owns cosets {owned}, got {sorted(mine)}")
     per_rank = (num_cosets + world - 1) // world
     backend = dist.get_backend(group)
-    ref = next(iter(mine.values())) if mine else None
-    shape = tuple(ref.shape) if ref is not None else None
-    shapes = [None] * world
-    dist.all_gather_object(shapes, shape, group=group)                     # a rank may own no coset (world > E)
-    shape = next(s for s in shapes if s is not None)
+    if shape is None:
+        if not mine:
+            raise ValueError("gather_coset_partials: a rank that owns no coset must be told the shape of a partial")
+        shape = tuple(next(iter(mine.values())).shape)
+    shape = tuple(shape)
     dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
     buf = torch.zeros((per_rank,) + shape, dtype=torch.int64, device=dev)
     for slot, c in enumerate(owned):

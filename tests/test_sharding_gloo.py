@@ -63,7 +63,7 @@ def _worker(rank, world, port, q):
     from halo2_experiments_amd.sharding import coset_owner, gather_coset_partials
     for e in (8, 4, 1):
         mine = {c: torch.full((5, 4), 100 * e + c, dtype=torch.int64) for c in range(e) if coset_owner(c, world) == rank}
-        allp = gather_coset_partials(mine, e)
+        allp = gather_coset_partials(mine, e, shape=(5, 4))                 # (e = 1: rank 1 owns nothing and must be told the shape)
         assert len(allp) == e and all(int(allp[c][0, 0]) == 100 * e + c and tuple(allp[c].shape) == (5, 4) for c in range(e)), (e, rank)
     try:
         gather_coset_partials({0: torch.zeros((5, 4), dtype=torch.int64)} if rank == 1 else {}, 8)
