@@ -453,10 +453,11 @@ def one_process_measurements(devs, device, log_global, replay_name, reps=3):
         out["msm_split"] = entry
         if replay_name:
             from halo2_experiments_amd.replay import run_replay
-            rep = run_replay(replay_name, device=device, include_host_pointer_estimate=False, solo=True)
+            rep = run_replay(replay_name, device=device, include_host_pointer_estimate=False, solo=True, devices=devs)
             rep["n_gpus"] = len(set(devs))
             rep["multi_gpu_split"] = ("one process: SRS replicated on every listed device, each phase of commitments dealt round-robin as whole "
-                                      "commitments inside hm_msm_batch_bn256_g1_dev; transforms and every other step on the first device")
+                                      "commitments inside hm_msm_batch_bn256_g1_dev; the extended-domain steps by cosets over the devices, one "
+                                      "host thread per device (k >= 14), n x 32 B per coset back to the first device; the rest on the first device")
             out["create_proof_replay"] = rep
     finally:
         _lib.check(lib.hm_set_msm_devices(None, 0))

@@ -115,9 +115,14 @@ def _sparse_column(n, used_rows, seed, device):
 
 
 def run_replay(shape_name: str, device=None, group=None, include_host_pointer_estimate: bool = True,
-               in_flight: int = 8, solo: bool = False, by_cosets=None, share_of=None) -> dict:
+               in_flight: int = 8, solo: bool = False, by_cosets=None, share_of=None, devices=None) -> dict:
     """``solo``: this process runs the replay ALONE even inside an initialised process group (bench.py's one-process form:
     the other ranks are parked; the split over devices, if any, is hm_set_msm_devices' inside the library).
+    ``devices`` (with ``solo``): the device list of the one-process form (hm_set_msm_devices has been called with it).  With
+    more than one entry and k >= 14 the extended-domain steps go BY COSETS OVER THE DEVICES, one host thread per device -- what
+    a Rust prover with one process for the node would do with its thread pool: every device inverse-transforms all columns,
+    takes its cosets, and (like the ranks of the per-process form) builds the z columns and permuted lookup columns itself;
+    n x 32 B per coset come back to the first device over xGMI.  The commitments go through the multi-device handle as before.
     ``share_of=(rank, world)``: ONE rank's share of the `world`-rank replay, run alone (no process group, no exchange):
     its commitments of every phase, its cosets, and -- for rank 0 -- the steps only rank 0 runs.  What a one-GPU box can
     MEASURE of the N-GPU replay; the exchanges (96 B per commitment, n x 32 B per coset) are what it leaves out.
@@ -157,8 +162,9 @@ def run_replay(shape_name: str, device=None, group=None, include_host_pointer_es
     # full SRS; a 2^15-point index-range shard would be pure latency), and so do the transforms; index-range
     # shards are for n >= 2^22.
     job_mode = world > 1 and k < 22
+    one_proc_devs = list(devices) if (solo and devices and len(devices) > 1 and k >= 14) else None
     if by_cosets is None:
-        by_cosets = job_mode and k >= 14            # below that the per-coset launches cost more than the split returns (k = 11: 3 ms in all)
+        by_cosets = (job_mode and k >= 14) or one_proc_devs is not None   # below k = 14 the per-coset launches cost more than the split returns
     # a real SRS with a known trapdoor; in index-range mode this rank keeps its slice of g and g_lagrange resident
     lo, hi = (0, n) if job_mode else shard_range(n, rank, world)
     gen = G1_GENERATOR
@@ -213,6 +219,19 @@ def run_replay(shape_name: str, device=None, group=None, include_host_pointer_es
         my_cosets = [c for c in range(E) if coset_owner(c, world) == rank]
         coset_cols = torch.empty((8, n, 4), dtype=torch.int64, device=device)
         coset_values = {c: torch.zeros((n, 4), dtype=torch.int64, device=device) for c in my_cosets}
+    slots = []
+    if one_proc_devs:
+        # one state per listed device (a device listed twice -- the one-GPU rehearsal -- gets two states): its own copy of the
+        # columns, its own evaluator program (programs belong to a device context), its own outputs
+        for i, dv in enumerate(one_proc_devs):
+            with torch.cuda.device(dv):
+                tdev = torch.device("cuda", dv)
+                slots.append({
+                    "index": i, "device": tdev, "cosets": [c for c in range(E) if c % len(one_proc_devs) == i],
+                    "ntt_batch": ntt_batch.to(tdev).clone(), "coset_cols": torch.empty((8, n, 4), dtype=torch.int64, device=tdev),
+                    "values": {c: torch.zeros((n, 4), dtype=torch.int64, device=tdev) for c in range(E) if c % len(one_proc_devs) == i},
+                    "prog": ge1.compile(lay1.num_fixed_entries, cs.num_advice, cs.num_instance, num_challenges=1, rot_scale=1),
+                })
 
     def gate_cols(e):            # every column of the table aliases one of the extended arrays (the arithmetic does not care)
         cols = [e[i % e.shape[0]] for i in range(lay.num_fixed_entries + cs.num_advice + cs.num_instance)]
@@ -235,6 +254,12 @@ def run_replay(shape_name: str, device=None, group=None, include_host_pointer_es
     lookup_table = linear_combination([lookup_table], np.stack([fr_words((1 << 256) % FR_MODULUS)]))
     lookup_input = lookup_table[torch.randperm(n, device=device)].contiguous()
     lookup_input[n - 7:] = lookup_table[:7]            # (rows beyond the usable ones are not read)
+    for st in slots[1:]:                               # the devices beyond the first build the z / permuted columns themselves
+        with torch.cuda.device(st["device"]):
+            st["z_factors"] = z_factors.to(st["device"]).clone()
+            st["z_columns"] = torch.empty_like(st["z_factors"])
+            st["lookup_input"] = lookup_input.to(st["device"]).clone()
+            st["lookup_table"] = lookup_table.to(st["device"]).clone()
 
     def msm_phase(jobs):
         """The commitments of one prover phase are independent: every rank keeps `in_flight` of its local
@@ -332,6 +357,68 @@ def run_replay(shape_name: str, device=None, group=None, include_host_pointer_es
 
     replicate_columns = by_cosets and world > 1
 
+    def device_share(st):
+        """One device's part of the one-process form, on its own host thread (ctypes calls release the GIL; the current device
+        is per thread): all inverse transforms, its cosets, and -- beyond the first device -- the z and permuted columns."""
+        torch.cuda.set_device(st["device"])
+        times = {"ntt": 0.0, "evaluate_h": 0.0, "columns": 0.0}
+        t0 = time.perf_counter()
+        todo = counts["intt_n"]
+        while todo > 0:
+            b = min(8, todo)
+            dom.lagrange_to_coeff(st["ntt_batch"][:b])
+            todo -= b
+        torch.cuda.synchronize(st["device"])
+        times["ntt"] += time.perf_counter() - t0
+        parts = {}
+        for c in st["cosets"]:
+            t0 = time.perf_counter()
+            todo = counts["coset_ntt_ext"]
+            while todo > 0:
+                b = min(8, todo)
+                dom.coeff_to_coset(st["ntt_batch"][:b], c, internal=True, out=st["coset_cols"][:b])
+                todo -= b
+            torch.cuda.synchronize(st["device"])
+            times["ntt"] += time.perf_counter() - t0
+            t0 = time.perf_counter()
+            cols = [st["coset_cols"][i % 8] for i in range(lay.num_fixed_entries + cs.num_advice + cs.num_instance)]
+            st["prog"].evaluate(cols, st["values"][c], challenges=[dom.coset_vanishing_inverse(c)], beta=REPLAY_S + 1, gamma=REPLAY_S + 2,
+                                theta=REPLAY_S + 3, y=REPLAY_S, columns_internal=True)
+            torch.cuda.synchronize(st["device"])
+            times["evaluate_h"] += time.perf_counter() - t0
+            t0 = time.perf_counter()
+            parts[c] = dom.coset_to_partial(st["values"][c], c)
+            torch.cuda.synchronize(st["device"])
+            times["ntt"] += time.perf_counter() - t0
+        if st["index"] != 0:
+            t0 = time.perf_counter()
+            batch_invert(st["z_factors"])
+            if zp:
+                grand_product_batch(list(st["z_factors"][:zp]), fr_words(1), chain_row=n - 7, outs=list(st["z_columns"][:zp]))
+            if L:
+                grand_product_batch(list(st["z_factors"][zp:]), fr_words(1), outs=list(st["z_columns"][zp:]))
+                permute_expression_pairs([st["lookup_input"]] * L, [st["lookup_table"]] * L, n - 7, blinding_seed=1)
+            torch.cuda.synchronize(st["device"])
+            times["columns"] += time.perf_counter() - t0
+        return parts, times
+
+    def coset_steps_over_devices(t):
+        """The one-process form: one host thread per listed device runs device_share; the partials cross xGMI to the first
+        device (n x 32 B per coset), which recombines.  t["ntt"] / t["evaluate_h"]: the longest device's own times."""
+        from concurrent.futures import ThreadPoolExecutor
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(max_workers=len(slots)) as pool:
+            results = list(pool.map(device_share, slots))
+        torch.cuda.set_device(device)
+        parts = {}
+        for pr, _ in results:
+            parts.update(pr)
+        dom.combine_cosets([parts[c].to(device) for c in range(E)])
+        torch.cuda.synchronize()
+        block = time.perf_counter() - t0
+        t["evaluate_h"] = max(tm["evaluate_h"] for _, tm in results)
+        t["ntt"] = block - t["evaluate_h"]              # everything else of the block: transforms, the other devices' columns, gather, recombination
+
     def proof_once():
         t = {"msm": 0.0, "ntt": 0.0}
         torch.cuda.synchronize()
@@ -343,7 +430,9 @@ def run_replay(shape_name: str, device=None, group=None, include_host_pointer_es
         torch.cuda.synchronize()
         t["msm"] = time.perf_counter() - t0
         t["results"] = (r1, r2)
-        if by_cosets:
+        if one_proc_devs:
+            coset_steps_over_devices(t)
+        elif by_cosets:
             coset_steps(t)
         else:
             whole_array_steps(t)
@@ -421,7 +510,8 @@ def run_replay(shape_name: str, device=None, group=None, include_host_pointer_es
                             f"{E} cosets dealt over the ranks, n x 32 B per coset gathered" if by_cosets else
                             "whole commitments / transforms per rank (full SRS on every GPU)") if job_mode else
                            ("index-range shards" if world > 1 else "none"),
-        "extended_domain": "by cosets (coeff_to_coset, per-coset evaluate_h, coset_to_partial, combine_cosets)" if by_cosets
+        "extended_domain": (f"by cosets over {len(one_proc_devs)} devices, one host thread each" if one_proc_devs else
+                            "by cosets (coeff_to_coset, per-coset evaluate_h, coset_to_partial, combine_cosets)") if by_cosets
                            else "whole array (coeff_to_extended, evaluate_h over 2^extended_k rows, extended_to_coeff)",
         "shape": {"advice": A, "lookups": L, "equality_columns": shape.equality_columns, "max_degree": d,
                   "source": shape.source},
@@ -483,6 +573,9 @@ def run_replay(shape_name: str, device=None, group=None, include_host_pointer_es
     gate_prog.destroy()
     if coset_prog is not None:
         coset_prog.destroy()
+    for st in slots:
+        with torch.cuda.device(st["device"]):
+            st["prog"].destroy()
     if world > 1 and not job_mode:
         release_bases(g_h)
         release_bases(gl_h)

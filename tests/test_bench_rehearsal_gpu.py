@@ -77,6 +77,7 @@ def test_two_ranks_replay_the_k18_proof_and_rank0_replays_it_in_one_process():
     assert rep["verified"]["commitments_checked"] >= 3 * (rep["calls"]["msm_sparse"] + rep["calls"]["msm_dense"])
     op = two["one_process"]["create_proof_replay"]
     assert op["k"] == 18 and op["multi_gpu_split"].startswith("one process")
+    assert op["extended_domain"].startswith("by cosets over 2 devices")           # one host thread per listed device
     assert op["verified"]["commitments_checked"] >= 3 * (op["calls"]["msm_sparse"] + op["calls"]["msm_dense"])
     assert "strong_scaling" not in two
 

@@ -504,3 +504,28 @@ def test_coset_tables_survive_many_shifts_and_two_streams():
         _lib.check(lib.hm_coeff_to_coset_bn256_fr_dev(ctypes.c_void_p(a.data_ptr()), ctypes.c_void_p(out.data_ptr()), 1, _ptr(fr_words(dom.omega)),
                                                       k, _ptr(fr_words(1000 + i)), 0, ctypes.c_void_p(_stream_ptr(a))))
     assert bool((dom.coeff_to_coset(a, 5) == want[5::8]).all())             # rebuilt after eviction
+
+
+def test_coset_transforms_at_the_smallest_sizes(pyref):
+    """log_n = 0 and 1 through the C entry points themselves (EvaluationDomain starts at k = 1): one element is its own
+    transform on any coset; two elements a0 + a1 X at shift and -shift."""
+    import torch
+    from halo2_experiments_amd.arithmetic import _ptr, _stream_ptr
+    lib = _lib.load()
+    R = pyref.R
+    shift = 0x1234567890ABCDEF1234567890ABCDEF % R
+    a = rand_fr_gpu(2, 4700)
+    av = pyref.fr_from_array(a.cpu().numpy().view(np.uint64))
+    out = torch.empty_like(a)
+    one = fr_words(1)
+    _lib.check(lib.hm_coeff_to_coset_bn256_fr_dev(ctypes.c_void_p(a.data_ptr()), ctypes.c_void_p(out.data_ptr()), 2, _ptr(one), 0, _ptr(fr_words(shift)),
+                                                  0, ctypes.c_void_p(_stream_ptr(a))))
+    assert bool((out == a).all())                                           # two 1-element arrays
+    _lib.check(lib.hm_coeff_to_coset_bn256_fr_dev(ctypes.c_void_p(a.data_ptr()), ctypes.c_void_p(out.data_ptr()), 1, _ptr(fr_words(R - 1)), 1,
+                                                  _ptr(fr_words(shift)), 0, ctypes.c_void_p(_stream_ptr(a))))
+    assert pyref.fr_from_array(out.cpu().numpy().view(np.uint64)) == [(av[0] + av[1] * shift) % R, (av[0] - av[1] * shift) % R]
+    back = out.clone()
+    _lib.check(lib.hm_coset_to_coeff_bn256_fr_dev(ctypes.c_void_p(back.data_ptr()), 1, _ptr(fr_words(R - 1)), 1, _ptr(fr_words(pow(2, -1, R))),
+                                                  _ptr(fr_words(pow(shift, -1, R))), ctypes.c_void_p(_stream_ptr(back))))
+    assert bool((back == a).all())                                          # the inverse route returns the coefficients
+    assert lib.hm_coeff_to_coset_bn256_fr_dev(ctypes.c_void_p(a.data_ptr()), ctypes.c_void_p(out.data_ptr()), 0, _ptr(one), 1, _ptr(one), 0, None) == 0
