@@ -277,9 +277,10 @@ def run_replay(shape_name: str, device=None, group=None, include_host_pointer_es
 
     def whole_array_steps(t):
         t0 = time.perf_counter()
-        # each transform stays on ONE GPU (north star); in job mode the independent transforms of a phase are dealt
-        # to the ranks like the commitments, otherwise rank 0 runs them all
-        share = (lambda c: len(range(rank, c, world))) if job_mode else (lambda c: c if rank == 0 else 0)
+        # each transform stays on ONE GPU (north star) and rank 0 runs them all: evaluate_h below reads every extended array,
+        # and arrays transformed elsewhere would have to cross xGMI whole (round 3 dealt them and never moved them; with more
+        # than one rank the scaling route is coset_steps)
+        share = lambda c: c if rank == 0 else 0
         if share(counts["intt_n"]) or share(counts["coset_ntt_ext"]):
             # same-size transforms of one prover phase go through one batched call (<= 8 polynomials at a
             # time here, bounding the extended-domain buffers)
