@@ -593,7 +593,10 @@ static int msm_batch_impl(DeviceCtx* ctx, uint64_t handle, size_t offset, const 
       // (and as many chains as waiter threads when there are commitments for them: the host fold of a chain's results is
       // serial per chain)
       const size_t chains_min = (count + HM_MSM_GROUP - 1) / HM_MSM_GROUP;
-      const size_t want = count / 2 < 4 ? count / 2 : 4;
+#ifndef HM_BATCH_SMALL_CHAINS
+#define HM_BATCH_SMALL_CHAINS 4
+#endif
+      const size_t want = count / 2 < (size_t)HM_BATCH_SMALL_CHAINS ? count / 2 : (size_t)HM_BATCH_SMALL_CHAINS;
       const size_t chains = chains_min > want ? chains_min : want;
       size_t per_chain = (count + chains - 1) / (chains ? chains : 1);
       if (per_chain < 1) per_chain = 1;
@@ -713,7 +716,10 @@ static int msm_batch_impl(DeviceCtx* ctx, uint64_t handle, size_t offset, const 
   // the 36 advice columns of a k = 18 proof on one thread -- measured as 40 % GPU idle time in that phase).  So up to
   // kWaiters threads of this call await the chains, waiter t taking chains t, t + T, t + 2T, ...; the calling thread
   // only submits.  They are started after the first lanes are filled, so that their creation overlaps the GPU's work.
-  constexpr size_t kWaiters = 4;
+#ifndef HM_BATCH_WAITERS
+#define HM_BATCH_WAITERS 8      // A/B knob (tools/ab_build.sh): 8 against 4 -- 36 sparse commitments at k = 18 1.60 -> 1.41 ms, dense phases unchanged
+#endif
+  constexpr size_t kWaiters = HM_BATCH_WAITERS;
   size_t n_waiters = 0;                         // set before any waiter starts
   auto waiter = [&](size_t t) {
     (void)hipSetDevice(device);
