@@ -36,6 +36,22 @@ def fr_words(v: int) -> np.ndarray:
     return np.array([(m >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)], dtype=np.uint64)
 
 
+def _vandermonde_inverse(nodes, r):
+    """Inverse of V[a][t] = nodes[a]^t mod r (q x q, q <= a few dozen) by Gauss-Jordan on Python integers."""
+    q = len(nodes)
+    m = [[pow(x, t, r) for t in range(q)] + [1 if a == b else 0 for b in range(q)] for a, x in enumerate(nodes)]
+    for col in range(q):
+        piv = next(row for row in range(col, q) if m[row][col] % r)
+        m[col], m[piv] = m[piv], m[col]
+        inv = pow(m[col][col], -1, r)
+        m[col] = [v * inv % r for v in m[col]]
+        for row in range(q):
+            if row != col and m[row][col]:
+                f = m[row][col]
+                m[row] = [(v - f * w) % r for v, w in zip(m[row], m[col])]
+    return [row[q:] for row in m]
+
+
 class EvaluationDomain:
     def __init__(self, j: int, k: int):
         if j < 2:
@@ -157,25 +173,46 @@ class EvaluationDomain:
             _ptr(fr_words(pow(self.coset_shift(j), -1, FR_MODULUS))), ctypes.c_void_p(_stream_ptr(v))))
         return v
 
-    def combine_cosets(self, partials, pieces: int = None):
-        """partials[j] = coset_to_partial(values on coset j), j = 0 .. E - 1 -> the (pieces * n, 4) coefficients that
-        ``extended_to_coeff`` returns for the same polynomial (pieces defaults to the quotient degree j - 1): piece q is
-        zeta^(-n q) / E * sum_j w^(-j q) partials[j], one linear combination of E arrays."""
+    def min_cosets(self) -> int:
+        """Cosets that DETERMINE the quotient: h has fewer than n * (j - 1) coefficients, so its values on any j - 1 of the E
+        cosets do (each coset contributes n equations per residue class of coefficients)."""
+        return self.quotient_poly_degree
+
+    def combine_cosets(self, partials, pieces: int = None, cosets=None):
+        """partials[a] = coset_to_partial(values on coset cosets[a]) -> the coefficients of the polynomial those values belong
+        to.  ``cosets=None``: all E cosets in order -- any polynomial of degree < E n, the same words ``extended_to_coeff``
+        returns (``pieces`` rows of n coefficients, default the quotient's j - 1).  ``cosets=[j_0, .., j_(q-1)]``: q distinct
+        cosets only -- the polynomial of degree < q n through those values (q * n coefficients).  For the quotient h of a
+        SATISFIED circuit (degree < n (j - 1): upstream's extended_to_coeff truncates to exactly that many coefficients)
+        q = j - 1 cosets give the same words as all E; the other E - (j - 1) cosets of evaluate_h need not be computed at all.
+        For an unsatisfied witness the numerator is not divisible by X^n - 1, the two differ, and neither is a proof.
+        With u_j = (zeta * extended_omega^j)^n: partial_j[i] = sum_t piece_t[i] u_j^t, so piece_t = sum_a Vinv[t][a] partial_a
+        with V[a][t] = u_(j_a)^t -- one linear combination of q arrays per piece (for all E cosets Vinv is the inverse DFT
+        zeta^(-n t) / E * w^(-j t))."""
         import torch
         from .arithmetic import linear_combination
 
         e = self.num_cosets()
-        if len(partials) != e:
-            raise ValueError("combine_cosets: one partial per coset")
-        pieces = self.quotient_poly_degree if pieces is None else pieces
         r = FR_MODULUS
-        w_inv = pow(pow(self.extended_omega, self.n, r), -1, r)
-        zn_inv = pow(pow(self.g_coset, self.n, r), -1, r)
-        e_inv = pow(e, -1, r)
+        if cosets is None:
+            cosets = list(range(e))
+            default_pieces = self.quotient_poly_degree
+        else:
+            cosets = [int(c) for c in cosets]
+            default_pieces = len(cosets)
+            if len(set(cosets)) != len(cosets) or any(not 0 <= c < e for c in cosets):
+                raise ValueError("combine_cosets: cosets must be distinct indices below E")
+        q = len(cosets)
+        if len(partials) != q:
+            raise ValueError("combine_cosets: one partial per coset")
+        pieces = default_pieces if pieces is None else pieces
+        if not 0 < pieces <= q:
+            raise ValueError("combine_cosets: at most one piece per coset")
+        nodes = [pow(self.coset_shift(c), self.n, r) for c in cosets]
+        vinv = _vandermonde_inverse(nodes, r)
         out = torch.empty((pieces, self.n, 4), dtype=partials[0].dtype, device=partials[0].device)
-        for q in range(pieces):
-            coeffs = np.stack([fr_words(pow(zn_inv, q, r) * e_inv % r * pow(w_inv, j * q, r) % r) for j in range(e)])
-            linear_combination(list(partials), coeffs, out=out[q])
+        for t in range(pieces):
+            linear_combination(list(partials), np.stack([fr_words(vinv[t][a]) for a in range(q)]), out=out[t])
         return out.reshape(pieces * self.n, 4)
 
     def extended_to_coeff(self, a):

@@ -134,6 +134,28 @@ def test_mini_proof_quotient_identity(pyref, tamper):
     h_coeff = dom.extended_to_coeff(h_ext)                                             # (3n, 4): h(X); in place on h_ext
     torch.cuda.synchronize()
     degree_ok = not h_ext[3 * n:].any()                                                # deg h < 3n iff Z_H divides the numerator
+    # ---- the same quotient from j - 1 = 3 of the 4 cosets of the extended domain only (EvaluationDomain.combine_cosets) ----
+    # every column onto the coset from its coefficients, the per-coset program (rotations unscaled, 1 / (X^n - 1) a constant),
+    # the inverse transform: for a SATISFIED circuit word for word the h above; for the tampered one a different polynomial
+    g1 = ev.GraphEvaluator()
+    g1.add_custom_gates(exprs)
+    g1.add_vanishing_division(ev.Challenge(0))
+    prog1 = g1.compile(10, 8, 0, num_challenges=1, rot_scale=1)
+    all_coeffs = torch.cat([coeffs, x_poly.reshape(1, n, 4)])
+    assert dom.min_cosets() == 3 and dom.num_cosets() == 4
+    parts, use = [], [3, 0, 2]
+    for c in use:
+        cc = dom.coeff_to_coset(all_coeffs, c)
+        cols_c = [cc[i] for i in range(8)] + [cc[16], cc[16]] + [cc[8 + i] for i in range(8)]      # (fixed 9, the pattern column, is unread here)
+        v = torch.zeros((n, 4), dtype=torch.int64, device="cuda")
+        prog1.evaluate(cols_c, v, challenges=[dom.coset_vanishing_inverse(c)], beta=beta, gamma=gamma, theta=theta, y=y)
+        parts.append(dom.coset_to_partial(v, c))
+    prog1.destroy()
+    h_min = dom.combine_cosets(parts, cosets=use)
+    if not tamper:
+        assert h_min.shape == h_coeff.shape and bool((h_min == h_coeff).all())
+    else:
+        assert not bool((h_min == h_coeff).all())
 
     # ---- the verifier's check at x ----------------------------------------------------------------------------------
     rots = [0, 1, -1, -(blinding + 1)]

@@ -529,3 +529,41 @@ def test_coset_transforms_at_the_smallest_sizes(pyref):
                                                   _ptr(fr_words(pow(shift, -1, R))), ctypes.c_void_p(_stream_ptr(back))))
     assert bool((back == a).all())                                          # the inverse route returns the coefficients
     assert lib.hm_coeff_to_coset_bn256_fr_dev(ctypes.c_void_p(a.data_ptr()), ctypes.c_void_p(out.data_ptr()), 0, _ptr(one), 1, _ptr(one), 0, None) == 0
+
+
+@pytest.mark.parametrize("k,j", [(4, 6), (10, 6), (13, 7), (16, 4)])
+def test_a_polynomial_below_q_n_is_recovered_from_any_q_cosets(pyref, k, j):
+    """The quotient of a satisfied circuit has fewer than n (j - 1) coefficients, so its values on j - 1 of the E cosets
+    determine it: combine_cosets(cosets=[...]) solves the (j - 1) x (j - 1) Vandermonde system per residue class.  A random
+    polynomial with q n coefficients (as q pieces of n) is evaluated on the cosets piece by piece -- value on coset c =
+    sum_t u_c^t * coeff_to_coset(piece_t, c), u_c = shift_c^n -- and comes back word for word from several subsets; with one coset
+    more than needed the extra piece is zero; all E cosets agree with extended_to_coeff (the existing test)."""
+    import torch
+    dom = EvaluationDomain(j, k)
+    n, e, q = dom.n, dom.num_cosets(), dom.min_cosets()
+    R = pyref.R
+    assert q == j - 1 and q <= e
+    pieces = rand_fr_gpu(q * n, 5100 + k).reshape(q, n, 4)
+
+    def values_on(c):
+        u = pow(dom.coset_shift(c), n, R)
+        terms = [dom.coeff_to_coset(pieces[t], c) for t in range(q)]
+        return h.linear_combination(terms, np.stack([fr_words(pow(u, t, R)) for t in range(q)]))
+
+    rng = np.random.default_rng(k)
+    subsets = [list(range(q)), sorted(rng.choice(e, q, replace=False).tolist(), reverse=True)]
+    if q < e:
+        subsets.append(list(range(e - q, e)))
+    for cosets in subsets:
+        parts = [dom.coset_to_partial(values_on(c), c) for c in cosets]
+        got = dom.combine_cosets(parts, cosets=cosets)
+        assert got.shape == (q * n, 4) and bool((got == pieces.reshape(q * n, 4)).all()), (k, cosets)
+    if q < e:
+        cosets = list(range(q + 1))
+        parts = [dom.coset_to_partial(values_on(c), c) for c in cosets]
+        got = dom.combine_cosets(parts, cosets=cosets)
+        assert bool((got[: q * n] == pieces.reshape(q * n, 4)).all()) and not got[q * n:].any()
+    with pytest.raises(ValueError):
+        dom.combine_cosets([pieces[0]], cosets=[e])
+    with pytest.raises(ValueError):
+        dom.combine_cosets([pieces[0], pieces[1]], cosets=[1, 1])
