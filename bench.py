@@ -798,24 +798,41 @@ def main():
         scalars = None
         torch.cuda.empty_cache()
         replay = [run_replay(name, device=device) for name in args.replay.split(",")]   # every rank takes part
-        # N = 1: what ONE GPU can measure of the N-GPU replay -- rank 0's share (it also runs the rank-0-only steps, so it is the
-        # longest) of the 2-, 4- and 8-rank deal of the largest shape, alone, nothing exchanged.  DESIGN.md section 6 builds its
+        # N = 1: what ONE GPU can measure of the N-GPU replay -- the first and the last rank's share of the 2-, 4- and 8-rank deal of
+        # the largest shape, each alone, nothing exchanged.  DESIGN.md section 6 builds its
         # predicted curve on these.
         if world == 1 and not args.no_extras and not args.no_shares:
             big = [nm for nm in args.replay.split(",") if nm == "merkle_sum_tree_k18"]
             for nm in big:
                 shares = []
                 for w in (2, 4, 8):
+                    for rk in (0, w - 1):           # rank 0 also runs the rank-0-only steps; the last rank gets the first coset
+                        try:
+                            r = run_replay(nm, device=device, include_host_pointer_estimate=False, share_of=(rk, w))
+                            shares.append({"world": w, "rank": rk, "ms": {k2: v * 1e3 for k2, v in r["device_resident_s"].items()},
+                                           "extended_domain": r["extended_domain"]})
+                        except Exception as exc:  # noqa: BLE001 -- a side measurement never costs the line
+                            shares.append({"world": w, "rank": rk, "error": f"{type(exc).__name__}: {exc}"})
+                rep18 = next(rep for rep in replay if rep["k"] == 18)
+                # the same trace with the extended-domain steps taken coset by coset on this one GPU: all E cosets (the multi-GPU
+                # route's work, 5 % more than the whole array) and only the j - 1 cosets that determine the quotient
+                routes = {"whole_array": {k2: v * 1e3 for k2, v in rep18["device_resident_s"].items()}}
+                for label, kw in (("by_all_cosets", {"min_cosets": False}), ("by_the_cosets_that_determine_h", {"min_cosets": True})):
                     try:
-                        r = run_replay(nm, device=device, include_host_pointer_estimate=False, share_of=(0, w))
-                        shares.append({"world": w, "rank": 0, "ms": {k2: v * 1e3 for k2, v in r["device_resident_s"].items()},
-                                       "extended_domain": r["extended_domain"]})
-                    except Exception as exc:  # noqa: BLE001 -- a side measurement never costs the line
-                        shares.append({"world": w, "error": f"{type(exc).__name__}: {exc}"})
-                next(rep for rep in replay if rep["k"] == 18)["rank0_share_measured_alone"] = {
-                    "shares": shares, "note": "rank 0's share of the N-rank replay run alone on this GPU (its commitments of every phase, its "
-                                              "cosets of the extended domain, the steps only rank 0 runs); the exchanges -- 96 B per commitment, "
-                                              "n x 32 B per coset -- are not in the time"}
+                        r = run_replay(nm, device=device, include_host_pointer_estimate=False, by_cosets=True, **kw)
+                        routes[label] = {k2: v * 1e3 for k2, v in r["device_resident_s"].items()}
+                        routes[label]["extended_domain"] = r["extended_domain"]
+                    except Exception as exc:  # noqa: BLE001
+                        routes[label] = {"error": f"{type(exc).__name__}: {exc}"}
+                routes["note"] = ("the quotient of a satisfied circuit has fewer than n (j - 1) coefficients: j - 1 of the E cosets determine it "
+                                  "(same h word for word: tests/test_mini_prover_gpu.py); create_proof_replay.device_resident_s stays the "
+                                  "whole-array route, upstream's own steps")
+                rep18["extended_domain_routes_ms"] = routes
+                rep18["rank_shares_measured_alone"] = {
+                    "shares": shares, "note": "the first and the last rank's share of the N-rank replay, each run alone on this GPU (its "
+                                              "commitments of every phase, its cosets of the extended domain, for rank 0 the steps only rank 0 "
+                                              "runs); the step takes the longer of them plus the exchanges -- 96 B per commitment, n x 32 B "
+                                              "per coset -- which are not in these times"}
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
             for rep in replay:
                 rep["cpu_baseline"] = replay_cpu_baseline(rep, device)

@@ -135,21 +135,52 @@ class EvaluationDomain {
     arithmetic::check(hm_coset_to_coeff_bn256_fr_dev(v.d, v.batch, omega_inv.l, k, ifft_divisor.l, coset_shift(j).invert().l, stream),
                       "coset_to_partial");
   }
-  // the E partials (device pointers to n elements each) -> `pieces` x n coefficients at out: piece q = zeta^(-n q) / E *
-  // sum_j w^(-j q) partials[j] -- what extended_to_coeff returns for the same polynomial
-  void combine_cosets(const std::vector<const Fr*>& partials, size_t pieces, Fr* out, hipStream_t stream = nullptr) const {
-    const size_t e = num_cosets();
-    if (partials.size() != e) throw std::invalid_argument("combine_cosets: one partial per coset");
-    Fr zn = g_coset;
-    for (uint32_t b = 0; b < k; ++b) zn = zn.square();
-    Fr w = extended_omega;
-    for (uint32_t b = 0; b < k; ++b) w = w.square();              // extended_omega^n: a primitive E-th root of unity
-    const Fr zn_inv = zn.invert(), w_inv = w.invert(), e_inv = Fr::from_u64((uint64_t)e).invert();
-    for (size_t q = 0; q < pieces; ++q) {
-      std::vector<Fr> c(e);
-      for (size_t j = 0; j < e; ++j) c[j] = zn_inv.pow_u64(q) * e_inv * w_inv.pow_u64(j * q);
-      arithmetic::linear_combination(partials, c, n, out + q * n, stream);
+  // The quotient has fewer than n * quotient_poly_degree coefficients: that many cosets determine it.
+  size_t min_cosets() const { return quotient_poly_degree; }
+  // partials[a] = coset_to_partial(values on coset cosets[a]) (device pointers to n elements each) -> `pieces` x n
+  // coefficients at out: the polynomial of degree < q n through the values on those q cosets.  With all E cosets in order it
+  // is what extended_to_coeff returns; with q = quotient_poly_degree cosets it is the same quotient for a satisfied circuit,
+  // and the other E - q cosets of evaluate_h need not be computed.  partial_j[i] = sum_t piece_t[i] u_j^t, u_j =
+  // coset_shift(j)^n: piece_t = sum_a Vinv[t][a] partial_a, V[a][t] = u_(j_a)^t (Gauss-Jordan on the host, q <= E).
+  void combine_cosets(const std::vector<const Fr*>& partials, const std::vector<size_t>& cosets, size_t pieces, Fr* out,
+                      hipStream_t stream = nullptr) const {
+    const size_t q = cosets.size();
+    if (partials.size() != q || q == 0 || pieces == 0 || pieces > q) throw std::invalid_argument("combine_cosets: one partial per coset, at most one piece per coset");
+    for (size_t a = 0; a < q; ++a) {
+      if (cosets[a] >= num_cosets()) throw std::invalid_argument("combine_cosets: no such coset");
+      for (size_t b = 0; b < a; ++b)
+        if (cosets[a] == cosets[b]) throw std::invalid_argument("combine_cosets: cosets must be distinct");
     }
+    std::vector<std::vector<Fr>> m(q, std::vector<Fr>(2 * q, Fr::zero()));
+    for (size_t a = 0; a < q; ++a) {
+      Fr u = coset_shift(cosets[a]);
+      for (uint32_t b = 0; b < k; ++b) u = u.square();
+      Fr p = Fr::one();
+      for (size_t t = 0; t < q; ++t) { m[a][t] = p; p = p * u; }
+      m[a][q + a] = Fr::one();
+    }
+    for (size_t col = 0; col < q; ++col) {
+      size_t piv = col;
+      while (m[piv][col] == Fr::zero()) ++piv;                    // distinct nodes: the matrix is invertible
+      std::swap(m[col], m[piv]);
+      const Fr inv = m[col][col].invert();
+      for (Fr& v : m[col]) v = v * inv;
+      for (size_t row = 0; row < q; ++row) {
+        if (row == col || m[row][col] == Fr::zero()) continue;
+        const Fr f = m[row][col];
+        for (size_t c2 = 0; c2 < 2 * q; ++c2) m[row][c2] = m[row][c2] - f * m[col][c2];
+      }
+    }
+    for (size_t t = 0; t < pieces; ++t) {
+      std::vector<Fr> c(q);
+      for (size_t a = 0; a < q; ++a) c[a] = m[t][q + a];
+      arithmetic::linear_combination(partials, c, n, out + t * n, stream);
+    }
+  }
+  void combine_cosets(const std::vector<const Fr*>& partials, size_t pieces, Fr* out, hipStream_t stream = nullptr) const {
+    std::vector<size_t> all(num_cosets());
+    for (size_t j = 0; j < all.size(); ++j) all[j] = j;
+    combine_cosets(partials, all, pieces, out, stream);
   }
   // extended_to_coeff: ifft over the extended domain, undo the coset shift (caller truncates to n*(j-1))
   void extended_to_coeff(DevicePolys& a, hipStream_t stream = nullptr) const {

@@ -355,6 +355,20 @@ int main(int argc, char** argv) {
         if (!(a[i] == b[i])) opening_ok = false;
       for (size_t i = 0; i < n; ++i)                              // a polynomial of degree < n: its own coefficients, then zeros
         if (!(a[i] == dense[i])) opening_ok = false;
+      // ... and from the quotient_poly_degree cosets that determine a polynomial of that degree (here any subset does)
+      if (dom.min_cosets() <= e && e >= 2) {
+        const size_t q = dom.min_cosets() < 2 ? 2 : dom.min_cosets();
+        std::vector<const Fr*> sub;
+        std::vector<size_t> which;
+        for (size_t a2 = 0; a2 < q; ++a2) { which.push_back(e - 1 - a2); sub.push_back(part.poly(e - 1 - a2)); }
+        poly::DevicePolys few(n, q);
+        dom.combine_cosets(sub, which, q, few.d);
+        const std::vector<Fr> c = few.download();
+        for (size_t i = 0; i < n; ++i)
+          if (!(c[i] == dense[i])) opening_ok = false;
+        for (size_t i = n; i < c.size(); i += 37)
+          if (!(c[i] == Fr::zero())) opening_ok = false;
+      }
     }
     if (!opening_ok) ok = false;
     size_t bad = 0;

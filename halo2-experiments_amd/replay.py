@@ -46,7 +46,7 @@ from .arithmetic import (G1_GENERATOR, batch_invert, best_multiexp, best_multiex
                          release_bases)
 from .domain import EvaluationDomain, FR_MODULUS, fr_words
 from .kzg import ParamsKZG
-from .sharding import (_NO_GROUP, coset_owner, gather_coset_partials, job_owner, job_parallel_multiexp_batch, shard_range, sharded_multiexp,
+from .sharding import (_NO_GROUP, coset_owners, gather_coset_partials, job_owner, job_parallel_multiexp_batch, shard_range, sharded_multiexp,
                        sharded_multiexp_batch)
 
 # the replay's SRS trapdoor (the reference draws it from OsRng, utils.rs:28): known here, so that every
@@ -115,7 +115,7 @@ def _sparse_column(n, used_rows, seed, device):
 
 
 def run_replay(shape_name: str, device=None, group=None, include_host_pointer_estimate: bool = True,
-               in_flight: int = 8, solo: bool = False, by_cosets=None, share_of=None, devices=None) -> dict:
+               in_flight: int = 8, solo: bool = False, by_cosets=None, share_of=None, devices=None, min_cosets=None) -> dict:
     """``solo``: this process runs the replay ALONE even inside an initialised process group (bench.py's one-process form:
     the other ranks are parked; the split over devices, if any, is hm_set_msm_devices' inside the library).
     ``devices`` (with ``solo``): the device list of the one-process form (hm_set_msm_devices has been called with it).  With
@@ -126,6 +126,10 @@ def run_replay(shape_name: str, device=None, group=None, include_host_pointer_es
     ``share_of=(rank, world)``: ONE rank's share of the `world`-rank replay, run alone (no process group, no exchange):
     its commitments of every phase, its cosets, and -- for rank 0 -- the steps only rank 0 runs.  What a one-GPU box can
     MEASURE of the N-GPU replay; the exchanges (96 B per commitment, n x 32 B per coset) are what it leaves out.
+    ``min_cosets`` (with the coset route; default on): evaluate_h on the j - 1 cosets that DETERMINE the quotient instead of all
+    E = 2^(extended_k - k) (EvaluationDomain.combine_cosets(cosets=...): h has fewer than n (j - 1) coefficients -- 5 of 8 cosets for
+    the MerkleSumTree circuit); the cosets are then dealt from the last rank backwards, rank 0 gets one last.  The same h for a
+    satisfied circuit, word for word (tests/test_mini_prover_gpu.py); the replay's columns are synthetic and its h is not checked.
     ``by_cosets``: the extended-domain steps (coset transforms, evaluate_h, the inverse transform of h) one coset of the
     n-th roots at a time (EvaluationDomain.coeff_to_coset).  Default: on with more than one rank from k = 14 -- the E = 2^(extended_k
     - k) cosets are dealt over the ranks, every rank transforms all columns onto ITS cosets from the coefficient arrays, runs
@@ -212,24 +216,30 @@ def run_replay(shape_name: str, device=None, group=None, include_host_pointer_es
                            short_columns=lay.short_columns)
     t_inv_col = _rand_fr(1 << (dom.extended_k - k), 500, device)          # the 2^(extended_k - k) values of 1 / (X^n - 1) on the coset
     E = dom.num_cosets()
+    if min_cosets is None:
+        min_cosets = True
+    use_cosets = list(range(dom.min_cosets() if min_cosets else E))       # the cosets evaluate_h runs on (positions = indices here)
+    NC = len(use_cosets)
     coset_prog = None
     if by_cosets:
         ge1, lay1 = evaluate_h_program(cs, k, dom.extended_k, delta=pow(7, 1 << 28, FR_MODULUS), per_coset=True)
         coset_prog = ge1.compile(lay1.num_fixed_entries, cs.num_advice, cs.num_instance, num_challenges=1, rot_scale=1)
-        my_cosets = [c for c in range(E) if coset_owner(c, world) == rank]
+        owners = coset_owners(NC, world, spare_rank0=min_cosets) if world > 1 else [0] * NC
+        my_cosets = [c for c in use_cosets if owners[c] == rank]
         coset_cols = torch.empty((8, n, 4), dtype=torch.int64, device=device)
         coset_values = {c: torch.zeros((n, 4), dtype=torch.int64, device=device) for c in my_cosets}
     slots = []
     if one_proc_devs:
         # one state per listed device (a device listed twice -- the one-GPU rehearsal -- gets two states): its own copy of the
         # columns, its own evaluator program (programs belong to a device context), its own outputs
+        dev_owner = coset_owners(NC, len(one_proc_devs), spare_rank0=min_cosets)
         for i, dv in enumerate(one_proc_devs):
             with torch.cuda.device(dv):
                 tdev = torch.device("cuda", dv)
                 slots.append({
-                    "index": i, "device": tdev, "cosets": [c for c in range(E) if c % len(one_proc_devs) == i],
+                    "index": i, "device": tdev, "cosets": [c for c in use_cosets if dev_owner[c] == i],
                     "ntt_batch": ntt_batch.to(tdev).clone(), "coset_cols": torch.empty((8, n, 4), dtype=torch.int64, device=tdev),
-                    "values": {c: torch.zeros((n, 4), dtype=torch.int64, device=tdev) for c in range(E) if c % len(one_proc_devs) == i},
+                    "values": {c: torch.zeros((n, 4), dtype=torch.int64, device=tdev) for c in use_cosets if dev_owner[c] == i},
                     "prog": ge1.compile(lay1.num_fixed_entries, cs.num_advice, cs.num_instance, num_challenges=1, rot_scale=1),
                 })
 
@@ -348,11 +358,12 @@ def run_replay(shape_name: str, device=None, group=None, include_host_pointer_es
             t["ntt"] += time.perf_counter() - t0
         t0 = time.perf_counter()
         if share_of is not None:              # no exchange: the recombination runs on this rank's partials, repeated
-            allp = [parts[my_cosets[c % len(my_cosets)]] for c in range(E)] if my_cosets else []
+            # (a rank without a coset -- rank 0 of eight with five cosets -- still pays for the recombination: any array stands in)
+            allp = [parts[my_cosets[c % len(my_cosets)]] if my_cosets else coset_cols[c % 8] for c in use_cosets]
         else:
-            allp = gather_coset_partials(parts, E, group=group, shape=(n, 4))
+            allp = gather_coset_partials(parts, NC, group=group, shape=(n, 4), owners=owners)
         if rank == 0 and allp:
-            dom.combine_cosets([p.to(device) for p in allp])
+            dom.combine_cosets([p.to(device) for p in allp], cosets=use_cosets if min_cosets else None)
         torch.cuda.synchronize()
         t["ntt"] += time.perf_counter() - t0
 
@@ -414,7 +425,7 @@ def run_replay(shape_name: str, device=None, group=None, include_host_pointer_es
         parts = {}
         for pr, _ in results:
             parts.update(pr)
-        dom.combine_cosets([parts[c].to(device) for c in range(E)])
+        dom.combine_cosets([parts[c].to(device) for c in use_cosets], cosets=use_cosets if min_cosets else None)
         torch.cuda.synchronize()
         block = time.perf_counter() - t0
         t["evaluate_h"] = max(tm["evaluate_h"] for _, tm in results)
@@ -508,11 +519,12 @@ def run_replay(shape_name: str, device=None, group=None, include_host_pointer_es
                                                                "(96 B per commitment, n x 32 B per coset) in the time"}}
            if share_of is not None else {}),
         "multi_gpu_split": ("whole commitments per rank (full SRS on every GPU); extended-domain steps by cosets: "
-                            f"{E} cosets dealt over the ranks, n x 32 B per coset gathered" if by_cosets else
+                            f"{NC} of {E} cosets dealt over the ranks, n x 32 B per coset gathered" if by_cosets else
                             "whole commitments / transforms per rank (full SRS on every GPU)") if job_mode else
                            ("index-range shards" if world > 1 else "none"),
-        "extended_domain": (f"by cosets over {len(one_proc_devs)} devices, one host thread each" if one_proc_devs else
-                            "by cosets (coeff_to_coset, per-coset evaluate_h, coset_to_partial, combine_cosets)") if by_cosets
+        "extended_domain": (f"by cosets over {len(one_proc_devs)} devices, one host thread each ({NC} of {E} cosets)" if one_proc_devs else
+                            f"by cosets, {NC} of {E} (coeff_to_coset, per-coset evaluate_h, coset_to_partial, combine_cosets"
+                            + (": the j - 1 cosets that determine the quotient)" if NC < E else ")")) if by_cosets
                            else "whole array (coeff_to_extended, evaluate_h over 2^extended_k rows, extended_to_coeff)",
         "shape": {"advice": A, "lookups": L, "equality_columns": shape.equality_columns, "max_degree": d,
                   "source": shape.source},

@@ -146,9 +146,18 @@ def coset_owner(coset: int, world: int) -> int:
     return coset % world
 
 
-def gather_coset_partials(mine, num_cosets: int, group=None, shape=None):
+def coset_owners(num_cosets: int, world: int, spare_rank0: bool = False):
+    """rank of every coset position 0 .. num_cosets - 1.  ``spare_rank0``: dealt from the LAST rank backwards, so that with
+    fewer cosets than ranks (evaluate_h on the j - 1 cosets that determine the quotient) rank 0 -- which also runs the steps
+    only one rank runs -- gets one last."""
+    if spare_rank0:
+        return [world - 1 - (c % world) for c in range(num_cosets)]
+    return [coset_owner(c, world) for c in range(num_cosets)]
+
+
+def gather_coset_partials(mine, num_cosets: int, group=None, shape=None, owners=None):
     """evaluate_h by cosets over the ranks: ``mine`` = {coset: (n, 4) tensor} -- what ``coset_to_partial`` left for the
-    cosets this rank owns (``coset_owner``).  ONE all-gather of ceil(E / world) x n x 32 B per rank; returns the list of
+    coset POSITIONS this rank owns (``owners[position]``, default ``coset_owner``: position % world).  ONE all-gather of ceil(E / world) x n x 32 B per rank; returns the list of
     the E partials in coset order (on the device for RCCL, on the host for gloo), ready for ``combine_cosets``.  Without a
     process group (or with ``_NO_GROUP``) ``mine`` must hold all E.  ``shape``: the shape of one partial -- required on a
     rank that owns no coset (more ranks than cosets)."""
@@ -159,10 +168,17 @@ def gather_coset_partials(mine, num_cosets: int, group=None, shape=None):
     if not distributed:
         return [mine[c] for c in range(num_cosets)]
     world, rank = dist.get_world_size(group), dist.get_rank(group)
-    owned = [c for c in range(num_cosets) if coset_owner(c, world) == rank]
+    owners = list(owners) if owners is not None else coset_owners(num_cosets, world)
+    if len(owners) != num_cosets or any(not 0 <= o < world for o in owners):
+        raise ValueError("gather_coset_partials: one owner rank per coset position")
+    owned = [c for c in range(num_cosets) if owners[c] == rank]
     if sorted(mine) != owned:
         raise ValueError(f"gather_coset_partials: rank {rank} owns cosets {owned}, got {sorted(mine)}")
-    per_rank = (num_cosets + world - 1) // world
+    per_rank = max(1, max(owners.count(r) for r in range(world)))
+    slot_of = {}
+    for r in range(world):
+        for slot, c in enumerate([c for c in range(num_cosets) if owners[c] == r]):
+            slot_of[c] = slot
     backend = dist.get_backend(group)
     if shape is None:
         if not mine:
@@ -171,8 +187,8 @@ def gather_coset_partials(mine, num_cosets: int, group=None, shape=None):
     shape = tuple(shape)
     dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
     buf = torch.zeros((per_rank,) + shape, dtype=torch.int64, device=dev)
-    for slot, c in enumerate(owned):
-        buf[slot] = mine[c].to(dev)
+    for c in owned:
+        buf[slot_of[c]] = mine[c].to(dev)
     gathered = [torch.empty_like(buf) for _ in range(world)]
     dist.all_gather(gathered, buf, group=group)
-    return [gathered[coset_owner(c, world)][c // world] for c in range(num_cosets)]
+    return [gathered[owners[c]][slot_of[c]] for c in range(num_cosets)]

@@ -73,7 +73,7 @@ def test_two_ranks_replay_the_k18_proof_and_rank0_replays_it_in_one_process():
     two = _bench(2, 18, replay="merkle_sum_tree_k18", extra=("--no-strong",))
     (rep,) = two["create_proof_replay"]
     assert rep["k"] == 18 and rep["n_gpus"] == 2 and rep["multi_gpu_split"].startswith("whole commitments")
-    assert "8 cosets dealt over the ranks" in rep["multi_gpu_split"] and rep["extended_domain"].startswith("by cosets")
+    assert "5 of 8 cosets dealt over the ranks" in rep["multi_gpu_split"] and rep["extended_domain"].startswith("by cosets")
     assert rep["verified"]["commitments_checked"] >= 3 * (rep["calls"]["msm_sparse"] + rep["calls"]["msm_dense"])
     op = two["one_process"]["create_proof_replay"]
     assert op["k"] == 18 and op["multi_gpu_split"].startswith("one process")
@@ -83,16 +83,19 @@ def test_two_ranks_replay_the_k18_proof_and_rank0_replays_it_in_one_process():
 
 
 @pytest.mark.gpu
-def test_one_gpu_line_carries_rank0_shares_of_the_k18_replay():
-    """N = 1: beside the replay itself, rank 0's share of the 2-, 4- and 8-rank deal measured alone (what DESIGN 6's predicted curve
+def test_one_gpu_line_carries_rank_shares_of_the_k18_replay():
+    """N = 1: beside the replay itself, the first and the last rank's share of the 2-, 4- and 8-rank deal measured alone (what DESIGN 6's predicted curve
     is built on): less work with every doubling, the extended domain by cosets."""
     line = _bench(1, 18, replay="merkle_sum_tree_k18", extras=True)
     (rep,) = line["create_proof_replay"]
-    shares = rep["rank0_share_measured_alone"]["shares"]
-    assert [s["world"] for s in shares] == [2, 4, 8] and all("error" not in s for s in shares), shares
-    totals = [s["ms"]["total"] for s in shares]
-    assert rep["device_resident_s"]["total"] * 1e3 > totals[0] > totals[1] > totals[2] > 0
-    assert all(s["extended_domain"].startswith("by cosets") for s in shares)
+    shares = rep["rank_shares_measured_alone"]["shares"]
+    assert [(s["world"], s["rank"]) for s in shares] == [(2, 0), (2, 1), (4, 0), (4, 3), (8, 0), (8, 7)] and all("error" not in s for s in shares), shares
+    longest = [max(s["ms"]["total"] for s in shares if s["world"] == w) for w in (2, 4, 8)]
+    assert rep["device_resident_s"]["total"] * 1e3 > longest[0] > longest[1] > longest[2] > 0
+    assert all(s["extended_domain"].startswith("by cosets, 5 of 8") for s in shares)
+    routes = rep["extended_domain_routes_ms"]          # the same trace with the extended-domain steps by all / by the determining cosets
+    assert routes["whole_array"]["total"] == pytest.approx(rep["device_resident_s"]["total"] * 1e3)
+    assert routes["by_all_cosets"]["evaluate_h"] > routes["by_the_cosets_that_determine_h"]["evaluate_h"] > 0
 
 
 @pytest.mark.gpu

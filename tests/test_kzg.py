@@ -112,8 +112,13 @@ def test_replay_by_cosets_and_one_ranks_share():
     dev = torch.device("cuda", 0)
     whole = run_replay("merkle_v3_k17", device=dev, include_host_pointer_estimate=False)
     assert whole["extended_domain"].startswith("whole array") and "share_of" not in whole
-    cosets = run_replay("merkle_v3_k17", device=dev, include_host_pointer_estimate=False, by_cosets=True)
-    assert cosets["extended_domain"].startswith("by cosets")
+    cosets = run_replay("merkle_v3_k17", device=dev, include_host_pointer_estimate=False, by_cosets=True, min_cosets=False)
+    from halo2_experiments_amd.circuits import CONSTRAINT_SYSTEMS
+    from halo2_experiments_amd.domain import EvaluationDomain
+    e = EvaluationDomain(CONSTRAINT_SYSTEMS["merkle_v3_k17"]().degree(), 17).num_cosets()
+    assert cosets["extended_domain"].startswith(f"by cosets, {e} of {e}")
+    fewer = run_replay("merkle_sum_tree_k18", device=dev, include_host_pointer_estimate=False, by_cosets=True)
+    assert fewer["extended_domain"].startswith("by cosets, 5 of 8") and "determine the quotient" in fewer["extended_domain"]
     assert cosets["verified"]["commitments_checked"] == whole["verified"]["commitments_checked"]
     jobs = whole["calls"]["msm_sparse"] + whole["calls"]["msm_dense"]
     seen = 0

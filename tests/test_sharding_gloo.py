@@ -65,6 +65,14 @@ def _worker(rank, world, port, q):
         mine = {c: torch.full((5, 4), 100 * e + c, dtype=torch.int64) for c in range(e) if coset_owner(c, world) == rank}
         allp = gather_coset_partials(mine, e, shape=(5, 4))                 # (e = 1: rank 1 owns nothing and must be told the shape)
         assert len(allp) == e and all(int(allp[c][0, 0]) == 100 * e + c and tuple(allp[c].shape) == (5, 4) for c in range(e)), (e, rank)
+    # five positions dealt from the last rank backwards (evaluate_h on the cosets that determine the quotient): rank 1 gets 3, rank 0 gets 2
+    from halo2_experiments_amd.sharding import coset_owners
+    owners = coset_owners(5, world, spare_rank0=True)
+    assert owners == [1, 0, 1, 0, 1]
+    mine = {c: torch.full((5, 4), 700 + c, dtype=torch.int64) for c in range(5) if owners[c] == rank}
+    allp = gather_coset_partials(mine, 5, shape=(5, 4), owners=owners)
+    assert [int(p[0, 0]) for p in allp] == [700, 701, 702, 703, 704]
+    assert coset_owners(5, 8, spare_rank0=True) == [7, 6, 5, 4, 3]
     try:
         gather_coset_partials({0: torch.zeros((5, 4), dtype=torch.int64)} if rank == 1 else {}, 8)
         raise AssertionError("a rank holding another rank's coset must be refused")
