@@ -89,6 +89,8 @@ _SIGNATURES = {
                                                          ctypes.c_uint32, _u64p, ctypes.c_void_p]),
     "hm_coeff_to_coset_bn256_fr_dev": (ctypes.c_int, [_vp, _vp, ctypes.c_size_t, _u64p, ctypes.c_uint32, _u64p, ctypes.c_int, _vp]),
     "hm_coset_to_coeff_bn256_fr_dev": (ctypes.c_int, [_vp, ctypes.c_size_t, _u64p, ctypes.c_uint32, _u64p, _u64p, _vp]),
+    "hm_coeff_to_cosets_bn256_fr_dev": (ctypes.c_int, [_vp, _vp, ctypes.c_size_t, _u64p, ctypes.c_uint32, _u64p, ctypes.c_size_t, ctypes.c_int, _vp]),
+    "hm_cosets_to_coeff_bn256_fr_dev": (ctypes.c_int, [_vp, ctypes.c_size_t, _u64p, ctypes.c_uint32, _u64p, _u64p, _vp]),
     "hm_msm_set_window": (ctypes.c_int, [ctypes.c_int]),
     "hm_msm_set_phase_timing": (ctypes.c_int, [ctypes.c_int]),
     "hm_set_host_base_cache": (ctypes.c_int, [ctypes.c_int]),
@@ -105,6 +107,8 @@ _SIGNATURES = {
                                              ctypes.c_uint32, _vp, _vp]),
     "hm_graph_evaluate_flags_dev": (ctypes.c_int, [ctypes.c_uint64, ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t, _u64p, ctypes.c_size_t,
                                                    ctypes.c_uint32, _vp, ctypes.c_uint32, _vp]),
+    "hm_graph_evaluate_segments_dev": (ctypes.c_int, [ctypes.c_uint64, ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t, _u64p, ctypes.c_size_t,
+                                                      ctypes.c_uint32, ctypes.c_uint32, _vp, ctypes.c_uint32, _vp]),
     "hm_graph_destroy": (ctypes.c_int, [ctypes.c_uint64]),
     "hm_fr_powers_dev": (ctypes.c_int, [_vp, ctypes.c_size_t, _u64p, _vp]),
     "hm_fr_mul_periodic_dev": (ctypes.c_int, [_vp, ctypes.c_size_t, _u64p, ctypes.c_uint32, _vp]),

@@ -266,12 +266,15 @@ class EvaluateHLayout:
     short_columns: Dict[int, int] = field(default_factory=dict)
 
 
-def evaluate_h_program(cs: ConstraintSystem, k: int, extended_k: int, delta: int, with_arguments: bool = True, per_coset: bool = False):
+def evaluate_h_program(cs: ConstraintSystem, k: int, extended_k: int, delta: int, with_arguments: bool = True, per_coset: bool = False,
+                       divide: bool = True):
     """GraphEvaluator for evaluate_h of `cs`: the custom gates, then (with_arguments) the permutation argument over the
     equality columns, every lookup argument, and divide_by_vanishing_poly as the last multiplication.
     per_coset: the program for ONE coset of the n-th roots inside the extended domain (EvaluationDomain.coeff_to_coset;
     compile with rot_scale = 1, evaluate over 2^k rows): 1 / (X^n - 1) is a single constant there and enters as Challenge(0)
     (compile with num_challenges = 1; the t_inv entry of the column table stays, unread).
+    divide=False: the numerator only -- the division rides on the recombination (EvaluationDomain.combine_cosets(...,
+    divide_by_vanishing=True)), so one launch can take several cosets as segments (CompiledGraph.evaluate(segments=...)).
     -> (GraphEvaluator, EvaluateHLayout)."""
     nf = cs.num_fixed
     P, nsets, L = len(cs.equality), cs.permutation_sets(), len(cs.lookups)
@@ -294,7 +297,7 @@ def evaluate_h_program(cs: ConstraintSystem, k: int, extended_k: int, delta: int
                                         lambda r, b=b: Fixed(b + 2, r), Fixed(lay.l0), Fixed(lay.l_last), Fixed(lay.l_active))
     g = GraphEvaluator()
     g.add_custom_gates(polys)
-    if with_arguments:
+    if with_arguments and divide:
         g.add_vanishing_division(Challenge(0) if per_coset else Fixed(lay.t_inv))
     if per_coset:
         lay.short_columns = {}

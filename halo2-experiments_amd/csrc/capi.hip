@@ -1285,6 +1285,43 @@ int hm_coeff_to_coset_bn256_fr_dev(const void* d_coeffs, void* d_out, size_t bat
   return rc;
 } HM_API_CATCH("hm_coeff_to_coset_bn256_fr_dev")
 
+int hm_coeff_to_cosets_bn256_fr_dev(const void* d_coeffs, void* d_out, size_t batch, const uint64_t omega[4], uint32_t log_n,
+                                    const uint64_t* shifts, size_t count, int columns_internal, void* stream) try {
+  if ((batch && count && (!d_coeffs || !d_out)) || !omega || (count && !shifts))
+    return hm_fail(HM_ERR_BAD_ARG, "hm_coeff_to_cosets_bn256_fr_dev: null argument");
+  if (log_n > 28) return hm_fail(HM_ERR_BAD_ARG, "hm_coeff_to_cosets_bn256_fr_dev: log_n > 28");
+  if (count > 16) return hm_fail(HM_ERR_BAD_ARG, "hm_coeff_to_cosets_bn256_fr_dev: at most 16 cosets per call");
+  if (batch * (count ? count : 1) > 65535) return hm_fail(HM_ERR_BAD_ARG, "hm_coeff_to_cosets_bn256_fr_dev: batch * count > 65535");
+  if (batch == 0 || count == 0) return HM_OK;
+  {
+    const size_t in_bytes = ((size_t)32 << log_n) * batch, out_bytes = in_bytes * count;
+    const char *a = (const char*)d_coeffs, *b = (const char*)d_out;
+    if (a < b + out_bytes && b < a + in_bytes)
+      return hm_fail(HM_ERR_BAD_ARG, "hm_coeff_to_cosets_bn256_fr_dev: the output overlaps the coefficients");
+  }
+  DeviceCtx* ctx = ctx_for_current_device();
+  if (!ctx) return HM_ERR_NO_DEVICE;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  const int rc = ntt_cosets_run(*ctx, (const uint32_t*)d_coeffs, (uint32_t*)d_out, (uint32_t)batch, omega, log_n, shifts, (uint32_t)count,
+                                columns_internal != 0, (hipStream_t)stream);
+  if (rc == HM_OK) count_ntt(*ctx, log_n, batch * count);
+  return rc;
+} HM_API_CATCH("hm_coeff_to_cosets_bn256_fr_dev")
+
+int hm_cosets_to_coeff_bn256_fr_dev(void* d_a, size_t count, const uint64_t omega_inv[4], uint32_t log_n, const uint64_t divisor[4],
+                                    const uint64_t* shift_invs, void* stream) try {
+  if ((count && (!d_a || !shift_invs)) || !omega_inv || !divisor) return hm_fail(HM_ERR_BAD_ARG, "hm_cosets_to_coeff_bn256_fr_dev: null argument");
+  if (log_n > 28) return hm_fail(HM_ERR_BAD_ARG, "hm_cosets_to_coeff_bn256_fr_dev: log_n > 28");
+  if (count > 16) return hm_fail(HM_ERR_BAD_ARG, "hm_cosets_to_coeff_bn256_fr_dev: at most 16 cosets per call");
+  if (count == 0) return HM_OK;
+  DeviceCtx* ctx = ctx_for_current_device();
+  if (!ctx) return HM_ERR_NO_DEVICE;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  const int rc = ntt_cosets_inverse_run(*ctx, (uint32_t*)d_a, (uint32_t)count, omega_inv, log_n, divisor, shift_invs, (hipStream_t)stream);
+  if (rc == HM_OK) count_ntt(*ctx, log_n, count);
+  return rc;
+} HM_API_CATCH("hm_cosets_to_coeff_bn256_fr_dev")
+
 int hm_coset_to_coeff_bn256_fr_dev(void* d_a, size_t batch, const uint64_t omega_inv[4], uint32_t log_n, const uint64_t divisor[4],
                                    const uint64_t shift_inv[4], void* stream) try {
   if ((batch && !d_a) || !omega_inv || !divisor || !shift_inv) return hm_fail(HM_ERR_BAD_ARG, "hm_coset_to_coeff_bn256_fr_dev: null argument");
@@ -1513,8 +1550,8 @@ int hm_graph_create(const uint32_t* calcs, size_t n_calc, const uint64_t* consta
 } HM_API_CATCH("hm_graph_create")
 
 static int graph_evaluate_entry(const char* who, uint64_t handle, const void* const* d_columns, size_t n_columns,
-                                const uint64_t* dynamic_constants, size_t n_dynamic, uint32_t log_size, void* d_values, uint32_t flags,
-                                void* stream) {
+                                const uint64_t* dynamic_constants, size_t n_dynamic, uint32_t log_size, uint32_t segments, void* d_values,
+                                uint32_t flags, void* stream) {
   if (!d_values || (n_columns && !d_columns) || (n_dynamic && !dynamic_constants))
     return hm_fail(HM_ERR_BAD_ARG, std::string(who) + ": null argument");
   DeviceCtx* ctx = ctx_for_current_device();
@@ -1522,22 +1559,29 @@ static int graph_evaluate_entry(const char* who, uint64_t handle, const void* co
   std::lock_guard<std::mutex> lk(ctx->mu);
   for (auto& g : ctx->graphs)
     if (g->handle == handle) {
-      count_vector(*ctx, HM_STAT_GRAPH_EVALUATE, 1, log_size < 40 ? (uint64_t)1 << log_size : 0);
-      return graph_evaluate(*ctx, *g, d_columns, n_columns, dynamic_constants, n_dynamic, log_size, d_values, flags, (hipStream_t)stream);
+      count_vector(*ctx, HM_STAT_GRAPH_EVALUATE, 1, log_size < 40 ? (uint64_t)segments << log_size : 0);
+      return graph_evaluate(*ctx, *g, d_columns, n_columns, dynamic_constants, n_dynamic, log_size, segments, d_values, flags,
+                            (hipStream_t)stream);
     }
   return hm_fail(HM_ERR_NOT_FOUND, std::string(who) + ": unknown program handle");
 }
 
 int hm_graph_evaluate_dev(uint64_t handle, const void* const* d_columns, size_t n_columns, const uint64_t* dynamic_constants,
                           size_t n_dynamic, uint32_t log_size, void* d_values, void* stream) try {
-  return graph_evaluate_entry("hm_graph_evaluate_dev", handle, d_columns, n_columns, dynamic_constants, n_dynamic, log_size, d_values, 0, stream);
+  return graph_evaluate_entry("hm_graph_evaluate_dev", handle, d_columns, n_columns, dynamic_constants, n_dynamic, log_size, 1, d_values, 0, stream);
 } HM_API_CATCH("hm_graph_evaluate_dev")
 
 int hm_graph_evaluate_flags_dev(uint64_t handle, const void* const* d_columns, size_t n_columns, const uint64_t* dynamic_constants,
                                 size_t n_dynamic, uint32_t log_size, void* d_values, uint32_t flags, void* stream) try {
-  return graph_evaluate_entry("hm_graph_evaluate_flags_dev", handle, d_columns, n_columns, dynamic_constants, n_dynamic, log_size, d_values,
+  return graph_evaluate_entry("hm_graph_evaluate_flags_dev", handle, d_columns, n_columns, dynamic_constants, n_dynamic, log_size, 1, d_values,
                               flags, stream);
 } HM_API_CATCH("hm_graph_evaluate_flags_dev")
+
+int hm_graph_evaluate_segments_dev(uint64_t handle, const void* const* d_columns, size_t n_columns, const uint64_t* dynamic_constants,
+                                   size_t n_dynamic, uint32_t log_segment, uint32_t segments, void* d_values, uint32_t flags, void* stream) try {
+  return graph_evaluate_entry("hm_graph_evaluate_segments_dev", handle, d_columns, n_columns, dynamic_constants, n_dynamic, log_segment,
+                              segments, d_values, flags, stream);
+} HM_API_CATCH("hm_graph_evaluate_segments_dev")
 
 int hm_graph_destroy(uint64_t handle) try {
   DeviceCtx* ctx = ctx_for_current_device();

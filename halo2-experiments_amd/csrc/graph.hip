@@ -120,7 +120,9 @@ __device__ __forceinline__ Fr ge_fetch(uint32_t src, const GraphColumns* __restr
     }
     HM_DECLARE(r, 1.0);
   } else if (kind == GSRC_COLUMN) {
-    uint64_t row = (idx + (uint64_t)(int64_t)rotations[gsrc_rot(src)]) & mask;   // two's complement: a negative rotation wraps
+    // two's complement: a negative rotation wraps -- inside the row's SEGMENT (mask = segment length - 1; one segment = the
+    // whole domain in the ordinary call, one coset of the extended domain in hm_graph_evaluate_segments_dev)
+    uint64_t row = (idx & ~mask) | ((idx + (uint64_t)(int64_t)rotations[gsrc_rot(src)]) & mask);
     const uint32_t lr = gsrc_log_rows(src);          // a short column (the vanishing polynomial's inverse pattern) is periodic
     if (lr != 0) row &= (1ull << lr) - 1ull;
     const uint32_t* cell = columns->p[gsrc_column(src)] + row * 8;
@@ -137,10 +139,10 @@ __global__ __launch_bounds__(GE_THREADS) void graph_evaluate_kernel(const GraphC
                                                                     const int32_t* __restrict__ rotations,
                                                                     const GraphCalc* __restrict__ calcs, uint32_t n_calc, uint32_t result_src,
                                                                     uint32_t result_prev, uint32_t* __restrict__ scratch,
-                                                                    uint32_t* __restrict__ values, uint32_t log_size) {
+                                                                    uint32_t* __restrict__ values, uint64_t size, uint32_t log_segment) {
   const uint32_t T = gridDim.x * GE_THREADS;
   const uint32_t lane_slot = blockIdx.x * GE_THREADS + threadIdx.x;
-  const uint64_t size = 1ull << log_size, mask = size - 1;
+  const uint64_t mask = (1ull << log_segment) - 1;
   for (uint64_t idx = lane_slot; idx < size; idx += T) {
     uint32_t* vrow = values + idx * 8;
     Fr prev = fe_zero<FrParams>();                         // the previous calculation's result, in registers
@@ -422,8 +424,9 @@ void graph_release(GraphProgram& g) {
   }
 }
 
+// rows = segments << log_segment; rotations wrap inside a segment (segments == 1: the ordinary evaluation over 2^log_segment rows)
 int graph_evaluate(DeviceCtx& ctx, GraphProgram& g, const void* const* d_columns, size_t n_columns, const uint64_t* dyn_ext,
-                   size_t n_dyn, uint32_t log_size, void* d_values, uint32_t flags, hipStream_t stream) {
+                   size_t n_dyn, uint32_t log_size, uint32_t segments, void* d_values, uint32_t flags, hipStream_t stream) {
   if (flags & ~(uint32_t)HM_GRAPH_COLUMNS_INTERNAL) return hm_fail(HM_ERR_BAD_ARG, "graph: unknown flag");
   const bool internal_cols = (flags & HM_GRAPH_COLUMNS_INTERNAL) != 0;
   GraphVariant& v = g.variant[internal_cols ? 1 : 0];
@@ -434,7 +437,8 @@ int graph_evaluate(DeviceCtx& ctx, GraphProgram& g, const void* const* d_columns
   if (n_columns != g.n_columns) return hm_fail(HM_ERR_BAD_ARG, "graph: the program was built for another number of columns");
   if (n_dyn != g.n_dynamic) return hm_fail(HM_ERR_BAD_ARG, "graph: the program was built for another number of per-call constants");
   if (log_size > 30) return hm_fail(HM_ERR_BAD_ARG, "graph: log_size > 30");
-  const uint64_t size = 1ull << log_size;
+  if (segments == 0 || ((uint64_t)segments << log_size) > (1ull << 32)) return hm_fail(HM_ERR_BAD_ARG, "graph: segments must be >= 1 and rows <= 2^32");
+  const uint64_t size = (uint64_t)segments << log_size;
   // enough lanes to fill the chip, few enough that the intermediates' scratch stays cache-sized
   // 93 VGPRs: five waves per SIMD fit, i.e. five 256-lane workgroups per CU -- the interpreter's loads from the scratch
   // (Infinity Cache latency) need them: measured on the MerkleSumTree program over 2^21 rows, 512 / 768 / 1024 / 1280 / 2048
@@ -464,11 +468,11 @@ int graph_evaluate(DeviceCtx& ctx, GraphProgram& g, const void* const* d_columns
   if (internal_cols)
     hipLaunchKernelGGL(graph_evaluate_kernel<true>, dim3(blocks), dim3(GE_THREADS), 0, stream, (const GraphColumns*)d_cols,
                        (const uint32_t*)g.d_consts, (const int32_t*)g.d_rot, (const GraphCalc*)v.d_calcs, v.n_calc, v.result_src,
-                       v.result_prev, (uint32_t*)buf, (uint32_t*)d_values, log_size);
+                       v.result_prev, (uint32_t*)buf, (uint32_t*)d_values, size, log_size);
   else
     hipLaunchKernelGGL(graph_evaluate_kernel<false>, dim3(blocks), dim3(GE_THREADS), 0, stream, (const GraphColumns*)d_cols,
                        (const uint32_t*)g.d_consts, (const int32_t*)g.d_rot, (const GraphCalc*)v.d_calcs, v.n_calc, v.result_src,
-                       v.result_prev, (uint32_t*)buf, (uint32_t*)d_values, log_size);
+                       v.result_prev, (uint32_t*)buf, (uint32_t*)d_values, size, log_size);
   HM_HIP_CHECK(hipGetLastError());
   return aux_release(ctx, slot, stream);
 }

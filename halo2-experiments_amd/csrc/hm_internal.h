@@ -292,7 +292,11 @@ struct NttFused {
   const uint64_t* coset = nullptr;   // 12 words: input element i *= coset[i % 3] (coeff_to_extended)
   const uint64_t* post3 = nullptr;   // 12 words: output element i *= post3[i % 3] (extended_to_coeff)
   const uint32_t* d_in_scale = nullptr;   // DEVICE table, n x 8 words: input element i *= table[i] / 32 (the transform on a coset)
+  // several cosets of the SAME inputs in one launch chain: n_in_scales tables; output array (b, c) = number b * n_in_scales + c
+  const uint32_t* d_in_scales[16] = {};
+  uint32_t n_in_scales = 0;
 };
+constexpr uint32_t HM_NTT_COSETS_MAX = 16;
 int ntt_run(DeviceCtx& ctx, uint32_t* d_a, const uint64_t omega_ext[4], uint32_t log_n, uint32_t batch,
             const NttFused& fused, hipStream_t stream, const uint32_t* d_in = nullptr, uint32_t log_z = 0);
 int ntt_plan_first_digit(uint32_t log_n, int* passes);
@@ -304,6 +308,12 @@ void coset_tables_release(DeviceCtx& ctx);
 // internal: outputs multiplied by 32 (HM_GRAPH_COLUMNS_INTERNAL)
 int ntt_coset_run(DeviceCtx& ctx, const uint32_t* d_in, uint32_t* d_out, uint32_t batch, const uint64_t omega_ext[4], uint32_t log_n,
                   const uint64_t shift_ext[4], bool internal, hipStream_t stream);
+// the same for `count` cosets at once: d_out holds batch * count arrays, array b * count + c = input b on coset shifts[c]
+int ntt_cosets_run(DeviceCtx& ctx, const uint32_t* d_in, uint32_t* d_out, uint32_t batch, const uint64_t omega_ext[4], uint32_t log_n,
+                   const uint64_t* shifts_ext, uint32_t count, bool internal, hipStream_t stream);
+// in place, `count` arrays: a_c <- divisor * inverse transform of a_c, then a_c[i] *= shift_invs[c]^i
+int ntt_cosets_inverse_run(DeviceCtx& ctx, uint32_t* d_a, uint32_t count, const uint64_t omega_inv_ext[4], uint32_t log_n,
+                           const uint64_t divisor_ext[4], const uint64_t* shift_invs_ext, hipStream_t stream);
 // in place: a_b <- divisor * inverse transform of a_b, then a_b[i] *= shift_inv^i
 int ntt_coset_inverse_run(DeviceCtx& ctx, uint32_t* d_a, uint32_t batch, const uint64_t omega_inv_ext[4], uint32_t log_n,
                           const uint64_t divisor_ext[4], const uint64_t shift_inv_ext[4], hipStream_t stream);
@@ -313,7 +323,7 @@ int graph_create(DeviceCtx& ctx, const uint32_t* calcs5, size_t n_calc, const ui
                  size_t n_dynamic, const int32_t* rotations, size_t n_rot, size_t n_columns, uint32_t n_intermediates,
                  uint64_t* out_handle);
 int graph_evaluate(DeviceCtx& ctx, GraphProgram& g, const void* const* d_columns, size_t n_columns, const uint64_t* dyn_ext,
-                   size_t n_dyn, uint32_t log_size, void* d_values, uint32_t flags, hipStream_t stream);
+                   size_t n_dyn, uint32_t log_size, uint32_t segments, void* d_values, uint32_t flags, hipStream_t stream);
 void graph_release(GraphProgram& g);
 
 // poly.hip

@@ -92,6 +92,11 @@ __device__ __forceinline__ uint32_t bitrev(uint32_t v, uint32_t bits) {
   return bits == 0 ? 0u : (__brev(v) >> (32 - bits));
 }
 
+struct NttCosetTables {          // pointer table by value (indexed by blockIdx.z: scalar loads)
+  const uint32_t* table[16];
+  uint32_t count;
+};
+
 struct NttPassParams {
   uint32_t log_n;        // transform size
   uint32_t s;            // log2 of this pass's digit R
@@ -190,7 +195,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(const uint32_t* i
                                                                NttPassParams pp, const uint32_t* __restrict__ stage_tw,
                                                                const uint32_t* __restrict__ tw_lo,
                                                                const uint32_t* __restrict__ tw_hi,
-                                                               const uint32_t* __restrict__ in_scale) {
+                                                               const uint32_t* __restrict__ in_scale, NttCosetTables zc) {
   extern __shared__ uint32_t lds[];
   __shared__ uint32_t s_const[FUSED ? 54 : 1];   // [0, 27): coset pattern, [27, 54): final constants (indexed per element)
   const uint32_t tid = threadIdx.x;
@@ -210,7 +215,12 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(const uint32_t* i
   const uint64_t tile = blockIdx.x;
   // batched transforms: blockIdx.y selects one of `gridDim.y` back-to-back arrays of n elements
   in += ((size_t)blockIdx.y << (pp.log_n - pp.log_z)) * 8;   // an extending first pass reads compact input arrays
-  out += ((size_t)blockIdx.y << pp.log_n) * 8;
+  uint32_t out_index = blockIdx.y;
+  if (TABLE && zc.count) {                                    // several cosets of the same inputs: blockIdx.z = coset
+    out_index = blockIdx.y * zc.count + blockIdx.z;
+    in_scale = zc.table[blockIdx.z];
+  }
+  out += ((size_t)out_index << pp.log_n) * 8;
 
   // ---- tile -> global index mapping ---------------------------------------------------------
   // non-last: element (d, c) lives at  o*m + d*stride + i0 + c        (m = R*stride)
@@ -438,6 +448,24 @@ __global__ void fr_mul_table_kernel(uint32_t* __restrict__ a, const uint32_t* __
   p[1] = make_uint4(o[4], o[5], o[6], o[7]);
 }
 
+// the same with one table per array (blockIdx.y = array): several cosets' partials in one launch
+__global__ void fr_mul_tables_kernel(uint32_t* __restrict__ a, NttCosetTables tabs, uint64_t n) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint4* p = reinterpret_cast<uint4*>(a + ((uint64_t)blockIdx.y * n + i) * 8);
+  const uint4* t = reinterpret_cast<const uint4*>(tabs.table[blockIdx.y] + i * 8);
+  const uint4 lo = p[0], hi = p[1], tl = t[0], th = t[1];
+  const uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+  const uint32_t tw[8] = {tl.x, tl.y, tl.z, tl.w, th.x, th.y, th.z, th.w};
+  Fr ts = fe_unpack<FrParams>(tw);
+  HM_DECLARE(ts, 6.0);
+  Fr y = fe_canonical(fe_mul(fe_unpack<FrParams>(w), ts));
+  uint32_t o[8];
+  fe_pack(o, y);
+  p[0] = make_uint4(o[0], o[1], o[2], o[3]);
+  p[1] = make_uint4(o[4], o[5], o[6], o[7]);
+}
+
 // a[i] *= c3[i % 3] (EvaluationDomain::distribute_powers_zeta); c3: 3 external constants
 __global__ void fr_mul_pattern3_kernel(uint32_t* a, FrWords3 c3_ext, uint64_t n) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -608,6 +636,15 @@ int ntt_run(DeviceCtx& ctx, uint32_t* d_a, const uint64_t omega_ext[4], uint32_t
             hipStream_t stream, const uint32_t* d_in, uint32_t log_z) {
   if (log_n > 28) return hm_fail(HM_ERR_BAD_ARG, "ntt: log_n > 28 (Fr has 2-adicity 28)");
   if (batch == 0) return HM_OK;
+  // several cosets of the same inputs (fused.n_in_scales): the first pass reads `batch` inputs and writes batch * cosets arrays,
+  // every later pass is an ordinary batched pass over those
+  const uint32_t cosets = fused.n_in_scales, in_batch = batch;
+  if (cosets > HM_NTT_COSETS_MAX) return hm_fail(HM_ERR_BAD_ARG, "ntt: more than 16 cosets per call");
+  if (cosets) {
+    if ((uint64_t)batch * cosets > 65535) return hm_fail(HM_ERR_BAD_ARG, "ntt: batch * cosets > 65535");
+    if (!d_in || log_z != 0) return hm_fail(HM_ERR_INTERNAL, "ntt: the multi-coset form is out of place and not extending");
+    batch *= cosets;
+  }
   if (batch > 65535) return hm_fail(HM_ERR_BAD_ARG, "ntt: batch > 65535");
   NttTables* tab = ntt_get_tables(ctx, omega_ext, log_n, stream);
   if (!tab) return HM_ERR_HIP;
@@ -666,7 +703,7 @@ int ntt_run(DeviceCtx& ctx, uint32_t* d_a, const uint64_t omega_ext[4], uint32_t
     if (pp.has_coset) std::memcpy(pp.coset, coset9, sizeof coset9);
     if (pp.fin_mode) std::memcpy(pp.fin, fin9, sizeof fin9);
     pp.log_z = (p == 0 && d_in) ? log_z : 0u;
-    pp.has_table = (p == 0 && fused.d_in_scale) ? 1u : 0u;
+    pp.has_table = (p == 0 && (fused.d_in_scale || cosets)) ? 1u : 0u;
     uint32_t log_c = (uint32_t)LOG_TILE > pp.s ? (uint32_t)LOG_TILE - pp.s : 0u;
     const uint32_t avail = pp.last ? pp.log_rows : pp.log_stride;  // columns / rows that exist
     if (log_c > avail) log_c = avail;
@@ -683,15 +720,20 @@ int ntt_run(DeviceCtx& ctx, uint32_t* d_a, const uint64_t omega_ext[4], uint32_t
         lo_tab = tab->d_mid;
       }
     }
+    NttCosetTables zc{};
     if (pp.has_table) {
-      hipLaunchKernelGGL((ntt_pass_kernel<LOG_TILE, true, true>), dim3((uint32_t)tiles, batch), dim3(NTT_THREADS), lds_bytes, stream, src, dst,
-                         pp, (const uint32_t*)tab->d_stage[pp.s], lo_tab, (const uint32_t*)tab->d_hi, fused.d_in_scale);
+      if (cosets) {
+        zc.count = cosets;
+        for (uint32_t c = 0; c < cosets; ++c) zc.table[c] = fused.d_in_scales[c];
+      }
+      hipLaunchKernelGGL((ntt_pass_kernel<LOG_TILE, true, true>), dim3((uint32_t)tiles, in_batch, cosets ? cosets : 1), dim3(NTT_THREADS), lds_bytes,
+                         stream, src, dst, pp, (const uint32_t*)tab->d_stage[pp.s], lo_tab, (const uint32_t*)tab->d_hi, fused.d_in_scale, zc);
     } else if (pp.has_coset | pp.fin_mode) {
       hipLaunchKernelGGL((ntt_pass_kernel<LOG_TILE, true>), dim3((uint32_t)tiles, batch), dim3(NTT_THREADS), lds_bytes, stream, src, dst,
-                         pp, (const uint32_t*)tab->d_stage[pp.s], lo_tab, (const uint32_t*)tab->d_hi, (const uint32_t*)nullptr);
+                         pp, (const uint32_t*)tab->d_stage[pp.s], lo_tab, (const uint32_t*)tab->d_hi, (const uint32_t*)nullptr, zc);
     } else {
       hipLaunchKernelGGL((ntt_pass_kernel<LOG_TILE, false>), dim3((uint32_t)tiles, batch), dim3(NTT_THREADS), lds_bytes, stream, src, dst,
-                         pp, (const uint32_t*)tab->d_stage[pp.s], lo_tab, (const uint32_t*)tab->d_hi, (const uint32_t*)nullptr);
+                         pp, (const uint32_t*)tab->d_stage[pp.s], lo_tab, (const uint32_t*)tab->d_hi, (const uint32_t*)nullptr, zc);
     }
     HM_HIP_CHECK(hipGetLastError());
   }
@@ -770,6 +812,41 @@ int ntt_coset_run(DeviceCtx& ctx, const uint32_t* d_in, uint32_t* d_out, uint32_
   NttFused f;
   f.d_in_scale = table;
   return ntt_run(ctx, d_out, omega_ext, log_n, batch, f, stream, d_in == d_out ? nullptr : d_in, 0);
+}
+
+int ntt_cosets_run(DeviceCtx& ctx, const uint32_t* d_in, uint32_t* d_out, uint32_t batch, const uint64_t omega_ext[4], uint32_t log_n,
+                   const uint64_t* shifts_ext, uint32_t count, bool internal, hipStream_t stream) {
+  if (log_n > 28) return hm_fail(HM_ERR_BAD_ARG, "ntt: log_n > 28 (Fr has 2-adicity 28)");
+  if (batch == 0 || count == 0) return HM_OK;
+  if (count > HM_NTT_COSETS_MAX) return hm_fail(HM_ERR_BAD_ARG, "ntt: more than 16 cosets per call");
+  NttFused f;
+  f.n_in_scales = count;
+  for (uint32_t c = 0; c < count; ++c) {
+    f.d_in_scales[c] = coset_table_get(ctx, shifts_ext + 4 * c, log_n, internal, stream);
+    if (!f.d_in_scales[c]) return HM_ERR_HIP;
+  }
+  return ntt_run(ctx, d_out, omega_ext, log_n, batch, f, stream, d_in, 0);
+}
+
+int ntt_cosets_inverse_run(DeviceCtx& ctx, uint32_t* d_a, uint32_t count, const uint64_t omega_inv_ext[4], uint32_t log_n,
+                           const uint64_t divisor_ext[4], const uint64_t* shift_invs_ext, hipStream_t stream) {
+  if (log_n > 28) return hm_fail(HM_ERR_BAD_ARG, "ntt: log_n > 28 (Fr has 2-adicity 28)");
+  if (count == 0) return HM_OK;
+  if (count > HM_NTT_COSETS_MAX) return hm_fail(HM_ERR_BAD_ARG, "ntt: more than 16 cosets per call");
+  NttCosetTables tabs{};
+  tabs.count = count;
+  for (uint32_t c = 0; c < count; ++c) {
+    tabs.table[c] = coset_table_get(ctx, shift_invs_ext + 4 * c, log_n, false, stream);
+    if (!tabs.table[c]) return HM_ERR_HIP;
+  }
+  NttFused f;
+  f.scale = divisor_ext;
+  const int rc = ntt_run(ctx, d_a, omega_inv_ext, log_n, count, f, stream);
+  if (rc != HM_OK) return rc;
+  const uint64_t n = 1ull << log_n;
+  hipLaunchKernelGGL(fr_mul_tables_kernel, dim3((uint32_t)((n + 255) / 256), count), dim3(256), 0, stream, d_a, tabs, n);
+  HM_HIP_CHECK(hipGetLastError());
+  return HM_OK;
 }
 
 int ntt_coset_inverse_run(DeviceCtx& ctx, uint32_t* d_a, uint32_t batch, const uint64_t omega_inv_ext[4], uint32_t log_n,

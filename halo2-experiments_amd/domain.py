@@ -159,6 +159,36 @@ class EvaluationDomain:
             _ptr(fr_words(self.coset_shift(j))), 1 if internal else 0, ctypes.c_void_p(_stream_ptr(out))))
         return out
 
+    def coeff_to_cosets(self, a, cosets, internal: bool = False):
+        """(batch, n, 4) coefficient tensor -> (batch, len(cosets), n, 4): [b, i] = polynomial b on coset cosets[i], ONE launch
+        chain for all of them (at most 16 cosets).  Reshaped to (batch, len(cosets) * n, 4) every row b is a column of
+        ``CompiledGraph.evaluate(..., segments=len(cosets))``."""
+        import torch
+
+        batch = self._batch_of(a, self.n, "coeff_to_cosets")
+        cosets = [int(c) for c in cosets]
+        if not cosets or len(cosets) > 16 or any(not 0 <= c < self.num_cosets() for c in cosets):
+            raise ValueError("coeff_to_cosets: 1 .. 16 coset indices below E")
+        a = a.contiguous()
+        out = torch.empty((batch, len(cosets), self.n, 4), dtype=a.dtype, device=a.device)
+        shifts = np.stack([fr_words(self.coset_shift(c)) for c in cosets])
+        _lib.check(_lib.load().hm_coeff_to_cosets_bn256_fr_dev(
+            ctypes.c_void_p(a.data_ptr()), ctypes.c_void_p(out.data_ptr()), batch, _ptr(fr_words(self.omega)), self.k, _ptr(shifts),
+            len(cosets), 1 if internal else 0, ctypes.c_void_p(_stream_ptr(out))))
+        return out
+
+    def cosets_to_partials(self, v, cosets):
+        """In place on (len(cosets), n, 4): the values ONE polynomial takes on those cosets -> its partials (``coset_to_partial``
+        of each), one launch chain."""
+        cosets = [int(c) for c in cosets]
+        if v.dim() != 3 or v.shape[0] != len(cosets) or v.shape[1] != self.n or not v.is_contiguous():
+            raise ValueError("cosets_to_partials: expected a contiguous (len(cosets), n, 4) tensor")
+        inv = np.stack([fr_words(pow(self.coset_shift(c), -1, FR_MODULUS)) for c in cosets])
+        _lib.check(_lib.load().hm_cosets_to_coeff_bn256_fr_dev(
+            ctypes.c_void_p(v.data_ptr()), len(cosets), _ptr(fr_words(self.omega_inv)), self.k, _ptr(fr_words(self.ifft_divisor)), _ptr(inv),
+            ctypes.c_void_p(_stream_ptr(v))))
+        return v
+
     def coset_vanishing_inverse(self, j: int) -> int:
         """1 / (X^n - 1) on coset j: one constant (the entry j of divide_by_vanishing_poly's periodic pattern)."""
         r = FR_MODULUS
@@ -178,7 +208,7 @@ class EvaluationDomain:
         cosets do (each coset contributes n equations per residue class of coefficients)."""
         return self.quotient_poly_degree
 
-    def combine_cosets(self, partials, pieces: int = None, cosets=None):
+    def combine_cosets(self, partials, pieces: int = None, cosets=None, divide_by_vanishing: bool = False):
         """partials[a] = coset_to_partial(values on coset cosets[a]) -> the coefficients of the polynomial those values belong
         to.  ``cosets=None``: all E cosets in order -- any polynomial of degree < E n, the same words ``extended_to_coeff``
         returns (``pieces`` rows of n coefficients, default the quotient's j - 1).  ``cosets=[j_0, .., j_(q-1)]``: q distinct
@@ -188,7 +218,8 @@ class EvaluationDomain:
         For an unsatisfied witness the numerator is not divisible by X^n - 1, the two differ, and neither is a proof.
         With u_j = (zeta * extended_omega^j)^n: partial_j[i] = sum_t piece_t[i] u_j^t, so piece_t = sum_a Vinv[t][a] partial_a
         with V[a][t] = u_(j_a)^t -- one linear combination of q arrays per piece (for all E cosets Vinv is the inverse DFT
-        zeta^(-n t) / E * w^(-j t))."""
+        zeta^(-n t) / E * w^(-j t)).  ``divide_by_vanishing``: the partials are of the UNDIVIDED numerator; 1 / (X^n - 1) is the
+        constant 1 / (u_c - 1) on coset c and rides on column c of Vinv (no pass over the data, no constant in the program)."""
         import torch
         from .arithmetic import linear_combination
 
@@ -210,6 +241,9 @@ class EvaluationDomain:
             raise ValueError("combine_cosets: at most one piece per coset")
         nodes = [pow(self.coset_shift(c), self.n, r) for c in cosets]
         vinv = _vandermonde_inverse(nodes, r)
+        if divide_by_vanishing:
+            tinv = [pow((u - 1) % r, -1, r) for u in nodes]
+            vinv = [[row[a] * tinv[a] % r for a in range(q)] for row in vinv]
         out = torch.empty((pieces, self.n, 4), dtype=partials[0].dtype, device=partials[0].device)
         for t in range(pieces):
             linear_combination(list(partials), np.stack([fr_words(vinv[t][a]) for a in range(q)]), out=out[t])

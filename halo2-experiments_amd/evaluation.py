@@ -309,13 +309,18 @@ class CompiledGraph:
         self.handle = h.value
 
     def evaluate(self, columns: Sequence, values, challenges: Sequence[int] = (), beta: int = 0, gamma: int = 0, theta: int = 0,
-                 y: int = 0, columns_internal: bool = False) -> None:
+                 y: int = 0, columns_internal: bool = False, segments: int = 1) -> None:
         """``columns``: GPU tensors (size, 4), fixed then advice then instance; ``values``: (size, 4) GPU tensor holding
         PreviousValue on entry and the program's value on return.  ``columns_internal``: every column holds 32 * value
-        (HM_GRAPH_COLUMNS_INTERNAL: what ``EvaluationDomain.coeff_to_extended(..., internal=True)`` writes)."""
+        (HM_GRAPH_COLUMNS_INTERNAL: what ``EvaluationDomain.coeff_to_extended(..., internal=True)`` writes).
+        ``segments`` > 1: the rows are that many back-to-back blocks of size / segments rows (a power of two) and a rotation
+        wraps inside its block -- several cosets of the extended domain in one launch (``EvaluationDomain.coeff_to_cosets``)."""
         size = _tensor_rows(values, 4, "values")
-        if size & (size - 1) or size == 0:
-            raise ValueError("evaluate: the extended domain size must be a power of two")
+        if segments < 1 or size % segments:
+            raise ValueError("evaluate: the rows must be a whole number of segments")
+        seg = size // segments
+        if seg & (seg - 1) or seg == 0:
+            raise ValueError("evaluate: the (segment of the) domain must be a power of two")
         if len(columns) != self.n_columns or len(challenges) != self.num_challenges:
             raise ValueError("evaluate: column / challenge count differs from the compiled program's")
         for i, c in enumerate(columns):
@@ -324,9 +329,9 @@ class CompiledGraph:
                 raise ValueError(f"evaluate: column {i} must hold {want} rows")
         ptrs = (ctypes.c_void_p * max(len(columns), 1))(*[c.data_ptr() for c in columns])
         dyn = np.stack([fr_words(v) for v in list(challenges) + [beta, gamma, theta, y]])
-        _lib.check(_lib.load().hm_graph_evaluate_flags_dev(ctypes.c_uint64(self.handle), ptrs, len(columns), _ptr(dyn), dyn.shape[0],
-                                                           size.bit_length() - 1, ctypes.c_void_p(values.data_ptr()),
-                                                           1 if columns_internal else 0, ctypes.c_void_p(_stream_ptr(values))))
+        _lib.check(_lib.load().hm_graph_evaluate_segments_dev(ctypes.c_uint64(self.handle), ptrs, len(columns), _ptr(dyn), dyn.shape[0],
+                                                              seg.bit_length() - 1, segments, ctypes.c_void_p(values.data_ptr()),
+                                                              1 if columns_internal else 0, ctypes.c_void_p(_stream_ptr(values))))
 
     def destroy(self) -> None:
         if self.handle:

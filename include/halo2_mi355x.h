@@ -232,6 +232,20 @@ int hm_coeff_to_coset_bn256_fr_dev(const void* d_coeffs, void* d_out, size_t bat
                                    const uint64_t shift[4], int columns_internal, void* stream);
 int hm_coset_to_coeff_bn256_fr_dev(void* d_a, size_t batch, const uint64_t omega_inv[4], uint32_t log_n, const uint64_t divisor[4],
                                    const uint64_t shift_inv[4], void* stream);
+/* Several cosets in one launch chain (at most 16 per call).
+ *   hm_coeff_to_cosets: d_out holds batch * count arrays of 2^log_n Fr; array b * count + c = coefficient array b evaluated
+ *     on the coset shifts[c] * <omega> -- per input the `count` cosets lie one after the other, which is the column layout
+ *     hm_graph_evaluate_segments_dev reads (segment c = coset c).  shifts: host, count x 4 u64.  d_out must not overlap d_coeffs.
+ *   hm_cosets_to_coeff: in place on `count` back-to-back arrays (the values of ONE polynomial on `count` cosets): array c
+ *     <- divisor * inverse transform, then element i *= shift_invs[c]^i.
+ * Only j - 1 of the E cosets are needed for the quotient of a satisfied circuit (it has fewer than n (j - 1) coefficients):
+ * partial_c[i] = sum_t h[i + t n] u_c^t with u_c = shifts[c]^n is a (j - 1) x (j - 1) Vandermonde system per i, whose
+ * inverse matrix -- times 1 / (u_c - 1), the vanishing polynomial's inverse on coset c, if the numerator was evaluated
+ * undivided -- gives every piece of h as ONE hm_fr_linear_combination_dev of the partials. */
+int hm_coeff_to_cosets_bn256_fr_dev(const void* d_coeffs, void* d_out, size_t batch, const uint64_t omega[4], uint32_t log_n,
+                                    const uint64_t* shifts, size_t count, int columns_internal, void* stream);
+int hm_cosets_to_coeff_bn256_fr_dev(void* d_a, size_t count, const uint64_t omega_inv[4], uint32_t log_n, const uint64_t divisor[4],
+                                    const uint64_t* shift_invs, void* stream);
 
 /* EvaluationDomain::extended_to_coeff's arithmetic in one call (halo2_proofs poly/domain.rs: ifft over the
  * extended domain, then distribute_powers_zeta with the INVERSE coset powers): `batch` arrays of 2^log_ext
@@ -347,6 +361,12 @@ int hm_graph_destroy(uint64_t handle);
 #define HM_GRAPH_COLUMNS_INTERNAL 1
 int hm_graph_evaluate_flags_dev(uint64_t handle, const void* const* d_columns, size_t n_columns, const uint64_t* dynamic_constants,
                                 size_t n_dynamic, uint32_t log_size, void* d_values, uint32_t flags, void* stream);
+/* The same program over `segments` back-to-back blocks of 2^log_segment rows (every column holds segments << log_segment rows;
+ * short columns stay periodic in the row index): a rotation wraps INSIDE its block.  One launch for several cosets of the
+ * extended domain laid out one after the other per column (hm_coeff_to_cosets_bn256_fr_dev): block c = coset c, rotations
+ * unscaled.  segments = 1 is hm_graph_evaluate_flags_dev. */
+int hm_graph_evaluate_segments_dev(uint64_t handle, const void* const* d_columns, size_t n_columns, const uint64_t* dynamic_constants,
+                                   size_t n_dynamic, uint32_t log_segment, uint32_t segments, void* d_values, uint32_t flags, void* stream);
 
 /* Inputs and known answer of the benchmark of SURVEY.md §8d, without leaving the device:
  *   hm_fr_random_dev           out[i] uniform in [0, r) (Fr::random): one xoshiro256** stream per element, seeded by

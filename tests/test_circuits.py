@@ -9,8 +9,9 @@ import random
 import numpy as np
 import pytest
 
+import halo2_experiments_amd as h
 from halo2_experiments_amd import circuits, evaluation as ev
-from halo2_experiments_amd.domain import FR_MODULUS
+from halo2_experiments_amd.domain import FR_MODULUS, fr_words
 
 R = FR_MODULUS
 
@@ -203,4 +204,64 @@ def test_evaluate_h_coset_by_coset_gives_the_same_quotient(pyref, name):
         assert h_b.shape == h_a.shape and bool((h_a == h_b).all()), name
     finally:
         prog_all.destroy()
+        prog_one.destroy()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(circuits.CONSTRAINT_SYSTEMS))
+def test_evaluate_h_on_several_cosets_in_one_launch(pyref, name):
+    """The fused form of the coset route: every column onto q cosets in ONE transform call (hm_coeff_to_cosets), the UNDIVIDED
+    numerator over q segments of n rows in ONE launch (rotations wrap inside a segment), the partials in one call, and
+    1 / (X^n - 1) folded into the recombination matrix.  With all E cosets: word for word the quotient of the whole-array
+    route (random columns: any numerator); the per-segment values equal the per-coset program's, coset by coset."""
+    import torch
+    from halo2_experiments_amd.domain import EvaluationDomain
+    cs = circuits.CONSTRAINT_SYSTEMS[name]()
+    k = 6
+    dom = EvaluationDomain(cs.degree(), k)
+    ek, n, e = dom.extended_k, dom.n, dom.num_cosets()
+    delta = pow(7, 1 << 28, R)
+    g_all, lay = circuits.evaluate_h_program(cs, k, ek, delta)
+    g_num, lay_n = circuits.evaluate_h_program(cs, k, ek, delta, per_coset=True, divide=False)
+    g_one, lay1 = circuits.evaluate_h_program(cs, k, ek, delta, per_coset=True)
+    n_cols = lay.num_fixed_entries + cs.num_advice + cs.num_instance
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(99 + len(name))
+    coeffs = torch.randint(-(2 ** 63), 2 ** 63 - 1, (n_cols, n, 4), dtype=torch.int64, device="cuda", generator=gen)
+    coeffs[:, :, 3] &= 0x0FFFFFFFFFFFFFFF
+    coeffs[lay.x_coset] = torch.from_numpy(pyref.fr_array([0, 1] + [0] * (n - 2)).view(np.int64)).cuda()
+    rng = random.Random(6)
+    beta, gamma, theta, y = (rng.randrange(R) for _ in range(4))
+    to_dev = lambda vals: torch.from_numpy(pyref.fr_array(vals).view(np.int64)).cuda()
+    prog_all = g_all.compile(lay.num_fixed_entries, cs.num_advice, cs.num_instance, num_challenges=0, rot_scale=e, short_columns=lay.short_columns)
+    prog_num = g_num.compile(lay_n.num_fixed_entries, cs.num_advice, cs.num_instance, num_challenges=0, rot_scale=1)
+    prog_one = g_one.compile(lay1.num_fixed_entries, cs.num_advice, cs.num_instance, num_challenges=1, rot_scale=1)
+    try:
+        ext = dom.coeff_to_extended(coeffs, internal=True)
+        cols = [ext[i] for i in range(n_cols)]
+        cols[lay.t_inv] = to_dev([32 * dom.coset_vanishing_inverse(c) % R for c in range(e)])
+        h_ext = torch.zeros((1 << ek, 4), dtype=torch.int64, device="cuda")
+        prog_all.evaluate(cols, h_ext, beta=beta, gamma=gamma, theta=theta, y=y, columns_internal=True)
+        h_a = dom.extended_to_coeff(h_ext.clone()).clone()
+        for cosets in (list(range(e)), [e - 1, 0, 2][: min(3, e)]):
+            q = len(cosets)
+            cc = dom.coeff_to_cosets(coeffs, cosets, internal=True)                       # (n_cols, q, n, 4)
+            for i, c in enumerate(cosets):
+                assert bool((cc[:, i] == dom.coeff_to_coset(coeffs, c, internal=True)).all()), (name, c)
+            v = torch.zeros((q, n, 4), dtype=torch.int64, device="cuda")
+            prog_num.evaluate([cc[j].reshape(q * n, 4) for j in range(n_cols)], v.reshape(q * n, 4), beta=beta, gamma=gamma, theta=theta, y=y,
+                              columns_internal=True, segments=q)
+            for i, c in enumerate(cosets):                                                 # the divided per-coset program = numerator * 1 / (u_c - 1)
+                one = torch.zeros((n, 4), dtype=torch.int64, device="cuda")
+                prog_one.evaluate([cc[j, i] for j in range(n_cols)], one, challenges=[dom.coset_vanishing_inverse(c)], beta=beta, gamma=gamma,
+                                  theta=theta, y=y, columns_internal=True)
+                scaled = h.linear_combination([v[i]], np.stack([fr_words(dom.coset_vanishing_inverse(c))]))
+                assert bool((scaled == one).all()) and bool((one == h_ext[c::e]).all()), (name, c)
+            parts = dom.cosets_to_partials(v, cosets)
+            if q == e:
+                h_b = dom.combine_cosets([parts[i] for i in range(q)], cosets=cosets, pieces=dom.quotient_poly_degree, divide_by_vanishing=True)
+                assert bool((h_b == h_a).all()), name
+    finally:
+        prog_all.destroy()
+        prog_num.destroy()
         prog_one.destroy()
