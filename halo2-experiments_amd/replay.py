@@ -222,12 +222,13 @@ def run_replay(shape_name: str, device=None, group=None, include_host_pointer_es
     NC = len(use_cosets)
     coset_prog = None
     if by_cosets:
-        ge1, lay1 = evaluate_h_program(cs, k, dom.extended_k, delta=pow(7, 1 << 28, FR_MODULUS), per_coset=True)
-        coset_prog = ge1.compile(lay1.num_fixed_entries, cs.num_advice, cs.num_instance, num_challenges=1, rot_scale=1)
+        # the per-coset program: the undivided numerator, rotations unscaled (1 / (X^n - 1), a constant per coset, rides on
+        # the recombination matrix)
+        ge1, lay1 = evaluate_h_program(cs, k, dom.extended_k, delta=pow(7, 1 << 28, FR_MODULUS), per_coset=True, divide=False)
+        coset_prog = ge1.compile(lay1.num_fixed_entries, cs.num_advice, cs.num_instance, num_challenges=0, rot_scale=1)
         owners = coset_owners(NC, world, spare_rank0=min_cosets) if world > 1 else [0] * NC
         my_cosets = [c for c in use_cosets if owners[c] == rank]
-        coset_cols = torch.empty((8, n, 4), dtype=torch.int64, device=device)
-        coset_values = {c: torch.zeros((n, 4), dtype=torch.int64, device=device) for c in my_cosets}
+        stand_in = torch.zeros((n, 4), dtype=torch.int64, device=device)       # share_of: a rank without a coset still recombines
     slots = []
     if one_proc_devs:
         # one state per listed device (a device listed twice -- the one-GPU rehearsal -- gets two states): its own copy of the
@@ -238,9 +239,8 @@ def run_replay(shape_name: str, device=None, group=None, include_host_pointer_es
                 tdev = torch.device("cuda", dv)
                 slots.append({
                     "index": i, "device": tdev, "cosets": [c for c in use_cosets if dev_owner[c] == i],
-                    "ntt_batch": ntt_batch.to(tdev).clone(), "coset_cols": torch.empty((8, n, 4), dtype=torch.int64, device=tdev),
-                    "values": {c: torch.zeros((n, 4), dtype=torch.int64, device=tdev) for c in use_cosets if dev_owner[c] == i},
-                    "prog": ge1.compile(lay1.num_fixed_entries, cs.num_advice, cs.num_instance, num_challenges=1, rot_scale=1),
+                    "ntt_batch": ntt_batch.to(tdev).clone(),
+                    "prog": ge1.compile(lay1.num_fixed_entries, cs.num_advice, cs.num_instance, num_challenges=0, rot_scale=1),
                 })
 
     def gate_cols(e):            # every column of the table aliases one of the extended arrays (the arithmetic does not care)
@@ -321,12 +321,41 @@ def run_replay(shape_name: str, device=None, group=None, include_host_pointer_es
         torch.cuda.synchronize()
         t["evaluate_h"] = time.perf_counter() - t0
 
+    def run_cosets(batch8, cosets, prog, dev, times):
+        """The extended-domain steps of `cosets` on one device, fused: every column onto ALL of them in one transform call per 8
+        columns (hm_coeff_to_cosets: the cosets of a column lie one after the other), the undivided numerator over
+        len(cosets) segments of n rows in ONE launch, the partials in one call.  -> {coset: (n, 4) partial}; times["ntt"] /
+        times["evaluate_h"] grow by what this took."""
+        if not cosets:
+            return {}
+        q = len(cosets)
+        t0 = time.perf_counter()
+        cc = None
+        todo = counts["coset_ntt_ext"]
+        while todo > 0:
+            b = min(8, todo)
+            cc = dom.coeff_to_cosets(batch8[:b], cosets, internal=True)             # (b, q, n, 4)
+            todo -= b
+        torch.cuda.synchronize(dev)
+        times["ntt"] += time.perf_counter() - t0
+        t0 = time.perf_counter()
+        cols = [cc[i % cc.shape[0]].reshape(q * n, 4) for i in range(lay.num_fixed_entries + cs.num_advice + cs.num_instance)]
+        values = torch.zeros((q, n, 4), dtype=torch.int64, device=dev)
+        prog.evaluate(cols, values.reshape(q * n, 4), beta=REPLAY_S + 1, gamma=REPLAY_S + 2, theta=REPLAY_S + 3, y=REPLAY_S,
+                      columns_internal=True, segments=q)
+        torch.cuda.synchronize(dev)
+        times["evaluate_h"] += time.perf_counter() - t0
+        t0 = time.perf_counter()
+        dom.cosets_to_partials(values, cosets)
+        torch.cuda.synchronize(dev)
+        times["ntt"] += time.perf_counter() - t0
+        return {c: values[i] for i, c in enumerate(cosets)}
+
     def coset_steps(t):
-        """The same steps with the extended domain taken one coset at a time.  Every rank: all inverse transforms (each rank
-        needs every coefficient array: 8 MiB per column at k = 18; redundant work instead of an all-gather of them), then for
-        each coset it owns: every column onto the coset (one batched call per 8 columns, the powers table shared), the
-        per-coset evaluate_h program over n rows, the inverse transform of the result.  Then ONE all-gather of n x 32 B per
-        coset, and rank 0 recombines the quotient's pieces (j - 1 linear combinations of E arrays)."""
+        """The same steps with the extended domain taken by cosets.  Every rank: all inverse transforms (each rank needs every
+        coefficient array: 8 MiB per column at k = 18; redundant work instead of an all-gather of them), then its cosets, fused
+        (run_cosets).  Then ONE all-gather of n x 32 B per coset, and rank 0 recombines the quotient's pieces (one linear
+        combination of the partials per piece, the vanishing division on the matrix)."""
         t0 = time.perf_counter()
         todo = counts["intt_n"]
         while todo > 0:
@@ -336,34 +365,15 @@ def run_replay(shape_name: str, device=None, group=None, include_host_pointer_es
         torch.cuda.synchronize()
         t["ntt"] = time.perf_counter() - t0
         t["evaluate_h"] = 0.0
-        parts = {}
-        for c in my_cosets:
-            t0 = time.perf_counter()
-            todo = counts["coset_ntt_ext"]
-            while todo > 0:
-                b = min(8, todo)
-                dom.coeff_to_coset(ntt_batch[:b], c, internal=True, out=coset_cols[:b])
-                todo -= b
-            torch.cuda.synchronize()
-            t["ntt"] += time.perf_counter() - t0
-            t0 = time.perf_counter()
-            cols = [coset_cols[i % 8] for i in range(lay.num_fixed_entries + cs.num_advice + cs.num_instance)]
-            coset_prog.evaluate(cols, coset_values[c], challenges=[dom.coset_vanishing_inverse(c)], beta=REPLAY_S + 1, gamma=REPLAY_S + 2,
-                                theta=REPLAY_S + 3, y=REPLAY_S, columns_internal=True)
-            torch.cuda.synchronize()
-            t["evaluate_h"] += time.perf_counter() - t0
-            t0 = time.perf_counter()
-            parts[c] = dom.coset_to_partial(coset_values[c], c)
-            torch.cuda.synchronize()
-            t["ntt"] += time.perf_counter() - t0
+        parts = run_cosets(ntt_batch, my_cosets, coset_prog, device, t)
         t0 = time.perf_counter()
         if share_of is not None:              # no exchange: the recombination runs on this rank's partials, repeated
             # (a rank without a coset -- rank 0 of eight with five cosets -- still pays for the recombination: any array stands in)
-            allp = [parts[my_cosets[c % len(my_cosets)]] if my_cosets else coset_cols[c % 8] for c in use_cosets]
+            allp = [parts[my_cosets[c % len(my_cosets)]] if my_cosets else stand_in for c in use_cosets]
         else:
             allp = gather_coset_partials(parts, NC, group=group, shape=(n, 4), owners=owners)
         if rank == 0 and allp:
-            dom.combine_cosets([p.to(device) for p in allp], cosets=use_cosets if min_cosets else None)
+            dom.combine_cosets([p.to(device) for p in allp], cosets=use_cosets, divide_by_vanishing=True)
         torch.cuda.synchronize()
         t["ntt"] += time.perf_counter() - t0
 
@@ -382,26 +392,7 @@ def run_replay(shape_name: str, device=None, group=None, include_host_pointer_es
             todo -= b
         torch.cuda.synchronize(st["device"])
         times["ntt"] += time.perf_counter() - t0
-        parts = {}
-        for c in st["cosets"]:
-            t0 = time.perf_counter()
-            todo = counts["coset_ntt_ext"]
-            while todo > 0:
-                b = min(8, todo)
-                dom.coeff_to_coset(st["ntt_batch"][:b], c, internal=True, out=st["coset_cols"][:b])
-                todo -= b
-            torch.cuda.synchronize(st["device"])
-            times["ntt"] += time.perf_counter() - t0
-            t0 = time.perf_counter()
-            cols = [st["coset_cols"][i % 8] for i in range(lay.num_fixed_entries + cs.num_advice + cs.num_instance)]
-            st["prog"].evaluate(cols, st["values"][c], challenges=[dom.coset_vanishing_inverse(c)], beta=REPLAY_S + 1, gamma=REPLAY_S + 2,
-                                theta=REPLAY_S + 3, y=REPLAY_S, columns_internal=True)
-            torch.cuda.synchronize(st["device"])
-            times["evaluate_h"] += time.perf_counter() - t0
-            t0 = time.perf_counter()
-            parts[c] = dom.coset_to_partial(st["values"][c], c)
-            torch.cuda.synchronize(st["device"])
-            times["ntt"] += time.perf_counter() - t0
+        parts = run_cosets(st["ntt_batch"], st["cosets"], st["prog"], st["device"], times)
         if st["index"] != 0:
             t0 = time.perf_counter()
             batch_invert(st["z_factors"])
@@ -425,7 +416,7 @@ def run_replay(shape_name: str, device=None, group=None, include_host_pointer_es
         parts = {}
         for pr, _ in results:
             parts.update(pr)
-        dom.combine_cosets([parts[c].to(device) for c in use_cosets], cosets=use_cosets if min_cosets else None)
+        dom.combine_cosets([parts[c].to(device) for c in use_cosets], cosets=use_cosets, divide_by_vanishing=True)
         torch.cuda.synchronize()
         block = time.perf_counter() - t0
         t["evaluate_h"] = max(tm["evaluate_h"] for _, tm in results)
