@@ -129,6 +129,30 @@ class EvaluationDomain {
     if (j >= num_cosets()) throw std::invalid_argument("coeff_to_coset: no such coset");
     arithmetic::check(hm_coeff_to_coset_bn256_fr_dev(a.d, out.d, a.batch, omega.l, k, coset_shift(j).l, internal ? 1 : 0, stream), "coeff_to_coset");
   }
+  // a.batch coefficient arrays onto several cosets in ONE launch chain: out holds a.batch * cosets.size() arrays of n, array
+  // b * cosets.size() + c = polynomial b on coset cosets[c] (per input the cosets lie one after the other: the column layout
+  // hm_graph_evaluate_segments_dev reads, segment c = coset c).  At most 16 cosets per call.
+  void coeff_to_cosets(const DevicePolys& a, const std::vector<size_t>& cosets, DevicePolys& out, bool internal = false,
+                       hipStream_t stream = nullptr) const {
+    if (a.len != n || out.len != n || out.batch < a.batch * cosets.size()) throw std::invalid_argument("coeff_to_cosets: shapes");
+    std::vector<Fr> shifts;
+    for (size_t c : cosets) {
+      if (c >= num_cosets()) throw std::invalid_argument("coeff_to_cosets: no such coset");
+      shifts.push_back(coset_shift(c));
+    }
+    arithmetic::check(hm_coeff_to_cosets_bn256_fr_dev(a.d, out.d, a.batch, omega.l, k, reinterpret_cast<const uint64_t*>(shifts.data()),
+                                                      shifts.size(), internal ? 1 : 0, stream),
+                      "coeff_to_cosets");
+  }
+  // the values ONE polynomial takes on cosets.size() cosets (v.batch arrays of n, in that order) -> its partials, in place
+  void cosets_to_partials(DevicePolys& v, const std::vector<size_t>& cosets, hipStream_t stream = nullptr) const {
+    if (v.len != n || v.batch != cosets.size()) throw std::invalid_argument("cosets_to_partials: one array of n per coset");
+    std::vector<Fr> inv;
+    for (size_t c : cosets) inv.push_back(coset_shift(c).invert());
+    arithmetic::check(hm_cosets_to_coeff_bn256_fr_dev(v.d, v.batch, omega_inv.l, k, ifft_divisor.l, reinterpret_cast<const uint64_t*>(inv.data()),
+                                                      stream),
+                      "cosets_to_partials");
+  }
   // values of h on coset j -> d_j[i] = sum_q h[i + q n] zeta^(n q) w^(j q), in place
   void coset_to_partial(DevicePolys& v, size_t j, hipStream_t stream = nullptr) const {
     if (v.len != n) throw std::invalid_argument("coset_to_partial: v.len() != n");
@@ -142,8 +166,9 @@ class EvaluationDomain {
   // is what extended_to_coeff returns; with q = quotient_poly_degree cosets it is the same quotient for a satisfied circuit,
   // and the other E - q cosets of evaluate_h need not be computed.  partial_j[i] = sum_t piece_t[i] u_j^t, u_j =
   // coset_shift(j)^n: piece_t = sum_a Vinv[t][a] partial_a, V[a][t] = u_(j_a)^t (Gauss-Jordan on the host, q <= E).
+  // divide_by_vanishing: the partials are of the UNDIVIDED numerator; 1 / (X^n - 1) = 1 / (u_c - 1) on coset c rides on the matrix
   void combine_cosets(const std::vector<const Fr*>& partials, const std::vector<size_t>& cosets, size_t pieces, Fr* out,
-                      hipStream_t stream = nullptr) const {
+                      hipStream_t stream = nullptr, bool divide_by_vanishing = false) const {
     const size_t q = cosets.size();
     if (partials.size() != q || q == 0 || pieces == 0 || pieces > q) throw std::invalid_argument("combine_cosets: one partial per coset, at most one piece per coset");
     for (size_t a = 0; a < q; ++a) {
@@ -171,9 +196,12 @@ class EvaluationDomain {
         for (size_t c2 = 0; c2 < 2 * q; ++c2) m[row][c2] = m[row][c2] - f * m[col][c2];
       }
     }
+    std::vector<Fr> tinv(q, Fr::one());
+    if (divide_by_vanishing)
+      for (size_t a = 0; a < q; ++a) tinv[a] = coset_vanishing_inverse(cosets[a]);
     for (size_t t = 0; t < pieces; ++t) {
       std::vector<Fr> c(q);
-      for (size_t a = 0; a < q; ++a) c[a] = m[t][q + a];
+      for (size_t a = 0; a < q; ++a) c[a] = m[t][q + a] * tinv[a];
       arithmetic::linear_combination(partials, c, n, out + t * n, stream);
     }
   }

@@ -355,6 +355,21 @@ int main(int argc, char** argv) {
         if (!(a[i] == b[i])) opening_ok = false;
       for (size_t i = 0; i < n; ++i)                              // a polynomial of degree < n: its own coefficients, then zeros
         if (!(a[i] == dense[i])) opening_ok = false;
+      {   // the same cosets in one launch chain: array c of the output = coset which[c]
+        std::vector<size_t> which;
+        for (size_t j = 0; j < e && j < 16; ++j) which.push_back(e - 1 - j);
+        poly::DevicePolys many(n, which.size());
+        dom.coeff_to_cosets(c1, which, many);
+        const std::vector<Fr> got = many.download();
+        for (size_t c = 0; c < which.size(); ++c)
+          for (size_t t = 0; t < n; t += (n / 32 ? n / 32 : 1))
+            if (!(got[c * n + t] == rows[e * t + which[c]])) opening_ok = false;
+        dom.cosets_to_partials(many, which);
+        const std::vector<Fr> p2 = many.download(), p1 = part.download();
+        for (size_t c = 0; c < which.size(); ++c)
+          for (size_t i = 0; i < n; i += 53)
+            if (!(p2[c * n + i] == p1[which[c] * n + i])) opening_ok = false;
+      }
       // ... and from the quotient_poly_degree cosets that determine a polynomial of that degree (here any subset does)
       if (dom.min_cosets() <= e && e >= 2) {
         const size_t q = dom.min_cosets() < 2 ? 2 : dom.min_cosets();

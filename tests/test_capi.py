@@ -73,6 +73,11 @@ def test_device_pointer_entry_points_without_a_device():
     assert lib.hm_fr_grand_product_batch_dev(None, 8, zp, 3, None, 2, None) == -1
     assert lib.hm_coeff_to_coset_bn256_fr_dev(None, None, 2, zp, 3, zp, 0, None) == -1
     assert lib.hm_coset_to_coeff_bn256_fr_dev(None, 2, zp, 3, zp, zp, None) == -1
+    assert lib.hm_coeff_to_cosets_bn256_fr_dev(None, None, 2, zp, 3, zp, 1, 0, None) == -1
+    assert lib.hm_coeff_to_cosets_bn256_fr_dev(ctypes.c_void_p(0x1000), ctypes.c_void_p(0x100000), 1, zp, 3, zp, 17, 0, None) == -1      # > 16 cosets
+    assert lib.hm_coeff_to_cosets_bn256_fr_dev(ctypes.c_void_p(0x1000), ctypes.c_void_p(0x1080), 1, zp, 3, zp, 2, 0, None) == -1         # overlap
+    assert lib.hm_cosets_to_coeff_bn256_fr_dev(None, 2, zp, 3, zp, zp, None) == -1
+    assert lib.hm_graph_evaluate_segments_dev(ctypes.c_uint64(1), None, 0, None, 0, 3, 2, None, 0, None) == -1
     assert lib.hm_coeff_to_coset_bn256_fr_dev(ctypes.c_void_p(0x1000), ctypes.c_void_p(0x100000), 1, zp, 29, zp, 0, None) == -1      # log_n > 28
     assert lib.hm_coeff_to_coset_bn256_fr_dev(ctypes.c_void_p(0x1000), ctypes.c_void_p(0x1020), 1, zp, 3, zp, 0, None) == -1        # partial overlap
     assert lib.hm_fr_batch_invert_dev(None, 8, None) == -1
@@ -92,6 +97,8 @@ def test_device_pointer_entry_points_without_a_device():
     assert lib.hm_fr_grand_product_batch_dev(two, 8, zp, 3, far, 2, None) == -2
     assert lib.hm_coeff_to_coset_bn256_fr_dev(fake, ctypes.c_void_p(0x100000), 1, zp, 3, zp, 0, None) == -2
     assert lib.hm_coset_to_coeff_bn256_fr_dev(fake, 1, zp, 3, zp, zp, None) == -2
+    assert lib.hm_coeff_to_cosets_bn256_fr_dev(fake, ctypes.c_void_p(0x100000), 1, zp, 3, zp, 1, 0, None) == -2
+    assert lib.hm_cosets_to_coeff_bn256_fr_dev(fake, 1, zp, 3, zp, zp, None) == -2
     assert lib.hm_fr_batch_invert_dev(fake, 8, None) == -2
     assert lib.hm_lookup_permute_bn256_fr_dev(fake, fake, 8, fake, fake, None) == -2
     assert b"no CPU fallback" in lib.hm_last_error()
