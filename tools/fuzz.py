@@ -143,8 +143,20 @@ elif mode == "cosets":
             if not bool((dom.coeff_to_coset(a, c, internal=internal) == ext[:, c::e]).all()):
                 bad += 1
                 print("MISMATCH coset", case, k, j, batch, c, internal, flush=True)
+        sub = rng.sample(range(e), rng.randrange(1, min(e, 16) + 1))
+        many = dom.coeff_to_cosets(a, sub, internal=internal)                     # several cosets in one launch chain
+        for i, c in enumerate(sub):
+            if not bool((many[:, i] == ext[:, c::e]).all()):
+                bad += 1
+                print("MISMATCH cosets (fused)", case, k, j, batch, sub, c, internal, flush=True)
+                break
         hx = rand_fr(e * n, 77 * case + 1)
         parts = [dom.coset_to_partial(hx[c::e].contiguous(), c) for c in range(e)]
+        fused = torch.stack([hx[c::e] for c in sub]).contiguous()
+        dom.cosets_to_partials(fused, sub)
+        if any(not bool((fused[i] == parts[c]).all()) for i, c in enumerate(sub)):
+            bad += 1
+            print("MISMATCH partials (fused)", case, k, j, sub, flush=True)
         whole = hx.clone()
         dom.extended_to_coeff(whole)
         if not bool((dom.combine_cosets(parts, pieces=e) == whole).all()):
