@@ -96,8 +96,13 @@ __global__ __launch_bounds__(LK_THREADS) void lk_convert_kernel(LkPtrs ptr, uint
     hi_bits |= __shfl_xor(hi_bits, off, 64);
   }
   if ((threadIdx.x & 63) == 0) {
-    if (lo_bits) atomicOr(kbits + 2 * blockIdx.y, lo_bits);
-    if (hi_bits) atomicOr(kbits + 2 * blockIdx.y + 1, hi_bits);
+    // OR is monotone: a wave whose bits are already in the word skips the atomic (a stale read only costs an atomic that was not
+    // needed).  Without the test every wave of every array hits the same 2 words per array: 131 000 serialised atomics at
+    // 2^18 rows x 16 arrays were 0.6 of the kernel's 0.63 ms.
+    const uint32_t cur_lo = __atomic_load_n(kbits + 2 * blockIdx.y, __ATOMIC_RELAXED);
+    const uint32_t cur_hi = __atomic_load_n(kbits + 2 * blockIdx.y + 1, __ATOMIC_RELAXED);
+    if (lo_bits & ~cur_lo) atomicOr(kbits + 2 * blockIdx.y, lo_bits);
+    if (hi_bits & ~cur_hi) atomicOr(kbits + 2 * blockIdx.y + 1, hi_bits);
   }
 }
 
