@@ -19,6 +19,7 @@
 
 #include <cstdlib>
 #include <cstring>
+#include <vector>
 
 #include "g1.h"
 #include "hm_internal.h"
@@ -59,6 +60,10 @@ struct LkFr {
 // A batch of lookups: pair p has its columns in ptr.in[2p] (input) and ptr.in[2p + 1] (table), its outputs in
 // ptr.out[2p] / ptr.out[2p + 1]; by value, LK_MAX_PAIRS pairs per launch chain
 constexpr int LK_MAX_PAIRS = 8;
+// the key-bit words of lk_convert_kernel: per key array LK_KB_SLOTS slots of (lo, hi), one 64-byte line each (a slot is shared by
+// the workgroups with blockIdx.x % LK_KB_SLOTS == slot: no word is hot), OR-ed on the host
+constexpr uint32_t LK_KB_SLOTS = 32, LK_KB_STRIDE = 16;
+constexpr size_t LK_KB_WORDS = (size_t)2 * LK_MAX_PAIRS * LK_KB_SLOTS * LK_KB_STRIDE;
 struct LkPtrs {
   const uint32_t* in[2 * LK_MAX_PAIRS];
   uint32_t* out[2 * LK_MAX_PAIRS];
@@ -66,7 +71,7 @@ struct LkPtrs {
 
 // Montgomery words -> canonical integers: one product by `c` (2^-256 in the form the raw words need); rows >= live get
 // the all-ones key (above r: sorts behind every field element).  grid.y = key array (2 per pair).
-// kbits[2 a] |= word 0 of every live key of array a, kbits[2 a + 1] |= its words 1 .. 7: the host picks the sort by them (one OR
+// kbits slots of array a (LK_KB_SLOTS) |= word 0 of its live keys, resp. |= their words 1 .. 7: the host picks the sort by them (one OR
 // per wave, not per key).
 __global__ __launch_bounds__(LK_THREADS) void lk_convert_kernel(LkPtrs ptr, uint32_t* keys, uint64_t pitch, uint64_t live, uint64_t total, LkFr c,
                                                                 uint32_t* __restrict__ kbits) {
@@ -96,13 +101,13 @@ __global__ __launch_bounds__(LK_THREADS) void lk_convert_kernel(LkPtrs ptr, uint
     hi_bits |= __shfl_xor(hi_bits, off, 64);
   }
   if ((threadIdx.x & 63) == 0) {
-    // OR is monotone: a wave whose bits are already in the word skips the atomic (a stale read only costs an atomic that was not
-    // needed).  Without the test every wave of every array hits the same 2 words per array: 131 000 serialised atomics at
-    // 2^18 rows x 16 arrays were 0.6 of the kernel's 0.63 ms.
-    const uint32_t cur_lo = __atomic_load_n(kbits + 2 * blockIdx.y, __ATOMIC_RELAXED);
-    const uint32_t cur_hi = __atomic_load_n(kbits + 2 * blockIdx.y + 1, __ATOMIC_RELAXED);
-    if (lo_bits & ~cur_lo) atomicOr(kbits + 2 * blockIdx.y, lo_bits);
-    if (hi_bits & ~cur_hi) atomicOr(kbits + 2 * blockIdx.y + 1, hi_bits);
+    // OR is monotone: a wave whose bits are already in its slot skips the atomic (a stale read only costs an atomic that was not
+    // needed).  With ONE pair of words per array every wave of the launch hit the same line: 131 000 serialised atomics at
+    // 2^18 rows x 16 arrays were 0.6 of the kernel's 0.63 ms, and the plain reads of the test alone still 0.2.
+    uint32_t* slot = kbits + ((size_t)blockIdx.y * LK_KB_SLOTS + blockIdx.x % LK_KB_SLOTS) * LK_KB_STRIDE;
+    const uint32_t cur_lo = __atomic_load_n(slot, __ATOMIC_RELAXED), cur_hi = __atomic_load_n(slot + 1, __ATOMIC_RELAXED);
+    if (lo_bits & ~cur_lo) atomicOr(slot, lo_bits);
+    if (hi_bits & ~cur_hi) atomicOr(slot + 1, hi_bits);
   }
 }
 
@@ -468,7 +473,7 @@ int lookup_permute_run(DeviceCtx& ctx, const void* const* d_inputs, const void* 
   auto carve = [&](size_t bytes) { const size_t o = off; off += align(bytes); return o; };
   const size_t o_keys = carve((size_t)2 * P * n2 * 32), o_rep = carve((size_t)P * stride * 4), o_used = carve((size_t)P * stride * 4),
                o_rank = carve((size_t)P * stride * 4), o_left = carve((size_t)P * stride * 4), o_reppos = carve((size_t)P * stride * 4),
-               o_sums = carve((size_t)P * blocks * 4 * 2), o_small = carve((size_t)LK_MAX_PAIRS * 16), o_kbits = carve((size_t)4 * LK_MAX_PAIRS * 4);
+               o_sums = carve((size_t)P * blocks * 4 * 2), o_small = carve((size_t)LK_MAX_PAIRS * 16), o_kbits = carve(LK_KB_WORDS * 4);
   // the counting sort of small keys wants 2^bits counters per key array; they are carved only when the sort can be used at all
   // (more keys than a few LDS tiles: below that the bitonic network is one or two launches), sized for the worst case it accepts
   static const bool count_sort_on = [] { const char* v = std::getenv("HALO2_MI355X_LOOKUP_COUNT_SORT"); return !(v && *v == '0'); }();   // A/B
@@ -503,15 +508,20 @@ int lookup_permute_run(DeviceCtx& ctx, const void* const* d_inputs, const void* 
     HM_HIP_CHECK(hipMemsetAsync(used, 0, (size_t)cnt * stride * 4, stream));
     HM_HIP_CHECK(hipMemsetAsync(small, 0, (size_t)LK_MAX_PAIRS * 16, stream));
     const uint32_t cb = (uint32_t)((n2 + LK_THREADS - 1) / LK_THREADS), rb = (uint32_t)((rows + LK_THREADS - 1) / LK_THREADS);
-    HM_HIP_CHECK(hipMemsetAsync(kbits, 0, (size_t)4 * LK_MAX_PAIRS * 4, stream));
+    HM_HIP_CHECK(hipMemsetAsync(kbits, 0, LK_KB_WORDS * 4, stream));
     hipLaunchKernelGGL(lk_convert_kernel, dim3(cb, 2 * cnt), dim3(LK_THREADS), 0, stream, ptr, keys, pitch, rows, n2, to_canon, kbits);
     uint32_t small_bits = 0;                                       // != 0: every live key of the chain is below 2^small_bits
     if (may_count) {                                               // (one small copy and a wait: the call synchronises at its end anyway)
-      uint32_t h_bits[4 * LK_MAX_PAIRS];
-      HM_HIP_CHECK(hipMemcpyAsync(h_bits, kbits, sizeof h_bits, hipMemcpyDeviceToHost, stream));
+      static thread_local std::vector<uint32_t> h_bits_v(LK_KB_WORDS);
+      uint32_t* h_bits = h_bits_v.data();
+      HM_HIP_CHECK(hipMemcpyAsync(h_bits, kbits, LK_KB_WORDS * 4, hipMemcpyDeviceToHost, stream));
       HM_HIP_CHECK(hipStreamSynchronize(stream));
       uint32_t lo_or = 0, hi_or = 0;
-      for (uint32_t a = 0; a < 2 * cnt; ++a) { lo_or |= h_bits[2 * a]; hi_or |= h_bits[2 * a + 1]; }
+      for (uint32_t a = 0; a < 2 * cnt; ++a)
+        for (uint32_t sl = 0; sl < LK_KB_SLOTS; ++sl) {
+          lo_or |= h_bits[((size_t)a * LK_KB_SLOTS + sl) * LK_KB_STRIDE];
+          hi_or |= h_bits[((size_t)a * LK_KB_SLOTS + sl) * LK_KB_STRIDE + 1];
+        }
       uint32_t need = 1;
       while (need < 32 && (lo_or >> need) != 0) ++need;
       if (hi_or == 0 && need <= LK_COUNT_BITS) small_bits = need;
