@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstring>
+#include <type_traits>
 #include <vector>
 
 #include "g1.h"
@@ -347,7 +348,7 @@ __global__ __launch_bounds__(PO_THREADS) void fr_batch_invert_kernel(uint32_t* _
   const Fr k32 = po_arg(k32_int);
   const uint64_t lo = L * INV_B;
   Fr val[INV_B], pre[INV_B];                     // val: true internal values (1 in place of a zero or a missing element)
-  uint32_t zero_mask = 0;
+  uint64_t zero_mask = 0;                        // INV_B <= 64
   Fr run = fe_one<FrParams>();
 #pragma unroll
   for (int k = 0; k < INV_B; ++k) {
@@ -357,7 +358,7 @@ __global__ __launch_bounds__(PO_THREADS) void fr_batch_invert_kernel(uint32_t* _
       uint32_t any = 0;
 #pragma unroll
       for (int i = 0; i < 9; ++i) any |= raw.l[i];
-      if (any == 0) zero_mask |= 1u << k;
+      if (any == 0) zero_mask |= 1ull << k;
       else val[k] = fe_mul(raw, k32);
     }
     pre[k] = run;                                // product of the lane's elements before k
@@ -384,7 +385,7 @@ __global__ __launch_bounds__(PO_THREADS) void fr_batch_invert_kernel(uint32_t* _
   for (int k = INV_B - 1; k >= 0; --k) {
     if (lo + k < n) {
       const Fr inv_k = fe_mul(inv_run, pre[k]);              // 1 / val[k]
-      if (zero_mask & (1u << k)) {
+      if (zero_mask & (1ull << k)) {
         uint4* dst = reinterpret_cast<uint4*>(v + (lo + k) * 8);
         dst[0] = make_uint4(0, 0, 0, 0);
         dst[1] = make_uint4(0, 0, 0, 0);
@@ -571,13 +572,23 @@ int fr_batch_invert_run(uint32_t* d_v, uint64_t n, hipStream_t stream) {
   if (n == 0) return HM_OK;
   PoFr k32;
   host::fr_to_internal9(host::FR_32, k32.l);
-  if (n >= ((uint64_t)1 << 21)) {
-    const uint64_t lanes = (n + 31) / 32;
-    hipLaunchKernelGGL(fr_batch_invert_kernel<32>, dim3((uint32_t)((lanes + PO_THREADS - 1) / PO_THREADS)), dim3(PO_THREADS), 0, stream, d_v, n, k32);
-  } else {
-    const uint64_t lanes = (n + 7) / 8;
-    hipLaunchKernelGGL(fr_batch_invert_kernel<8>, dim3((uint32_t)((lanes + PO_THREADS - 1) / PO_THREADS)), dim3(PO_THREADS), 0, stream, d_v, n, k32);
-  }
+  // Elements per lane.  A wave's time is its chain -- 5 products per element, ~12 for the wave scans, ~380 for the shared Fermat
+  // inversion -- and a SIMD runs one wave at full speed, two at half: what counts is how many ROUNDS of 1 024 waves (256 CUs x 4
+  // SIMDs) the launch needs.  The 2.9 M denominators of the k = 18 proof took 1 408 waves at 32 per lane -- two rounds on a
+  // third of the SIMDs, 0.565 ms; at 48 per lane they are 939 waves, one round, 0.34 ms (A single workgroup-wide inversion
+  // instead -- one wave inverting for sixteen -- was measured too: less work, but the other fifteen waves wait out the same
+  // chain and the launch has too few workgroups to fill the gaps: 0.8 -> 1.17 ms for the z columns of that proof.)
+  const uint64_t one_round = (uint64_t)1024 * 64;                         // lanes of one round
+  auto launch = [&](auto tag) {
+    constexpr int B = decltype(tag)::value;
+    const uint64_t lanes = (n + B - 1) / B;
+    hipLaunchKernelGGL(fr_batch_invert_kernel<B>, dim3((uint32_t)((lanes + PO_THREADS - 1) / PO_THREADS)), dim3(PO_THREADS), 0, stream, d_v, n, k32);
+  };
+  if (n < ((uint64_t)1 << 21)) launch(std::integral_constant<int, 8>{});            // small: more lanes, the same ~0.2 ms chain
+  else if (n <= one_round * 32) launch(std::integral_constant<int, 32>{});
+  else if (n <= one_round * 48) launch(std::integral_constant<int, 48>{});
+  else if (n <= one_round * 64) launch(std::integral_constant<int, 64>{});
+  else launch(std::integral_constant<int, 32>{});                                   // many rounds either way: the least scratch per lane
   HM_HIP_CHECK(hipGetLastError());
   return HM_OK;
 }

@@ -119,17 +119,18 @@ def test_batch_invert_matches_oracle(pyref, n):
     assert from_gpu(pyref, d) == pr.batch_invert(v), n
 
 
-@pytest.mark.parametrize("n", [1 << 20, (1 << 21) + 5])
+@pytest.mark.parametrize("n", [1 << 20, (1 << 21) + 5, 11 << 18, 65536 * 60 + 3, (1 << 22) + 17])
 def test_batch_invert_large_is_an_involution(pyref, n):
-    """2^20 (8 elements per lane) and 2^21 + 5 (32 per lane, ragged tail): x * x^-1 = 1 at sampled rows, planted zeros
-    stay zero, and inverting twice returns the input."""
+    """2^20 (8 elements per lane), 2^21 + 5 (32 per lane, ragged tail), the 11 x 2^18 denominators of the k = 18 proof (48 per
+    lane: one round of waves), 60 x 65536 + 3 (64 per lane) and 2^22 + 17 (32 again): x * x^-1 = 1 at sampled rows, planted
+    zeros stay zero -- at every position of a 64-element lane chunk --, and inverting twice returns the input."""
     import torch
     a = rand_fr_gpu(n, 77)
-    zeros = [3, 31, 32, 33, 64 * 32 - 1, n // 2, n - 1]
+    zeros = [3, 31, 32, 33, 47, 48, 63, 64, 64 * 32 - 1, 64 * 48 - 1, 64 * 64 - 1, n // 2, n - 1]
     a[zeros] = 0
     b = a.clone()
     h.batch_invert(b)
-    rows = [0, 1, 7, 8, 30, 34, 63, 64, 4095, n // 3, n - 9, n - 2]
+    rows = [0, 1, 7, 8, 30, 34, 46, 49, 62, 65, 4094, n // 3, n - 9, n - 2]
     av, bv = from_gpu(pyref, a[rows]), from_gpu(pyref, b[rows])
     for x, y in zip(av, bv):
         assert x * y % R == 1
