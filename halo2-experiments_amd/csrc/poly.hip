@@ -375,8 +375,18 @@ int fr_eval_polynomial_run(DeviceCtx& ctx, const uint32_t* d_polys, uint64_t n, 
       qs.q[i].poly = poly_index ? poly_index[q0 + i] : (uint32_t)(q0 + i);
       host::fr_to_internal9(host::fr_load(points_ext + (q0 + i) * 4), qs.q[i].x.l);
     }
-    hipLaunchKernelGGL(fr_eval_partial_kernel, dim3(B, cnt), dim3(EV_THREADS), 0, stream, d_polys, n, qs, CH, d_partial);
-    hipLaunchKernelGGL(fr_eval_final_kernel, dim3(cnt), dim3(EV_THREADS), 0, stream, (const uint32_t*)d_partial, qs, B, 8u, CH, d_out);
+    // Coefficients per lane of THIS launch.  A lane pays ~25 products whatever its share (x^256, x^t, the block sum), so with
+    // many queries in the launch -- the 94 openings of a k = 18 proof go 48 at a time -- longer shares are cheaper as long as
+    // the launch still has ~1 000 workgroups: 16 per lane costs 2.5 products per coefficient, 64 per lane 1.4.
+    uint32_t CHq = CH;
+    {
+      const uint32_t want_blocks = 1024 / cnt ? 1024 / cnt : 1;                        // workgroups per query
+      const uint64_t ch = (n + (uint64_t)EV_THREADS * want_blocks - 1) / ((uint64_t)EV_THREADS * want_blocks);
+      if (ch > CHq) CHq = (uint32_t)(ch > 256 ? 256 : ch);
+    }
+    const uint32_t Bq = (uint32_t)((n + (uint64_t)EV_THREADS * CHq - 1) / ((uint64_t)EV_THREADS * CHq));     // <= B
+    hipLaunchKernelGGL(fr_eval_partial_kernel, dim3(Bq, cnt), dim3(EV_THREADS), 0, stream, d_polys, n, qs, CHq, d_partial);
+    hipLaunchKernelGGL(fr_eval_final_kernel, dim3(cnt), dim3(EV_THREADS), 0, stream, (const uint32_t*)d_partial, qs, Bq, 8u, CHq, d_out);
     HM_HIP_CHECK(hipGetLastError());
     HM_HIP_CHECK(hipMemcpyAsync(out_ext + q0 * 4, d_out, (size_t)cnt * 32, hipMemcpyDeviceToHost, stream));
     HM_HIP_CHECK(hipStreamSynchronize(stream));      // the results go to the caller's (pageable) memory
