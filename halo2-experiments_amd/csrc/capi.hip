@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "hm_internal.h"
+#include "host_fr.h"
 
 namespace hm {
 
@@ -327,6 +328,7 @@ int hm_shutdown(void) try {
     a.scratch.release();
     a.table.release();
     a.args.release();
+    a.work.release();
     if (a.done) (void)hipEventDestroy(a.done);
     a = AuxSlot{};
   }
@@ -1582,6 +1584,122 @@ int hm_graph_evaluate_segments_dev(uint64_t handle, const void* const* d_columns
   return graph_evaluate_entry("hm_graph_evaluate_segments_dev", handle, d_columns, n_columns, dynamic_constants, n_dynamic, log_segment,
                               segments, d_values, flags, stream);
 } HM_API_CATCH("hm_graph_evaluate_segments_dev")
+
+// ---------------------------------------------------------------------------------------------
+// The quotient h(X) of a proof in ONE call, from coefficient arrays: every column onto `count` cosets of the n-th roots
+// (hm_coeff_to_cosets), the numerator program over count segments of n rows (hm_graph_evaluate_segments), the inverse
+// transforms (hm_cosets_to_coeff), and the recombination with the vanishing division on its matrix -- what upstream's
+// evaluate_h + divide_by_vanishing_poly + extended_to_coeff make of the extended arrays.
+// ---------------------------------------------------------------------------------------------
+int hm_quotient_by_cosets_bn256_fr_dev(uint64_t program, const void* const* d_coeff_columns, const void* const* d_on_cosets, size_t n_columns,
+                                       const uint64_t* dynamic_constants, size_t n_dynamic, uint32_t log_n, const uint64_t omega[4],
+                                       const uint64_t* shifts, size_t count, size_t pieces, void* d_h, void* stream) try {
+  const char* who = "hm_quotient_by_cosets_bn256_fr_dev";
+  if (!d_h || !omega || !shifts || (n_columns && !d_coeff_columns) || (n_dynamic && !dynamic_constants))
+    return hm_fail(HM_ERR_BAD_ARG, std::string(who) + ": null argument");
+  if (log_n > 28 || log_n == 0) return hm_fail(HM_ERR_BAD_ARG, std::string(who) + ": log_n must be in 1 .. 28");
+  if (count == 0 || count > 16 || pieces == 0 || pieces > count)
+    return hm_fail(HM_ERR_BAD_ARG, std::string(who) + ": 1 <= pieces <= cosets <= 16");
+  if (n_columns == 0 || n_columns * count > 65535) return hm_fail(HM_ERR_BAD_ARG, std::string(who) + ": columns x cosets must be in 1 .. 65535");
+  // a column comes as coefficients (transformed here) or, when d_on_cosets[i] is set, as its values on the `count` cosets already
+  // (count x n words of 32 * value, what hm_coeff_to_cosets(..., columns_internal = 1) wrote: the fixed columns of a proving key)
+  std::vector<size_t> todo;
+  for (size_t i = 0; i < n_columns; ++i) {
+    if (d_on_cosets && d_on_cosets[i]) continue;
+    if (!d_coeff_columns[i]) return hm_fail(HM_ERR_BAD_ARG, std::string(who) + ": a column has neither coefficients nor coset values");
+    todo.push_back(i);
+  }
+  const uint64_t n = 1ull << log_n;
+  // host side: u_c = shift_c^n, the inverse shifts, V^-1 with 1 / (u_c - 1) on column c
+  std::vector<host::Fr4> u(count), shift_inv(count);
+  for (size_t c = 0; c < count; ++c) {
+    host::Fr4 x = host::fr_load(shifts + 4 * c);
+    if (host::fr_is_zero(x)) return hm_fail(HM_ERR_BAD_ARG, std::string(who) + ": a coset shift is zero");
+    shift_inv[c] = host::fr_inv(x);
+    for (uint32_t b = 0; b < log_n; ++b) x = host::fr_mul(x, x);
+    u[c] = x;
+    if (host::fr_eq(u[c], host::FR_ONE)) return hm_fail(HM_ERR_BAD_ARG, std::string(who) + ": a coset lies in the n-th roots (X^n - 1 vanishes on it)");
+    for (size_t b = 0; b < c; ++b)
+      if (host::fr_eq(u[b], u[c])) return hm_fail(HM_ERR_BAD_ARG, std::string(who) + ": two shifts name the same coset");
+  }
+  const host::Fr4 zero = {{0, 0, 0, 0}};
+  std::vector<std::vector<host::Fr4>> m(count, std::vector<host::Fr4>(2 * count, zero));      // [V | I] -> [I | V^-1], Gauss-Jordan
+  for (size_t a = 0; a < count; ++a) {
+    host::Fr4 p = host::FR_ONE;
+    for (size_t t = 0; t < count; ++t) { m[a][t] = p; p = host::fr_mul(p, u[a]); }
+    m[a][count + a] = host::FR_ONE;
+  }
+  for (size_t col = 0; col < count; ++col) {
+    size_t piv = col;
+    while (piv < count && host::fr_is_zero(m[piv][col])) ++piv;
+    if (piv == count) return hm_fail(HM_ERR_INTERNAL, std::string(who) + ": singular coset matrix");
+    std::swap(m[col], m[piv]);
+    const host::Fr4 inv = host::fr_inv(m[col][col]);
+    for (auto& v : m[col]) v = host::fr_mul(v, inv);
+    for (size_t row = 0; row < count; ++row) {
+      if (row == col || host::fr_is_zero(m[row][col])) continue;
+      const host::Fr4 f = m[row][col];
+      for (size_t c2 = 0; c2 < 2 * count; ++c2) m[row][c2] = host::fr_sub(m[row][c2], host::fr_mul(f, m[col][c2]));
+    }
+  }
+  std::vector<host::Fr4> tinv(count);
+  for (size_t c = 0; c < count; ++c) tinv[c] = host::fr_inv(host::fr_sub(u[c], host::FR_ONE));
+  host::Fr4 nn = host::FR_ONE;                                               // n = 2^log_n in Montgomery form: 1 doubled log_n times
+  for (uint32_t b = 0; b < log_n; ++b) nn = host::fr_sub(nn, host::fr_sub(zero, nn));
+  const host::Fr4 n_inv = host::fr_inv(nn);
+  const host::Fr4 om_inv = host::fr_inv(host::fr_load(omega));
+
+  DeviceCtx* ctx = ctx_for_current_device();
+  if (!ctx) return HM_ERR_NO_DEVICE;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  GraphProgram* g = nullptr;
+  for (auto& gp : ctx->graphs)
+    if (gp->handle == program) g = gp.get();
+  if (!g) return hm_fail(HM_ERR_NOT_FOUND, std::string(who) + ": unknown program handle");
+  if (n_columns != g->n_columns) return hm_fail(HM_ERR_BAD_ARG, std::string(who) + ": the program was built for another number of columns");
+  hipStream_t st = (hipStream_t)stream;
+  AuxSlot* slot = aux_acquire(*ctx, st);
+  if (!slot) return HM_ERR_HIP;
+  // work: [columns contiguous: C x n] [columns on cosets: C x count x n] [values: count x n]
+  const size_t row = (size_t)n * 32;
+  const size_t T = todo.size();
+  uint8_t* work = (uint8_t*)slot->work.ensure(row * (T + T * count + count) + 32);
+  if (!work) return hm_fail(HM_ERR_HIP, std::string(who) + ": workspace allocation failed");
+  uint8_t* contig = work;
+  uint8_t* on_cosets = contig + row * T;
+  uint8_t* values = on_cosets + row * T * count;
+  int rc = HM_OK;
+  if (T) {
+    for (size_t j = 0; j < T; ++j)
+      HM_HIP_CHECK(hipMemcpyAsync(contig + row * j, d_coeff_columns[todo[j]], row, hipMemcpyDeviceToDevice, st));
+    rc = ntt_cosets_run(*ctx, (const uint32_t*)contig, (uint32_t*)on_cosets, (uint32_t)T, omega, log_n, shifts, (uint32_t)count, true, st);
+    if (rc != HM_OK) return rc;
+    count_ntt(*ctx, log_n, T * count);
+  }
+  std::vector<const void*> cols(n_columns);
+  for (size_t i = 0; i < n_columns; ++i) cols[i] = d_on_cosets ? d_on_cosets[i] : nullptr;
+  for (size_t j = 0; j < T; ++j) cols[todo[j]] = on_cosets + row * count * j;
+  HM_HIP_CHECK(hipMemsetAsync(values, 0, row * count, st));                    // PreviousValue: upstream starts h at zero
+  rc = graph_evaluate(*ctx, *g, cols.data(), n_columns, dynamic_constants, n_dynamic, log_n, (uint32_t)count, values, HM_GRAPH_COLUMNS_INTERNAL, st);
+  if (rc != HM_OK) return rc;
+  count_vector(*ctx, HM_STAT_GRAPH_EVALUATE, 1, (uint64_t)count << log_n);
+  rc = ntt_cosets_inverse_run(*ctx, (uint32_t*)values, (uint32_t)count, om_inv.l, log_n, n_inv.l, shift_inv[0].l, st);
+  if (rc != HM_OK) return rc;
+  count_ntt(*ctx, log_n, count);
+  std::vector<const void*> parts(count);
+  for (size_t c = 0; c < count; ++c) parts[c] = values + row * c;
+  std::vector<uint64_t> coeffs(4 * count);
+  for (size_t t = 0; t < pieces; ++t) {
+    for (size_t c = 0; c < count; ++c) {
+      const host::Fr4 v = host::fr_mul(m[t][count + c], tinv[c]);
+      std::memcpy(&coeffs[4 * c], v.l, 32);
+    }
+    rc = fr_linear_combination_run(parts.data(), coeffs.data(), count, n, (uint32_t*)((uint8_t*)d_h + row * t), st);
+    if (rc != HM_OK) return rc;
+  }
+  count_vector(*ctx, HM_STAT_LINEAR_COMBINATION, pieces, (uint64_t)pieces * count * n);
+  return aux_release(*ctx, slot, st);
+} HM_API_CATCH("hm_quotient_by_cosets_bn256_fr_dev")
 
 int hm_graph_destroy(uint64_t handle) try {
   DeviceCtx* ctx = ctx_for_current_device();

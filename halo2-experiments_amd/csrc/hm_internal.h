@@ -179,6 +179,7 @@ struct AuxSlot {
   DevBuf scratch;                 // NTT ping-pong buffer
   DevBuf table;                   // multiples table of hm_g1_fixed_base_mul_dev
   DevBuf args;                    // per-call argument block of hm_graph_evaluate_dev (column table + per-proof constants)
+  DevBuf work;                    // hm_quotient_by_cosets_bn256_fr_dev: the columns on the cosets, the numerator's values
   hipStream_t stream = nullptr;   // stream of the last user
   hipEvent_t done = nullptr;      // recorded behind the last user's launches
   bool used = false;

@@ -52,6 +52,41 @@ static inline Fr4 fr_mul(const Fr4& a, const Fr4& b) {
   return r;
 }
 
+static inline Fr4 fr_sub(const Fr4& a, const Fr4& b) {            // canonical inputs -> canonical output
+  u128 d = (u128)a.l[0] - b.l[0];
+  uint64_t t0 = (uint64_t)d;
+  d = (u128)a.l[1] - b.l[1] - ((uint64_t)(d >> 64) & 1);
+  uint64_t t1 = (uint64_t)d;
+  d = (u128)a.l[2] - b.l[2] - ((uint64_t)(d >> 64) & 1);
+  uint64_t t2 = (uint64_t)d;
+  d = (u128)a.l[3] - b.l[3] - ((uint64_t)(d >> 64) & 1);
+  uint64_t t3 = (uint64_t)d;
+  if ((uint64_t)(d >> 64) & 1) {   // borrow: add r back
+    u128 c = (u128)t0 + FR_MOD[0];
+    t0 = (uint64_t)c;
+    c = (c >> 64) + t1 + FR_MOD[1];
+    t1 = (uint64_t)c;
+    c = (c >> 64) + t2 + FR_MOD[2];
+    t2 = (uint64_t)c;
+    c = (c >> 64) + t3 + FR_MOD[3];
+    t3 = (uint64_t)c;
+  }
+  return Fr4{{t0, t1, t2, t3}};
+}
+static inline bool fr_is_zero(const Fr4& a) { return (a.l[0] | a.l[1] | a.l[2] | a.l[3]) == 0; }
+static inline bool fr_eq(const Fr4& a, const Fr4& b) {
+  return ((a.l[0] ^ b.l[0]) | (a.l[1] ^ b.l[1]) | (a.l[2] ^ b.l[2]) | (a.l[3] ^ b.l[3])) == 0;
+}
+static inline Fr4 fr_inv(const Fr4& a) {   // a^(r-2); zero stays zero
+  const uint64_t e[4] = {FR_MOD[0] - 2, FR_MOD[1], FR_MOD[2], FR_MOD[3]};
+  Fr4 acc = FR_ONE;
+  for (int i = 255; i >= 0; --i) {
+    acc = fr_mul(acc, acc);
+    if ((e[i >> 6] >> (i & 63)) & 1) acc = fr_mul(acc, a);
+  }
+  return acc;
+}
+
 static inline Fr4 fr_load(const uint64_t w[4]) {
   Fr4 r;
   memcpy(r.l, w, 32);

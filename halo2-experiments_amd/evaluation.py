@@ -333,6 +333,46 @@ class CompiledGraph:
                                                               seg.bit_length() - 1, segments, ctypes.c_void_p(values.data_ptr()),
                                                               1 if columns_internal else 0, ctypes.c_void_p(_stream_ptr(values))))
 
+    def quotient_by_cosets(self, domain, coeff_columns: Sequence, cosets=None, challenges: Sequence[int] = (), beta: int = 0, gamma: int = 0,
+                           theta: int = 0, y: int = 0, on_cosets: Sequence = None):
+        """h(X) in ONE call (``hm_quotient_by_cosets_bn256_fr_dev``): this program must be the UNDIVIDED numerator compiled with
+        ``rot_scale=1`` (``circuits.evaluate_h_program(per_coset=True, divide=False)``); ``coeff_columns``: (n, 4) coefficient
+        tensors, one per entry of the column table; ``cosets``: indices into the extended domain's cosets (default: the
+        ``domain.min_cosets()`` that determine the quotient of a satisfied circuit).  -> (len(cosets) * n, 4)... the first
+        ``len(cosets)`` pieces, i.e. all of h when the circuit is satisfied.  ``on_cosets``: per column None or its values on
+        those cosets already, (len(cosets), n, 4) as ``domain.coeff_to_cosets(col, cosets, internal=True)`` returns them (the fixed
+        columns of a proving key: transformed once); the coefficient entry of such a column may be None."""
+        import torch
+
+        cosets = list(range(domain.min_cosets())) if cosets is None else [int(c) for c in cosets]
+        if len(coeff_columns) != self.n_columns or len(challenges) != self.num_challenges:
+            raise ValueError("quotient_by_cosets: column / challenge count differs from the compiled program's")
+        if self.short_columns:
+            raise ValueError("quotient_by_cosets: the program must not read short columns (compile the undivided numerator)")
+        q = len(cosets)
+        pre = list(on_cosets) if on_cosets is not None else [None] * len(coeff_columns)
+        if len(pre) != len(coeff_columns):
+            raise ValueError("quotient_by_cosets: on_cosets must have one entry per column")
+        cols = [None if pre[i] is not None else c.contiguous() for i, c in enumerate(coeff_columns)]
+        for c in cols:
+            if c is not None and _tensor_rows(c, 4, "column") != domain.n:
+                raise ValueError("quotient_by_cosets: every column must hold n coefficients")
+        pre = [None if p is None else p.contiguous() for p in pre]
+        for p in pre:
+            if p is not None and _tensor_rows(p, 4, "on_cosets") != q * domain.n:
+                raise ValueError("quotient_by_cosets: a column on the cosets must hold len(cosets) * n values")
+        ref = next(t for t in cols + pre if t is not None)
+        out = torch.empty((q * domain.n, 4), dtype=ref.dtype, device=ref.device)
+        ptrs = (ctypes.c_void_p * len(cols))(*[(c.data_ptr() if c is not None else None) for c in cols])
+        pre_ptrs = (ctypes.c_void_p * len(cols))(*[(p.data_ptr() if p is not None else None) for p in pre])
+        dyn = np.stack([fr_words(v) for v in list(challenges) + [beta, gamma, theta, y]])
+        shifts = np.stack([fr_words(domain.coset_shift(c)) for c in cosets])
+        _lib.check(_lib.load().hm_quotient_by_cosets_bn256_fr_dev(
+            ctypes.c_uint64(self.handle), ptrs, pre_ptrs if on_cosets is not None else None, len(cols), _ptr(dyn), dyn.shape[0], domain.k,
+            _ptr(fr_words(domain.omega)), _ptr(shifts), q, q,
+            ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(_stream_ptr(out))))
+        return out
+
     def destroy(self) -> None:
         if self.handle:
             _lib.check(_lib.load().hm_graph_destroy(ctypes.c_uint64(self.handle)))

@@ -350,6 +350,28 @@ int hm_graph_create(const uint32_t* calcs, size_t n_calc, const uint64_t* consta
                     const int32_t* rotations, size_t n_rot, size_t n_columns, uint32_t n_intermediates, uint64_t* out_handle);
 int hm_graph_evaluate_dev(uint64_t handle, const void* const* d_columns, size_t n_columns, const uint64_t* dynamic_constants,
                           size_t n_dynamic, uint32_t log_size, void* d_values, void* stream);
+/* The quotient h(X) of a proof in ONE call, from COEFFICIENT arrays -- what upstream's evaluate_h, divide_by_vanishing_poly and
+ * extended_to_coeff make of the extended arrays (halo2_proofs plonk/evaluation.rs, poly/domain.rs; reached from
+ * /root/reference/src/circuits/utils.rs:40-48).
+ *   program: an hm_graph_create handle of the UNDIVIDED numerator (custom gates, permutation and lookup terms combined by y)
+ *     with rotations as on the n-row domain (unscaled) and every entry of its column table a polynomial of n coefficients;
+ *   d_coeff_columns: n_columns device pointers, 2^log_n coefficients each (fixed, then advice, then instance -- the
+ *     identity polynomial X where the program reads the point itself);
+ *   d_on_cosets: NULL, or n_columns entries of which the non-NULL ones name columns whose values on the `count` cosets exist
+ *     already -- count x 2^log_n words as hm_coeff_to_cosets_bn256_fr_dev(..., columns_internal = 1) wrote them for the same
+ *     shifts (the fixed columns, permutation polynomials and l_0 / l_last / l_active of a proving key: transformed once, not
+ *     once per proof); d_coeff_columns[i] is then not read;
+ *   shifts: host, count x 4 u64 -- the cosets shift_c * <omega> to evaluate on, shift_c = zeta * extended_omega^(j_c), distinct
+ *     and outside the n-th roots; `count` >= `pieces`, and pieces = (max degree - 1) cosets determine the quotient of a satisfied
+ *     circuit (it has fewer than pieces * n coefficients): 5 of the 8 cosets of the extended domain for the reference's circuits;
+ *   d_h: pieces x 2^log_n coefficients of h, piece t = coefficients [t n, (t + 1) n).
+ * With all E cosets the result equals hm_extended_to_coeff of the divided whole-array evaluation word for word for ANY
+ * columns; with fewer it is the polynomial of degree < count * n through the numerator / (X^n - 1) on those cosets -- the same
+ * h exactly when the circuit is satisfied.  Asynchronous on `stream`; the workspace (columns x (count + 1) + count arrays of n)
+ * belongs to the stream's slot. */
+int hm_quotient_by_cosets_bn256_fr_dev(uint64_t program, const void* const* d_coeff_columns, const void* const* d_on_cosets, size_t n_columns,
+                                       const uint64_t* dynamic_constants, size_t n_dynamic, uint32_t log_n, const uint64_t omega[4],
+                                       const uint64_t* shifts, size_t count, size_t pieces, void* d_h, void* stream);
 int hm_graph_destroy(uint64_t handle);
 /* The same evaluation with options.  HM_GRAPH_COLUMNS_INTERNAL: every column of the table (short ones included) holds
  * 32 * value mod r instead of value -- the library's internal Montgomery radix is 2^261, so such words need no conversion

@@ -265,3 +265,66 @@ def test_evaluate_h_on_several_cosets_in_one_launch(pyref, name):
         prog_all.destroy()
         prog_num.destroy()
         prog_one.destroy()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(circuits.CONSTRAINT_SYSTEMS))
+def test_the_one_call_quotient_equals_the_whole_array_route(pyref, name):
+    """hm_quotient_by_cosets_bn256_fr_dev: coefficient columns in, h out.  With all E cosets: word for word what coeff_to_extended
+    -> the divided program over 2^extended_k rows -> extended_to_coeff returns, for random columns; with a subset: the same as the
+    Python composition of the fused calls (coeff_to_cosets, segments, cosets_to_partials, combine_cosets with the division on its
+    matrix)."""
+    import torch
+    from halo2_experiments_amd.domain import EvaluationDomain
+    cs = circuits.CONSTRAINT_SYSTEMS[name]()
+    k = 7
+    dom = EvaluationDomain(cs.degree(), k)
+    ek, n, e = dom.extended_k, dom.n, dom.num_cosets()
+    delta = pow(7, 1 << 28, R)
+    g_all, lay = circuits.evaluate_h_program(cs, k, ek, delta)
+    g_num, lay_n = circuits.evaluate_h_program(cs, k, ek, delta, per_coset=True, divide=False)
+    n_cols = lay.num_fixed_entries + cs.num_advice + cs.num_instance
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(123 + len(name))
+    coeffs = torch.randint(-(2 ** 63), 2 ** 63 - 1, (n_cols, n, 4), dtype=torch.int64, device="cuda", generator=gen)
+    coeffs[:, :, 3] &= 0x0FFFFFFFFFFFFFFF
+    coeffs[lay.x_coset] = torch.from_numpy(pyref.fr_array([0, 1] + [0] * (n - 2)).view(np.int64)).cuda()
+    rng = random.Random(8)
+    beta, gamma, theta, y = (rng.randrange(R) for _ in range(4))
+    to_dev = lambda vals: torch.from_numpy(pyref.fr_array(vals).view(np.int64)).cuda()
+    prog_all = g_all.compile(lay.num_fixed_entries, cs.num_advice, cs.num_instance, num_challenges=0, rot_scale=e, short_columns=lay.short_columns)
+    prog_num = g_num.compile(lay_n.num_fixed_entries, cs.num_advice, cs.num_instance, num_challenges=0, rot_scale=1)
+    try:
+        ext = dom.coeff_to_extended(coeffs, internal=True)
+        cols = [ext[i] for i in range(n_cols)]
+        cols[lay.t_inv] = to_dev([32 * dom.coset_vanishing_inverse(c) % R for c in range(e)])
+        h_ext = torch.zeros((1 << ek, 4), dtype=torch.int64, device="cuda")
+        prog_all.evaluate(cols, h_ext, beta=beta, gamma=gamma, theta=theta, y=y, columns_internal=True)
+        dom.extended_to_coeff(h_ext)                                   # in place: all E n coefficients
+        columns = [coeffs[i] for i in range(n_cols)]
+        got = prog_num.quotient_by_cosets(dom, columns, cosets=list(range(e)), beta=beta, gamma=gamma, theta=theta, y=y)
+        assert got.shape == (e * n, 4) and bool((got == h_ext).all()), name
+        sub = [e - 1, 1, 0][: min(3, e)]
+        got = prog_num.quotient_by_cosets(dom, columns, cosets=sub, beta=beta, gamma=gamma, theta=theta, y=y)
+        q = len(sub)
+        cc = dom.coeff_to_cosets(coeffs, sub, internal=True)
+        v = torch.zeros((q, n, 4), dtype=torch.int64, device="cuda")
+        prog_num.evaluate([cc[j].reshape(q * n, 4) for j in range(n_cols)], v.reshape(q * n, 4), beta=beta, gamma=gamma, theta=theta, y=y,
+                          columns_internal=True, segments=q)
+        parts = dom.cosets_to_partials(v, sub)
+        want = dom.combine_cosets([parts[i] for i in range(q)], cosets=sub, divide_by_vanishing=True)
+        assert bool((got == want).all()), name
+        # the fixed entries of the table transformed ONCE (a proving key keeps them): same result, their coefficients not read
+        nf = lay.num_fixed_entries
+        kept = dom.coeff_to_cosets(coeffs[:nf], sub, internal=True)
+        pre = [kept[i] for i in range(nf)] + [None] * (n_cols - nf)
+        got2 = prog_num.quotient_by_cosets(dom, [None] * nf + columns[nf:], cosets=sub, beta=beta, gamma=gamma, theta=theta, y=y, on_cosets=pre)
+        assert bool((got2 == want).all()), name
+        assert coeffs[lay.x_coset][1].any() and not coeffs[lay.x_coset][2:].any()          # the inputs are untouched
+        with pytest.raises(Exception):
+            prog_num.quotient_by_cosets(dom, columns[:-1], cosets=sub)
+        with pytest.raises(Exception):
+            prog_num.quotient_by_cosets(dom, columns, cosets=[0, 0])
+    finally:
+        prog_all.destroy()
+        prog_num.destroy()

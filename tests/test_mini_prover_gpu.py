@@ -152,6 +152,15 @@ def test_mini_proof_quotient_identity(pyref, tamper):
         parts.append(dom.coset_to_partial(v, c))
     prog1.destroy()
     h_min = dom.combine_cosets(parts, cosets=use)
+    # ... and in ONE call from the coefficient arrays (hm_quotient_by_cosets_bn256_fr_dev: the undivided numerator, the division on
+    # the recombination matrix)
+    g2 = ev.GraphEvaluator()
+    g2.add_custom_gates(exprs)
+    prog2 = g2.compile(10, 8, 0, rot_scale=1)
+    coeff_cols = [all_coeffs[i] for i in range(8)] + [all_coeffs[16], all_coeffs[16]] + [all_coeffs[8 + i] for i in range(8)]
+    h_one = prog2.quotient_by_cosets(dom, coeff_cols, cosets=use, beta=beta, gamma=gamma, theta=theta, y=y)
+    prog2.destroy()
+    assert bool((h_one == h_min).all())
     if not tamper:
         assert h_min.shape == h_coeff.shape and bool((h_min == h_coeff).all())
     else:
