@@ -78,6 +78,10 @@ def test_device_pointer_entry_points_without_a_device():
     assert lib.hm_coeff_to_cosets_bn256_fr_dev(ctypes.c_void_p(0x1000), ctypes.c_void_p(0x1080), 1, zp, 3, zp, 2, 0, None) == -1         # overlap
     assert lib.hm_cosets_to_coeff_bn256_fr_dev(None, 2, zp, 3, zp, zp, None) == -1
     assert lib.hm_graph_evaluate_segments_dev(ctypes.c_uint64(1), None, 0, None, 0, 3, 2, None, 0, None) == -1
+    one_col = (ctypes.c_void_p * 1)(0x1000)
+    assert lib.hm_quotient_by_cosets_bn256_fr_dev(ctypes.c_uint64(1), one_col, None, 1, zp, 1, 3, zp, zp, 1, 1, None, None) == -1       # no output
+    assert lib.hm_quotient_by_cosets_bn256_fr_dev(ctypes.c_uint64(1), one_col, None, 1, zp, 1, 3, zp, zp, 2, 3, ctypes.c_void_p(0x9000), None) == -1   # pieces > cosets
+    assert lib.hm_quotient_by_cosets_bn256_fr_dev(ctypes.c_uint64(1), one_col, None, 1, zp, 1, 3, zp, zp, 1, 1, ctypes.c_void_p(0x9000), None) == -1   # a zero shift
     assert lib.hm_coeff_to_coset_bn256_fr_dev(ctypes.c_void_p(0x1000), ctypes.c_void_p(0x100000), 1, zp, 29, zp, 0, None) == -1      # log_n > 28
     assert lib.hm_coeff_to_coset_bn256_fr_dev(ctypes.c_void_p(0x1000), ctypes.c_void_p(0x1020), 1, zp, 3, zp, 0, None) == -1        # partial overlap
     assert lib.hm_fr_batch_invert_dev(None, 8, None) == -1
@@ -99,6 +103,10 @@ def test_device_pointer_entry_points_without_a_device():
     assert lib.hm_coset_to_coeff_bn256_fr_dev(fake, 1, zp, 3, zp, zp, None) == -2
     assert lib.hm_coeff_to_cosets_bn256_fr_dev(fake, ctypes.c_void_p(0x100000), 1, zp, 3, zp, 1, 0, None) == -2
     assert lib.hm_cosets_to_coeff_bn256_fr_dev(fake, 1, zp, 3, zp, zp, None) == -2
+    two = np.array([2, 0, 0, 0], dtype=np.uint64)
+    twop = two.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64))
+    one_col = (ctypes.c_void_p * 1)(0x1000)
+    assert lib.hm_quotient_by_cosets_bn256_fr_dev(ctypes.c_uint64(1), one_col, None, 1, zp, 1, 3, twop, twop, 1, 1, ctypes.c_void_p(0x9000), None) == -2
     assert lib.hm_fr_batch_invert_dev(fake, 8, None) == -2
     assert lib.hm_lookup_permute_bn256_fr_dev(fake, fake, 8, fake, fake, None) == -2
     assert b"no CPU fallback" in lib.hm_last_error()
