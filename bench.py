@@ -405,6 +405,50 @@ def strong_scaling_msm(log_global, seed, rank, world, device, comm_device, reps=
             "split": f"index ranges x{world}, all-gather of 96 B partials + host fold per MSM"}
 
 
+def quotient_one_call(device, k=18, reps=5):
+    """hm_quotient_by_cosets_bn256_fr_dev on the MerkleSumTree circuit's own numerator program at k = 18, every one of its 83 table
+    entries an array of its own: the 48 per-proof columns from coefficients, the circuit's 35 constant columns (fixed, sigmas, l_0 /
+    l_last / l_active, X) kept on the cosets as a proving key would keep them.  Five cosets (what determines the quotient) and all eight."""
+    from halo2_experiments_amd import circuits
+    from halo2_experiments_amd.domain import EvaluationDomain, FR_MODULUS
+    from halo2_experiments_amd.replay import _rand_fr
+    cs = circuits.merkle_sum_tree()
+    dom = EvaluationDomain(cs.degree(), k)
+    g, lay = circuits.evaluate_h_program(cs, k, dom.extended_k, pow(7, 1 << 28, FR_MODULUS), per_coset=True, divide=False)
+    n_cols = lay.num_fixed_entries + cs.num_advice + cs.num_instance
+    prog = g.compile(lay.num_fixed_entries, cs.num_advice, cs.num_instance, num_challenges=0, rot_scale=1)
+    out = {"k": k, "columns": n_cols, "program_calculations": int(len(prog.calcs))}
+    try:
+        cols = [_rand_fr(dom.n, 7000 + i, device) for i in range(n_cols)]
+        const_idx = sorted(set(range(cs.num_fixed)) | set(range(lay.sigma0, lay.sigma0 + len(cs.equality)))
+                           | {lay.l0, lay.l_last, lay.l_active, lay.x_coset, lay.t_inv})
+        out["columns_kept_on_the_cosets"] = len(const_idx)
+        for label, q in (("five_cosets", dom.min_cosets()), ("all_cosets", dom.num_cosets())):
+            cosets = list(range(q))
+            kept = dom.coeff_to_cosets(torch.stack([cols[i] for i in const_idx]), cosets, internal=True)
+            pre = [None] * n_cols
+            for j, i in enumerate(const_idx):
+                pre[i] = kept[j]
+            per_proof = [None if pre[i] is not None else cols[i] for i in range(n_cols)]
+            run = lambda: prog.quotient_by_cosets(dom, per_proof, cosets=cosets, beta=3, gamma=4, theta=5, y=6, on_cosets=pre)  # noqa: E731
+            run()
+            ts = []
+            for _ in range(reps):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                run()
+                torch.cuda.synchronize()
+                ts.append(time.perf_counter() - t0)
+            out[label] = {"cosets": q, "ms": float(np.median(ts)) * 1e3}
+            del kept, pre, per_proof
+        out["note"] = ("coefficient columns in, the pieces of h out, one C call; upstream's steps for the same columns in the replay above: "
+                       "coset transforms + evaluate_h + extended_to_coeff")
+    finally:
+        prog.destroy()
+        torch.cuda.empty_cache()
+    return out
+
+
 def one_process_measurements(devs, device, log_global, replay_name, reps=3):
     """The one-process form (csrc/multi.hip under the C ABI): hm_set_msm_devices(devs), then (a) ONE 2^log_global MSM on a
     base set SLICED by index range over the devices -- scalars as one device array on devs[0] (the slices of the other
@@ -828,6 +872,10 @@ def main():
                                   "(same h word for word: tests/test_mini_prover_gpu.py); create_proof_replay.device_resident_s stays the "
                                   "whole-array route, upstream's own steps")
                 rep18["extended_domain_routes_ms"] = routes
+                try:
+                    rep18["quotient_in_one_call_ms"] = quotient_one_call(device)
+                except Exception as exc:  # noqa: BLE001 -- a side measurement never costs the line
+                    rep18["quotient_in_one_call_ms"] = {"error": f"{type(exc).__name__}: {exc}"}
                 rep18["rank_shares_measured_alone"] = {
                     "shares": shares, "note": "the first and the last rank's share of the N-rank replay, each run alone on this GPU (its "
                                               "commitments of every phase, its cosets of the extended domain, for rank 0 the steps only rank 0 "

@@ -96,6 +96,9 @@ def test_one_gpu_line_carries_rank_shares_of_the_k18_replay():
     routes = rep["extended_domain_routes_ms"]          # the same trace with the extended-domain steps by all / by the determining cosets
     assert routes["whole_array"]["total"] == pytest.approx(rep["device_resident_s"]["total"] * 1e3)
     assert routes["by_all_cosets"]["evaluate_h"] > routes["by_the_cosets_that_determine_h"]["evaluate_h"] > 0
+    one = rep["quotient_in_one_call_ms"]                  # hm_quotient_by_cosets_bn256_fr_dev on the circuit's own program, 83 columns
+    assert "error" not in one and one["columns"] == 83 and one["columns_kept_on_the_cosets"] == 35
+    assert one["all_cosets"]["ms"] > one["five_cosets"]["ms"] > 0 and one["five_cosets"]["cosets"] == 5
 
 
 @pytest.mark.gpu
