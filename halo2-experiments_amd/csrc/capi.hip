@@ -1591,31 +1591,12 @@ int hm_graph_evaluate_segments_dev(uint64_t handle, const void* const* d_columns
 // transforms (hm_cosets_to_coeff), and the recombination with the vanishing division on its matrix -- what upstream's
 // evaluate_h + divide_by_vanishing_poly + extended_to_coeff make of the extended arrays.
 // ---------------------------------------------------------------------------------------------
-int hm_quotient_by_cosets_bn256_fr_dev(uint64_t program, const void* const* d_coeff_columns, const void* const* d_on_cosets, size_t n_columns,
-                                       const uint64_t* dynamic_constants, size_t n_dynamic, uint32_t log_n, const uint64_t omega[4],
-                                       const uint64_t* shifts, size_t count, size_t pieces, void* d_h, void* stream) try {
-  const char* who = "hm_quotient_by_cosets_bn256_fr_dev";
-  if (!d_h || !omega || !shifts || (n_columns && !d_coeff_columns) || (n_dynamic && !dynamic_constants))
-    return hm_fail(HM_ERR_BAD_ARG, std::string(who) + ": null argument");
-  if (log_n > 28 || log_n == 0) return hm_fail(HM_ERR_BAD_ARG, std::string(who) + ": log_n must be in 1 .. 28");
-  if (count == 0 || count > 16 || pieces == 0 || pieces > count)
-    return hm_fail(HM_ERR_BAD_ARG, std::string(who) + ": 1 <= pieces <= cosets <= 16");
-  if (n_columns == 0 || n_columns * count > 65535) return hm_fail(HM_ERR_BAD_ARG, std::string(who) + ": columns x cosets must be in 1 .. 65535");
-  // a column comes as coefficients (transformed here) or, when d_on_cosets[i] is set, as its values on the `count` cosets already
-  // (count x n words of 32 * value, what hm_coeff_to_cosets(..., columns_internal = 1) wrote: the fixed columns of a proving key)
-  std::vector<size_t> todo;
-  for (size_t i = 0; i < n_columns; ++i) {
-    if (d_on_cosets && d_on_cosets[i]) continue;
-    if (!d_coeff_columns[i]) return hm_fail(HM_ERR_BAD_ARG, std::string(who) + ": a column has neither coefficients nor coset values");
-    todo.push_back(i);
-  }
-  const uint64_t n = 1ull << log_n;
-  // host side: u_c = shift_c^n, the inverse shifts, V^-1 with 1 / (u_c - 1) on column c
-  std::vector<host::Fr4> u(count), shift_inv(count);
+// host side of the recombination: u_c = shift_c^n, V^-1 (Gauss-Jordan) with 1 / (u_c - 1) on column c -> rows of 4 * count words
+static int quotient_matrix(const char* who, const uint64_t* shifts, size_t count, uint32_t log_n, std::vector<std::vector<uint64_t>>* rows) {
+  std::vector<host::Fr4> u(count);
   for (size_t c = 0; c < count; ++c) {
     host::Fr4 x = host::fr_load(shifts + 4 * c);
     if (host::fr_is_zero(x)) return hm_fail(HM_ERR_BAD_ARG, std::string(who) + ": a coset shift is zero");
-    shift_inv[c] = host::fr_inv(x);
     for (uint32_t b = 0; b < log_n; ++b) x = host::fr_mul(x, x);
     u[c] = x;
     if (host::fr_eq(u[c], host::FR_ONE)) return hm_fail(HM_ERR_BAD_ARG, std::string(who) + ": a coset lies in the n-th roots (X^n - 1 vanishes on it)");
@@ -1623,7 +1604,7 @@ int hm_quotient_by_cosets_bn256_fr_dev(uint64_t program, const void* const* d_co
       if (host::fr_eq(u[b], u[c])) return hm_fail(HM_ERR_BAD_ARG, std::string(who) + ": two shifts name the same coset");
   }
   const host::Fr4 zero = {{0, 0, 0, 0}};
-  std::vector<std::vector<host::Fr4>> m(count, std::vector<host::Fr4>(2 * count, zero));      // [V | I] -> [I | V^-1], Gauss-Jordan
+  std::vector<std::vector<host::Fr4>> m(count, std::vector<host::Fr4>(2 * count, zero));      // [V | I] -> [I | V^-1]
   for (size_t a = 0; a < count; ++a) {
     host::Fr4 p = host::FR_ONE;
     for (size_t t = 0; t < count; ++t) { m[a][t] = p; p = host::fr_mul(p, u[a]); }
@@ -1642,59 +1623,152 @@ int hm_quotient_by_cosets_bn256_fr_dev(uint64_t program, const void* const* d_co
       for (size_t c2 = 0; c2 < 2 * count; ++c2) m[row][c2] = host::fr_sub(m[row][c2], host::fr_mul(f, m[col][c2]));
     }
   }
-  std::vector<host::Fr4> tinv(count);
-  for (size_t c = 0; c < count; ++c) tinv[c] = host::fr_inv(host::fr_sub(u[c], host::FR_ONE));
+  rows->assign(count, std::vector<uint64_t>(4 * count));
+  for (size_t c = 0; c < count; ++c) {
+    const host::Fr4 tinv = host::fr_inv(host::fr_sub(u[c], host::FR_ONE));
+    for (size_t t = 0; t < count; ++t) {
+      const host::Fr4 v = host::fr_mul(m[t][count + c], tinv);
+      std::memcpy(&(*rows)[t][4 * c], v.l, 32);
+    }
+  }
+  return HM_OK;
+}
+
+// steps 1 - 3 on this device: the columns onto `count` cosets, the numerator over count segments, the inverse transforms ->
+// d_partials (count x n).  ctx.mu held.
+static int quotient_partials(const char* who, DeviceCtx& ctx, uint64_t program, const void* const* d_coeff_columns, const void* const* d_on_cosets,
+                             size_t n_columns, const uint64_t* dynamic_constants, size_t n_dynamic, uint32_t log_n, const uint64_t omega[4],
+                             const uint64_t* shifts, size_t count, void* d_partials, hipStream_t st) {
+  std::vector<size_t> todo;
+  for (size_t i = 0; i < n_columns; ++i) {
+    if (d_on_cosets && d_on_cosets[i]) continue;
+    if (!d_coeff_columns || !d_coeff_columns[i]) return hm_fail(HM_ERR_BAD_ARG, std::string(who) + ": a column has neither coefficients nor coset values");
+    todo.push_back(i);
+  }
+  const uint64_t n = 1ull << log_n;
+  std::vector<host::Fr4> shift_inv(count);
+  for (size_t c = 0; c < count; ++c) {
+    const host::Fr4 x = host::fr_load(shifts + 4 * c);
+    if (host::fr_is_zero(x)) return hm_fail(HM_ERR_BAD_ARG, std::string(who) + ": a coset shift is zero");
+    shift_inv[c] = host::fr_inv(x);
+  }
+  const host::Fr4 zero = {{0, 0, 0, 0}};
   host::Fr4 nn = host::FR_ONE;                                               // n = 2^log_n in Montgomery form: 1 doubled log_n times
   for (uint32_t b = 0; b < log_n; ++b) nn = host::fr_sub(nn, host::fr_sub(zero, nn));
   const host::Fr4 n_inv = host::fr_inv(nn);
   const host::Fr4 om_inv = host::fr_inv(host::fr_load(omega));
-
-  DeviceCtx* ctx = ctx_for_current_device();
-  if (!ctx) return HM_ERR_NO_DEVICE;
-  std::lock_guard<std::mutex> lk(ctx->mu);
   GraphProgram* g = nullptr;
-  for (auto& gp : ctx->graphs)
+  for (auto& gp : ctx.graphs)
     if (gp->handle == program) g = gp.get();
   if (!g) return hm_fail(HM_ERR_NOT_FOUND, std::string(who) + ": unknown program handle");
   if (n_columns != g->n_columns) return hm_fail(HM_ERR_BAD_ARG, std::string(who) + ": the program was built for another number of columns");
-  hipStream_t st = (hipStream_t)stream;
-  AuxSlot* slot = aux_acquire(*ctx, st);
+  AuxSlot* slot = aux_acquire(ctx, st);
   if (!slot) return HM_ERR_HIP;
-  // work: [columns contiguous: C x n] [columns on cosets: C x count x n] [values: count x n]
+  // work: [the columns to transform, side by side: T x n] [those columns on the cosets: T x count x n]
   const size_t row = (size_t)n * 32;
   const size_t T = todo.size();
-  uint8_t* work = (uint8_t*)slot->work.ensure(row * (T + T * count + count) + 32);
+  uint8_t* work = (uint8_t*)slot->work.ensure(row * (T + T * count) + 32);
   if (!work) return hm_fail(HM_ERR_HIP, std::string(who) + ": workspace allocation failed");
   uint8_t* contig = work;
   uint8_t* on_cosets = contig + row * T;
-  uint8_t* values = on_cosets + row * T * count;
   int rc = HM_OK;
   if (T) {
     for (size_t j = 0; j < T; ++j)
       HM_HIP_CHECK(hipMemcpyAsync(contig + row * j, d_coeff_columns[todo[j]], row, hipMemcpyDeviceToDevice, st));
-    rc = ntt_cosets_run(*ctx, (const uint32_t*)contig, (uint32_t*)on_cosets, (uint32_t)T, omega, log_n, shifts, (uint32_t)count, true, st);
+    rc = ntt_cosets_run(ctx, (const uint32_t*)contig, (uint32_t*)on_cosets, (uint32_t)T, omega, log_n, shifts, (uint32_t)count, true, st);
     if (rc != HM_OK) return rc;
-    count_ntt(*ctx, log_n, T * count);
+    count_ntt(ctx, log_n, T * count);
   }
   std::vector<const void*> cols(n_columns);
   for (size_t i = 0; i < n_columns; ++i) cols[i] = d_on_cosets ? d_on_cosets[i] : nullptr;
   for (size_t j = 0; j < T; ++j) cols[todo[j]] = on_cosets + row * count * j;
-  HM_HIP_CHECK(hipMemsetAsync(values, 0, row * count, st));                    // PreviousValue: upstream starts h at zero
-  rc = graph_evaluate(*ctx, *g, cols.data(), n_columns, dynamic_constants, n_dynamic, log_n, (uint32_t)count, values, HM_GRAPH_COLUMNS_INTERNAL, st);
+  HM_HIP_CHECK(hipMemsetAsync(d_partials, 0, row * count, st));                // PreviousValue: upstream starts h at zero
+  rc = graph_evaluate(ctx, *g, cols.data(), n_columns, dynamic_constants, n_dynamic, log_n, (uint32_t)count, d_partials, HM_GRAPH_COLUMNS_INTERNAL, st);
   if (rc != HM_OK) return rc;
-  count_vector(*ctx, HM_STAT_GRAPH_EVALUATE, 1, (uint64_t)count << log_n);
-  rc = ntt_cosets_inverse_run(*ctx, (uint32_t*)values, (uint32_t)count, om_inv.l, log_n, n_inv.l, shift_inv[0].l, st);
+  count_vector(ctx, HM_STAT_GRAPH_EVALUATE, 1, (uint64_t)count << log_n);
+  rc = ntt_cosets_inverse_run(ctx, (uint32_t*)d_partials, (uint32_t)count, om_inv.l, log_n, n_inv.l, shift_inv[0].l, st);
   if (rc != HM_OK) return rc;
-  count_ntt(*ctx, log_n, count);
-  std::vector<const void*> parts(count);
-  for (size_t c = 0; c < count; ++c) parts[c] = values + row * c;
-  std::vector<uint64_t> coeffs(4 * count);
+  count_ntt(ctx, log_n, count);
+  return aux_release(ctx, slot, st);
+}
+
+static int quotient_check_args(const char* who, const void* out, const uint64_t* omega, const uint64_t* shifts, size_t n_columns,
+                               const void* const* d_coeff_columns, const void* const* d_on_cosets, size_t n_dynamic,
+                               const uint64_t* dynamic_constants, uint32_t log_n, size_t count) {
+  if (!out || !omega || !shifts || (n_columns && !d_coeff_columns && !d_on_cosets) || (n_dynamic && !dynamic_constants))
+    return hm_fail(HM_ERR_BAD_ARG, std::string(who) + ": null argument");
+  if (log_n > 28 || log_n == 0) return hm_fail(HM_ERR_BAD_ARG, std::string(who) + ": log_n must be in 1 .. 28");
+  if (count == 0 || count > 16) return hm_fail(HM_ERR_BAD_ARG, std::string(who) + ": 1 .. 16 cosets per call");
+  if (n_columns == 0 || n_columns * count > 65535) return hm_fail(HM_ERR_BAD_ARG, std::string(who) + ": columns x cosets must be in 1 .. 65535");
+  return HM_OK;
+}
+
+int hm_quotient_partials_bn256_fr_dev(uint64_t program, const void* const* d_coeff_columns, const void* const* d_on_cosets, size_t n_columns,
+                                      const uint64_t* dynamic_constants, size_t n_dynamic, uint32_t log_n, const uint64_t omega[4],
+                                      const uint64_t* shifts, size_t count, void* d_partials, void* stream) try {
+  const char* who = "hm_quotient_partials_bn256_fr_dev";
+  const int arc = quotient_check_args(who, d_partials, omega, shifts, n_columns, d_coeff_columns, d_on_cosets, n_dynamic, dynamic_constants, log_n, count);
+  if (arc != HM_OK) return arc;
+  DeviceCtx* ctx = ctx_for_current_device();
+  if (!ctx) return HM_ERR_NO_DEVICE;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  return quotient_partials(who, *ctx, program, d_coeff_columns, d_on_cosets, n_columns, dynamic_constants, n_dynamic, log_n, omega, shifts, count,
+                           d_partials, (hipStream_t)stream);
+} HM_API_CATCH("hm_quotient_partials_bn256_fr_dev")
+
+int hm_quotient_combine_bn256_fr_dev(const void* const* d_partials, const uint64_t* shifts, size_t count, uint32_t log_n, size_t pieces, void* d_h,
+                                     void* stream) try {
+  const char* who = "hm_quotient_combine_bn256_fr_dev";
+  if (!d_partials || !shifts || !d_h) return hm_fail(HM_ERR_BAD_ARG, std::string(who) + ": null argument");
+  if (log_n > 28 || log_n == 0) return hm_fail(HM_ERR_BAD_ARG, std::string(who) + ": log_n must be in 1 .. 28");
+  if (count == 0 || count > 64 || pieces == 0 || pieces > count) return hm_fail(HM_ERR_BAD_ARG, std::string(who) + ": 1 <= pieces <= cosets <= 64");
+  for (size_t c = 0; c < count; ++c)
+    if (!d_partials[c]) return hm_fail(HM_ERR_BAD_ARG, std::string(who) + ": null partial");
+  std::vector<std::vector<uint64_t>> rows;
+  const int mrc = quotient_matrix(who, shifts, count, log_n, &rows);
+  if (mrc != HM_OK) return mrc;
+  DeviceCtx* ctx = ctx_for_current_device();
+  if (!ctx) return HM_ERR_NO_DEVICE;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  const uint64_t n = 1ull << log_n;
   for (size_t t = 0; t < pieces; ++t) {
-    for (size_t c = 0; c < count; ++c) {
-      const host::Fr4 v = host::fr_mul(m[t][count + c], tinv[c]);
-      std::memcpy(&coeffs[4 * c], v.l, 32);
-    }
-    rc = fr_linear_combination_run(parts.data(), coeffs.data(), count, n, (uint32_t*)((uint8_t*)d_h + row * t), st);
+    const int rc = fr_linear_combination_run(d_partials, rows[t].data(), count, n, (uint32_t*)((uint8_t*)d_h + (size_t)n * 32 * t), (hipStream_t)stream);
+    if (rc != HM_OK) return rc;
+  }
+  count_vector(*ctx, HM_STAT_LINEAR_COMBINATION, pieces, (uint64_t)pieces * count * n);
+  return HM_OK;
+} HM_API_CATCH("hm_quotient_combine_bn256_fr_dev")
+
+int hm_quotient_by_cosets_bn256_fr_dev(uint64_t program, const void* const* d_coeff_columns, const void* const* d_on_cosets, size_t n_columns,
+                                       const uint64_t* dynamic_constants, size_t n_dynamic, uint32_t log_n, const uint64_t omega[4],
+                                       const uint64_t* shifts, size_t count, size_t pieces, void* d_h, void* stream) try {
+  const char* who = "hm_quotient_by_cosets_bn256_fr_dev";
+  const int arc = quotient_check_args(who, d_h, omega, shifts, n_columns, d_coeff_columns, d_on_cosets, n_dynamic, dynamic_constants, log_n, count);
+  if (arc != HM_OK) return arc;
+  if (pieces == 0 || pieces > count) return hm_fail(HM_ERR_BAD_ARG, std::string(who) + ": 1 <= pieces <= cosets <= 16");
+  std::vector<std::vector<uint64_t>> rows;
+  const int mrc = quotient_matrix(who, shifts, count, log_n, &rows);
+  if (mrc != HM_OK) return mrc;
+  DeviceCtx* ctx = ctx_for_current_device();
+  if (!ctx) return HM_ERR_NO_DEVICE;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  hipStream_t st = (hipStream_t)stream;
+  const uint64_t n = 1ull << log_n;
+  const size_t row = (size_t)n * 32;
+  // the partials live in the stream's NTT scratch slot? no: that is the transforms' ping-pong buffer.  They get the tail of a
+  // buffer of their own (AuxSlot::table is the scans' scratch: free between calls on this stream)
+  AuxSlot* slot = aux_acquire(*ctx, st);
+  if (!slot) return HM_ERR_HIP;
+  const size_t keep = (size_t)64 * 15 * 28 * 4;             // never shrink below the fixed-base table (see poly.hip)
+  uint8_t* parts_buf = (uint8_t*)slot->table.ensure(row * count > keep ? row * count : keep);
+  if (!parts_buf) return hm_fail(HM_ERR_HIP, std::string(who) + ": workspace allocation failed");
+  int rc = quotient_partials(who, *ctx, program, d_coeff_columns, d_on_cosets, n_columns, dynamic_constants, n_dynamic, log_n, omega, shifts, count,
+                             parts_buf, st);
+  if (rc != HM_OK) return rc;
+  std::vector<const void*> parts(count);
+  for (size_t c = 0; c < count; ++c) parts[c] = parts_buf + row * c;
+  for (size_t t = 0; t < pieces; ++t) {
+    rc = fr_linear_combination_run(parts.data(), rows[t].data(), count, n, (uint32_t*)((uint8_t*)d_h + row * t), st);
     if (rc != HM_OK) return rc;
   }
   count_vector(*ctx, HM_STAT_LINEAR_COMBINATION, pieces, (uint64_t)pieces * count * n);

@@ -333,44 +333,63 @@ class CompiledGraph:
                                                               seg.bit_length() - 1, segments, ctypes.c_void_p(values.data_ptr()),
                                                               1 if columns_internal else 0, ctypes.c_void_p(_stream_ptr(values))))
 
+    def _quotient_args(self, domain, coeff_columns, cosets, challenges, beta, gamma, theta, y, on_cosets, who):
+        cosets = list(range(domain.min_cosets())) if cosets is None else [int(c) for c in cosets]
+        if len(coeff_columns) != self.n_columns or len(challenges) != self.num_challenges:
+            raise ValueError(f"{who}: column / challenge count differs from the compiled program's")
+        if self.short_columns:
+            raise ValueError(f"{who}: the program must not read short columns (compile the undivided numerator)")
+        q = len(cosets)
+        pre = list(on_cosets) if on_cosets is not None else [None] * len(coeff_columns)
+        if len(pre) != len(coeff_columns):
+            raise ValueError(f"{who}: on_cosets must have one entry per column")
+        cols = [None if pre[i] is not None else c.contiguous() for i, c in enumerate(coeff_columns)]
+        for c in cols:
+            if c is not None and _tensor_rows(c, 4, "column") != domain.n:
+                raise ValueError(f"{who}: every column must hold n coefficients")
+        pre = [None if p is None else p.contiguous() for p in pre]
+        for p in pre:
+            if p is not None and _tensor_rows(p, 4, "on_cosets") != q * domain.n:
+                raise ValueError(f"{who}: a column on the cosets must hold len(cosets) * n values")
+        ref = next(t for t in cols + pre if t is not None)
+        ptrs = (ctypes.c_void_p * len(cols))(*[(c.data_ptr() if c is not None else None) for c in cols])
+        pre_ptrs = (ctypes.c_void_p * len(cols))(*[(p.data_ptr() if p is not None else None) for p in pre]) if on_cosets is not None else None
+        dyn = np.stack([fr_words(v) for v in list(challenges) + [beta, gamma, theta, y]])
+        shifts = np.stack([fr_words(domain.coset_shift(c)) for c in cosets])
+        return cosets, q, ref, (cols, pre), ptrs, pre_ptrs, dyn, shifts
+
     def quotient_by_cosets(self, domain, coeff_columns: Sequence, cosets=None, challenges: Sequence[int] = (), beta: int = 0, gamma: int = 0,
                            theta: int = 0, y: int = 0, on_cosets: Sequence = None):
         """h(X) in ONE call (``hm_quotient_by_cosets_bn256_fr_dev``): this program must be the UNDIVIDED numerator compiled with
         ``rot_scale=1`` (``circuits.evaluate_h_program(per_coset=True, divide=False)``); ``coeff_columns``: (n, 4) coefficient
         tensors, one per entry of the column table; ``cosets``: indices into the extended domain's cosets (default: the
-        ``domain.min_cosets()`` that determine the quotient of a satisfied circuit).  -> (len(cosets) * n, 4)... the first
+        ``domain.min_cosets()`` that determine the quotient of a satisfied circuit).  -> (len(cosets) * n, 4): the first
         ``len(cosets)`` pieces, i.e. all of h when the circuit is satisfied.  ``on_cosets``: per column None or its values on
         those cosets already, (len(cosets), n, 4) as ``domain.coeff_to_cosets(col, cosets, internal=True)`` returns them (the fixed
         columns of a proving key: transformed once); the coefficient entry of such a column may be None."""
         import torch
 
-        cosets = list(range(domain.min_cosets())) if cosets is None else [int(c) for c in cosets]
-        if len(coeff_columns) != self.n_columns or len(challenges) != self.num_challenges:
-            raise ValueError("quotient_by_cosets: column / challenge count differs from the compiled program's")
-        if self.short_columns:
-            raise ValueError("quotient_by_cosets: the program must not read short columns (compile the undivided numerator)")
-        q = len(cosets)
-        pre = list(on_cosets) if on_cosets is not None else [None] * len(coeff_columns)
-        if len(pre) != len(coeff_columns):
-            raise ValueError("quotient_by_cosets: on_cosets must have one entry per column")
-        cols = [None if pre[i] is not None else c.contiguous() for i, c in enumerate(coeff_columns)]
-        for c in cols:
-            if c is not None and _tensor_rows(c, 4, "column") != domain.n:
-                raise ValueError("quotient_by_cosets: every column must hold n coefficients")
-        pre = [None if p is None else p.contiguous() for p in pre]
-        for p in pre:
-            if p is not None and _tensor_rows(p, 4, "on_cosets") != q * domain.n:
-                raise ValueError("quotient_by_cosets: a column on the cosets must hold len(cosets) * n values")
-        ref = next(t for t in cols + pre if t is not None)
+        cosets, q, ref, keep, ptrs, pre_ptrs, dyn, shifts = self._quotient_args(domain, coeff_columns, cosets, challenges, beta, gamma, theta, y,
+                                                                                on_cosets, "quotient_by_cosets")
         out = torch.empty((q * domain.n, 4), dtype=ref.dtype, device=ref.device)
-        ptrs = (ctypes.c_void_p * len(cols))(*[(c.data_ptr() if c is not None else None) for c in cols])
-        pre_ptrs = (ctypes.c_void_p * len(cols))(*[(p.data_ptr() if p is not None else None) for p in pre])
-        dyn = np.stack([fr_words(v) for v in list(challenges) + [beta, gamma, theta, y]])
-        shifts = np.stack([fr_words(domain.coset_shift(c)) for c in cosets])
         _lib.check(_lib.load().hm_quotient_by_cosets_bn256_fr_dev(
-            ctypes.c_uint64(self.handle), ptrs, pre_ptrs if on_cosets is not None else None, len(cols), _ptr(dyn), dyn.shape[0], domain.k,
+            ctypes.c_uint64(self.handle), ptrs, pre_ptrs, len(coeff_columns), _ptr(dyn), dyn.shape[0], domain.k,
             _ptr(fr_words(domain.omega)), _ptr(shifts), q, q,
             ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(_stream_ptr(out))))
+        return out
+
+    def quotient_partials(self, domain, coeff_columns: Sequence, cosets, challenges: Sequence[int] = (), beta: int = 0, gamma: int = 0,
+                          theta: int = 0, y: int = 0, on_cosets: Sequence = None):
+        """The first half of ``quotient_by_cosets`` on THIS device's cosets (``hm_quotient_partials_bn256_fr_dev``): ->
+        (len(cosets), n, 4) partials.  ``quotient_combine`` turns the partials of all devices into h."""
+        import torch
+
+        cosets, q, ref, keep, ptrs, pre_ptrs, dyn, shifts = self._quotient_args(domain, coeff_columns, cosets, challenges, beta, gamma, theta, y,
+                                                                                on_cosets, "quotient_partials")
+        out = torch.empty((q, domain.n, 4), dtype=ref.dtype, device=ref.device)
+        _lib.check(_lib.load().hm_quotient_partials_bn256_fr_dev(
+            ctypes.c_uint64(self.handle), ptrs, pre_ptrs, len(coeff_columns), _ptr(dyn), dyn.shape[0], domain.k,
+            _ptr(fr_words(domain.omega)), _ptr(shifts), q, ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(_stream_ptr(out))))
         return out
 
     def destroy(self) -> None:
@@ -428,3 +447,21 @@ def lookup_expressions(inputs: Sequence[Expression], tables: Sequence[Expression
             (z(1) * (a + BETA) * (sp + GAMMA) - z(0) * table_value) * l_active,
             a_minus_s * l0,
             a_minus_s * (a - permuted_input(-1)) * l_active]
+
+
+def quotient_combine(domain, partials: Sequence, cosets: Sequence[int], pieces: int = None):
+    """``hm_quotient_combine_bn256_fr_dev``: the partials of ALL the cosets used (one (n, 4) tensor per coset, in the order of
+    ``cosets``, on this device) -> (pieces * n, 4) coefficients of h; the vanishing division rides on the matrix."""
+    import torch
+
+    cosets = [int(c) for c in cosets]
+    parts = [p.contiguous() for p in partials]
+    if len(parts) != len(cosets) or any(_tensor_rows(p, 4, "partial") != domain.n for p in parts):
+        raise ValueError("quotient_combine: one (n, 4) partial per coset")
+    pieces = len(cosets) if pieces is None else pieces
+    out = torch.empty((pieces * domain.n, 4), dtype=parts[0].dtype, device=parts[0].device)
+    ptrs = (ctypes.c_void_p * len(parts))(*[p.data_ptr() for p in parts])
+    shifts = np.stack([fr_words(domain.coset_shift(c)) for c in cosets])
+    _lib.check(_lib.load().hm_quotient_combine_bn256_fr_dev(ptrs, _ptr(shifts), len(parts), domain.k, pieces, ctypes.c_void_p(out.data_ptr()),
+                                                           ctypes.c_void_p(_stream_ptr(out))))
+    return out

@@ -372,6 +372,15 @@ int hm_graph_evaluate_dev(uint64_t handle, const void* const* d_columns, size_t 
 int hm_quotient_by_cosets_bn256_fr_dev(uint64_t program, const void* const* d_coeff_columns, const void* const* d_on_cosets, size_t n_columns,
                                        const uint64_t* dynamic_constants, size_t n_dynamic, uint32_t log_n, const uint64_t omega[4],
                                        const uint64_t* shifts, size_t count, size_t pieces, void* d_h, void* stream);
+/* The same in two steps, for a proof split over several GPUs: every device runs hm_quotient_partials on ITS cosets (same
+ * arguments; d_partials: count x 2^log_n words, the partial of shifts[c] at c * 2^log_n), the partials travel to one device
+ * (2^log_n x 32 B per coset), and hm_quotient_combine turns ALL of them -- d_partials: host array of `count` device pointers in the
+ * order of `shifts`, count <= 64 -- into the pieces of h.  hm_quotient_by_cosets is the two on one device. */
+int hm_quotient_partials_bn256_fr_dev(uint64_t program, const void* const* d_coeff_columns, const void* const* d_on_cosets, size_t n_columns,
+                                      const uint64_t* dynamic_constants, size_t n_dynamic, uint32_t log_n, const uint64_t omega[4],
+                                      const uint64_t* shifts, size_t count, void* d_partials, void* stream);
+int hm_quotient_combine_bn256_fr_dev(const void* const* d_partials, const uint64_t* shifts, size_t count, uint32_t log_n, size_t pieces, void* d_h,
+                                     void* stream);
 int hm_graph_destroy(uint64_t handle);
 /* The same evaluation with options.  HM_GRAPH_COLUMNS_INTERNAL: every column of the table (short ones included) holds
  * 32 * value mod r instead of value -- the library's internal Montgomery radix is 2^261, so such words need no conversion

@@ -80,6 +80,9 @@ def test_device_pointer_entry_points_without_a_device():
     assert lib.hm_graph_evaluate_segments_dev(ctypes.c_uint64(1), None, 0, None, 0, 3, 2, None, 0, None) == -1
     one_col = (ctypes.c_void_p * 1)(0x1000)
     assert lib.hm_quotient_by_cosets_bn256_fr_dev(ctypes.c_uint64(1), one_col, None, 1, zp, 1, 3, zp, zp, 1, 1, None, None) == -1       # no output
+    assert lib.hm_quotient_partials_bn256_fr_dev(ctypes.c_uint64(1), one_col, None, 1, zp, 1, 3, zp, zp, 17, ctypes.c_void_p(0x9000), None) == -1   # > 16 cosets
+    assert lib.hm_quotient_combine_bn256_fr_dev(one_col, zp, 1, 3, 2, ctypes.c_void_p(0x9000), None) == -1                              # pieces > cosets
+    assert lib.hm_quotient_combine_bn256_fr_dev(one_col, zp, 1, 3, 1, ctypes.c_void_p(0x9000), None) == -1                              # a zero shift
     assert lib.hm_quotient_by_cosets_bn256_fr_dev(ctypes.c_uint64(1), one_col, None, 1, zp, 1, 3, zp, zp, 2, 3, ctypes.c_void_p(0x9000), None) == -1   # pieces > cosets
     assert lib.hm_quotient_by_cosets_bn256_fr_dev(ctypes.c_uint64(1), one_col, None, 1, zp, 1, 3, zp, zp, 1, 1, ctypes.c_void_p(0x9000), None) == -1   # a zero shift
     assert lib.hm_coeff_to_coset_bn256_fr_dev(ctypes.c_void_p(0x1000), ctypes.c_void_p(0x100000), 1, zp, 29, zp, 0, None) == -1      # log_n > 28
@@ -107,6 +110,8 @@ def test_device_pointer_entry_points_without_a_device():
     twop = two.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64))
     one_col = (ctypes.c_void_p * 1)(0x1000)
     assert lib.hm_quotient_by_cosets_bn256_fr_dev(ctypes.c_uint64(1), one_col, None, 1, zp, 1, 3, twop, twop, 1, 1, ctypes.c_void_p(0x9000), None) == -2
+    assert lib.hm_quotient_partials_bn256_fr_dev(ctypes.c_uint64(1), one_col, None, 1, zp, 1, 3, twop, twop, 1, ctypes.c_void_p(0x9000), None) == -2
+    assert lib.hm_quotient_combine_bn256_fr_dev(one_col, twop, 1, 3, 1, ctypes.c_void_p(0x9000), None) == -2
     assert lib.hm_fr_batch_invert_dev(fake, 8, None) == -2
     assert lib.hm_lookup_permute_bn256_fr_dev(fake, fake, 8, fake, fake, None) == -2
     assert b"no CPU fallback" in lib.hm_last_error()

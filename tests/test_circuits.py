@@ -320,6 +320,12 @@ def test_the_one_call_quotient_equals_the_whole_array_route(pyref, name):
         pre = [kept[i] for i in range(nf)] + [None] * (n_cols - nf)
         got2 = prog_num.quotient_by_cosets(dom, [None] * nf + columns[nf:], cosets=sub, beta=beta, gamma=gamma, theta=theta, y=y, on_cosets=pre)
         assert bool((got2 == want).all()), name
+        # ... and in two steps, as two devices would: each its cosets (hm_quotient_partials), then all partials combined on one
+        five = list(range(min(5, e)))
+        pa = prog_num.quotient_partials(dom, columns, five[:2], beta=beta, gamma=gamma, theta=theta, y=y)
+        pb = prog_num.quotient_partials(dom, columns, five[2:], beta=beta, gamma=gamma, theta=theta, y=y)
+        both = ev.quotient_combine(dom, [pa[i] for i in range(pa.shape[0])] + [pb[i] for i in range(pb.shape[0])], five)
+        assert bool((both == prog_num.quotient_by_cosets(dom, columns, cosets=five, beta=beta, gamma=gamma, theta=theta, y=y)).all()), name
         assert coeffs[lay.x_coset][1].any() and not coeffs[lay.x_coset][2:].any()          # the inputs are untouched
         with pytest.raises(Exception):
             prog_num.quotient_by_cosets(dom, columns[:-1], cosets=sub)
