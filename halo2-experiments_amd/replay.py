@@ -84,12 +84,8 @@ SHAPES = _shapes()
 
 
 def _rand_fr(n, seed, device):
-    import torch
-    g = torch.Generator(device=device)
-    g.manual_seed(seed)
-    x = torch.randint(-(2 ** 63), 2 ** 63 - 1, (n, 4), dtype=torch.int64, device=device, generator=g)
-    x[:, 3] &= 0x0FFFFFFFFFFFFFFF
-    return x
+    from halo2_experiments_amd.arithmetic import random_fr
+    return random_fr(n, seed, device)                 # uniform over the whole of [0, r)
 
 
 def _sparse_column(n, used_rows, seed, device):

@@ -16,11 +16,11 @@ from . import _lib  # noqa: F401
 from .arithmetic import (bases_info, batch_invert, best_fft, best_multiexp, best_multiexp_batch, best_multiexp_submit,  # noqa: F401
                          best_multiexp_wait, eval_polynomial, g1_fixed_base_mul, grand_product, grand_product_batch, kate_division,
                          kate_division_batch,
-                         linear_combination, msm_stats, permute_expression_pair, permute_expression_pairs, register_bases,
+                         linear_combination, msm_stats, permute_expression_pair, permute_expression_pairs, random_fr, register_bases,
                          release_bases)
 from .domain import EvaluationDomain  # noqa: F401
 
 __all__ = ["eval_polynomial", "best_multiexp", "best_multiexp_batch", "best_multiexp_submit", "best_multiexp_wait", "best_fft",
            "register_bases", "release_bases", "bases_info", "g1_fixed_base_mul", "msm_stats", "kate_division", "kate_division_batch", "grand_product",
            "grand_product_batch", "batch_invert",
-           "linear_combination", "permute_expression_pair", "permute_expression_pairs", "EvaluationDomain"]
+           "linear_combination", "random_fr", "permute_expression_pair", "permute_expression_pairs", "EvaluationDomain"]

@@ -19,9 +19,20 @@ def _free_port():
         return s.getsockname()[1]
 
 
+LINE_MAX_BYTES = 4096
+
+
+class Record(dict):
+    """The FULL record bench.py wrote to --extras-out, with the compact stdout line (what the driver parses) as `.line`."""
+    line: dict
+
+
 def _bench(world, log_points, replay="none", extra=(), extras=False):
+    import tempfile
+    fd, extras_out = tempfile.mkstemp(prefix="hm_bench_extras_", suffix=".json", dir="/tmp")
+    os.close(fd)
     args = ["--gpus", str(world), "--steps", "2", "--warmup", "1", "--log-points", str(log_points), "--no-cpu-baseline", "--no-ntt",
-            "--replay", replay, "--no-2-26"] + ([] if extras else ["--no-extras"]) + list(extra)
+            "--replay", replay, "--no-2-26", "--extras-out", extras_out] + ([] if extras else ["--no-extras"]) + list(extra)
     if "--live-pmc" in args:
         args.remove("--live-pmc")
     else:
@@ -36,7 +47,21 @@ def _bench(world, log_points, replay="none", extra=(), extras=False):
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]                     # rank 0 prints ONE JSON line, the other ranks nothing
-    return json.loads(lines[0])
+    assert len(lines[0]) < LINE_MAX_BYTES, len(lines[0])           # ... short enough for the driver (round 4's 21 KB line: parsed null)
+    assert len(out.stdout) < 2 * LINE_MAX_BYTES, out.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert list(line)[:8] == ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better"]
+    assert set(line["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms"}
+    assert all(not isinstance(v, (dict, list)) for v in line["summary"].values()) and len(line["summary"]) <= 10
+    with open(extras_out) as f:
+        full = Record(json.load(f))
+    os.unlink(extras_out)
+    for k in ("metric", "unit", "n_gpus", "steps", "warmup", "higher_is_better", "scaling", "vs_baseline", "data", "known_answer_ok",
+              "ranks_in_collective"):
+        assert line[k] == full[k], k                               # the line is a projection of the record
+    assert abs(line["value"] - full["value"]) < 1e-8 * full["value"]
+    full.line = line
+    return full
 
 
 @pytest.mark.gpu
@@ -73,7 +98,14 @@ def test_two_ranks_replay_the_k18_proof_and_rank0_replays_it_in_one_process():
     two = _bench(2, 18, replay="merkle_sum_tree_k18", extra=("--no-strong",))
     (rep,) = two["create_proof_replay"]
     assert rep["k"] == 18 and rep["n_gpus"] == 2 and rep["multi_gpu_split"].startswith("whole commitments")
-    assert "5 of 8 cosets dealt over the ranks" in rep["multi_gpu_split"] and rep["extended_domain"].startswith("by cosets")
+    # both coset routes at N > 1: device_resident_s on all 8 cosets (the same h as N = 1's whole-array steps), the 5 that determine h beside it
+    assert "8 of 8 cosets dealt over the ranks" in rep["multi_gpu_split"] and rep["extended_domain"].startswith("by cosets")
+    routes = rep["extended_domain_routes_ms"]
+    assert routes["by_all_cosets"]["total"] == pytest.approx(rep["device_resident_s"]["total"] * 1e3)
+    assert routes["by_the_cosets_that_determine_h"]["extended_domain"].startswith("by cosets, 5 of 8")
+    assert routes["by_all_cosets"]["evaluate_h"] > routes["by_the_cosets_that_determine_h"]["evaluate_h"] > 0
+    assert two.line["summary"]["k18_replay_ms"] == pytest.approx(rep["device_resident_s"]["total"] * 1e3, rel=1e-3)
+    assert two.line["summary"]["one_process_k18_replay_ms"] > 0
     assert rep["verified"]["commitments_checked"] >= 3 * (rep["calls"]["msm_sparse"] + rep["calls"]["msm_dense"])
     op = two["one_process"]["create_proof_replay"]
     assert op["k"] == 18 and op["multi_gpu_split"].startswith("one process")
@@ -123,6 +155,8 @@ def test_pmc_counters_are_measured_in_the_run():
         assert "NOT measured in this run" in rf["traffic_note"]
         return
     assert rf["traffic_note"].startswith("MEASURED IN THIS RUN"), rf["traffic_note"]
+    assert line.line["roofline"]["traffic_src"].startswith("rocprofv3 --pmc in this run") and line.line["roofline"]["traffic"] == pytest.approx(rf["traffic"])
+    assert line.line["roofline"]["valu_issue_frac"] == pytest.approx(rf["valu_issue"]["frac"], rel=1e-3)
     assert rf["traffic"] > 96 * (1 << 20)                       # at least the algorithmic bytes of 2^20 points
     assert rf["valu_issue"]["stale"] is False and rf["valu_issue"]["sq_insts_valu_per_launch"] > 0
     assert 1000 < rf["valu_issue"]["wave_instr_per_64_units"] < 4000        # ~2 200 wave-instructions per 64 mixed additions

@@ -69,12 +69,8 @@ def test_a_throw_on_another_thread_stays_on_that_thread(fi):
 # ---- with a device: faults under the device lock, in helper-thread creation and inside helper threads ---------------------
 
 def _rand_fr(n, seed):
-    import torch
-    g = torch.Generator(device="cuda")
-    g.manual_seed(seed)
-    x = torch.randint(-(2 ** 63), 2 ** 63 - 1, (n, 4), dtype=torch.int64, device="cuda", generator=g)
-    x[:, 3] &= 0x0FFFFFFFFFFFFFFF
-    return x
+    from halo2_experiments_amd.arithmetic import random_fr
+    return random_fr(n, seed, "cuda")                 # uniform over the whole of [0, r)
 
 
 def _fi_bases(fi, n, seed, cref):

@@ -172,10 +172,7 @@ def test_evaluate_h_coset_by_coset_gives_the_same_quotient(pyref, name):
     g_all, lay = circuits.evaluate_h_program(cs, k, ek, delta)
     g_one, lay1 = circuits.evaluate_h_program(cs, k, ek, delta, per_coset=True)
     n_cols = lay.num_fixed_entries + cs.num_advice + cs.num_instance
-    gen = torch.Generator(device="cuda")
-    gen.manual_seed(77 + len(name))
-    coeffs = torch.randint(-(2 ** 63), 2 ** 63 - 1, (n_cols, n, 4), dtype=torch.int64, device="cuda", generator=gen)
-    coeffs[:, :, 3] &= 0x0FFFFFFFFFFFFFFF
+    coeffs = h.random_fr(n_cols * n, 77 + len(name), "cuda", shape=(n_cols, n, 4))          # uniform over the whole of [0, r)
     x_poly = [0, 1] + [0] * (n - 2)                                         # the identity polynomial: its evaluations are the points
     coeffs[lay.x_coset] = torch.from_numpy(pyref.fr_array(x_poly).view(np.int64)).cuda()
     rng = random.Random(5)
@@ -225,10 +222,7 @@ def test_evaluate_h_on_several_cosets_in_one_launch(pyref, name):
     g_num, lay_n = circuits.evaluate_h_program(cs, k, ek, delta, per_coset=True, divide=False)
     g_one, lay1 = circuits.evaluate_h_program(cs, k, ek, delta, per_coset=True)
     n_cols = lay.num_fixed_entries + cs.num_advice + cs.num_instance
-    gen = torch.Generator(device="cuda")
-    gen.manual_seed(99 + len(name))
-    coeffs = torch.randint(-(2 ** 63), 2 ** 63 - 1, (n_cols, n, 4), dtype=torch.int64, device="cuda", generator=gen)
-    coeffs[:, :, 3] &= 0x0FFFFFFFFFFFFFFF
+    coeffs = h.random_fr(n_cols * n, 99 + len(name), "cuda", shape=(n_cols, n, 4))          # uniform over the whole of [0, r)
     coeffs[lay.x_coset] = torch.from_numpy(pyref.fr_array([0, 1] + [0] * (n - 2)).view(np.int64)).cuda()
     rng = random.Random(6)
     beta, gamma, theta, y = (rng.randrange(R) for _ in range(4))
@@ -284,10 +278,7 @@ def test_the_one_call_quotient_equals_the_whole_array_route(pyref, name):
     g_all, lay = circuits.evaluate_h_program(cs, k, ek, delta)
     g_num, lay_n = circuits.evaluate_h_program(cs, k, ek, delta, per_coset=True, divide=False)
     n_cols = lay.num_fixed_entries + cs.num_advice + cs.num_instance
-    gen = torch.Generator(device="cuda")
-    gen.manual_seed(123 + len(name))
-    coeffs = torch.randint(-(2 ** 63), 2 ** 63 - 1, (n_cols, n, 4), dtype=torch.int64, device="cuda", generator=gen)
-    coeffs[:, :, 3] &= 0x0FFFFFFFFFFFFFFF
+    coeffs = h.random_fr(n_cols * n, 123 + len(name), "cuda", shape=(n_cols, n, 4))          # uniform over the whole of [0, r)
     coeffs[lay.x_coset] = torch.from_numpy(pyref.fr_array([0, 1] + [0] * (n - 2)).view(np.int64)).cuda()
     rng = random.Random(8)
     beta, gamma, theta, y = (rng.randrange(R) for _ in range(4))

@@ -164,12 +164,10 @@ def test_device_graph_at_prover_size_and_argument_checks(pyref):
     g.add_custom_gates(polys)
     k, ek = 16, 19
     isize, rot_scale = 1 << ek, 1 << (ek - k)
-    gen = torch.Generator(device="cuda")
-    gen.manual_seed(5)
+    from halo2_experiments_amd.arithmetic import random_fr
+    seeds = iter(range(500, 10 ** 6))
     def rand_col():
-        x = torch.randint(-(2 ** 63), 2 ** 63 - 1, (isize, 4), dtype=torch.int64, device="cuda", generator=gen)
-        x[:, 3] &= 0x0FFFFFFFFFFFFFFF
-        return x
+        return random_fr(isize, next(seeds), "cuda")           # uniform over the whole of [0, r)
     cols = [rand_col() for _ in range(nf + na + ni)]
     values = rand_col()
     prev_h = values.cpu().numpy().view(np.uint64).copy()

@@ -14,12 +14,8 @@ pytestmark = pytest.mark.gpu
 
 
 def rand_fr_gpu(n, seed):
-    import torch
-    g = torch.Generator(device="cuda")
-    g.manual_seed(seed)
-    x = torch.randint(-(2 ** 63), 2 ** 63 - 1, (n, 4), dtype=torch.int64, device="cuda", generator=g)
-    x[:, 3] &= 0x0FFFFFFFFFFFFFFF
-    return x
+    from halo2_experiments_amd.arithmetic import random_fr
+    return random_fr(n, seed, "cuda")                 # uniform over the whole of [0, r)
 
 
 def test_golden_vectors(golden):

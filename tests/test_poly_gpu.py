@@ -14,12 +14,8 @@ pytestmark = pytest.mark.gpu
 
 
 def rand_fr_gpu(n, seed):
-    import torch
-    g = torch.Generator(device="cuda")
-    g.manual_seed(seed)
-    x = torch.randint(-(2 ** 63), 2 ** 63 - 1, (n, 4), dtype=torch.int64, device="cuda", generator=g)
-    x[:, 3] &= 0x0FFFFFFFFFFFFFFF
-    return x
+    from halo2_experiments_amd.arithmetic import random_fr
+    return random_fr(n, seed, "cuda")                 # uniform over the whole of [0, r)
 
 
 @pytest.mark.parametrize("n", [1, 2, 5, 255, 256, 257, 4095, 4096, 4097, (1 << 14) + 3, 1 << 16, (1 << 18) - 1, 1 << 18])
@@ -106,3 +102,20 @@ def test_benchmark_input_kernels(cref, pyref):
     _lib.check(lib.hm_fr_random_dev(ctypes.c_void_p(x2.data_ptr()), 64, 8, None))
     torch.cuda.synchronize()
     assert not torch.equal(x1, x2)
+
+
+def test_random_inputs_cover_the_whole_field():
+    """The helper every device-side test draws its inputs from (hm_fr_random_dev through arithmetic.random_fr): every word below r,
+    and the top sixth of the field -- [2^252, r), which masked 64-bit words never reach -- populated in proportion."""
+    import halo2_experiments_amd as h
+    from halo2_experiments_amd.domain import FR_MODULUS
+    n = 1 << 16
+    x = h.random_fr(n, 2024, "cuda").cpu().numpy().view(np.uint64)
+    vals = [int(w[0]) | int(w[1]) << 64 | int(w[2]) << 128 | int(w[3]) << 192 for w in x]
+    assert max(vals) < FR_MODULUS and len(set(vals)) == n
+    above = sum(v >> 252 != 0 for v in vals) / n
+    expect = 1 - (1 << 252) / FR_MODULUS                      # 0.669: two thirds of the field lie above 2^252
+    assert abs(above - expect) < 0.01, (above, expect)
+    assert sum(v > FR_MODULUS - (FR_MODULUS >> 4) for v in vals) > n / 32      # the last sixteenth, where r - x is small
+    y = h.random_fr(6 * 1024, 2024, "cuda", shape=(6, 1024, 4))
+    assert y.shape == (6, 1024, 4) and np.array_equal(y.reshape(-1, 4)[:n].cpu().numpy().view(np.uint64), x[:6 * 1024])

@@ -25,12 +25,8 @@ def from_gpu(pyref, t):
 
 
 def rand_fr_gpu(n, seed):
-    import torch
-    g = torch.Generator(device="cuda")
-    g.manual_seed(seed)
-    x = torch.randint(-(2 ** 63), 2 ** 63 - 1, (n, 4), dtype=torch.int64, device="cuda", generator=g)
-    x[:, 3] &= 0x0FFFFFFFFFFFFFFF
-    return x
+    from halo2_experiments_amd.arithmetic import random_fr
+    return random_fr(n, seed, "cuda")                 # uniform over the whole of [0, r)
 
 
 SIZES = [1, 2, 3, 4, 5, 255, 256, 257, 1023, 1024, 1025, 4099, (1 << 14) - 1, 1 << 16, (1 << 16) + 1, (1 << 18) + 7]

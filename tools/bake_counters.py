@@ -58,12 +58,15 @@ def main():
             sq[name] = ast.literal_eval("{" + d.strip())
     traffic = json.load(open(os.path.join(e, "pmc_traffic.json")))
     under = json.load(open(os.path.join(e, "bench_under_rocprof.json")))
+    under_full = under                      # round 5 on: the stdout line is compact, the full record sits beside it
+    if os.path.exists(os.path.join(e, "bench_under_rocprof_extras.json")):
+        under_full = json.load(open(os.path.join(e, "bench_under_rocprof_extras.json")))
     ntt_name = next(k for k in sq if k.startswith("hm::ntt_pass_kernel<11"))
     ntt_traffic = next(v for k, v in traffic.items() if k.startswith("hm::ntt_pass_kernel<11"))
     prof = os.path.join(ROOT, "profiles")
     copies = {"kernel_stats.csv": f"{args.tag}_bench_kernel_stats.csv", "bench_under_rocprof.json": f"{args.tag}_bench_under_rocprof.json",
               "bench.json": f"{args.tag}_bench.json", "pmc_traffic.json": f"{args.tag}_pmc_traffic.json",
-              "sq_counters.txt": f"{args.tag}_sq_counters.txt"}
+              "sq_counters.txt": f"{args.tag}_sq_counters.txt", "bench_extras.json": f"{args.tag}_bench_extras.json"}
     for src, dst in copies.items():
         if os.path.exists(os.path.join(e, src)):
             shutil.copyfile(os.path.join(e, src), os.path.join(prof, dst))
@@ -74,7 +77,7 @@ def main():
                          "k3_calls": rows[evidence.K3][0], "k3_average_ms": rows[evidence.K3][1] / 1e6,
                          "kernel_ms_of_the_line_under_the_profiler": under["roofline"]["kernel_ms"]},
         "k3": {"kernel": evidence.K3, "sq_insts_valu_per_launch": sq[evidence.K3]["SQ_INSTS_VALU"],
-               "pairs_per_launch": under["msm_phase_ms"]["pairs"], "grbm_gui_active": sq[evidence.K3].get("GRBM_GUI_ACTIVE"),
+               "pairs_per_launch": under_full["msm_phase_ms"]["pairs"], "grbm_gui_active": sq[evidence.K3].get("GRBM_GUI_ACTIVE"),
                "from": f"profiles/{copies['sq_counters.txt']}", "sources": evidence.SOURCES["k3"], "sources_sha256": now["k3_sources_sha256"]},
         "ntt": {"kernel": ntt_name, "sq_insts_valu_per_launch": sq[ntt_name]["SQ_INSTS_VALU"], "elements_per_launch": args.ntt_elements,
                 "from": f"profiles/{copies['sq_counters.txt']}", "sources": evidence.SOURCES["ntt"], "sources_sha256": now["ntt_sources_sha256"]},

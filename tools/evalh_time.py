@@ -15,11 +15,10 @@ ek = k + 3
 g, lay = circuits.evaluate_h_program(cs, k, ek, pow(7, 1 << 28, FR_MODULUS))
 prog = g.compile(lay.num_fixed_entries, cs.num_advice, cs.num_instance, rot_scale=1 << (ek - k), short_columns=lay.short_columns)
 n = 1 << ek
-gen = torch.Generator(device="cuda"); gen.manual_seed(1)
+from halo2_experiments_amd.arithmetic import random_fr
+_seeds = iter(range(1, 10 ** 6))
 def rand_col(rows):
-    x = torch.randint(-(2 ** 63), 2 ** 63 - 1, (rows, 4), dtype=torch.int64, device="cuda", generator=gen)
-    x[:, 3] &= 0x0FFFFFFFFFFFFFFF
-    return x
+    return random_fr(rows, next(_seeds), "cuda")
 ncols = lay.num_fixed_entries + cs.num_advice + cs.num_instance
 cols = [rand_col(1 << lay.short_columns[i]) if i in lay.short_columns else rand_col(n) for i in range(ncols)]
 values = rand_col(n)

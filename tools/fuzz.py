@@ -21,10 +21,8 @@ if mode == "single":
     cpu_ref.build()
     lib = _lib.load()
     def rand_fr(n, seed):
-        g = torch.Generator(device="cuda"); g.manual_seed(seed)
-        x = torch.randint(-(2**63), 2**63 - 1, (n, 4), dtype=torch.int64, device="cuda", generator=g)
-        x[:, 3] &= 0x0FFFFFFFFFFFFFFF
-        return x
+        from halo2_experiments_amd.arithmetic import random_fr
+        return random_fr(n, seed, "cuda")                 # uniform over the whole of [0, r)
     rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
     NMAX = 1_300_000
     pool = h.g1_fixed_base_mul(rand_fr(NMAX, 1), cpu_ref.g1_generator())
@@ -67,10 +65,8 @@ elif mode == "scans":
     from halo2_experiments_amd.domain import fr_words
     from oracle import bn256_ref as o, poly_ref as pr
     def rand_fr(n, seed):
-        g = torch.Generator(device="cuda"); g.manual_seed(seed)
-        x = torch.randint(-(2**63), 2**63 - 1, (n, 4), dtype=torch.int64, device="cuda", generator=g)
-        x[:, 3] &= 0x0FFFFFFFFFFFFFFF
-        return x
+        from halo2_experiments_amd.arithmetic import random_fr
+        return random_fr(n, seed, "cuda")                 # uniform over the whole of [0, r)
     vals = lambda t: o.fr_from_array(t.cpu().numpy().view(np.uint64))
     rng = random.Random(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
     bad, t0 = 0, time.time()
@@ -122,10 +118,8 @@ elif mode == "cosets":
     import numpy as np, torch
     from halo2_experiments_amd.domain import EvaluationDomain
     def rand_fr(n, seed):
-        g = torch.Generator(device="cuda"); g.manual_seed(seed)
-        x = torch.randint(-(2**63), 2**63 - 1, (n, 4), dtype=torch.int64, device="cuda", generator=g)
-        x[:, 3] &= 0x0FFFFFFFFFFFFFFF
-        return x
+        from halo2_experiments_amd.arithmetic import random_fr
+        return random_fr(n, seed, "cuda")                 # uniform over the whole of [0, r)
     rng = random.Random(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
     bad, t0 = 0, time.time()
     for case in range(int(sys.argv[2]) if len(sys.argv) > 2 else 40):
@@ -212,10 +206,8 @@ else:
     from oracle import cpu_ref
     cpu_ref.build()
     def rand_fr(n, seed):
-        g = torch.Generator(device="cuda"); g.manual_seed(seed)
-        x = torch.randint(-(2**63), 2**63 - 1, (n, 4), dtype=torch.int64, device="cuda", generator=g)
-        x[:, 3] &= 0x0FFFFFFFFFFFFFFF
-        return x
+        from halo2_experiments_amd.arithmetic import random_fr
+        return random_fr(n, seed, "cuda")                 # uniform over the whole of [0, r)
     rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
     dev = torch.device("cuda", 0)
     bad = 0

@@ -8,10 +8,8 @@ from halo2_experiments_amd import _lib
 from halo2_experiments_amd.arithmetic import G1_GENERATOR
 
 def rand_fr(n, seed):
-    g = torch.Generator(device="cuda"); g.manual_seed(seed)
-    x = torch.randint(-(2**63), 2**63 - 1, (n, 4), dtype=torch.int64, device="cuda", generator=g)
-    x[:, 3] &= 0x0FFFFFFFFFFFFFFF
-    return x
+    from halo2_experiments_amd.arithmetic import random_fr
+    return random_fr(n, seed, "cuda")                 # uniform over the whole of [0, r)
 
 _lib.load().hm_msm_set_phase_timing(1)      # per-phase events also for the five-launch plan
 sizes = [int(a) for a in sys.argv[1].split(",")] if len(sys.argv) > 1 else [12, 14, 16, 18, 20, 22, 24]
