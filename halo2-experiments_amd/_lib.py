@@ -97,6 +97,8 @@ _SIGNATURES = {
     "hm_set_fixed_base_threshold": (ctypes.c_int, [ctypes.c_uint32]),
     "hm_set_msm_devices": (ctypes.c_int, [ctypes.POINTER(ctypes.c_int), ctypes.c_int]),
     "hm_ntt_bn256_fr": (ctypes.c_int, [_u64p, _u64p, ctypes.c_uint32]),
+    "hm_coeff_to_extended_bn256_fr": (ctypes.c_int, [_u64p, _u64p, _u64p, ctypes.c_uint32, ctypes.c_uint32, _u64p]),
+    "hm_extended_to_coeff_bn256_fr": (ctypes.c_int, [_u64p, ctypes.c_size_t, _u64p, ctypes.c_uint32, _u64p, _u64p]),
     "hm_ntt_bn256_fr_dev": (ctypes.c_int, [_vp, _u64p, ctypes.c_uint32, _vp]),
     "hm_ntt_batch_bn256_fr_dev": (ctypes.c_int, [_vp, ctypes.c_size_t, _u64p, ctypes.c_uint32, _u64p, _u64p, _vp]),
     "hm_ifft_bn256_fr_dev": (ctypes.c_int, [_vp, _u64p, ctypes.c_uint32, _u64p, _vp]),

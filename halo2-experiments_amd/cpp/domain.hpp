@@ -96,6 +96,29 @@ class EvaluationDomain {
     arithmetic::check(hm_coeff_to_extended_bn256_fr_dev(a.d, ext.d, a.batch, extended_omega.l, k, extended_k, coset[0].l, stream),
                       "coeff_to_extended");
   }
+  // ... on HOST vectors, upstream's own signature (Polynomial<Coeff> -> Polynomial<ExtendedLagrangeCoeff>): what the patched
+  // EvaluationDomain::coeff_to_extended of the drop-in prover calls.  n coefficients cross PCIe upwards, never the zero padding.
+  std::vector<Fr> coeff_to_extended(const std::vector<Fr>& a) const {
+    if (a.size() != n) throw std::invalid_argument("coeff_to_extended: a.len() != n");
+    std::vector<Fr> ext(extended_len());
+    const Fr coset[3] = {Fr::one(), g_coset, g_coset.square()};
+    arithmetic::check(hm_coeff_to_extended_bn256_fr(reinterpret_cast<const uint64_t*>(a.data()), reinterpret_cast<uint64_t*>(ext.data()),
+                                                    extended_omega.l, k, extended_k, coset[0].l),
+                      "coeff_to_extended");
+    return ext;
+  }
+  // extended_to_coeff on a HOST vector: consumes the evaluations, returns the n * (j - 1) coefficients upstream keeps (only those
+  // come back over PCIe)
+  std::vector<Fr> extended_to_coeff(std::vector<Fr> a) const {
+    if (a.size() != extended_len()) throw std::invalid_argument("extended_to_coeff: a.len() != extended_len()");
+    const Fr c3[3] = {Fr::one(), g_coset_inv, g_coset_inv.square()};
+    const size_t keep = n * quotient_poly_degree;
+    arithmetic::check(hm_extended_to_coeff_bn256_fr(reinterpret_cast<uint64_t*>(a.data()), keep, extended_omega_inv.l, extended_k,
+                                                    extended_ifft_divisor.l, c3[0].l),
+                      "extended_to_coeff");
+    a.resize(keep);
+    return a;
+  }
   // divide_by_vanishing_poly: a[i] *= t_evaluations[i % 2^(extended_k - k)] on the extended coset, in place
   void divide_by_vanishing_poly(DevicePolys& a, hipStream_t stream = nullptr) const {
     if (a.len != extended_len()) throw std::invalid_argument("divide_by_vanishing_poly: a.len() != extended_len()");

@@ -1220,16 +1220,9 @@ int hm_ntt_batch_bn256_fr_dev(void* d_a, size_t batch, const uint64_t omega[4], 
   return rc;
 } HM_API_CATCH("hm_ntt_batch_bn256_fr_dev")
 
-int hm_coeff_to_extended_bn256_fr_dev(const void* d_coeffs, void* d_ext, size_t batch, const uint64_t extended_omega[4],
-                                      uint32_t log_n, uint32_t log_ext, const uint64_t* coset, void* stream) try {
-  if ((batch && (!d_coeffs || !d_ext)) || !extended_omega)
-    return hm_fail(HM_ERR_BAD_ARG, "hm_coeff_to_extended_bn256_fr_dev: null argument");
-  if (log_ext < log_n || log_ext > 28) return hm_fail(HM_ERR_BAD_ARG, "hm_coeff_to_extended_bn256_fr_dev: need log_n <= log_ext <= 28");
-  if (batch > 65535) return hm_fail(HM_ERR_BAD_ARG, "hm_coeff_to_extended_bn256_fr_dev: batch > 65535");
-  if (batch == 0) return HM_OK;
-  DeviceCtx* ctx = ctx_for_current_device();
-  if (!ctx) return HM_ERR_NO_DEVICE;
-  std::lock_guard<std::mutex> lk(ctx->mu);
+// ctx->mu is held by the caller.  The zero part of the padded array is neither written nor read when the plan allows it.
+static int coeff_to_extended_locked(DeviceCtx* ctx, const void* d_coeffs, void* d_ext, size_t batch, const uint64_t extended_omega[4],
+                                    uint32_t log_n, uint32_t log_ext, const uint64_t* coset, void* stream) {
   NttFused f;
   f.coset = coset;
   const uint32_t log_z = log_ext - log_n;
@@ -1248,7 +1241,93 @@ int hm_coeff_to_extended_bn256_fr_dev(const void* d_coeffs, void* d_ext, size_t 
   }
   if (rc == HM_OK) count_ntt(*ctx, log_ext, batch);
   return rc;
+}
+
+int hm_coeff_to_extended_bn256_fr_dev(const void* d_coeffs, void* d_ext, size_t batch, const uint64_t extended_omega[4],
+                                      uint32_t log_n, uint32_t log_ext, const uint64_t* coset, void* stream) try {
+  if ((batch && (!d_coeffs || !d_ext)) || !extended_omega)
+    return hm_fail(HM_ERR_BAD_ARG, "hm_coeff_to_extended_bn256_fr_dev: null argument");
+  if (log_ext < log_n || log_ext > 28) return hm_fail(HM_ERR_BAD_ARG, "hm_coeff_to_extended_bn256_fr_dev: need log_n <= log_ext <= 28");
+  if (batch > 65535) return hm_fail(HM_ERR_BAD_ARG, "hm_coeff_to_extended_bn256_fr_dev: batch > 65535");
+  if (batch == 0) return HM_OK;
+  DeviceCtx* ctx = ctx_for_current_device();
+  if (!ctx) return HM_ERR_NO_DEVICE;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  return coeff_to_extended_locked(ctx, d_coeffs, d_ext, batch, extended_omega, log_n, log_ext, coset, stream);
 } HM_API_CATCH("hm_coeff_to_extended_bn256_fr_dev")
+
+// Host-pointer forms of the two EvaluationDomain steps that cross PCIe in a drop-in prover: only what upstream's arrays really
+// hold travels -- the 2^log_n coefficients up (never the zero padding), the first `keep` coefficients down (never the part
+// extended_to_coeff truncates).
+int hm_coeff_to_extended_bn256_fr(const uint64_t* coeffs, uint64_t* ext, const uint64_t extended_omega[4], uint32_t log_n,
+                                  uint32_t log_ext, const uint64_t* coset) try {
+  if (!coeffs || !ext || !extended_omega) return hm_fail(HM_ERR_BAD_ARG, "hm_coeff_to_extended_bn256_fr: null argument");
+  if (log_ext < log_n || log_ext > 28) return hm_fail(HM_ERR_BAD_ARG, "hm_coeff_to_extended_bn256_fr: need log_n <= log_ext <= 28");
+  DeviceCtx* ctx = ctx_for_current_device();
+  if (!ctx) return HM_ERR_NO_DEVICE;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  const size_t bytes_in = (size_t)32 << log_n, bytes_out = (size_t)32 << log_ext;
+  char* d_out = (char*)ctx->io.ensure(bytes_out + bytes_in);
+  if (!d_out) return hm_fail(HM_ERR_HIP, "hm_coeff_to_extended_bn256_fr: staging allocation failed");
+  char* d_in = d_out + bytes_out;
+  const double t0 = now_us();
+  HM_HIP_CHECK(hipMemcpy(d_in, coeffs, bytes_in, hipMemcpyHostToDevice));
+  const double t1 = now_us();
+  const int rc = coeff_to_extended_locked(ctx, d_in, d_out, 1, extended_omega, log_n, log_ext, coset, nullptr);
+  if (rc != HM_OK) return rc;
+  HM_HIP_CHECK(hipStreamSynchronize(nullptr));
+  const double t2 = now_us();
+  {   // `ext` is written by this copy alone (it may be the very allocation `coeffs` lives in: the input has been uploaded whole)
+    const hipError_t e = hipMemcpy(ext, d_out, bytes_out, hipMemcpyDeviceToHost);
+    if (e != hipSuccess)
+      return hm_fail(HM_ERR_PARTIAL_OUTPUT, std::string("hm_coeff_to_extended_bn256_fr: copying the result back failed, the output is "
+                                                        "partly written: ") + hipGetErrorString(e));
+  }
+  const double t3 = now_us();
+  ctx->calls.ntt_h2d_us += t1 - t0;
+  ctx->calls.ntt_device_us += t2 - t1;
+  ctx->calls.ntt_d2h_us += t3 - t2;
+  ctx->calls.h2d_bytes += bytes_in;
+  ctx->calls.d2h_bytes += bytes_out;
+  return HM_OK;
+} HM_API_CATCH("hm_coeff_to_extended_bn256_fr")
+
+int hm_extended_to_coeff_bn256_fr(uint64_t* a, size_t keep, const uint64_t extended_omega_inv[4], uint32_t log_ext,
+                                  const uint64_t divisor[4], const uint64_t coset_inv[12]) try {
+  if (!a || !extended_omega_inv || !divisor || !coset_inv) return hm_fail(HM_ERR_BAD_ARG, "hm_extended_to_coeff_bn256_fr: null argument");
+  if (log_ext > 28) return hm_fail(HM_ERR_BAD_ARG, "hm_extended_to_coeff_bn256_fr: log_ext > 28");
+  if (keep > ((size_t)1 << log_ext)) return hm_fail(HM_ERR_BAD_ARG, "hm_extended_to_coeff_bn256_fr: keep exceeds 2^log_ext");
+  DeviceCtx* ctx = ctx_for_current_device();
+  if (!ctx) return HM_ERR_NO_DEVICE;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  const size_t bytes = (size_t)32 << log_ext;
+  void* d_a = ctx->io.ensure(bytes);
+  if (!d_a) return hm_fail(HM_ERR_HIP, "hm_extended_to_coeff_bn256_fr: staging allocation failed");
+  const double t0 = now_us();
+  HM_HIP_CHECK(hipMemcpy(d_a, a, bytes, hipMemcpyHostToDevice));
+  const double t1 = now_us();
+  NttFused f;
+  f.scale = divisor;
+  f.post3 = coset_inv;
+  const int rc = ntt_run(*ctx, (uint32_t*)d_a, extended_omega_inv, log_ext, 1, f, nullptr);
+  if (rc != HM_OK) return rc;
+  HM_HIP_CHECK(hipStreamSynchronize(nullptr));
+  const double t2 = now_us();
+  if (keep) {
+    const hipError_t e = hipMemcpy(a, d_a, keep * 32, hipMemcpyDeviceToHost);
+    if (e != hipSuccess)
+      return hm_fail(HM_ERR_PARTIAL_OUTPUT, std::string("hm_extended_to_coeff_bn256_fr: copying the result back failed, the array is "
+                                                        "partly overwritten: ") + hipGetErrorString(e));
+  }
+  const double t3 = now_us();
+  count_ntt(*ctx, log_ext, 1);
+  ctx->calls.ntt_h2d_us += t1 - t0;
+  ctx->calls.ntt_device_us += t2 - t1;
+  ctx->calls.ntt_d2h_us += t3 - t2;
+  ctx->calls.h2d_bytes += bytes;
+  ctx->calls.d2h_bytes += keep * 32;
+  return HM_OK;
+} HM_API_CATCH("hm_extended_to_coeff_bn256_fr")
 
 int hm_extended_to_coeff_bn256_fr_dev(void* d_a, size_t batch, const uint64_t extended_omega_inv[4], uint32_t log_ext,
                                       const uint64_t divisor[4], const uint64_t coset_inv[12], void* stream) try {

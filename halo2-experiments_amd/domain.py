@@ -20,7 +20,7 @@ import ctypes
 import numpy as np
 
 from . import _lib
-from .arithmetic import _ptr, _stream_ptr, _tensor_rows
+from .arithmetic import _np, _ptr, _stream_ptr, _tensor_rows
 
 FR_MODULUS = 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001
 FR_S = 28
@@ -103,15 +103,25 @@ class EvaluationDomain:
         tensor of evaluations on the zeta-coset.  ``internal``: the evaluations come out multiplied by 32 -- the form
         ``hm_graph_evaluate_flags_dev(HM_GRAPH_COLUMNS_INTERNAL)`` loads without a conversion product; the factor rides on the
         coset constants the first NTT pass multiplies in anyway."""
-        import torch
-
-        batch = self._batch_of(a, self.n, "coeff_to_extended")
-        en = self.extended_len()
-        a = a.contiguous()
-        ext = torch.empty((batch, en, 4), dtype=a.dtype, device=a.device)      # the zero part is never materialised
         r = FR_MODULUS
         sc = 32 if internal else 1
         coset = np.concatenate([fr_words(sc), fr_words(sc * self.g_coset), fr_words(sc * self.g_coset * self.g_coset % r)])
+        en = self.extended_len()
+        if isinstance(a, np.ndarray):
+            # host memory (the drop-in prover's Polynomial): (n, 4) uint64 in, new (2^extended_k, 4) uint64 out; only the n
+            # coefficients cross PCIe upwards, never the zero padding upstream's resize() appends
+            src = _np(a, 4, "coeff_to_extended")
+            if src.shape[0] != self.n:
+                raise ValueError(f"coeff_to_extended: expected ({self.n}, 4) words")
+            out = np.empty((en, 4), dtype=np.uint64)
+            _lib.check(_lib.load().hm_coeff_to_extended_bn256_fr(_ptr(src), _ptr(out), _ptr(fr_words(self.extended_omega)), self.k,
+                                                                 self.extended_k, _ptr(coset)))
+            return out
+        import torch
+
+        batch = self._batch_of(a, self.n, "coeff_to_extended")
+        a = a.contiguous()
+        ext = torch.empty((batch, en, 4), dtype=a.dtype, device=a.device)      # the zero part is never materialised
         _lib.check(_lib.load().hm_coeff_to_extended_bn256_fr_dev(
             ctypes.c_void_p(a.data_ptr()), ctypes.c_void_p(ext.data_ptr()), batch, _ptr(fr_words(self.extended_omega)), self.k,
             self.extended_k, _ptr(coset), ctypes.c_void_p(_stream_ptr(ext))))
@@ -253,9 +263,18 @@ class EvaluationDomain:
         """In place on a (2^extended_k, 4) or (batch, 2^extended_k, 4) tensor; returns the first
         n*(j-1) rows of each polynomial (a view)."""
         en = self.extended_len()
-        batch = self._batch_of(a, en, "extended_to_coeff")
         r = FR_MODULUS
         c3 = np.concatenate([fr_words(1), fr_words(self.g_coset_inv), fr_words(self.g_coset_inv * self.g_coset_inv % r)])
+        if isinstance(a, np.ndarray):
+            # host memory: in place on a (2^extended_k, 4) uint64 array; only the n*(j-1) coefficients upstream keeps come back
+            arr = _np(a, 4, "extended_to_coeff", writable=True)
+            if arr.shape[0] != en:
+                raise ValueError(f"extended_to_coeff: expected ({en}, 4) words")
+            keep = self.n * self.quotient_poly_degree
+            _lib.check(_lib.load().hm_extended_to_coeff_bn256_fr(_ptr(arr), keep, _ptr(fr_words(self.extended_omega_inv)), self.extended_k,
+                                                                 _ptr(fr_words(self.extended_ifft_divisor)), _ptr(c3)))
+            return arr[:keep]
+        batch = self._batch_of(a, en, "extended_to_coeff")
         # one call: the ifft divisor and the zeta^-(i % 3) pattern are folded into the last NTT pass
         _lib.check(_lib.load().hm_extended_to_coeff_bn256_fr_dev(
             ctypes.c_void_p(a.data_ptr()), batch, _ptr(fr_words(self.extended_omega_inv)), self.extended_k,

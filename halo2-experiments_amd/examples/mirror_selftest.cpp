@@ -1,4 +1,4 @@
-// mirror_selftest.cpp -- host-only checks of the C++ mirror (cpp/*.hpp); runs without a GPU.
+// mirror_selftest.cpp -- checks of the C++ mirror (cpp/*.hpp); the host-only part runs without a GPU, the rest when one is there.
 // Field constants against their defining properties, the public alt_bn128 known answer for 2G, the
 // EvaluationDomain constants, and the error behaviour of the arithmetic mirror: length mismatch is
 // std::invalid_argument (upstream: assert_eq! panic); a missing device is std::runtime_error -- never
@@ -67,6 +67,25 @@ int main() {
   std::vector<Fr> a(6, Fr::one());
   try { arithmetic::best_fft(a, d.omega, 3); } catch (const std::invalid_argument&) { threw = true; }
   CHECK(threw);
+  threw = false;
+  try { (void)d.coeff_to_extended(a); } catch (const std::invalid_argument&) { threw = true; }     // a.len() != n
+  CHECK(threw);
+  threw = false;
+  try { (void)d.extended_to_coeff(a); } catch (const std::invalid_argument&) { threw = true; }     // a.len() != extended_len()
+  CHECK(threw);
+  if (hm_device_count() > 0) {
+    // host-vector EvaluationDomain steps: coeff -> extended -> coeff returns the coefficients, zeros above n, n * (j - 1) of them
+    std::vector<Fr> c(d.n);
+    for (size_t i = 0; i < d.n; ++i) c[i] = Fr::from_u64(3 * i + 1);
+    const std::vector<Fr> ext = d.coeff_to_extended(c);
+    CHECK(ext.size() == d.extended_len());
+    Fr at_zeta = Fr::zero();                                  // row 0 of the extended array is the value at zeta: Horner
+    for (size_t i = d.n; i-- > 0;) at_zeta = at_zeta * d.g_coset + c[i];
+    CHECK(ext[0] == at_zeta);
+    const std::vector<Fr> back = d.extended_to_coeff(ext);
+    CHECK(back.size() == d.n * d.quotient_poly_degree);
+    for (size_t i = 0; i < back.size(); ++i) CHECK(back[i] == (i < d.n ? c[i] : Fr::zero()));
+  }
   if (hm_device_count() == 0) {
     threw = false;
     b.resize(4);

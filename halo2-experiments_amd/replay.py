@@ -545,6 +545,13 @@ def run_replay(shape_name: str, device=None, group=None, include_host_pointer_es
         a_e = np.zeros((dom.extended_len(), 4), dtype=np.uint64); a_e[:n] = h_s
         best_fft(a_e, fr_words(dom.extended_omega), dom.extended_k)
         t0 = time.perf_counter(); best_fft(a_e, fr_words(dom.extended_omega), dom.extended_k); t_ntt_e = time.perf_counter() - t0
+        # the two EvaluationDomain steps through their own host-pointer forms (the optional src/poly/domain.rs edits of rust/): the zero
+        # padding never goes up, the truncated tail never comes down
+        dom.coeff_to_extended(h_s)                                  # warm-up (staging buffer, twiddles)
+        t0 = time.perf_counter(); ext_h = dom.coeff_to_extended(h_s); t_c2e = time.perf_counter() - t0
+        dom.extended_to_coeff(ext_h.copy())
+        t0 = time.perf_counter(); dom.extended_to_coeff(ext_h); t_e2c = time.perf_counter() - t0
+        del ext_h
         # ... and the commitments of the whole proof from HOST arrays through the batch call (uploads pipelined behind the
         # other commitments' kernels): what a prover that keeps its polynomials in host vectors gets per proof
         from .arithmetic import best_multiexp_batch
@@ -560,14 +567,18 @@ def run_replay(shape_name: str, device=None, group=None, include_host_pointer_es
             + t_ntt_e * (counts["coset_ntt_ext"] + counts["intt_ext"])
         # the two totals side by side: what a prover gets from the UNMODIFIED drop-in (every best_multiexp / best_fft call
         # moves its arrays over PCIe) and what it gets once its polynomials stay in HBM -- neither hidden behind the other
+        batched = hp_total - t_msm * (counts["msm_sparse"] + counts["msm_dense"]) + t_batch_host
+        domain_edits = batched - t_ntt_e * (counts["coset_ntt_ext"] + counts["intt_ext"]) + t_c2e * counts["coset_ntt_ext"] + t_e2c * counts["intt_ext"]
         out["total_s"] = {"drop_in_host_pointers": hp_total, "device_resident": wall,
-                          "drop_in_with_batched_commitments": hp_total - t_msm * (counts["msm_sparse"] + counts["msm_dense"]) + t_batch_host,
+                          "drop_in_with_batched_commitments": batched, "drop_in_with_domain_edits": domain_edits,
                           "note": "drop_in_host_pointers = per-call times of hm_msm_bn256_g1_h / hm_ntt_bn256_fr x the trace's counts (MSM and "
                                   "NTT only); drop_in_with_batched_commitments replaces the per-call MSMs by two hm_msm_batch_bn256_g1_h "
-                                  "calls; device_resident = the whole replayed trace, polynomials in HBM (includes the non-MSM/NTT steps)"}
+                                  "calls; drop_in_with_domain_edits also replaces the extended-domain best_fft calls by "
+                                  "hm_coeff_to_extended_bn256_fr / hm_extended_to_coeff_bn256_fr (rust/edits.json, src/poly/domain.rs); "
+                                  "device_resident = the whole replayed trace, polynomials in HBM (includes the non-MSM/NTT steps)"}
         out["host_pointer_estimate_s"] = {
             "msm_batches_from_host_arrays": t_batch_host,
-            "msm_each": t_msm, "ntt_n_each": t_ntt_n, "ntt_ext_each": t_ntt_e,
+            "msm_each": t_msm, "ntt_n_each": t_ntt_n, "ntt_ext_each": t_ntt_e, "coeff_to_extended_each": t_c2e, "extended_to_coeff_each": t_e2c,
             "total": hp_total,
             "note": "PCIe-inclusive: every call uploads its scalars / moves its array both ways"}
     gate_prog.destroy()

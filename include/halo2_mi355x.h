@@ -256,6 +256,22 @@ int hm_cosets_to_coeff_bn256_fr_dev(void* d_a, size_t count, const uint64_t omeg
 int hm_extended_to_coeff_bn256_fr_dev(void* d_a, size_t batch, const uint64_t extended_omega_inv[4], uint32_t log_ext,
                                       const uint64_t divisor[4], const uint64_t coset_inv[12], void* stream);
 
+/* Host-pointer forms of the two steps above, for a prover whose polynomials stay in host memory (the drop-in patch of
+ * rust/halo2_proofs-patch: EvaluationDomain::coeff_to_extended / extended_to_coeff, halo2_proofs poly/domain.rs).  Only what
+ * upstream's arrays really hold crosses PCIe:
+ *   hm_coeff_to_extended_bn256_fr: coeffs = 2^log_n x 4 u64 in (the zero padding upstream's `resize` appends is never uploaded),
+ *     ext = 2^log_ext x 4 u64 out; coset = {1, zeta, zeta^2} (12 words) or NULL.  `ext` is written by the final copy alone and
+ *     may be the allocation `coeffs` lives in (upstream resizes its Vec in place): every error code but HM_ERR_PARTIAL_OUTPUT
+ *     leaves both arrays as they were.
+ *   hm_extended_to_coeff_bn256_fr: a = 2^log_ext x 4 u64 evaluations in; the first `keep` coefficients (keep <= 2^log_ext:
+ *     upstream truncates to n * (j - 1)) come back into a[0 .. keep), the rest of `a` keeps its old contents -- the caller
+ *     truncates.  Same error contract.
+ * Synchronous; run on the calling thread's current device (the library's own stream). */
+int hm_coeff_to_extended_bn256_fr(const uint64_t* coeffs, uint64_t* ext, const uint64_t extended_omega[4], uint32_t log_n,
+                                  uint32_t log_ext, const uint64_t* coset);
+int hm_extended_to_coeff_bn256_fr(uint64_t* a, size_t keep, const uint64_t extended_omega_inv[4], uint32_t log_ext,
+                                  const uint64_t divisor[4], const uint64_t coset_inv[12]);
+
 /* halo2_proofs::arithmetic::eval_polynomial (the Horner evaluations create_proof makes of every committed
  * polynomial at x * omega^rot): out[q] = sum_i poly_q[i] * points[q]^i for q < count, where poly_q is the
  * coefficient array number poly_index[q] (or q when poly_index is NULL) of the back-to-back arrays of n Fr at

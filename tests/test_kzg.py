@@ -104,6 +104,20 @@ def test_replays_verify_their_commitments(name):
 
 
 @pytest.mark.gpu
+def test_replay_reports_the_drop_in_totals_side_by_side():
+    """The host-pointer (drop-in) cost of the k = 17 trace next to the device-resident one: per-call forms, the batched commitments, and
+    the EvaluationDomain edits (hm_coeff_to_extended_bn256_fr / hm_extended_to_coeff_bn256_fr: 9/16 of the bytes of a zero-padded
+    best_fft round trip at j = 7) -- each cheaper than the one before."""
+    import torch
+    from halo2_experiments_amd.replay import run_replay
+    r = run_replay("merkle_v3_k17", device=torch.device("cuda", 0))
+    t, e = r["total_s"], r["host_pointer_estimate_s"]
+    assert set(t) >= {"drop_in_host_pointers", "drop_in_with_batched_commitments", "drop_in_with_domain_edits", "device_resident"}
+    assert t["drop_in_host_pointers"] > t["drop_in_with_batched_commitments"] > t["drop_in_with_domain_edits"] > t["device_resident"] > 0
+    assert 0 < e["coeff_to_extended_each"] < e["ntt_ext_each"] and 0 < e["extended_to_coeff_each"] < e["ntt_ext_each"]
+
+
+@pytest.mark.gpu
 def test_replay_by_cosets_and_one_ranks_share():
     """The extended-domain steps by cosets on one GPU (what several ranks deal among themselves), and ONE rank's share of a
     four-rank replay run alone: its commitments only (each still checked against the KZG identity), its cosets, no exchange."""

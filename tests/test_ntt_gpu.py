@@ -115,6 +115,100 @@ def test_evaluation_domain_at_the_config_shapes_matches_oracle(cref, pyref, k):
     assert out.shape[-2] == n * 6
 
 
+@pytest.mark.parametrize("k", [17, 18])
+def test_host_pointer_domain_steps_match_oracle(cref, pyref, k):
+    """hm_coeff_to_extended_bn256_fr / hm_extended_to_coeff_bn256_fr (host arrays: what the patched EvaluationDomain::coeff_to_extended /
+    extended_to_coeff of the drop-in prover call) at configs 3 and 4's shapes, j = 7: every element against the ORACLE's compositions
+    (zero-pad, distribute_powers_zeta, best_fft; best_fft with the inverse root, divisor, inverse zeta powers, truncate), and the
+    PCIe byte counters show that neither the zero padding nor the truncated tail travelled."""
+    import ctypes
+    from halo2_experiments_amd import _lib
+    o = pyref
+    d = EvaluationDomain(j=7, k=k)
+    n, en, R = d.n, d.extended_len(), o.R
+    coeffs = rand_fr_gpu(n, 6100 + k).cpu().numpy().view(np.uint64)
+    before = coeffs.copy()
+    zeta = _pattern3([1, d.g_coset, d.g_coset * d.g_coset % R], en)
+    pad = np.zeros((en, 4), dtype=np.uint64)
+    pad[:n] = coeffs
+    exp_ext = cref.best_fft(cref.fr_mul(pad, zeta), fr_words(d.extended_omega), d.extended_k)
+    lib = _lib.load()
+    def pcie_bytes():
+        st = _lib.Stats()
+        _lib.check(lib.hm_get_stats(ctypes.byref(st)))
+        return st.h2d_bytes, st.d2h_bytes
+    up0, down0 = pcie_bytes()
+    ext = d.coeff_to_extended(coeffs)
+    assert isinstance(ext, np.ndarray) and ext.shape == (en, 4) and np.array_equal(coeffs, before)
+    assert np.array_equal(ext, exp_ext)
+    # extended_to_coeff on an ARBITRARY extended array, in place; the first n * 6 coefficients come back, the tail keeps its contents
+    x = rand_fr_gpu(en, 6200 + k).cpu().numpy().view(np.uint64)
+    inv = cref.fr_mul(cref.best_fft(x, fr_words(d.extended_omega_inv), d.extended_k), np.tile(fr_words(d.extended_ifft_divisor), (en, 1)))
+    exp_back = cref.fr_mul(inv, _pattern3([1, d.g_coset_inv, d.g_coset_inv * d.g_coset_inv % R], en))
+    got = x.copy()
+    out = d.extended_to_coeff(got)
+    keep = n * 6
+    assert out.shape == (keep, 4) and np.array_equal(out, exp_back[:keep])
+    assert np.array_equal(got[keep:], x[keep:])                       # never downloaded: upstream truncates it away
+    up1, down1 = pcie_bytes()
+    assert up1 - up0 == 32 * (n + en) and down1 - down0 == 32 * (en + keep)      # 8 + 64 MiB up, 64 + 48 MiB down at k = 18
+    # round trip of a band-limited polynomial: coeff -> extended -> coeff returns the coefficients, zeros above n
+    back = d.extended_to_coeff(d.coeff_to_extended(coeffs))
+    assert np.array_equal(back[:n], coeffs) and not back[n:].any()
+    # argument checks: the reference's assert_eq!(a.len(), 1 << k) becomes ValueError; NULL pointers an error code, not a crash
+    with pytest.raises(ValueError):
+        d.coeff_to_extended(coeffs[:-1])
+    with pytest.raises(ValueError):
+        d.extended_to_coeff(np.zeros((en // 2, 4), dtype=np.uint64))
+    assert lib.hm_coeff_to_extended_bn256_fr(None, None, None, k, k + 3, None) == -1
+    assert lib.hm_extended_to_coeff_bn256_fr(None, 0, None, k, None, None) == -1
+
+
+def test_host_pointer_domain_steps_small_and_unextended(cref, pyref):
+    """The host forms on the plans the big shapes do not reach: single-pass sizes, log_ext == log_n, one extension bit, keep = 0 and
+    keep = 2^log_ext, output aliasing the input allocation (upstream resizes its Vec in place)."""
+    import ctypes
+    from halo2_experiments_amd import _lib
+    o = pyref
+    lib = _lib.load()
+    R = o.R
+    u64p = ctypes.POINTER(ctypes.c_uint64)
+    for k, j in ((3, 2), (5, 3), (9, 4), (11, 7), (12, 5), (13, 9)):
+        d = EvaluationDomain(j=j, k=k)
+        n, en = d.n, d.extended_len()
+        coeffs = rand_fr_gpu(n, 6300 + k).cpu().numpy().view(np.uint64)
+        pad = np.zeros((en, 4), dtype=np.uint64)
+        pad[:n] = coeffs
+        exp = cref.best_fft(cref.fr_mul(pad, _pattern3([1, d.g_coset, d.g_coset * d.g_coset % R], en)), fr_words(d.extended_omega), d.extended_k)
+        assert np.array_equal(d.coeff_to_extended(coeffs), exp), (k, j)
+        # in one allocation: coefficients at the front of the buffer the evaluations are written to
+        buf = np.zeros((en, 4), dtype=np.uint64)
+        buf[:n] = coeffs
+        coset = np.concatenate([fr_words(1), fr_words(d.g_coset), fr_words(d.g_coset * d.g_coset % R)])
+        p = buf.ctypes.data_as(u64p)
+        _lib.check(lib.hm_coeff_to_extended_bn256_fr(p, p, fr_words(d.extended_omega).ctypes.data_as(u64p), k, d.extended_k, coset.ctypes.data_as(u64p)))
+        assert np.array_equal(buf, exp), (k, j)
+        back = d.extended_to_coeff(exp.copy())
+        keep = n * (j - 1)
+        assert back.shape == (keep, 4) and np.array_equal(back[:n], coeffs) and not back[n:].any(), (k, j)
+        c3 = np.concatenate([fr_words(1), fr_words(d.g_coset_inv), fr_words(d.g_coset_inv * d.g_coset_inv % R)])
+        for keep in (0, en):
+            y = exp.copy()
+            _lib.check(lib.hm_extended_to_coeff_bn256_fr(y.ctypes.data_as(u64p), keep, fr_words(d.extended_omega_inv).ctypes.data_as(u64p), d.extended_k,
+                                                         fr_words(d.extended_ifft_divisor).ctypes.data_as(u64p), c3.ctypes.data_as(u64p)))
+            if keep == 0:
+                assert np.array_equal(y, exp)
+            else:
+                assert np.array_equal(y[:n], coeffs) and not y[n:].any()
+        assert lib.hm_extended_to_coeff_bn256_fr(exp.ctypes.data_as(u64p), en + 1, fr_words(d.extended_omega_inv).ctypes.data_as(u64p), d.extended_k,
+                                                 fr_words(d.extended_ifft_divisor).ctypes.data_as(u64p), c3.ctypes.data_as(u64p)) == -1
+    d = EvaluationDomain(j=2, k=6)                                 # quotient degree 1: the extended domain IS the domain
+    assert d.extended_k == 6
+    coeffs = rand_fr_gpu(64, 6400).cpu().numpy().view(np.uint64)
+    exp = cref.best_fft(cref.fr_mul(coeffs, _pattern3([1, d.g_coset, d.g_coset * d.g_coset % R], 64)), fr_words(d.extended_omega), 6)
+    assert np.array_equal(d.coeff_to_extended(coeffs), exp)
+
+
 def test_edge_values(cref, pyref):
     o = pyref
     k = 6

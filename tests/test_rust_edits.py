@@ -64,6 +64,11 @@ def test_apply_edits_makes_every_edit_once(tmp_path):
     # the optional batch-commit method: provided by the trait, overridden for ParamsKZG
     assert (root / "src" / "poly" / "commitment.rs").read_text().count("fn commit_lagrange_batch(") == 1
     assert kzg.count("self.gpu.commit_lagrange_batch::<E::G1Affine>") == 1
+    # the optional EvaluationDomain edits: each step tries the GPU first, the upstream statements stay behind it
+    dom = (root / "src" / "poly" / "domain.rs").read_text()
+    assert dom.count("mi355x::try_coeff_to_extended(") == 1 and dom.count("mi355x::try_extended_to_coeff(") == 1
+    assert dom.index("try_coeff_to_extended") < dom.index("        self.distribute_powers_zeta(&mut a.values, true);")
+    assert dom.index("        assert_eq!(a.values.len(), self.extended_len());") < dom.index("try_extended_to_coeff")
     again = _run(root)                                          # idempotent
     assert again.returncode == 0 and "already edited" in again.stdout
     assert (root / "src" / "poly" / "kzg" / "commitment.rs").read_text() == kzg
@@ -99,7 +104,8 @@ def test_the_unified_diff_makes_the_same_edits(tmp_path):
     assert _run(a).returncode == 0
     r = subprocess.run(["patch", "-p1", "-i", os.path.join(RUST, "halo2_proofs.patch")], cwd=b, capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
-    for rel in ("src/arithmetic.rs", "src/poly/kzg/commitment.rs", "src/poly/commitment.rs", "Cargo.toml", "src/mi355x.rs", "src/mi355x_kzg.rs"):
+    for rel in ("src/arithmetic.rs", "src/poly/kzg/commitment.rs", "src/poly/commitment.rs", "src/poly/domain.rs", "Cargo.toml", "src/mi355x.rs",
+                "src/mi355x_kzg.rs"):
         assert (a / rel).read_text() == (b / rel).read_text(), rel
 
 
@@ -110,3 +116,7 @@ def test_glue_is_free_of_the_risks_the_review_named():
     assert "use group::prime::PrimeCurveAffine;" in glue and "use group::Group as _;" in glue
     assert "HM_ERR_PARTIAL_OUTPUT" in glue and "panic!" in glue                  # never run the CPU body on a half-written array
     assert "hm_register_bases(" in kzg and "hm_msm_batch_bn256_g1_h(" in kzg and "hm_release_bases(" in kzg
+    # the EvaluationDomain steps: coeff_to_extended writes a fresh Vec (no failure can touch the input), extended_to_coeff is in place
+    # and therefore panics on a half-written array instead of letting the CPU body continue on it
+    assert "Vec::with_capacity(len)" in glue and "*a = ext;" in glue and glue.count("HM_ERR_PARTIAL_OUTPUT") >= 3
+    assert "hm_coeff_to_extended_bn256_fr(" in glue and "hm_extended_to_coeff_bn256_fr(" in glue and "a.truncate(keep);" in glue

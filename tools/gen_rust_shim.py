@@ -314,6 +314,73 @@ pub fn try_best_fft<G: Group>(a: &mut [G], omega: &G::Scalar, log_n: u32) -> boo
     rc == sys::HM_OK // every other error code leaves `a` exactly as it was: the caller runs the CPU body
 }
 
+/// R mod r: bn256::Fr::one() as the four Montgomery words the library reads (spelled out: no dependence on the ff version's `one()` / `ONE`).
+const FR_ONE: [u64; 4] = [0xac96341c4ffffffb, 0x36fc76959f60cd29, 0x666ea36f7879462e, 0x0e0a77c19a07df2f];
+
+fn fr_words<S>(s: &S) -> [u64; 4] {
+    unsafe { std::mem::transmute_copy::<S, [u64; 4]>(s) } // S == Fr here (TypeId-checked by the callers; 32 bytes by layout_ok)
+}
+
+/// EvaluationDomain::coeff_to_extended in one library call (hm_coeff_to_extended_bn256_fr): `a` holds the 2^k coefficients on
+/// entry and, when this returns true, the 2^extended_k evaluations on the zeta-coset.  Only the 2^k coefficients cross PCIe
+/// upwards (never the zero padding `resize` would append); distribute_powers_zeta is fused into the first NTT pass.  The result
+/// is written to a FRESH Vec that replaces `a` only on success, so every failure -- HM_ERR_PARTIAL_OUTPUT included -- leaves
+/// `a` exactly as it was and the caller runs the CPU body.
+pub fn try_coeff_to_extended<G: Group>(a: &mut Vec<G>, extended_omega: &G::Scalar, k: u32, extended_k: u32, g_coset: &G::Scalar,
+                                       g_coset_inv: &G::Scalar) -> bool {
+    if TypeId::of::<G>() != TypeId::of::<Fr>() || TypeId::of::<G::Scalar>() != TypeId::of::<Fr>() || extended_k < GPU_MIN_LOG_N_NTT
+        || extended_k > 28 || k > extended_k || a.len() != (1usize << k) || !layout_ok()
+    {
+        return false;
+    }
+    // a[i] *= [1, g_coset, g_coset_inv][i % 3]: distribute_powers_zeta(a, true) (zeta^3 = 1, so g_coset_inv = zeta^2)
+    let mut coset = [0u64; 12];
+    coset[..4].copy_from_slice(&FR_ONE);
+    coset[4..8].copy_from_slice(&fr_words(g_coset));
+    coset[8..].copy_from_slice(&fr_words(g_coset_inv));
+    let len = 1usize << extended_k;
+    let mut ext: Vec<G> = Vec::with_capacity(len);
+    let rc = unsafe {
+        sys::hm_coeff_to_extended_bn256_fr(a.as_ptr() as *const u64, ext.as_mut_ptr() as *mut u64, extended_omega as *const _ as *const u64,
+                                           k, extended_k, coset.as_ptr())
+    };
+    if rc != sys::HM_OK {
+        return false; // `ext` (possibly half-written) is dropped; `a` is untouched
+    }
+    unsafe { ext.set_len(len) }; // every element was written by the library's final copy
+    *a = ext;
+    true
+}
+
+/// EvaluationDomain::extended_to_coeff in one library call (hm_extended_to_coeff_bn256_fr): in place on the 2^extended_k
+/// evaluations; the ifft divisor and distribute_powers_zeta(a, false) ride on the last NTT pass, only the `keep` coefficients
+/// upstream keeps come back over PCIe, and `a` is truncated to them.
+pub fn try_extended_to_coeff<G: Group>(a: &mut Vec<G>, extended_omega_inv: &G::Scalar, extended_k: u32, divisor: &G::Scalar,
+                                       g_coset: &G::Scalar, g_coset_inv: &G::Scalar, keep: usize) -> bool {
+    if TypeId::of::<G>() != TypeId::of::<Fr>() || TypeId::of::<G::Scalar>() != TypeId::of::<Fr>() || extended_k < GPU_MIN_LOG_N_NTT
+        || extended_k > 28 || a.len() != (1usize << extended_k) || keep > a.len() || !layout_ok()
+    {
+        return false;
+    }
+    // a[i] *= [1, g_coset_inv, g_coset][i % 3]: distribute_powers_zeta(a, false)
+    let mut coset_inv = [0u64; 12];
+    coset_inv[..4].copy_from_slice(&FR_ONE);
+    coset_inv[4..8].copy_from_slice(&fr_words(g_coset_inv));
+    coset_inv[8..].copy_from_slice(&fr_words(g_coset));
+    let rc = unsafe {
+        sys::hm_extended_to_coeff_bn256_fr(a.as_mut_ptr() as *mut u64, keep, extended_omega_inv as *const _ as *const u64, extended_k,
+                                           divisor as *const _ as *const u64, coset_inv.as_ptr())
+    };
+    if rc == sys::HM_ERR_PARTIAL_OUTPUT {
+        panic!("hm_extended_to_coeff_bn256_fr: {}", sys::last_error()); // as in try_best_fft: `a` is neither input nor output
+    }
+    if rc != sys::HM_OK {
+        return false;
+    }
+    a.truncate(keep);
+    true
+}
+
 /// One process, several GPUs: every later best_multiexp / registered base set is split over `devices` inside the library.
 pub fn use_devices(devices: &[i32]) -> bool {
     unsafe { sys::hm_set_msm_devices(devices.as_ptr(), devices.len() as i32) == sys::HM_OK }
@@ -545,6 +612,24 @@ EDITS += [
 ]
 
 
+# OPTIONAL edits of src/poly/domain.rs: the two EvaluationDomain steps that move the extended arrays.  Without them every
+# coeff_to_extended reaches the GPU through best_fft as a zero-padded 2^extended_k array (64 MiB up and down at k = 18, 48 times
+# a proof); with them 2^k coefficients go up and 2^extended_k evaluations come down, and extended_to_coeff brings back only the
+# n (j - 1) coefficients it keeps.  Anchors: the first statement of each function body after its assert, as recalled.
+EDITS += [
+    ("src/poly/domain.rs", "        self.distribute_powers_zeta(&mut a.values, true);",
+     [["        if crate::arithmetic::mi355x::try_coeff_to_extended(&mut a.values, &self.extended_omega, self.k, self.extended_k, &self.g_coset, &self.g_coset_inv) {",
+       "            return Polynomial { values: a.values, _marker: PhantomData };",
+       "        }",
+       "        self.distribute_powers_zeta(&mut a.values, true);"]], 250, True),
+    ("src/poly/domain.rs", "        assert_eq!(a.values.len(), self.extended_len());",
+     [["        assert_eq!(a.values.len(), self.extended_len());",
+       "        if crate::arithmetic::mi355x::try_extended_to_coeff(&mut a.values, &self.extended_omega_inv, self.extended_k, &self.extended_ifft_divisor, &self.g_coset, &self.g_coset_inv, (&self.n * self.quotient_poly_degree) as usize) {",
+       "            return a.values;",
+       "        }"]], 310, True),
+]
+
+
 def emit_patch() -> str:
     def new_file(path, text):
         lines = text.rstrip("\n").split("\n")
@@ -593,7 +678,7 @@ made of the recalled anchor lines.
 | path | what |
 |---|---|
 | `halo2-mi355x-sys/` | the FFI crate: `Cargo.toml`, `build.rs` (links `libhalo2_mi355x.so` from `$HALO2_MI355X_LIB_DIR`), `src/lib.rs` (one `extern "C"` item per header entry, `#[repr(C)]` structs, `HM_*` constants) |
-| `halo2_proofs-patch/src/mi355x.rs` | glue for the two free functions: `try_best_multiexp`, `try_best_fft` (TypeId dispatch on `bn256::G1Affine` / `bn256::Fr`, layout assertions behind `std::sync::Once`, fall back to the CPU body on any error that left the arrays untouched, panic on `HM_ERR_PARTIAL_OUTPUT`), `use_devices` |
+| `halo2_proofs-patch/src/mi355x.rs` | glue for the two free functions and the two `EvaluationDomain` steps: `try_coeff_to_extended` (fresh output Vec: every failure leaves the input untouched), `try_extended_to_coeff`; `try_best_multiexp`, `try_best_fft` (TypeId dispatch on `bn256::G1Affine` / `bn256::Fr`, layout assertions behind `std::sync::Once`, fall back to the CPU body on any error that left the arrays untouched, panic on `HM_ERR_PARTIAL_OUTPUT`), `use_devices` |
 | `halo2_proofs-patch/src/mi355x_kzg.rs` | `SrsHandles`, the new field of `ParamsKZG`: `g` / `g_lagrange` registered ONCE per `ParamsKZG` (`hm_register_bases`: resident, converted, fixed-base table from 2^17 points), `commit` / `commit_lagrange` through the handle (`hm_msm_bn256_g1_h`), `commit_lagrange_batch` = a phase of commitments in one call (`hm_msm_batch_bn256_g1_h`); `Clone` = empty, `Drop` = release, `reset()` for `downsize` |
 | `edits.json`, `apply_edits.py` | the edits of EXISTING upstream files as a table (file, anchor line, replacement per occurrence) and the script that applies it by literal line match: idempotent, refuses a file whose anchors do not occur as often as expected |
 | `halo2_proofs.patch` | the same as a unified diff (new files + zero-context hunks, one per occurrence) for `patch -p1` |
@@ -605,6 +690,7 @@ The edits (all in `halo2_proofs/` of the pinned tag, `/root/reference/Cargo.toml
 | `src/arithmetic.rs` | `best_multiexp` / `best_fft` become wrappers with the same signatures that try the GPU and fall through to the untouched bodies, renamed `original_*`; declares the two new modules |
 | `src/poly/kzg/commitment.rs` | `ParamsKZG` gains the field `gpu: SrsHandles` (added to its three struct literals as `Default::default()`), `downsize` resets it, `commit_lagrange` and `commit` try `self.gpu.commit*` before their `best_multiexp(&scalars, &bases[0..size])` |
 | `Cargo.toml` | the `halo2-mi355x-sys` dependency |
+| `src/poly/domain.rs` (optional) | `EvaluationDomain::coeff_to_extended` / `extended_to_coeff` try `mi355x::try_coeff_to_extended` / `try_extended_to_coeff` first (`hm_coeff_to_extended_bn256_fr`, `hm_extended_to_coeff_bn256_fr`): the zero padding is never uploaded, the truncated tail never downloaded, the coset shifts and the divisor ride on NTT passes |
 
 ## Recipe (on a machine with Rust and an MI355X)
 
