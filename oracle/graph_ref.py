@@ -15,55 +15,73 @@ from typing import Dict, List, Sequence
 R = 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001
 
 
+def _evaluate_row(calculations, constants, rotations, cell, challenges, beta, gamma, theta, y, previous_value, idx, rot_scale, isize) -> int:
+    """One row of GraphEvaluator::evaluate.  cell(kind, column, row) -> the column's value at that row."""
+    inter: Dict[int, int] = {}
+
+    def get(vs):
+        kind = vs[0]
+        if kind == "Constant":
+            return constants[vs[1]]
+        if kind == "Intermediate":
+            return inter[vs[1]]
+        if kind in ("Fixed", "Advice", "Instance"):
+            return cell(kind, vs[1], (idx + rotations[vs[2]] * rot_scale) % isize)
+        if kind == "Challenge":
+            return challenges[vs[1]]
+        return {"Beta": beta, "Gamma": gamma, "Theta": theta, "Y": y, "PreviousValue": previous_value}[kind]
+
+    last = 0
+    for calc, target in calculations:
+        name = calc[0]
+        if name == "Add":
+            v = (get(calc[1]) + get(calc[2])) % R
+        elif name == "Sub":
+            v = (get(calc[1]) - get(calc[2])) % R
+        elif name == "Mul":
+            v = get(calc[1]) * get(calc[2]) % R
+        elif name == "Square":
+            v = get(calc[1]) ** 2 % R
+        elif name == "Double":
+            v = 2 * get(calc[1]) % R
+        elif name == "Negate":
+            v = -get(calc[1]) % R
+        elif name == "Store":
+            v = get(calc[1])
+        elif name == "Horner":
+            v = get(calc[1])
+            f = get(calc[3])
+            for part in calc[2]:
+                v = (v * f + get(part)) % R
+        else:
+            raise ValueError(name)
+        inter[target] = v
+        last = v
+    return last
+
+
 def evaluate_graph(calculations, constants: Sequence[int], rotations: Sequence[int], fixed: List[List[int]], advice: List[List[int]],
                    instance: List[List[int]], challenges: Sequence[int], beta: int, gamma: int, theta: int, y: int,
                    previous: Sequence[int], rot_scale: int, isize: int) -> List[int]:
     """calculations: [(calc tuple, target)] as built by the GraphEvaluator mirror; columns are lists of ints of length isize."""
-    out = []
-    for idx in range(isize):
-        inter: Dict[int, int] = {}
+    table = {"Fixed": fixed, "Advice": advice, "Instance": instance}
+    cell = lambda kind, col, row: table[kind][col][row]
+    return [_evaluate_row(calculations, constants, rotations, cell, challenges, beta, gamma, theta, y, previous[idx], idx, rot_scale, isize)
+            for idx in range(isize)]
 
-        def get(vs):
-            kind = vs[0]
-            if kind == "Constant":
-                return constants[vs[1]]
-            if kind == "Intermediate":
-                return inter[vs[1]]
-            if kind in ("Fixed", "Advice", "Instance"):
-                col = {"Fixed": fixed, "Advice": advice, "Instance": instance}[kind][vs[1]]
-                return col[(idx + rotations[vs[2]] * rot_scale) % isize]
-            if kind == "Challenge":
-                return challenges[vs[1]]
-            return {"Beta": beta, "Gamma": gamma, "Theta": theta, "Y": y, "PreviousValue": previous[idx]}[kind]
 
-        last = 0
-        for calc, target in calculations:
-            name = calc[0]
-            if name == "Add":
-                v = (get(calc[1]) + get(calc[2])) % R
-            elif name == "Sub":
-                v = (get(calc[1]) - get(calc[2])) % R
-            elif name == "Mul":
-                v = get(calc[1]) * get(calc[2]) % R
-            elif name == "Square":
-                v = get(calc[1]) ** 2 % R
-            elif name == "Double":
-                v = 2 * get(calc[1]) % R
-            elif name == "Negate":
-                v = -get(calc[1]) % R
-            elif name == "Store":
-                v = get(calc[1])
-            elif name == "Horner":
-                v = get(calc[1])
-                f = get(calc[3])
-                for part in calc[2]:
-                    v = (v * f + get(part)) % R
-            else:
-                raise ValueError(name)
-            inter[target] = v
-            last = v
-        out.append(last)
-    return out
+def evaluate_graph_rows(calculations, constants: Sequence[int], rotations: Sequence[int], cell, challenges: Sequence[int], beta: int,
+                        gamma: int, theta: int, y: int, previous, rows: Sequence[int], rot_scale: int, isize: int) -> List[int]:
+    """The same interpreter on the listed rows only (domains too large to walk in Python: 2^21 rows at k = 18): columns are read
+    through cell(kind, column, row) -- a sparse window gathered around the rows, see cells_needed() -- and previous[idx] must
+    exist for every listed row."""
+    return [_evaluate_row(calculations, constants, rotations, cell, challenges, beta, gamma, theta, y, previous[idx], idx, rot_scale, isize)
+            for idx in rows]
+
+
+def cells_needed(rotations: Sequence[int], rows: Sequence[int], rot_scale: int, isize: int) -> List[int]:
+    """Every row index the program can read for the listed rows: (idx + rotation * rot_scale) mod isize over all its rotations."""
+    return sorted({(idx + r * rot_scale) % isize for idx in rows for r in list(rotations) + [0]})
 
 
 def evaluate_expression(e, fixed, advice, instance, challenges, idx: int, rot_scale: int, isize: int) -> int:

@@ -28,6 +28,14 @@ def test_mirror_selftest_runs_without_gpu(built):
     assert "mirror selftest ok" in r.stdout
 
 
+@pytest.mark.gpu
+def test_mirror_selftest_with_a_device(built):
+    """With a GPU the selftest also runs the host-vector EvaluationDomain steps (hm_coeff_to_extended_bn256_fr /
+    hm_extended_to_coeff_bn256_fr through cpp/domain.hpp): round trip and the value at zeta by Horner."""
+    r = subprocess.run([os.path.join(built, "mirror_selftest")], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "mirror selftest ok" in r.stdout, r.stdout + r.stderr
+
+
 def test_full_prover_replay_refuses_to_run_without_device(built):
     if _lib.load().hm_device_count() > 0:
         pytest.skip("a GPU is present")

@@ -621,7 +621,7 @@ def test_coset_transforms_at_the_smallest_sizes(pyref):
     assert lib.hm_coeff_to_coset_bn256_fr_dev(ctypes.c_void_p(a.data_ptr()), ctypes.c_void_p(out.data_ptr()), 0, _ptr(one), 1, _ptr(one), 0, None) == 0
 
 
-@pytest.mark.parametrize("k,j", [(4, 6), (10, 6), (13, 7), (16, 4)])
+@pytest.mark.parametrize("k,j", [(4, 6), (10, 6), (13, 7), (16, 4), (18, 6)])
 def test_a_polynomial_below_q_n_is_recovered_from_any_q_cosets(pyref, k, j):
     """The quotient of a satisfied circuit has fewer than n (j - 1) coefficients, so its values on j - 1 of the E cosets
     determine it: combine_cosets(cosets=[...]) solves the (j - 1) x (j - 1) Vandermonde system per residue class.  A random
