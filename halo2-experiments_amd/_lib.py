@@ -39,7 +39,8 @@ class Stats(ctypes.Structure):
                 ("ntt_calls_by_log2", ctypes.c_uint64 * 32), ("msm_h2d_us", ctypes.c_double), ("msm_device_us", ctypes.c_double),
                 ("msm_host_us", ctypes.c_double), ("ntt_h2d_us", ctypes.c_double), ("ntt_device_us", ctypes.c_double),
                 ("ntt_d2h_us", ctypes.c_double), ("h2d_bytes", ctypes.c_uint64), ("d2h_bytes", ctypes.c_uint64),
-                ("vector_calls", ctypes.c_uint64 * 8), ("vector_elements", ctypes.c_uint64 * 8)]
+                ("vector_calls", ctypes.c_uint64 * 8), ("vector_elements", ctypes.c_uint64 * 8),
+                ("coset_table_bytes", ctypes.c_uint64), ("coset_tables", ctypes.c_uint64)]
     KINDS = ("eval_polynomial", "graph_evaluate", "kate_division", "grand_product", "batch_invert", "linear_combination", "lookup_permute")
 
 

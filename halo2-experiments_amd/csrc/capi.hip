@@ -1171,6 +1171,8 @@ int hm_get_stats(hm_stats* out) try {
   out->ntt_h2d_us = c.ntt_h2d_us; out->ntt_device_us = c.ntt_device_us; out->ntt_d2h_us = c.ntt_d2h_us;
   out->h2d_bytes = c.h2d_bytes; out->d2h_bytes = c.d2h_bytes;
   for (int i = 0; i < 8; ++i) { out->vector_calls[i] = c.vector_calls[i]; out->vector_elements[i] = c.vector_elements[i]; }
+  out->coset_table_bytes = ctx->coset_table_bytes;
+  out->coset_tables = ctx->coset_tables.size();
   return HM_OK;
 } HM_API_CATCH("hm_get_stats")
 
@@ -1801,8 +1803,12 @@ int hm_quotient_combine_bn256_fr_dev(const void* const* d_partials, const uint64
   if (!d_partials || !shifts || !d_h) return hm_fail(HM_ERR_BAD_ARG, std::string(who) + ": null argument");
   if (log_n > 28 || log_n == 0) return hm_fail(HM_ERR_BAD_ARG, std::string(who) + ": log_n must be in 1 .. 28");
   if (count == 0 || count > 64 || pieces == 0 || pieces > count) return hm_fail(HM_ERR_BAD_ARG, std::string(who) + ": 1 <= pieces <= cosets <= 64");
-  for (size_t c = 0; c < count; ++c)
+  for (size_t c = 0; c < count; ++c) {
     if (!d_partials[c]) return hm_fail(HM_ERR_BAD_ARG, std::string(who) + ": null partial");
+    // piece t is written before piece t + 1 reads EVERY partial again: h must not share memory with any of them
+    if (ranges_overlap(d_h, ((size_t)32 << log_n) * pieces, d_partials[c], (size_t)32 << log_n))
+      return hm_fail(HM_ERR_BAD_ARG, std::string(who) + ": d_h overlaps a partial (recombining in place is not supported)");
+  }
   std::vector<std::vector<uint64_t>> rows;
   const int mrc = quotient_matrix(who, shifts, count, log_n, &rows);
   if (mrc != HM_OK) return mrc;

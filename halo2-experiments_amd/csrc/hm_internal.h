@@ -224,6 +224,7 @@ struct DeviceCtx {
   std::vector<std::unique_ptr<NttTables>> ntt_tables;
   std::vector<std::unique_ptr<CosetTable>> coset_tables;
   uint64_t coset_clock = 0;
+  size_t coset_table_bytes = 0;        // HBM held by coset_tables (capped: ntt.hip kCosetTableBytesMax)
   AuxSlot aux[HM_AUX_SLOTS];
   uint64_t aux_clock = 0;
   DevBuf io;              // staging for host-pointer calls (scalars / NTT array)

@@ -747,6 +747,7 @@ int ntt_run(DeviceCtx& ctx, uint32_t* d_a, const uint64_t omega_ext[4], uint32_t
 // different GPUs)
 // ---------------------------------------------------------------------------------------------
 constexpr size_t kCosetTablesMax = 48;
+constexpr size_t kCosetTableBytesMax = (size_t)2 << 30;      // 2 GiB of HBM held between calls at most (48 tables of 2^24 would be 24 GiB)
 
 void coset_tables_release(DeviceCtx& ctx) {
   for (auto& t : ctx.coset_tables) {
@@ -754,9 +755,33 @@ void coset_tables_release(DeviceCtx& ctx) {
     if (t->ready) (void)hipEventDestroy(t->ready);
   }
   ctx.coset_tables.clear();
+  ctx.coset_table_bytes = 0;
 }
 
-static const uint32_t* coset_table_get(DeviceCtx& ctx, const uint64_t shift_ext[4], uint32_t log_n, bool internal, hipStream_t stream) {
+// Evict the least recently used table that the CURRENT call has not asked for (last_use < keep_from: a call gathers up to 16
+// table pointers before it launches, so its own tables must stay).  A kernel in flight may still read the table that goes:
+// the device is synchronised first.  false = nothing evictable.
+static bool coset_table_evict_one(DeviceCtx& ctx, uint64_t keep_from, bool* synced) {
+  size_t oldest = ctx.coset_tables.size();
+  for (size_t i = 0; i < ctx.coset_tables.size(); ++i)
+    if (ctx.coset_tables[i]->last_use < keep_from && (oldest == ctx.coset_tables.size() || ctx.coset_tables[i]->last_use < ctx.coset_tables[oldest]->last_use))
+      oldest = i;
+  if (oldest == ctx.coset_tables.size()) return false;
+  if (!*synced) {
+    (void)hipDeviceSynchronize();
+    *synced = true;
+  }
+  CosetTable& t = *ctx.coset_tables[oldest];
+  if (t.d) (void)hipFree(t.d);
+  if (t.ready) (void)hipEventDestroy(t.ready);
+  ctx.coset_table_bytes -= (size_t)32 << t.log_n;
+  ctx.coset_tables.erase(ctx.coset_tables.begin() + oldest);
+  return true;
+}
+
+// keep_from: the coset clock when the calling entry point started (tables it has already been handed are not evicted under it)
+static const uint32_t* coset_table_get(DeviceCtx& ctx, const uint64_t shift_ext[4], uint32_t log_n, bool internal, hipStream_t stream,
+                                       uint64_t keep_from) {
   for (auto& t : ctx.coset_tables) {
     if (t->log_n == log_n && t->internal == (internal ? 1u : 0u) && std::memcmp(t->shift, shift_ext, 32) == 0) {
       if (!t->published) {
@@ -770,21 +795,24 @@ static const uint32_t* coset_table_get(DeviceCtx& ctx, const uint64_t shift_ext[
       return t->d;
     }
   }
-  if (ctx.coset_tables.size() >= kCosetTablesMax) {        // rare: a kernel in flight may still read the table that goes
-    HM_HIP_CHECK_PTR(hipDeviceSynchronize());
-    size_t oldest = 0;
-    for (size_t i = 1; i < ctx.coset_tables.size(); ++i)
-      if (ctx.coset_tables[i]->last_use < ctx.coset_tables[oldest]->last_use) oldest = i;
-    if (ctx.coset_tables[oldest]->d) (void)hipFree(ctx.coset_tables[oldest]->d);
-    if (ctx.coset_tables[oldest]->ready) (void)hipEventDestroy(ctx.coset_tables[oldest]->ready);
-    ctx.coset_tables.erase(ctx.coset_tables.begin() + oldest);
+  const uint64_t n = 1ull << log_n;
+  const size_t bytes = (size_t)n * 32;
+  bool synced = false;
+  // bounded by count AND by bytes (LRU); the cap is soft for ONE call's own working set (nothing evictable: go on)
+  while ((ctx.coset_tables.size() >= kCosetTablesMax || ctx.coset_table_bytes + bytes > kCosetTableBytesMax) &&
+         coset_table_evict_one(ctx, keep_from, &synced)) {
   }
   auto t = std::make_unique<CosetTable>();
   std::memcpy(t->shift, shift_ext, 32);
   t->log_n = log_n;
   t->internal = internal ? 1u : 0u;
-  const uint64_t n = 1ull << log_n;
-  bool ok = hipMalloc(&t->d, n * 32) == hipSuccess;
+  bool ok = hipMalloc(&t->d, bytes) == hipSuccess;
+  while (!ok) {                                            // out of memory: the cache gives back what it can, one table at a time
+    (void)hipGetLastError();
+    t->d = nullptr;
+    if (!coset_table_evict_one(ctx, keep_from, &synced)) break;
+    ok = hipMalloc(&t->d, bytes) == hipSuccess;
+  }
   if (!ok) t->d = nullptr;
   const host::Fr4 c = internal ? host::fr_mul(host::FR_32, host::FR_32) : host::FR_32;       // 1024 resp. 32, Montgomery words
   if (ok) ok = fr_powers_run(t->d, n, shift_ext, stream) == HM_OK && fr_scale_run(t->d, c.l, n, stream) == HM_OK;
@@ -799,6 +827,7 @@ static const uint32_t* coset_table_get(DeviceCtx& ctx, const uint64_t shift_ext[
   }
   t->build_stream = stream;
   t->last_use = ++ctx.coset_clock;
+  ctx.coset_table_bytes += bytes;
   ctx.coset_tables.push_back(std::move(t));
   return ctx.coset_tables.back()->d;
 }
@@ -807,7 +836,7 @@ int ntt_coset_run(DeviceCtx& ctx, const uint32_t* d_in, uint32_t* d_out, uint32_
                   const uint64_t shift_ext[4], bool internal, hipStream_t stream) {
   if (log_n > 28) return hm_fail(HM_ERR_BAD_ARG, "ntt: log_n > 28 (Fr has 2-adicity 28)");
   if (batch == 0) return HM_OK;
-  const uint32_t* table = coset_table_get(ctx, shift_ext, log_n, internal, stream);
+  const uint32_t* table = coset_table_get(ctx, shift_ext, log_n, internal, stream, ctx.coset_clock + 1);
   if (!table) return HM_ERR_HIP;
   NttFused f;
   f.d_in_scale = table;
@@ -821,8 +850,9 @@ int ntt_cosets_run(DeviceCtx& ctx, const uint32_t* d_in, uint32_t* d_out, uint32
   if (count > HM_NTT_COSETS_MAX) return hm_fail(HM_ERR_BAD_ARG, "ntt: more than 16 cosets per call");
   NttFused f;
   f.n_in_scales = count;
+  const uint64_t mine = ctx.coset_clock + 1;               // the tables handed out from here on belong to this call
   for (uint32_t c = 0; c < count; ++c) {
-    f.d_in_scales[c] = coset_table_get(ctx, shifts_ext + 4 * c, log_n, internal, stream);
+    f.d_in_scales[c] = coset_table_get(ctx, shifts_ext + 4 * c, log_n, internal, stream, mine);
     if (!f.d_in_scales[c]) return HM_ERR_HIP;
   }
   return ntt_run(ctx, d_out, omega_ext, log_n, batch, f, stream, d_in, 0);
@@ -835,8 +865,9 @@ int ntt_cosets_inverse_run(DeviceCtx& ctx, uint32_t* d_a, uint32_t count, const 
   if (count > HM_NTT_COSETS_MAX) return hm_fail(HM_ERR_BAD_ARG, "ntt: more than 16 cosets per call");
   NttCosetTables tabs{};
   tabs.count = count;
+  const uint64_t mine = ctx.coset_clock + 1;
   for (uint32_t c = 0; c < count; ++c) {
-    tabs.table[c] = coset_table_get(ctx, shift_invs_ext + 4 * c, log_n, false, stream);
+    tabs.table[c] = coset_table_get(ctx, shift_invs_ext + 4 * c, log_n, false, stream, mine);
     if (!tabs.table[c]) return HM_ERR_HIP;
   }
   NttFused f;
@@ -853,7 +884,7 @@ int ntt_coset_inverse_run(DeviceCtx& ctx, uint32_t* d_a, uint32_t batch, const u
                           const uint64_t divisor_ext[4], const uint64_t shift_inv_ext[4], hipStream_t stream) {
   if (log_n > 28) return hm_fail(HM_ERR_BAD_ARG, "ntt: log_n > 28 (Fr has 2-adicity 28)");
   if (batch == 0) return HM_OK;
-  const uint32_t* table = coset_table_get(ctx, shift_inv_ext, log_n, false, stream);
+  const uint32_t* table = coset_table_get(ctx, shift_inv_ext, log_n, false, stream, ctx.coset_clock + 1);
   if (!table) return HM_ERR_HIP;
   NttFused f;
   f.scale = divisor_ext;

@@ -98,11 +98,13 @@ class EvaluationDomain:
         self._ifft(a, self.omega_inv, self.k, self.ifft_divisor)
         return a
 
-    def coeff_to_extended(self, a, internal: bool = False):
+    def coeff_to_extended(self, a, internal: bool = False, out=None):
         """(n, 4) or (batch, n, 4) coefficient tensor -> new (2^extended_k, 4) / (batch, 2^extended_k, 4)
         tensor of evaluations on the zeta-coset.  ``internal``: the evaluations come out multiplied by 32 -- the form
         ``hm_graph_evaluate_flags_dev(HM_GRAPH_COLUMNS_INTERNAL)`` loads without a conversion product; the factor rides on the
-        coset constants the first NTT pass multiplies in anyway."""
+        coset constants the first NTT pass multiplies in anyway.  A ``numpy`` array takes the host-pointer form
+        (``hm_coeff_to_extended_bn256_fr``: n x 32 B up, 2^extended_k x 32 B down); ``out`` (host form only) receives the result
+        instead of a fresh array."""
         r = FR_MODULUS
         sc = 32 if internal else 1
         coset = np.concatenate([fr_words(sc), fr_words(sc * self.g_coset), fr_words(sc * self.g_coset * self.g_coset % r)])
@@ -113,7 +115,10 @@ class EvaluationDomain:
             src = _np(a, 4, "coeff_to_extended")
             if src.shape[0] != self.n:
                 raise ValueError(f"coeff_to_extended: expected ({self.n}, 4) words")
-            out = np.empty((en, 4), dtype=np.uint64)
+            if out is None:
+                out = np.empty((en, 4), dtype=np.uint64)        # fresh pages: the copy back takes their first-touch faults
+            elif not (isinstance(out, np.ndarray) and out.dtype == np.uint64 and out.shape == (en, 4) and out.flags["C_CONTIGUOUS"]):
+                raise ValueError(f"coeff_to_extended: out must be a C-contiguous ({en}, 4) uint64 array")
             _lib.check(_lib.load().hm_coeff_to_extended_bn256_fr(_ptr(src), _ptr(out), _ptr(fr_words(self.extended_omega)), self.k,
                                                                  self.extended_k, _ptr(coset)))
             return out

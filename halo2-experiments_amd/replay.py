@@ -548,7 +548,15 @@ def run_replay(shape_name: str, device=None, group=None, include_host_pointer_es
         # the two EvaluationDomain steps through their own host-pointer forms (the optional src/poly/domain.rs edits of rust/): the zero
         # padding never goes up, the truncated tail never comes down
         dom.coeff_to_extended(h_s)                                  # warm-up (staging buffer, twiddles)
-        t0 = time.perf_counter(); ext_h = dom.coeff_to_extended(h_s); t_c2e = time.perf_counter() - t0
+        t0 = time.perf_counter(); ext_h = dom.coeff_to_extended(h_s); t_c2e_fresh = time.perf_counter() - t0
+        # ... into a buffer whose pages exist already: the library's own time.  A fresh 2^extended_k x 32 B allocation (the Vec the
+        # Rust glue returns, numpy's here) costs first-touch page faults on top -- the same faults upstream's `resize` to the
+        # extended length takes BEFORE it calls best_fft, which the per-call best_fft figure above does not contain either
+        t0 = time.perf_counter(); dom.coeff_to_extended(h_s, out=ext_h); t_c2e = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        pad = np.empty((dom.extended_len(), 4), dtype=np.uint64); pad[:n] = h_s; pad[n:] = 0
+        t_resize = time.perf_counter() - t0
+        del pad
         dom.extended_to_coeff(ext_h.copy())
         t0 = time.perf_counter(); dom.extended_to_coeff(ext_h); t_e2c = time.perf_counter() - t0
         del ext_h
@@ -579,6 +587,9 @@ def run_replay(shape_name: str, device=None, group=None, include_host_pointer_es
         out["host_pointer_estimate_s"] = {
             "msm_batches_from_host_arrays": t_batch_host,
             "msm_each": t_msm, "ntt_n_each": t_ntt_n, "ntt_ext_each": t_ntt_e, "coeff_to_extended_each": t_c2e, "extended_to_coeff_each": t_e2c,
+            "coeff_to_extended_into_a_fresh_array_each": t_c2e_fresh, "host_zero_padding_each": t_resize,
+            "page_fault_note": "coeff_to_extended_each writes into touched pages; a fresh output array adds first-touch faults, as upstream's "
+                               "resize-to-extended-length (host_zero_padding_each, numpy here) does before best_fft in the other totals",
             "total": hp_total,
             "note": "PCIe-inclusive: every call uploads its scalars / moves its array both ways"}
     gate_prog.destroy()

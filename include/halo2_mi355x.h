@@ -459,6 +459,9 @@ typedef struct hm_stats {
   /* the entry points beyond the two functions, by HM_STAT_* kind: calls (queries / lookups where a call carries several)
    * and the field elements they covered */
   uint64_t vector_calls[8], vector_elements[8];
+  /* HBM the library holds between calls for the coset transforms' power tables (2^log_n x 32 B per (shift, log_n, form)): a
+   * state, not a counter -- hm_reset_stats leaves it.  LRU, at most 48 tables and 2 GiB; given back on an allocation failure. */
+  uint64_t coset_table_bytes, coset_tables;
 } hm_stats;
 #define HM_STAT_EVAL_POLYNOMIAL 0
 #define HM_STAT_GRAPH_EVALUATE 1

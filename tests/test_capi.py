@@ -83,6 +83,10 @@ def test_device_pointer_entry_points_without_a_device():
     assert lib.hm_quotient_partials_bn256_fr_dev(ctypes.c_uint64(1), one_col, None, 1, zp, 1, 3, zp, zp, 17, ctypes.c_void_p(0x9000), None) == -1   # > 16 cosets
     assert lib.hm_quotient_combine_bn256_fr_dev(one_col, zp, 1, 3, 2, ctypes.c_void_p(0x9000), None) == -1                              # pieces > cosets
     assert lib.hm_quotient_combine_bn256_fr_dev(one_col, zp, 1, 3, 1, ctypes.c_void_p(0x9000), None) == -1                              # a zero shift
+    nz = np.array([2, 0, 0, 0], dtype=np.uint64).ctypes.data_as(ctypes.POINTER(ctypes.c_uint64))
+    assert lib.hm_quotient_combine_bn256_fr_dev(one_col, nz, 1, 3, 1, ctypes.c_void_p(0x1000), None) == -1                              # h IS the partial
+    assert lib.hm_quotient_combine_bn256_fr_dev(one_col, nz, 1, 3, 1, ctypes.c_void_p(0x1000 + 8 * 32 - 32), None) == -1                # h overlaps its tail
+    assert b"overlaps a partial" in lib.hm_last_error()
     assert lib.hm_quotient_by_cosets_bn256_fr_dev(ctypes.c_uint64(1), one_col, None, 1, zp, 1, 3, zp, zp, 2, 3, ctypes.c_void_p(0x9000), None) == -1   # pieces > cosets
     assert lib.hm_quotient_by_cosets_bn256_fr_dev(ctypes.c_uint64(1), one_col, None, 1, zp, 1, 3, zp, zp, 1, 1, ctypes.c_void_p(0x9000), None) == -1   # a zero shift
     assert lib.hm_coeff_to_coset_bn256_fr_dev(ctypes.c_void_p(0x1000), ctypes.c_void_p(0x100000), 1, zp, 29, zp, 0, None) == -1      # log_n > 28

@@ -596,6 +596,56 @@ def test_coset_tables_survive_many_shifts_and_two_streams():
     assert bool((dom.coeff_to_coset(a, 5) == want[5::8]).all())             # rebuilt after eviction
 
 
+def test_coset_table_cache_is_bounded_by_bytes():
+    """The power tables of the coset transforms are kept between calls (LRU): at most 48 of them AND at most 2 GiB -- 48 tables of
+    2^24 elements would hold 24 GiB of HBM until hm_shutdown.  hm_get_stats reports what is held.  One call's own working
+    set may exceed the cap (16 cosets of 2^23 = 4 GiB: the call's tables are pinned while it gathers them); the next call trims it."""
+    import torch
+    from halo2_experiments_amd.arithmetic import _ptr, _stream_ptr
+    lib = _lib.load()
+
+    def held():
+        st = _lib.Stats()
+        _lib.check(lib.hm_get_stats(ctypes.byref(st)))
+        return st.coset_table_bytes, st.coset_tables
+
+    cap = 2 << 30
+    k = 22                                                                  # 128 MiB per table: the byte cap binds at 16 tables
+    from halo2_experiments_amd.domain import FR_MODULUS, FR_ROOT_OF_UNITY
+    a = rand_fr_gpu(1 << k, 4800)
+    omega = fr_words(pow(FR_ROOT_OF_UNITY, 1 << (28 - k), FR_MODULUS))
+    out = torch.empty_like(a)
+    first = None
+    for i in range(20):
+        _lib.check(lib.hm_coeff_to_coset_bn256_fr_dev(ctypes.c_void_p(a.data_ptr()), ctypes.c_void_p(out.data_ptr()), 1, _ptr(omega), k,
+                                                      _ptr(fr_words(2000 + i)), 0, ctypes.c_void_p(_stream_ptr(a))))
+        if i == 0:
+            first = out.clone()
+        b, cnt = held()
+        assert b <= cap and cnt <= 48 and b >= (32 << k), (i, b, cnt)
+    assert held()[0] == cap                                                 # 16 tables of 128 MiB: full, the four oldest went
+    _lib.check(lib.hm_coeff_to_coset_bn256_fr_dev(ctypes.c_void_p(a.data_ptr()), ctypes.c_void_p(out.data_ptr()), 1, _ptr(omega), k,
+                                                  _ptr(fr_words(2000)), 0, ctypes.c_void_p(_stream_ptr(a))))
+    assert bool((out == first).all())                                       # shift 2000 was evicted and rebuilt: same values
+    # one call that needs more than the cap by itself: 16 cosets at 2^23 (16 x 256 MiB)
+    k2 = 23
+    a2 = rand_fr_gpu(1 << k2, 4801)
+    omega2 = fr_words(pow(FR_ROOT_OF_UNITY, 1 << (28 - k2), FR_MODULUS))
+    shifts = np.stack([fr_words(3000 + i) for i in range(16)])
+    out2 = torch.empty((16, 1 << k2, 4), dtype=torch.int64, device="cuda")
+    _lib.check(lib.hm_coeff_to_cosets_bn256_fr_dev(ctypes.c_void_p(a2.data_ptr()), ctypes.c_void_p(out2.data_ptr()), 1, _ptr(omega2), k2,
+                                                   _ptr(shifts), 16, 0, ctypes.c_void_p(_stream_ptr(a2))))
+    assert held()[0] >= 16 * (32 << k2)                                     # soft for the call's own tables
+    one = torch.empty_like(a2)
+    for i in (0, 15):                                                       # ... whose results are those of the one-coset call
+        _lib.check(lib.hm_coeff_to_coset_bn256_fr_dev(ctypes.c_void_p(a2.data_ptr()), ctypes.c_void_p(one.data_ptr()), 1, _ptr(omega2), k2,
+                                                      _ptr(fr_words(3000 + i)), 0, ctypes.c_void_p(_stream_ptr(a2))))
+        assert bool((one == out2[i]).all()), i
+    _lib.check(lib.hm_coeff_to_coset_bn256_fr_dev(ctypes.c_void_p(a.data_ptr()), ctypes.c_void_p(out.data_ptr()), 1, _ptr(omega), k,
+                                                  _ptr(fr_words(2000)), 0, ctypes.c_void_p(_stream_ptr(a))))
+    assert held()[0] <= cap and bool((out == first).all())                  # the next call that builds a table trims the cache
+
+
 def test_coset_transforms_at_the_smallest_sizes(pyref):
     """log_n = 0 and 1 through the C entry points themselves (EvaluationDomain starts at k = 1): one element is its own
     transform on any coset; two elements a0 + a1 X at shift and -shift."""
