@@ -79,16 +79,18 @@ __device__ __forceinline__ Fr ge_from_internal(const uint32_t* __restrict__ p) {
 
 // The call's column table and per-call constants (2.6 KiB) travel through a DEVICE buffer of the stream's AuxSlot,
 // filled by a stream-ordered copy ahead of the launch.  Rounds 1-2 passed the struct by value, and a variant with a
-// BYTE table in it (the columns' periods) aborted at run time.  Cause (round 4, tools/ubench/kernarg_byval.hip,
-// profiles/r04_kernarg_byval.txt): nothing to do with the argument's size (3 176 bytes of kernarg, limit 4 096; no
-// scratch) -- a dynamically indexed table of 32- or 64-bit entries in a by-value argument is read with SCALAR loads from
-// the kernarg segment (s_load_dword s, s[0:1], s_off), which work, but a table of BYTES cannot be (s_load has no
+// BYTE table in it (the columns' periods) aborted at run time.  What is known (tools/ubench/kernarg_byval.hip,
+// profiles/r04_kernarg_byval.txt, profiles/r05_kernarg_isa.txt): not the argument's size (3 176 bytes of kernarg, limit
+// 4 096; no scratch).  A dynamically indexed table of 32- or 64-bit entries in a by-value argument is read with SCALAR
+// loads from the kernarg segment (s_load_dword s, s[0:1], s_off), which work; a table of BYTES cannot be (s_load has no
 // sub-dword form), so the compiler emits a VECTOR load addressed through the kernarg pointer (global_load_ubyte v, v,
-// s[0:1] offset:...), and on this stack that load faults: the same stand-alone kernel runs without the byte table and
-// dies with it (GPU fault, process killed).  A divergent index into a word table would take the same vector path.  The
-// kernel therefore takes ONE pointer to a device copy: every table access is an ordinary global load, and the argument
-// block is 72 bytes whatever the program's shape.  tests/test_evaluation.py runs 256 columns, short-period columns
-// and 16 per-call constants through it.
+// s[0:1] offset:...).  A stand-alone kernel of that shape faulted ONCE on this stack and runs without the byte table --
+// a correlation, not an established cause: the load is legal ISA, s[0:1] is intact and the offset in range.  HYPOTHESIS:
+// the vector path cannot read the runtime's kernarg buffer here.  The library does not rest on it: this kernel takes ONE
+// pointer to a device copy (every table access an ordinary global load, a 72-byte argument block whatever the program's
+// shape), and tests/test_isa.py asserts on the built objects that no kernel of the library addresses a vector memory
+// instruction through its kernarg pointer.  tests/test_evaluation.py runs 256 columns, short-period columns and 16
+// per-call constants through it.
 constexpr uint32_t GE_MAX_COLUMNS = 256;
 constexpr uint32_t GE_MAX_DYN = 16;
 struct GraphColumns {
