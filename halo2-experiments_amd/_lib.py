@@ -40,7 +40,8 @@ class Stats(ctypes.Structure):
                 ("msm_host_us", ctypes.c_double), ("ntt_h2d_us", ctypes.c_double), ("ntt_device_us", ctypes.c_double),
                 ("ntt_d2h_us", ctypes.c_double), ("h2d_bytes", ctypes.c_uint64), ("d2h_bytes", ctypes.c_uint64),
                 ("vector_calls", ctypes.c_uint64 * 8), ("vector_elements", ctypes.c_uint64 * 8),
-                ("coset_table_bytes", ctypes.c_uint64), ("coset_tables", ctypes.c_uint64)]
+                ("coset_table_bytes", ctypes.c_uint64), ("coset_tables", ctypes.c_uint64),
+                ("ntt_table_bytes", ctypes.c_uint64), ("ntt_tables", ctypes.c_uint64)]
     KINDS = ("eval_polynomial", "graph_evaluate", "kate_division", "grand_product", "batch_invert", "linear_combination", "lookup_permute")
 
 

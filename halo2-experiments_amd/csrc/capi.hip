@@ -296,6 +296,7 @@ int hm_shutdown(void) try {
   (void)hipDeviceSynchronize();
   for (auto& t : c.ntt_tables) ntt_tables_release(*t);
   c.ntt_tables.clear();
+  c.ntt_table_bytes = 0;
   coset_tables_release(c);
   for (auto* list : {&c.bases, &c.zombie_bases}) {
     for (auto& b : *list) {
@@ -1173,6 +1174,8 @@ int hm_get_stats(hm_stats* out) try {
   for (int i = 0; i < 8; ++i) { out->vector_calls[i] = c.vector_calls[i]; out->vector_elements[i] = c.vector_elements[i]; }
   out->coset_table_bytes = ctx->coset_table_bytes;
   out->coset_tables = ctx->coset_tables.size();
+  out->ntt_table_bytes = ctx->ntt_table_bytes;
+  out->ntt_tables = ctx->ntt_tables.size();
   return HM_OK;
 } HM_API_CATCH("hm_get_stats")
 

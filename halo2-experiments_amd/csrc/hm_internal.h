@@ -89,6 +89,8 @@ struct NttTables {
   uint32_t* d_hi = nullptr;
   uint32_t* d_mid = nullptr;   // direct twiddles of the middle pass of a 3-pass plan
   uint32_t* d_stage[16] = {};
+  size_t bytes = 0;            // device memory of all of the above
+  uint64_t last_use = 0;       // ctx.ntt_table_clock at the last ntt_get_tables hit (LRU)
 };
 
 // The powers table of a transform on a coset shift * <omega> (ntt.hip: coset_table_get): n external words holding
@@ -221,7 +223,9 @@ struct CallStats {
 struct DeviceCtx {
   int device = 0;
   std::mutex mu;
-  std::vector<std::unique_ptr<NttTables>> ntt_tables;
+  std::vector<std::unique_ptr<NttTables>> ntt_tables;   // LRU, bounded by count and bytes (ntt.hip: kNttTablesMax, kNttTableBytesMax)
+  size_t ntt_table_bytes = 0;
+  uint64_t ntt_table_clock = 0;
   std::vector<std::unique_ptr<CosetTable>> coset_tables;
   uint64_t coset_clock = 0;
   size_t coset_table_bytes = 0;        // HBM held by coset_tables (capped: ntt.hip kCosetTableBytesMax)

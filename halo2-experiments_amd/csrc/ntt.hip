@@ -492,7 +492,16 @@ __global__ void fr_mul_pattern3_kernel(uint32_t* a, FrWords3 c3_ext, uint64_t n)
 #define HM_NTT_LOG_TILE 11
 #endif
 constexpr int LOG_TILE = HM_NTT_LOG_TILE;
-constexpr uint32_t NTT_DIRECT_LOG = 16;   // sub-problems up to 2^16 get a direct inter-pass twiddle table (2.4 MB)
+// Sub-problems up to 2^NTT_DIRECT_LOG get a DIRECT inter-pass twiddle table (omega_m^e for every e < m, 36 B per entry: 75 MB at
+// 2^21) instead of two sqrt-sized tables and a forming product per element.  Round 5 (tools/ntt_plans.py, profiles/r05_ntt_plans.txt):
+// 16 -> 21 together with the smaller digit first takes 6.7 % of the VALU instructions out of a 2^21 transform (3 328 -> 3 105 lane
+// instructions per element) and 4-6 % off every prover-sized shape (48 x 2^21: 11.5 -> 10.9 ms); the table is read as 36-byte
+// gathers and the transform stays VALU-bound.  Beyond 2^21 the plan has three passes and only its middle pass can be direct.
+#ifndef HM_NTT_DIRECT_LOG
+#define HM_NTT_DIRECT_LOG 21
+#endif
+constexpr uint32_t NTT_DIRECT_LOG = HM_NTT_DIRECT_LOG;
+// (a direct first-pass table is used by two-pass plans only: in a three-pass plan the first pass's m is n but the middle pass's is not)
 
 static int plan_digits(uint32_t log_n, uint32_t digits[3]) {
   if (log_n <= (uint32_t)LOG_TILE) {
@@ -510,6 +519,9 @@ static int plan_digits(uint32_t log_n, uint32_t digits[3]) {
     digits[p] = (rem + (passes - p) - 1) / (passes - p);
     rem -= digits[p];
   }
+#ifndef HM_NTT_LARGE_FIRST      // two passes: the smaller digit first (2^21 = 2^10 x 2^11): the first pass then has two columns per tile
+  if (passes == 2 && digits[0] > digits[1]) { const uint32_t t = digits[0]; digits[0] = digits[1]; digits[1] = t; }
+#endif
   return passes;
 }
 
@@ -518,6 +530,9 @@ int ntt_plan_first_digit(uint32_t log_n, int* passes) {
   *passes = plan_digits(log_n, digits);
   return (int)digits[0];
 }
+
+constexpr size_t kNttTablesMax = 64;
+constexpr size_t kNttTableBytesMax = (size_t)1 << 30;        // 1 GiB: a prover keeps four (omega, omega^-1 at k and extended_k): < 200 MB
 
 void ntt_tables_release(NttTables& t) {
   if (t.d_lo) (void)hipFree(t.d_lo);
@@ -541,7 +556,26 @@ NttTables* ntt_get_tables(DeviceCtx& ctx, const uint64_t omega_ext[4], uint32_t 
           HM_HIP_CHECK_PTR(hipStreamWaitEvent(stream, t->ready, 0));
         }
       }
+      t->last_use = ++ctx.ntt_table_clock;
       return t.get();
+    }
+  }
+  // bounded (LRU): with direct tables up to 75 MB a caller that walks through many roots of unity must not keep them all.  A kernel
+  // in flight on another stream may still read the set that goes: the device is synchronised first (rare: a prover uses four sets).
+  {
+    const size_t guess = log_n > (uint32_t)LOG_TILE && log_n <= NTT_DIRECT_LOG ? ((size_t)36 << log_n) : ((size_t)36 << ((log_n + 1) / 2 + 1));
+    bool synced = false;
+    while (!ctx.ntt_tables.empty() && (ctx.ntt_tables.size() >= kNttTablesMax || ctx.ntt_table_bytes + guess > kNttTableBytesMax)) {
+      if (!synced) {
+        (void)hipDeviceSynchronize();
+        synced = true;
+      }
+      size_t oldest = 0;
+      for (size_t i = 1; i < ctx.ntt_tables.size(); ++i)
+        if (ctx.ntt_tables[i]->last_use < ctx.ntt_tables[oldest]->last_use) oldest = i;
+      ctx.ntt_table_bytes -= ctx.ntt_tables[oldest]->bytes;
+      ntt_tables_release(*ctx.ntt_tables[oldest]);
+      ctx.ntt_tables.erase(ctx.ntt_tables.begin() + oldest);
     }
   }
   auto t = std::make_unique<NttTables>();
@@ -556,11 +590,12 @@ NttTables* ntt_get_tables(DeviceCtx& ctx, const uint64_t omega_ext[4], uint32_t 
   auto make = [&](uint32_t count, uint32_t shift, uint32_t** dst) {
     if (!ok) return;
     if (hipMalloc(dst, (size_t)count * 36) != hipSuccess) { *dst = nullptr; ok = false; return; }
+    t->bytes += (size_t)count * 36;
     hipLaunchKernelGGL(ntt_pow_table_kernel, dim3((count + 127) / 128), dim3(128), 0, stream, om, *dst, count, shift);
     if (hipGetLastError() != hipSuccess) ok = false;
   };
   if (passes > 1) {
-    if (log_n <= NTT_DIRECT_LOG) {
+    if (log_n <= NTT_DIRECT_LOG && passes == 2) {
       make(1u << log_n, 0, &t->d_lo);                                              // omega_n^e for every e < n
     } else {
       make(1u << t->log_lb, 0, &t->d_lo);
@@ -585,6 +620,8 @@ NttTables* ntt_get_tables(DeviceCtx& ctx, const uint64_t omega_ext[4], uint32_t 
     return nullptr;
   }
   t->build_stream = stream;
+  t->last_use = ++ctx.ntt_table_clock;
+  ctx.ntt_table_bytes += t->bytes;
   ctx.ntt_tables.push_back(std::move(t));
   return ctx.ntt_tables.back().get();
 }
@@ -713,7 +750,7 @@ int ntt_run(DeviceCtx& ctx, uint32_t* d_a, const uint64_t omega_ext[4], uint32_t
     uint32_t* dst = (p == passes - 1) ? d_a : scratch;
     const uint32_t* lo_tab = tab->d_lo;
     if (!pp.last) {
-      if (log_n <= NTT_DIRECT_LOG) {
+      if (log_n <= NTT_DIRECT_LOG && passes == 2) {
         pp.direct_tw = 1;            // d_lo = omega_n^e; omega_m^e = omega_n^(e << (log_n - log_m)) only for p == 0 (m = n)
       } else if (p == 1 && tab->d_mid) {
         pp.direct_tw = 1;

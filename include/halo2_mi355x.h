@@ -462,6 +462,9 @@ typedef struct hm_stats {
   /* HBM the library holds between calls for the coset transforms' power tables (2^log_n x 32 B per (shift, log_n, form)): a
    * state, not a counter -- hm_reset_stats leaves it.  LRU, at most 48 tables and 2 GiB; given back on an allocation failure. */
   uint64_t coset_table_bytes, coset_tables;
+  /* ... and for the twiddle tables of the transforms, one set per (omega, log_n): stage tables, and up to 2^21 a direct inter-pass
+   * table of 2^log_n x 36 B (75 MB at 2^21).  LRU, at most 64 sets and 1 GiB. */
+  uint64_t ntt_table_bytes, ntt_tables;
 } hm_stats;
 #define HM_STAT_EVAL_POLYNOMIAL 0
 #define HM_STAT_GRAPH_EVALUATE 1

@@ -646,6 +646,37 @@ def test_coset_table_cache_is_bounded_by_bytes():
     assert held()[0] <= cap and bool((out == first).all())                  # the next call that builds a table trims the cache
 
 
+def test_twiddle_table_cache_is_bounded(cref):
+    """One set of twiddle tables per (omega, log_n), kept between calls: with the direct inter-pass table (75 MB at 2^21) a caller that walks
+    through many roots of unity would pile them up -- LRU, at most 64 sets and 1 GiB; results after an eviction are those before it."""
+    from halo2_experiments_amd.domain import FR_MODULUS, FR_ROOT_OF_UNITY
+    lib = _lib.load()
+
+    def held():
+        st = _lib.Stats()
+        _lib.check(lib.hm_get_stats(ctypes.byref(st)))
+        return st.ntt_table_bytes, st.ntt_tables
+
+    k = 21
+    w = pow(FR_ROOT_OF_UNITY, 1 << (28 - k), FR_MODULUS)
+    a0 = rand_fr_gpu(1 << k, 4900)
+    first = a0.clone()
+    h.best_fft(first, fr_words(w), k)
+    for e in range(3, 3 + 2 * 18, 2):                                       # 18 more primitive 2^21-th roots: w^odd
+        a = a0.clone()
+        h.best_fft(a, fr_words(pow(w, e, FR_MODULUS)), k)
+        b, cnt = held()
+        assert 0 < b <= (1 << 30) and cnt <= 64, (e, b, cnt)
+    assert held()[0] > (1 << 30) - (80 << 20)                               # thirteen 75 MB sets fit 1 GiB; the first ones went
+    again = a0.clone()
+    h.best_fft(again, fr_words(w), k)                                       # rebuilt
+    assert bool((again == first).all())
+    small = a0[: 1 << 12].clone()
+    exp = cref.best_fft(small.cpu().numpy().view(np.uint64), fr_words(pow(w, 1 << 9, FR_MODULUS)), 12)
+    h.best_fft(small, fr_words(pow(w, 1 << 9, FR_MODULUS)), 12)
+    assert np.array_equal(small.cpu().numpy().view(np.uint64), exp)
+
+
 def test_coset_transforms_at_the_smallest_sizes(pyref):
     """log_n = 0 and 1 through the C entry points themselves (EvaluationDomain starts at k = 1): one element is its own
     transform on any coset; two elements a0 + a1 X at shift and -shift."""
