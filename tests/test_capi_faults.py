@@ -113,6 +113,35 @@ def test_faults_in_the_drop_in_call(fi, cref):
 
 
 @pytest.mark.gpu
+def test_the_prefault_helpers_are_optional(fi):
+    """hm_coeff_to_extended_bn256_fr first-touches its (normally fresh) 2^log_ext x 32 B output from helper threads while the
+    transform runs: helpers that cannot be started leave their pages to the copy -- same result, no error."""
+    from halo2_experiments_amd.domain import EvaluationDomain, fr_words
+    d = EvaluationDomain(7, 15)                            # 2^18 x 32 B = 8 MiB out: above the 4 MiB threshold of the prefault
+    n, en = d.n, d.extended_len()
+    coeffs = _rand_fr(n, 9150).cpu().numpy().view(np.uint64).copy()
+    coset = np.concatenate([fr_words(1), fr_words(d.g_coset), fr_words(d.g_coset * d.g_coset)])
+    def run():
+        out = np.empty((en, 4), dtype=np.uint64)           # fresh pages
+        rc = fi.hm_coeff_to_extended_bn256_fr(_u64(coeffs), _u64(out), _u64(fr_words(d.extended_omega)), d.k, d.extended_k, _u64(coset))
+        return rc, out
+    rc, want = run()
+    assert rc == 0
+    fi.hm_test_arm_fault(b"prefault", 0)                   # not even the first helper thread can be had
+    rc, got = run()
+    assert rc == 0 and np.array_equal(got, want)
+    fi.hm_test_arm_fault(b"prefault", 2)                   # the third cannot
+    rc, got = run()
+    assert rc == 0 and np.array_equal(got, want)
+    fi.hm_test_arm_fault(None, 0)
+    back = got.copy()                                      # ... and in place on the allocation the coefficients live in: contents kept
+    buf = np.zeros((en, 4), dtype=np.uint64)
+    buf[:n] = coeffs
+    assert fi.hm_coeff_to_extended_bn256_fr(_u64(buf), _u64(buf), _u64(fr_words(d.extended_omega)), d.k, d.extended_k, _u64(coset)) == 0
+    assert np.array_equal(buf, back)
+
+
+@pytest.mark.gpu
 def test_faults_in_the_multi_device_workers(fi, cref):
     """hm_set_msm_devices((0, 0, 0)): a worker thread that cannot be started hands its part to the calling thread; a throw
     inside a worker comes back as an error code from the caller's call (and the other workers are joined, not abandoned)."""
