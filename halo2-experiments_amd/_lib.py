@@ -41,7 +41,8 @@ class Stats(ctypes.Structure):
                 ("ntt_d2h_us", ctypes.c_double), ("h2d_bytes", ctypes.c_uint64), ("d2h_bytes", ctypes.c_uint64),
                 ("vector_calls", ctypes.c_uint64 * 8), ("vector_elements", ctypes.c_uint64 * 8),
                 ("coset_table_bytes", ctypes.c_uint64), ("coset_tables", ctypes.c_uint64),
-                ("ntt_table_bytes", ctypes.c_uint64), ("ntt_tables", ctypes.c_uint64)]
+                ("ntt_table_bytes", ctypes.c_uint64), ("ntt_tables", ctypes.c_uint64),
+                ("host_copy_stalls", ctypes.c_uint64), ("host_copy_lanes", ctypes.c_uint64)]
     KINDS = ("eval_polynomial", "graph_evaluate", "kate_division", "grand_product", "batch_invert", "linear_combination", "lookup_permute")
 
 
@@ -99,6 +100,7 @@ _SIGNATURES = {
     "hm_set_fixed_base_threshold": (ctypes.c_int, [ctypes.c_uint32]),
     "hm_set_msm_devices": (ctypes.c_int, [ctypes.POINTER(ctypes.c_int), ctypes.c_int]),
     "hm_ntt_bn256_fr": (ctypes.c_int, [_u64p, _u64p, ctypes.c_uint32]),
+    "hm_set_host_copies": (ctypes.c_int, [ctypes.c_int]),
     "hm_coeff_to_extended_bn256_fr": (ctypes.c_int, [_u64p, _u64p, _u64p, ctypes.c_uint32, ctypes.c_uint32, _u64p]),
     "hm_extended_to_coeff_bn256_fr": (ctypes.c_int, [_u64p, ctypes.c_size_t, _u64p, ctypes.c_uint32, _u64p, _u64p]),
     "hm_ntt_bn256_fr_dev": (ctypes.c_int, [_vp, _u64p, ctypes.c_uint32, _vp]),

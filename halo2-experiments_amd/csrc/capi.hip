@@ -251,7 +251,10 @@ int msm_h_local(uint64_t handle, size_t offset, const uint64_t* scalars, size_t 
   void* d_s = ctx->io.ensure(n ? n * 32 : 32);
   if (!d_s) return hm_fail(HM_ERR_HIP, "hm_msm_bn256_g1_h: staging allocation failed");
   const double t0 = now_us();
-  HM_HIP_CHECK(hipMemcpy(d_s, scalars, n * 32, hipMemcpyHostToDevice));
+  {
+    const int rc = xfer_h2d(*ctx, d_s, scalars, n * 32, "hm_msm_bn256_g1_h: scalar upload");
+    if (rc != HM_OK) return rc;
+  }
   ctx->calls.msm_h2d_us += now_us() - t0;
   ctx->calls.h2d_bytes += n * 32;
   const uint32_t pc = (offset == 0 && n == b->n) ? b->pc_c : 0u;
@@ -297,6 +300,7 @@ int hm_shutdown(void) try {
   for (auto& t : c.ntt_tables) ntt_tables_release(*t);
   c.ntt_tables.clear();
   c.ntt_table_bytes = 0;
+  xfer_release(c);
   coset_tables_release(c);
   for (auto* list : {&c.bases, &c.zombie_bases}) {
     for (auto& b : *list) {
@@ -354,6 +358,11 @@ int hm_set_host_base_cache(int enable) try {
   return HM_OK;
 } HM_API_CATCH("hm_set_host_base_cache")
 
+int hm_set_host_copies(int mode) try {
+  if (xfer_set_policy(mode) != 0) return hm_fail(HM_ERR_BAD_ARG, "hm_set_host_copies: mode must be 0 (auto), 1 (lanes) or 2 (direct)");
+  return HM_OK;
+} HM_API_CATCH("hm_set_host_copies")
+
 int hm_msm_set_window(int c) try {
   if (c != 0 && (c < 2 || c > 22)) return hm_fail(HM_ERR_BAD_ARG, "hm_msm_set_window: c must be 0 or in [2, 22]");
   msm_set_window_override(c);
@@ -383,7 +392,10 @@ static int register_entry(const char* who, const uint64_t* bases_host, const voi
   if (bases_host) {
     void* stage = ctx->io_bases.ensure(n ? n * 64 : 64);
     if (!stage) return hm_fail(HM_ERR_HIP, std::string(who) + ": staging allocation failed");
-    HM_HIP_CHECK(hipMemcpy(stage, bases_host, n * 64, hipMemcpyHostToDevice));
+    {
+      const int rc = xfer_h2d(*ctx, stage, bases_host, n * 64, who);
+      if (rc != HM_OK) return rc;
+    }
     d_ext = (const uint32_t*)stage;
     st = nullptr;
   }
@@ -799,13 +811,15 @@ static int msm_batch_impl(DeviceCtx* ctx, uint64_t handle, size_t offset, const 
         submit_error = hm_last_error();
         break;
       }
-      hipError_t herr = hipSuccess;
-      for (uint32_t e = 0; e < group && herr == hipSuccess; ++e) {
-        herr = hipMemcpyAsync(buf + (size_t)e * n * 32, staged[e], n * 32, hipMemcpyHostToDevice, ctx->batch_streams[lane]);
+      // through the library's pinned lanes (xfer.hip), synchronous for this thread: the other lanes' chains compute meanwhile, and
+      // this lane's chain is submitted behind it (a pageable hipMemcpyAsync blocked the submitting thread just the same)
+      int xrc = HM_OK;
+      for (uint32_t e = 0; e < group && xrc == HM_OK; ++e) {
+        xrc = xfer_h2d(*ctx, buf + (size_t)e * n * 32, staged[e], n * 32, "hm_msm_batch_bn256_g1_h: scalar upload");
         staged[e] = buf + (size_t)e * n * 32;
       }
-      if (herr != hipSuccess) {
-        submit_rc.store(hm_fail(HM_ERR_HIP, std::string("hm_msm_batch_bn256_g1_h: H2D copy: ") + hipGetErrorString(herr)));
+      if (xrc != HM_OK) {
+        submit_rc.store(xrc);
         submit_error = hm_last_error();
         break;
       }
@@ -1071,8 +1085,9 @@ static int msm_host_one(const uint64_t* scalars, const uint64_t* bases, size_t n
     ctx->cached_host_n = 0;
     void* stage = ctx->io_bases.ensure(n * 64);
     if (!stage) return hm_fail(HM_ERR_HIP, "hm_msm_bn256_g1: staging allocation failed");
-    HM_HIP_CHECK(hipMemcpy(stage, bases, n * 64, hipMemcpyHostToDevice));
-    int rc = msm_convert_bases((const uint32_t*)stage, d_xy, d_inf, n, nullptr);
+    int rc = xfer_h2d(*ctx, stage, bases, n * 64, "hm_msm_bn256_g1: base upload");
+    if (rc != HM_OK) return rc;
+    rc = msm_convert_bases((const uint32_t*)stage, d_xy, d_inf, n, nullptr);
     if (rc != HM_OK) return rc;
     ctx->calls.h2d_bytes += n * 64;
     if (use_cache) {
@@ -1081,7 +1096,10 @@ static int msm_host_one(const uint64_t* scalars, const uint64_t* bases, size_t n
       std::memcpy(ctx->cached_digest, dg, sizeof dg);
     }
   }
-  HM_HIP_CHECK(hipMemcpy(d_s, scalars, n * 32, hipMemcpyHostToDevice));
+  {
+    const int rc = xfer_h2d(*ctx, d_s, scalars, n * 32, "hm_msm_bn256_g1: scalar upload");
+    if (rc != HM_OK) return rc;
+  }
   ctx->calls.msm_h2d_us += now_us() - t0;
   ctx->calls.h2d_bytes += n * 32;
   int rc = msm_run(*ctx, (const uint32_t*)d_s, d_xy, d_inf, n, 0, jac, is_id, nullptr);
@@ -1176,6 +1194,8 @@ int hm_get_stats(hm_stats* out) try {
   out->coset_tables = ctx->coset_tables.size();
   out->ntt_table_bytes = ctx->ntt_table_bytes;
   out->ntt_tables = ctx->ntt_tables.size();
+  out->host_copy_stalls = ctx->xfer.stalls.load(std::memory_order_relaxed);
+  out->host_copy_lanes = (uint64_t)xfer_mode(*ctx);
   return HM_OK;
 } HM_API_CATCH("hm_get_stats")
 
@@ -1261,34 +1281,6 @@ int hm_coeff_to_extended_bn256_fr_dev(const void* d_coeffs, void* d_ext, size_t 
   return coeff_to_extended_locked(ctx, d_coeffs, d_ext, batch, extended_omega, log_n, log_ext, coset, stream);
 } HM_API_CATCH("hm_coeff_to_extended_bn256_fr_dev")
 
-// First-touch the pages of a host range from several threads, WITHOUT changing its contents (every page's first byte is read and
-// written back).  A copy from the device into memory the process has never touched takes its page faults one by one inside the
-// runtime's staging loop: measured 17 ms for a fresh 64 MiB array against 1.3 ms into touched pages, and the fresh array is the normal
-// case of EvaluationDomain::coeff_to_extended's result (a new Vec of 2^extended_k elements; upstream's own `resize` pays the same
-// faults single-threaded, ~4 ms).  Run while the transform is in flight; threads that cannot be started just leave their share to the
-// copy.  Nothing here can fail the call.
-static void prefault_pages(void* p, size_t bytes) {
-  constexpr size_t kPage = 4096;
-  if (bytes < ((size_t)4 << 20)) return;
-  unsigned nt = std::thread::hardware_concurrency();
-  nt = nt == 0 ? 4u : (nt > 8u ? 8u : nt);
-  volatile unsigned char* base = (volatile unsigned char*)p;
-  auto touch = [base, bytes](size_t lo, size_t hi) {
-    for (size_t off = lo; off < hi && off < bytes; off += kPage) {
-      const unsigned char v = base[off];
-      base[off] = v;
-    }
-  };
-  const size_t share = ((bytes / nt) / kPage + 1) * kPage;
-  JoinOnExit pool;
-  for (unsigned t = 1; t < nt; ++t) {
-    const size_t lo = (size_t)t * share, hi = lo + share;
-    if (lo >= bytes) break;
-    if (!spawn_or_false(pool, "prefault", [touch, lo, hi] { touch(lo, hi); })) break;
-  }
-  touch(0, share);
-}
-
 // Host-pointer forms of the two EvaluationDomain steps that cross PCIe in a drop-in prover: only what upstream's arrays really
 // hold travels -- the 2^log_n coefficients up (never the zero padding), the first `keep` coefficients down (never the part
 // extended_to_coeff truncates).
@@ -1304,19 +1296,21 @@ int hm_coeff_to_extended_bn256_fr(const uint64_t* coeffs, uint64_t* ext, const u
   if (!d_out) return hm_fail(HM_ERR_HIP, "hm_coeff_to_extended_bn256_fr: staging allocation failed");
   char* d_in = d_out + bytes_out;
   const double t0 = now_us();
-  HM_HIP_CHECK(hipMemcpy(d_in, coeffs, bytes_in, hipMemcpyHostToDevice));
+  {
+    const int rc = xfer_h2d(*ctx, d_in, coeffs, bytes_in, "hm_coeff_to_extended_bn256_fr: upload");
+    if (rc != HM_OK) return rc;
+  }
   const double t1 = now_us();
   const int rc = coeff_to_extended_locked(ctx, d_in, d_out, 1, extended_omega, log_n, log_ext, coset, nullptr);
   if (rc != HM_OK) return rc;
-  prefault_pages(ext, bytes_out);                      // under the transform: `ext` is normally a fresh allocation (contents kept)
+  xfer_prefault(ext, bytes_out);                       // under the transform: `ext` is normally a fresh allocation (contents kept)
   HM_HIP_CHECK(hipStreamSynchronize(nullptr));
   const double t2 = now_us();
-  {   // `ext` is written by this copy alone (it may be the very allocation `coeffs` lives in: the input has been uploaded whole)
-    const hipError_t e = hipMemcpy(ext, d_out, bytes_out, hipMemcpyDeviceToHost);
-    if (e != hipSuccess)
-      return hm_fail(HM_ERR_PARTIAL_OUTPUT, std::string("hm_coeff_to_extended_bn256_fr: copying the result back failed, the output is "
-                                                        "partly written: ") + hipGetErrorString(e));
-  }
+  // `ext` is written by this copy alone (it may be the very allocation `coeffs` lives in: the input has been uploaded whole).  It is
+  // normally a FRESH allocation (the new Vec of the result): its first-touch page faults were taken by xfer_prefault's threads above.
+  if (xfer_d2h(*ctx, ext, d_out, bytes_out, "hm_coeff_to_extended_bn256_fr") != HM_OK)
+    return hm_fail(HM_ERR_PARTIAL_OUTPUT, "hm_coeff_to_extended_bn256_fr: copying the result back failed, the output is partly written: " +
+                                              hm_last_error_string());
   const double t3 = now_us();
   ctx->calls.ntt_h2d_us += t1 - t0;
   ctx->calls.ntt_device_us += t2 - t1;
@@ -1338,7 +1332,10 @@ int hm_extended_to_coeff_bn256_fr(uint64_t* a, size_t keep, const uint64_t exten
   void* d_a = ctx->io.ensure(bytes);
   if (!d_a) return hm_fail(HM_ERR_HIP, "hm_extended_to_coeff_bn256_fr: staging allocation failed");
   const double t0 = now_us();
-  HM_HIP_CHECK(hipMemcpy(d_a, a, bytes, hipMemcpyHostToDevice));
+  {
+    const int rc = xfer_h2d(*ctx, d_a, a, bytes, "hm_extended_to_coeff_bn256_fr: upload");
+    if (rc != HM_OK) return rc;
+  }
   const double t1 = now_us();
   NttFused f;
   f.scale = divisor;
@@ -1347,12 +1344,9 @@ int hm_extended_to_coeff_bn256_fr(uint64_t* a, size_t keep, const uint64_t exten
   if (rc != HM_OK) return rc;
   HM_HIP_CHECK(hipStreamSynchronize(nullptr));
   const double t2 = now_us();
-  if (keep) {
-    const hipError_t e = hipMemcpy(a, d_a, keep * 32, hipMemcpyDeviceToHost);
-    if (e != hipSuccess)
-      return hm_fail(HM_ERR_PARTIAL_OUTPUT, std::string("hm_extended_to_coeff_bn256_fr: copying the result back failed, the array is "
-                                                        "partly overwritten: ") + hipGetErrorString(e));
-  }
+  if (keep && xfer_d2h(*ctx, a, d_a, keep * 32, "hm_extended_to_coeff_bn256_fr") != HM_OK)
+    return hm_fail(HM_ERR_PARTIAL_OUTPUT, "hm_extended_to_coeff_bn256_fr: copying the result back failed, the array is partly overwritten: " +
+                                              hm_last_error_string());
   const double t3 = now_us();
   count_ntt(*ctx, log_ext, 1);
   ctx->calls.ntt_h2d_us += t1 - t0;
@@ -1461,18 +1455,17 @@ int hm_ntt_bn256_fr(uint64_t* a, const uint64_t omega[4], uint32_t log_n) try {
   void* d_a = ctx->io.ensure(bytes);
   if (!d_a) return hm_fail(HM_ERR_HIP, "hm_ntt_bn256_fr: staging allocation failed");
   const double t0 = now_us();
-  HM_HIP_CHECK(hipMemcpy(d_a, a, bytes, hipMemcpyHostToDevice));
+  int rc = xfer_h2d(*ctx, d_a, a, bytes, "hm_ntt_bn256_fr: upload");
+  if (rc != HM_OK) return rc;
   const double t1 = now_us();
-  int rc = ntt_run(*ctx, (uint32_t*)d_a, omega, log_n, 1, NttFused{}, nullptr);
+  rc = ntt_run(*ctx, (uint32_t*)d_a, omega, log_n, 1, NttFused{}, nullptr);
   if (rc != HM_OK) return rc;
   HM_HIP_CHECK(hipStreamSynchronize(nullptr));
   const double t2 = now_us();
-  {   // from here on `a` is being overwritten: a failure is NOT one a caller may answer by running its CPU body on `a`
-    const hipError_t e = hipMemcpy(a, d_a, bytes, hipMemcpyDeviceToHost);
-    if (e != hipSuccess)
-      return hm_fail(HM_ERR_PARTIAL_OUTPUT, std::string("hm_ntt_bn256_fr: copying the result back failed, the array is partly "
-                                                        "overwritten: ") + hipGetErrorString(e));
-  }
+  // from here on `a` is being overwritten: a failure is NOT one a caller may answer by running its CPU body on `a`
+  if (xfer_d2h(*ctx, a, d_a, bytes, "hm_ntt_bn256_fr") != HM_OK)
+    return hm_fail(HM_ERR_PARTIAL_OUTPUT, "hm_ntt_bn256_fr: copying the result back failed, the array is partly overwritten: " +
+                                              hm_last_error_string());
   const double t3 = now_us();
   count_ntt(*ctx, log_n, 1);
   ctx->calls.ntt_h2d_us += t1 - t0;

@@ -127,6 +127,21 @@ struct DevBuf {
   }
 };
 
+// xfer.hip: host <-> device copies of the host-pointer entry points through pinned staging the library owns (never the caller's
+// pages: see the file's head).  One transfer at a time per device (mu); lanes are created on first use and kept.
+constexpr int HM_XFER_LANES = 8;
+struct XferLane {
+  void* pin[2] = {nullptr, nullptr};      // 2 MiB each, hipHostMalloc
+  hipEvent_t ev[2] = {nullptr, nullptr};
+  hipStream_t stream = nullptr;
+};
+struct HostXfer {
+  std::mutex mu;
+  XferLane lanes[HM_XFER_LANES];
+  int ready = 0;
+  std::atomic<uint64_t> stalls{0};        // direct copies that took several times their healthy worst case (policy: xfer.hip)
+};
+
 struct BasesEntry {          // device-resident, converted base set (hm_register_bases)
   uint64_t handle = 0;
   size_t n = 0;
@@ -231,6 +246,7 @@ struct DeviceCtx {
   size_t coset_table_bytes = 0;        // HBM held by coset_tables (capped: ntt.hip kCosetTableBytesMax)
   AuxSlot aux[HM_AUX_SLOTS];
   uint64_t aux_clock = 0;
+  HostXfer xfer;          // pinned staging lanes of the host-pointer forms' copies (xfer.hip)
   DevBuf io;              // staging for host-pointer calls (scalars / NTT array)
   DevBuf io_bases;        // staging for raw external bases of host-pointer MSM calls
   DevBuf conv_bases;      // converted bases of un-registered calls
@@ -264,6 +280,15 @@ AuxSlot* aux_acquire(DeviceCtx& ctx, hipStream_t stream);
 int aux_release(DeviceCtx& ctx, AuxSlot* slot, hipStream_t stream);
 
 DeviceCtx* ctx_for_current_device();
+
+// xfer.hip.  Synchronous; the device side must be idle on the range (the callers synchronise their stream first).  May be called
+// with or without ctx.mu held (takes ctx.xfer.mu, never ctx.mu).  d2h failures leave `dst` partly written.
+int xfer_h2d(DeviceCtx& ctx, void* d_dst, const void* src, size_t bytes, const char* who);
+int xfer_d2h(DeviceCtx& ctx, void* dst, const void* d_src, size_t bytes, const char* who);
+void xfer_release(DeviceCtx& ctx);
+void xfer_prefault(void* p, size_t bytes);      // first-touch a fresh destination from helper threads (contents kept)
+int xfer_set_policy(int mode);                  // 0 auto, 1 lanes, 2 direct; -1 on anything else
+int xfer_mode(DeviceCtx& ctx);                  // 0 = direct (the runtime's pageable path), 1 = the library's pinned lanes
 
 // capi.hip: the one-device bodies the multi-device layer runs per part (Jacobian results, so that partials fold)
 int msm_h_local(uint64_t handle, size_t offset, const uint64_t* scalars, size_t n, uint64_t jac[12], int* is_id);

@@ -167,6 +167,12 @@ int hm_g1_sum(const uint64_t* points_xyz, size_t count, uint64_t out_xyz[12]);
  * matches; 0: always upload and convert. */
 int hm_set_host_base_cache(int enable);
 
+/* How the host-pointer forms move their arrays (csrc/xfer.hip): 0 = auto (the default; HALO2_MI355X_HOST_COPIES sets the start value):
+ * the runtime's pageable path on the caller's pointers until a copy has twice taken several times its healthy worst case, then the
+ * library's own pinned staging lanes for the rest of the process; 1 = lanes always (nothing of the caller's memory is ever registered
+ * with the driver: latency independent of what the caller maps and unmaps, +0.7 ms per 72 MiB); 2 = direct always.  Process-wide. */
+int hm_set_host_copies(int mode);
+
 /* Window-size override for experiments (0 = automatic). */
 int hm_msm_set_window(int c);
 /* Per-phase timing of an MSM (digits / sort / accumulate / reduce and the accumulate kernel alone, reported by
@@ -465,6 +471,10 @@ typedef struct hm_stats {
   /* ... and for the twiddle tables of the transforms, one set per (omega, log_n): stage tables, and up to 2^21 a direct inter-pass
    * table of 2^log_n x 36 B (75 MB at 2^21).  LRU, at most 64 sets and 1 GiB. */
   uint64_t ntt_table_bytes, ntt_tables;
+  /* The host-pointer forms' copies (csrc/xfer.hip): direct copies that took several times their healthy worst case since the library
+   * was loaded (hm_reset_stats leaves it), and whether the copies now go through the library's own pinned staging lanes (1) or the
+   * runtime's pageable path on the caller's pointers (0).  HALO2_MI355X_HOST_COPIES = auto (direct until the second stall) | lanes | direct. */
+  uint64_t host_copy_stalls, host_copy_lanes;
 } hm_stats;
 #define HM_STAT_EVAL_POLYNOMIAL 0
 #define HM_STAT_GRAPH_EVALUATE 1

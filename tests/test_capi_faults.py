@@ -113,11 +113,12 @@ def test_faults_in_the_drop_in_call(fi, cref):
 
 
 @pytest.mark.gpu
-def test_the_prefault_helpers_are_optional(fi):
-    """hm_coeff_to_extended_bn256_fr first-touches its (normally fresh) 2^log_ext x 32 B output from helper threads while the
-    transform runs: helpers that cannot be started leave their pages to the copy -- same result, no error."""
+def test_the_copy_lanes_are_optional(fi, cref):
+    """The host-pointer forms move their arrays through up to eight pinned staging lanes, a helper thread each (csrc/xfer.hip): lanes
+    whose thread cannot be started are run by the calling thread -- same result, no error; in place on the allocation the coefficients
+    live in the contents are kept."""
     from halo2_experiments_amd.domain import EvaluationDomain, fr_words
-    d = EvaluationDomain(7, 15)                            # 2^18 x 32 B = 8 MiB out: above the 4 MiB threshold of the prefault
+    d = EvaluationDomain(7, 15)                            # 1 MiB up, 8 MiB down: eight lanes
     n, en = d.n, d.extended_len()
     coeffs = _rand_fr(n, 9150).cpu().numpy().view(np.uint64).copy()
     coset = np.concatenate([fr_words(1), fr_words(d.g_coset), fr_words(d.g_coset * d.g_coset)])
@@ -125,20 +126,32 @@ def test_the_prefault_helpers_are_optional(fi):
         out = np.empty((en, 4), dtype=np.uint64)           # fresh pages
         rc = fi.hm_coeff_to_extended_bn256_fr(_u64(coeffs), _u64(out), _u64(fr_words(d.extended_omega)), d.k, d.extended_k, _u64(coset))
         return rc, out
+    assert fi.hm_set_host_copies(1) == 0                   # lanes always (the default policy starts on the runtime's path)
     rc, want = run()
     assert rc == 0
-    fi.hm_test_arm_fault(b"prefault", 0)                   # not even the first helper thread can be had
-    rc, got = run()
-    assert rc == 0 and np.array_equal(got, want)
-    fi.hm_test_arm_fault(b"prefault", 2)                   # the third cannot
+    pad = np.zeros((en, 4), dtype=np.uint64)
+    pad[:n] = cref.fr_mul(coeffs, np.stack([fr_words([1, d.g_coset, d.g_coset * d.g_coset][i % 3]) for i in range(n)]))
+    assert np.array_equal(want, cref.best_fft(pad, fr_words(d.extended_omega), d.extended_k))
+    for after in (0, 2, 9):                                # not even the first helper / the third / one of the second transfer's
+        fi.hm_test_arm_fault(b"xfer_spawn", after)
+        rc, got = run()
+        assert rc == 0 and np.array_equal(got, want), after
+    fi.hm_test_arm_fault(None, 0)
+    buf = np.zeros((en, 4), dtype=np.uint64)               # in place on the allocation the coefficients live in
+    buf[:n] = coeffs
+    assert fi.hm_coeff_to_extended_bn256_fr(_u64(buf), _u64(buf), _u64(fr_words(d.extended_omega)), d.k, d.extended_k, _u64(coset)) == 0
+    assert np.array_equal(buf, want)
+    a = want.copy()                                        # hm_ntt_bn256_fr through the same lanes, odd sizes of transfer included
+    exp = cref.best_fft(want, fr_words(d.extended_omega), d.extended_k)
+    fi.hm_test_arm_fault(b"xfer_spawn", 3)
+    assert fi.hm_ntt_bn256_fr(_u64(a), _u64(fr_words(d.extended_omega)), d.extended_k) == 0 and np.array_equal(a, exp)
+    fi.hm_test_arm_fault(None, 0)
+    assert fi.hm_set_host_copies(2) == 0                   # direct always: the prefault helpers are optional too
+    fi.hm_test_arm_fault(b"prefault", 1)
     rc, got = run()
     assert rc == 0 and np.array_equal(got, want)
     fi.hm_test_arm_fault(None, 0)
-    back = got.copy()                                      # ... and in place on the allocation the coefficients live in: contents kept
-    buf = np.zeros((en, 4), dtype=np.uint64)
-    buf[:n] = coeffs
-    assert fi.hm_coeff_to_extended_bn256_fr(_u64(buf), _u64(buf), _u64(fr_words(d.extended_omega)), d.k, d.extended_k, _u64(coset)) == 0
-    assert np.array_equal(buf, back)
+    assert fi.hm_set_host_copies(3) == -1 and fi.hm_set_host_copies(0) == 0
 
 
 @pytest.mark.gpu

@@ -1133,3 +1133,37 @@ def test_ragged_small_sizes_across_the_window_table(cref, pyref, n):
     for s in (uni, pro):
         exp = cref.g1_to_affine(cref.best_multiexp(s, bases, 4))[0]
         assert g1_equal(h.best_multiexp(s, bases), exp)
+
+
+@pytest.mark.parametrize("mode", ["lanes", "direct"])
+def test_host_pointer_forms_through_both_copy_paths(cref, mode):
+    """The host-pointer forms move their arrays either through the runtime's pageable path or through the library's pinned staging lanes
+    (csrc/xfer.hip; the default policy starts on the first and moves to the second when copies stall): the same results either way --
+    the drop-in pointer form (bases + scalars), the handle form, a phase of commitments from host arrays, and best_fft, at sizes that
+    are not a whole number of lanes, slots or pages."""
+    import ctypes
+    from halo2_experiments_amd import _lib
+    from halo2_experiments_amd.arithmetic import G1_GENERATOR, best_multiexp_batch
+    lib = _lib.load()
+    _lib.check(lib.hm_set_host_copies(1 if mode == "lanes" else 2))
+    try:
+        for n in (8193, 100003, (1 << 18) + 5):                          # 256 KiB + 32 B, 3.05 MiB, 8 MiB + 160 B of scalars
+            s_d = rand_fr_gpu(n, 7700 + n % 97)
+            b_d = h.g1_fixed_base_mul(rand_fr_gpu(n, 7800 + n % 89), G1_GENERATOR)
+            s, b = s_d.cpu().numpy().view(np.uint64).copy(), b_d.cpu().numpy().view(np.uint64).copy()
+            want = cref.g1_to_affine(cref.best_multiexp(s, b, 8))[0]
+            assert np.array_equal(h.best_multiexp(s, b)[:8], want), (mode, n)          # pointer form: both arrays cross
+            hd = h.register_bases(b)                                                   # host registration: the bases cross
+            try:
+                assert np.array_equal(h.best_multiexp(s, hd)[:8], want), (mode, n)
+                cols = [s, np.roll(s, 1, axis=0).copy(), s.copy()]
+                got = best_multiexp_batch(cols, hd)
+                assert np.array_equal(got[0][:8], want) and np.array_equal(got[2], got[0]), (mode, n)
+                assert np.array_equal(got[1], h.best_multiexp(cols[1], hd)), (mode, n)
+            finally:
+                h.release_bases(hd)
+        st = _lib.Stats()
+        _lib.check(lib.hm_get_stats(ctypes.byref(st)))
+        assert st.host_copy_lanes == (1 if mode == "lanes" else 0)
+    finally:
+        _lib.check(lib.hm_set_host_copies(0))

@@ -115,8 +115,17 @@ def test_evaluation_domain_at_the_config_shapes_matches_oracle(cref, pyref, k):
     assert out.shape[-2] == n * 6
 
 
+@pytest.fixture(params=["direct", "lanes"])
+def host_copies(request):
+    """Both ways the host-pointer forms move their arrays (csrc/xfer.hip): the runtime's pageable path and the library's pinned lanes."""
+    lib = _lib.load()
+    _lib.check(lib.hm_set_host_copies(2 if request.param == "direct" else 1))
+    yield request.param
+    _lib.check(lib.hm_set_host_copies(0))
+
+
 @pytest.mark.parametrize("k", [17, 18])
-def test_host_pointer_domain_steps_match_oracle(cref, pyref, k):
+def test_host_pointer_domain_steps_match_oracle(cref, pyref, k, host_copies):
     """hm_coeff_to_extended_bn256_fr / hm_extended_to_coeff_bn256_fr (host arrays: what the patched EvaluationDomain::coeff_to_extended /
     extended_to_coeff of the drop-in prover call) at configs 3 and 4's shapes, j = 7: every element against the ORACLE's compositions
     (zero-pad, distribute_powers_zeta, best_fft; best_fft with the inverse root, divisor, inverse zeta powers, truncate), and the
@@ -164,7 +173,7 @@ def test_host_pointer_domain_steps_match_oracle(cref, pyref, k):
     assert lib.hm_extended_to_coeff_bn256_fr(None, 0, None, k, None, None) == -1
 
 
-def test_host_pointer_domain_steps_small_and_unextended(cref, pyref):
+def test_host_pointer_domain_steps_small_and_unextended(cref, pyref, host_copies):
     """The host forms on the plans the big shapes do not reach: single-pass sizes, log_ext == log_n, one extension bit, keep = 0 and
     keep = 2^log_ext, output aliasing the input allocation (upstream resizes its Vec in place)."""
     import ctypes

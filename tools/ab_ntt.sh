@@ -7,5 +7,5 @@ cd "$(dirname "$0")/../halo2-experiments_amd/csrc"
 make -s libhalo2_mi355x.so
 out=../../gpurun_ab; mkdir -p $out
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-result "$@" -c ntt.hip -o $out/ntt_$tag.o
-/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o $out/libhalo2_mi355x_$tag.so capi.o multi.o $out/ntt_$tag.o poly.o polyops.o lookup.o graph.o msm.o msm_small.o
+/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o $out/libhalo2_mi355x_$tag.so capi.o multi.o xfer.o $out/ntt_$tag.o poly.o polyops.o lookup.o graph.o msm.o msm_small.o
 rm -f $out/ntt_$tag.o; ls -la $out/libhalo2_mi355x_$tag.so

@@ -22,7 +22,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "halo2-experiments_amd", "csrc")
 LLVM = "/opt/rocm/lib/llvm/bin"
 TARGET = "hipv4-amdgcn-amd-amdhsa--gfx950"
-OBJECTS = ["capi.o", "multi.o", "ntt.o", "poly.o", "polyops.o", "lookup.o", "graph.o", "msm.o", "msm_small.o"]
+OBJECTS = ["capi.o", "multi.o", "xfer.o", "ntt.o", "poly.o", "polyops.o", "lookup.o", "graph.o", "msm.o", "msm_small.o"]
 
 _VMEM = re.compile(r"^\s*(global_|flat_|buffer_|scratch_)(load|store|atomic)\w*\s+(.*)$")
 _SLOAD = re.compile(r"^\s*s_load_dword(?:x\d+)?\s+\S+,\s*(s\[\d+:\d+\])")
@@ -36,7 +36,7 @@ def device_disassembly(obj_path: str) -> str:
         r = subprocess.run([f"{LLVM}/llvm-objcopy", f"--dump-section=.hip_fatbin={fat}", obj_path, os.path.join(tmp, "copy.o")],
                            capture_output=True, text=True)
         if r.returncode != 0:
-            if "not found" in r.stderr:                     # a host-only translation unit (capi.hip, multi.hip): no device code
+            if "not found" in r.stderr:                     # a host-only translation unit (capi.hip, multi.hip, xfer.hip): no device code
                 return ""
             raise RuntimeError(r.stderr)
         subprocess.run([f"{LLVM}/clang-offload-bundler", "--type=o", f"--input={fat}", f"--targets={TARGET}", "--unbundle", f"--output={co}"],
