@@ -1303,11 +1303,12 @@ int hm_coeff_to_extended_bn256_fr(const uint64_t* coeffs, uint64_t* ext, const u
   const double t1 = now_us();
   const int rc = coeff_to_extended_locked(ctx, d_in, d_out, 1, extended_omega, log_n, log_ext, coset, nullptr);
   if (rc != HM_OK) return rc;
-  xfer_prefault(ext, bytes_out);                       // under the transform: `ext` is normally a fresh allocation (contents kept)
+  if (xfer_mode(*ctx) == 0) xfer_prefault(ext, bytes_out);   // direct copies: under the transform (`ext` is normally a fresh allocation)
   HM_HIP_CHECK(hipStreamSynchronize(nullptr));
   const double t2 = now_us();
   // `ext` is written by this copy alone (it may be the very allocation `coeffs` lives in: the input has been uploaded whole).  It is
-  // normally a FRESH allocation (the new Vec of the result): its first-touch page faults were taken by xfer_prefault's threads above.
+  // normally a FRESH allocation (the new Vec of the result): its first-touch page faults are taken by xfer_prefault's threads above or
+  // by the lanes' copying threads.
   if (xfer_d2h(*ctx, ext, d_out, bytes_out, "hm_coeff_to_extended_bn256_fr") != HM_OK)
     return hm_fail(HM_ERR_PARTIAL_OUTPUT, "hm_coeff_to_extended_bn256_fr: copying the result back failed, the output is partly written: " +
                                               hm_last_error_string());

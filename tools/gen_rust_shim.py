@@ -325,8 +325,8 @@ fn fr_words<S>(s: &S) -> [u64; 4] {
 /// entry and, when this returns true, the 2^extended_k evaluations on the zeta-coset.  Only the 2^k coefficients cross PCIe
 /// upwards (never the zero padding `resize` would append); distribute_powers_zeta is fused into the first NTT pass.  The result
 /// is written to a FRESH Vec that replaces `a` only on success, so every failure -- HM_ERR_PARTIAL_OUTPUT included -- leaves
-/// `a` exactly as it was and the caller runs the CPU body.  (The fresh allocation's first-touch page faults -- which upstream's own
-/// `resize` takes single-threaded -- are taken inside the call by helper threads while the transform runs.)
+/// `a` exactly as it was and the caller runs the CPU body.  (The fresh allocation's first-touch page faults replace the ones upstream's own
+/// `resize` to the extended length takes; the library touches the pages from helper threads while the transform runs.)
 pub fn try_coeff_to_extended<G: Group>(a: &mut Vec<G>, extended_omega: &G::Scalar, k: u32, extended_k: u32, g_coset: &G::Scalar,
                                        g_coset_inv: &G::Scalar) -> bool {
     if TypeId::of::<G>() != TypeId::of::<Fr>() || TypeId::of::<G::Scalar>() != TypeId::of::<Fr>() || extended_k < GPU_MIN_LOG_N_NTT
