@@ -536,29 +536,39 @@ def run_replay(shape_name: str, device=None, group=None, include_host_pointer_es
         # the drop-in (host-pointer) cost of the same trace: one representative call of each kind
         import ctypes
         h_s = dense[0].cpu().numpy().view(np.uint64)
-        best_multiexp(h_s, gl_h)                                   # warm-up (staging buffers)
-        t0 = time.perf_counter(); best_multiexp(h_s, gl_h); t_msm = time.perf_counter() - t0
+
+        def best_of(fn, reps=3):
+            """Seconds of the fastest of `reps` calls after one warm-up: a per-call figure, not a sample of whatever one call met (staging
+            buffers growing, copy lanes being created, a stalled copy)."""
+            fn()
+            best = None
+            for _ in range(reps):
+                t0 = time.perf_counter()
+                fn()
+                dt = time.perf_counter() - t0
+                best = dt if best is None or dt < best else best
+            return best
+
         from .arithmetic import best_fft
+        t_msm = best_of(lambda: best_multiexp(h_s, gl_h))
         a_n = h_s.copy()
-        best_fft(a_n, fr_words(dom.omega), k)                       # warm-up (twiddle tables of this omega)
-        t0 = time.perf_counter(); best_fft(a_n, fr_words(dom.omega), k); t_ntt_n = time.perf_counter() - t0
+        t_ntt_n = best_of(lambda: best_fft(a_n, fr_words(dom.omega), k))
         a_e = np.zeros((dom.extended_len(), 4), dtype=np.uint64); a_e[:n] = h_s
-        best_fft(a_e, fr_words(dom.extended_omega), dom.extended_k)
-        t0 = time.perf_counter(); best_fft(a_e, fr_words(dom.extended_omega), dom.extended_k); t_ntt_e = time.perf_counter() - t0
+        t_ntt_e = best_of(lambda: best_fft(a_e, fr_words(dom.extended_omega), dom.extended_k))
         # the two EvaluationDomain steps through their own host-pointer forms (the optional src/poly/domain.rs edits of rust/): the zero
         # padding never goes up, the truncated tail never comes down
-        dom.coeff_to_extended(h_s)                                  # warm-up (staging buffer, twiddles)
-        t0 = time.perf_counter(); ext_h = dom.coeff_to_extended(h_s); t_c2e_fresh = time.perf_counter() - t0
-        # ... into a buffer whose pages exist already: the library's own time.  A fresh 2^extended_k x 32 B allocation (the Vec the
-        # Rust glue returns, numpy's here) costs first-touch page faults on top -- the same faults upstream's `resize` to the
-        # extended length takes BEFORE it calls best_fft, which the per-call best_fft figure above does not contain either
-        t0 = time.perf_counter(); dom.coeff_to_extended(h_s, out=ext_h); t_c2e = time.perf_counter() - t0
-        t0 = time.perf_counter()
-        pad = np.empty((dom.extended_len(), 4), dtype=np.uint64); pad[:n] = h_s; pad[n:] = 0
-        t_resize = time.perf_counter() - t0
-        del pad
-        dom.extended_to_coeff(ext_h.copy())
-        t0 = time.perf_counter(); dom.extended_to_coeff(ext_h); t_e2c = time.perf_counter() - t0
+        ext_h = dom.coeff_to_extended(h_s)
+        t_c2e = best_of(lambda: dom.coeff_to_extended(h_s, out=ext_h))          # into pages that exist: the library's own time
+        # ... into a FRESH 2^extended_k x 32 B array (what the Rust glue's new Vec is): first-touch faults on top -- the same faults
+        # upstream's `resize` to the extended length takes BEFORE it calls best_fft, which the best_fft figure above does not contain
+        t_c2e_fresh = best_of(lambda: dom.coeff_to_extended(h_s))
+
+        def zero_pad():
+            pad = np.empty((dom.extended_len(), 4), dtype=np.uint64)
+            pad[:n] = h_s
+            pad[n:] = 0
+        t_resize = best_of(zero_pad)
+        t_e2c = best_of(lambda: dom.extended_to_coeff(ext_h))
         del ext_h
         # ... and the commitments of the whole proof from HOST arrays through the batch call (uploads pipelined behind the
         # other commitments' kernels): what a prover that keeps its polynomials in host vectors gets per proof
