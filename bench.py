@@ -185,12 +185,13 @@ def compact_line(full: dict, extras_file: str = EXTRAS_FILE) -> dict:
         if "error" in op:
             s["one_process_error"] = _short(op["error"], 80)
         else:
-            s["one_process_msm_2_26_ms"] = _r(_get(op, "msm_split", "ms_per_msm"), 4)
+            s[f"one_process_msm_2_{_get(op, 'msm_split', 'global_log_points', default=26)}_ms"] = _r(_get(op, "msm_split", "ms_per_msm"), 4)
             if _get(op, "create_proof_replay", "device_resident_s", "total") is not None:
                 s["one_process_k18_replay_ms"] = _r(1e3 * _get(op, "create_proof_replay", "device_resident_s", "total"), 4)
-    order = ["k18_replay_ms", "msm_2_26_global_points_per_s", "one_process_msm_2_26_ms", "one_process_k18_replay_ms", "one_process_error",
+    order = ["k18_replay_ms", "msm_2_26_global_points_per_s", "one_process_msm_2_26_ms", "one_process_k18_replay_ms", "one_process_error",  # noqa: E501
              "ntt_ms", "ntt_hbm_frac", "ntt_log_n", "k18_cpu_msm_ntt_s", "k18_drop_in_ms", "k18_drop_in_domain_edits_ms", "msm_sort_ms", "ntt_cpu_ms"]
-    keys = sorted(s, key=lambda k_: order.index(k_) if k_ in order else len(order))      # the first ten, by what a scaling record needs most
+    rank_of = lambda k_: order.index(k_) if k_ in order else (2 if k_.startswith("one_process_msm_") else len(order))
+    keys = sorted(s, key=rank_of)                                                         # the first ten, by what a scaling record needs most
     line["summary"] = {k_: s[k_] for k_ in keys[:10]}
     line["extras_file"] = extras_file
     return line
