@@ -101,6 +101,11 @@ _SIGNATURES = {
     "hm_set_msm_devices": (ctypes.c_int, [ctypes.POINTER(ctypes.c_int), ctypes.c_int]),
     "hm_ntt_bn256_fr": (ctypes.c_int, [_u64p, _u64p, ctypes.c_uint32]),
     "hm_set_host_copies": (ctypes.c_int, [ctypes.c_int]),
+    "hm_device_malloc": (ctypes.c_int, [ctypes.c_size_t, ctypes.POINTER(ctypes.c_void_p)]),
+    "hm_device_free": (ctypes.c_int, [ctypes.c_void_p]),
+    "hm_copy_to_device": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]),
+    "hm_copy_to_host": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]),
+    "hm_device_synchronize": (ctypes.c_int, []),
     "hm_coeff_to_extended_bn256_fr": (ctypes.c_int, [_u64p, _u64p, _u64p, ctypes.c_uint32, ctypes.c_uint32, _u64p]),
     "hm_extended_to_coeff_bn256_fr": (ctypes.c_int, [_u64p, ctypes.c_size_t, _u64p, ctypes.c_uint32, _u64p, _u64p]),
     "hm_ntt_bn256_fr_dev": (ctypes.c_int, [_vp, _u64p, ctypes.c_uint32, _vp]),

@@ -358,6 +358,63 @@ int hm_set_host_base_cache(int enable) try {
   return HM_OK;
 } HM_API_CATCH("hm_set_host_base_cache")
 
+int hm_device_malloc(size_t bytes, void** d_out) try {
+  if (!d_out) return hm_fail(HM_ERR_BAD_ARG, "hm_device_malloc: null output");
+  *d_out = nullptr;
+  DeviceCtx* ctx = ctx_for_current_device();
+  if (!ctx) return HM_ERR_NO_DEVICE;
+  if (bytes == 0) return HM_OK;
+  void* p = nullptr;
+  hipError_t e = hipMalloc(&p, bytes);
+  if (e != hipSuccess) {                                  // the library's own caches give back what they can, once
+    (void)hipGetLastError();
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (drop_parked_bases(*ctx)) e = hipMalloc(&p, bytes);
+  }
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    return hm_fail(HM_ERR_HIP, std::string("hm_device_malloc: ") + hipGetErrorString(e));
+  }
+  *d_out = p;
+  return HM_OK;
+} HM_API_CATCH("hm_device_malloc")
+
+int hm_device_free(void* d_ptr) try {
+  if (!d_ptr) return HM_OK;
+  if (!ctx_for_current_device()) return HM_ERR_NO_DEVICE;
+  HM_HIP_CHECK(hipFree(d_ptr));
+  return HM_OK;
+} HM_API_CATCH("hm_device_free")
+
+int hm_copy_to_device(void* d_dst, const void* src, size_t bytes) try {
+  if (bytes && (!d_dst || !src)) return hm_fail(HM_ERR_BAD_ARG, "hm_copy_to_device: null argument");
+  DeviceCtx* ctx = ctx_for_current_device();
+  if (!ctx) return HM_ERR_NO_DEVICE;
+  const int rc = xfer_h2d(*ctx, d_dst, src, bytes, "hm_copy_to_device");
+  if (rc == HM_OK) {
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    ctx->calls.h2d_bytes += bytes;
+  }
+  return rc;
+} HM_API_CATCH("hm_copy_to_device")
+
+int hm_copy_to_host(void* dst, const void* d_src, size_t bytes) try {
+  if (bytes && (!dst || !d_src)) return hm_fail(HM_ERR_BAD_ARG, "hm_copy_to_host: null argument");
+  DeviceCtx* ctx = ctx_for_current_device();
+  if (!ctx) return HM_ERR_NO_DEVICE;
+  if (xfer_d2h(*ctx, dst, d_src, bytes, "hm_copy_to_host") != HM_OK)
+    return hm_fail(HM_ERR_PARTIAL_OUTPUT, "hm_copy_to_host: the destination is partly written: " + hm_last_error_string());
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  ctx->calls.d2h_bytes += bytes;
+  return HM_OK;
+} HM_API_CATCH("hm_copy_to_host")
+
+int hm_device_synchronize(void) try {
+  if (!ctx_for_current_device()) return HM_ERR_NO_DEVICE;
+  HM_HIP_CHECK(hipDeviceSynchronize());
+  return HM_OK;
+} HM_API_CATCH("hm_device_synchronize")
+
 int hm_set_host_copies(int mode) try {
   if (xfer_set_policy(mode) != 0) return hm_fail(HM_ERR_BAD_ARG, "hm_set_host_copies: mode must be 0 (auto), 1 (lanes) or 2 (direct)");
   return HM_OK;

@@ -167,6 +167,20 @@ int hm_g1_sum(const uint64_t* points_xyz, size_t count, uint64_t out_xyz[12]);
  * matches; 0: always upload and convert. */
 int hm_set_host_base_cache(int enable);
 
+/* ---- device memory for callers without a HIP binding of their own -------------------------------------------------
+ * Everything a Rust (or C) prover needs to keep its polynomials in HBM between the steps of create_proof and use the *_dev
+ * entry points with nothing but this library (rust/halo2_proofs-patch/src/mi355x_dev.rs: DevicePoly).  All on the calling
+ * thread's current device (hm_set_device).
+ *   hm_device_malloc / hm_device_free: hipMalloc / hipFree (free waits for the device: keep buffers for the life of a proof);
+ *   hm_copy_to_device / hm_copy_to_host: synchronous, through the same copy policy as the host-pointer forms (hm_set_host_copies);
+ *     the device range must not be in use by work in flight -- hm_device_synchronize() (all streams of the device) or the
+ *     caller's own stream synchronisation first.  stream == NULL in the *_dev entry points is the device's default stream. */
+int hm_device_malloc(size_t bytes, void** d_out);
+int hm_device_free(void* d_ptr);
+int hm_copy_to_device(void* d_dst, const void* src, size_t bytes);
+int hm_copy_to_host(void* dst, const void* d_src, size_t bytes);
+int hm_device_synchronize(void);
+
 /* How the host-pointer forms move their arrays (csrc/xfer.hip): 0 = auto (the default; HALO2_MI355X_HOST_COPIES sets the start value):
  * the runtime's pageable path on the caller's pointers until a copy has twice taken several times its healthy worst case, then the
  * library's own pinned staging lanes for the rest of the process; 1 = lanes always (nothing of the caller's memory is ever registered

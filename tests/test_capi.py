@@ -91,6 +91,8 @@ def test_device_pointer_entry_points_without_a_device():
     assert lib.hm_quotient_by_cosets_bn256_fr_dev(ctypes.c_uint64(1), one_col, None, 1, zp, 1, 3, zp, zp, 1, 1, ctypes.c_void_p(0x9000), None) == -1   # a zero shift
     assert lib.hm_coeff_to_coset_bn256_fr_dev(ctypes.c_void_p(0x1000), ctypes.c_void_p(0x100000), 1, zp, 29, zp, 0, None) == -1      # log_n > 28
     assert lib.hm_coeff_to_coset_bn256_fr_dev(ctypes.c_void_p(0x1000), ctypes.c_void_p(0x1020), 1, zp, 3, zp, 0, None) == -1        # partial overlap
+    assert lib.hm_device_malloc(64, None) == -1 and lib.hm_copy_to_device(None, None, 8) == -1 and lib.hm_copy_to_host(None, None, 8) == -1
+    assert lib.hm_copy_to_device(None, None, 0) in (0, -2) and lib.hm_set_host_copies(7) == -1 and lib.hm_set_host_copies(0) == 0
     assert lib.hm_fr_batch_invert_dev(None, 8, None) == -1
     assert lib.hm_fr_linear_combination_dev(None, None, 2, 8, None, None) == -1
     assert lib.hm_lookup_permute_bn256_fr_dev(None, None, 8, None, None, None) == -1
@@ -116,6 +118,9 @@ def test_device_pointer_entry_points_without_a_device():
     assert lib.hm_quotient_by_cosets_bn256_fr_dev(ctypes.c_uint64(1), one_col, None, 1, zp, 1, 3, twop, twop, 1, 1, ctypes.c_void_p(0x9000), None) == -2
     assert lib.hm_quotient_partials_bn256_fr_dev(ctypes.c_uint64(1), one_col, None, 1, zp, 1, 3, twop, twop, 1, ctypes.c_void_p(0x9000), None) == -2
     assert lib.hm_quotient_combine_bn256_fr_dev(one_col, twop, 1, 3, 1, ctypes.c_void_p(0x9000), None) == -2
+    pp = ctypes.c_void_p(0x55)
+    assert lib.hm_device_malloc(64, ctypes.byref(pp)) == -2 and pp.value is None      # the output is cleared before the device check
+    assert lib.hm_device_free(fake) == -2 and lib.hm_device_synchronize() == -2 and lib.hm_copy_to_host(fake, fake, 8) == -2
     assert lib.hm_fr_batch_invert_dev(fake, 8, None) == -2
     assert lib.hm_lookup_permute_bn256_fr_dev(fake, fake, 8, fake, fake, None) == -2
     assert b"no CPU fallback" in lib.hm_last_error()

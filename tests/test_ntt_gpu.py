@@ -7,7 +7,7 @@ import pytest
 
 import halo2_experiments_amd as h
 from halo2_experiments_amd import _lib
-from halo2_experiments_amd.domain import EvaluationDomain, fr_words
+from halo2_experiments_amd.domain import EvaluationDomain, FR_MODULUS as FR_MODULUS_FOR_TESTS, fr_words
 
 pytestmark = pytest.mark.gpu
 
@@ -216,6 +216,45 @@ def test_host_pointer_domain_steps_small_and_unextended(cref, pyref, host_copies
     coeffs = rand_fr_gpu(64, 6400).cpu().numpy().view(np.uint64)
     exp = cref.best_fft(cref.fr_mul(coeffs, _pattern3([1, d.g_coset, d.g_coset * d.g_coset % R], 64)), fr_words(d.extended_omega), 6)
     assert np.array_equal(d.coeff_to_extended(coeffs), exp)
+
+
+def test_device_memory_entry_points_carry_a_prover_without_a_hip_binding(cref, host_copies):
+    """hm_device_malloc / hm_copy_to_device / hm_copy_to_host / hm_device_synchronize / hm_device_free: what rust/.../mi355x_dev.rs's
+    DevicePoly is made of.  Upload, the EvaluationDomain steps on the device-resident array (default stream = NULL), download: the
+    same words as the host-pointer forms and as the oracle; both copy paths."""
+    from halo2_experiments_amd.arithmetic import _ptr
+    lib = _lib.load()
+    d = EvaluationDomain(6, 14)
+    n, en = d.n, d.extended_len()
+    coeffs = rand_fr_gpu(n, 6500).cpu().numpy().view(np.uint64).copy()
+    want = d.coeff_to_extended(coeffs)                                        # host-pointer form (oracle-checked above)
+    d_in, d_out = ctypes.c_void_p(), ctypes.c_void_p()
+    _lib.check(lib.hm_device_malloc(n * 32, ctypes.byref(d_in)))
+    _lib.check(lib.hm_device_malloc(en * 32, ctypes.byref(d_out)))
+    try:
+        assert d_in.value and d_out.value
+        _lib.check(lib.hm_copy_to_device(d_in, coeffs.ctypes.data_as(ctypes.c_void_p), n * 32))
+        R = FR_MODULUS_FOR_TESTS
+        coset = np.concatenate([fr_words(1), fr_words(d.g_coset), fr_words(d.g_coset * d.g_coset % R)])
+        _lib.check(lib.hm_coeff_to_extended_bn256_fr_dev(d_in, d_out, 1, _ptr(fr_words(d.extended_omega)), d.k, d.extended_k, _ptr(coset), None))
+        _lib.check(lib.hm_device_synchronize())
+        got = np.empty((en, 4), dtype=np.uint64)
+        _lib.check(lib.hm_copy_to_host(got.ctypes.data_as(ctypes.c_void_p), d_out, en * 32))
+        assert np.array_equal(got, want)
+        c3 = np.concatenate([fr_words(1), fr_words(d.g_coset_inv), fr_words(d.g_coset_inv * d.g_coset_inv % R)])
+        _lib.check(lib.hm_extended_to_coeff_bn256_fr_dev(d_out, 1, _ptr(fr_words(d.extended_omega_inv)), d.extended_k,
+                                                         _ptr(fr_words(d.extended_ifft_divisor)), _ptr(c3), None))
+        _lib.check(lib.hm_device_synchronize())
+        back = np.empty((n, 4), dtype=np.uint64)
+        _lib.check(lib.hm_copy_to_host(back.ctypes.data_as(ctypes.c_void_p), d_out, n * 32))     # a prefix of the device array
+        assert np.array_equal(back, coeffs)
+        assert lib.hm_copy_to_host(back.ctypes.data_as(ctypes.c_void_p), d_out, 0) == 0
+    finally:
+        _lib.check(lib.hm_device_free(d_in))
+        _lib.check(lib.hm_device_free(d_out))
+    assert lib.hm_device_free(None) == 0
+    z = ctypes.c_void_p(0x1)
+    assert lib.hm_device_malloc(0, ctypes.byref(z)) == 0 and z.value is None
 
 
 def test_edge_values(cref, pyref):

@@ -54,7 +54,8 @@ def test_apply_edits_makes_every_edit_once(tmp_path):
     assert (root / "src" / "mi355x.rs").exists() and (root / "src" / "mi355x_kzg.rs").exists()
     arith = (root / "src" / "arithmetic.rs").read_text()
     assert arith.count("fn original_best_multiexp<C: CurveAffine>") == 1 and arith.count("fn original_best_fft<G: Group>") == 1
-    assert arith.count("pub mod mi355x;") == 1 and arith.count("pub mod mi355x_kzg;") == 1
+    assert arith.count("pub mod mi355x;") == 1 and arith.count("pub mod mi355x_kzg;") == 1 and arith.count("pub mod mi355x_dev;") == 1
+    assert (root / "src" / "mi355x_dev.rs").exists()
     kzg = (root / "src" / "poly" / "kzg" / "commitment.rs").read_text()
     assert kzg.count("gpu: Default::default(),") == 3 and kzg.count("pub(crate) gpu: crate::arithmetic::mi355x_kzg::SrsHandles,") == 1
     assert kzg.count("self.gpu.reset();") == 1
@@ -105,8 +106,43 @@ def test_the_unified_diff_makes_the_same_edits(tmp_path):
     r = subprocess.run(["patch", "-p1", "-i", os.path.join(RUST, "halo2_proofs.patch")], cwd=b, capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     for rel in ("src/arithmetic.rs", "src/poly/kzg/commitment.rs", "src/poly/commitment.rs", "src/poly/domain.rs", "Cargo.toml", "src/mi355x.rs",
-                "src/mi355x_kzg.rs"):
+                "src/mi355x_kzg.rs", "src/mi355x_dev.rs"):
         assert (a / rel).read_text() == (b / rel).read_text(), rel
+
+
+def test_the_device_resident_glue_binds_what_the_header_declares():
+    """mi355x_dev.rs (DevicePoly, DeviceDomain, commit_dev, QuotientProgram): every sys:: item it calls is declared by the generated
+    lib.rs with the arity it is called with (the header <-> lib.rs check is tests/test_capi.py); RAII on both handle types; nothing
+    panics."""
+    import re
+    dev = open(os.path.join(RUST, "halo2_proofs-patch", "src", "mi355x_dev.rs")).read()
+    lib = open(os.path.join(RUST, "halo2-mi355x-sys", "src", "lib.rs")).read()
+    declared = {m.group(1): len([a for a in m.group(2).split(",") if a.strip()])
+                for m in re.finditer(r"pub\s+fn\s+(hm_[a-z0-9_]+)\s*\(([^)]*)\)", lib, flags=re.S)}
+    calls = re.findall(r"sys::(hm_[a-z0-9_]+)\s*\(", dev)
+    assert set(calls) >= {"hm_device_malloc", "hm_device_free", "hm_copy_to_device", "hm_copy_to_host", "hm_device_synchronize",
+                          "hm_ntt_batch_bn256_fr_dev", "hm_coeff_to_extended_bn256_fr_dev", "hm_extended_to_coeff_bn256_fr_dev",
+                          "hm_msm_bn256_g1_dev", "hm_msm_batch_bn256_g1_dev", "hm_eval_polynomial_bn256_fr_dev", "hm_graph_create",
+                          "hm_quotient_by_cosets_bn256_fr_dev", "hm_graph_destroy"}
+    for m in re.finditer(r"sys::(hm_[a-z0-9_]+)\s*\(", dev):
+        name, i, depth, args, cur = m.group(1), m.end(), 1, 0, ""
+        while depth:                                          # count top-level commas of the call's argument list
+            ch = dev[i]
+            if ch in "([{":
+                depth += 1
+            elif ch in ")]}":
+                depth -= 1
+            elif ch == "," and depth == 1:
+                args += 1 if cur.strip() else 0
+                cur = ""
+                i += 1
+                continue
+            if depth:
+                cur += ch
+            i += 1
+        args += 1 if cur.strip() else 0
+        assert name in declared and declared[name] == args, (name, declared.get(name), args)
+    assert dev.count("impl Drop for") == 2 and "panic!" not in dev and "unwrap()" not in dev
 
 
 def test_glue_is_free_of_the_risks_the_review_named():
