@@ -21,6 +21,7 @@
 
 #include <atomic>
 #include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -165,8 +166,12 @@ static int xfer_run(DeviceCtx& ctx, bool up, void* dev, void* host, size_t bytes
     const double t0 = xfer_now_us();
     const hipError_t e = up ? hipMemcpy(dev, host, bytes, hipMemcpyHostToDevice) : hipMemcpy(host, dev, bytes, hipMemcpyDeviceToHost);
     if (e != hipSuccess) return hm_fail(HM_ERR_HIP, std::string(who) + ": " + hipGetErrorString(e));
-    if (bytes >= kXferDirectBelow && xfer_now_us() - t0 > 2000.0 + (double)bytes / 4000.0)      // 4 GB/s = 4 000 bytes per microsecond
+    const double dt = xfer_now_us() - t0;
+    if (bytes >= kXferDirectBelow && dt > 2000.0 + (double)bytes / 4000.0) {      // 4 GB/s = 4 000 bytes per microsecond
       ctx.xfer.stalls.fetch_add(1, std::memory_order_relaxed);
+      static const bool trace = std::getenv("HALO2_MI355X_XFER_TRACE") != nullptr;
+      if (trace) std::fprintf(stderr, "[halo2_mi355x] stalled copy: %s %zu bytes in %.2f ms (%s)\n", up ? "H2D" : "D2H", bytes, dt / 1e3, who);
+    }
     return HM_OK;
   }
   std::lock_guard<std::mutex> lk(ctx.xfer.mu);                    // the lanes' slots belong to one transfer at a time
