@@ -113,3 +113,67 @@ def test_shard_ranges_cover_everything():
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             sizes = [hi - lo for lo, hi in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def _worker_many(rank, world, port, q):
+    """The same exchange logic at a world size where ranks outnumber some of the things dealt (5 cosets over 4 ranks, a 1-point MSM
+    over 4 ranks, 5 jobs over 4 ranks): what the driver's N = 4 / 8 runs rely on and no one-GPU box can rehearse over RCCL."""
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from halo2_experiments_amd.sharding import (coset_owners, gather_coset_partials, job_parallel_multiexp_batch, shard_range,
+                                                 sharded_multiexp)
+    from oracle import cpu_ref
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = np.load(os.path.join(ROOT, "tests", "golden", "msm.npz"))
+    results = {}
+    for name in ("n255_uniform", "n33_edge", "n1_uniform"):             # n = 1: three of the four ranks hold an empty shard
+        s, b = g[f"{name}_s"], g[f"{name}_b"]
+        lo, hi = shard_range(s.shape[0], rank, world)
+        results[name] = sharded_multiexp(s[lo:hi], b[lo:hi], local_msm=lambda c, p: cpu_ref.best_multiexp(c, p, 1))
+    jnames = ("n255_uniform", "pmone", "n33_edge", "n1_uniform", "n1024_uniform")
+    calls = []
+
+    def local(js):
+        calls.append(len(js))
+        return [cpu_ref.best_multiexp(c, p, 1) for c, p in js]
+
+    outs = job_parallel_multiexp_batch([(g[f"{nm}_s"], g[f"{nm}_b"]) for nm in jnames], local_batch=local)
+    assert calls == [2 if rank == 0 else 1]                             # five jobs round-robin over four ranks
+    for nm, out in zip(jnames, outs):
+        results["jobs_" + nm] = out
+    for e, spare in ((8, False), (5, True), (5, False), (3, True)):     # 8 or 5 cosets over four ranks; 3: a rank without a coset
+        owners = coset_owners(e, world, spare_rank0=spare)
+        assert sorted(set(owners)) == sorted(set(range(world)) & set(owners)) and len(owners) == e
+        if spare and e < world:
+            assert 0 not in owners                                       # rank 0 (which also runs the one-rank steps) is spared
+        mine = {c: torch.full((6, 4), 1000 * e + c, dtype=torch.int64) for c in range(e) if owners[c] == rank}
+        allp = gather_coset_partials(mine, e, shape=(6, 4), owners=owners)
+        assert [int(p[0, 0]) for p in allp] == [1000 * e + c for c in range(e)], (e, spare, rank)
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, results))
+
+
+def test_world_size_4_gloo(cref):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_many, args=(r, 4, port, q)) for r in range(4)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    g = np.load(os.path.join(ROOT, "tests", "golden", "msm.npz"))
+    assert sorted(r for r, _ in got) == [0, 1, 2, 3]
+    for rank, results in got:
+        for name, out in results.items():
+            exp = g[f"{name.replace('jobs_', '')}_r"]
+            if exp.any():
+                assert np.array_equal(out[:8], exp), (rank, name)
+            else:
+                assert not out.any(), (rank, name)
