@@ -42,6 +42,8 @@ import os
 import sys
 import time
 
+PROCESS_T0 = time.perf_counter()          # the leg budget (class Legs) counts from here: the imports below are part of the run
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -98,9 +100,10 @@ NTT_BYTES_PER_ELEM = 64
 # ---- the ONE stdout line ------------------------------------------------------------------------------------------------
 # The driver reads ONE short JSON line (round 4's 21 KB line came back `parsed: null`).  Everything measured goes into the
 # FULL record, written to bench_extras.json next to this script (--extras-out); stdout carries compact_line(full): the
-# contract's keys, roofline, cpu_baseline and at most ten scalar summaries.  Bounded: tests/test_bench_line.py.
+# contract's keys, roofline, cpu_baseline and at most SUMMARY_MAX scalar summaries.  Bounded: tests/test_bench_line.py.
 LINE_MAX_BYTES = 4096
 LINE_MAX_STRING = 120
+SUMMARY_MAX = 12
 EXTRAS_FILE = "bench_extras.json"
 
 
@@ -141,10 +144,22 @@ def compact_line(full: dict, extras_file: str = EXTRAS_FILE) -> dict:
     if isinstance(base_set, dict):
         base_set = "fixed-base table, sliced over the devices" if base_set.get("sliced") else "fixed-base table"
     line["config"] = {"workload": _short(cfg.get("workload")), "points_per_gpu": cfg.get("points_per_gpu"),
-                      "global_points": cfg.get("global_points"), "base_set": _short(base_set, 48),
+                      "global_points": cfg.get("global_points"), "base_set": _short(base_set),
                       "window_bits": cfg.get("window_bits"), "windows": cfg.get("windows"), "parallelism": _short(cfg.get("parallelism"))}
     if "devices" in cfg:
         line["config"]["devices"] = cfg["devices"]
+    # what the headline's base set COSTS (registration is outside the timed region) and its sibling on the other layout -- in
+    # `config` because that is an object the driver's record keeps whole
+    for k_ in ("base_set_register_ms", "base_set_bytes"):
+        if cfg.get(k_) is not None:
+            line["config"][k_] = _r(cfg[k_], 5)
+    plain = full.get("msm_plain_bases")
+    if plain:
+        line["config"]["plain_layout"] = {"points_per_s": _r(plain.get("points_per_s"), 4), "ms": _r(plain.get("ms"), 4),
+                                          "register_ms": _r(plain.get("register_ms"), 4), "base_set_bytes": plain.get("base_set_bytes"),
+                                          "note": "the same MSM on ONE copy of the points (best_multiexp's arbitrary bases per call)"}
+    if full.get("collective"):
+        line["config"]["collective"] = _short(_get(full, "collective", "summary"), 100)
     line["roofline"] = {"bound": rf.get("bound"), "achieved": _r(rf.get("achieved")), "peak": rf.get("peak"), "unit": rf.get("unit"),
                         "frac": _r(rf.get("frac")), "traffic": _r(rf.get("traffic"), 9), "kernel": rf.get("kernel"),
                         "kernel_ms": _r(rf.get("kernel_ms")), "algorithmic_bytes": rf.get("algorithmic_bytes"),
@@ -156,16 +171,22 @@ def compact_line(full: dict, extras_file: str = EXTRAS_FILE) -> dict:
                                 "sample": _short(cpu.get("sample")), "agrees_with_gpu": cpu.get("agrees_with_gpu")}
     line["known_answer_ok"] = full.get("known_answer_ok")
     line["ranks_in_collective"] = full.get("ranks_in_collective")
-    # at most ten scalar summaries; the objects they come from are in the extras file
+    # at most SUMMARY_MAX scalar summaries; the objects they come from are in the extras file
     s = {}
     if full.get("msm_phase_ms"):
         s["msm_sort_ms"] = _r(_get(full, "msm_phase_ms", "sort"), 4)
+    if plain:
+        s["msm_plain_points_per_s"] = _r(plain.get("points_per_s"), 4)
     if full.get("ntt"):
-        s["ntt_log_n"] = _get(full, "ntt", "log_n")
-        s["ntt_ms"] = _r(_get(full, "ntt", "ms"), 4)
+        s[f"ntt_2_{_get(full, 'ntt', 'log_n')}_ms"] = _r(_get(full, "ntt", "ms"), 4)
         s["ntt_hbm_frac"] = _r(_get(full, "ntt", "roofline", "frac"), 4)
         if _get(full, "ntt", "cpu_baseline", "ms") is not None:
             s["ntt_cpu_ms"] = _r(_get(full, "ntt", "cpu_baseline", "ms"), 4)
+    rep9 = next((r for r in full.get("create_proof_replay") or [] if r.get("k") == 9), None)
+    if rep9:                          # the reference's own proving configuration (merkle_sum_tree.rs:345-358)
+        s["k9_replay_ms"] = _r(1e3 * _get(rep9, "device_resident_s", "total", default=0.0), 4)
+        if _get(rep9, "cpu_baseline", "total_s") is not None:
+            s["k9_cpu_msm_ntt_ms"] = _r(1e3 * _get(rep9, "cpu_baseline", "total_s"), 4)
     for e in full.get("strong_scaling") or []:
         if e.get("global_log_points") == 26:
             s["msm_2_26_global_points_per_s"] = _r(e.get("points_per_s"), 4)
@@ -180,6 +201,8 @@ def compact_line(full: dict, extras_file: str = EXTRAS_FILE) -> dict:
             s[f"{kk}_drop_in_ms"] = _r(1e3 * _get(rep, "total_s", "drop_in_host_pointers"), 4)
         if _get(rep, "total_s", "drop_in_with_domain_edits") is not None:
             s[f"{kk}_drop_in_domain_edits_ms"] = _r(1e3 * _get(rep, "total_s", "drop_in_with_domain_edits"), 4)
+        if _get(rep, "rust_device_glue", "total_ms") is not None:     # the proof through exactly mi355x_dev.rs's entry points
+            s[f"{kk}_rust_dev_glue_ms"] = _r(_get(rep, "rust_device_glue", "total_ms"), 4)
     op = full.get("one_process")
     if op:
         if "error" in op:
@@ -188,13 +211,30 @@ def compact_line(full: dict, extras_file: str = EXTRAS_FILE) -> dict:
             s[f"one_process_msm_2_{_get(op, 'msm_split', 'global_log_points', default=26)}_ms"] = _r(_get(op, "msm_split", "ms_per_msm"), 4)
             if _get(op, "create_proof_replay", "device_resident_s", "total") is not None:
                 s["one_process_k18_replay_ms"] = _r(1e3 * _get(op, "create_proof_replay", "device_resident_s", "total"), 4)
-    order = ["k18_replay_ms", "msm_2_26_global_points_per_s", "one_process_msm_2_26_ms", "one_process_k18_replay_ms", "one_process_error",  # noqa: E501
-             "ntt_ms", "ntt_hbm_frac", "ntt_log_n", "k18_cpu_msm_ntt_s", "k18_drop_in_ms", "k18_drop_in_domain_edits_ms", "msm_sort_ms", "ntt_cpu_ms"]
-    rank_of = lambda k_: order.index(k_) if k_ in order else (2 if k_.startswith("one_process_msm_") else len(order))
-    keys = sorted(s, key=rank_of)                                                         # the first ten, by what a scaling record needs most
-    line["summary"] = {k_: s[k_] for k_ in keys[:10]}
+    if _get(full, "time_budget", "dropped"):
+        s["legs_dropped"] = len(full["time_budget"]["dropped"])
+    order = ["k18_replay_ms", "msm_plain_points_per_s", "msm_2_26_global_points_per_s", "one_process_msm_2_26_ms", "one_process_k18_replay_ms",
+             "one_process_error", "legs_dropped", "ntt_2_24_ms", "ntt_hbm_frac", "k9_replay_ms", "k9_cpu_msm_ntt_ms", "k18_rust_dev_glue_ms",
+             "k18_drop_in_ms", "k18_cpu_msm_ntt_s", "k18_drop_in_domain_edits_ms", "msm_sort_ms", "ntt_cpu_ms"]
+    rank_of = lambda k_: order.index(k_) if k_ in order else (3 if k_.startswith("one_process_msm_") else len(order))
+    keys = sorted(s, key=rank_of)                                                         # the first SUMMARY_MAX, by what a scaling record needs most
+    line["summary"] = {k_: s[k_] for k_ in keys[:SUMMARY_MAX]}
     line["extras_file"] = extras_file
     return line
+
+
+_REAL_STDOUT_FD = None
+
+
+def guard_stdout():
+    """stdout carries ONE line.  RCCL prints a version banner on STDOUT when a communicator is built (five lines, seen in round 6's
+    first one-rank run), gloo prints its own: file descriptor 1 is pointed at stderr for the life of the process, and emit() writes
+    the line to the saved descriptor -- whatever a library prints, the driver reads exactly one JSON line."""
+    global _REAL_STDOUT_FD
+    if _REAL_STDOUT_FD is None:
+        sys.stdout.flush()
+        _REAL_STDOUT_FD = os.dup(1)
+        os.dup2(2, 1)
 
 
 def emit(full: dict, extras_out: str):
@@ -216,8 +256,12 @@ def emit(full: dict, extras_out: str):
     if len(text) >= LINE_MAX_BYTES:            # then everything of config but the workload
         line["config"] = {"workload": line["config"]["workload"]}
         text = json.dumps(line)
-    print(text)
-    sys.stdout.flush()
+    if _REAL_STDOUT_FD is None:
+        print(text)
+        sys.stdout.flush()
+    else:
+        sys.stdout.flush()
+        os.write(_REAL_STDOUT_FD, (text + "\n").encode())
 
 
 def rand_fr(n, seed, device):
@@ -379,7 +423,7 @@ def replay_cpu_baseline(rep, device):
     cpu_ref.build()
     k, ek = rep["k"], rep["extended_k"]
     n = 1 << k
-    used = next(sh.used_rows for sh in SHAPES.values() if sh.name == rep["circuit"])
+    used = SHAPES[rep["shape_key"]].used_rows
     bases = h.g1_fixed_base_mul(_rand_fr(n, 77, device), G1_GENERATOR).cpu().numpy().view(np.uint64)
     dense = _rand_fr(n, 78, device).cpu().numpy().view(np.uint64)
     sparse = _sparse_column(n, used, 79, device).cpu().numpy().view(np.uint64)
@@ -408,6 +452,42 @@ def replay_cpu_baseline(rep, device):
     return info
 
 
+def rust_threshold_account(rep):
+    """Which calls of a replayed trace the Rust shim's size thresholds (GPU_MIN_LOG_N_MSM / GPU_MIN_LOG_N_NTT of
+    rust/halo2_proofs-patch/src/mi355x.rs, read from that file) would leave on the CPU, and what the proof's MSM + NTT calls cost
+    on each route -- from per-call times MEASURED in this run: the CPU port (rep.cpu_baseline.per_call_s) and the drop-in
+    host-pointer calls (rep.host_pointer_estimate_s).  Written for the reference's own k = 9 case, which sits at the crossover."""
+    import re
+    try:
+        with open(os.path.join(ROOT, "rust", "halo2_proofs-patch", "src", "mi355x.rs")) as f:
+            text = f.read()
+        thr = {name: int(re.search(rf"pub const GPU_MIN_LOG_N_{name}: u32 = (\d+);", text).group(1)) for name in ("MSM", "NTT")}
+        cpu, hp, calls = rep["cpu_baseline"]["per_call_s"], rep["host_pointer_estimate_s"], rep["calls"]
+    except (OSError, AttributeError, KeyError, TypeError):
+        return None
+    k, ek = rep["k"], rep["extended_k"]
+    rows = [  # (what, log size, calls, CPU port s per call, GPU drop-in s per call, threshold)
+        ("best_multiexp, sparse columns", k, calls["msm_sparse"], cpu["msm_sparse"], hp["msm_each"], thr["MSM"]),
+        ("best_multiexp, dense columns", k, calls["msm_dense"], cpu["msm_dense"], hp["msm_each"], thr["MSM"]),
+        ("best_fft 2^k", k, calls["intt_n"], cpu["intt_n"], hp["ntt_n_each"], thr["NTT"]),
+        ("best_fft 2^extended_k", ek, calls["coset_ntt_ext"] + calls["intt_ext"], cpu["coset_ntt_ext"], hp["ntt_ext_each"], thr["NTT"])]
+    out_rows, tot = [], {"all_on_cpu_port": 0.0, "all_through_the_gpu_drop_in": 0.0, "as_the_shim_routes_them": 0.0}
+    for what, lg, cnt, c_s, g_s, th in rows:
+        on_gpu = lg >= th
+        out_rows.append({"call": what, "log_n": lg, "calls": cnt, "cpu_port_ms_each": c_s * 1e3, "gpu_drop_in_ms_each": g_s * 1e3,
+                         "shim_routes_to": "gpu" if on_gpu else "cpu", "gpu_wins_per_call": bool(g_s < c_s)})
+        tot["all_on_cpu_port"] += cnt * c_s
+        tot["all_through_the_gpu_drop_in"] += cnt * g_s
+        tot["as_the_shim_routes_them"] += cnt * (g_s if on_gpu else c_s)
+    return {"thresholds": {"GPU_MIN_LOG_N_MSM": thr["MSM"], "GPU_MIN_LOG_N_NTT": thr["NTT"], "from": "rust/halo2_proofs-patch/src/mi355x.rs"},
+            "calls": out_rows, "msm_plus_ntt_ms": {k_: v * 1e3 for k_, v in tot.items()},
+            "device_resident_msm_plus_ntt_ms": (rep["device_resident_s"]["msm"] + rep["device_resident_s"]["ntt"]) * 1e3,
+            "calls_left_on_the_cpu": sum(r["calls"] for r in out_rows if r["shim_routes_to"] == "cpu"),
+            "gpu_route_wins": bool(tot["as_the_shim_routes_them"] < tot["all_on_cpu_port"]),
+            "cpu_threads": rep["cpu_baseline"]["cores"],
+            "note": "MSM + best_fft calls only, per-call time x the trace's counts; the CPU port runs on cpu_threads threads"}
+
+
 def live_pmc(log_points, log_ntt, with_ntt):
     """HBM traffic and VALU instruction counts of the two hot kernels MEASURED IN THIS RUN: three child processes, each this
     same script (two timed steps of the headline workload, nothing else) under `rocprofv3 --pmc <one counter group>
@@ -425,7 +505,7 @@ def live_pmc(log_points, log_ntt, with_ntt):
     tmp = tempfile.mkdtemp(prefix="hm_pmc_", dir="/tmp")
     try:
         child = [sys.executable, os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--log-points", str(log_points), "--log-ntt",
-                 str(log_ntt), "--no-cpu-baseline", "--replay", "none", "--no-extras", "--no-strong", "--no-live-pmc", "--extras-out", "none"] + ([] if with_ntt else ["--no-ntt"])
+                 str(log_ntt), "--no-cpu-baseline", "--replay", "none", "--no-extras", "--no-strong", "--no-live-pmc", "--no-collective", "--extras-out", "none"] + ([] if with_ntt else ["--no-ntt"])
         env = dict(os.environ, TMPDIR="/tmp")
         for group in (["FETCH_SIZE"], ["WRITE_SIZE"], ["SQ_INSTS_VALU", "GRBM_GUI_ACTIVE"]):
             d = os.path.join(tmp, group[0])
@@ -468,9 +548,96 @@ def cpu_side_barrier(tag, rank, world):
         dist.barrier()
 
 
+COLLECTIVE = {"on": False, "backend": None, "ranks_seen": 1, "error": None, "init_s": None}
+
+
+def _free_port():
+    import socket
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        return s_.getsockname()[1]
+
+
+def init_collective(backend, rank, world, device, comm_device, at_one_rank=True):
+    """The process group of the run.  N > 1: as the driver launched it (RANK / WORLD_SIZE / MASTER_* from the environment).
+    N = 1: a ONE-RANK RCCL communicator on this GPU, so that the timed step takes the same route as at N > 1 -- partial to
+    a device tensor, dist.all_gather over RCCL, fold -- and `ranks_in_collective` is what an RCCL all-reduce returned, not a
+    constant.  A box on which the one-rank communicator cannot be built loses the collective, never the headline: the
+    error goes into the record (`collective.error`) and the step runs without the exchange."""
+    t0 = time.perf_counter()
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    try:
+        if world > 1:
+            if backend == "nccl":
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+            else:
+                dist.init_process_group(backend, rank=rank, world_size=world)
+        elif at_one_rank:
+            os.environ.setdefault("MASTER_PORT", str(_free_port()))
+            if backend == "nccl":
+                dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
+            else:
+                dist.init_process_group(backend, rank=0, world_size=1)
+        else:
+            return
+        one = torch.ones(1, dtype=torch.int64, device=comm_device)
+        dist.all_reduce(one)                                    # how many ranks the collective really saw
+        if comm_device.type == "cuda":
+            torch.cuda.synchronize()
+        COLLECTIVE.update(on=True, backend=("rccl" if backend == "nccl" else backend), ranks_seen=int(one.item()))
+    except Exception as e:  # noqa: BLE001
+        if world > 1:
+            raise
+        COLLECTIVE.update(on=False, error=f"{type(e).__name__}: {e}"[:300])
+        try:
+            if dist.is_initialized():
+                dist.destroy_process_group()
+        except Exception:  # noqa: BLE001
+            pass
+    COLLECTIVE["init_s"] = time.perf_counter() - t0
+
+
+class Legs:
+    """Wall-clock budget of the run.  Every leg of the script (a side measurement beside the headline) is entered through
+    ``start(name, estimate_s)``: the time since the process started -- max over the ranks, so that every rank takes the same
+    decision before a leg that holds a collective -- plus the leg's estimate must fit the budget, or the leg is DROPPED
+    (recorded in `dropped`).  The headline (inputs, registration, warm-up, timed steps) is not a leg and is never dropped.
+    Estimates: measured on one MI355X (profiles/r06_*), with the registration-bound legs scaled by the rank count where all
+    ranks register at once.  The first run on eight physical devices shares the driver's limit with code whose cost there
+    has never been measured; this is what bounds it."""
+
+    def __init__(self, budget_s, world, comm_device):
+        self.budget, self.world, self.comm_device = float(budget_s), world, comm_device
+        self.wall, self.dropped, self._open = {}, [], None
+
+    def elapsed(self, local=False):
+        now = time.perf_counter() - PROCESS_T0
+        return now if local or self.world == 1 else max_over_ranks(now, self.world, self.comm_device)
+
+    def start(self, name, estimate_s, local=False):
+        """``local``: a leg only this rank runs (no collective inside): decided on this rank's own clock."""
+        now = self.elapsed(local)
+        if self.budget > 0 and now + estimate_s > self.budget:
+            self.dropped.append({"leg": name, "at_s": round(now, 2), "estimate_s": estimate_s})
+            return False
+        self._open = (name, time.perf_counter())
+        return True
+
+    def stop(self):
+        if self._open:
+            name, t0 = self._open
+            self.wall[name] = self.wall.get(name, 0.0) + (time.perf_counter() - t0)
+            self._open = None
+
+    def record(self):
+        return {"budget_s": self.budget, "legs_wall_s": {k: round(v, 3) for k, v in self.wall.items()}, "dropped": self.dropped,
+                "total_s": round(time.perf_counter() - PROCESS_T0, 3),
+                "note": "rank 0's wall per leg; a leg starts only if (time since process start, max over ranks) + its estimate fits the budget"}
+
+
 def fold_known_answers(expected_local, world, comm_device):
     """The global expected point from every rank's [sum s_i t_i]G over its own index range."""
-    if world == 1:
+    if world == 1 and not COLLECTIVE["on"]:
         return expected_local
     from halo2_experiments_amd.sharding import g1_sum
     mine = torch.from_numpy(expected_local.view(np.int64).copy()).to(comm_device)
@@ -480,7 +647,7 @@ def fold_known_answers(expected_local, world, comm_device):
 
 
 def max_over_ranks(x, world, comm_device):
-    if world == 1:
+    if world == 1 and not COLLECTIVE["on"]:
         return x
     t = torch.tensor([x], dtype=torch.float64, device=comm_device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -716,7 +883,7 @@ def main():
     ap.add_argument("--cpu-log-sample", type=int, default=0, help="log2 of the CPU baseline's MSM (default: the timed size, capped at 24)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ntt", action="store_true")
-    ap.add_argument("--replay", default="poseidon_k11,merkle_v3_k17,merkle_sum_tree_k18",
+    ap.add_argument("--replay", default="merkle_sum_tree_k9,poseidon_k11,merkle_v3_k17,merkle_sum_tree_k18",
                     help="comma-separated create_proof MSM/NTT traces to replay after the timed MSM steps ('none' to skip)")
     ap.add_argument("--no-extras", action="store_true", help="skip the prover-like and host-pointer MSM side measurements")
     ap.add_argument("--no-2-26", action="store_true", help="skip the global 2^26-point strong-scaling measurement")
@@ -728,10 +895,15 @@ def main():
     ap.add_argument("--extras-out", default=EXTRAS_FILE,
                     help="where the FULL record goes (every side measurement; relative to this script; 'none' = nowhere); stdout carries "
                          "only the compact line")
+    ap.add_argument("--no-collective", action="store_true",
+                    help="N = 1: do not build the one-rank RCCL communicator (the timed step then skips the all-gather)")
+    ap.add_argument("--time-budget", type=float, default=300.0,
+                    help="seconds from process start within which side legs may still START (0 = no limit); the headline is never dropped")
     ap.add_argument("--one-process", action="store_true",
                     help="ONE process drives --gpus devices through hm_set_msm_devices (launch WITHOUT torchrun): the whole benchmark in the "
                          "form the reference's single-process prover would use")
     args = ap.parse_args()
+    guard_stdout()
     if args.one_process:
         return main_one_process(args)
 
@@ -750,16 +922,10 @@ def main():
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
     comm_device = device if backend == "nccl" else torch.device("cpu")
-    ranks_seen = 1
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
-        one = torch.ones(1, dtype=torch.int64, device=comm_device)
-        dist.all_reduce(one)                                    # how many ranks the collective really saw
-        ranks_seen = int(one.item())
+    under_profiler = any("ROCPROF" in k.upper() for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
+    init_collective(backend, rank, world, device, comm_device, at_one_rank=not args.no_collective)
+    ranks_seen = COLLECTIVE["ranks_seen"]
+    legs = Legs(args.time_budget, world, comm_device)
 
     import halo2_experiments_amd as h
     from halo2_experiments_amd import _lib
@@ -779,13 +945,14 @@ def main():
     handle = h.register_bases(bases)                                            # device-resident SRS slice, the library's default layout
     torch.cuda.synchronize()
     headline_register_ms = (time.perf_counter() - t_reg0) * 1e3
+    headline_bases_info = h.bases_info(handle)
     del bases
     expected_local = known_answer(scalars, t_local, device)                     # [sum_i s_i (a + i b)]G over this rank's range
     del t_local
     torch.cuda.synchronize()
 
-    def step():
-        return sharded_multiexp(scalars, handle)
+    def step():                      # N = 1 with the one-rank communicator: the same route as N > 1 (all-gather over RCCL, fold)
+        return sharded_multiexp(scalars, handle, force_collective=COLLECTIVE["on"])
 
     for _ in range(args.warmup):
         step()
@@ -824,7 +991,7 @@ def main():
 
     # ---- NTT (single GPU by design: "replicas only") -------------------------------------------
     ntt = None
-    if not args.no_ntt and rank == 0:
+    if not args.no_ntt and rank == 0 and legs.start("ntt", 6.0, local=True):
         from halo2_experiments_amd.domain import FR_MODULUS, FR_ROOT_OF_UNITY, fr_words
         k = args.log_ntt
         omega = fr_words(pow(FR_ROOT_OF_UNITY, 1 << (28 - k), FR_MODULUS))
@@ -851,10 +1018,11 @@ def main():
         del a
         if world == 1 and not args.no_cpu_baseline:
             ntt["cpu_baseline"] = ntt_cpu_baseline(k, device)
+        legs.stop()
 
     # ---- side measurements: prover-like scalars; the PCIe-inclusive drop-in call ----
     extras = None
-    if not args.no_extras and world == 1:
+    if not args.no_extras and world == 1 and legs.start("msm_side_measurements", 8.0):
         extras = {}
         u = torch.rand(n_local, device=device, generator=torch.Generator(device=device).manual_seed(7))
         pl = scalars.clone()
@@ -903,6 +1071,7 @@ def main():
         extras["msm_plain_bases" if other_is_plain else "msm_precomputed_bases"] = {
             "points_per_s": n_local / dt, "ms": dt * 1e3, "window_bits": stp["window_bits"], "windows": stp["windows"],
             "accumulate_kernel_ms": stp["accumulate_kernel_ms"], "sort_ms": stp["sort_ms"], "register_ms": t_reg * 1e3,
+            "base_set_bytes": int(h.bases_info(hp)["device_bytes"]),
             "same_result_as_headline": bool(np.array_equal(ref_out, got_pc))}
         h.release_bases(hp)
         # independent MSMs issued asynchronously, three in flight on three streams (hm_msm_submit_dev):
@@ -935,6 +1104,7 @@ def main():
         extras["msm_host_pointer"] = {"ms": (time.perf_counter() - t1) * 1e3,
                                       "note": "hm_msm_bn256_g1_h: scalars cross PCIe in the call (pageable host memory); never `value`"}
         del hs
+        legs.stop()
 
     # ---- strong scaling (BASELINE configs[4]: "2^26 MSM ... 1/2/4/8 GPUs"): one GLOBAL MSM split over the ranks ----
     strong = None
@@ -952,10 +1122,13 @@ def main():
                            "ms_per_msm": elapsed / args.steps * 1e3, "points_per_s": n_global * args.steps / elapsed,
                            "known_answer_ok": answer_ok, "window_bits": st["window_bits"], "windows": st["windows"],
                            "rank0_kernel_ms": acc1, "split": "none (the timed headline steps)"})
-        else:
+        elif legs.start(f"strong_2_{args.log_points}", 8.0):
             strong.append(strong_scaling_msm(args.log_points, BENCH_SEED + 24, rank, world, device, comm_device))
-        if args.log_points == 24 and not args.no_2_26 and not args.no_extras:      # (--no-extras: the profiled command -- one MSM size in the trace)
+            legs.stop()
+        # (--no-extras: the profiled command -- one MSM size in the trace); 2^26 / N points per rank: generation + registration dominate
+        if args.log_points == 24 and not args.no_2_26 and not args.no_extras and legs.start("strong_2_26", 6.0 + 16.0 / world):
             strong.append(strong_scaling_msm(26, BENCH_SEED + 26, rank, world, device, comm_device))
+            legs.stop()
         for e in strong:
             if not e["known_answer_ok"]:
                 raise SystemExit(f"bench.py: the global 2^{e['global_log_points']} MSM does not match its known answer")
@@ -972,24 +1145,35 @@ def main():
         # scaling record compares like with like: all E cosets = the same polynomial as N = 1's whole-array device_resident_s
         # (upstream's own steps), and the j - 1 cosets that determine the quotient of a satisfied circuit (a different
         # computation on the replay's synthetic columns: never the headline)
-        if world > 1:
-            replay = []
-            for name in args.replay.split(","):
+        # the largest shape LAST in the list but FIRST in the budget: when time runs short the small shapes are what goes
+        names = args.replay.split(",")
+        replay_est = {"merkle_sum_tree_k18": 9.0, "merkle_v3_k17": 5.0}
+        by_name = {}
+        for name in sorted(names, key=lambda nm: -replay_est.get(nm, 3.0)):
+            est = replay_est.get(name, 3.0)
+            if world > 1:
+                if not legs.start(f"replay_{name}", est):
+                    continue
                 rep = run_replay(name, device=device, min_cosets=False)
-                fewer = run_replay(name, device=device, include_host_pointer_estimate=False, min_cosets=True)
-                rep["extended_domain_routes_ms"] = {
-                    "by_all_cosets": {**{k2: v * 1e3 for k2, v in rep["device_resident_s"].items()}, "extended_domain": rep["extended_domain"]},
-                    "by_the_cosets_that_determine_h": {**{k2: v * 1e3 for k2, v in fewer["device_resident_s"].items()},
-                                                       "extended_domain": fewer["extended_domain"]},
-                    "note": "device_resident_s = by_all_cosets: the same h as the N = 1 whole-array route"}
-                replay.append(rep)
-        else:
-            replay = [run_replay(name, device=device) for name in args.replay.split(",")]
+                legs.stop()
+                if legs.start(f"replay_{name}_min_cosets", est):
+                    fewer = run_replay(name, device=device, include_host_pointer_estimate=False, min_cosets=True)
+                    legs.stop()
+                    rep["extended_domain_routes_ms"] = {
+                        "by_all_cosets": {**{k2: v * 1e3 for k2, v in rep["device_resident_s"].items()}, "extended_domain": rep["extended_domain"]},
+                        "by_the_cosets_that_determine_h": {**{k2: v * 1e3 for k2, v in fewer["device_resident_s"].items()},
+                                                           "extended_domain": fewer["extended_domain"]},
+                        "note": "device_resident_s = by_all_cosets: the same h as the N = 1 whole-array route"}
+                by_name[name] = rep
+            elif legs.start(f"replay_{name}", est + (6.0 if name.endswith("k18") else 1.0)):     # + the host-pointer (drop-in) calls of the trace
+                by_name[name] = run_replay(name, device=device)
+                legs.stop()
+        replay = [by_name[nm] for nm in names if nm in by_name]
         # N = 1: what ONE GPU can measure of the N-GPU replay -- the first and the last rank's share of the 2-, 4- and 8-rank deal of
         # the largest shape, each alone, nothing exchanged.  DESIGN.md section 6 builds its
         # predicted curve on these.
-        if world == 1 and not args.no_extras and not args.no_shares:
-            big = [nm for nm in args.replay.split(",") if nm == "merkle_sum_tree_k18"]
+        if world == 1 and not args.no_extras and not args.no_shares and legs.start("k18_rank_shares_and_coset_routes", 12.0):
+            big = [nm for nm in args.replay.split(",") if nm == "merkle_sum_tree_k18" and nm in by_name]
             for nm in big:
                 shares = []
                 for w in (2, 4, 8):
@@ -1024,18 +1208,29 @@ def main():
                                               "commitments of every phase, its cosets of the extended domain, for rank 0 the steps only rank 0 "
                                               "runs); the step takes the longer of them plus the exchanges -- 96 B per commitment, n x 32 B "
                                               "per coset -- which are not in these times"}
-        if rank == 0 and world == 1 and not args.no_cpu_baseline:
+            legs.stop()
+        if rank == 0 and world == 1 and not args.no_cpu_baseline and legs.start("replay_cpu_baselines", 10.0):
             for rep in replay:
                 rep["cpu_baseline"] = replay_cpu_baseline(rep, device)
+                acct = rust_threshold_account(rep)
+                if acct is not None:
+                    rep["rust_shim_routing"] = acct
+            legs.stop()
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # the contract's cpu_baseline: not droppable, but SIZED to what is left (the whole 2^24 workload is ~8 s on 16 cores;
+        # each halving of the sample halves it)
         log_sample = args.cpu_log_sample or min(args.log_points, 24)
+        while log_sample > 16 and legs.budget > 0 and legs.elapsed() + 10.0 * (1 << log_sample) / (1 << 24) > legs.budget:
+            log_sample -= 1
+        legs.start("cpu_baseline", 0.0)
         cpu = cpu_baseline(log_sample, device, full=log_sample == args.log_points)
+        legs.stop()
 
     # ---- N > 1: the ONE-PROCESS form, by rank 0 alone -------------------------------------------------------------
     one_proc = None
-    if world > 1 and not args.no_one_process:
+    if world > 1 and not args.no_one_process and legs.start("one_process", 45.0 + 2.5 * world):
         if handle is not None:
             h.release_bases(handle)
             handle = None
@@ -1057,17 +1252,18 @@ def main():
                 except Exception:  # noqa: BLE001
                     pass
         cpu_side_barrier("one_process_done", rank, world)        # ... and waits here, on the CPU, until rank 0 is done
+        legs.stop()
 
     # ---- PMC counters of the two hot kernels, measured in THIS run (child processes under rocprofv3) --------------------
     live = None
-    under_profiler = any("ROCPROF" in k.upper() for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
-    if rank == 0 and world == 1 and not args.no_live_pmc and not under_profiler:
+    if rank == 0 and world == 1 and not args.no_live_pmc and not under_profiler and legs.start("live_pmc", 35.0, local=True):
         if handle is not None:
             h.release_bases(handle)
             handle = None
         scalars = None
         torch.cuda.empty_cache()
         live = live_pmc(args.log_points, args.log_ntt, ntt is not None)
+        legs.stop()
 
     if rank == 0:
         acc = float(np.median(acc_ms))
@@ -1124,9 +1320,12 @@ def main():
                        "scalars": "uniform in [0, r), xoshiro256** per element, seed 0x48324d4933353558 (SURVEY.md §8d)",
                        "bases": "P_i = [a + i b]G, device-resident; result checked against [sum s_i (a + i b)]G outside the timed loop",
                        "base_set": headline_mode, "base_set_register_ms": headline_register_ms,
+                       "base_set_bytes": int(headline_bases_info["device_bytes"]),
                        "window_bits": st["window_bits"], "windows": st["windows"], "parallelism": f"index-range shards x{world}, "
                        "all-gather of 96 B partials (RCCL) + host fold"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            # bound: what limits the kernel (integer VALU issue, `valu_issue`); achieved / peak / frac stay the contract's HBM
+            # figures (algorithmic bytes / kernel time against the 8 TB/s peak)
+            "roofline": {"bound": "valu", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": k3_traffic, "traffic_src": k3_traffic_src, "traffic_note": k3_traffic_note,
                          "kernel": "msm_accumulate_kernel", "kernel_ms": acc, "algorithmic_bytes": MSM_BYTES_PER_POINT * n_local,
@@ -1137,6 +1336,12 @@ def main():
             "known_answer_ok": answer_ok,
         }
         line["ranks_in_collective"] = ranks_seen
+        line["collective"] = {
+            "on": COLLECTIVE["on"], "backend": COLLECTIVE["backend"], "ranks_seen_by_all_reduce": ranks_seen, "init_s": COLLECTIVE["init_s"],
+            "error": COLLECTIVE["error"],
+            "summary": (f"{COLLECTIVE['backend']} all-gather of 96 B partials in every timed step, {ranks_seen} rank(s) seen by all-reduce"
+                        if COLLECTIVE["on"] else f"none in the timed step ({COLLECTIVE['error'] or 'switched off: --no-collective'})")}
+        line["time_budget"] = legs.record()
         if strong is not None:
             line["strong_scaling"] = strong
         if one_proc is not None:
@@ -1150,7 +1355,7 @@ def main():
         if cpu is not None:
             line["cpu_baseline"] = cpu
         emit(line, args.extras_out)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -246,6 +246,9 @@ def poseidon() -> ConstraintSystem:
 
 CONSTRAINT_SYSTEMS: Dict[str, Callable[[], ConstraintSystem]] = {
     "poseidon_k11": poseidon, "merkle_v3_k17": merkle_v3, "merkle_sum_tree_k18": merkle_sum_tree,
+    # the ONE configuration the reference proves for real: test_full_prover, k = 9, a depth-5 path
+    # (/root/reference/src/circuits/merkle_sum_tree.rs:345-358, path :172-212) -- the same constraint system as k = 18
+    "merkle_sum_tree_k9": merkle_sum_tree,
 }
 
 

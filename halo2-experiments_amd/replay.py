@@ -71,7 +71,8 @@ def _shapes():
     circuits.py (the reference's chip files, cited there; Pow5Chip / LtChip as recalled) -- not from estimates.  `used_rows`
     (how many rows of a 2^k column synthesis fills) stays an estimate: it is a property of the floor planner's layout."""
     from .circuits import CONSTRAINT_SYSTEMS
-    ks = {"poseidon_k11": (11, 40), "merkle_v3_k17": (17, 840), "merkle_sum_tree_k18": (18, 1100)}
+    # merkle_sum_tree_k9: the reference's own test_full_prover (merkle_sum_tree.rs:345-358: k = 9, depth-5 path); rows per level as at k = 18
+    ks = {"poseidon_k11": (11, 40), "merkle_v3_k17": (17, 840), "merkle_sum_tree_k18": (18, 1100), "merkle_sum_tree_k9": (9, 290)}
     out = {}
     for key, make in CONSTRAINT_SYSTEMS.items():
         cs = make()
@@ -501,7 +502,7 @@ def run_replay(shape_name: str, device=None, group=None, include_host_pointer_es
             wall, phases = w, ph
 
     out = {
-        "circuit": shape.name, "k": k, "extended_k": dom.extended_k, "n_gpus": world,
+        "circuit": shape.name, "shape_key": shape_name, "k": k, "extended_k": dom.extended_k, "n_gpus": world,
         **({"share_of": {"rank": rank, "world": world, "note": "ONE rank's share of the replay, measured alone on one GPU: no exchange "
                                                                "(96 B per commitment, n x 32 B per coset) in the time"}}
            if share_of is not None else {}),

@@ -16,6 +16,7 @@ every rank by ``hm_g1_sum`` -- EC addition is not an RCCL reduction operator, so
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Callable, Optional, Tuple
 
 import numpy as np
@@ -41,19 +42,43 @@ def g1_sum(points: np.ndarray) -> np.ndarray:
     return out
 
 
+def _exchanges(group, force_collective: Optional[bool]) -> bool:
+    """Does this call go through the process group's collective?  Yes with more than one rank.  With ONE rank the
+    exchange is an identity and is skipped -- unless ``force_collective`` (or HALO2_MI355X_FORCE_COLLECTIVE=1) asks for
+    it: the all-gather over RCCL then really runs (a one-rank communicator), which is how a one-GPU box executes the
+    `nccl` branch of every function here (tests/test_rccl_gpu.py, ``bench.py --gpus 1``)."""
+    import torch.distributed as dist
+
+    if group is _NO_GROUP or not dist.is_available() or not dist.is_initialized():
+        return False
+    if dist.get_world_size(group) > 1:
+        return True
+    if force_collective is None:
+        force_collective = os.environ.get("HALO2_MI355X_FORCE_COLLECTIVE", "0") not in ("", "0")
+    return bool(force_collective)
+
+
+def _comm_device(group):
+    """Where the exchanged words live: the rank's GPU for RCCL (device tensors over xGMI), the host for gloo."""
+    import torch
+    import torch.distributed as dist
+
+    return torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+
+
 def sharded_multiexp(local_coeffs, local_bases, group=None,
-                     local_msm: Optional[Callable] = None) -> np.ndarray:
+                     local_msm: Optional[Callable] = None, force_collective: Optional[bool] = None) -> np.ndarray:
     """Each rank passes ITS shard; every rank returns the full sum.  ``local_msm`` defaults to the
-    GPU ``best_multiexp`` (tests on CPU-only hosts inject a stand-in to exercise the exchange)."""
+    GPU ``best_multiexp`` (tests on CPU-only hosts inject a stand-in to exercise the exchange).
+    ``force_collective``: see ``_exchanges``."""
     import torch
     import torch.distributed as dist
 
     partial = (local_msm or best_multiexp)(local_coeffs, local_bases)
-    if group is _NO_GROUP or not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not _exchanges(group, force_collective):
         return g1_sum(partial.reshape(1, 12))
     world = dist.get_world_size(group)
-    backend = dist.get_backend(group)
-    dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+    dev = _comm_device(group)
     mine = torch.from_numpy(partial.view(np.int64).copy()).to(dev)
     gathered = [torch.empty_like(mine) for _ in range(world)]
     dist.all_gather(gathered, mine, group=group)
@@ -65,7 +90,8 @@ MAX_IN_FLIGHT = 8      # asynchronous MSM slots per device (csrc/hm_internal.h: 
 _NO_GROUP = object()   # marker: run the local part only, even inside an initialised process group
 
 
-def sharded_multiexp_batch(jobs, group=None, streams=None, local_batch: Optional[Callable] = None) -> np.ndarray:
+def sharded_multiexp_batch(jobs, group=None, streams=None, local_batch: Optional[Callable] = None,
+                           force_collective: Optional[bool] = None) -> np.ndarray:
     """Several independent MSMs (the commitments of one prover phase): ``jobs`` = [(local_coeffs,
     local_bases_handle), ...], every rank passing ITS shards.  Each rank keeps up to MAX_IN_FLIGHT of its
     local MSMs in flight (``hm_msm_submit_dev`` on different streams), then ALL partials travel in one
@@ -89,13 +115,12 @@ def sharded_multiexp_batch(jobs, group=None, streams=None, local_batch: Optional
                 j += 1
             partials[i:j] = best_multiexp_batch([col for col, _ in jobs[i:j]], jobs[i][1])
             i = j
-    if group is _NO_GROUP or not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not _exchanges(group, force_collective):
         if local_batch is None:
             return partials             # one rank: the library's results are already normalised (x, y, 1) / zeros
         return np.stack([g1_sum(p.reshape(1, 12)) for p in partials]) if len(partials) else partials     # a stand-in's may not be
     world = dist.get_world_size(group)
-    backend = dist.get_backend(group)
-    dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+    dev = _comm_device(group)
     mine = torch.from_numpy(partials.view(np.int64).copy()).to(dev)
     gathered = [torch.empty_like(mine) for _ in range(world)]
     dist.all_gather(gathered, mine, group=group)
@@ -108,7 +133,8 @@ def job_owner(job: int, world: int) -> int:
     return job % world
 
 
-def job_parallel_multiexp_batch(jobs, group=None, streams=None, local_batch: Optional[Callable] = None) -> np.ndarray:
+def job_parallel_multiexp_batch(jobs, group=None, streams=None, local_batch: Optional[Callable] = None,
+                                force_collective: Optional[bool] = None) -> np.ndarray:
     """Job-level multi-GPU for prover-sized MSMs: ``jobs`` = [(coeffs, bases_handle), ...], the SAME list on every
     rank (every rank holds the full SRS and can see every column); rank r computes the whole MSMs j with
     j % world == r -- up to MAX_IN_FLIGHT of them in flight -- and ONE all-gather of ceil(len(jobs) / world) x 96 B
@@ -119,7 +145,7 @@ def job_parallel_multiexp_batch(jobs, group=None, streams=None, local_batch: Opt
     import torch
     import torch.distributed as dist
 
-    distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    distributed = _exchanges(group, force_collective)
     world = dist.get_world_size(group) if distributed else 1
     rank = dist.get_rank(group) if distributed else 0
     mine_idx = [j for j in range(len(jobs)) if job_owner(j, world) == rank]
@@ -129,8 +155,7 @@ def job_parallel_multiexp_batch(jobs, group=None, streams=None, local_batch: Opt
     per_rank = (len(jobs) + world - 1) // world
     buf = np.zeros((per_rank, 12), dtype=np.uint64)
     buf[: len(mine_idx)] = mine
-    backend = dist.get_backend(group)
-    dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+    dev = _comm_device(group)
     t = torch.from_numpy(buf.view(np.int64).copy()).to(dev)
     gathered = [torch.empty_like(t) for _ in range(world)]
     dist.all_gather(gathered, t, group=group)
@@ -155,7 +180,7 @@ def coset_owners(num_cosets: int, world: int, spare_rank0: bool = False):
     return [coset_owner(c, world) for c in range(num_cosets)]
 
 
-def gather_coset_partials(mine, num_cosets: int, group=None, shape=None, owners=None):
+def gather_coset_partials(mine, num_cosets: int, group=None, shape=None, owners=None, force_collective: Optional[bool] = None):
     """evaluate_h by cosets over the ranks: ``mine`` = {coset: (n, 4) tensor} -- what ``coset_to_partial`` left for the
     coset POSITIONS this rank owns (``owners[position]``, default ``coset_owner``: position % world).  ONE all-gather of ceil(E / world) x n x 32 B per rank; returns the list of
     the E partials in coset order (on the device for RCCL, on the host for gloo), ready for ``combine_cosets``.  Without a
@@ -164,8 +189,7 @@ def gather_coset_partials(mine, num_cosets: int, group=None, shape=None, owners=
     import torch
     import torch.distributed as dist
 
-    distributed = group is not _NO_GROUP and dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
-    if not distributed:
+    if not _exchanges(group, force_collective):
         return [mine[c] for c in range(num_cosets)]
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     owners = list(owners) if owners is not None else coset_owners(num_cosets, world)
@@ -179,13 +203,12 @@ def gather_coset_partials(mine, num_cosets: int, group=None, shape=None, owners=
     for r in range(world):
         for slot, c in enumerate([c for c in range(num_cosets) if owners[c] == r]):
             slot_of[c] = slot
-    backend = dist.get_backend(group)
     if shape is None:
         if not mine:
             raise ValueError("gather_coset_partials: a rank that owns no coset must be told the shape of a partial")
         shape = tuple(next(iter(mine.values())).shape)
     shape = tuple(shape)
-    dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+    dev = _comm_device(group)
     buf = torch.zeros((per_rank,) + shape, dtype=torch.int64, device=dev)
     for c in owned:
         buf[slot_of[c]] = mine[c].to(dev)

@@ -38,7 +38,7 @@ def _check(line):
     assert list(line)[:len(CONTRACT_KEYS)] == CONTRACT_KEYS
     assert set(line["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms"}
     assert all(len(s) <= bench.LINE_MAX_STRING for s in _strings(line))
-    assert len(line["summary"]) <= 10 and all(not isinstance(v, (dict, list)) for v in line["summary"].values())
+    assert len(line["summary"]) <= bench.SUMMARY_MAX <= 12 and all(not isinstance(v, (dict, list)) for v in line["summary"].values())
     assert json.loads(text) == line
     return text
 
@@ -51,8 +51,36 @@ def test_the_round4_record_compacts_under_4k():
     assert line["roofline"]["frac"] == float(f"{full['roofline']['frac']:.6g}") and line["roofline"]["bound"] == "hbm"
     assert set(line["cpu_baseline"]) == {"value", "unit", "cores", "kind", "sample", "agrees_with_gpu"}
     assert line["cpu_baseline"]["cores"] == full["cpu_baseline"]["cores"] and line["cpu_baseline"]["kind"] == "port"
-    assert line["summary"]["k18_replay_ms"] > 0 and line["summary"]["ntt_ms"] > 0 and line["summary"]["k18_cpu_msm_ntt_s"] > 1
+    assert line["summary"]["k18_replay_ms"] > 0 and line["summary"]["ntt_2_24_ms"] > 0 and line["summary"]["k18_cpu_msm_ntt_s"] > 1
     assert line["extras_file"] == "bench_extras.json"
+
+
+def test_the_line_carries_what_the_headline_base_set_costs_and_its_plain_sibling():
+    """the driver's record keeps `config` / `roofline` / `cpu_baseline` whole (and nothing of `summary`), so the
+    registration cost of the fixed-base table, its bytes and the plain-layout figure ride in `config`; base_set is not cut; the
+    bound says what the note says."""
+    full = _round4_record()
+    mode = "fixed-base table (registration default from 2^17 points)"
+    full["config"].update(base_set=mode, base_set_register_ms=224.123456, base_set_bytes=12 << 30)
+    full["roofline"]["bound"] = "valu"
+    full["msm_plain_bases"] = {"points_per_s": 7.7612345e8, "ms": 21.6, "register_ms": 9.87654, "base_set_bytes": 1 << 30, "window_bits": 16}
+    full["collective"] = {"on": True, "summary": "rccl all-gather of 96 B partials in every timed step, 1 rank(s) seen by all-reduce"}
+    full["time_budget"] = {"budget_s": 300.0, "dropped": [{"leg": "strong_2_26", "at_s": 299.0, "estimate_s": 8.0}], "legs_wall_s": {}}
+    line = bench.compact_line(full, "bench_extras.json")
+    _check(line)
+    cfg = line["config"]
+    assert cfg["base_set"] == mode and cfg["base_set_register_ms"] == 224.12 and cfg["base_set_bytes"] == 12 << 30
+    assert cfg["plain_layout"]["points_per_s"] == 7.761e8 and cfg["plain_layout"]["base_set_bytes"] == 1 << 30
+    assert cfg["collective"].startswith("rccl all-gather")
+    assert line["roofline"]["bound"] == "valu" and line["roofline"]["unit"] == "GB/s" and line["roofline"]["peak"] == 8000.0
+    assert line["summary"]["msm_plain_points_per_s"] == 7.761e8 and line["summary"]["legs_dropped"] == 1
+    # the reference's own configuration (k = 9) and the Rust device glue, when the record has them
+    rep9 = {"k": 9, "device_resident_s": {"total": 0.0021}, "cpu_baseline": {"total_s": 0.0153}}
+    full["create_proof_replay"] = [rep9] + full["create_proof_replay"]
+    full["create_proof_replay"][-1]["rust_device_glue"] = {"total_ms": 41.5}
+    line = bench.compact_line(full, "bench_extras.json")
+    _check(line)
+    assert line["summary"]["k9_replay_ms"] == 2.1 and line["summary"]["k9_cpu_msm_ntt_ms"] == 15.3 and line["summary"]["k18_rust_dev_glue_ms"] == 41.5
 
 
 def test_an_eight_rank_record_with_one_process_entries_compacts_under_4k():

@@ -87,7 +87,7 @@ def test_setup_commit_and_file_round_trip(cref, pyref, tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["poseidon_k11", "merkle_v3_k17", "merkle_sum_tree_k18"])
+@pytest.mark.parametrize("name", ["merkle_sum_tree_k9", "poseidon_k11", "merkle_v3_k17", "merkle_sum_tree_k18"])
 def test_replays_verify_their_commitments(name):
     """BASELINE configs[1] / [2] / [3]: the create_proof trace replay checks every commitment it computes against the
     KZG identity (prove, then verify -- merkle_sum_tree.rs:345-358).  Config 4's flow (k = 18: 20 advice columns, 8
@@ -101,6 +101,12 @@ def test_replays_verify_their_commitments(name):
     cs = CONSTRAINT_SYSTEMS[name]()
     assert r["shape"]["advice"] == cs.num_advice and r["shape"]["lookups"] == len(cs.lookups) and r["shape"]["max_degree"] == cs.degree()
     assert f"{len(cs.polynomials())} gate polynomials" in r["beyond_msm_ntt"]["evaluate_h"]
+    if name.startswith("merkle_sum_tree"):
+        # the reference's own proving configuration is k = 9 (test_full_prover, merkle_sum_tree.rs:345-358); same constraint system at
+        # k = 18: 20 advice columns, 8 lookups, 12 equality columns in 3 sets, degree 7 => 56 MSMs and 97 transforms per proof
+        # 
+        assert r["k"] == (9 if name.endswith("k9") else 18) and r["extended_k"] == r["k"] + 3 and r["shape_key"] == name
+        assert r["calls"] == {"msm_sparse": 36, "msm_dense": 20, "intt_n": 48, "coset_ntt_ext": 48, "intt_ext": 1}
 
 
 @pytest.mark.gpu
