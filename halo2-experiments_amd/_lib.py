@@ -42,7 +42,7 @@ class Stats(ctypes.Structure):
                 ("vector_calls", ctypes.c_uint64 * 8), ("vector_elements", ctypes.c_uint64 * 8),
                 ("coset_table_bytes", ctypes.c_uint64), ("coset_tables", ctypes.c_uint64),
                 ("ntt_table_bytes", ctypes.c_uint64), ("ntt_tables", ctypes.c_uint64),
-                ("host_copy_stalls", ctypes.c_uint64), ("host_copy_lanes", ctypes.c_uint64)]
+                ("host_copies_direct", ctypes.c_uint64), ("host_copies_staged", ctypes.c_uint64), ("host_ranges_registered", ctypes.c_uint64)]
     KINDS = ("eval_polynomial", "graph_evaluate", "kate_division", "grand_product", "batch_invert", "linear_combination", "lookup_permute")
 
 
@@ -101,6 +101,8 @@ _SIGNATURES = {
     "hm_set_msm_devices": (ctypes.c_int, [ctypes.POINTER(ctypes.c_int), ctypes.c_int]),
     "hm_ntt_bn256_fr": (ctypes.c_int, [_u64p, _u64p, ctypes.c_uint32]),
     "hm_set_host_copies": (ctypes.c_int, [ctypes.c_int]),
+    "hm_host_register": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_size_t]),
+    "hm_host_unregister": (ctypes.c_int, [ctypes.c_void_p]),
     "hm_device_malloc": (ctypes.c_int, [ctypes.c_size_t, ctypes.POINTER(ctypes.c_void_p)]),
     "hm_device_free": (ctypes.c_int, [ctypes.c_void_p]),
     "hm_copy_to_device": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]),

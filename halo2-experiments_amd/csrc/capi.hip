@@ -390,6 +390,9 @@ int hm_copy_to_device(void* d_dst, const void* src, size_t bytes) try {
   if (bytes && (!d_dst || !src)) return hm_fail(HM_ERR_BAD_ARG, "hm_copy_to_device: null argument");
   DeviceCtx* ctx = ctx_for_current_device();
   if (!ctx) return HM_ERR_NO_DEVICE;
+  // the same ordering whichever way the bytes travel (the lanes' streams are non-blocking; hipMemcpy alone would wait for the
+  // default stream and every blocking stream): behind everything queued on the default stream / the blocking streams
+  HM_HIP_CHECK(hipStreamSynchronize(nullptr));
   const int rc = xfer_h2d(*ctx, d_dst, src, bytes, "hm_copy_to_device");
   if (rc == HM_OK) {
     std::lock_guard<std::mutex> lk(ctx->mu);
@@ -402,12 +405,23 @@ int hm_copy_to_host(void* dst, const void* d_src, size_t bytes) try {
   if (bytes && (!dst || !d_src)) return hm_fail(HM_ERR_BAD_ARG, "hm_copy_to_host: null argument");
   DeviceCtx* ctx = ctx_for_current_device();
   if (!ctx) return HM_ERR_NO_DEVICE;
+  HM_HIP_CHECK(hipStreamSynchronize(nullptr));              // (see hm_copy_to_device)
   if (xfer_d2h(*ctx, dst, d_src, bytes, "hm_copy_to_host") != HM_OK)
     return hm_fail(HM_ERR_PARTIAL_OUTPUT, "hm_copy_to_host: the destination is partly written: " + hm_last_error_string());
   std::lock_guard<std::mutex> lk(ctx->mu);
   ctx->calls.d2h_bytes += bytes;
   return HM_OK;
 } HM_API_CATCH("hm_copy_to_host")
+
+int hm_host_register(const void* p, size_t bytes) try {
+  if (!ctx_for_current_device()) return HM_ERR_NO_DEVICE;
+  return xfer_host_register(p, bytes);
+} HM_API_CATCH("hm_host_register")
+
+int hm_host_unregister(const void* p) try {
+  if (!ctx_for_current_device()) return HM_ERR_NO_DEVICE;
+  return xfer_host_unregister(p);
+} HM_API_CATCH("hm_host_unregister")
 
 int hm_device_synchronize(void) try {
   if (!ctx_for_current_device()) return HM_ERR_NO_DEVICE;
@@ -1251,8 +1265,9 @@ int hm_get_stats(hm_stats* out) try {
   out->coset_tables = ctx->coset_tables.size();
   out->ntt_table_bytes = ctx->ntt_table_bytes;
   out->ntt_tables = ctx->ntt_tables.size();
-  out->host_copy_stalls = ctx->xfer.stalls.load(std::memory_order_relaxed);
-  out->host_copy_lanes = (uint64_t)xfer_mode(*ctx);
+  out->host_copies_direct = ctx->xfer.direct.load(std::memory_order_relaxed);
+  out->host_copies_staged = ctx->xfer.staged.load(std::memory_order_relaxed);
+  out->host_ranges_registered = xfer_host_ranges();
   return HM_OK;
 } HM_API_CATCH("hm_get_stats")
 
@@ -1360,7 +1375,7 @@ int hm_coeff_to_extended_bn256_fr(const uint64_t* coeffs, uint64_t* ext, const u
   const double t1 = now_us();
   const int rc = coeff_to_extended_locked(ctx, d_in, d_out, 1, extended_omega, log_n, log_ext, coset, nullptr);
   if (rc != HM_OK) return rc;
-  if (xfer_mode(*ctx) == 0) xfer_prefault(ext, bytes_out);   // direct copies: under the transform (`ext` is normally a fresh allocation)
+  if (xfer_mode(ext, bytes_out) == 0) xfer_prefault(ext, bytes_out);   // direct copies: under the transform (`ext` is normally a fresh allocation)
   HM_HIP_CHECK(hipStreamSynchronize(nullptr));
   const double t2 = now_us();
   // `ext` is written by this copy alone (it may be the very allocation `coeffs` lives in: the input has been uploaded whole).  It is

@@ -139,7 +139,7 @@ struct HostXfer {
   std::mutex mu;
   XferLane lanes[HM_XFER_LANES];
   int ready = 0;
-  std::atomic<uint64_t> stalls{0};        // direct copies that took several times their healthy worst case (policy: xfer.hip)
+  std::atomic<uint64_t> direct{0}, staged{0};   // copies handed to hipMemcpy on the caller's pointers / moved through the lanes (policy: xfer.hip)
 };
 
 struct BasesEntry {          // device-resident, converted base set (hm_register_bases)
@@ -288,7 +288,10 @@ int xfer_d2h(DeviceCtx& ctx, void* dst, const void* d_src, size_t bytes, const c
 void xfer_release(DeviceCtx& ctx);
 void xfer_prefault(void* p, size_t bytes);      // first-touch a fresh destination from helper threads (contents kept)
 int xfer_set_policy(int mode);                  // 0 auto, 1 lanes, 2 direct; -1 on anything else
-int xfer_mode(DeviceCtx& ctx);                  // 0 = direct (the runtime's pageable path), 1 = the library's pinned lanes
+int xfer_mode(const void* host, size_t bytes);  // which way a copy of this host range goes NOW: 0 = hipMemcpy on the caller's pointers, 1 = the library's pinned lanes
+int xfer_host_register(const void* p, size_t bytes);   // hm_host_register / hm_host_unregister: ranges the caller declares long-lived
+int xfer_host_unregister(const void* p);
+size_t xfer_host_ranges();
 
 // capi.hip: the one-device bodies the multi-device layer runs per part (Jacobian results, so that partials fold)
 int msm_h_local(uint64_t handle, size_t offset, const uint64_t* scalars, size_t n, uint64_t jac[12], int* is_id);

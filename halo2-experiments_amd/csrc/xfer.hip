@@ -1,30 +1,42 @@
 // xfer.hip -- the host <-> device copies of the host-pointer entry points (hm_msm_bn256_g1*, hm_ntt_bn256_fr, hm_coeff_to_extended /
-// hm_extended_to_coeff, the batch call's scalar uploads).
+// hm_extended_to_coeff, the batch call's scalar uploads, hm_copy_to_device / hm_copy_to_host).
 //
-// Two paths.  DIRECT: hipMemcpy on the caller's pointers.  For pageable memory of this size the runtime pins the user's pages on the fly
-// (a userptr registration with the kernel driver): the fastest path while it works -- 52 GB/s up, 49 GB/s down on this host, 1.63 ms
-// for the 8 + 64 MiB of a k = 18 coeff_to_extended -- but it ties the library's latency to what the CALLER's allocator does around the
-// calls: a prover maps and unmaps a 64 MiB Vec around every coeff_to_extended, and on some boxes of the pool (3 sessions of ~20 in
-// round 5, never reproduced on demand) the copy that followed stalled for 7-27 ms: an 8 MiB upload measured at 22 ms instead of 0.16,
-// the same 27 ms per call at k = 17 and k = 18, mmap itself slow (0.9 ms) in those sessions.  LANES: the library's own pinned staging,
-// up to 8 lanes, each a host thread with its own stream and two 2 MiB pinned slots moving one contiguous share of the transfer (memcpy
-// into a slot / DMA from the other, and the reverse).  Nothing of the caller's memory is ever registered with the driver, so nothing
-// the caller maps or unmaps can invalidate what the GPU queues depend on -- at 0.7 ms more per 72 MiB on a healthy box (2.38 against
-// 1.63 ms; profiles/r05_host_copies.txt).
+// Two paths.  DIRECT: hipMemcpy on the caller's pointers.  LANES: the library's own pinned staging, up to 8 lanes, each a host thread
+// with its own stream and two 2 MiB pinned slots moving one contiguous share of the transfer (memcpy into a slot / DMA from the other,
+// and the reverse).
 //
-// Policy (HALO2_MI355X_HOST_COPIES = auto | lanes | direct, default auto): direct until a copy has TWICE taken longer than
-// 2 ms + bytes / 4 GB/s -- several times the healthy worst case, first-touch page faults included --, then lanes for the rest of the
-// process; hm_get_stats reports the stalls seen and the mode.  Copies below 256 KiB always go straight to hipMemcpy (the runtime
-// stages those itself).  xfer_prefault first-touches a destination the process has never written (the fresh Vec of a result) from
-// helper threads while the transform is still running: a direct copy into untouched pages took its faults one by one (5 ms per 64 MiB).
+// FINDING (rounds 5-6; tools/ubench/hostcopy_probe.hip, profiles/r06_hostcopy_probe.txt, profiles/r05_host_copies.txt).  For pageable
+// memory of these sizes hipMemcpy PINS the caller's pages on the fly -- a userptr registration with the kernel driver, cached by the
+// runtime per (address, size) -- and then DMAs at 50-55 GB/s.  What that costs is a property of the BOX, not of the copy:
+//   * on most boxes of the pool pinning costs 0.1-0.2 us per 4 KiB page (hipHostRegister of 64 MiB: 2.2 ms; first hipMemcpy from a fresh
+//     64 MiB mapping 1.64 ms against 1.33 ms for the second; a re-mapped range at the same address pays it again on every OTHER cycle:
+//     2.5 / 1.4 / 2.5 / 1.4 ms -- the runtime's cached pin is found stale and rebuilt);
+//   * on some boxes it costs ~9 us per page (2.2-2.4 ms per MiB: the 8 MiB upload of a k = 18 column 17.7 ms instead of 0.16, a 4 MiB one
+//     9.9 ms: the same per-page figure at every size, round 5's "stalls" of 7-27 ms) -- and a prover's arrays are NEW on every call
+//     (a fresh Vec per polynomial, unmapped afterwards: glibc serves anything above 32 MiB straight from mmap), so there EVERY copy is a
+//     first copy.  That, not a transient, is what round 5's timing detector kept tripping on; whether a session saw it depended on the
+//     box it landed on (3 of ~20 sessions in round 5, the first session of round 6).
+// The lanes never hand the caller's memory to the driver: nothing is pinned, nothing the caller maps or unmaps can invalidate anything
+// the GPU queues depend on, and the cost is the same on every box: +0.7 ms per 72 MiB against the direct path on a fast-pinning box.
+//
+// POLICY -- a rule on the RANGE, never on the clock (HALO2_MI355X_HOST_COPIES = auto | lanes | direct, hm_set_host_copies; default auto):
+//   auto    a host range goes DIRECT only if the caller has declared it long-lived with hm_host_register (pinned once, by the caller's
+//           choice: an SRS kept in memory, a reused staging buffer) -- the copy is then a plain DMA from registered memory; every other
+//           range of 256 KiB or more goes through the LANES; below 256 KiB straight to hipMemcpy (the runtime stages those itself, no pin);
+//   lanes   registered ranges too;
+//   direct  everything to hipMemcpy (what round 5's default did until its second "stall"): for boxes known to pin fast.
+// hm_get_stats counts the copies each way.  xfer_prefault first-touches a destination the process has never written (the fresh Vec
+// of a result) from helper threads while the transform is still running -- only the direct path needs it (a direct copy into untouched
+// pages takes its faults one by one, 5 ms per 64 MiB; the lanes' eight threads take them in parallel while they copy out).
 #include <hip/hip_runtime.h>
 
 #include <atomic>
-#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
+#include <vector>
 
 #include "hm_internal.h"
 
@@ -49,10 +61,63 @@ int xfer_set_policy(int mode) {
   xfer_policy_cell().store(mode, std::memory_order_relaxed);
   return 0;
 }
-constexpr int kXferStallsBeforeLanes = 2;
 
-static double xfer_now_us() {
-  return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
+// ---- ranges the caller has registered (hm_host_register): process-wide, a handful of entries --------------------------------------------
+struct HostRange {
+  const char* lo;
+  size_t bytes;
+};
+static std::mutex& host_ranges_mu() {
+  static std::mutex m;
+  return m;
+}
+static std::vector<HostRange>& host_ranges() {
+  static std::vector<HostRange> v;
+  return v;
+}
+static bool host_range_registered(const void* p, size_t bytes) {
+  std::lock_guard<std::mutex> lk(host_ranges_mu());
+  const char* q = (const char*)p;
+  for (const HostRange& r : host_ranges())
+    if (q >= r.lo && bytes <= r.bytes && (size_t)(q - r.lo) <= r.bytes - bytes) return true;
+  return false;
+}
+int xfer_host_register(const void* p, size_t bytes) {
+  if (!p || bytes == 0) return hm_fail(HM_ERR_BAD_ARG, "hm_host_register: null or empty range");
+  {
+    std::lock_guard<std::mutex> lk(host_ranges_mu());
+    const char* q = (const char*)p;
+    for (const HostRange& r : host_ranges())
+      if (q < r.lo + r.bytes && r.lo < q + bytes) return hm_fail(HM_ERR_BAD_ARG, "hm_host_register: the range overlaps a registered one");
+  }
+  const hipError_t e = hipHostRegister(const_cast<void*>(p), bytes, hipHostRegisterPortable);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    return hm_fail(HM_ERR_HIP, std::string("hm_host_register: ") + hipGetErrorString(e));
+  }
+  std::lock_guard<std::mutex> lk(host_ranges_mu());
+  host_ranges().push_back(HostRange{(const char*)p, bytes});
+  return HM_OK;
+}
+int xfer_host_unregister(const void* p) {
+  {
+    std::lock_guard<std::mutex> lk(host_ranges_mu());
+    auto& v = host_ranges();
+    size_t i = 0;
+    while (i < v.size() && v[i].lo != (const char*)p) ++i;
+    if (i == v.size()) return hm_fail(HM_ERR_BAD_ARG, "hm_host_unregister: not the start of a registered range");
+    v.erase(v.begin() + (long)i);
+  }
+  const hipError_t e = hipHostUnregister(const_cast<void*>(p));
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    return hm_fail(HM_ERR_HIP, std::string("hm_host_unregister: ") + hipGetErrorString(e));
+  }
+  return HM_OK;
+}
+size_t xfer_host_ranges() {
+  std::lock_guard<std::mutex> lk(host_ranges_mu());
+  return host_ranges().size();
 }
 
 // First-touch the pages of a host range from several threads WITHOUT changing its contents (every page's first byte is read and
@@ -158,22 +223,27 @@ static hipError_t lane_d2h(XferLane& l, int device, char* dst, const char* d_src
   return e;
 }
 
+// which way a copy goes is decided by the RANGE and the policy alone (see the head of this file)
+static bool xfer_goes_direct(const void* host, size_t bytes) {
+  if (bytes < kXferDirectBelow) return true;
+  const int policy = xfer_policy();
+  if (policy == XFER_DIRECT) return true;
+  if (policy == XFER_LANES) return false;
+  return host_range_registered(host, bytes);
+}
+
 static int xfer_run(DeviceCtx& ctx, bool up, void* dev, void* host, size_t bytes, const char* who) {
   if (bytes == 0) return HM_OK;
-  const int policy = xfer_policy();
-  const bool lanes_now = policy == XFER_LANES || (policy == XFER_AUTO && ctx.xfer.stalls.load(std::memory_order_relaxed) >= kXferStallsBeforeLanes);
-  if (bytes < kXferDirectBelow || !lanes_now) {
-    const double t0 = xfer_now_us();
+  static const bool trace = std::getenv("HALO2_MI355X_XFER_TRACE") != nullptr;
+  if (xfer_goes_direct(host, bytes)) {
     const hipError_t e = up ? hipMemcpy(dev, host, bytes, hipMemcpyHostToDevice) : hipMemcpy(host, dev, bytes, hipMemcpyDeviceToHost);
     if (e != hipSuccess) return hm_fail(HM_ERR_HIP, std::string(who) + ": " + hipGetErrorString(e));
-    const double dt = xfer_now_us() - t0;
-    if (bytes >= kXferDirectBelow && dt > 2000.0 + (double)bytes / 4000.0) {      // 4 GB/s = 4 000 bytes per microsecond
-      ctx.xfer.stalls.fetch_add(1, std::memory_order_relaxed);
-      static const bool trace = std::getenv("HALO2_MI355X_XFER_TRACE") != nullptr;
-      if (trace) std::fprintf(stderr, "[halo2_mi355x] stalled copy: %s %zu bytes in %.2f ms (%s)\n", up ? "H2D" : "D2H", bytes, dt / 1e3, who);
-    }
+    ctx.xfer.direct.fetch_add(1, std::memory_order_relaxed);
+    if (trace) std::fprintf(stderr, "[halo2_mi355x] copy: %s %zu bytes direct (%s)\n", up ? "H2D" : "D2H", bytes, who);
     return HM_OK;
   }
+  ctx.xfer.staged.fetch_add(1, std::memory_order_relaxed);
+  if (trace) std::fprintf(stderr, "[halo2_mi355x] copy: %s %zu bytes through the lanes (%s)\n", up ? "H2D" : "D2H", bytes, who);
   std::lock_guard<std::mutex> lk(ctx.xfer.mu);                    // the lanes' slots belong to one transfer at a time
   int want = (int)((bytes + ((size_t)1 << 20) - 1) >> 20);        // a lane per MiB, eight at most
   if (want > HM_XFER_LANES) want = HM_XFER_LANES;
@@ -207,10 +277,8 @@ static int xfer_run(DeviceCtx& ctx, bool up, void* dev, void* host, size_t bytes
   return HM_OK;
 }
 
-int xfer_mode(DeviceCtx& ctx) {
-  const int policy = xfer_policy();
-  return policy == XFER_LANES || (policy == XFER_AUTO && ctx.xfer.stalls.load(std::memory_order_relaxed) >= kXferStallsBeforeLanes) ? 1 : 0;
-}
+// 1: a copy of `bytes` from / to `host` would go through the lanes now; 0: straight to hipMemcpy
+int xfer_mode(const void* host, size_t bytes) { return xfer_goes_direct(host, bytes) ? 0 : 1; }
 
 int xfer_h2d(DeviceCtx& ctx, void* d_dst, const void* src, size_t bytes, const char* who) {
   return xfer_run(ctx, true, d_dst, const_cast<void*>(src), bytes, who);

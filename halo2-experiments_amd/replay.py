@@ -608,9 +608,11 @@ def run_replay(shape_name: str, device=None, group=None, include_host_pointer_es
         _st = _l.Stats()
         _l.check(_l.load().hm_get_stats(ctypes.byref(_st)))
         out["host_pointer_estimate_s"] = {
-            "host_copies": {"stalls_seen_by_this_process": int(_st.host_copy_stalls), "through_the_librarys_pinned_lanes": bool(_st.host_copy_lanes),
-                            "note": "csrc/xfer.hip: the runtime's pageable path until a copy has stalled twice, then the library's own lanes "
-                                    "(+0.7 ms per 72 MiB): which of the two these per-call figures were taken on"},
+            "host_copies": {"through_the_librarys_pinned_lanes": int(_st.host_copies_staged), "handed_to_hipMemcpy": int(_st.host_copies_direct),
+                            "ranges_registered": int(_st.host_ranges_registered),
+                            "note": "csrc/xfer.hip: copies of this process so far, by route.  The rule is on the range, not on a timing: unregistered "
+                                    "host ranges of 256 KiB or more go through the library's pinned lanes (the same cost on every box), registered "
+                                    "ones (hm_host_register) and small ones straight to hipMemcpy"},
             "msm_batches_from_host_arrays": t_batch_host,
             "msm_each": t_msm, "ntt_n_each": t_ntt_n, "ntt_ext_each": t_ntt_e, "coeff_to_extended_each": t_c2e, "extended_to_coeff_each": t_e2c,
             "coeff_to_extended_into_a_fresh_array_each": t_c2e_fresh, "host_zero_padding_each": t_resize,

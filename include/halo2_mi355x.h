@@ -172,20 +172,30 @@ int hm_set_host_base_cache(int enable);
  * entry points with nothing but this library (rust/halo2_proofs-patch/src/mi355x_dev.rs: DevicePoly).  All on the calling
  * thread's current device (hm_set_device).
  *   hm_device_malloc / hm_device_free: hipMalloc / hipFree (free waits for the device: keep buffers for the life of a proof);
- *   hm_copy_to_device / hm_copy_to_host: synchronous, through the same copy policy as the host-pointer forms (hm_set_host_copies);
- *     the device range must not be in use by work in flight -- hm_device_synchronize() (all streams of the device) or the
- *     caller's own stream synchronisation first.  stream == NULL in the *_dev entry points is the device's default stream. */
+ *   hm_copy_to_device / hm_copy_to_host: synchronous, through the same copy policy as the host-pointer forms (hm_set_host_copies).
+ *     Ordered behind everything queued on the device's default stream and on blocking streams (the call waits for them, whichever
+ *     way the bytes travel); work on NON-blocking streams of the caller's own needs the caller's synchronisation first
+ *     (hm_device_synchronize() waits for all streams).  stream == NULL in the *_dev entry points is the device's default stream. */
 int hm_device_malloc(size_t bytes, void** d_out);
 int hm_device_free(void* d_ptr);
 int hm_copy_to_device(void* d_dst, const void* src, size_t bytes);
 int hm_copy_to_host(void* dst, const void* d_src, size_t bytes);
 int hm_device_synchronize(void);
 
-/* How the host-pointer forms move their arrays (csrc/xfer.hip): 0 = auto (the default; HALO2_MI355X_HOST_COPIES sets the start value):
- * the runtime's pageable path on the caller's pointers until a copy has twice taken several times its healthy worst case, then the
- * library's own pinned staging lanes for the rest of the process; 1 = lanes always (nothing of the caller's memory is ever registered
- * with the driver: latency independent of what the caller maps and unmaps, +0.7 ms per 72 MiB); 2 = direct always.  Process-wide. */
+/* How the host-pointer forms move their arrays (csrc/xfer.hip) -- a rule on the host RANGE, never on a timing.
+ * 0 = auto (the default; HALO2_MI355X_HOST_COPIES sets the start value): a range the caller has declared long-lived with
+ *     hm_host_register goes straight to hipMemcpy (a DMA from registered memory); every other range of 256 KiB or more goes through the
+ *     library's own pinned staging lanes -- nothing of the caller's memory is handed to the driver, so the cost does not depend on what
+ *     pinning a page costs on the box (0.1 us or 9 us: both exist in one pool) nor on what the caller maps and unmaps around the calls;
+ * 1 = lanes always (registered ranges too); 2 = direct always (hipMemcpy pins the caller's pages on the fly: 0.7 ms per 72 MiB
+ *     faster where pinning is cheap, 2.3 ms per MiB slower where it is not -- for boxes known to pin fast).  Process-wide. */
 int hm_set_host_copies(int mode);
+/* Declare [p, p + bytes) long-lived host memory (an SRS kept in memory, a staging buffer reused for every proof): pinned ONCE here
+ * (hipHostRegister, portable across devices), after which the host-pointer forms and hm_copy_to_* DMA from / into it directly.  The
+ * range must stay mapped until hm_host_unregister(p) (p = the start of a registered range); ranges must not overlap.  Needs a
+ * device (the registration is the runtime's).  Not for arrays that live for one call: registering costs what the lanes avoid. */
+int hm_host_register(const void* p, size_t bytes);
+int hm_host_unregister(const void* p);
 
 /* Window-size override for experiments (0 = automatic). */
 int hm_msm_set_window(int c);
@@ -485,10 +495,10 @@ typedef struct hm_stats {
   /* ... and for the twiddle tables of the transforms, one set per (omega, log_n): stage tables, and up to 2^21 a direct inter-pass
    * table of 2^log_n x 36 B (75 MB at 2^21).  LRU, at most 64 sets and 1 GiB. */
   uint64_t ntt_table_bytes, ntt_tables;
-  /* The host-pointer forms' copies (csrc/xfer.hip): direct copies that took several times their healthy worst case since the library
-   * was loaded (hm_reset_stats leaves it), and whether the copies now go through the library's own pinned staging lanes (1) or the
-   * runtime's pageable path on the caller's pointers (0).  HALO2_MI355X_HOST_COPIES = auto (direct until the second stall) | lanes | direct. */
-  uint64_t host_copy_stalls, host_copy_lanes;
+  /* The host-pointer forms' copies (csrc/xfer.hip), counted on this device since the library was loaded (hm_reset_stats leaves
+   * them): copies handed to hipMemcpy on the caller's pointers (registered ranges, anything below 256 KiB, policy "direct"), copies
+   * moved through the library's pinned staging lanes, and the ranges registered now (hm_host_register; process-wide). */
+  uint64_t host_copies_direct, host_copies_staged, host_ranges_registered;
 } hm_stats;
 #define HM_STAT_EVAL_POLYNOMIAL 0
 #define HM_STAT_GRAPH_EVALUATE 1

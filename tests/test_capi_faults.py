@@ -126,7 +126,7 @@ def test_the_copy_lanes_are_optional(fi, cref):
         out = np.empty((en, 4), dtype=np.uint64)           # fresh pages
         rc = fi.hm_coeff_to_extended_bn256_fr(_u64(coeffs), _u64(out), _u64(fr_words(d.extended_omega)), d.k, d.extended_k, _u64(coset))
         return rc, out
-    assert fi.hm_set_host_copies(1) == 0                   # lanes always (the default policy starts on the runtime's path)
+    assert fi.hm_set_host_copies(1) == 0                   # lanes always (the default policy too, for ranges the caller has not registered)
     rc, want = run()
     assert rc == 0
     pad = np.zeros((en, 4), dtype=np.uint64)

@@ -257,6 +257,67 @@ def test_device_memory_entry_points_carry_a_prover_without_a_hip_binding(cref, h
     assert lib.hm_device_malloc(0, ctypes.byref(z)) == 0 and z.value is None
 
 
+def test_the_copy_route_is_a_rule_on_the_range_and_both_routes_are_ordered_behind_the_default_stream(cref):
+    """csrc/xfer.hip, round 6: no timing decides anything.  Under the default policy an array the caller has NOT registered goes through
+    the library's pinned lanes, a range registered with hm_host_register straight to hipMemcpy (a DMA from registered memory) -- counted
+    by hm_get_stats, the same words either way.  And hm_copy_to_host waits for the default stream whichever way the bytes go: a transform
+    queued on stream NULL just before it, no hm_device_synchronize in between (on the lanes' non-blocking streams that read
+    stale data)."""
+    from halo2_experiments_amd.arithmetic import _ptr
+    lib = _lib.load()
+    _lib.check(lib.hm_set_host_copies(0))
+    k = 20                                                                     # 32 MiB: eight lanes
+    n = 1 << k
+    omega = fr_words(pow(7, (FR_MODULUS_FOR_TESTS - 1) >> k, FR_MODULUS_FOR_TESTS))
+    a0 = rand_fr_gpu(n, 6600).cpu().numpy().view(np.uint64).copy()
+    want = cref.best_fft(a0, omega, k, 8)
+
+    def stats():
+        st = _lib.Stats()
+        _lib.check(lib.hm_get_stats(ctypes.byref(st)))
+        return int(st.host_copies_direct), int(st.host_copies_staged), int(st.host_ranges_registered)
+
+    d0, s0, r0 = stats()
+    a = a0.copy()
+    h.best_fft(a, omega, k)                                                    # unregistered: up and down through the lanes
+    d1, s1, _ = stats()
+    assert np.array_equal(a, want) and s1 == s0 + 2 and d1 == d0
+    reg = a0.copy()
+    p = reg.ctypes.data_as(ctypes.c_void_p)
+    _lib.check(lib.hm_host_register(p, reg.nbytes))
+    try:
+        assert stats()[2] == r0 + 1
+        assert lib.hm_host_register(ctypes.c_void_p(p.value + 4096), 4096) == -1            # overlaps a registered range
+        assert lib.hm_host_unregister(ctypes.c_void_p(p.value + 4096)) == -1                # not the start of one
+        h.best_fft(reg, omega, k)                                              # registered: both copies direct
+        d2, s2, _ = stats()
+        assert np.array_equal(reg, want) and d2 == d1 + 2 and s2 == s1
+        half = reg[: n // 2]                                                   # a sub-range of a registered range is registered
+        h.best_fft(half, fr_words(pow(7, (FR_MODULUS_FOR_TESTS - 1) >> (k - 1), FR_MODULUS_FOR_TESTS)), k - 1)
+        assert stats()[0] == d2 + 2
+    finally:
+        _lib.check(lib.hm_host_unregister(p))
+    assert stats()[2] == r0 and lib.hm_host_unregister(p) == -1 and lib.hm_host_register(None, 8) == -1
+    # ordering: queue the transform on the default stream, read back at once
+    d_a = ctypes.c_void_p()
+    _lib.check(lib.hm_device_malloc(n * 32, ctypes.byref(d_a)))
+    try:
+        for mode in (0, 2):                                                    # the lanes (default policy), then hipMemcpy
+            _lib.check(lib.hm_set_host_copies(mode))
+            _lib.check(lib.hm_copy_to_device(d_a, a0.ctypes.data_as(ctypes.c_void_p), n * 32))
+            for _ in range(3):                                                 # forward, forward, forward: ~1 ms of queued work
+                _lib.check(lib.hm_ntt_batch_bn256_fr_dev(d_a, 1, _ptr(omega), k, None, None, None))
+            got = np.empty((n, 4), dtype=np.uint64)
+            _lib.check(lib.hm_copy_to_host(got.ctypes.data_as(ctypes.c_void_p), d_a, n * 32))        # no synchronize before it
+            exp = want
+            for _ in range(2):
+                exp = cref.best_fft(exp, omega, k, 8)
+            assert np.array_equal(got, exp), mode
+    finally:
+        _lib.check(lib.hm_set_host_copies(0))
+        _lib.check(lib.hm_device_free(d_a))
+
+
 def test_edge_values(cref, pyref):
     o = pyref
     k = 6

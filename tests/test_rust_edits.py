@@ -156,3 +156,27 @@ def test_glue_is_free_of_the_risks_the_review_named():
     # and therefore panics on a half-written array instead of letting the CPU body continue on it
     assert "Vec::with_capacity(len)" in glue and "*a = ext;" in glue and glue.count("HM_ERR_PARTIAL_OUTPUT") >= 3
     assert "hm_coeff_to_extended_bn256_fr(" in glue and "hm_extended_to_coeff_bn256_fr(" in glue and "a.truncate(keep);" in glue
+
+
+def test_the_device_glue_cannot_cost_the_drop_in_its_build():
+    """mi355x_dev.rs (264 lines that have never met rustc) was compiled for every user of the drop-in patch.  Now behind a
+    cargo feature; every generated module carries its own lint allowance (the crate denies missing_docs / missing_debug_implementations
+    / unsafe_code as recalled); none depends on the ff version's `one()`."""
+    table = json.load(open(os.path.join(RUST, "edits.json")))
+    arith = next(e for e in table if e["file"] == "src/arithmetic.rs" and "best_multiexp" in e["anchor"])
+    lines = arith["replacements"][0]
+    i = lines.index("pub mod mi355x_dev;")
+    assert lines[i - 2] == '#[cfg(feature = "mi355x-dev")]' and lines[i - 1] == '#[path = "mi355x_dev.rs"]'
+    assert lines[lines.index("pub mod mi355x;") - 1] == '#[path = "mi355x.rs"]' and "cfg" not in lines[lines.index("pub mod mi355x;") - 2]
+    feat = [e for e in table if e["file"] == "Cargo.toml" and e["anchor"] == "[features]"]
+    assert len(feat) == 1 and feat[0]["optional"] is True and feat[0]["replacements"][0] == ["[features]", "mi355x-dev = []"]
+    for name in ("mi355x.rs", "mi355x_kzg.rs", "mi355x_dev.rs"):
+        text = open(os.path.join(RUST, "halo2_proofs-patch", "src", name)).read()
+        assert "#![allow(unsafe_code, missing_docs, missing_debug_implementations" in text, name
+        head = text[: text.index("#![allow(")]
+        assert all(ln.startswith("//") or not ln.strip() for ln in head.splitlines()), name       # inner attributes come before any item
+        assert "Fr::one()" not in text.replace("bn256::Fr::one()", "") and "Fr::ONE" not in text, name
+    dev = open(os.path.join(RUST, "halo2_proofs-patch", "src", "mi355x_dev.rs")).read()
+    for struct in ("DevicePoly", "DeviceDomain", "QuotientProgram"):
+        at = dev.index(f"pub struct {struct} ")
+        assert dev[:at].rstrip().endswith("#[derive(Debug)]"), struct

@@ -241,6 +241,9 @@ MI355X_RS = '''//! mi355x.rs -- glue between halo2_proofs::arithmetic and libhal
 //! WITHOUT having touched the caller's arrays, and the caller falls through to the untouched upstream body: other
 //! curves / fields, tiny inputs, no device, any error code but HM_ERR_PARTIAL_OUTPUT (which panics: see try_best_fft).
 //! Needs nothing newer than Rust 1.56: std::sync::Once + AtomicBool for the one-time check (the pinned tag predates the 1.70 cell types).
+// halo2_proofs' lib.rs denies these crate-wide (as recalled: #![deny(missing_docs)], #![deny(missing_debug_implementations)],
+// #![deny(unsafe_code)]); this module is FFI glue -- the allowance is scoped to it.
+#![allow(unsafe_code, missing_docs, missing_debug_implementations, clippy::all)]
 use std::any::TypeId;
 use std::sync::atomic::{AtomicBool, Ordering};
 use std::sync::Once;
@@ -315,7 +318,13 @@ pub fn try_best_fft<G: Group>(a: &mut [G], omega: &G::Scalar, log_n: u32) -> boo
 }
 
 /// R mod r: bn256::Fr::one() as the four Montgomery words the library reads (spelled out: no dependence on the ff version's `one()` / `ONE`).
-const FR_ONE: [u64; 4] = [0xac96341c4ffffffb, 0x36fc76959f60cd29, 0x666ea36f7879462e, 0x0e0a77c19a07df2f];
+pub(crate) const FR_ONE: [u64; 4] = [0xac96341c4ffffffb, 0x36fc76959f60cd29, 0x666ea36f7879462e, 0x0e0a77c19a07df2f];
+
+/// The same as an `Fr` (Montgomery words are the in-memory form: layout_ok() has checked 32 bytes).
+#[allow(dead_code)]
+pub(crate) fn fr_one() -> Fr {
+    unsafe { std::mem::transmute_copy::<[u64; 4], Fr>(&FR_ONE) }
+}
 
 fn fr_words<S>(s: &S) -> [u64; 4] {
     unsafe { std::mem::transmute_copy::<S, [u64; 4]>(s) } // S == Fr here (TypeId-checked by the callers; 32 bytes by layout_ok)
@@ -402,6 +411,9 @@ MI355X_KZG_RS = '''//! mi355x_kzg.rs -- ParamsKZG's side of the binding (added b
 //! both sets, and a handle is used only while the Vec it came from still starts at the same address and is at least as
 //! long as when it was registered (`downsize` truncates g in place -- a prefix, still valid -- and REPLACES g_lagrange,
 //! whose new buffer fails that test and is registered afresh).
+// halo2_proofs' lib.rs denies these crate-wide (as recalled: #![deny(missing_docs)], #![deny(missing_debug_implementations)],
+// #![deny(unsafe_code)]); this module is FFI glue -- the allowance is scoped to it.
+#![allow(unsafe_code, missing_docs, missing_debug_implementations, clippy::all)]
 use std::any::TypeId;
 use std::fmt;
 use std::sync::atomic::{AtomicU64, AtomicUsize, Ordering};
@@ -567,6 +579,9 @@ MI355X_DEV_RS = '''//! mi355x_dev.rs -- polynomials that STAY in HBM between the
 //! arrays.  A prover adopts it step by step: upload advice columns once (`DevicePoly::from_slice`), commit from the device, transform
 //! on the device, bring back only what the transcript needs.  Nothing here is reached by the drop-in edits; nothing here has met rustc.
 //! Every function returns None / false on any error (sys::last_error() has the message) and never panics.
+// halo2_proofs' lib.rs denies these crate-wide (as recalled: #![deny(missing_docs)], #![deny(missing_debug_implementations)],
+// #![deny(unsafe_code)]); this module is FFI glue -- the allowance is scoped to it.
+#![allow(unsafe_code, missing_docs, missing_debug_implementations, clippy::all)]
 use std::os::raw::c_void;
 use std::ptr;
 
@@ -574,13 +589,14 @@ use ff::Field;
 use halo2_mi355x_sys as sys;
 use halo2curves::bn256::{Fr, G1};
 
-use crate::arithmetic::mi355x::{g1_from_words, layout_ok};
+use crate::arithmetic::mi355x::{fr_one, g1_from_words, layout_ok, FR_ONE};
 
 fn words(x: &Fr) -> [u64; 4] {
     unsafe { std::mem::transmute_copy::<Fr, [u64; 4]>(x) } // 32 bytes, Montgomery words (layout_ok() asserts the layout once)
 }
 
 /// `len` field elements in device memory; freed on drop (hipFree waits for the device: keep buffers for the life of a proof).
+#[derive(Debug)]
 pub struct DevicePoly {
     ptr: *mut c_void,
     len: usize,
@@ -640,6 +656,7 @@ impl Drop for DevicePoly {
 }
 
 /// The constants of an `EvaluationDomain<Fr>` the device steps need (all of them fields of poly/domain.rs), copied out once.
+#[derive(Debug)]
 pub struct DeviceDomain {
     pub k: u32,
     pub extended_k: u32,
@@ -686,7 +703,7 @@ impl DeviceDomain {
         }
         let batch = a.len() / self.n();
         let mut ext = DevicePoly::new(batch * self.extended_len())?;
-        let coset = self.coset_words(if internal { Fr::from(32u64) } else { Fr::one() });
+        let coset = self.coset_words(if internal { Fr::from(32u64) } else { fr_one() });
         let w = words(&self.extended_omega);
         let rc = unsafe {
             sys::hm_coeff_to_extended_bn256_fr_dev(a.as_ptr(), ext.as_mut_ptr(), batch, w.as_ptr(), self.k, self.extended_k, coset.as_ptr(), ptr::null_mut())
@@ -700,7 +717,7 @@ impl DeviceDomain {
             return false;
         }
         let mut c = [0u64; 12]; // [1, g_coset_inv, g_coset]: distribute_powers_zeta(a, false)
-        c[..4].copy_from_slice(&words(&Fr::one()));
+        c[..4].copy_from_slice(&FR_ONE);
         c[4..8].copy_from_slice(&words(&self.g_coset_inv));
         c[8..].copy_from_slice(&words(&self.g_coset));
         let (w, d) = (words(&self.extended_omega_inv), words(&self.extended_ifft_divisor));
@@ -771,6 +788,7 @@ pub fn eval_polynomial_dev(polys: &DevicePoly, n: usize, points: &[Fr]) -> Optio
 /// The UNDIVIDED numerator of h(X) -- custom gates, permutation and lookup terms combined by y -- as a straight-line program on
 /// the device (hm_graph_create: five words per calculation, include/halo2_mi355x.h; halo2-experiments_amd/evaluation.py lowers
 /// upstream's GraphEvaluator to it).  Built once per proving key.
+#[derive(Debug)]
 pub struct QuotientProgram {
     handle: u64,
     n_columns: usize,
@@ -831,7 +849,10 @@ _COMMIT_VIA = ["        if let Some(r) = self.gpu.{fn}::<E::G1Affine>(&scalars, 
 _LITERAL = ["            s_g2,", "            gpu: Default::default(),"]
 EDITS = [
     ("src/arithmetic.rs", "pub fn best_multiexp<C: CurveAffine>(coeffs: &[C::Scalar], bases: &[C]) -> C::Curve {",
-     [['#[path = "mi355x.rs"]', "pub mod mi355x;", '#[path = "mi355x_kzg.rs"]', "pub mod mi355x_kzg;", '#[path = "mi355x_dev.rs"]', "pub mod mi355x_dev;", "",
+     [['#[path = "mi355x.rs"]', "pub mod mi355x;", '#[path = "mi355x_kzg.rs"]', "pub mod mi355x_kzg;",
+       # the device-resident glue is NOT part of the drop-in: compiled only with `--features mi355x-dev` (declared by the optional
+       # [features] edit below), so that a defect in it can never cost the drop-in paths their build
+       '#[cfg(feature = "mi355x-dev")]', '#[path = "mi355x_dev.rs"]', "pub mod mi355x_dev;", "",
        "pub fn best_multiexp<C: CurveAffine>(coeffs: &[C::Scalar], bases: &[C]) -> C::Curve {",
        "    assert_eq!(coeffs.len(), bases.len());",
        "    if let Some(r) = mi355x::try_best_multiexp(coeffs, bases) {", "        return r;", "    }",
@@ -877,6 +898,13 @@ EDITS += [
        "            return r;", "        }",
        "        polys.iter().map(|p| self.commit_lagrange(p, Blind::default())).collect()",
        "    }", "", "    /// Writes params to a buffer."]], 300, True),
+]
+
+
+# OPTIONAL: the cargo feature that compiles mi355x_dev.rs (`cargo build --features mi355x-dev`).  Without this edit the cfg is simply
+# false and the module is left out.
+EDITS += [
+    ("Cargo.toml", "[features]", [["[features]", "mi355x-dev = []"]], 70, True),
 ]
 
 

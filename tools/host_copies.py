@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """The host-pointer (drop-in) entry points with their copies through the library's pinned staging lanes (csrc/xfer.hip, HALO2_MI355X_HOST_COPIES=lanes) and
-through the runtime's pageable path (HALO2_MI355X_HOST_COPIES=direct; the default policy `auto` starts there and moves to the lanes at the second stall), each mode in its own process: median AND worst of 12 calls per shape --
-the worst is the point: on some boxes the runtime's path stalls for 7-27 ms when the caller allocates / frees big arrays around the calls
-(what a prover does around every coeff_to_extended).  Every shape allocates a FRESH output / input array per call, like the Rust glue.
+through the runtime's pageable path (HALO2_MI355X_HOST_COPIES=direct), and with the default policy `auto` (lanes for every range the caller has not registered with
+hm_host_register), each mode in its own process: median AND worst of 12 calls per shape -- the worst is the point: on some boxes the runtime's path pays ~9 us per
+4 KiB page for every array it has not pinned before (what a prover hands it on every call).  Every "fresh" shape allocates a new output / input array per call, like
+the Rust glue; the "registered" rows reuse ONE array the caller has registered (the direct path by the caller's choice).
 
     python tools/host_copies.py            # both modes, table
     python tools/host_copies.py --child    # (internal) one mode, JSON line
@@ -52,6 +53,14 @@ def child():
         rec(f"best_fft 2^{dom.extended_k}, zero-padded fresh array", lambda: h.best_fft(np.concatenate([hs, np.zeros((dom.extended_len() - dom.n, 4), dtype=np.uint64)]), w, dom.extended_k))
         buf = keep.copy()
         rec(f"best_fft 2^{dom.extended_k}, touched array", lambda: h.best_fft(buf, w, dom.extended_k))
+    # a long-lived array the caller registers: direct DMA under the default policy
+    dom = EvaluationDomain(7, 18)
+    reg = np.zeros((dom.extended_len(), 4), dtype=np.uint64)
+    reg[:dom.n] = h.random_fr(dom.n, 6, dev).cpu().numpy().view(np.uint64)
+    lib = _lib.load()
+    if lib.hm_host_register(reg.ctypes.data_as(ctypes.c_void_p), reg.nbytes) == 0:
+        rec("best_fft 2^21, an array registered with hm_host_register", lambda: h.best_fft(reg, fr_words(dom.extended_omega), dom.extended_k))
+        _lib.check(lib.hm_host_unregister(reg.ctypes.data_as(ctypes.c_void_p)))
     n = 1 << 18
     bases = h.g1_fixed_base_mul(h.random_fr(n, 7, dev), G1_GENERATOR)
     handle = h.register_bases(bases)
@@ -62,7 +71,7 @@ def child():
     rec("... from fresh copies", lambda: best_multiexp_batch([c.copy() for c in cols], handle), reps=6)
     st = _lib.Stats()
     _lib.check(_lib.load().hm_get_stats(ctypes.byref(st)))
-    out["_policy"] = {"median_ms": float(st.host_copy_stalls), "max_ms": float(st.host_copy_lanes), "min_ms": 0.0}     # stalls seen / lanes active at the end
+    out["_copies"] = {"median_ms": float(st.host_copies_direct), "max_ms": float(st.host_copies_staged), "min_ms": 0.0}     # copies handed to hipMemcpy / through the lanes
     print(json.dumps(out))
 
 
