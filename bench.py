@@ -435,12 +435,20 @@ def replay_cpu_baseline(rep, device):
         fn()
         return time.perf_counter() - t0
 
-    per = {"msm_sparse": timed(lambda: cpu_ref.best_multiexp(sparse, bases, T)),
-           "msm_dense": timed(lambda: cpu_ref.best_multiexp(dense, bases, T)),
-           "intt_n": timed(lambda: cpu_ref.best_fft(dense, fr_words(pow(FR_ROOT_OF_UNITY, 1 << (28 - k), FR_MODULUS)), k, T))}
+    # The port starts its threads per call (upstream keeps a rayon pool): below 2^14 that start-up is most of a call, so small shapes
+    # are timed on ONE thread as well and the faster figure stands for a pooled runtime
+    def best_threads(fn, log_size):
+        t = timed(lambda: fn(T))
+        if log_size < 14:
+            t = min(t, timed(lambda: fn(T)), timed(lambda: fn(1)), timed(lambda: fn(1)))
+        return t
+
+    per = {"msm_sparse": best_threads(lambda th: cpu_ref.best_multiexp(sparse, bases, th), k),
+           "msm_dense": best_threads(lambda th: cpu_ref.best_multiexp(dense, bases, th), k),
+           "intt_n": best_threads(lambda th: cpu_ref.best_fft(dense, fr_words(pow(FR_ROOT_OF_UNITY, 1 << (28 - k), FR_MODULUS)), k, th), k)}
     ext = np.zeros((1 << ek, 4), dtype=np.uint64)
     ext[:n] = dense
-    per["coset_ntt_ext"] = timed(lambda: cpu_ref.best_fft(ext, fr_words(pow(FR_ROOT_OF_UNITY, 1 << (28 - ek), FR_MODULUS)), ek, T))
+    per["coset_ntt_ext"] = best_threads(lambda th: cpu_ref.best_fft(ext, fr_words(pow(FR_ROOT_OF_UNITY, 1 << (28 - ek), FR_MODULUS)), ek, th), ek)
     per["intt_ext"] = per["coset_ntt_ext"]
     calls = rep["calls"]
     msm = per["msm_sparse"] * calls["msm_sparse"] + per["msm_dense"] * calls["msm_dense"]
@@ -448,7 +456,8 @@ def replay_cpu_baseline(rep, device):
     info.update({"per_call_s": per, "calls": calls, "msm_s": msm, "ntt_s": ntt, "total_s": msm + ntt, "unit": "s",
                  "gpu_msm_plus_ntt_s": rep["device_resident_s"]["msm"] + rep["device_resident_s"]["ntt"],
                  "sample": "each distinct call shape timed ONCE on the oracle (oracle/cpu_ref.c, C restatement of halo2_proofs "
-                           "v2023_02_02 best_multiexp / best_fft), multiplied by the trace's call counts; MSM + best_fft only"})
+                           "v2023_02_02 best_multiexp / best_fft; shapes below 2^14: the faster of `cores` threads and one thread, twice "
+                           "each), multiplied by the trace's call counts; MSM + best_fft only"})
     return info
 
 
@@ -1208,6 +1217,16 @@ def main():
                                               "commitments of every phase, its cosets of the extended domain, for rank 0 the steps only rank 0 "
                                               "runs); the step takes the longer of them plus the exchanges -- 96 B per commitment, n x 32 B "
                                               "per coset -- which are not in these times"}
+            legs.stop()
+        # the same proof through exactly the calls of rust/halo2_proofs-patch/src/mi355x_dev.rs (halo2-experiments_amd/rust_glue.py):
+        # what a Rust prover that keeps its polynomials in DevicePolys gets -- upload once, resident steps, download -- next to the
+        # per-call drop-in total
+        if world == 1 and not args.no_extras and "merkle_sum_tree_k18" in by_name and legs.start("k18_rust_device_glue", 8.0):
+            try:
+                from halo2_experiments_amd.rust_glue import run_proof
+                by_name["merkle_sum_tree_k18"]["rust_device_glue"] = run_proof("merkle_sum_tree_k18", device=device, reps=3, check=True)
+            except Exception as exc:  # noqa: BLE001 -- a side measurement never costs the line
+                by_name["merkle_sum_tree_k18"]["rust_device_glue"] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
             legs.stop()
         if rank == 0 and world == 1 and not args.no_cpu_baseline and legs.start("replay_cpu_baselines", 10.0):
             for rep in replay:

@@ -183,18 +183,25 @@ static int xfer_prepare(HostXfer& x, int want) {
   return x.ready < want ? x.ready : want;
 }
 
+// Chunks of one lane's share: uniform, one slot each.  Measured negative (round 6, profiles/r06_host_copies.txt): chunks ramping
+// 256 KiB -> 2 MiB -> 256 KiB (to shorten the pipeline's fill and drain) made every shape slower -- a phase of 19 commitments 13.3 ms against
+// 10.9, coeff_to_extended into a fresh array 6.0 against 5.1 -- as round 5's 512 KiB ring had: the fixed cost per DMA (~15 us, serialised
+// on the copy engines over all lanes) outweighs the shorter fill.  32 DMAs of 2 MiB per 64 MiB is where the two costs balance.
+static size_t xfer_next_chunk(size_t /*done*/, size_t remaining) { return remaining < kXferSlot ? remaining : kXferSlot; }
+
 static hipError_t lane_h2d(XferLane& l, int device, char* d_dst, const char* src, size_t bytes) {
   hipError_t e = hipSetDevice(device);
   bool used[2] = {false, false};
   int slot = 0;
-  for (size_t off = 0; off < bytes && e == hipSuccess; off += kXferSlot, slot ^= 1) {
-    const size_t len = bytes - off < kXferSlot ? bytes - off : kXferSlot;
+  for (size_t off = 0; off < bytes && e == hipSuccess; slot ^= 1) {
+    const size_t len = xfer_next_chunk(off, bytes - off);
     if (used[slot]) e = hipEventSynchronize(l.ev[slot]);          // the DMA that last read this slot
     if (e != hipSuccess) break;
     std::memcpy(l.pin[slot], src + off, len);
     e = hipMemcpyAsync(d_dst + off, l.pin[slot], len, hipMemcpyHostToDevice, l.stream);
     if (e == hipSuccess) e = hipEventRecord(l.ev[slot], l.stream);
     used[slot] = true;
+    off += len;
   }
   const hipError_t s = hipStreamSynchronize(l.stream);
   return e != hipSuccess ? e : s;
@@ -203,21 +210,24 @@ static hipError_t lane_h2d(XferLane& l, int device, char* d_dst, const char* src
 static hipError_t lane_d2h(XferLane& l, int device, char* dst, const char* d_src, size_t bytes) {
   hipError_t e = hipSetDevice(device);
   if (e != hipSuccess || bytes == 0) return e;
-  auto len_at = [&](size_t off) { return bytes - off < kXferSlot ? bytes - off : kXferSlot; };
-  auto issue = [&](int slot, size_t off) {
-    hipError_t r = hipMemcpyAsync(l.pin[slot], d_src + off, len_at(off), hipMemcpyDeviceToHost, l.stream);
+  size_t issued = 0, copied = 0, len[2] = {0, 0};
+  auto issue = [&](int slot) {
+    len[slot] = xfer_next_chunk(issued, bytes - issued);
+    hipError_t r = hipMemcpyAsync(l.pin[slot], d_src + issued, len[slot], hipMemcpyDeviceToHost, l.stream);
     if (r == hipSuccess) r = hipEventRecord(l.ev[slot], l.stream);
+    issued += len[slot];
     return r;
   };
   int slot = 0;
-  e = issue(0, 0);
-  for (size_t off = 0; off < bytes && e == hipSuccess; off += kXferSlot, slot ^= 1) {
-    const size_t next = off + kXferSlot;
-    if (next < bytes) e = issue(slot ^ 1, next);                  // the next DMA runs while this slot is copied out
+  e = issue(0);
+  while (copied < bytes && e == hipSuccess) {
+    if (issued < bytes) e = issue(slot ^ 1);                      // the next DMA runs while this slot is copied out
     const hipError_t w = hipEventSynchronize(l.ev[slot]);
     if (e == hipSuccess) e = w;
     if (e != hipSuccess) break;
-    std::memcpy(dst + off, l.pin[slot], len_at(off));
+    std::memcpy(dst + copied, l.pin[slot], len[slot]);
+    copied += len[slot];
+    slot ^= 1;
   }
   if (e != hipSuccess) (void)hipStreamSynchronize(l.stream);     // nothing of ours stays in flight behind an error
   return e;

@@ -538,28 +538,33 @@ def run_replay(shape_name: str, device=None, group=None, include_host_pointer_es
         import ctypes
         h_s = dense[0].cpu().numpy().view(np.uint64)
 
-        def best_of(fn, reps=3):
+        medians = {}
+
+        def best_of(fn, reps=5, name=None):
             """Seconds of the fastest of `reps` calls after one warm-up: a per-call figure, not a sample of whatever one call met (staging
-            buffers growing, copy lanes being created, a stalled copy)."""
+            buffers growing, copy lanes being created).  The MEDIAN of the same calls goes to `medians[name]`: the totals are reported on
+            both (round 5 reported the fastest of three only, round 4 one sample: not comparable round over round -- profiles/README.md)."""
             fn()
-            best = None
+            ts = []
             for _ in range(reps):
                 t0 = time.perf_counter()
                 fn()
-                dt = time.perf_counter() - t0
-                best = dt if best is None or dt < best else best
-            return best
+                ts.append(time.perf_counter() - t0)
+            ts.sort()
+            if name:
+                medians[name] = ts[len(ts) // 2]
+            return ts[0]
 
         from .arithmetic import best_fft
-        t_msm = best_of(lambda: best_multiexp(h_s, gl_h))
+        t_msm = best_of(lambda: best_multiexp(h_s, gl_h), name="msm_each")
         a_n = h_s.copy()
-        t_ntt_n = best_of(lambda: best_fft(a_n, fr_words(dom.omega), k))
+        t_ntt_n = best_of(lambda: best_fft(a_n, fr_words(dom.omega), k), name="ntt_n_each")
         a_e = np.zeros((dom.extended_len(), 4), dtype=np.uint64); a_e[:n] = h_s
-        t_ntt_e = best_of(lambda: best_fft(a_e, fr_words(dom.extended_omega), dom.extended_k))
+        t_ntt_e = best_of(lambda: best_fft(a_e, fr_words(dom.extended_omega), dom.extended_k), name="ntt_ext_each")
         # the two EvaluationDomain steps through their own host-pointer forms (the optional src/poly/domain.rs edits of rust/): the zero
         # padding never goes up, the truncated tail never comes down
         ext_h = dom.coeff_to_extended(h_s)
-        t_c2e = best_of(lambda: dom.coeff_to_extended(h_s, out=ext_h))          # into pages that exist: the library's own time
+        t_c2e = best_of(lambda: dom.coeff_to_extended(h_s, out=ext_h), name="coeff_to_extended_each")          # into pages that exist: the library's own time
         # ... into a FRESH 2^extended_k x 32 B array (what the Rust glue's new Vec is): first-touch faults on top -- the same faults
         # upstream's `resize` to the extended length takes BEFORE it calls best_fft, which the best_fft figure above does not contain
         t_c2e_fresh = best_of(lambda: dom.coeff_to_extended(h_s))
@@ -569,7 +574,7 @@ def run_replay(shape_name: str, device=None, group=None, include_host_pointer_es
             pad[:n] = h_s
             pad[n:] = 0
         t_resize = best_of(zero_pad)
-        t_e2c = best_of(lambda: dom.extended_to_coeff(ext_h))
+        t_e2c = best_of(lambda: dom.extended_to_coeff(ext_h), name="extended_to_coeff_each")
         del ext_h
         # ... and the commitments of the whole proof from HOST arrays through the batch call (uploads pipelined behind the
         # other commitments' kernels): what a prover that keeps its polynomials in host vectors gets per proof
@@ -592,7 +597,9 @@ def run_replay(shape_name: str, device=None, group=None, include_host_pointer_es
         # pages), the domain edits write into a fresh output array instead (first-touch faults inside the call)
         domain_edits = batched - t_ntt_e * (counts["coset_ntt_ext"] + counts["intt_ext"]) + t_c2e * counts["coset_ntt_ext"] \
             + t_e2c * counts["intt_ext"]
-        out["total_s"] = {"drop_in_host_pointers": hp_total, "device_resident": wall,
+        hp_total_median = medians["msm_each"] * (counts["msm_sparse"] + counts["msm_dense"]) + medians["ntt_n_each"] * counts["intt_n"] \
+            + medians["ntt_ext_each"] * (counts["coset_ntt_ext"] + counts["intt_ext"])
+        out["total_s"] = {"drop_in_host_pointers": hp_total, "drop_in_host_pointers_on_median_calls": hp_total_median, "device_resident": wall,
                           "drop_in_with_batched_commitments": batched, "drop_in_with_domain_edits": domain_edits,
                           "host_page_faults_on_top": {"best_fft_routes_resize_to_extended_length": t_resize * counts["coset_ntt_ext"],
                                                       "domain_edits_fresh_output_arrays": max(t_c2e_fresh - t_c2e, 0.0) * counts["coset_ntt_ext"]},
@@ -619,8 +626,9 @@ def run_replay(shape_name: str, device=None, group=None, include_host_pointer_es
             "page_fault_note": "coeff_to_extended_each writes into touched pages; a fresh output array (the normal case: a new Vec) adds its "
                                "first-touch faults (the kernel zeroes 2^extended_k x 32 B either way); upstream's resize-to-extended-length "
                                "(host_zero_padding_each, numpy here) takes the same faults before best_fft",
-            "total": hp_total,
-            "note": "PCIe-inclusive: every call uploads its scalars / moves its array both ways"}
+            "total": hp_total, "median_of_five_calls": dict(medians),
+            "note": "PCIe-inclusive: every call uploads its scalars / moves its array both ways; *_each = the fastest of five calls after one "
+                    "warm-up, median_of_five_calls = the median of the same five"}
     gate_prog.destroy()
     if coset_prog is not None:
         coset_prog.destroy()

@@ -1,0 +1,479 @@
+"""The call sequence of ``rust/halo2_proofs-patch/src/mi355x_dev.rs``, executed.
+
+There is no Rust toolchain in this image, so the device-resident half of the Rust boundary (``DevicePoly``, ``DeviceDomain``,
+``commit_dev`` / ``commit_batch_dev`` / ``commit_pieces_dev``, ``eval_polynomial_dev``, ``QuotientProgram``) has never run.  This
+module is its twin, method for method: every method below makes the C-ABI call its Rust namesake makes -- the same entry point,
+the same argument order, NULL stream, host arrays where the Rust passes slices -- through ``sys``, a recorder over the
+library that counts calls by name.  No torch, no HIP binding: device memory comes from ``hm_device_malloc`` exactly as a Rust
+prover's would.  tests/test_rust_glue_gpu.py extracts the ``sys::hm_*`` names from the .rs file and holds this module (and a whole
+k = 18 proof driven through it, ``run_proof``) to that list: what ``run_proof`` measures is what a prover adopting that file gets.
+
+Reference boundary: /root/reference/src/circuits/utils.rs:40-48 (create_proof) over halo2_proofs v2023_02_02.
+"""
+from __future__ import annotations
+
+import ctypes
+import re
+import time
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+from .domain import FR_MODULUS, fr_words
+
+_vp = ctypes.c_void_p
+FR_ONE = fr_words(1)
+
+
+class _Sys:
+    """``halo2_mi355x_sys``: the extern block, with a counter per entry point."""
+
+    def __init__(self):
+        self.calls: Dict[str, int] = {}
+
+    def reset(self):
+        self.calls = {}
+
+    def __getattr__(self, name):
+        if not name.startswith("hm_"):
+            raise AttributeError(name)
+        fn = getattr(_lib.load(), name)
+
+        def call(*args):
+            self.calls[name] = self.calls.get(name, 0) + 1
+            return fn(*args)
+
+        return call
+
+
+sys = _Sys()
+HM_OK = 0
+
+
+def _last_error() -> str:
+    return _lib.load().hm_last_error().decode()
+
+
+def entry_points_of_the_rust_file(path: str) -> List[str]:
+    """The ``sys::hm_*`` items a Rust source calls, in order of first appearance."""
+    seen: List[str] = []
+    for m in re.finditer(r"sys::(hm_[a-z0-9_]+)\s*\(", open(path).read()):
+        if m.group(1) not in seen:
+            seen.append(m.group(1))
+    return seen
+
+
+def _u64p(a: np.ndarray):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64))
+
+
+def _host(a) -> np.ndarray:
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    return a.reshape(-1, 4)
+
+
+class DevicePoly:
+    """``DevicePoly``: `len` field elements in device memory, freed on drop."""
+
+    def __init__(self, ptr: int, length: int):
+        self.ptr, self.len = ptr, length
+
+    @classmethod
+    def new(cls, length: int) -> Optional["DevicePoly"]:
+        p = _vp()
+        if sys.hm_device_malloc(length * 32, ctypes.byref(p)) != HM_OK:
+            return None
+        return cls(p.value or 0, length)
+
+    @classmethod
+    def from_slice(cls, a) -> Optional["DevicePoly"]:
+        a = _host(a)
+        d = cls.new(a.shape[0])
+        if d is None or sys.hm_copy_to_device(_vp(d.ptr), a.ctypes.data_as(_vp), a.shape[0] * 32) != HM_OK:
+            return None
+        return d
+
+    def upload_at(self, first: int, a) -> bool:
+        a = _host(a)
+        if first + a.shape[0] > self.len:
+            return False
+        return sys.hm_copy_to_device(_vp(self.ptr + first * 32), a.ctypes.data_as(_vp), a.shape[0] * 32) == HM_OK
+
+    def to_vec(self) -> Optional[np.ndarray]:
+        return self.to_vec_range(0, self.len)
+
+    def to_vec_range(self, first: int, length: int) -> Optional[np.ndarray]:
+        if first + length > self.len or sys.hm_device_synchronize() != HM_OK:
+            return None
+        v = np.empty((length, 4), dtype=np.uint64)            # Vec::with_capacity: fresh pages
+        if sys.hm_copy_to_host(v.ctypes.data_as(_vp), _vp(self.ptr + first * 32), length * 32) != HM_OK:
+            return None
+        return v
+
+    def drop(self):
+        if self.ptr:
+            sys.hm_device_free(_vp(self.ptr))
+            self.ptr = 0
+
+    def __del__(self):
+        try:
+            self.drop()
+        except Exception:  # noqa: BLE001 -- interpreter shutdown
+            pass
+
+
+class DeviceDomain:
+    """``DeviceDomain``: the constants of an ``EvaluationDomain<Fr>`` the device steps need, copied out once."""
+
+    def __init__(self, dom):
+        self.k, self.extended_k, self.quotient_poly_degree = dom.k, dom.extended_k, dom.quotient_poly_degree
+        self.omega, self.omega_inv = dom.omega, dom.omega_inv
+        self.extended_omega, self.extended_omega_inv = dom.extended_omega, dom.extended_omega_inv
+        self.g_coset, self.g_coset_inv = dom.g_coset, dom.g_coset_inv
+        self.ifft_divisor, self.extended_ifft_divisor = dom.ifft_divisor, dom.extended_ifft_divisor
+
+    def n(self) -> int:
+        return 1 << self.k
+
+    def extended_len(self) -> int:
+        return 1 << self.extended_k
+
+    def _coset_words(self, scale: int) -> np.ndarray:
+        return np.concatenate([fr_words(scale % FR_MODULUS), fr_words(self.g_coset * scale % FR_MODULUS),
+                               fr_words(self.g_coset_inv * scale % FR_MODULUS)])
+
+    def lagrange_to_coeff(self, a: DevicePoly) -> bool:
+        if a.len == 0 or a.len % self.n():
+            return False
+        return self.lagrange_to_coeff_range(a, 0, a.len // self.n())
+
+    def lagrange_to_coeff_range(self, a: DevicePoly, first: int, count: int) -> bool:
+        if count == 0 or (first + count) * self.n() > a.len:
+            return False
+        w, d = fr_words(self.omega_inv), fr_words(self.ifft_divisor)
+        return sys.hm_ntt_batch_bn256_fr_dev(_vp(a.ptr + first * self.n() * 32), count, _u64p(w), self.k, _u64p(d), None, None) == HM_OK
+
+    def coeff_to_extended(self, a: DevicePoly, internal: bool) -> Optional[DevicePoly]:
+        if a.len == 0 or a.len % self.n():
+            return None
+        batch = a.len // self.n()
+        ext = DevicePoly.new(batch * self.extended_len())
+        if ext is None:
+            return None
+        coset = self._coset_words(32 if internal else 1)
+        rc = sys.hm_coeff_to_extended_bn256_fr_dev(_vp(a.ptr), _vp(ext.ptr), batch, _u64p(fr_words(self.extended_omega)), self.k, self.extended_k,
+                                                   _u64p(coset), None)
+        return ext if rc == HM_OK else None
+
+    def extended_to_coeff(self, a: DevicePoly) -> bool:
+        if a.len == 0 or a.len % self.extended_len():
+            return False
+        c = np.concatenate([FR_ONE, fr_words(self.g_coset_inv), fr_words(self.g_coset)])
+        return sys.hm_extended_to_coeff_bn256_fr_dev(_vp(a.ptr), a.len // self.extended_len(), _u64p(fr_words(self.extended_omega_inv)), self.extended_k,
+                                                     _u64p(fr_words(self.extended_ifft_divisor)), _u64p(c), None) == HM_OK
+
+    def coset_shift(self, j: int) -> int:
+        return self.g_coset * pow(self.extended_omega, j, FR_MODULUS) % FR_MODULUS
+
+
+def commit_dev(handle: int, scalars: DevicePoly) -> Optional[np.ndarray]:
+    xyz = np.zeros(12, dtype=np.uint64)
+    if sys.hm_msm_bn256_g1_dev(ctypes.c_uint64(handle), 0, _vp(scalars.ptr), scalars.len, None, _u64p(xyz)) != HM_OK:
+        return None
+    return xyz
+
+
+def commit_batch_dev(handle: int, columns: Sequence[DevicePoly]) -> Optional[np.ndarray]:
+    if not columns:
+        return np.zeros((0, 12), dtype=np.uint64)
+    n = columns[0].len
+    if any(c.len != n for c in columns):
+        return None
+    ptrs = (_vp * len(columns))(*[c.ptr for c in columns])
+    out = np.zeros((len(columns), 12), dtype=np.uint64)
+    if sys.hm_msm_batch_bn256_g1_dev(ctypes.c_uint64(handle), 0, ptrs, n, len(columns), None, _u64p(out)) != HM_OK:
+        return None
+    return out
+
+
+def commit_pieces_dev(handle: int, polys: DevicePoly, n: int, first: int, count: int) -> Optional[np.ndarray]:
+    if count == 0:
+        return np.zeros((0, 12), dtype=np.uint64)
+    if n == 0 or (first + count) * n > polys.len:
+        return None
+    ptrs = (_vp * count)(*[polys.ptr + i * n * 32 for i in range(first, first + count)])
+    out = np.zeros((count, 12), dtype=np.uint64)
+    if sys.hm_msm_batch_bn256_g1_dev(ctypes.c_uint64(handle), 0, ptrs, n, count, None, _u64p(out)) != HM_OK:
+        return None
+    return out
+
+
+def eval_polynomial_dev(polys: DevicePoly, n: int, points) -> Optional[np.ndarray]:
+    points = _host(points)
+    if n == 0 or polys.len < n * points.shape[0]:
+        return None
+    out = np.empty((points.shape[0], 4), dtype=np.uint64)
+    if sys.hm_eval_polynomial_bn256_fr_dev(_vp(polys.ptr), n, None, _u64p(points), points.shape[0], _u64p(out), None) != HM_OK:
+        return None
+    return out
+
+
+class QuotientProgram:
+    """``QuotientProgram``: the undivided numerator of h(X) as a device program; built once per proving key."""
+
+    def __init__(self, handle: int, n_columns: int, n_dynamic: int):
+        self.handle, self.n_columns, self.n_dynamic = handle, n_columns, n_dynamic
+
+    @classmethod
+    def new(cls, calcs: np.ndarray, constants: np.ndarray, n_dynamic: int, rotations: np.ndarray, n_columns: int,
+            n_intermediates: int) -> Optional["QuotientProgram"]:
+        calcs = np.ascontiguousarray(calcs, dtype=np.uint32).reshape(-1, 5)
+        constants = _host(constants) if len(constants) else np.zeros((0, 4), dtype=np.uint64)
+        rotations = np.ascontiguousarray(rotations, dtype=np.int32)
+        h = ctypes.c_uint64(0)
+        rc = sys.hm_graph_create(calcs.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), calcs.shape[0], _u64p(constants), constants.shape[0], n_dynamic,
+                                 rotations.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), rotations.shape[0], n_columns, n_intermediates,
+                                 ctypes.byref(h))
+        return cls(h.value, n_columns, n_dynamic) if rc == HM_OK else None
+
+    def _run(self, domain: DeviceDomain, ptrs, dynamic, cosets) -> Optional[DevicePoly]:
+        dynamic = _host(dynamic)
+        n = domain.n()
+        shifts = np.stack([fr_words(domain.coset_shift(j)) for j in cosets])
+        h = DevicePoly.new(len(cosets) * n)
+        if h is None:
+            return None
+        rc = sys.hm_quotient_by_cosets_bn256_fr_dev(ctypes.c_uint64(self.handle), ptrs, None, self.n_columns, _u64p(dynamic), dynamic.shape[0], domain.k,
+                                                    _u64p(fr_words(domain.omega)), _u64p(shifts), len(cosets), len(cosets), _vp(h.ptr), None)
+        return h if rc == HM_OK else None
+
+    def quotient_by_cosets(self, domain: DeviceDomain, columns: Sequence[DevicePoly], dynamic, cosets: Sequence[int]) -> Optional[DevicePoly]:
+        n = domain.n()
+        if len(columns) != self.n_columns or len(_host(dynamic)) != self.n_dynamic or not cosets or any(c.len != n for c in columns):
+            return None
+        return self._run(domain, (_vp * len(columns))(*[c.ptr for c in columns]), dynamic, cosets)
+
+    def quotient_by_cosets_packed(self, domain: DeviceDomain, table: DevicePoly, dynamic, cosets: Sequence[int]) -> Optional[DevicePoly]:
+        n = domain.n()
+        if table.len != self.n_columns * n or len(_host(dynamic)) != self.n_dynamic or not cosets:
+            return None
+        return self._run(domain, (_vp * self.n_columns)(*[table.ptr + i * n * 32 for i in range(self.n_columns)]), dynamic, cosets)
+
+    def drop(self):
+        if self.handle:
+            sys.hm_graph_destroy(ctypes.c_uint64(self.handle))
+            self.handle = 0
+
+    def __del__(self):
+        try:
+            self.drop()
+        except Exception:  # noqa: BLE001
+            pass
+
+
+def _runs(indices: Sequence[int]):
+    """[(first, count), ...] of the maximal runs of consecutive integers in a sorted list."""
+    out, i = [], 0
+    idx = list(indices)
+    while i < len(idx):
+        j = i
+        while j + 1 < len(idx) and idx[j + 1] == idx[j] + 1:
+            j += 1
+        out.append((idx[i], j - i + 1))
+        i = j + 1
+    return out
+
+
+def run_proof(shape_name: str = "merkle_sum_tree_k18", device=None, reps: int = 3, check: bool = True) -> dict:
+    """The transforms and commitments of one ``create_proof`` of the named shape, driven ONLY through this module -- i.e. through the
+    calls a Rust prover makes once it holds its polynomials in ``DevicePoly``s (mi355x_dev.rs):
+
+        per proving key   the program (``QuotientProgram::new``), ONE packed table of n_columns x n (``DevicePoly::new``), the key's
+                          constant columns (fixed, sigmas, l_0 / l_last / l_active, X) uploaded as coefficients (``upload_at``)
+        per proof         every per-proof column uploaded as synthesis / the CPU-side arguments produce it, Lagrange form
+                          (``upload_at``: A advice + instance + per lookup (z, permuted input, permuted table) + the permutation z's);
+                          committed where it lies (``commit_pieces_dev`` on g_lagrange); to coefficients in place
+                          (``lagrange_to_coeff_range``); the quotient in one call from the packed table on the cosets that
+                          determine it (``quotient_by_cosets_packed``); its pieces committed where they lie (``commit_pieces_dev`` on
+                          g); the Horner evaluations (``eval_polynomial_dev``); and the coefficient forms the CPU-side SHPLONK needs
+                          brought back (``to_vec_range``: the per-proof columns and h)
+
+    Synthetic columns as in replay.py (two distinct sparse, two distinct dense arrays).  ``check``: commitments against [f(s)]G
+    (the replay's own identity), the coefficient forms and h against the torch-side routes (domain.py / evaluation.py) on the same
+    inputs.  Returns per-step milliseconds (the fastest of ``reps`` proofs, and the median), the calls made by name, and what was
+    verified.  Host arrays are pageable and go through the library's copy policy like a prover's Vecs."""
+    import torch
+
+    from . import circuits
+    from .arithmetic import G1_GENERATOR, FQ_ONE_MONT, eval_polynomial, g1_fixed_base_mul
+    from .domain import EvaluationDomain
+    from .kzg import ParamsKZG
+    from .replay import REPLAY_S, SHAPES, _rand_fr, _sparse_column
+
+    shape = SHAPES[shape_name]
+    device = device or torch.device("cuda", torch.cuda.current_device())
+    k, n = shape.k, 1 << shape.k
+    cs = circuits.CONSTRAINT_SYSTEMS[shape_name]()
+    dom = EvaluationDomain(cs.degree(), k)
+    ddom = DeviceDomain(dom)
+    g, lay = circuits.evaluate_h_program(cs, k, dom.extended_k, pow(7, 1 << 28, FR_MODULUS), per_coset=True, divide=False)
+    n_cols = lay.num_fixed_entries + cs.num_advice + cs.num_instance
+    compiled = g.compile(lay.num_fixed_entries, cs.num_advice, cs.num_instance, num_challenges=0, rot_scale=1)
+    const_idx = sorted(set(range(cs.num_fixed)) | set(range(lay.sigma0, lay.sigma0 + len(cs.equality)))
+                       | {lay.l0, lay.l_last, lay.l_active, lay.x_coset, lay.t_inv})
+    proof_idx = [i for i in range(n_cols) if i not in set(const_idx)]
+    cosets = list(range(dom.min_cosets()))
+    params = ParamsKZG.setup(k, REPLAY_S, device=device)
+    sys.reset()
+    out = {"circuit": shape.name, "shape_key": shape_name, "k": k, "columns": n_cols, "per_proof_columns": len(proof_idx),
+           "constant_columns": len(const_idx), "cosets": len(cosets)}
+    try:
+        # ---- per proving key ----
+        t0 = time.perf_counter()
+        consts = np.stack([fr_words(c) for c in compiled.constants]) if compiled.constants else np.zeros((0, 4), dtype=np.uint64)
+        prog = QuotientProgram.new(compiled.calcs, consts, compiled.n_dynamic, np.array(compiled.rotations, dtype=np.int32), compiled.n_columns,
+                                   compiled.n_intermediates)
+        table = DevicePoly.new(n_cols * n)
+        if prog is None or table is None:
+            raise RuntimeError("rust_glue.run_proof: " + _last_error())
+        key_cols = {i: _rand_fr(n, 9000 + i, device).cpu().numpy().view(np.uint64).copy() for i in const_idx[:2]}     # two distinct arrays stand for the key's columns
+        for j, i in enumerate(const_idx):
+            if not table.upload_at(i * n, key_cols[const_idx[j % 2]]):
+                raise RuntimeError("rust_glue.run_proof: " + _last_error())
+        sys.hm_device_synchronize()
+        out["per_key_ms"] = (time.perf_counter() - t0) * 1e3
+        # ---- the per-proof columns on the host, as a prover holds them ----
+        sparse = [_sparse_column(n, shape.used_rows, 200 + i, device).cpu().numpy().view(np.uint64).copy() for i in range(2)]
+        dense = [_rand_fr(n, 100 + i, device).cpu().numpy().view(np.uint64).copy() for i in range(2)]
+        adv0 = lay.num_fixed_entries
+        is_sparse = {i: (adv0 <= i < adv0 + cs.num_advice) for i in proof_idx}                 # advice columns are the sparse ones
+        host_col = {i: (sparse if is_sparse[i] else dense)[j & 1] for j, i in enumerate(proof_idx)}
+        dyn = np.stack([fr_words(v) for v in (3, 4, 5, 6)])                                    # beta, gamma, theta, y
+        # the Horner evaluations create_proof makes (advice at ~2 rotations, the products at 3, ...): one point per polynomial here, on
+        # the table's last n_queries entries (the advice and instance columns and what precedes them)
+        n_queries = min(n_cols, 2 * cs.num_advice + 8)
+        eval_first = n_cols - n_queries
+        points = np.stack([fr_words(pow(REPLAY_S, 3 + q, FR_MODULUS)) for q in range(n_queries)])
+        runs = _runs(proof_idx)
+
+        def proof():
+            t = {}
+            t0 = time.perf_counter()
+            for i in proof_idx:
+                if not table.upload_at(i * n, host_col[i]):
+                    raise RuntimeError("upload_at: " + _last_error())
+            t["upload"] = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            commits = {}
+            for first, count in runs:                                                            # Lagrange-basis commitments, where the columns lie
+                r = commit_pieces_dev(params.g_lagrange_handle.handle, table, n, first, count)
+                if r is None:
+                    raise RuntimeError("commit_pieces_dev: " + _last_error())
+                for j in range(count):
+                    commits[first + j] = r[j]
+            t["commit"] = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            for first, count in runs:
+                if not ddom.lagrange_to_coeff_range(table, first, count):
+                    raise RuntimeError("lagrange_to_coeff_range: " + _last_error())
+            sys.hm_device_synchronize()
+            t["lagrange_to_coeff"] = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            h = prog.quotient_by_cosets_packed(ddom, table, dyn, cosets)
+            if h is None:
+                raise RuntimeError("quotient_by_cosets_packed: " + _last_error())
+            sys.hm_device_synchronize()
+            t["quotient"] = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            h_commits = commit_pieces_dev(params.g_handle.handle, h, n, 0, len(cosets))
+            if h_commits is None:
+                raise RuntimeError("commit_pieces_dev(h): " + _last_error())
+            t["commit_h"] = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            view = DevicePoly(table.ptr + eval_first * n * 32, n_queries * n)                      # a borrowed view of the table: never dropped
+            try:
+                evals = eval_polynomial_dev(view, n, points)
+            finally:
+                view.ptr = 0
+            if evals is None:
+                raise RuntimeError("eval_polynomial_dev: " + _last_error())
+            t["eval_polynomial"] = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            back = {}
+            for first, count in runs:                                                            # coefficient forms for the CPU-side multiopen
+                v = table.to_vec_range(first * n, count * n)
+                if v is None:
+                    raise RuntimeError("to_vec_range: " + _last_error())
+                back[first] = v
+            h_host = h.to_vec()
+            t["download"] = time.perf_counter() - t0
+            h.drop()
+            return t, commits, h_commits, evals, back, h_host
+
+        proof()                                                                                    # warm-up: tables, workspaces, lanes
+        before = dict(sys.calls)
+        runs_t = []
+        for _ in range(reps):
+            res = proof()
+            runs_t.append(res[0])
+        per_proof_calls = {name: (cnt - before.get(name, 0)) // reps for name, cnt in sys.calls.items() if cnt - before.get(name, 0)}
+        steps = list(runs_t[0])
+        totals = [sum(r.values()) for r in runs_t]
+        best = runs_t[int(np.argmin(totals))]
+        out["ms"] = {s: best[s] * 1e3 for s in steps}
+        out["total_ms"] = min(totals) * 1e3
+        out["total_ms_median"] = float(np.median(totals)) * 1e3
+        out["resident_ms"] = (min(totals) - best["upload"] - best["download"]) * 1e3
+        out["calls_per_proof"] = per_proof_calls
+        out["bytes"] = {"uploaded_per_proof": len(proof_idx) * n * 32, "downloaded_per_proof": (len(proof_idx) + len(cosets)) * n * 32,
+                        "table_in_hbm": n_cols * n * 32}
+        if check:
+            _, commits, h_commits, evals, back, h_host = res
+            # (1) commitments: [f(s)]G with f(s) by device Horner on the torch side (replay.py's identity)
+            gen = G1_GENERATOR
+
+            def expected(col_host, lagrange):
+                col = torch.from_numpy(col_host.view(np.int64)).to(device)
+                coeffs = dom.lagrange_to_coeff(col.clone()) if lagrange else col
+                fs = eval_polynomial(coeffs.reshape(1, n, 4), fr_words(REPLAY_S).reshape(1, 4))
+                pt = g1_fixed_base_mul(torch.from_numpy(fs.view(np.int64)).to(device), gen).cpu().numpy().view(np.uint64)[0]
+                e = np.zeros(12, dtype=np.uint64)
+                if pt.any():
+                    e[:8] = pt
+                    e[8:] = FQ_ONE_MONT
+                return e
+
+            exp = {id(a): expected(a, True) for a in sparse + dense}
+            ok_commit = all(np.array_equal(commits[i], exp[id(host_col[i])]) for i in proof_idx)
+            # (2) coefficient forms and h against the torch-side routes on the same inputs
+            coeff = {id(a): dom.lagrange_to_coeff(torch.from_numpy(a.view(np.int64)).to(device).clone()).cpu().numpy().view(np.uint64) for a in sparse + dense}
+            ok_coeff = all(np.array_equal(back[first][j * n:(j + 1) * n], coeff[id(host_col[first + j])]) for first, count in runs for j in range(count))
+            cols_t = [None] * n_cols
+            for j, i in enumerate(const_idx):
+                cols_t[i] = torch.from_numpy(key_cols[const_idx[j % 2]].view(np.int64)).to(device)
+            for i in proof_idx:
+                cols_t[i] = torch.from_numpy(coeff[id(host_col[i])].view(np.int64)).to(device)
+            want_h = compiled.quotient_by_cosets(dom, cols_t, cosets=cosets, beta=3, gamma=4, theta=5, y=6).cpu().numpy().view(np.uint64)
+            ok_h = bool(np.array_equal(h_host, want_h))
+            ok_hc = all(np.array_equal(h_commits[t_], expected(h_host[t_ * n:(t_ + 1) * n], False)) for t_ in range(len(cosets)))
+            want_ev = eval_polynomial(torch.stack([cols_t[i] for i in range(eval_first, n_cols)]), points)
+            ok_ev = bool(np.array_equal(evals, want_ev))
+            out["verified"] = {"commitments_equal_f_of_s_times_G": bool(ok_commit), "commitments_checked": len(proof_idx) + len(cosets),
+                               "coefficient_forms_equal_the_torch_route": bool(ok_coeff), "h_equals_the_torch_route": ok_h,
+                               "h_commitments_equal_f_of_s_times_G": bool(ok_hc), "evaluations_equal_the_torch_route": ok_ev}
+            ok_commit = ok_commit and ok_ev
+            if not (ok_commit and ok_coeff and ok_h and ok_hc):
+                raise RuntimeError(f"rust_glue.run_proof: verification failed: {out['verified']}")
+        out["note"] = ("the proof's transforms and commitments through the entry points rust/halo2_proofs-patch/src/mi355x_dev.rs calls, in its "
+                       "call order, host arrays pageable (the library's copy policy); upload = every per-proof column over PCIe once, "
+                       "download = the coefficient forms + h for the CPU-side multiopen; resident_ms = everything between")
+    finally:
+        try:
+            prog.drop()
+            table.drop()
+        except Exception:  # noqa: BLE001
+            pass
+        compiled.destroy()
+        params.release()
+    return out

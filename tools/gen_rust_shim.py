@@ -634,6 +634,28 @@ impl DevicePoly {
         unsafe { v.set_len(self.len) }; // every element was written by the copy
         Some(v)
     }
+    /// Upload `a` to elements [first, first + a.len()) of this array: how a prover fills ONE packed array (the column table of a
+    /// `QuotientProgram`, polynomial i at [i n, (i + 1) n)) column by column as synthesis produces them.
+    pub fn upload_at(&mut self, first: usize, a: &[Fr]) -> bool {
+        if first.checked_add(a.len()).map_or(true, |end| end > self.len) {
+            return false;
+        }
+        let dst = unsafe { (self.ptr as *mut u8).add(first * 32) } as *mut c_void;
+        unsafe { sys::hm_copy_to_device(dst, a.as_ptr() as *const c_void, a.len() * 32) == sys::HM_OK }
+    }
+    /// Download elements [first, first + len) after waiting for the device.
+    pub fn to_vec_range(&self, first: usize, len: usize) -> Option<Vec<Fr>> {
+        if first.checked_add(len).map_or(true, |end| end > self.len) || unsafe { sys::hm_device_synchronize() } != sys::HM_OK {
+            return None;
+        }
+        let src = unsafe { (self.ptr as *const u8).add(first * 32) } as *const c_void;
+        let mut v: Vec<Fr> = Vec::with_capacity(len);
+        if unsafe { sys::hm_copy_to_host(v.as_mut_ptr() as *mut c_void, src, len * 32) } != sys::HM_OK {
+            return None;
+        }
+        unsafe { v.set_len(len) }; // every element was written by the copy
+        Some(v)
+    }
     pub fn len(&self) -> usize {
         self.len
     }
@@ -693,6 +715,15 @@ impl DeviceDomain {
         }
         let (w, d) = (words(&self.omega_inv), words(&self.ifft_divisor));
         unsafe { sys::hm_ntt_batch_bn256_fr_dev(a.as_mut_ptr(), a.len() / self.n(), w.as_ptr(), self.k, d.as_ptr(), ptr::null(), ptr::null_mut()) == sys::HM_OK }
+    }
+    /// The same on polynomials [first, first + count) of a packed array (polynomial i at [i n, (i + 1) n)).
+    pub fn lagrange_to_coeff_range(&self, a: &mut DevicePoly, first: usize, count: usize) -> bool {
+        if count == 0 || first.checked_add(count).map_or(true, |end| end * self.n() > a.len()) {
+            return false;
+        }
+        let (w, d) = (words(&self.omega_inv), words(&self.ifft_divisor));
+        let p = unsafe { (a.as_mut_ptr() as *mut u8).add(first * self.n() * 32) } as *mut c_void;
+        unsafe { sys::hm_ntt_batch_bn256_fr_dev(p, count, w.as_ptr(), self.k, d.as_ptr(), ptr::null(), ptr::null_mut()) == sys::HM_OK }
     }
     /// EvaluationDomain::coeff_to_extended on `a.len() / n` polynomials -> a new array of 2^extended_k evaluations each (the zero
     /// padding is never materialised).  `internal`: the evaluations come out multiplied by 32, the form `QuotientProgram` and
@@ -768,6 +799,33 @@ pub fn commit_batch_dev(handle: u64, columns: &[&DevicePoly]) -> Option<Vec<G1>>
     )
 }
 
+/// The same for polynomials [first, first + count) of `n` scalars each lying back to back in `polys` (a packed column table, the
+/// pieces of h as `QuotientProgram::quotient_by_cosets` returns them): one call, nothing copied.
+pub fn commit_pieces_dev(handle: u64, polys: &DevicePoly, n: usize, first: usize, count: usize) -> Option<Vec<G1>> {
+    if count == 0 {
+        return Some(Vec::new());
+    }
+    if n == 0 || first.checked_add(count).map_or(true, |end| end.checked_mul(n).map_or(true, |e| e > polys.len())) {
+        return None;
+    }
+    let base = polys.as_ptr() as *const u8;
+    let ptrs: Vec<*const c_void> = (first..first + count).map(|i| unsafe { base.add(i * n * 32) } as *const c_void).collect();
+    let mut out = vec![0u64; 12 * count];
+    let rc = unsafe { sys::hm_msm_batch_bn256_g1_dev(handle, 0, ptrs.as_ptr(), n, count, ptr::null_mut(), out.as_mut_ptr()) };
+    if rc != sys::HM_OK {
+        return None;
+    }
+    Some(
+        out.chunks_exact(12)
+            .map(|w| {
+                let mut xyz = [0u64; 12];
+                xyz.copy_from_slice(w);
+                g1_from_words(xyz)
+            })
+            .collect(),
+    )
+}
+
 /// halo2_proofs::arithmetic::eval_polynomial for `points.len()` polynomials of `n` coefficients lying back to back in `polys`
 /// (polynomial q at point q): the Horner evaluations create_proof makes of every committed polynomial.
 pub fn eval_polynomial_dev(polys: &DevicePoly, n: usize, points: &[Fr]) -> Option<Vec<Fr>> {
@@ -820,6 +878,27 @@ impl QuotientProgram {
             return None;
         }
         let ptrs: Vec<*const c_void> = columns.iter().map(|c| c.as_ptr()).collect();
+        let mut shifts: Vec<u64> = Vec::with_capacity(4 * cosets.len());
+        for &j in cosets {
+            shifts.extend_from_slice(&words(&domain.coset_shift(j)));
+        }
+        let mut h = DevicePoly::new(cosets.len() * n)?;
+        let w = words(&domain.omega);
+        let rc = unsafe {
+            sys::hm_quotient_by_cosets_bn256_fr_dev(self.handle, ptrs.as_ptr(), ptr::null(), ptrs.len(), dynamic.as_ptr() as *const u64, dynamic.len(), domain.k,
+                                                    w.as_ptr(), shifts.as_ptr(), cosets.len(), cosets.len(), h.as_mut_ptr(), ptr::null_mut())
+        };
+        if rc == sys::HM_OK { Some(h) } else { None }
+    }
+    /// The same with the whole column table in ONE packed array (entry i at [i n, (i + 1) n)): what a prover that fills the table
+    /// with `DevicePoly::upload_at` and transforms it with `lagrange_to_coeff_range` holds.
+    pub fn quotient_by_cosets_packed(&self, domain: &DeviceDomain, table: &DevicePoly, dynamic: &[Fr], cosets: &[usize]) -> Option<DevicePoly> {
+        let n = domain.n();
+        if table.len() != self.n_columns * n || dynamic.len() != self.n_dynamic || cosets.is_empty() {
+            return None;
+        }
+        let base = table.as_ptr() as *const u8;
+        let ptrs: Vec<*const c_void> = (0..self.n_columns).map(|i| unsafe { base.add(i * n * 32) } as *const c_void).collect();
         let mut shifts: Vec<u64> = Vec::with_capacity(4 * cosets.len());
         for &j in cosets {
             shifts.extend_from_slice(&words(&domain.coset_shift(j)));

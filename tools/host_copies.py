@@ -79,7 +79,8 @@ def main():
     if "--child" in sys.argv:
         return child()
     res = {}
-    for tag, env in (("pinned lanes", {"HALO2_MI355X_HOST_COPIES": "lanes"}), ("runtime pageable path", {"HALO2_MI355X_HOST_COPIES": "direct"}), ("auto (default)", {})):
+    modes = [("pinned lanes", {"HALO2_MI355X_HOST_COPIES": "lanes"}), ("runtime pageable path", {"HALO2_MI355X_HOST_COPIES": "direct"}), ("auto (default)", {})]
+    for tag, env in modes:
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child"], env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
         line = [l for l in r.stdout.splitlines() if l.startswith("{")]
         if r.returncode != 0 or not line:
