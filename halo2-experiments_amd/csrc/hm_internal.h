@@ -131,14 +131,17 @@ struct DevBuf {
 // pages: see the file's head).  One transfer at a time per device (mu); lanes are created on first use and kept.
 constexpr int HM_XFER_LANES = 8;
 struct XferLane {
-  void* pin[2] = {nullptr, nullptr};      // 2 MiB each, hipHostMalloc
+  void* pin[2] = {nullptr, nullptr};      // 2 MiB each, carved from HostXfer::block
   hipEvent_t ev[2] = {nullptr, nullptr};
   hipStream_t stream = nullptr;
+  double t_wait_us = 0, t_copy_us = 0, t_issue_us = 0, t_start_us = 0;    // of the lane's last share: waiting for DMAs / host memcpy (HALO2_MI355X_XFER_TRACE)
 };
 struct HostXfer {
   std::mutex mu;
   XferLane lanes[HM_XFER_LANES];
   int ready = 0;
+  void* block = nullptr;                  // ONE pinned allocation for every lane's slots (16 separate ones took 49 ms to make)
+  void* d_warm = nullptr;                 // 4 KiB of device memory: a new lane's stream is used once in both directions when it is made
   std::atomic<uint64_t> direct{0}, staged{0};   // copies handed to hipMemcpy on the caller's pointers / moved through the lanes (policy: xfer.hip)
 };
 

@@ -1,9 +1,9 @@
 // xfer.hip -- the host <-> device copies of the host-pointer entry points (hm_msm_bn256_g1*, hm_ntt_bn256_fr, hm_coeff_to_extended /
 // hm_extended_to_coeff, the batch call's scalar uploads, hm_copy_to_device / hm_copy_to_host).
 //
-// Two paths.  DIRECT: hipMemcpy on the caller's pointers.  LANES: the library's own pinned staging, up to 8 lanes, each a host thread
-// with its own stream and two 2 MiB pinned slots moving one contiguous share of the transfer (memcpy into a slot / DMA from the other,
-// and the reverse).
+// Two paths.  DIRECT: hipMemcpy on the caller's pointers.  LANES: the library's own pinned staging, four lanes (up to 8 by
+// HALO2_MI355X_XFER_LANES), each a host thread with its own stream and two 2 MiB pinned slots moving one contiguous share of the
+// transfer (memcpy into a slot / DMA from the other, and the reverse): 64 MiB in 1.4 ms either way (46 GB/s) against 1.2-1.3 ms direct.
 //
 // FINDING (rounds 5-6; tools/ubench/hostcopy_probe.hip, profiles/r06_hostcopy_probe.txt, profiles/r05_host_copies.txt).  For pageable
 // memory of these sizes hipMemcpy PINS the caller's pages on the fly -- a userptr registration with the kernel driver, cached by the
@@ -17,7 +17,7 @@
 //     first copy.  That, not a transient, is what round 5's timing detector kept tripping on; whether a session saw it depended on the
 //     box it landed on (3 of ~20 sessions in round 5, the first session of round 6).
 // The lanes never hand the caller's memory to the driver: nothing is pinned, nothing the caller maps or unmaps can invalidate anything
-// the GPU queues depend on, and the cost is the same on every box: +0.7 ms per 72 MiB against the direct path on a fast-pinning box.
+// the GPU queues depend on, and the cost is the same on every box: +0.2 ms per 64 MiB against the direct path on a fast-pinning box.
 //
 // POLICY -- a rule on the RANGE, never on the clock (HALO2_MI355X_HOST_COPIES = auto | lanes | direct, hm_set_host_copies; default auto):
 //   auto    a host range goes DIRECT only if the caller has declared it long-lived with hm_host_register (pinned once, by the caller's
@@ -31,6 +31,7 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -44,6 +45,7 @@ namespace hm {
 
 constexpr size_t kXferSlot = (size_t)2 << 20;
 constexpr size_t kXferDirectBelow = (size_t)256 << 10;
+constexpr int kXferDefaultLanes = 4;
 
 enum { XFER_AUTO = 0, XFER_LANES = 1, XFER_DIRECT = 2 };
 static std::atomic<int>& xfer_policy_cell() {
@@ -60,6 +62,10 @@ int xfer_set_policy(int mode) {
   if (mode < XFER_AUTO || mode > XFER_DIRECT) return -1;
   xfer_policy_cell().store(mode, std::memory_order_relaxed);
   return 0;
+}
+
+static double xfer_now_us() {
+  return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
 // ---- ranges the caller has registered (hm_host_register): process-wide, a handful of entries --------------------------------------------
@@ -147,7 +153,6 @@ void xfer_release(DeviceCtx& ctx) {       // ctx.mu held (hm_shutdown)
   std::lock_guard<std::mutex> lk(ctx.xfer.mu);
   for (auto& l : ctx.xfer.lanes) {
     for (int s = 0; s < 2; ++s) {
-      if (l.pin[s]) (void)hipHostFree(l.pin[s]);
       if (l.ev[s]) (void)hipEventDestroy(l.ev[s]);
       l.pin[s] = nullptr;
       l.ev[s] = nullptr;
@@ -155,21 +160,42 @@ void xfer_release(DeviceCtx& ctx) {       // ctx.mu held (hm_shutdown)
     if (l.stream) (void)hipStreamDestroy(l.stream);
     l.stream = nullptr;
   }
+  if (ctx.xfer.block) (void)hipHostFree(ctx.xfer.block);
+  if (ctx.xfer.d_warm) (void)hipFree(ctx.xfer.d_warm);
+  ctx.xfer.block = nullptr;
+  ctx.xfer.d_warm = nullptr;
   ctx.xfer.ready = 0;
 }
 
-// lanes [0, want) exist afterwards, or fewer when pinned memory / streams cannot be had (at least one, else 0)
+// lanes [0, want) exist afterwards, or fewer when pinned memory / streams cannot be had (at least one, else 0).
+// New lanes are WARMED before they are handed out: one slot-sized device-to-host copy on every lane at once, twice.  Without it the
+// first device-to-host copy of every lane beyond the second blocked its issuing hipMemcpyAsync for ~7 ms -- found in round 6 as 8.3 ms
+// instead of 1.8 for the download of a 64 MiB array in six of a process's first seven calls with eight lanes, and mistaken for a
+// copy "stall" by round 5's timing detector (tools/ntt_ext_probe.py, profiles/r06_lane_warmup.txt: the time is inside the issue
+// call, not in the DMA nor in the host memcpy; the count is lanes - 2 whatever the order).  A warm-up of the streams one by one does
+// not remove it; all lanes copying at once does, for four lanes.
 static int xfer_prepare(HostXfer& x, int want) {
+  if (x.ready >= want) return want;
+  if (!x.block && hipHostMalloc(&x.block, (size_t)HM_XFER_LANES * 2 * kXferSlot, hipHostMallocDefault) != hipSuccess) {
+    (void)hipGetLastError();
+    x.block = nullptr;
+    return x.ready;
+  }
+  if (!x.d_warm && hipMalloc(&x.d_warm, kXferSlot) != hipSuccess) {
+    (void)hipGetLastError();
+    x.d_warm = nullptr;                   // lanes work without the warm-up
+  }
+  bool made = false;
   for (int i = x.ready; i < want; ++i) {
     XferLane& l = x.lanes[i];
     bool ok = hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking) == hipSuccess;
-    for (int s = 0; s < 2 && ok; ++s)
-      ok = hipHostMalloc(&l.pin[s], kXferSlot, hipHostMallocDefault) == hipSuccess &&
-           hipEventCreateWithFlags(&l.ev[s], hipEventDisableTiming) == hipSuccess;
+    for (int s = 0; s < 2 && ok; ++s) {
+      l.pin[s] = (char*)x.block + ((size_t)i * 2 + s) * kXferSlot;
+      ok = hipEventCreateWithFlags(&l.ev[s], hipEventDisableTiming) == hipSuccess;
+    }
     if (!ok) {
       (void)hipGetLastError();
       for (int s = 0; s < 2; ++s) {
-        if (l.pin[s]) (void)hipHostFree(l.pin[s]);
         if (l.ev[s]) (void)hipEventDestroy(l.ev[s]);
         l.pin[s] = nullptr;
         l.ev[s] = nullptr;
@@ -179,6 +205,20 @@ static int xfer_prepare(HostXfer& x, int want) {
       break;
     }
     x.ready = i + 1;
+    made = true;
+  }
+  if (made && x.d_warm) {
+    // all lanes at once, both directions, twice: whatever the runtime sets up the first time that many streams copy concurrently
+    // is set up here (errors are the first real transfer's to report)
+    for (int round = 0; round < 2; ++round) {
+      for (int i = 0; i < x.ready; ++i) {
+        XferLane& l = x.lanes[i];
+        (void)hipMemcpyAsync(l.pin[0], x.d_warm, kXferSlot, hipMemcpyDeviceToHost, l.stream);
+        (void)hipEventRecord(l.ev[0], l.stream);
+      }
+      for (int i = 0; i < x.ready; ++i) (void)hipEventSynchronize(x.lanes[i].ev[0]);
+    }
+    (void)hipGetLastError();
   }
   return x.ready < want ? x.ready : want;
 }
@@ -193,17 +233,24 @@ static hipError_t lane_h2d(XferLane& l, int device, char* d_dst, const char* src
   hipError_t e = hipSetDevice(device);
   bool used[2] = {false, false};
   int slot = 0;
+  l.t_wait_us = l.t_copy_us = l.t_issue_us = 0;
   for (size_t off = 0; off < bytes && e == hipSuccess; slot ^= 1) {
     const size_t len = xfer_next_chunk(off, bytes - off);
+    const double t0 = xfer_now_us();
     if (used[slot]) e = hipEventSynchronize(l.ev[slot]);          // the DMA that last read this slot
     if (e != hipSuccess) break;
+    const double t1 = xfer_now_us();
     std::memcpy(l.pin[slot], src + off, len);
+    l.t_wait_us += t1 - t0;
+    l.t_copy_us += xfer_now_us() - t1;
     e = hipMemcpyAsync(d_dst + off, l.pin[slot], len, hipMemcpyHostToDevice, l.stream);
     if (e == hipSuccess) e = hipEventRecord(l.ev[slot], l.stream);
     used[slot] = true;
     off += len;
   }
+  const double t2 = xfer_now_us();
   const hipError_t s = hipStreamSynchronize(l.stream);
+  l.t_wait_us += xfer_now_us() - t2;
   return e != hipSuccess ? e : s;
 }
 
@@ -212,20 +259,27 @@ static hipError_t lane_d2h(XferLane& l, int device, char* dst, const char* d_src
   if (e != hipSuccess || bytes == 0) return e;
   size_t issued = 0, copied = 0, len[2] = {0, 0};
   auto issue = [&](int slot) {
+    const double ti = xfer_now_us();
     len[slot] = xfer_next_chunk(issued, bytes - issued);
     hipError_t r = hipMemcpyAsync(l.pin[slot], d_src + issued, len[slot], hipMemcpyDeviceToHost, l.stream);
     if (r == hipSuccess) r = hipEventRecord(l.ev[slot], l.stream);
     issued += len[slot];
+    l.t_issue_us += xfer_now_us() - ti;
     return r;
   };
   int slot = 0;
+  l.t_wait_us = l.t_copy_us = l.t_issue_us = 0;
   e = issue(0);
   while (copied < bytes && e == hipSuccess) {
     if (issued < bytes) e = issue(slot ^ 1);                      // the next DMA runs while this slot is copied out
+    const double t0 = xfer_now_us();
     const hipError_t w = hipEventSynchronize(l.ev[slot]);
     if (e == hipSuccess) e = w;
     if (e != hipSuccess) break;
+    const double t1 = xfer_now_us();
     std::memcpy(dst + copied, l.pin[slot], len[slot]);
+    l.t_wait_us += t1 - t0;
+    l.t_copy_us += xfer_now_us() - t1;
     copied += len[slot];
     slot ^= 1;
   }
@@ -252,11 +306,19 @@ static int xfer_run(DeviceCtx& ctx, bool up, void* dev, void* host, size_t bytes
     if (trace) std::fprintf(stderr, "[halo2_mi355x] copy: %s %zu bytes direct (%s)\n", up ? "H2D" : "D2H", bytes, who);
     return HM_OK;
   }
+  const double t_start = xfer_now_us();
   ctx.xfer.staged.fetch_add(1, std::memory_order_relaxed);
   if (trace) std::fprintf(stderr, "[halo2_mi355x] copy: %s %zu bytes through the lanes (%s)\n", up ? "H2D" : "D2H", bytes, who);
   std::lock_guard<std::mutex> lk(ctx.xfer.mu);                    // the lanes' slots belong to one transfer at a time
   int want = (int)((bytes + ((size_t)1 << 20) - 1) >> 20);        // a lane per MiB, eight at most
+  // FOUR lanes by default (HALO2_MI355X_XFER_LANES = 1 .. 8 for experiments).  Round 5 ran eight; measured in round 6 on one 64 MiB
+  // round trip (profiles/r06_lane_warmup.txt): 1 lane 2.2 + 3.8 ms up + down, 2 lanes 1.38 + 2.0, 4 lanes 1.38 + 1.38, 8 lanes 1.45 + 1.78
+  // -- four already fill the link, and every lane beyond the second cost its first device-to-host copy a ~7 ms stall inside
+  // hipMemcpyAsync (six of a process's first seven 64 MiB downloads took 8.3 ms instead of 1.8 with eight lanes; with four, after the
+  // concurrent warm-up of xfer_prepare, none after the first call).
   if (want > HM_XFER_LANES) want = HM_XFER_LANES;
+  static const int lanes_cap = [] { const char* v = std::getenv("HALO2_MI355X_XFER_LANES"); return v && *v ? std::atoi(v) : kXferDefaultLanes; }();
+  if (lanes_cap >= 1 && want > lanes_cap) want = lanes_cap;
   const int lanes = xfer_prepare(ctx.xfer, want);
   if (lanes == 0) {                                               // no pinned memory to be had: the runtime's path still works
     const hipError_t e = up ? hipMemcpy(dev, host, bytes, hipMemcpyHostToDevice) : hipMemcpy(host, dev, bytes, hipMemcpyDeviceToHost);
@@ -268,6 +330,7 @@ static int xfer_run(DeviceCtx& ctx, bool up, void* dev, void* host, size_t bytes
   for (auto& e : errs) e = hipSuccess;
   const int device = ctx.device;
   auto part = [&](int i) {
+    ctx.xfer.lanes[i].t_start_us = xfer_now_us();
     const size_t lo = (size_t)i * share;
     if (lo >= bytes) return;
     const size_t len = bytes - lo < share ? bytes - lo : share;
@@ -284,6 +347,17 @@ static int xfer_run(DeviceCtx& ctx, bool up, void* dev, void* host, size_t bytes
   }
   for (int i = 0; i < lanes; ++i)
     if (errs[i] != hipSuccess) return hm_fail(HM_ERR_HIP, std::string(who) + ": " + hipGetErrorString(errs[i]));
+  if (trace) {                                                    // the slowest lane's split: waiting for its DMAs / copying on the host
+    double wmax = 0, cmax = 0, imax = 0, smax = 0;
+    for (int i = 0; i < lanes; ++i) {
+      if (ctx.xfer.lanes[i].t_wait_us > wmax) wmax = ctx.xfer.lanes[i].t_wait_us;
+      if (ctx.xfer.lanes[i].t_copy_us > cmax) cmax = ctx.xfer.lanes[i].t_copy_us;
+      if (ctx.xfer.lanes[i].t_issue_us > imax) imax = ctx.xfer.lanes[i].t_issue_us;
+      if (ctx.xfer.lanes[i].t_start_us - t_start > smax) smax = ctx.xfer.lanes[i].t_start_us - t_start;
+    }
+    std::fprintf(stderr, "[halo2_mi355x]   %d lanes, %.2f ms in all: latest lane start +%.2f ms, longest DMA wait %.2f ms, issue %.2f ms, host memcpy %.2f ms\n",
+                 lanes, (xfer_now_us() - t_start) / 1e3, smax / 1e3, wmax / 1e3, imax / 1e3, cmax / 1e3);
+  }
   return HM_OK;
 }
 

@@ -187,7 +187,7 @@ int hm_device_synchronize(void);
  *     hm_host_register goes straight to hipMemcpy (a DMA from registered memory); every other range of 256 KiB or more goes through the
  *     library's own pinned staging lanes -- nothing of the caller's memory is handed to the driver, so the cost does not depend on what
  *     pinning a page costs on the box (0.1 us or 9 us: both exist in one pool) nor on what the caller maps and unmaps around the calls;
- * 1 = lanes always (registered ranges too); 2 = direct always (hipMemcpy pins the caller's pages on the fly: 0.7 ms per 72 MiB
+ * 1 = lanes always (registered ranges too); 2 = direct always (hipMemcpy pins the caller's pages on the fly: 0.2 ms per 64 MiB
  *     faster where pinning is cheap, 2.3 ms per MiB slower where it is not -- for boxes known to pin fast).  Process-wide. */
 int hm_set_host_copies(int mode);
 /* Declare [p, p + bytes) long-lived host memory (an SRS kept in memory, a staging buffer reused for every proof): pinned ONCE here
