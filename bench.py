@@ -52,6 +52,12 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
+
+def to_host(t):
+    """halo2_experiments_amd.arithmetic.to_host: device -> fresh numpy array through the library's lanes (never tensor.cpu() for big arrays)."""
+    from halo2_experiments_amd.arithmetic import to_host as _to_host
+    return _to_host(t)
+
 # The real ceiling of both hot kernels (DESIGN.md §4/§5): VALU issue.  256 CUs x 4 SIMD16 units, one
 # wave64 VALU instruction per 4 cycles, at the 2.4 GHz peak engine clock (the chip holds ~2.07-2.2 GHz
 # under these kernels).  Instructions per unit are a property of the build, measured with SQ_INSTS_VALU
@@ -294,8 +300,8 @@ def cpu_baseline(log_sample, device, full):
     cpu_ref.build()
     n = 1 << log_sample
     scalars_d, bases_d, _ = bench_inputs(n, 0, 4242, device)
-    bases = bases_d.cpu().numpy().view(np.uint64)
-    scalars = scalars_d.cpu().numpy().view(np.uint64)
+    bases = to_host(bases_d)
+    scalars = to_host(scalars_d)
     threads = cpu_ref.default_threads()            # scheduler affinity capped by the container's CPU quota (HALO2_CPU_THREADS overrides)
     t0 = time.perf_counter()
     ref = cpu_ref.best_multiexp(scalars, bases, threads)
@@ -394,14 +400,14 @@ def ntt_cpu_baseline(log_n, device):
     cpu_ref.build()
     omega = fr_words(pow(FR_ROOT_OF_UNITY, 1 << (28 - log_n), FR_MODULUS))
     a_d = rand_fr(1 << log_n, 99, device)
-    a = a_d.cpu().numpy().view(np.uint64)
+    a = to_host(a_d)
     info = cpu_info()
     t0 = time.perf_counter()
     ref = cpu_ref.best_fft(a, omega, log_n, info["cores"])
     dt = time.perf_counter() - t0
     h.best_fft(a_d, omega, log_n)
     torch.cuda.synchronize()
-    ok = bool(np.array_equal(ref, a_d.cpu().numpy().view(np.uint64)))
+    ok = bool(np.array_equal(ref, to_host(a_d)))
     info.update({"value": (1 << log_n) / dt, "unit": "elements/s", "ms": dt * 1e3,
                  "sample": f"one 2^{log_n}-element best_fft (the whole timed workload, same input), {dt:.2f} s wall incl. the copy of the "
                            "array; C restatement of halo2_proofs v2023_02_02 best_fft (not the Rust binary)",
@@ -424,9 +430,9 @@ def replay_cpu_baseline(rep, device):
     k, ek = rep["k"], rep["extended_k"]
     n = 1 << k
     used = SHAPES[rep["shape_key"]].used_rows
-    bases = h.g1_fixed_base_mul(_rand_fr(n, 77, device), G1_GENERATOR).cpu().numpy().view(np.uint64)
-    dense = _rand_fr(n, 78, device).cpu().numpy().view(np.uint64)
-    sparse = _sparse_column(n, used, 79, device).cpu().numpy().view(np.uint64)
+    bases = to_host(h.g1_fixed_base_mul(_rand_fr(n, 77, device), G1_GENERATOR))
+    dense = to_host(_rand_fr(n, 78, device))
+    sparse = to_host(_sparse_column(n, used, 79, device))
     info = cpu_info()
     T = info["cores"]
 
@@ -784,7 +790,7 @@ def one_process_measurements(devs, device, log_global, replay_name, reps=3):
                  "base_set": {"sliced": bool(info["sliced"]), "devices": info["devices"], "table_windows": info["table_windows"],
                               "device_bytes": info["device_bytes"]},
                  "scalars": f"one device array on device {devs[0]}: the other devices' slices cross xGMI inside the call"}
-        hs = s.cpu().numpy().view(np.uint64)
+        hs = to_host(s)
         del s
         t1 = time.perf_counter()
         res_h = h.best_multiexp(hs, hnd)
@@ -998,6 +1004,101 @@ def main():
     if not answer_ok:
         raise SystemExit("bench.py: the MSM result does not match the known answer [sum s_i (a + i b)]G")
 
+    # ---- the create_proof replays (configs[1..3] and the reference's own k = 9), FIRST among the side legs: with the headline's base
+    # set and scalars still resident (12.5 GiB of 288: nothing is freed here).  Why first: freeing GiBs of device memory -- what the
+    # legs below do between their measurements -- leaves the copy engines at two thirds of their speed for seconds afterwards (the
+    # driver's work on the freed memory; tools/ntt_ext_probe.py <..> 64, profiles/r06_after_free.txt), and round 5's and round 6's first
+    # drop-in totals (286 / 314-325 ms at k = 18) were taken in exactly that state.  A prover keeps its SRS registered and frees nothing
+    # of that size between its calls; measured in that state the same calls total ~235 ms.
+    replay = None
+    if args.replay != "none":
+        from halo2_experiments_amd.replay import run_replay
+        # every rank takes part.  N > 1 runs the extended-domain steps by cosets; BOTH coset routes are measured at every N so that a
+        # scaling record compares like with like: all E cosets = the same polynomial as N = 1's whole-array device_resident_s
+        # (upstream's own steps), and the j - 1 cosets that determine the quotient of a satisfied circuit (a different
+        # computation on the replay's synthetic columns: never the headline)
+        # the largest shape LAST in the list but FIRST in the budget: when time runs short the small shapes are what goes
+        names = args.replay.split(",")
+        replay_est = {"merkle_sum_tree_k18": 9.0, "merkle_v3_k17": 5.0}
+        by_name = {}
+        for name in sorted(names, key=lambda nm: -replay_est.get(nm, 3.0)):
+            est = replay_est.get(name, 3.0)
+            if world > 1:
+                if not legs.start(f"replay_{name}", est):
+                    continue
+                rep = run_replay(name, device=device, min_cosets=False)
+                legs.stop()
+                if legs.start(f"replay_{name}_min_cosets", est):
+                    fewer = run_replay(name, device=device, include_host_pointer_estimate=False, min_cosets=True)
+                    legs.stop()
+                    rep["extended_domain_routes_ms"] = {
+                        "by_all_cosets": {**{k2: v * 1e3 for k2, v in rep["device_resident_s"].items()}, "extended_domain": rep["extended_domain"]},
+                        "by_the_cosets_that_determine_h": {**{k2: v * 1e3 for k2, v in fewer["device_resident_s"].items()},
+                                                           "extended_domain": fewer["extended_domain"]},
+                        "note": "device_resident_s = by_all_cosets: the same h as the N = 1 whole-array route"}
+                by_name[name] = rep
+            elif legs.start(f"replay_{name}", est + (6.0 if name.endswith("k18") else 1.0)):     # + the host-pointer (drop-in) calls of the trace
+                by_name[name] = run_replay(name, device=device)
+                legs.stop()
+        replay = [by_name[nm] for nm in names if nm in by_name]
+        # N = 1: what ONE GPU can measure of the N-GPU replay -- the first and the last rank's share of the 2-, 4- and 8-rank deal of
+        # the largest shape, each alone, nothing exchanged.  DESIGN.md section 6 builds its
+        # predicted curve on these.
+        if world == 1 and not args.no_extras and not args.no_shares and legs.start("k18_rank_shares_and_coset_routes", 12.0):
+            big = [nm for nm in args.replay.split(",") if nm == "merkle_sum_tree_k18" and nm in by_name]
+            for nm in big:
+                shares = []
+                for w in (2, 4, 8):
+                    for rk in (0, w - 1):           # rank 0 also runs the rank-0-only steps; the last rank gets the first coset
+                        try:
+                            r = run_replay(nm, device=device, include_host_pointer_estimate=False, share_of=(rk, w))
+                            shares.append({"world": w, "rank": rk, "ms": {k2: v * 1e3 for k2, v in r["device_resident_s"].items()},
+                                           "extended_domain": r["extended_domain"]})
+                        except Exception as exc:  # noqa: BLE001 -- a side measurement never costs the line
+                            shares.append({"world": w, "rank": rk, "error": f"{type(exc).__name__}: {exc}"})
+                rep18 = next(rep for rep in replay if rep["k"] == 18)
+                # the same trace with the extended-domain steps taken coset by coset on this one GPU: all E cosets (the multi-GPU
+                # route's work, 5 % more than the whole array) and only the j - 1 cosets that determine the quotient
+                routes = {"whole_array": {k2: v * 1e3 for k2, v in rep18["device_resident_s"].items()}}
+                for label, kw in (("by_all_cosets", {"min_cosets": False}), ("by_the_cosets_that_determine_h", {"min_cosets": True})):
+                    try:
+                        r = run_replay(nm, device=device, include_host_pointer_estimate=False, by_cosets=True, **kw)
+                        routes[label] = {k2: v * 1e3 for k2, v in r["device_resident_s"].items()}
+                        routes[label]["extended_domain"] = r["extended_domain"]
+                    except Exception as exc:  # noqa: BLE001
+                        routes[label] = {"error": f"{type(exc).__name__}: {exc}"}
+                routes["note"] = ("the quotient of a satisfied circuit has fewer than n (j - 1) coefficients: j - 1 of the E cosets determine it "
+                                  "(same h word for word: tests/test_mini_prover_gpu.py); create_proof_replay.device_resident_s stays the "
+                                  "whole-array route, upstream's own steps")
+                rep18["extended_domain_routes_ms"] = routes
+                try:
+                    rep18["quotient_in_one_call_ms"] = quotient_one_call(device)
+                except Exception as exc:  # noqa: BLE001 -- a side measurement never costs the line
+                    rep18["quotient_in_one_call_ms"] = {"error": f"{type(exc).__name__}: {exc}"}
+                rep18["rank_shares_measured_alone"] = {
+                    "shares": shares, "note": "the first and the last rank's share of the N-rank replay, each run alone on this GPU (its "
+                                              "commitments of every phase, its cosets of the extended domain, for rank 0 the steps only rank 0 "
+                                              "runs); the step takes the longer of them plus the exchanges -- 96 B per commitment, n x 32 B "
+                                              "per coset -- which are not in these times"}
+            legs.stop()
+        # the same proof through exactly the calls of rust/halo2_proofs-patch/src/mi355x_dev.rs (halo2-experiments_amd/rust_glue.py):
+        # what a Rust prover that keeps its polynomials in DevicePolys gets -- upload once, resident steps, download -- next to the
+        # per-call drop-in total
+        if world == 1 and not args.no_extras and "merkle_sum_tree_k18" in by_name and legs.start("k18_rust_device_glue", 8.0):
+            try:
+                from halo2_experiments_amd.rust_glue import run_proof
+                by_name["merkle_sum_tree_k18"]["rust_device_glue"] = run_proof("merkle_sum_tree_k18", device=device, reps=3, check=True)
+            except Exception as exc:  # noqa: BLE001 -- a side measurement never costs the line
+                by_name["merkle_sum_tree_k18"]["rust_device_glue"] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+            legs.stop()
+        if rank == 0 and world == 1 and not args.no_cpu_baseline and legs.start("replay_cpu_baselines", 10.0):
+            for rep in replay:
+                rep["cpu_baseline"] = replay_cpu_baseline(rep, device)
+                acct = rust_threshold_account(rep)
+                if acct is not None:
+                    rep["rust_shim_routing"] = acct
+            legs.stop()
+
     # ---- NTT (single GPU by design: "replicas only") -------------------------------------------
     ntt = None
     if not args.no_ntt and rank == 0 and legs.start("ntt", 6.0, local=True):
@@ -1107,7 +1208,7 @@ def main():
         dt = (time.perf_counter() - t1) / reps
         extras["msm_pipelined_3_in_flight"] = {"points_per_s": n_local / dt, "ms_per_msm": dt * 1e3,
                                                "same_result": bool(np.array_equal(last, ref_out))}
-        hs = scalars.cpu().numpy().view(np.uint64)
+        hs = to_host(scalars)
         t1 = time.perf_counter()
         h.best_multiexp(hs, handle)
         extras["msm_host_pointer"] = {"ms": (time.perf_counter() - t1) * 1e3,
@@ -1141,100 +1242,6 @@ def main():
         for e in strong:
             if not e["known_answer_ok"]:
                 raise SystemExit(f"bench.py: the global 2^{e['global_log_points']} MSM does not match its known answer")
-
-    replay = None
-    if args.replay != "none":
-        from halo2_experiments_amd.replay import run_replay
-        if handle is not None:
-            h.release_bases(handle)
-            handle = None
-        scalars = None
-        torch.cuda.empty_cache()
-        # every rank takes part.  N > 1 runs the extended-domain steps by cosets; BOTH coset routes are measured at every N so that a
-        # scaling record compares like with like: all E cosets = the same polynomial as N = 1's whole-array device_resident_s
-        # (upstream's own steps), and the j - 1 cosets that determine the quotient of a satisfied circuit (a different
-        # computation on the replay's synthetic columns: never the headline)
-        # the largest shape LAST in the list but FIRST in the budget: when time runs short the small shapes are what goes
-        names = args.replay.split(",")
-        replay_est = {"merkle_sum_tree_k18": 9.0, "merkle_v3_k17": 5.0}
-        by_name = {}
-        for name in sorted(names, key=lambda nm: -replay_est.get(nm, 3.0)):
-            est = replay_est.get(name, 3.0)
-            if world > 1:
-                if not legs.start(f"replay_{name}", est):
-                    continue
-                rep = run_replay(name, device=device, min_cosets=False)
-                legs.stop()
-                if legs.start(f"replay_{name}_min_cosets", est):
-                    fewer = run_replay(name, device=device, include_host_pointer_estimate=False, min_cosets=True)
-                    legs.stop()
-                    rep["extended_domain_routes_ms"] = {
-                        "by_all_cosets": {**{k2: v * 1e3 for k2, v in rep["device_resident_s"].items()}, "extended_domain": rep["extended_domain"]},
-                        "by_the_cosets_that_determine_h": {**{k2: v * 1e3 for k2, v in fewer["device_resident_s"].items()},
-                                                           "extended_domain": fewer["extended_domain"]},
-                        "note": "device_resident_s = by_all_cosets: the same h as the N = 1 whole-array route"}
-                by_name[name] = rep
-            elif legs.start(f"replay_{name}", est + (6.0 if name.endswith("k18") else 1.0)):     # + the host-pointer (drop-in) calls of the trace
-                by_name[name] = run_replay(name, device=device)
-                legs.stop()
-        replay = [by_name[nm] for nm in names if nm in by_name]
-        # N = 1: what ONE GPU can measure of the N-GPU replay -- the first and the last rank's share of the 2-, 4- and 8-rank deal of
-        # the largest shape, each alone, nothing exchanged.  DESIGN.md section 6 builds its
-        # predicted curve on these.
-        if world == 1 and not args.no_extras and not args.no_shares and legs.start("k18_rank_shares_and_coset_routes", 12.0):
-            big = [nm for nm in args.replay.split(",") if nm == "merkle_sum_tree_k18" and nm in by_name]
-            for nm in big:
-                shares = []
-                for w in (2, 4, 8):
-                    for rk in (0, w - 1):           # rank 0 also runs the rank-0-only steps; the last rank gets the first coset
-                        try:
-                            r = run_replay(nm, device=device, include_host_pointer_estimate=False, share_of=(rk, w))
-                            shares.append({"world": w, "rank": rk, "ms": {k2: v * 1e3 for k2, v in r["device_resident_s"].items()},
-                                           "extended_domain": r["extended_domain"]})
-                        except Exception as exc:  # noqa: BLE001 -- a side measurement never costs the line
-                            shares.append({"world": w, "rank": rk, "error": f"{type(exc).__name__}: {exc}"})
-                rep18 = next(rep for rep in replay if rep["k"] == 18)
-                # the same trace with the extended-domain steps taken coset by coset on this one GPU: all E cosets (the multi-GPU
-                # route's work, 5 % more than the whole array) and only the j - 1 cosets that determine the quotient
-                routes = {"whole_array": {k2: v * 1e3 for k2, v in rep18["device_resident_s"].items()}}
-                for label, kw in (("by_all_cosets", {"min_cosets": False}), ("by_the_cosets_that_determine_h", {"min_cosets": True})):
-                    try:
-                        r = run_replay(nm, device=device, include_host_pointer_estimate=False, by_cosets=True, **kw)
-                        routes[label] = {k2: v * 1e3 for k2, v in r["device_resident_s"].items()}
-                        routes[label]["extended_domain"] = r["extended_domain"]
-                    except Exception as exc:  # noqa: BLE001
-                        routes[label] = {"error": f"{type(exc).__name__}: {exc}"}
-                routes["note"] = ("the quotient of a satisfied circuit has fewer than n (j - 1) coefficients: j - 1 of the E cosets determine it "
-                                  "(same h word for word: tests/test_mini_prover_gpu.py); create_proof_replay.device_resident_s stays the "
-                                  "whole-array route, upstream's own steps")
-                rep18["extended_domain_routes_ms"] = routes
-                try:
-                    rep18["quotient_in_one_call_ms"] = quotient_one_call(device)
-                except Exception as exc:  # noqa: BLE001 -- a side measurement never costs the line
-                    rep18["quotient_in_one_call_ms"] = {"error": f"{type(exc).__name__}: {exc}"}
-                rep18["rank_shares_measured_alone"] = {
-                    "shares": shares, "note": "the first and the last rank's share of the N-rank replay, each run alone on this GPU (its "
-                                              "commitments of every phase, its cosets of the extended domain, for rank 0 the steps only rank 0 "
-                                              "runs); the step takes the longer of them plus the exchanges -- 96 B per commitment, n x 32 B "
-                                              "per coset -- which are not in these times"}
-            legs.stop()
-        # the same proof through exactly the calls of rust/halo2_proofs-patch/src/mi355x_dev.rs (halo2-experiments_amd/rust_glue.py):
-        # what a Rust prover that keeps its polynomials in DevicePolys gets -- upload once, resident steps, download -- next to the
-        # per-call drop-in total
-        if world == 1 and not args.no_extras and "merkle_sum_tree_k18" in by_name and legs.start("k18_rust_device_glue", 8.0):
-            try:
-                from halo2_experiments_amd.rust_glue import run_proof
-                by_name["merkle_sum_tree_k18"]["rust_device_glue"] = run_proof("merkle_sum_tree_k18", device=device, reps=3, check=True)
-            except Exception as exc:  # noqa: BLE001 -- a side measurement never costs the line
-                by_name["merkle_sum_tree_k18"]["rust_device_glue"] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
-            legs.stop()
-        if rank == 0 and world == 1 and not args.no_cpu_baseline and legs.start("replay_cpu_baselines", 10.0):
-            for rep in replay:
-                rep["cpu_baseline"] = replay_cpu_baseline(rep, device)
-                acct = rust_threshold_account(rep)
-                if acct is not None:
-                    rep["rust_shim_routing"] = acct
-            legs.stop()
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

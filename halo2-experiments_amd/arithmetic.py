@@ -91,6 +91,20 @@ def register_bases(bases, precompute: bool = False, plain: bool = False) -> Base
     return BasesHandle(h.value, n)
 
 
+def to_host(t) -> np.ndarray:
+    """A GPU tensor of Fr / Fq words as a fresh (rows, words) uint64 numpy array, copied by the LIBRARY (``hm_copy_to_host``: its pinned
+    staging lanes).  ``tensor.cpu()`` hands the fresh destination to hipMemcpy, which pins it on the fly (csrc/xfer.hip's finding): a
+    harness that measures the library's host copies keeps that machinery out of its own process state."""
+    if not _is_tensor(t) or not t.is_cuda:
+        raise TypeError("to_host: a GPU tensor is expected")
+    import torch
+    t = t.contiguous()
+    out = np.empty(tuple(t.shape), dtype=np.uint64)
+    torch.cuda.current_stream(t.device).synchronize()
+    _lib.check(_lib.load().hm_copy_to_host(out.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(t.data_ptr()), out.nbytes))
+    return out
+
+
 def bases_info(handle: BasesHandle) -> dict:
     """``hm_get_bases_info``: which layout the registration ended up with (``table_windows`` == 0: plain), the HBM it
     holds, and how many default registrations of the process fell back to the plain layout for lack of memory."""

@@ -41,7 +41,7 @@ from typing import Optional
 
 import numpy as np
 
-from .arithmetic import (G1_GENERATOR, batch_invert, best_multiexp, best_multiexp_submit, best_multiexp_wait, eval_polynomial,
+from .arithmetic import (G1_GENERATOR, to_host, batch_invert, best_multiexp, best_multiexp_submit, best_multiexp_wait, eval_polynomial,
                          g1_fixed_base_mul, grand_product_batch, kate_division, kate_division_batch, linear_combination, permute_expression_pairs, register_bases,
                          release_bases)
 from .domain import EvaluationDomain, FR_MODULUS, fr_words
@@ -536,7 +536,7 @@ def run_replay(shape_name: str, device=None, group=None, include_host_pointer_es
     if include_host_pointer_estimate and world == 1:
         # the drop-in (host-pointer) cost of the same trace: one representative call of each kind
         import ctypes
-        h_s = dense[0].cpu().numpy().view(np.uint64)
+        h_s = to_host(dense[0])
 
         medians = {}
 
@@ -560,7 +560,16 @@ def run_replay(shape_name: str, device=None, group=None, include_host_pointer_es
         a_n = h_s.copy()
         t_ntt_n = best_of(lambda: best_fft(a_n, fr_words(dom.omega), k), name="ntt_n_each")
         a_e = np.zeros((dom.extended_len(), 4), dtype=np.uint64); a_e[:n] = h_s
+        from . import _lib as _l0
+
+        def _phases():
+            st_ = _l0.Stats()
+            _l0.check(_l0.load().hm_get_stats(ctypes.byref(st_)))
+            return np.array([st_.ntt_h2d_us, st_.ntt_device_us, st_.ntt_d2h_us])
+
+        ph0 = _phases()
         t_ntt_e = best_of(lambda: best_fft(a_e, fr_words(dom.extended_omega), dom.extended_k), name="ntt_ext_each")
+        ntt_ext_phases = (_phases() - ph0) / 6.0           # mean of the six calls (warm-up + five): upload / device / download microseconds
         # the two EvaluationDomain steps through their own host-pointer forms (the optional src/poly/domain.rs edits of rust/): the zero
         # padding never goes up, the truncated tail never comes down
         ext_h = dom.coeff_to_extended(h_s)
@@ -579,7 +588,7 @@ def run_replay(shape_name: str, device=None, group=None, include_host_pointer_es
         # ... and the commitments of the whole proof from HOST arrays through the batch call (uploads pipelined behind the
         # other commitments' kernels): what a prover that keeps its polynomials in host vectors gets per proof
         from .arithmetic import best_multiexp_batch
-        h_sparse, h_dense = sparse[0].cpu().numpy().view(np.uint64), h_s
+        h_sparse, h_dense = to_host(sparse[0]), h_s
         for _ in range(2):                   # warm-up: the per-lane staging buffers and slot workspaces reach their sizes here
             best_multiexp_batch([h_sparse] * counts["msm_sparse"], gl_h)
             best_multiexp_batch([h_dense] * counts["msm_dense"], gl_h)
@@ -627,6 +636,7 @@ def run_replay(shape_name: str, device=None, group=None, include_host_pointer_es
                                "first-touch faults (the kernel zeroes 2^extended_k x 32 B either way); upstream's resize-to-extended-length "
                                "(host_zero_padding_each, numpy here) takes the same faults before best_fft",
             "total": hp_total, "median_of_five_calls": dict(medians),
+            "ntt_ext_mean_phase_us": {"h2d": float(ntt_ext_phases[0]), "device": float(ntt_ext_phases[1]), "d2h": float(ntt_ext_phases[2])},
             "note": "PCIe-inclusive: every call uploads its scalars / moves its array both ways; *_each = the fastest of five calls after one "
                     "warm-up, median_of_five_calls = the median of the same five"}
     gate_prog.destroy()

@@ -306,7 +306,7 @@ def run_proof(shape_name: str = "merkle_sum_tree_k18", device=None, reps: int = 
     import torch
 
     from . import circuits
-    from .arithmetic import G1_GENERATOR, FQ_ONE_MONT, eval_polynomial, g1_fixed_base_mul
+    from .arithmetic import G1_GENERATOR, FQ_ONE_MONT, eval_polynomial, g1_fixed_base_mul, to_host
     from .domain import EvaluationDomain
     from .kzg import ParamsKZG
     from .replay import REPLAY_S, SHAPES, _rand_fr, _sparse_column
@@ -337,15 +337,15 @@ def run_proof(shape_name: str = "merkle_sum_tree_k18", device=None, reps: int = 
         table = DevicePoly.new(n_cols * n)
         if prog is None or table is None:
             raise RuntimeError("rust_glue.run_proof: " + _last_error())
-        key_cols = {i: _rand_fr(n, 9000 + i, device).cpu().numpy().view(np.uint64).copy() for i in const_idx[:2]}     # two distinct arrays stand for the key's columns
+        key_cols = {i: to_host(_rand_fr(n, 9000 + i, device)) for i in const_idx[:2]}     # two distinct arrays stand for the key's columns
         for j, i in enumerate(const_idx):
             if not table.upload_at(i * n, key_cols[const_idx[j % 2]]):
                 raise RuntimeError("rust_glue.run_proof: " + _last_error())
         sys.hm_device_synchronize()
         out["per_key_ms"] = (time.perf_counter() - t0) * 1e3
         # ---- the per-proof columns on the host, as a prover holds them ----
-        sparse = [_sparse_column(n, shape.used_rows, 200 + i, device).cpu().numpy().view(np.uint64).copy() for i in range(2)]
-        dense = [_rand_fr(n, 100 + i, device).cpu().numpy().view(np.uint64).copy() for i in range(2)]
+        sparse = [to_host(_sparse_column(n, shape.used_rows, 200 + i, device)) for i in range(2)]
+        dense = [to_host(_rand_fr(n, 100 + i, device)) for i in range(2)]
         adv0 = lay.num_fixed_entries
         is_sparse = {i: (adv0 <= i < adv0 + cs.num_advice) for i in proof_idx}                 # advice columns are the sparse ones
         host_col = {i: (sparse if is_sparse[i] else dense)[j & 1] for j, i in enumerate(proof_idx)}
