@@ -919,9 +919,6 @@ __device__ __forceinline__ void p2v2_tile(const uint4 (&q)[P2_IPT / 4], uint32_t
     for (uint32_t b = tid; b < NF; b += SORT_THREADS)
       if (tcnt[b]) gcur[b] = atomicAdd(&gc[b], tcnt[b]);
   lds_barrier();
-#ifdef HM_P2_SEQ_EXPERIMENT      // CEILING EXPERIMENT (wrong results): the tile written where it was read, perfectly coalesced
-  for (uint32_t e = tid; e < kept; e += SORT_THREADS) sorted[(tb > lo ? tb : lo) + e] = st_pay[e];
-#else
   if (FULL) {
 #pragma unroll 4
     for (int k = 0; k < P2_IPT; ++k) {
@@ -934,7 +931,6 @@ __device__ __forceinline__ void p2v2_tile(const uint4 (&q)[P2_IPT / 4], uint32_t
       sorted[gcur[b] + (e - tstart[b])] = st_pay[e];
     }
   }
-#endif
   lds_barrier();
   for (uint32_t b = tid; b < NF; b += SORT_THREADS) {
     if (!COOP) gcur[b] += tcnt[b];
@@ -1004,167 +1000,12 @@ __global__ __launch_bounds__(SORT_THREADS) void msm_part2_scatter_v2_kernel(cons
   }
 }
 
-// ---------------------------------------------------------------------------------------------
-// The second-level scatter with CARRY slots (round 6).  msm_part2_scatter_v2_kernel writes, per tile, one run per fine
-// bucket of tile / buckets items: 4 items = 16 bytes at 2^24 on the table, at whatever alignment the bucket's cursor has -- measured 2.1 x
-// the item bytes in WRITE_SIZE, and 0.83 ms against 0.48 ms for the same kernel with its tile stored where it was read
-// (-DHM_P2_SEQ_EXPERIMENT: the ceiling).  Here a bucket's items WAIT in LDS (8 words per bucket) until they complete a 32-byte sector of
-// `sorted`: per tile a bucket emits the largest count that ends on a sector boundary -- the carried items first, then the tile's -- and
-// keeps the rest (< 8, and never enough to complete the sector: head + carried < 8) for the next tile; what is left when the region
-// ends is flushed.  Every store but a bucket's first and last partial sector is part of a full, aligned sector.  The slots cost
-// 2^fb x 32 B of LDS, so this form needs fb <= 11 (the plan then takes one more coarse bit: HALO2_MI355X_CB_FIRST).
-// Regions above `big` stay with the cooperative v2 kernel.
-#ifndef HM_P2C_IPT
-#define HM_P2C_IPT 8
-#endif
-constexpr int P2C_IPT = HM_P2C_IPT;
-constexpr int P2C_TILE = SORT_THREADS * P2C_IPT;
-constexpr int P2C_CAP = 8;                           // words per carry slot = one 32-byte sector
-static_assert(((size_t)4 * 2048 + 32 + (size_t)2048 * P2C_CAP + P2C_TILE) * 4 + (size_t)P2C_TILE * 2 + (PS_MAX_SC + 2 + P2C_TILE / 64) * 4 <= 160 * 1024,
-              "carry scatter does not fit the LDS at fb = 11");
-
-__device__ __forceinline__ void p2c_load(const uint32_t* __restrict__ tmp, uint32_t tb, uint32_t lo, uint32_t hi, uint32_t tid,
-                                         uint4 (&q)[P2C_IPT / 4]) {
-#pragma unroll
-  for (int j = 0; j < P2C_IPT / 4; ++j) {
-    const uint32_t p = tb + 4u * ((uint32_t)j * SORT_THREADS + tid);
-    q[j] = *reinterpret_cast<const uint4*>(tmp + (p < hi ? p : (lo & ~3u)));
-  }
-}
-
-template <bool FULL>
-__device__ __forceinline__ void p2c_tile(const uint4 (&q)[P2C_IPT / 4], uint32_t* __restrict__ sorted, uint32_t tb, uint32_t lo, uint32_t hi,
-                                         uint32_t region_lo, uint32_t ib, uint32_t NF, const Positional& ps, uint32_t* gcur, uint32_t* tcnt,
-                                         uint32_t* tstart, uint32_t* ec, uint32_t* carry, uint32_t* wsum, uint32_t* st_pay, uint16_t* st_bin,
-                                         const uint32_t* sc_start, uint32_t* tile_sc, uint32_t tid) {
-  constexpr int NV = P2C_IPT / 4;
-  const uint32_t imask = (1u << ib) - 1u;
-  if (ps.nsc && tid < P2C_TILE / 64) {                // the largest sc with sc_start[sc] <= position, per 64 positions of the tile
-    const uint32_t p0 = tb + 64u * tid;
-    const uint32_t rel = p0 > region_lo ? p0 - region_lo : 0u;
-    uint32_t a = 0, b = ps.nsc;
-    while (b - a > 1) {
-      const uint32_t m = (a + b) >> 1;
-      if (sc_start[m] <= rel) a = m; else b = m;
-    }
-    tile_sc[tid] = a;
-  }
-  uint32_t rank[P2C_IPT], vmask[NV];
-#pragma unroll
-  for (int j = 0; j < NV; ++j) {
-    const uint32_t p = tb + 4u * ((uint32_t)j * SORT_THREADS + tid);
-    const uint32_t i4[4] = {q[j].x, q[j].y, q[j].z, q[j].w};
-    uint32_t m = 0, bin[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      bin[c] = i4[c] >> (ib + 1);
-      m |= (FULL || (p + c >= lo && p + c < hi)) ? 1u << c : 0u;
-    }
-    vmask[j] = m;
-    lds_rank4<FULL>(tcnt, bin, m, &rank[4 * j]);
-  }
-  lds_barrier();
-  const uint32_t kept = tile_exclusive_scan(tcnt, tstart, wsum, NF, tid);
-#pragma unroll
-  for (int j = 0; j < NV; ++j) {
-    const uint32_t p = tb + 4u * ((uint32_t)j * SORT_THREADS + tid);
-    const uint32_t i4[4] = {q[j].x, q[j].y, q[j].z, q[j].w};
-    uint32_t a = 0, nb = 0xffffffffu;
-    if (ps.nsc && (FULL || vmask[j])) {
-      const uint32_t rel = (p > region_lo ? p - region_lo : 0u);
-      a = tile_sc[(p - tb) >> 6];
-      while (sc_start[a + 1] <= rel && a + 1 < ps.nsc) ++a;
-      nb = sc_start[a + 1];
-    }
-#pragma unroll
-    for (int c = 0; c < 4; ++c)
-      if (FULL || (vmask[j] & (1u << c))) {
-        uint32_t pay = (i4[c] & imask) | (((i4[c] >> ib) & 1u) << 31);
-        if (ps.nsc) {
-          const uint32_t rel = p + c - region_lo;
-          while (nb <= rel && a + 1 < ps.nsc) { ++a; nb = sc_start[a + 1]; }
-          pay |= a << ib;
-        }
-        const uint32_t bin = i4[c] >> (ib + 1);
-        st_pay[dst_of(tstart, bin, rank[4 * j + c])] = pay;
-        st_bin[dst_of(tstart, bin, rank[4 * j + c])] = (uint16_t)bin;
-      }
-  }
-  // per bucket: how many items leave now (E: carried first, then the tile's; ends on a sector boundary of `sorted`), and the carried
-  // ones leave here.  ec[b] holds the carried count between tiles and (E << 4 | carried) during the store phase below.
-  for (uint32_t b = tid; b < NF; b += SORT_THREADS) {
-    const uint32_t c = ec[b], t = tcnt[b], g = gcur[b], head = g & (P2C_CAP - 1), total = c + t;
-    uint32_t E = 0;
-    if (head + total >= (uint32_t)P2C_CAP) {
-      E = ((head + total) & ~(uint32_t)(P2C_CAP - 1)) - head;        // > c: head + c < CAP always
-      for (uint32_t j = 0; j < c; ++j) sorted[g + j] = carry[b * P2C_CAP + j];
-    }
-    ec[b] = (E << 4) | c;
-  }
-  lds_barrier();
-  for (uint32_t e = tid; e < kept; e += SORT_THREADS) {
-    const uint32_t b = st_bin[e], x = ec[b], E = x >> 4, at = (x & 15u) + (e - tstart[b]);     // position among carried + tile items
-    if (at < E) sorted[gcur[b] + at] = st_pay[e];
-    else carry[b * P2C_CAP + (at - E)] = st_pay[e];
-  }
-  lds_barrier();
-  for (uint32_t b = tid; b < NF; b += SORT_THREADS) {
-    const uint32_t x = ec[b], E = x >> 4;
-    gcur[b] += E;
-    ec[b] = (x & 15u) + tcnt[b] - E;
-    tcnt[b] = 0;
-  }
-  lds_barrier();
-}
-
-__global__ __launch_bounds__(SORT_THREADS) void msm_part2_scatter_carry_kernel(const uint32_t* __restrict__ tmp, const uint32_t* __restrict__ cstart,
-                                                                               const uint32_t* __restrict__ boff, uint32_t* __restrict__ sorted,
-                                                                               uint32_t fb, uint32_t ib, uint32_t NC, uint32_t NBP, uint32_t big,
-                                                                               Positional ps) {
-  extern __shared__ uint32_t sm[];
-  __shared__ uint32_t sc_start[PS_MAX_SC + 2];
-  __shared__ uint32_t tile_sc[P2C_TILE / 64];
-  const uint32_t hb = blockIdx.x, w = blockIdx.y, tid = threadIdx.x;
-  if (cstart[w * NC + hb + 1] - cstart[w * NC + hb] > big) return;       // the cooperative kernel's
-  const uint32_t NF = 1u << fb;                       // <= 2048
-  uint32_t* gcur = sm;
-  uint32_t* tcnt = gcur + NF;
-  uint32_t* tstart = tcnt + NF;
-  uint32_t* ec = tstart + NF;
-  uint32_t* wsum = ec + NF;                           // 32 words
-  uint32_t* carry = wsum + 32;                        // NF x P2C_CAP
-  uint32_t* st_pay = carry + (size_t)NF * P2C_CAP;
-  uint16_t* st_bin = reinterpret_cast<uint16_t*>(st_pay + P2C_TILE);
-  const uint32_t* bo = boff + (size_t)w * NBP + 1 + ((size_t)hb << fb);
-  for (uint32_t b = tid; b < NF; b += SORT_THREADS) { gcur[b] = bo[b]; tcnt[b] = 0; ec[b] = 0; }
-  const uint32_t lo = cstart[w * NC + hb], hi = cstart[w * NC + hb + 1];
-  const uint32_t region_lo = lo, region_n = hi - lo;
-  if (ps.nsc) {
-    for (uint32_t sc = tid; sc <= ps.nsc + 1; sc += SORT_THREADS)
-      sc_start[sc] = sc < ps.nsc ? ps.chist[((size_t)w * ps.G + (size_t)sc * ps.gpc) * NC + hb] : (sc == ps.nsc ? region_n : 0xffffffffu);
-  }
-  lds_barrier();
-  if (lo >= hi) return;
-  uint4 q[P2C_IPT / 4], qn[P2C_IPT / 4];
-  p2c_load(tmp, lo & ~3u, lo, hi, tid, q);
-  for (uint32_t tb = lo & ~3u; tb < hi; tb += P2C_TILE) {
-    const bool more = tb + P2C_TILE < hi;
-    if (more) p2c_load(tmp, tb + P2C_TILE, lo, hi, tid, qn);
-    if (tb >= lo && tb + P2C_TILE <= hi)
-      p2c_tile<true>(q, sorted, tb, lo, hi, region_lo, ib, NF, ps, gcur, tcnt, tstart, ec, carry, wsum, st_pay, st_bin, sc_start, tile_sc, tid);
-    else
-      p2c_tile<false>(q, sorted, tb, lo, hi, region_lo, ib, NF, ps, gcur, tcnt, tstart, ec, carry, wsum, st_pay, st_bin, sc_start, tile_sc, tid);
-    if (more) {
-#pragma unroll
-      for (int j = 0; j < P2C_IPT / 4; ++j) q[j] = qn[j];
-    }
-  }
-  // what still waits: each bucket's last partial sector
-  for (uint32_t b = tid; b < NF; b += SORT_THREADS) {
-    const uint32_t c = ec[b], g = gcur[b];
-    for (uint32_t j = 0; j < c; ++j) sorted[g + j] = carry[b * P2C_CAP + j];
-  }
-}
+// Measured negative in round 6 (profiles/r06_sort_ab.txt): the second-level scatter writes 4-item = 16-byte runs at 2^24 on the table
+// (2.1 x its bytes in WRITE_SIZE; with every tile stored where it was read the kernel takes 0.48 ms instead of 0.83 -- the ceiling).
+// A form with carry slots in LDS (8 words per bucket, items leave in whole aligned 32-byte sectors; needs fb <= 11, so one more coarse
+// bit and half-size tiles) was correct and SLOWER than the plain scatter on the same plan, 906 against 716 us: two more per-bucket
+// passes and a barrier per tile cost more than the full sectors save; ten coarse bits alone only move 0.13 ms from this level to the
+// first.  The plan stays 9 + 12 bits.
 
 // bucket offsets (exclusive scan of counts) and task offsets (exclusive scan of ceil(count / L)):
 // three small launches -- per-block sums, a one-block scan of those, per-block rescan + offset.
@@ -1951,12 +1792,6 @@ int msm_precompute(uint32_t* d_table, const uint8_t* d_inf, size_t n, uint32_t c
   return HM_OK;
 }
 
-// HALO2_MI355X_P2_CARRY=1: the second-level scatter with carry slots where its plan allows (fb <= 11) -- A/B switch, round 6
-static bool p2_carry() {
-  static const bool v = [] { const char* e = std::getenv("HALO2_MI355X_P2_CARRY"); return e && *e == '1'; }();
-  return v;
-}
-
 // HALO2_MI355X_SORT_V1=1: the round-1..3 tiled scatters (one 4-byte load per item) instead of the vector-load form (A/B)
 static bool sort_v1() {
   static const bool v = [] { const char* e = std::getenv("HALO2_MI355X_SORT_V1"); return e && *e == '1'; }();
@@ -2034,11 +1869,6 @@ static int launch_sort_scatter(const int32_t* d_digits, const uint32_t* d_cstart
   const size_t lds_fine = (size_t)4 << fb;
   if (cb && (fb <= 11 || (ps.nsc != 0 && fb <= 12)) && sizeof(ITEM) == 4 && !sort_v1()) {
     const size_t lds_tiled = ((size_t)3 * (1u << fb) + 32 + P2_TILE) * 4 + (size_t)P2_TILE * 2;
-    if (fb <= 11 && p2_carry()) {
-      const size_t lds_carry = ((size_t)4 * (1u << fb) + 32 + ((size_t)P2C_CAP << fb) + P2C_TILE) * 4 + (size_t)P2C_TILE * 2;
-      hipLaunchKernelGGL(msm_part2_scatter_carry_kernel, dim3(NC, SW), dim3(SORT_THREADS), lds_carry, stream, (const uint32_t*)d_tmp,
-                         d_cstart, d_boff, d_sorted, fb, ib, NC, NBP, br.big, ps);
-    } else
     hipLaunchKernelGGL((msm_part2_scatter_v2_kernel<false>), dim3(NC, SW), dim3(SORT_THREADS), lds_tiled, stream, (const uint32_t*)d_tmp,
                        d_cstart, d_boff, d_sorted, fb, ib, NC, NBP, br.big, br.slice, (const uint2*)br.list, (const uint32_t*)br.count,
                        br.gcursor, ps);
@@ -2326,9 +2156,6 @@ static int msm_issue(DeviceCtx& ctx, int slot, const uint32_t* const* d_scalars_
                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds_all));
     HM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(msm_part2_scatter_v2_kernel<true>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds_all));
-    HM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(msm_part2_scatter_carry_kernel),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)(((size_t)4 * 2048 + 32 + (size_t)2048 * P2C_CAP + P2C_TILE) * 4 + (size_t)P2C_TILE * 2)));
     ctx.msm_attr_set = true;
   }
   hipEvent_t* ev = sl.ev;
