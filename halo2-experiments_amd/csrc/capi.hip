@@ -365,11 +365,25 @@ int hm_device_malloc(size_t bytes, void** d_out) try {
   if (!ctx) return HM_ERR_NO_DEVICE;
   if (bytes == 0) return HM_OK;
   void* p = nullptr;
-  hipError_t e = hipMalloc(&p, bytes);
-  if (e != hipSuccess) {                                  // the library's own caches give back what they can, once
-    (void)hipGetLastError();
+  hipError_t e = hipSuccess;
+#ifdef HM_FAULT_INJECTION      // test build: an armed "device_malloc_oom" makes the FIRST attempt fail like an exhausted device
+  try {
+    hm_fault_point("device_malloc_oom");
+    e = hipMalloc(&p, bytes);
+  } catch (const std::exception&) {
+    e = hipErrorOutOfMemory;
+  }
+#else
+  e = hipMalloc(&p, bytes);
+#endif
+  if (e != hipSuccess) {                                  // the library's own caches give back what they can: parked base sets first,
+    (void)hipGetLastError();                              // then every cached twiddle / coset table (up to 3 GiB, rebuilt on demand)
     std::lock_guard<std::mutex> lk(ctx->mu);
     if (drop_parked_bases(*ctx)) e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      if (ntt_caches_give_back(*ctx) != 0) e = hipMalloc(&p, bytes);
+    }
   }
   if (e != hipSuccess) {
     (void)hipGetLastError();

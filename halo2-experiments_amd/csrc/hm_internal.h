@@ -341,6 +341,7 @@ int fr_scale_run(uint32_t* d_a, const uint64_t c_ext[4], uint64_t n, hipStream_t
 int fr_mul_pattern3_run(uint32_t* d_a, const uint64_t c3_ext[12], uint64_t n, hipStream_t stream);
 void ntt_tables_release(NttTables& t);
 void coset_tables_release(DeviceCtx& ctx);
+size_t ntt_caches_give_back(DeviceCtx& ctx);   // every cached twiddle / coset table freed (after a device synchronise); bytes given back
 // out_b[t] = sum_i in_b[i] (shift omega^t)^i for `batch` back-to-back n-element arrays, out of place (d_out may be d_in);
 // internal: outputs multiplied by 32 (HM_GRAPH_COLUMNS_INTERNAL)
 int ntt_coset_run(DeviceCtx& ctx, const uint32_t* d_in, uint32_t* d_out, uint32_t batch, const uint64_t omega_ext[4], uint32_t log_n,

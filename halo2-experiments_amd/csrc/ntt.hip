@@ -795,6 +795,20 @@ void coset_tables_release(DeviceCtx& ctx) {
   ctx.coset_table_bytes = 0;
 }
 
+// An allocation failed somewhere else in the library (hm_device_malloc: a prover's own polynomial): every cached table goes -- up to
+// 1 GiB of twiddle sets and 2 GiB of coset power tables, all rebuilt on demand.  Kernels in flight may still read them: the device is
+// synchronised first.  ctx.mu held.  -> bytes given back.
+size_t ntt_caches_give_back(DeviceCtx& ctx) {
+  const size_t held = ctx.ntt_table_bytes + ctx.coset_table_bytes;
+  if (ctx.ntt_tables.empty() && ctx.coset_tables.empty()) return 0;
+  (void)hipDeviceSynchronize();
+  for (auto& t : ctx.ntt_tables) ntt_tables_release(*t);
+  ctx.ntt_tables.clear();
+  ctx.ntt_table_bytes = 0;
+  coset_tables_release(ctx);
+  return held;
+}
+
 // Evict the least recently used table that the CURRENT call has not asked for (last_use < keep_from: a call gathers up to 16
 // table pointers before it launches, so its own tables must stay).  A kernel in flight may still read the table that goes:
 // the device is synchronised first.  false = nothing evictable.

@@ -114,11 +114,11 @@ def test_faults_in_the_drop_in_call(fi, cref):
 
 @pytest.mark.gpu
 def test_the_copy_lanes_are_optional(fi, cref):
-    """The host-pointer forms move their arrays through up to eight pinned staging lanes, a helper thread each (csrc/xfer.hip): lanes
+    """The host-pointer forms move their arrays through four (at most eight) pinned staging lanes, a helper thread each (csrc/xfer.hip): lanes
     whose thread cannot be started are run by the calling thread -- same result, no error; in place on the allocation the coefficients
     live in the contents are kept."""
     from halo2_experiments_amd.domain import EvaluationDomain, fr_words
-    d = EvaluationDomain(7, 15)                            # 1 MiB up, 8 MiB down: eight lanes
+    d = EvaluationDomain(7, 15)                            # 1 MiB up, 8 MiB down: every lane
     n, en = d.n, d.extended_len()
     coeffs = _rand_fr(n, 9150).cpu().numpy().view(np.uint64).copy()
     coset = np.concatenate([fr_words(1), fr_words(d.g_coset), fr_words(d.g_coset * d.g_coset)])
@@ -254,3 +254,29 @@ def test_faults_in_the_batch_waiter(fi, cref):
         assert np.array_equal(got, want)
     finally:
         assert fi.hm_release_bases(hd) == 0
+
+
+@pytest.mark.gpu
+def test_an_exhausted_device_gets_the_librarys_caches_back(fi):
+    """hm_device_malloc's retry freed parked base sets only, while the library may hold 1 GiB of twiddle sets and 2 GiB of
+    coset power tables.  Test build: an armed "device_malloc_oom" fails the first attempt like an exhausted device; the call must
+    succeed on the retry, after every cached table has gone (hm_get_stats), and the transforms rebuild theirs on demand."""
+    from halo2_experiments_amd.domain import EvaluationDomain, fr_words
+    d = EvaluationDomain(7, 12)
+    a = _rand_fr(d.n, 9300).cpu().numpy().view(np.uint64).copy()
+    want = a.copy()
+    assert fi.hm_ntt_bn256_fr(_u64(want), _u64(fr_words(d.omega)), d.k) == 0                  # builds a twiddle set
+    ext = np.empty((d.extended_len(), 4), dtype=np.uint64)
+    coset = np.concatenate([fr_words(1), fr_words(d.g_coset), fr_words(d.g_coset * d.g_coset)])
+    assert fi.hm_coeff_to_extended_bn256_fr(_u64(a), _u64(ext), _u64(fr_words(d.extended_omega)), d.k, d.extended_k, _u64(coset)) == 0
+    st = _lib.Stats()
+    assert fi.hm_get_stats(ctypes.byref(st)) == 0 and st.ntt_tables >= 2 and st.ntt_table_bytes > 0
+    fi.hm_test_arm_fault(b"device_malloc_oom", 0)
+    p = ctypes.c_void_p()
+    assert fi.hm_device_malloc(1 << 20, ctypes.byref(p)) == 0 and p.value                      # second attempt, after the caches went
+    fi.hm_test_arm_fault(None, 0)
+    assert fi.hm_get_stats(ctypes.byref(st)) == 0 and st.ntt_tables == 0 and st.ntt_table_bytes == 0 and st.coset_tables == 0
+    assert fi.hm_device_free(p) == 0
+    again = a.copy()
+    assert fi.hm_ntt_bn256_fr(_u64(again), _u64(fr_words(d.omega)), d.k) == 0 and np.array_equal(again, want)      # rebuilt on demand
+    assert fi.hm_get_stats(ctypes.byref(st)) == 0 and st.ntt_tables == 1
