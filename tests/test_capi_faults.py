@@ -271,12 +271,15 @@ def test_an_exhausted_device_gets_the_librarys_caches_back(fi):
     assert fi.hm_coeff_to_extended_bn256_fr(_u64(a), _u64(ext), _u64(fr_words(d.extended_omega)), d.k, d.extended_k, _u64(coset)) == 0
     st = _lib.Stats()
     assert fi.hm_get_stats(ctypes.byref(st)) == 0 and st.ntt_tables >= 2 and st.ntt_table_bytes > 0
-    fi.hm_test_arm_fault(b"device_malloc_oom", 0)
-    p = ctypes.c_void_p()
-    assert fi.hm_device_malloc(1 << 20, ctypes.byref(p)) == 0 and p.value                      # second attempt, after the caches went
-    fi.hm_test_arm_fault(None, 0)
+    # parked base sets (left by other tests of this process) go first and may satisfy the retry by themselves: the second "exhausted"
+    # call finds none and takes the tables
+    for _ in range(2):
+        fi.hm_test_arm_fault(b"device_malloc_oom", 0)
+        p = ctypes.c_void_p()
+        assert fi.hm_device_malloc(1 << 20, ctypes.byref(p)) == 0 and p.value                  # the retry, after the caches gave back
+        fi.hm_test_arm_fault(None, 0)
+        assert fi.hm_device_free(p) == 0
     assert fi.hm_get_stats(ctypes.byref(st)) == 0 and st.ntt_tables == 0 and st.ntt_table_bytes == 0 and st.coset_tables == 0
-    assert fi.hm_device_free(p) == 0
     again = a.copy()
     assert fi.hm_ntt_bn256_fr(_u64(again), _u64(fr_words(d.omega)), d.k) == 0 and np.array_equal(again, want)      # rebuilt on demand
     assert fi.hm_get_stats(ctypes.byref(st)) == 0 and st.ntt_tables == 1
