@@ -226,7 +226,9 @@ static int xfer_prepare(HostXfer& x, int want) {
 // Chunks of one lane's share: uniform, one slot each.  Measured negative (round 6, profiles/r06_host_copies.txt): chunks ramping
 // 256 KiB -> 2 MiB -> 256 KiB (to shorten the pipeline's fill and drain) made every shape slower -- a phase of 19 commitments 13.3 ms against
 // 10.9, coeff_to_extended into a fresh array 6.0 against 5.1 -- as round 5's 512 KiB ring had: the fixed cost per DMA (~15 us, serialised
-// on the copy engines over all lanes) outweighs the shorter fill.  32 DMAs of 2 MiB per 64 MiB is where the two costs balance.
+// on the copy engines over all lanes) outweighs the shorter fill.  32 DMAs of 2 MiB per 64 MiB is where the two costs balance.  The same
+// for SMALL shares (a quarter of the share per chunk, so that a lane moving 2 MiB of an 8 MiB column overlaps its memcpy with its DMA):
+// a phase of 19 commitments 12.7 ms against 11.25, coeff_to_extended into a fresh array 6.6 against 5.4.  One slot per chunk, always.
 static size_t xfer_next_chunk(size_t /*done*/, size_t remaining) { return remaining < kXferSlot ? remaining : kXferSlot; }
 
 static hipError_t lane_h2d(XferLane& l, int device, char* d_dst, const char* src, size_t bytes) {
