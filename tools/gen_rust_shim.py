@@ -1056,7 +1056,7 @@ made of the recalled anchor lines.
 | `halo2-mi355x-sys/` | the FFI crate: `Cargo.toml`, `build.rs` (links `libhalo2_mi355x.so` from `$HALO2_MI355X_LIB_DIR`), `src/lib.rs` (one `extern "C"` item per header entry, `#[repr(C)]` structs, `HM_*` constants) |
 | `halo2_proofs-patch/src/mi355x.rs` | glue for the two free functions and the two `EvaluationDomain` steps: `try_coeff_to_extended` (fresh output Vec: every failure leaves the input untouched), `try_extended_to_coeff`; `try_best_multiexp`, `try_best_fft` (TypeId dispatch on `bn256::G1Affine` / `bn256::Fr`, layout assertions behind `std::sync::Once`, fall back to the CPU body on any error that left the arrays untouched, panic on `HM_ERR_PARTIAL_OUTPUT`), `use_devices` |
 | `halo2_proofs-patch/src/mi355x_kzg.rs` | `SrsHandles`, the new field of `ParamsKZG`: `g` / `g_lagrange` registered ONCE per `ParamsKZG` (`hm_register_bases`: resident, converted, fixed-base table from 2^17 points), `commit` / `commit_lagrange` through the handle (`hm_msm_bn256_g1_h`), `commit_lagrange_batch` = a phase of commitments in one call (`hm_msm_batch_bn256_g1_h`); `Clone` = empty, `Drop` = release, `reset()` for `downsize` |
-| `halo2_proofs-patch/src/mi355x_dev.rs` | the device-resident half of the boundary as code: `DevicePoly` (RAII over `hm_device_malloc` / `hm_copy_to_*`), `DeviceDomain` (`lagrange_to_coeff`, `coeff_to_extended`, `extended_to_coeff` on arrays that stay in HBM), `commit_dev` / `commit_batch_dev`, `eval_polynomial_dev`, `QuotientProgram::quotient_by_cosets` (evaluate_h + the vanishing division + `extended_to_coeff` in one call); reached by none of the drop-in edits — a prover adopts it step by step |
+| `halo2_proofs-patch/src/mi355x_dev.rs` | the device-resident half of the boundary as code: `DevicePoly` (RAII over `hm_device_malloc` / `hm_copy_to_*`), `DeviceDomain` (`lagrange_to_coeff`, `coeff_to_extended`, `extended_to_coeff` on arrays that stay in HBM), `commit_dev` / `commit_batch_dev`, `eval_polynomial_dev`, `QuotientProgram::quotient_by_cosets` (evaluate_h + the vanishing division + `extended_to_coeff` in one call), and the packed-table forms (`upload_at`, `to_vec_range`, `lagrange_to_coeff_range`, `commit_pieces_dev`, `quotient_by_cosets_packed`); compiled only with `--features mi355x-dev`; reached by none of the drop-in edits — a prover adopts it step by step; its call sequence is executed and timed by `halo2-experiments_amd/rust_glue.py` |
 | `edits.json`, `apply_edits.py` | the edits of EXISTING upstream files as a table (file, anchor line, replacement per occurrence) and the script that applies it by literal line match: idempotent, refuses a file whose anchors do not occur as often as expected |
 | `halo2_proofs.patch` | the same as a unified diff (new files + zero-context hunks, one per occurrence) for `patch -p1` |
 
