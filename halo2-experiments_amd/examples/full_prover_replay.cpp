@@ -12,12 +12,13 @@
 // The run ends with the MEASURED call trace of the library's counters (hm_get_stats): what a Rust build of the
 // shim reads after create_proof instead of SURVEY.md §3.2's estimates.
 //
-//   full_prover_replay [k=9] [advice=20] [lookups=8] [equality=12] [max_degree=7] [fixed=8] [tamper=0] [srs_path]
+//   full_prover_replay [k=9] [advice=20] [lookups=8] [equality=12] [max_degree=6] [fixed=18] [tamper=0] [srs_path]
 // tamper=1 changes one evaluation between the two commitments, as the reference's tests tamper with
 // a witness and expect `verify()` to fail: the run must then report a mismatch and exit 1.
 // srs_path: load the SRS from that file if it exists (ParamsKZG::read), else generate it and write it there.
 // Defaults are test_full_prover's k = 9 (/root/reference/src/circuits/merkle_sum_tree.rs:347) with the
-// MerkleSumTree column counts.
+// MerkleSumTree constraint system as transcribed in halo2-experiments_amd/circuits.py (20 advice, 8 lookups, 12 equality columns,
+// degree 6, 18 fixed columns): the shape replay.py calls merkle_sum_tree_k9.
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -92,8 +93,8 @@ int main(int argc, char** argv) {
   const uint32_t advice = argc > 2 ? (uint32_t)atoi(argv[2]) : 20;
   const uint32_t lookups = argc > 3 ? (uint32_t)atoi(argv[3]) : 8;
   const uint32_t equality = argc > 4 ? (uint32_t)atoi(argv[4]) : 12;
-  const uint32_t max_degree = argc > 5 ? (uint32_t)atoi(argv[5]) : 7;
-  const uint32_t fixed = argc > 6 ? (uint32_t)atoi(argv[6]) : 8;
+  const uint32_t max_degree = argc > 5 ? (uint32_t)atoi(argv[5]) : 6;
+  const uint32_t fixed = argc > 6 ? (uint32_t)atoi(argv[6]) : 18;
   const bool tamper = argc > 7 && atoi(argv[7]) != 0;
   const std::string srs_path = argc > 8 ? argv[8] : "";
   if (k < 4 || k > 22 || max_degree < 3) { std::fprintf(stderr, "unsupported shape\n"); return 2; }
