@@ -266,7 +266,7 @@ def test_the_copy_route_is_a_rule_on_the_range_and_both_routes_are_ordered_behin
     from halo2_experiments_amd.arithmetic import _ptr
     lib = _lib.load()
     _lib.check(lib.hm_set_host_copies(0))
-    k = 20                                                                     # 32 MiB: eight lanes
+    k = 20                                                                     # 32 MiB: every lane
     n = 1 << k
     omega = fr_words(pow(7, (FR_MODULUS_FOR_TESTS - 1) >> k, FR_MODULUS_FOR_TESTS))
     a0 = rand_fr_gpu(n, 6600).cpu().numpy().view(np.uint64).copy()
