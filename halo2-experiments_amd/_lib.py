@@ -107,6 +107,8 @@ _SIGNATURES = {
     "hm_device_free": (ctypes.c_int, [ctypes.c_void_p]),
     "hm_copy_to_device": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]),
     "hm_copy_to_host": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]),
+    "hm_copy_many_to_device": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_size_t), ctypes.c_size_t]),
+    "hm_copy_many_to_host": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_size_t), ctypes.c_size_t]),
     "hm_device_synchronize": (ctypes.c_int, []),
     "hm_coeff_to_extended_bn256_fr": (ctypes.c_int, [_u64p, _u64p, _u64p, ctypes.c_uint32, ctypes.c_uint32, _u64p]),
     "hm_extended_to_coeff_bn256_fr": (ctypes.c_int, [_u64p, ctypes.c_size_t, _u64p, ctypes.c_uint32, _u64p, _u64p]),

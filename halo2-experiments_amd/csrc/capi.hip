@@ -427,6 +427,32 @@ int hm_copy_to_host(void* dst, const void* d_src, size_t bytes) try {
   return HM_OK;
 } HM_API_CATCH("hm_copy_to_host")
 
+static int copy_many(const char* who, bool up, void* const* dev, void* const* host, const size_t* bytes, size_t count) {
+  if (count && (!dev || !host || !bytes)) return hm_fail(HM_ERR_BAD_ARG, std::string(who) + ": null argument");
+  size_t total = 0;
+  for (size_t i = 0; i < count; ++i) {
+    if (bytes[i] && (!dev[i] || !host[i])) return hm_fail(HM_ERR_BAD_ARG, std::string(who) + ": null array");
+    total += bytes[i];
+  }
+  DeviceCtx* ctx = ctx_for_current_device();
+  if (!ctx) return HM_ERR_NO_DEVICE;
+  if (total == 0) return HM_OK;
+  HM_HIP_CHECK(hipStreamSynchronize(nullptr));              // the same ordering as hm_copy_to_device / _to_host
+  const int rc = xfer_many(*ctx, up, dev, host, bytes, count, who);
+  if (rc != HM_OK) return up ? rc : hm_fail(HM_ERR_PARTIAL_OUTPUT, std::string(who) + ": the destinations are partly written: " + hm_last_error_string());
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  (up ? ctx->calls.h2d_bytes : ctx->calls.d2h_bytes) += total;
+  return HM_OK;
+}
+
+int hm_copy_many_to_device(void* const* d_dsts, const void* const* srcs, const size_t* bytes, size_t count) try {
+  return copy_many("hm_copy_many_to_device", true, d_dsts, const_cast<void* const*>(srcs), bytes, count);
+} HM_API_CATCH("hm_copy_many_to_device")
+
+int hm_copy_many_to_host(void* const* dsts, const void* const* d_srcs, const size_t* bytes, size_t count) try {
+  return copy_many("hm_copy_many_to_host", false, const_cast<void* const*>(d_srcs), dsts, bytes, count);
+} HM_API_CATCH("hm_copy_many_to_host")
+
 int hm_host_register(const void* p, size_t bytes) try {
   if (!ctx_for_current_device()) return HM_ERR_NO_DEVICE;
   return xfer_host_register(p, bytes);

@@ -288,6 +288,8 @@ DeviceCtx* ctx_for_current_device();
 // with or without ctx.mu held (takes ctx.xfer.mu, never ctx.mu).  d2h failures leave `dst` partly written.
 int xfer_h2d(DeviceCtx& ctx, void* d_dst, const void* src, size_t bytes, const char* who);
 int xfer_d2h(DeviceCtx& ctx, void* dst, const void* d_src, size_t bytes, const char* who);
+// `count` arrays as ONE job of the lanes (hm_copy_many_to_device / _to_host): dev[i] <-> host[i], bytes[i] each
+int xfer_many(DeviceCtx& ctx, bool up, void* const* dev, void* const* host, const size_t* bytes, size_t count, const char* who);
 void xfer_release(DeviceCtx& ctx);
 void xfer_prefault(void* p, size_t bytes);      // first-touch a fresh destination from helper threads (contents kept)
 int xfer_set_policy(int mode);                  // 0 auto, 1 lanes, 2 direct; -1 on anything else

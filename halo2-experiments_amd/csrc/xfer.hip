@@ -229,26 +229,52 @@ static int xfer_prepare(HostXfer& x, int want) {
 // on the copy engines over all lanes) outweighs the shorter fill.  32 DMAs of 2 MiB per 64 MiB is where the two costs balance.  The same
 // for SMALL shares (a quarter of the share per chunk, so that a lane moving 2 MiB of an 8 MiB column overlaps its memcpy with its DMA):
 // a phase of 19 commitments 12.7 ms against 11.25, coeff_to_extended into a fresh array 6.6 against 5.4.  One slot per chunk, always.
-static size_t xfer_next_chunk(size_t /*done*/, size_t remaining) { return remaining < kXferSlot ? remaining : kXferSlot; }
 
-static hipError_t lane_h2d(XferLane& l, int device, char* d_dst, const char* src, size_t bytes) {
+// One contiguous stretch of a transfer: `len` bytes between device and host addresses.  A lane gets a short list of them (one for a
+// plain copy; several when a call moves many arrays at once: hm_copy_many_*), and walks it in chunks of at most one slot.
+struct XferPiece {
+  char* dev;
+  char* host;
+  size_t len;
+};
+struct PieceCursor {
+  const XferPiece* p;
+  size_t n, i, off;
+  bool next(char** dev, char** host, size_t* len) {
+    while (i < n && off >= p[i].len) {
+      ++i;
+      off = 0;
+    }
+    if (i >= n) return false;
+    const size_t rem = p[i].len - off;
+    *len = rem < kXferSlot ? rem : kXferSlot;
+    *dev = p[i].dev + off;
+    *host = p[i].host + off;
+    off += *len;
+    return true;
+  }
+};
+
+static hipError_t lane_h2d(XferLane& l, int device, const XferPiece* pieces, size_t npieces) {
   hipError_t e = hipSetDevice(device);
   bool used[2] = {false, false};
   int slot = 0;
   l.t_wait_us = l.t_copy_us = l.t_issue_us = 0;
-  for (size_t off = 0; off < bytes && e == hipSuccess; slot ^= 1) {
-    const size_t len = xfer_next_chunk(off, bytes - off);
+  PieceCursor cur{pieces, npieces, 0, 0};
+  char *dv = nullptr, *hs = nullptr;
+  size_t len = 0;
+  while (e == hipSuccess && cur.next(&dv, &hs, &len)) {
     const double t0 = xfer_now_us();
     if (used[slot]) e = hipEventSynchronize(l.ev[slot]);          // the DMA that last read this slot
     if (e != hipSuccess) break;
     const double t1 = xfer_now_us();
-    std::memcpy(l.pin[slot], src + off, len);
+    std::memcpy(l.pin[slot], hs, len);
     l.t_wait_us += t1 - t0;
     l.t_copy_us += xfer_now_us() - t1;
-    e = hipMemcpyAsync(d_dst + off, l.pin[slot], len, hipMemcpyHostToDevice, l.stream);
+    e = hipMemcpyAsync(dv, l.pin[slot], len, hipMemcpyHostToDevice, l.stream);
     if (e == hipSuccess) e = hipEventRecord(l.ev[slot], l.stream);
     used[slot] = true;
-    off += len;
+    slot ^= 1;
   }
   const double t2 = xfer_now_us();
   const hipError_t s = hipStreamSynchronize(l.stream);
@@ -256,33 +282,36 @@ static hipError_t lane_h2d(XferLane& l, int device, char* d_dst, const char* src
   return e != hipSuccess ? e : s;
 }
 
-static hipError_t lane_d2h(XferLane& l, int device, char* dst, const char* d_src, size_t bytes) {
+static hipError_t lane_d2h(XferLane& l, int device, const XferPiece* pieces, size_t npieces) {
   hipError_t e = hipSetDevice(device);
-  if (e != hipSuccess || bytes == 0) return e;
-  size_t issued = 0, copied = 0, len[2] = {0, 0};
-  auto issue = [&](int slot) {
+  if (e != hipSuccess) return e;
+  PieceCursor cur{pieces, npieces, 0, 0};
+  char* dst[2] = {nullptr, nullptr};
+  size_t len[2] = {0, 0};
+  bool pending[2] = {false, false};
+  auto issue = [&](int slot) {                                    // false: nothing left to issue
+    char* dv = nullptr;
     const double ti = xfer_now_us();
-    len[slot] = xfer_next_chunk(issued, bytes - issued);
-    hipError_t r = hipMemcpyAsync(l.pin[slot], d_src + issued, len[slot], hipMemcpyDeviceToHost, l.stream);
-    if (r == hipSuccess) r = hipEventRecord(l.ev[slot], l.stream);
-    issued += len[slot];
+    if (!cur.next(&dv, &dst[slot], &len[slot])) return false;
+    e = hipMemcpyAsync(l.pin[slot], dv, len[slot], hipMemcpyDeviceToHost, l.stream);
+    if (e == hipSuccess) e = hipEventRecord(l.ev[slot], l.stream);
     l.t_issue_us += xfer_now_us() - ti;
-    return r;
+    return true;
   };
   int slot = 0;
   l.t_wait_us = l.t_copy_us = l.t_issue_us = 0;
-  e = issue(0);
-  while (copied < bytes && e == hipSuccess) {
-    if (issued < bytes) e = issue(slot ^ 1);                      // the next DMA runs while this slot is copied out
+  pending[0] = issue(0);
+  while (pending[slot] && e == hipSuccess) {
+    pending[slot ^ 1] = issue(slot ^ 1);                          // the next DMA runs while this slot is copied out
+    if (e != hipSuccess) break;
     const double t0 = xfer_now_us();
-    const hipError_t w = hipEventSynchronize(l.ev[slot]);
-    if (e == hipSuccess) e = w;
+    e = hipEventSynchronize(l.ev[slot]);
     if (e != hipSuccess) break;
     const double t1 = xfer_now_us();
-    std::memcpy(dst + copied, l.pin[slot], len[slot]);
+    std::memcpy(dst[slot], l.pin[slot], len[slot]);
     l.t_wait_us += t1 - t0;
     l.t_copy_us += xfer_now_us() - t1;
-    copied += len[slot];
+    pending[slot] = false;
     slot ^= 1;
   }
   if (e != hipSuccess) (void)hipStreamSynchronize(l.stream);     // nothing of ours stays in flight behind an error
@@ -298,22 +327,39 @@ static bool xfer_goes_direct(const void* host, size_t bytes) {
   return host_range_registered(host, bytes);
 }
 
-static int xfer_run(DeviceCtx& ctx, bool up, void* dev, void* host, size_t bytes, const char* who) {
+// The transfer of `segs` (one array, or the many of hm_copy_many_*) as ONE job of the lanes: the concatenation of the segments is cut
+// into page-aligned shares, a lane each, so that forty 8 MiB columns move like one 320 MiB array (one spawn, no per-array fill and
+// drain) instead of forty small transfers.  All segments direct by the range rule: plain hipMemcpy each.
+static int xfer_run_many(DeviceCtx& ctx, bool up, const std::vector<XferPiece>& segs, const char* who) {
+  size_t bytes = 0;
+  bool all_direct = true;
+  for (const XferPiece& sg : segs) {
+    bytes += sg.len;
+    if (sg.len && !xfer_goes_direct(sg.host, sg.len)) all_direct = false;
+  }
   if (bytes == 0) return HM_OK;
   static const bool trace = std::getenv("HALO2_MI355X_XFER_TRACE") != nullptr;
-  if (xfer_goes_direct(host, bytes)) {
-    const hipError_t e = up ? hipMemcpy(dev, host, bytes, hipMemcpyHostToDevice) : hipMemcpy(host, dev, bytes, hipMemcpyDeviceToHost);
-    if (e != hipSuccess) return hm_fail(HM_ERR_HIP, std::string(who) + ": " + hipGetErrorString(e));
+  auto direct = [&]() {
+    for (const XferPiece& sg : segs) {
+      if (!sg.len) continue;
+      const hipError_t e = up ? hipMemcpy(sg.dev, sg.host, sg.len, hipMemcpyHostToDevice) : hipMemcpy(sg.host, sg.dev, sg.len, hipMemcpyDeviceToHost);
+      if (e != hipSuccess) return hm_fail(HM_ERR_HIP, std::string(who) + ": " + hipGetErrorString(e));
+    }
+    return (int)HM_OK;
+  };
+  if (all_direct) {
+    const int rc = direct();
+    if (rc != HM_OK) return rc;
     ctx.xfer.direct.fetch_add(1, std::memory_order_relaxed);
-    if (trace) std::fprintf(stderr, "[halo2_mi355x] copy: %s %zu bytes direct (%s)\n", up ? "H2D" : "D2H", bytes, who);
+    if (trace) std::fprintf(stderr, "[halo2_mi355x] copy: %s %zu bytes in %zu array(s) direct (%s)\n", up ? "H2D" : "D2H", bytes, segs.size(), who);
     return HM_OK;
   }
   const double t_start = xfer_now_us();
   ctx.xfer.staged.fetch_add(1, std::memory_order_relaxed);
-  if (trace) std::fprintf(stderr, "[halo2_mi355x] copy: %s %zu bytes through the lanes (%s)\n", up ? "H2D" : "D2H", bytes, who);
+  if (trace) std::fprintf(stderr, "[halo2_mi355x] copy: %s %zu bytes in %zu array(s) through the lanes (%s)\n", up ? "H2D" : "D2H", bytes, segs.size(), who);
   std::lock_guard<std::mutex> lk(ctx.xfer.mu);                    // the lanes' slots belong to one transfer at a time
-  int want = (int)((bytes + ((size_t)1 << 20) - 1) >> 20);        // a lane per MiB, eight at most
-  // FOUR lanes by default (HALO2_MI355X_XFER_LANES = 1 .. 8 for experiments).  Round 5 ran eight; measured in round 6 on one 64 MiB
+  int want = (int)((bytes + ((size_t)1 << 20) - 1) >> 20);        // a lane per MiB ...
+  // ... FOUR at most by default (HALO2_MI355X_XFER_LANES = 1 .. 8 for experiments).  Round 5 ran eight; measured in round 6 on one 64 MiB
   // round trip (profiles/r06_lane_warmup.txt): 1 lane 2.2 + 3.8 ms up + down, 2 lanes 1.38 + 2.0, 4 lanes 1.38 + 1.38, 8 lanes 1.45 + 1.78
   // -- four already fill the link, and every lane beyond the second cost its first device-to-host copy a ~7 ms stall inside
   // hipMemcpyAsync (six of a process's first seven 64 MiB downloads took 8.3 ms instead of 1.8 with eight lanes; with four, after the
@@ -322,22 +368,30 @@ static int xfer_run(DeviceCtx& ctx, bool up, void* dev, void* host, size_t bytes
   static const int lanes_cap = [] { const char* v = std::getenv("HALO2_MI355X_XFER_LANES"); return v && *v ? std::atoi(v) : kXferDefaultLanes; }();
   if (lanes_cap >= 1 && want > lanes_cap) want = lanes_cap;
   const int lanes = xfer_prepare(ctx.xfer, want);
-  if (lanes == 0) {                                               // no pinned memory to be had: the runtime's path still works
-    const hipError_t e = up ? hipMemcpy(dev, host, bytes, hipMemcpyHostToDevice) : hipMemcpy(host, dev, bytes, hipMemcpyDeviceToHost);
-    if (e != hipSuccess) return hm_fail(HM_ERR_HIP, std::string(who) + ": " + hipGetErrorString(e));
-    return HM_OK;
+  if (lanes == 0) return direct();                                // no pinned memory to be had: the runtime's path still works
+  const size_t share = (((bytes + lanes - 1) / lanes) + 4095) & ~(size_t)4095;     // page-aligned shares of the concatenation
+  std::vector<XferPiece> work[HM_XFER_LANES];
+  {
+    size_t at = 0;                                                // position in the concatenation
+    for (const XferPiece& sg : segs) {
+      size_t done = 0;
+      while (done < sg.len) {
+        const size_t lane = (at / share) < (size_t)lanes ? at / share : (size_t)lanes - 1;
+        const size_t room = (lane + 1) * share - at, take = sg.len - done < room ? sg.len - done : room;
+        work[lane].push_back(XferPiece{sg.dev + done, sg.host + done, take});
+        done += take;
+        at += take;
+      }
+    }
   }
-  const size_t share = (((bytes + lanes - 1) / lanes) + 4095) & ~(size_t)4095;     // page-aligned shares
   hipError_t errs[HM_XFER_LANES];
   for (auto& e : errs) e = hipSuccess;
   const int device = ctx.device;
   auto part = [&](int i) {
     ctx.xfer.lanes[i].t_start_us = xfer_now_us();
-    const size_t lo = (size_t)i * share;
-    if (lo >= bytes) return;
-    const size_t len = bytes - lo < share ? bytes - lo : share;
-    errs[i] = up ? lane_h2d(ctx.xfer.lanes[i], device, (char*)dev + lo, (const char*)host + lo, len)
-                 : lane_d2h(ctx.xfer.lanes[i], device, (char*)host + lo, (const char*)dev + lo, len);
+    if (work[i].empty()) return;
+    errs[i] = up ? lane_h2d(ctx.xfer.lanes[i], device, work[i].data(), work[i].size())
+                 : lane_d2h(ctx.xfer.lanes[i], device, work[i].data(), work[i].size());
   };
   {
     JoinOnExit pool;
@@ -361,6 +415,19 @@ static int xfer_run(DeviceCtx& ctx, bool up, void* dev, void* host, size_t bytes
                  lanes, (xfer_now_us() - t_start) / 1e3, smax / 1e3, wmax / 1e3, imax / 1e3, cmax / 1e3);
   }
   return HM_OK;
+}
+
+static int xfer_run(DeviceCtx& ctx, bool up, void* dev, void* host, size_t bytes, const char* who) {
+  if (bytes == 0) return HM_OK;
+  const std::vector<XferPiece> one{XferPiece{(char*)dev, (char*)host, bytes}};
+  return xfer_run_many(ctx, up, one, who);
+}
+
+int xfer_many(DeviceCtx& ctx, bool up, void* const* dev, void* const* host, const size_t* bytes, size_t count, const char* who) {
+  std::vector<XferPiece> segs;
+  segs.reserve(count);
+  for (size_t i = 0; i < count; ++i) segs.push_back(XferPiece{(char*)dev[i], (char*)host[i], bytes[i]});
+  return xfer_run_many(ctx, up, segs, who);
 }
 
 // 1: a copy of `bytes` from / to `host` would go through the lanes now; 0: straight to hipMemcpy

@@ -100,6 +100,30 @@ class DevicePoly:
             return False
         return sys.hm_copy_to_device(_vp(self.ptr + first * 32), a.ctypes.data_as(_vp), a.shape[0] * 32) == HM_OK
 
+    def upload_many_at(self, firsts: Sequence[int], arrays: Sequence) -> bool:
+        if len(firsts) != len(arrays):
+            return False
+        arrays = [_host(a) for a in arrays]
+        if any(f + a.shape[0] > self.len for f, a in zip(firsts, arrays)):
+            return False
+        k = len(arrays)
+        dsts = (_vp * k)(*[self.ptr + f * 32 for f in firsts])
+        srcs = (_vp * k)(*[a.ctypes.data for a in arrays])
+        nbytes = (ctypes.c_size_t * k)(*[a.shape[0] * 32 for a in arrays])
+        return sys.hm_copy_many_to_device(dsts, srcs, nbytes, k) == HM_OK
+
+    def to_vecs_ranges(self, ranges: Sequence) -> Optional[List[np.ndarray]]:
+        if any(f + n > self.len for f, n in ranges) or sys.hm_device_synchronize() != HM_OK:
+            return None
+        out = [np.empty((n, 4), dtype=np.uint64) for _, n in ranges]          # Vec::with_capacity each: fresh pages
+        k = len(out)
+        dsts = (_vp * k)(*[v.ctypes.data for v in out])
+        srcs = (_vp * k)(*[self.ptr + f * 32 for f, _ in ranges])
+        nbytes = (ctypes.c_size_t * k)(*[n * 32 for _, n in ranges])
+        if sys.hm_copy_many_to_host(dsts, srcs, nbytes, k) != HM_OK:
+            return None
+        return out
+
     def to_vec(self) -> Optional[np.ndarray]:
         return self.to_vec_range(0, self.len)
 
@@ -209,6 +233,18 @@ def commit_pieces_dev(handle: int, polys: DevicePoly, n: int, first: int, count:
     return out
 
 
+def commit_indexed_dev(handle: int, polys: DevicePoly, n: int, indices: Sequence[int]) -> Optional[np.ndarray]:
+    if not indices:
+        return np.zeros((0, 12), dtype=np.uint64)
+    if n == 0 or any((i + 1) * n > polys.len for i in indices):
+        return None
+    ptrs = (_vp * len(indices))(*[polys.ptr + i * n * 32 for i in indices])
+    out = np.zeros((len(indices), 12), dtype=np.uint64)
+    if sys.hm_msm_batch_bn256_g1_dev(ctypes.c_uint64(handle), 0, ptrs, n, len(indices), None, _u64p(out)) != HM_OK:
+        return None
+    return out
+
+
 def eval_polynomial_dev(polys: DevicePoly, n: int, points) -> Optional[np.ndarray]:
     points = _host(points)
     if n == 0 or polys.len < n * points.shape[0]:
@@ -237,14 +273,41 @@ class QuotientProgram:
                                  ctypes.byref(h))
         return cls(h.value, n_columns, n_dynamic) if rc == HM_OK else None
 
-    def _run(self, domain: DeviceDomain, ptrs, dynamic, cosets) -> Optional[DevicePoly]:
+    def keep_on_cosets(self, domain: DeviceDomain, table: DevicePoly, which: Sequence[int], cosets: Sequence[int]) -> Optional[DevicePoly]:
+        n = domain.n()
+        if table.len != self.n_columns * n or not cosets or len(cosets) > 16 or any(i >= self.n_columns for i in which):
+            return None
+        shifts = np.stack([fr_words(domain.coset_shift(j)) for j in cosets])
+        kept = DevicePoly.new(len(which) * len(cosets) * n)
+        if kept is None:
+            return None
+        w = fr_words(domain.omega)
+        for slot, i in enumerate(which):
+            if sys.hm_coeff_to_cosets_bn256_fr_dev(_vp(table.ptr + i * n * 32), _vp(kept.ptr + slot * len(cosets) * n * 32), 1, _u64p(w), domain.k,
+                                                   _u64p(shifts), len(cosets), 1, None) != HM_OK:
+                return None
+        return kept
+
+    def quotient_by_cosets_packed_kept(self, domain: DeviceDomain, table: DevicePoly, kept: DevicePoly, which: Sequence[int], dynamic,
+                                       cosets: Sequence[int]) -> Optional[DevicePoly]:
+        n = domain.n()
+        if (table.len != self.n_columns * n or len(_host(dynamic)) != self.n_dynamic or not cosets or kept.len != len(which) * len(cosets) * n
+                or any(i >= self.n_columns for i in which)):
+            return None
+        ptrs = (_vp * self.n_columns)(*[table.ptr + i * n * 32 for i in range(self.n_columns)])
+        pre = [None] * self.n_columns
+        for slot, i in enumerate(which):
+            pre[i] = kept.ptr + slot * len(cosets) * n * 32
+        return self._run(domain, ptrs, dynamic, cosets, (_vp * self.n_columns)(*pre))
+
+    def _run(self, domain: DeviceDomain, ptrs, dynamic, cosets, pre=None) -> Optional[DevicePoly]:
         dynamic = _host(dynamic)
         n = domain.n()
         shifts = np.stack([fr_words(domain.coset_shift(j)) for j in cosets])
         h = DevicePoly.new(len(cosets) * n)
         if h is None:
             return None
-        rc = sys.hm_quotient_by_cosets_bn256_fr_dev(ctypes.c_uint64(self.handle), ptrs, None, self.n_columns, _u64p(dynamic), dynamic.shape[0], domain.k,
+        rc = sys.hm_quotient_by_cosets_bn256_fr_dev(ctypes.c_uint64(self.handle), ptrs, pre, self.n_columns, _u64p(dynamic), dynamic.shape[0], domain.k,
                                                     _u64p(fr_words(domain.omega)), _u64p(shifts), len(cosets), len(cosets), _vp(h.ptr), None)
         return h if rc == HM_OK else None
 
@@ -290,14 +353,15 @@ def run_proof(shape_name: str = "merkle_sum_tree_k18", device=None, reps: int = 
     calls a Rust prover makes once it holds its polynomials in ``DevicePoly``s (mi355x_dev.rs):
 
         per proving key   the program (``QuotientProgram::new``), ONE packed table of n_columns x n (``DevicePoly::new``), the key's
-                          constant columns (fixed, sigmas, l_0 / l_last / l_active, X) uploaded as coefficients (``upload_at``)
+                          constant columns (fixed, sigmas, l_0 / l_last / l_active, X) uploaded as coefficients (``upload_at``) and
+                          taken onto the cosets once (``keep_on_cosets``)
         per proof         every per-proof column uploaded as synthesis / the CPU-side arguments produce it, Lagrange form
-                          (``upload_at``: A advice + instance + per lookup (z, permuted input, permuted table) + the permutation z's);
-                          committed where it lies (``commit_pieces_dev`` on g_lagrange); to coefficients in place
+                          (``upload_many_at``: A advice + instance + per lookup (z, permuted input, permuted table) + the permutation z's, one call);
+                          committed where it lies (``commit_indexed_dev`` on g_lagrange, one call); to coefficients in place
                           (``lagrange_to_coeff_range``); the quotient in one call from the packed table on the cosets that
-                          determine it (``quotient_by_cosets_packed``); its pieces committed where they lie (``commit_pieces_dev`` on
+                          determine it, the key's columns read where ``keep_on_cosets`` left them (``quotient_by_cosets_packed_kept``); its pieces committed where they lie (``commit_pieces_dev`` on
                           g); the Horner evaluations (``eval_polynomial_dev``); and the coefficient forms the CPU-side SHPLONK needs
-                          brought back (``to_vec_range``: the per-proof columns and h)
+                          brought back (``to_vecs_ranges``: the per-proof columns; ``to_vec``: h)
 
     Synthetic columns as in replay.py (two distinct sparse, two distinct dense arrays).  ``check``: commitments against [f(s)]G
     (the replay's own identity), the coefficient forms and h against the torch-side routes (domain.py / evaluation.py) on the same
@@ -341,6 +405,9 @@ def run_proof(shape_name: str = "merkle_sum_tree_k18", device=None, reps: int = 
         for j, i in enumerate(const_idx):
             if not table.upload_at(i * n, key_cols[const_idx[j % 2]]):
                 raise RuntimeError("rust_glue.run_proof: " + _last_error())
+        kept = prog.keep_on_cosets(ddom, table, const_idx, cosets)                             # the key's columns on the cosets, once
+        if kept is None:
+            raise RuntimeError("rust_glue.run_proof: " + _last_error())
         sys.hm_device_synchronize()
         out["per_key_ms"] = (time.perf_counter() - t0) * 1e3
         # ---- the per-proof columns on the host, as a prover holds them ----
@@ -360,18 +427,14 @@ def run_proof(shape_name: str = "merkle_sum_tree_k18", device=None, reps: int = 
         def proof():
             t = {}
             t0 = time.perf_counter()
-            for i in proof_idx:
-                if not table.upload_at(i * n, host_col[i]):
-                    raise RuntimeError("upload_at: " + _last_error())
+            if not table.upload_many_at([i * n for i in proof_idx], [host_col[i] for i in proof_idx]):     # every per-proof column, one call
+                raise RuntimeError("upload_many_at: " + _last_error())
             t["upload"] = time.perf_counter() - t0
             t0 = time.perf_counter()
-            commits = {}
-            for first, count in runs:                                                            # Lagrange-basis commitments, where the columns lie
-                r = commit_pieces_dev(params.g_lagrange_handle.handle, table, n, first, count)
-                if r is None:
-                    raise RuntimeError("commit_pieces_dev: " + _last_error())
-                for j in range(count):
-                    commits[first + j] = r[j]
+            r = commit_indexed_dev(params.g_lagrange_handle.handle, table, n, proof_idx)        # Lagrange-basis commitments, where the columns lie: one call
+            if r is None:
+                raise RuntimeError("commit_indexed_dev: " + _last_error())
+            commits = {i: r[j] for j, i in enumerate(proof_idx)}
             t["commit"] = time.perf_counter() - t0
             t0 = time.perf_counter()
             for first, count in runs:
@@ -380,9 +443,9 @@ def run_proof(shape_name: str = "merkle_sum_tree_k18", device=None, reps: int = 
             sys.hm_device_synchronize()
             t["lagrange_to_coeff"] = time.perf_counter() - t0
             t0 = time.perf_counter()
-            h = prog.quotient_by_cosets_packed(ddom, table, dyn, cosets)
+            h = prog.quotient_by_cosets_packed_kept(ddom, table, kept, const_idx, dyn, cosets)
             if h is None:
-                raise RuntimeError("quotient_by_cosets_packed: " + _last_error())
+                raise RuntimeError("quotient_by_cosets_packed_kept: " + _last_error())
             sys.hm_device_synchronize()
             t["quotient"] = time.perf_counter() - t0
             t0 = time.perf_counter()
@@ -400,12 +463,10 @@ def run_proof(shape_name: str = "merkle_sum_tree_k18", device=None, reps: int = 
                 raise RuntimeError("eval_polynomial_dev: " + _last_error())
             t["eval_polynomial"] = time.perf_counter() - t0
             t0 = time.perf_counter()
-            back = {}
-            for first, count in runs:                                                            # coefficient forms for the CPU-side multiopen
-                v = table.to_vec_range(first * n, count * n)
-                if v is None:
-                    raise RuntimeError("to_vec_range: " + _last_error())
-                back[first] = v
+            vs = table.to_vecs_ranges([(first * n, count * n) for first, count in runs])           # coefficient forms for the CPU-side multiopen
+            if vs is None:
+                raise RuntimeError("to_vecs_ranges: " + _last_error())
+            back = {first: v for (first, _), v in zip(runs, vs)}
             h_host = h.to_vec()
             t["download"] = time.perf_counter() - t0
             h.drop()
@@ -472,6 +533,7 @@ def run_proof(shape_name: str = "merkle_sum_tree_k18", device=None, reps: int = 
         try:
             prog.drop()
             table.drop()
+            kept.drop()
         except Exception:  # noqa: BLE001
             pass
         compiled.destroy()

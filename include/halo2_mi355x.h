@@ -180,6 +180,12 @@ int hm_device_malloc(size_t bytes, void** d_out);
 int hm_device_free(void* d_ptr);
 int hm_copy_to_device(void* d_dst, const void* src, size_t bytes);
 int hm_copy_to_host(void* dst, const void* d_src, size_t bytes);
+/* `count` arrays in ONE call: srcs[i] -> d_dsts[i] (resp. d_srcs[i] -> dsts[i]), bytes[i] each.  The copy lanes treat them as one
+ * transfer -- the columns of a proof (48 x 8 MiB at k = 18) move at the rate of one 384 MiB array instead of 48 small ones, each with
+ * its own helper threads, pipeline fill and drain.  Same ordering and error convention as the single forms; a failure of the
+ * _to_host form may leave any of the destinations partly written (HM_ERR_PARTIAL_OUTPUT). */
+int hm_copy_many_to_device(void* const* d_dsts, const void* const* srcs, const size_t* bytes, size_t count);
+int hm_copy_many_to_host(void* const* dsts, const void* const* d_srcs, const size_t* bytes, size_t count);
 int hm_device_synchronize(void);
 
 /* How the host-pointer forms move their arrays (csrc/xfer.hip) -- a rule on the host RANGE, never on a timing.

@@ -318,6 +318,45 @@ def test_the_copy_route_is_a_rule_on_the_range_and_both_routes_are_ordered_behin
         _lib.check(lib.hm_device_free(d_a))
 
 
+def test_many_arrays_travel_as_one_transfer(host_copies):
+    """hm_copy_many_to_device / _to_host (what DevicePoly::upload_many_at / to_vecs_ranges call): arrays of odd sizes -- below a page, not a
+    multiple of a slot, several MiB --, scattered into one device buffer and read back from it in another order; both copy policies; the
+    byte counters see the sum."""
+    lib = _lib.load()
+    sizes = [32, 4096 + 32, 100003 * 32, (1 << 18) * 32, 7 * 32, (3 << 20) + 64, 2 << 20]
+    rng = np.random.default_rng(77)
+    arrays = [rng.integers(0, 1 << 63, size=sz // 8, dtype=np.uint64) for sz in sizes]
+    total = sum(sizes)
+    d = ctypes.c_void_p()
+    _lib.check(lib.hm_device_malloc(total, ctypes.byref(d)))
+    try:
+        offs = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.int64)
+        k = len(sizes)
+        st0 = _lib.Stats()
+        _lib.check(lib.hm_get_stats(ctypes.byref(st0)))
+        dsts = (ctypes.c_void_p * k)(*[d.value + int(o) for o in offs])
+        srcs = (ctypes.c_void_p * k)(*[a.ctypes.data for a in arrays])
+        nb = (ctypes.c_size_t * k)(*sizes)
+        _lib.check(lib.hm_copy_many_to_device(dsts, srcs, nb, k))
+        whole = np.empty(total // 8, dtype=np.uint64)
+        _lib.check(lib.hm_copy_to_host(whole.ctypes.data_as(ctypes.c_void_p), d, total))
+        assert np.array_equal(whole, np.concatenate(arrays))
+        order = [3, 0, 6, 2, 5, 1, 4]
+        outs = [np.zeros(sizes[i] // 8, dtype=np.uint64) for i in order]
+        _lib.check(lib.hm_copy_many_to_host((ctypes.c_void_p * k)(*[o.ctypes.data for o in outs]),
+                                            (ctypes.c_void_p * k)(*[d.value + int(offs[i]) for i in order]),
+                                            (ctypes.c_size_t * k)(*[sizes[i] for i in order]), k))
+        assert all(np.array_equal(o, arrays[i]) for o, i in zip(outs, order))
+        st1 = _lib.Stats()
+        _lib.check(lib.hm_get_stats(ctypes.byref(st1)))
+        assert st1.h2d_bytes - st0.h2d_bytes == total and st1.d2h_bytes - st0.d2h_bytes == 2 * total
+        assert lib.hm_copy_many_to_device(dsts, srcs, nb, 0) == 0 and lib.hm_copy_many_to_device(None, srcs, nb, k) == -1
+        bad = (ctypes.c_void_p * k)(*([None] + [a.ctypes.data for a in arrays[1:]]))
+        assert lib.hm_copy_many_to_device(dsts, bad, nb, k) == -1
+    finally:
+        _lib.check(lib.hm_device_free(d))
+
+
 def test_edge_values(cref, pyref):
     o = pyref
     k = 6

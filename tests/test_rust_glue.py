@@ -70,7 +70,7 @@ def test_every_public_item_of_the_rust_file_has_its_twin():
 @pytest.mark.parametrize("name", ["merkle_sum_tree_k9", "merkle_sum_tree_k18"])
 def test_a_proof_through_the_rust_glue_makes_only_its_calls_and_every_result_checks(name):
     """VERDICT r5 next-6.  The k = 18 MerkleSumTree proof (and the reference's own k = 9) through DevicePoly / DeviceDomain / commit_pieces_dev /
-    QuotientProgram exactly: 48 per-proof columns uploaded once, committed and transformed where they lie, the quotient in one call,
+    QuotientProgram exactly: 48 per-proof columns uploaded in one call, committed and transformed where they lie, the quotient in one call,
     its pieces committed where they lie, the coefficient forms brought back.  Every commitment equals [f(s)]G, the coefficient forms and
     h equal the torch-side routes' (which the oracle tests pin at these shapes: tests/test_timed_shapes_gpu.py)."""
     import torch
@@ -81,9 +81,11 @@ def test_a_proof_through_the_rust_glue_makes_only_its_calls_and_every_result_che
     assert all(v is True or isinstance(v, int) for v in r["verified"].values()) and r["verified"]["h_equals_the_torch_route"] is True
     assert r["verified"]["commitments_checked"] == 48 + 5 and r["per_proof_columns"] == 48 and r["columns"] == 83 and r["cosets"] == 5
     c = r["calls_per_proof"]
-    assert c["hm_copy_to_device"] == 48 and c["hm_quotient_by_cosets_bn256_fr_dev"] == 1 and c["hm_eval_polynomial_bn256_fr_dev"] == 1
-    assert c["hm_msm_batch_bn256_g1_dev"] == c["hm_ntt_batch_bn256_fr_dev"] + 1          # one per run of columns, + the pieces of h
-    assert c["hm_copy_to_host"] == c["hm_ntt_batch_bn256_fr_dev"] + 1 and c["hm_device_malloc"] == 1 == c["hm_device_free"]      # h
+    assert c["hm_copy_many_to_device"] == 1 and "hm_copy_to_device" not in c            # 48 columns up in ONE call
+    assert c["hm_quotient_by_cosets_bn256_fr_dev"] == 1 and c["hm_eval_polynomial_bn256_fr_dev"] == 1
+    assert c["hm_msm_batch_bn256_g1_dev"] == 2 and c["hm_ntt_batch_bn256_fr_dev"] >= 1     # every per-proof column in one call, + the pieces of h
+    assert c["hm_copy_many_to_host"] == 1 and c["hm_copy_to_host"] == 1                  # the coefficient forms in one call; h
+    assert c["hm_device_malloc"] == 1 == c["hm_device_free"]                            # h
     assert r["total_ms"] >= r["resident_ms"] > 0 and set(r["ms"]) == {"upload", "commit", "lagrange_to_coeff", "quotient", "commit_h",
                                                                      "eval_polynomial", "download"}
     n = 1 << r["k"]

@@ -643,6 +643,42 @@ impl DevicePoly {
         let dst = unsafe { (self.ptr as *mut u8).add(first * 32) } as *mut c_void;
         unsafe { sys::hm_copy_to_device(dst, a.as_ptr() as *const c_void, a.len() * 32) == sys::HM_OK }
     }
+    /// Upload several arrays in ONE call (hm_copy_many_to_device): `arrays[i]` to elements [firsts[i], firsts[i] + arrays[i].len()).
+    /// The copy lanes move them as one transfer: the columns of a proof at the rate of one large array.
+    pub fn upload_many_at(&mut self, firsts: &[usize], arrays: &[&[Fr]]) -> bool {
+        if firsts.len() != arrays.len() {
+            return false;
+        }
+        let mut dsts: Vec<*mut c_void> = Vec::with_capacity(arrays.len());
+        let mut srcs: Vec<*const c_void> = Vec::with_capacity(arrays.len());
+        let mut bytes: Vec<usize> = Vec::with_capacity(arrays.len());
+        for (&first, a) in firsts.iter().zip(arrays.iter()) {
+            if first.checked_add(a.len()).map_or(true, |end| end > self.len) {
+                return false;
+            }
+            dsts.push(unsafe { (self.ptr as *mut u8).add(first * 32) } as *mut c_void);
+            srcs.push(a.as_ptr() as *const c_void);
+            bytes.push(a.len() * 32);
+        }
+        unsafe { sys::hm_copy_many_to_device(dsts.as_ptr(), srcs.as_ptr(), bytes.as_ptr(), bytes.len()) == sys::HM_OK }
+    }
+    /// Download several ranges (first element, length) in ONE call after waiting for the device (hm_copy_many_to_host).
+    pub fn to_vecs_ranges(&self, ranges: &[(usize, usize)]) -> Option<Vec<Vec<Fr>>> {
+        if ranges.iter().any(|&(first, len)| first.checked_add(len).map_or(true, |end| end > self.len)) || unsafe { sys::hm_device_synchronize() } != sys::HM_OK {
+            return None;
+        }
+        let mut out: Vec<Vec<Fr>> = ranges.iter().map(|&(_, len)| Vec::with_capacity(len)).collect();
+        let dsts: Vec<*mut c_void> = out.iter_mut().map(|v| v.as_mut_ptr() as *mut c_void).collect();
+        let srcs: Vec<*const c_void> = ranges.iter().map(|&(first, _)| unsafe { (self.ptr as *const u8).add(first * 32) } as *const c_void).collect();
+        let bytes: Vec<usize> = ranges.iter().map(|&(_, len)| len * 32).collect();
+        if unsafe { sys::hm_copy_many_to_host(dsts.as_ptr(), srcs.as_ptr(), bytes.as_ptr(), bytes.len()) } != sys::HM_OK {
+            return None;
+        }
+        for (v, &(_, len)) in out.iter_mut().zip(ranges.iter()) {
+            unsafe { v.set_len(len) }; // every element was written by the copy
+        }
+        Some(out)
+    }
     /// Download elements [first, first + len) after waiting for the device.
     pub fn to_vec_range(&self, first: usize, len: usize) -> Option<Vec<Fr>> {
         if first.checked_add(len).map_or(true, |end| end > self.len) || unsafe { sys::hm_device_synchronize() } != sys::HM_OK {
@@ -826,6 +862,33 @@ pub fn commit_pieces_dev(handle: u64, polys: &DevicePoly, n: usize, first: usize
     )
 }
 
+/// The same for ANY selection of the polynomials of a packed array (`indices[i]`: polynomial at [indices[i] n, (indices[i] + 1) n)):
+/// every per-proof column of the table in one call, whatever lies between them.
+pub fn commit_indexed_dev(handle: u64, polys: &DevicePoly, n: usize, indices: &[usize]) -> Option<Vec<G1>> {
+    if indices.is_empty() {
+        return Some(Vec::new());
+    }
+    if n == 0 || indices.iter().any(|&i| i.checked_add(1).map_or(true, |e| e.checked_mul(n).map_or(true, |e| e > polys.len()))) {
+        return None;
+    }
+    let base = polys.as_ptr() as *const u8;
+    let ptrs: Vec<*const c_void> = indices.iter().map(|&i| unsafe { base.add(i * n * 32) } as *const c_void).collect();
+    let mut out = vec![0u64; 12 * indices.len()];
+    let rc = unsafe { sys::hm_msm_batch_bn256_g1_dev(handle, 0, ptrs.as_ptr(), n, indices.len(), ptr::null_mut(), out.as_mut_ptr()) };
+    if rc != sys::HM_OK {
+        return None;
+    }
+    Some(
+        out.chunks_exact(12)
+            .map(|w| {
+                let mut xyz = [0u64; 12];
+                xyz.copy_from_slice(w);
+                g1_from_words(xyz)
+            })
+            .collect(),
+    )
+}
+
 /// halo2_proofs::arithmetic::eval_polynomial for `points.len()` polynomials of `n` coefficients lying back to back in `polys`
 /// (polynomial q at point q): the Horner evaluations create_proof makes of every committed polynomial.
 pub fn eval_polynomial_dev(polys: &DevicePoly, n: usize, points: &[Fr]) -> Option<Vec<Fr>> {
@@ -907,6 +970,58 @@ impl QuotientProgram {
         let w = words(&domain.omega);
         let rc = unsafe {
             sys::hm_quotient_by_cosets_bn256_fr_dev(self.handle, ptrs.as_ptr(), ptr::null(), ptrs.len(), dynamic.as_ptr() as *const u64, dynamic.len(), domain.k,
+                                                    w.as_ptr(), shifts.as_ptr(), cosets.len(), cosets.len(), h.as_mut_ptr(), ptr::null_mut())
+        };
+        if rc == sys::HM_OK { Some(h) } else { None }
+    }
+    /// Once per proving key: the values of the table entries `which` (the key's constant columns -- fixed, sigmas, l_0 / l_last /
+    /// l_active, X -- whose coefficients lie in `table`) on `cosets`, in the form the program loads without a conversion product.
+    /// -> which.len() x cosets.len() x n elements (entry w on coset c at [(w * cosets.len() + c) n, ...)), for
+    /// `quotient_by_cosets_packed_kept`: those columns are then not transformed again in every proof (35 of 83 for MerkleSumTree).
+    pub fn keep_on_cosets(&self, domain: &DeviceDomain, table: &DevicePoly, which: &[usize], cosets: &[usize]) -> Option<DevicePoly> {
+        let n = domain.n();
+        if table.len() != self.n_columns * n || cosets.is_empty() || cosets.len() > 16 || which.iter().any(|&i| i >= self.n_columns) {
+            return None;
+        }
+        let mut shifts: Vec<u64> = Vec::with_capacity(4 * cosets.len());
+        for &j in cosets {
+            shifts.extend_from_slice(&words(&domain.coset_shift(j)));
+        }
+        let mut kept = DevicePoly::new(which.len() * cosets.len() * n)?;
+        let w = words(&domain.omega);
+        for (slot, &i) in which.iter().enumerate() {
+            let src = unsafe { (table.as_ptr() as *const u8).add(i * n * 32) } as *const c_void;
+            let dst = unsafe { (kept.as_mut_ptr() as *mut u8).add(slot * cosets.len() * n * 32) } as *mut c_void;
+            if unsafe { sys::hm_coeff_to_cosets_bn256_fr_dev(src, dst, 1, w.as_ptr(), domain.k, shifts.as_ptr(), cosets.len(), 1, ptr::null_mut()) } != sys::HM_OK {
+                return None;
+            }
+        }
+        Some(kept)
+    }
+    /// `quotient_by_cosets_packed` with the columns `which` read from `kept` (what `keep_on_cosets` returned for the same `which` and
+    /// `cosets`) instead of being transformed from their coefficients.
+    pub fn quotient_by_cosets_packed_kept(&self, domain: &DeviceDomain, table: &DevicePoly, kept: &DevicePoly, which: &[usize], dynamic: &[Fr],
+                                          cosets: &[usize]) -> Option<DevicePoly> {
+        let n = domain.n();
+        if table.len() != self.n_columns * n || dynamic.len() != self.n_dynamic || cosets.is_empty() || kept.len() != which.len() * cosets.len() * n
+            || which.iter().any(|&i| i >= self.n_columns)
+        {
+            return None;
+        }
+        let base = table.as_ptr() as *const u8;
+        let ptrs: Vec<*const c_void> = (0..self.n_columns).map(|i| unsafe { base.add(i * n * 32) } as *const c_void).collect();
+        let mut pre: Vec<*const c_void> = vec![ptr::null(); self.n_columns];
+        for (slot, &i) in which.iter().enumerate() {
+            pre[i] = unsafe { (kept.as_ptr() as *const u8).add(slot * cosets.len() * n * 32) } as *const c_void;
+        }
+        let mut shifts: Vec<u64> = Vec::with_capacity(4 * cosets.len());
+        for &j in cosets {
+            shifts.extend_from_slice(&words(&domain.coset_shift(j)));
+        }
+        let mut h = DevicePoly::new(cosets.len() * n)?;
+        let w = words(&domain.omega);
+        let rc = unsafe {
+            sys::hm_quotient_by_cosets_bn256_fr_dev(self.handle, ptrs.as_ptr(), pre.as_ptr(), ptrs.len(), dynamic.as_ptr() as *const u64, dynamic.len(), domain.k,
                                                     w.as_ptr(), shifts.as_ptr(), cosets.len(), cosets.len(), h.as_mut_ptr(), ptr::null_mut())
         };
         if rc == sys::HM_OK { Some(h) } else { None }
