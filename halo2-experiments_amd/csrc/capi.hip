@@ -924,11 +924,17 @@ static int msm_batch_impl(DeviceCtx* ctx, uint64_t handle, size_t offset, const 
       }
       // through the library's pinned lanes (xfer.hip), synchronous for this thread: the other lanes' chains compute meanwhile, and
       // this lane's chain is submitted behind it (a pageable hipMemcpyAsync blocked the submitting thread just the same)
-      int xrc = HM_OK;
-      for (uint32_t e = 0; e < group && xrc == HM_OK; ++e) {
-        xrc = xfer_h2d(*ctx, buf + (size_t)e * n * 32, staged[e], n * 32, "hm_msm_batch_bn256_g1_h: scalar upload");
-        staged[e] = buf + (size_t)e * n * 32;
+      // the chain's arrays as ONE job of the lanes (an 8 MiB copy alone spends half its time starting threads and filling its pipeline)
+      void* up_dev[HM_MSM_GROUP];
+      void* up_host[HM_MSM_GROUP];
+      size_t up_bytes[HM_MSM_GROUP];
+      for (uint32_t e = 0; e < group; ++e) {
+        up_dev[e] = buf + (size_t)e * n * 32;
+        up_host[e] = const_cast<void*>(staged[e]);
+        up_bytes[e] = n * 32;
       }
+      const int xrc = xfer_many(*ctx, true, up_dev, up_host, up_bytes, group, "hm_msm_batch_bn256_g1_h: scalar upload");
+      for (uint32_t e = 0; e < group; ++e) staged[e] = up_dev[e];
       if (xrc != HM_OK) {
         submit_rc.store(xrc);
         submit_error = hm_last_error();
