@@ -129,3 +129,26 @@ def test_no_masked_random_words_are_left():
              + glob.glob(os.path.join(ROOT, "halo2-experiments_amd", "*.py")) + [os.path.join(ROOT, "bench.py"), os.path.join(ROOT, "__graft_entry__.py")])
     hits = [os.path.relpath(f, ROOT) for f in files if mask.lower() in open(f).read().lower()]
     assert hits == []
+
+
+def test_a_box_without_a_working_one_rank_communicator_keeps_its_headline():
+    """bench.py --gpus 1 builds a one-rank RCCL communicator so that its step takes the N > 1 route; where that cannot be built (here: no
+    GPU at all) the error is recorded and the run goes on without the exchange -- it must never cost the line.  N > 1 re-raises."""
+    import torch
+    import torch.distributed as dist
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip("needs a box where the nccl backend cannot start")
+    saved = dict(bench.COLLECTIVE)
+    try:
+        bench.init_collective("nccl", 0, 1, torch.device("cuda", 0), torch.device("cuda", 0), at_one_rank=True)
+        assert bench.COLLECTIVE["on"] is False and bench.COLLECTIVE["error"] and bench.COLLECTIVE["init_s"] is not None
+        assert not dist.is_initialized()
+        assert bench.max_over_ranks(1.5, 1, torch.device("cpu")) == 1.5            # no collective behind the helpers either
+        bench.init_collective("nccl", 0, 1, torch.device("cuda", 0), torch.device("cuda", 0), at_one_rank=False)     # --no-collective: nothing tried
+        assert not dist.is_initialized()
+    finally:
+        bench.COLLECTIVE.clear()
+        bench.COLLECTIVE.update(saved)
+        if dist.is_initialized():
+            dist.destroy_process_group()
