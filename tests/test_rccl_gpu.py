@@ -46,12 +46,14 @@ def _child(out_path):
 
     # spy on the collective: the forced route must really call dist.all_gather with device tensors
     calls = {"all_gather": 0, "on_device": 0, "bytes": 0}
+    max_gather = [0]
     real_all_gather = dist.all_gather
 
     def spy(tensor_list, tensor, group=None, async_op=False):
         calls["all_gather"] += 1
         calls["on_device"] += int(tensor.is_cuda and all(t.is_cuda for t in tensor_list))
         calls["bytes"] += tensor.numel() * tensor.element_size()
+        max_gather[0] = max(max_gather[0], tensor.numel() * tensor.element_size())
         return real_all_gather(tensor_list, tensor, group=group, async_op=async_op)
 
     dist.all_gather = spy
@@ -101,6 +103,13 @@ def _child(out_path):
         rep = run_replay("poseidon_k11", device=dev, include_host_pointer_estimate=False)
         report["replay_all_gathers"] = calls["all_gather"] - before
         report["replay_commitments_checked"] = rep["verified"]["commitments_checked"]
+        # ... and the extended-domain steps BY COSETS (what N > 1 ranks do from k = 14): the partials of all 8 cosets, n x 32 B each, cross
+        # the communicator as device tensors in one all-gather per proof
+        before, bytes_before = calls["all_gather"], calls["bytes"]
+        rep = run_replay("merkle_v3_k17", device=dev, include_host_pointer_estimate=False, by_cosets=True, min_cosets=False)
+        report["coset_replay_all_gathers"] = calls["all_gather"] - before
+        report["coset_replay_largest_gather_bytes"] = int(max_gather[0])
+        report["coset_replay_extended_domain"] = rep["extended_domain"]
         os.environ.pop("HALO2_MI355X_FORCE_COLLECTIVE")
     finally:
         dist.all_gather = real_all_gather
@@ -130,6 +139,8 @@ def test_every_exchange_function_runs_over_a_one_rank_rccl_communicator(tmp_path
         assert rep[key] is True, (key, rep)
     assert rep["all_gather_calls"] == rep["all_gather_on_device"] >= 6         # every exchange was an RCCL all-gather of DEVICE tensors
     assert rep["replay_all_gathers"] >= 3 and rep["replay_commitments_checked"] > 0
+    assert rep["coset_replay_extended_domain"].startswith("by cosets, 8 of 8")
+    assert rep["coset_replay_largest_gather_bytes"] == 8 * (1 << 17) * 32            # every coset's partial of the k = 17 proof in ONE all-gather
     assert any("rccl" in name for name in rep["mapped"]), rep["mapped"]
     assert any(name.startswith("libhalo2_mi355x") for name in rep["mapped"]), rep["mapped"]
 
